@@ -1,0 +1,376 @@
+"""CPU oracle for the chunked-spectrogram demix path (MDX / ConvTDFNet).
+
+TEST INFRASTRUCTURE ONLY.  This module is a plain numpy / torch-CPU fp32
+restatement of the reference algorithm.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it, and only as the checker -- the product path (the HIP engine behind
+``include/asx.h``) never calls into this file and fails loudly when the HIP
+library is missing.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the reference
+package itself (``/root/reference``; runnable only in the build container) and
+writes ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every
+function below against those vectors.  The one piece of the reference path that
+is *not* available (onnxruntime 1.23.0 executing ``UVR-MDX-NET-Inst_HQ_3.onnx``,
+call site mdx_separator.py:122-123) is restated from the reference's own torch
+definition of that graph, ``uvr_lib_v5/mdxnet.py:30-120`` +
+``uvr_lib_v5/modules.py:5-74``, and pinned against that class.
+
+All ``file:line`` citations are relative to
+``/root/reference/audio_separator/separator/``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import scipy.fft
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# STFT / iSTFT   (uvr_lib_v5/stft.py)
+# --------------------------------------------------------------------------
+
+def hann_periodic(n: int) -> np.ndarray:
+    """torch.hann_window(n, periodic=True) (stft.py:18) as float32."""
+    k = np.arange(n, dtype=np.float64)
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)).astype(np.float32)
+
+
+def stft_forward(x: np.ndarray, n_fft: int, hop: int, dim_f: int) -> np.ndarray:
+    """STFT.__call__ (stft.py:20-56).
+
+    x: float32 [B, 2, C].  Returns float32 [B, 4, dim_f, T] with channel order
+    (L_re, L_im, R_re, R_im), T = C // hop + 1.  torch.stft(center=True)
+    reflect-pads n_fft/2 on both sides of every row (stft.py:41).
+    """
+    x = np.asarray(x, dtype=np.float32)
+    B, ch, C = x.shape
+    half = n_fft // 2
+    xp = np.pad(x.reshape(B * ch, C), ((0, 0), (half, half)), mode="reflect")
+    T = C // hop + 1
+    idx = (np.arange(T) * hop)[:, None] + np.arange(n_fft)[None, :]
+    frames = xp[:, idx] * hann_periodic(n_fft)[None, None, :]          # [B*ch, T, n]
+    Z = scipy.fft.rfft(frames.astype(np.float32), axis=-1)             # complex64
+    Z = Z[:, :, :dim_f]                                                 # crop (stft.py:56)
+    out = np.empty((B * ch, 2, dim_f, T), dtype=np.float32)
+    out[:, 0] = Z.real.transpose(0, 2, 1)
+    out[:, 1] = Z.imag.transpose(0, 2, 1)
+    return out.reshape(B, ch * 2, dim_f, T)
+
+
+def istft_envelope(n_fft: int, hop: int, T: int) -> np.ndarray:
+    """Sum of squared windows as torch.istft builds it (overlap-add of w^2)."""
+    w = hann_periodic(n_fft).astype(np.float32)
+    env = np.zeros(n_fft + hop * (T - 1), dtype=np.float32)
+    w2 = (w * w).astype(np.float32)
+    for t in range(T):
+        env[t * hop: t * hop + n_fft] += w2
+    return env
+
+
+def stft_inverse(X: np.ndarray, n_fft: int, hop: int) -> np.ndarray:
+    """STFT.inverse (stft.py:99-126).
+
+    X: float32 [B, 4, F, T] -> float32 [B, 2, hop*(T-1)] (a [B, 2, F, T] input
+    yields the reference's quirky [B, 2, hop*(T-1)/2] fold, tests/unit/test_stft.py:134).
+    Bins F..n_fft/2 are zero-padded (stft.py:58-68), planes become complex
+    (stft.py:80-97), torch.istft(center=True): irfft (1/n), x window,
+    overlap-add, / sum w^2, strip n_fft/2 on both sides.
+    """
+    X = np.asarray(X, dtype=np.float32)
+    B, c4, Fq, T = X.shape
+    ch = c4 // 2
+    nb = n_fft // 2 + 1
+    Xr = X.reshape(B * ch, 2, Fq, T)
+    Z = np.zeros((B * ch, T, nb), dtype=np.complex64)
+    Z[:, :, :Fq] = (Xr[:, 0] + 1j * Xr[:, 1]).transpose(0, 2, 1)
+    y = scipy.fft.irfft(Z, n=n_fft, axis=-1).astype(np.float32)       # [B*ch, T, n]
+    y *= hann_periodic(n_fft)[None, None, :]
+    total = n_fft + hop * (T - 1)
+    acc = np.zeros((B * ch, total), dtype=np.float32)
+    for t in range(T):
+        acc[:, t * hop: t * hop + n_fft] += y[:, t]
+    env = istft_envelope(n_fft, hop, T)
+    half = n_fft // 2
+    out = acc[:, half: half + hop * (T - 1)] / env[None, half: half + hop * (T - 1)]
+    # stft.py:120 reshapes to [*batch, 2, -1] whatever the channel count was
+    return out.reshape(B, 2, -1).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# chunk loop   (architectures/mdx_separator.py)
+# --------------------------------------------------------------------------
+
+@dataclass
+class MDXParams:
+    """Scalars of MDXSeparator (mdx_separator.py:22-106, 205-228)."""
+    n_fft: int = 6144
+    hop_length: int = 1024
+    dim_f: int = 3072
+    segment_size: int = 256
+    overlap: float = 0.25
+    enable_denoise: bool = False
+    compensate: float = 1.0
+
+    @property
+    def trim(self) -> int:
+        return self.n_fft // 2
+
+    @property
+    def chunk_size(self) -> int:
+        return self.hop_length * (self.segment_size - 1)
+
+
+def chunk_plan(N: int, p: MDXParams, is_match_mix: bool = False):
+    """Index arithmetic of demix (mdx_separator.py:308-348).
+
+    Returns (chunk_size, gen_size, pad, L, step, starts).
+    """
+    chunk_size = p.chunk_size
+    overlap = 0.02 if is_match_mix else p.overlap
+    gen_size = chunk_size - 2 * p.trim
+    pad = gen_size + p.trim - (N % gen_size)
+    L = p.trim + N + pad
+    step = int((1 - overlap) * chunk_size)
+    starts = list(range(0, L, step))
+    return chunk_size, gen_size, pad, L, step, starts, overlap
+
+
+def run_model(mix_wave: np.ndarray, p: MDXParams, model_run, is_match_mix=False) -> np.ndarray:
+    """MDXSeparator.run_model (mdx_separator.py:414-450): [B,2,C] -> [B,2,C]."""
+    spek = stft_forward(mix_wave, p.n_fft, p.hop_length, p.dim_f)
+    spek[:, :, :3, :] *= 0                                    # :425
+    if is_match_mix:
+        spec_pred = spek                                      # :429-432
+    elif p.enable_denoise:
+        spec_pred = (model_run(-spek) * -0.5) + (model_run(spek) * 0.5)   # :435-440
+    else:
+        spec_pred = model_run(spek)                           # :443
+    return stft_inverse(np.asarray(spec_pred, dtype=np.float32), p.n_fft, p.hop_length)
+
+
+def demix(mix: np.ndarray, p: MDXParams, model_run, is_match_mix: bool = False) -> np.ndarray:
+    """MDXSeparator.demix (mdx_separator.py:293-412): [2,N] f32 -> [2,N] f32."""
+    mix = np.asarray(mix, dtype=np.float32)
+    N = mix.shape[-1]
+    chunk_size, gen_size, pad, L, step, starts, overlap = chunk_plan(N, p, is_match_mix)
+    mixture = np.concatenate((np.zeros((2, p.trim), np.float32), mix, np.zeros((2, pad), np.float32)), 1)
+    result = np.zeros((1, 2, L), dtype=np.float32)
+    divider = np.zeros((1, 2, L), dtype=np.float32)
+    for start in starts:
+        end = min(start + chunk_size, L)
+        n_act = end - start
+        window = None
+        if overlap != 0:
+            window = np.hanning(n_act)                         # float64, symmetric (:358)
+            window = np.tile(window[None, None, :], (1, 2, 1))
+        part = mixture[:, start:end]
+        if end != start + chunk_size:
+            part = np.concatenate((part, np.zeros((2, start + chunk_size - end), np.float32)), axis=-1)
+        tar = run_model(part[None].astype(np.float32), p, model_run, is_match_mix)
+        if window is not None:
+            tar[..., :n_act] *= window                         # f32 *= f64 (:387)
+            divider[..., start:end] += window                  # :388
+        else:
+            divider[..., start:end] += 1
+        result[..., start:end] += tar[..., :n_act]             # :392
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tar_waves = result / divider                           # :396 (0/0 at the rim, trimmed below)
+    tar_waves = tar_waves[:, :, p.trim:-p.trim]                # :400
+    tar_waves = np.concatenate(tar_waves, axis=-1)[:, :N]      # :401
+    return tar_waves
+
+
+def normalize(wave: np.ndarray, max_peak: float = 1.0, min_peak=None) -> np.ndarray:
+    """spec_utils.normalize (uvr_lib_v5/spec_utils.py:99-115), in place."""
+    maxv = np.abs(wave).max()
+    if maxv > max_peak:
+        wave *= max_peak / maxv
+    elif min_peak is not None and maxv < min_peak:
+        wave *= min_peak / maxv
+    return wave
+
+
+def separate_stems(mix: np.ndarray, p: MDXParams, model_run,
+                   normalization_threshold: float = 0.9, amplification_threshold: float = 0.0):
+    """Stem algebra of MDXSeparator.separate (mdx_separator.py:155-182).
+
+    Returns (primary [N,2], secondary [N,2]); ``mix`` is normalised in place
+    exactly like the reference does.
+    """
+    peak = np.abs(mix).max()
+    mix = normalize(mix, normalization_threshold, amplification_threshold)
+    source = demix(mix, p, model_run) * peak
+    primary = source.T
+    secondary = (-primary * p.compensate) + mix.T
+    return primary, secondary
+
+
+# --------------------------------------------------------------------------
+# ConvTDFNet   (uvr_lib_v5/mdxnet.py:30-120, uvr_lib_v5/modules.py:5-74)
+# --------------------------------------------------------------------------
+
+@dataclass
+class NetDims:
+    dim_c: int = 4
+    dim_f: int = 3072
+    dim_t: int = 256
+    g: int = 48
+    l: int = 3
+    num_blocks: int = 11
+    k: int = 3
+    bn: int = 8
+    bias: bool = False        # TDF Linear bias (kuielab configs train with bias=False)
+
+    @property
+    def n(self) -> int:
+        return self.num_blocks // 2
+
+
+def _bn_init(gen: torch.Generator, c: int, prefix: str, sd: dict):
+    sd[prefix + ".weight"] = 0.8 + 0.4 * torch.rand(c, generator=gen)
+    sd[prefix + ".bias"] = 0.1 * torch.randn(c, generator=gen)
+    sd[prefix + ".running_mean"] = 0.1 * torch.randn(c, generator=gen)
+    sd[prefix + ".running_var"] = 0.5 + torch.rand(c, generator=gen)
+
+
+def _tfc_tdf_init(gen, c, f, d: NetDims, prefix, sd):
+    for j in range(d.l):
+        fan = c * d.k * d.k
+        sd[f"{prefix}.tfc.H.{j}.0.weight"] = torch.randn(c, c, d.k, d.k, generator=gen) * math.sqrt(2.0 / fan)
+        sd[f"{prefix}.tfc.H.{j}.0.bias"] = 0.05 * torch.randn(c, generator=gen)
+        _bn_init(gen, c, f"{prefix}.tfc.H.{j}.1", sd)
+    sd[f"{prefix}.tdf.0.weight"] = torch.randn(f // d.bn, f, generator=gen) * math.sqrt(1.0 / f)
+    if d.bias:
+        sd[f"{prefix}.tdf.0.bias"] = 0.05 * torch.randn(f // d.bn, generator=gen)
+    _bn_init(gen, c, f"{prefix}.tdf.1", sd)
+    sd[f"{prefix}.tdf.3.weight"] = torch.randn(f, f // d.bn, generator=gen) * math.sqrt(1.0 / (f // d.bn))
+    if d.bias:
+        sd[f"{prefix}.tdf.3.bias"] = 0.05 * torch.randn(f, generator=gen)
+    _bn_init(gen, c, f"{prefix}.tdf.4", sd)
+
+
+def make_convtdf_state(d: NetDims, seed: int = 0) -> dict:
+    """Seeded synthetic weights with the reference ConvTDFNet's state_dict
+    names and shapes (mdxnet.py:54-95), BatchNorm running stats randomised so
+    that folding is exercised.  Scales keep activations O(1) through the
+    skip-multiplies of the decoder."""
+    gen = torch.Generator().manual_seed(seed)
+    sd: dict = {}
+    g = d.g
+    sd["first_conv.0.weight"] = torch.randn(g, d.dim_c, 1, 1, generator=gen) * math.sqrt(2.0 / d.dim_c)
+    sd["first_conv.0.bias"] = 0.05 * torch.randn(g, generator=gen)
+    _bn_init(gen, g, "first_conv.1", sd)
+    f, c = d.dim_f, g
+    for i in range(d.n):
+        _tfc_tdf_init(gen, c, f, d, f"encoding_blocks.{i}", sd)
+        sd[f"ds.{i}.0.weight"] = torch.randn(c + g, c, 2, 2, generator=gen) * math.sqrt(2.0 / (4 * c))
+        sd[f"ds.{i}.0.bias"] = 0.05 * torch.randn(c + g, generator=gen)
+        _bn_init(gen, c + g, f"ds.{i}.1", sd)
+        f //= 2
+        c += g
+    _tfc_tdf_init(gen, c, f, d, "bottleneck_block", sd)
+    for i in range(d.n):
+        sd[f"us.{i}.0.weight"] = torch.randn(c, c - g, 2, 2, generator=gen) * math.sqrt(1.0 / c)
+        sd[f"us.{i}.0.bias"] = 0.05 * torch.randn(c - g, generator=gen)
+        _bn_init(gen, c - g, f"us.{i}.1", sd)
+        f *= 2
+        c -= g
+        _tfc_tdf_init(gen, c, f, d, f"decoding_blocks.{i}", sd)
+    sd["final_conv.0.weight"] = torch.randn(d.dim_c, c, 1, 1, generator=gen) * math.sqrt(1.0 / c)
+    sd["final_conv.0.bias"] = 0.05 * torch.randn(d.dim_c, generator=gen)
+    return {k: v.float().contiguous() for k, v in sd.items()}
+
+
+def _bn(x, sd, prefix):
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                        sd[prefix + ".weight"], sd[prefix + ".bias"], training=False, eps=1e-5)
+
+
+def _tfc_tdf(x, sd, prefix, d: NetDims):
+    """modules.py:45-74 with TFC (modules.py:5-22), BatchNorm2d, eval mode."""
+    for j in range(d.l):
+        x = F.conv2d(x, sd[f"{prefix}.tfc.H.{j}.0.weight"], sd[f"{prefix}.tfc.H.{j}.0.bias"], padding=d.k // 2)
+        x = F.relu(_bn(x, sd, f"{prefix}.tfc.H.{j}.1"))
+    t = F.linear(x, sd[f"{prefix}.tdf.0.weight"], sd.get(f"{prefix}.tdf.0.bias"))
+    t = F.relu(_bn(t, sd, f"{prefix}.tdf.1"))
+    t = F.linear(t, sd[f"{prefix}.tdf.3.weight"], sd.get(f"{prefix}.tdf.3.bias"))
+    t = F.relu(_bn(t, sd, f"{prefix}.tdf.4"))
+    return x + t
+
+
+@torch.no_grad()
+def convtdf_forward(x, sd: dict, d: NetDims):
+    """ConvTDFNet.forward (mdxnet.py:97-120), optimizer='rmsprop' (BatchNorm2d) variant,
+    eval mode.  x: [B, dim_c, dim_f, dim_t] float32 (numpy or torch) -> same shape (numpy)."""
+    was_np = isinstance(x, np.ndarray)
+    x = torch.as_tensor(np.ascontiguousarray(x) if was_np else x, dtype=torch.float32)
+    x = F.conv2d(x, sd["first_conv.0.weight"], sd["first_conv.0.bias"])
+    x = F.relu(_bn(x, sd, "first_conv.1"))
+    x = x.transpose(-1, -2)
+    skips = []
+    for i in range(d.n):
+        x = _tfc_tdf(x, sd, f"encoding_blocks.{i}", d)
+        skips.append(x)
+        x = F.conv2d(x, sd[f"ds.{i}.0.weight"], sd[f"ds.{i}.0.bias"], stride=2)
+        x = F.relu(_bn(x, sd, f"ds.{i}.1"))
+    x = _tfc_tdf(x, sd, "bottleneck_block", d)
+    for i in range(d.n):
+        x = F.conv_transpose2d(x, sd[f"us.{i}.0.weight"], sd[f"us.{i}.0.bias"], stride=2)
+        x = F.relu(_bn(x, sd, f"us.{i}.1"))
+        x = x * skips[-i - 1]
+        x = _tfc_tdf(x, sd, f"decoding_blocks.{i}", d)
+    x = x.transpose(-1, -2)
+    x = F.conv2d(x, sd["final_conv.0.weight"], sd["final_conv.0.bias"])
+    return x.numpy() if was_np else x
+
+
+def make_model_run(sd: dict, d: NetDims):
+    """A ``model_run(spek) -> spec_pred`` callable like mdx_separator.py:123."""
+    def _run(spek):
+        return convtdf_forward(np.asarray(spek, dtype=np.float32), sd, d)
+    return _run
+
+
+def net_flops(d: NetDims, batch: int = 1) -> int:
+    """Algorithmic FLOPs (2*MAC) of one ConvTDFNet forward, conv + linear only
+    (the same quantity torch.utils.flop_counter counts on the reference class)."""
+    fl = 0
+    T, Fq, g = d.dim_t, d.dim_f, d.g
+    fl += 2 * d.dim_c * g * T * Fq
+
+    def block(c, t, f):
+        return d.l * 2 * d.k * d.k * c * c * t * f + 2 * 2 * c * t * f * (f // d.bn)
+    c, t, f = g, T, Fq
+    for _ in range(d.n):
+        fl += block(c, t, f)
+        fl += 2 * 4 * c * (c + g) * (t // 2) * (f // 2)
+        c, t, f = c + g, t // 2, f // 2
+    fl += block(c, t, f)
+    for _ in range(d.n):
+        fl += 2 * 4 * c * (c - g) * t * f
+        c, t, f = c - g, t * 2, f * 2
+        fl += block(c, t, f)
+    fl += 2 * g * d.dim_c * T * Fq
+    return fl * batch
+
+
+def synth_mix(n_samples: int, seed: int = 0, sr: int = 44100) -> np.ndarray:
+    """Seeded synthetic stereo input: 8 random sinusoids +
+    0.1*N(0,1), peak 0.9.  float32 [2, n_samples]."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n_samples, dtype=np.float64) / sr
+    out = np.zeros((2, n_samples), dtype=np.float64)
+    for ch in range(2):
+        for _ in range(8):
+            f0 = rng.uniform(50.0, 8000.0)
+            a = rng.uniform(0.1, 1.0)
+            ph = rng.uniform(0, 2 * np.pi)
+            out[ch] += a * np.sin(2 * np.pi * f0 * t + ph)
+        out[ch] += 0.1 * rng.standard_normal(n_samples)
+    out *= 0.9 / np.abs(out).max()
+    return out.astype(np.float32)
