@@ -1,0 +1,11 @@
+"""Import shim: the product package lives in ``python-audio-separator_amd/`` (a
+directory name Python cannot import directly); this module makes it importable as
+``audio_separator_amd`` by extending ``__path__``."""
+import os as _os
+
+_pkg = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "python-audio-separator_amd")
+__path__.append(_pkg)
+
+from .engine import Engine, AsxError, MDXConfig, NetConfig, lib_path  # noqa: E402,F401
+from .weights import fold_convtdf_state  # noqa: E402,F401
+from .mdx import STFT, MDXDemixer  # noqa: E402,F401

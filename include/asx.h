@@ -1,0 +1,193 @@
+/*
+ * asx.h -- C ABI of the MI355X-native demix engine (libasx.so).
+ *
+ * Drop-in boundary for ONE hot path of nomadkaraoke/python-audio-separator: the
+ * chunked-spectrogram demix loop of the MDX architecture plugin
+ * (audio_separator/separator/architectures/mdx_separator.py, MDXSeparator.demix
+ * :293-412 and run_model :414-450, with uvr_lib_v5/stft.py:20-126 and the
+ * ConvTDFNet graph of uvr_lib_v5/mdxnet.py:30-120 that the reference executes
+ * through onnxruntime at mdx_separator.py:122-123).
+ *
+ * Plain C: pointers and sizes only, no torch/STL types.  Every function returns
+ * ASX_OK (0) or a positive error code and never throws; the message of the last
+ * failing call on the calling thread is available from asx_last_error().
+ *
+ * Ownership: the caller owns every buffer it passes in; the engine owns its
+ * device workspace and copies weights at asx_net_commit().  One engine is bound
+ * to one GPU; calls on one engine must be serialised by the caller (the
+ * reference object is not re-entrant either).  "host" pointers are
+ * pageable or pinned host memory, "dev" pointers are HIP device pointers on the
+ * engine's GPU.  `stream` is a hipStream_t passed as void* (NULL = the null
+ * stream); *_dev entry points are asynchronous with respect to the host.
+ *
+ * All audio is float32.  Layouts are C-order.
+ */
+#ifndef ASX_H
+#define ASX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASX_OK 0
+#define ASX_ERR_INVALID 1 /* bad argument / inconsistent configuration       */
+#define ASX_ERR_HIP 2     /* a HIP runtime call failed (no GPU, OOM, launch) */
+#define ASX_ERR_STATE 3   /* call order violated (e.g. demix before commit)  */
+
+#define ASX_ABI_VERSION 1
+
+/* flags of asx_demix*(): */
+#define ASX_FLAG_MATCH_MIX 1u /* demix(mix, is_match_mix=True): overlap 0.02, no net (mdx_separator.py:308-313, :429-432) */
+
+typedef struct asx_engine asx_engine;
+
+/* Scalars of MDXSeparator that shape the path.
+ *   n_fft        model_data["mdx_n_fft_scale_set"]   mdx_separator.py:72
+ *   hop_length   arch_config["hop_length"]           mdx_separator.py:59
+ *   dim_f        model_data["mdx_dim_f_set"]         mdx_separator.py:70
+ *   segment_size arch_config["segment_size"]         mdx_separator.py:31   (frames per chunk)
+ *   overlap      arch_config["overlap"]              mdx_separator.py:36
+ *   enable_denoise arch_config["enable_denoise"]     mdx_separator.py:62
+ *   max_batch    chunks processed per device batch.  Engine knob: the reference's
+ *                batch_size never batches chunks and results do
+ *                not depend on it.  0 = engine default.
+ */
+typedef struct asx_mdx_config {
+  int32_t n_fft;
+  int32_t hop_length;
+  int32_t dim_f;
+  int32_t segment_size;
+  float overlap;
+  int32_t enable_denoise;
+  int32_t max_batch;
+} asx_mdx_config;
+
+/* ConvTDFNet hyper-parameters (uvr_lib_v5/mdxnet.py:31-52); dim_t must equal
+ * segment_size, dim_f must equal asx_mdx_config.dim_f.  tdf_bias != 0 when the
+ * TDF Linear layers carry a bias (modules.py:57-66). */
+typedef struct asx_net_config {
+  int32_t dim_c;
+  int32_t dim_f;
+  int32_t dim_t;
+  int32_t g;
+  int32_t l;
+  int32_t num_blocks;
+  int32_t k;
+  int32_t bn;
+  int32_t tdf_bias;
+} asx_net_config;
+
+/* Index arithmetic of one demix() call (mdx_separator.py:308-348). */
+typedef struct asx_plan {
+  int64_t n_samples;  /* N                                    */
+  int64_t padded_len; /* L = trim + N + pad                   */
+  int64_t chunk_size; /* hop * (segment_size - 1)             */
+  int64_t gen_size;   /* chunk_size - 2 * trim                */
+  int64_t pad;
+  int64_t step;       /* int((1 - overlap) * chunk_size)      */
+  int32_t trim;       /* n_fft / 2                            */
+  int32_t n_chunks;   /* len(range(0, L, step))               */
+  int32_t n_frames;   /* frames per chunk = segment_size      */
+  int32_t reserved;
+} asx_plan;
+
+/* Per-kernel-class device time, collected with hipEvents on the launch stream
+ * while profiling is enabled. */
+#define ASX_PROF_STFT 0
+#define ASX_PROF_CONV3X3 1
+#define ASX_PROF_TDF 2
+#define ASX_PROF_DOWN 3
+#define ASX_PROF_UP 4
+#define ASX_PROF_CONV1X1 5
+#define ASX_PROF_ISTFT 6
+#define ASX_PROF_OLA 7
+#define ASX_PROF_FINALIZE 8
+#define ASX_PROF_MISC 9
+#define ASX_PROF_NCLASS 10
+typedef struct asx_profile {
+  int64_t launches[ASX_PROF_NCLASS];
+  double ms[ASX_PROF_NCLASS];    /* summed kernel time                       */
+  double flops[ASX_PROF_NCLASS]; /* algorithmic 2*MAC of those launches      */
+  double bytes[ASX_PROF_NCLASS]; /* algorithmic HBM bytes of those launches  */
+} asx_profile;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int asx_abi_version(void);
+const char *asx_last_error(void);
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int asx_device_count(void);
+int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out);
+void asx_engine_destroy(asx_engine *e);
+
+/* ---- model weights: replaces ort.InferenceSession(model_path)  mdx_separator.py:122 ----
+ * The host hands over BatchNorm-folded fp32 tensors by canonical name, the
+ * engine packs them into its kernel layouts and uploads them at commit.
+ * Names (blk = enc<i> | mid | dec<i>, i counted like mdxnet.py:63-93):
+ *   first.w [g,dim_c]  first.b [g]                       first_conv   mdxnet.py:54-58
+ *   <blk>.tfc<j>.w [c,c,k,k]  <blk>.tfc<j>.b [c]         TFC convs    modules.py:11-17
+ *   <blk>.tdf0.w [f/bn,f]  .bias [f/bn]  .scale [c]  .shift [c]   TDF  modules.py:62-70
+ *   <blk>.tdf1.w [f,f/bn]  .bias [f]     .scale [c]  .shift [c]
+ *   ds<i>.w [c+g,c,2,2]  ds<i>.b [c+g]                   mdxnet.py:66-72
+ *   us<i>.w [c,c-g,2,2]  us<i>.b [c-g]                   mdxnet.py:80-86 (ConvTranspose2d layout)
+ *   final.w [dim_c,g]  final.b [dim_c]                   mdxnet.py:93-95
+ * TDF epilogue: relu(scale[c] * (x @ w.T + bias) + shift[c]).
+ */
+int asx_net_begin(asx_engine *e, const asx_net_config *cfg);
+int asx_net_set_tensor(asx_engine *e, const char *name, const float *host, int64_t numel);
+int asx_net_commit(asx_engine *e);
+/* Algorithmic FLOPs (2*MAC, conv + linear) of one forward over `batch` chunks. */
+double asx_net_flops(const asx_engine *e, int32_t batch);
+
+/* ---- the path ---------------------------------------------------------- */
+/* Index plan of demix() for a mix of n_samples per channel. */
+int asx_plan_query(const asx_engine *e, int64_t n_samples, uint32_t flags, asx_plan *out);
+
+/* MDXSeparator.demix (mdx_separator.py:293): mix [2,N] -> out [2,N]. */
+int asx_demix(asx_engine *e, const float *mix_host, int64_t n_samples, float *out_host, uint32_t flags);
+int asx_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, float *out_dev, uint32_t flags,
+                  void *stream);
+
+/* Sharded form: chunks [chunk_begin, chunk_end) of the plan are
+ * run and their windowed outputs written to chunk_out_dev[(k - chunk_begin), 2, chunk_size];
+ * asx_finalize_dev() then folds ALL n_chunks windowed chunks (gathered by the
+ * caller) into out [2,N] = (result / divider)[trim:-trim][:N]  (mdx_separator.py:386-401). */
+int asx_demix_chunks_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t chunk_begin,
+                         int32_t chunk_end, float *chunk_out_dev, uint32_t flags, void *stream);
+int asx_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t n_samples, float *out_dev,
+                     uint32_t flags, void *stream);
+
+/* ---- stage hooks (host buffers; mirror the reference's own test surface) ---- */
+/* STFT.__call__ (stft.py:20): wave [B,2,C] -> spec [B,4,dim_f,C/hop+1]. */
+int asx_stft(asx_engine *e, const float *wave_host, int32_t batch, int64_t n_time, float *spec_host);
+/* STFT.inverse (stft.py:99): spec [B,4,dim_f,T] -> wave [B,2,hop*(T-1)]. */
+int asx_istft(asx_engine *e, const float *spec_host, int32_t batch, int32_t n_frames, float *wave_host);
+/* model_run(spek) (mdx_separator.py:123): spec [B,dim_c,dim_f,dim_t] -> same shape. */
+int asx_net_forward(asx_engine *e, const float *spec_host, int32_t batch, float *out_host);
+/* MDXSeparator.run_model (mdx_separator.py:414): wave [B,2,chunk_size] -> [B,2,chunk_size]. */
+int asx_run_model(asx_engine *e, const float *wave_host, int32_t batch, float *out_host, uint32_t flags);
+
+/* Single-layer hooks used by the parity tests (activations [B,C,T,F], F fastest):
+ *   op = "conv3x3"  w [cout,cin,3,3]  b [cout]                 -> relu(conv(x)+b)
+ *   op = "down"     w [cout,cin,2,2]  b [cout]   stride 2      -> relu(conv(x)+b)         [B,cout,T/2,F/2]
+ *   op = "up"       w [cin,cout,2,2]  b [cout]   stride 2, aux = skip [B,cout,2T,2F]  -> relu(convT(x)+b)*skip
+ *   op = "conv1x1"  w [cout,cin]      b [cout]   relu flag in `relu`
+ *   op = "tdf"      w [n,k] bias [n] with x viewed as rows of length k=F;
+ *                   aux0 = scale [C], aux1 = shift [C], aux2 = residual or NULL -> relu(scale*(xW^T+bias)+shift) (+res)
+ */
+int asx_op_conv(asx_engine *e, const char *op, const float *x_host, int32_t batch, int32_t cin, int32_t t,
+                int32_t f, const float *w_host, const float *b_host, int32_t cout, const float *aux_host,
+                int32_t relu, float *y_host);
+int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int32_t t, int32_t k,
+               const float *w_host, const float *bias_host, int32_t n, const float *scale_host,
+               const float *shift_host, const float *res_host, float *y_host);
+
+/* ---- profiling ---------------------------------------------------------- */
+int asx_profile_enable(asx_engine *e, int32_t on); /* clears the counters */
+int asx_profile_read(asx_engine *e, asx_profile *out); /* synchronises the device */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASX_H */

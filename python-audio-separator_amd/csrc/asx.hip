@@ -1,0 +1,1183 @@
+// libasx.so -- engine + C ABI (include/asx.h) of the MI355X demix path.
+//
+// One engine = one GPU.  The engine owns: FFT tables, the packed ConvTDFNet
+// weights, and a device workspace sized for `max_batch` chunks.  The chunk loop
+// of MDXSeparator.demix (mdx_separator.py:348-392) is executed as batches of
+// independent chunks: STFT -> net -> iSTFT -> fold+window per batch, then one
+// gather pass folds all windowed chunks into the song (result / divider).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/asx.h"
+#include "kernels_fft.h"
+#include "kernels_net.h"
+
+using namespace asx;
+
+// ----------------------------------------------------------------------------
+// errors
+// ----------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static void set_err(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+#define HIPCHK(x)                                                                       \
+  do {                                                                                  \
+    hipError_t e_ = (x);                                                                \
+    if (e_ != hipSuccess) {                                                             \
+      set_err("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));         \
+      return ASX_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+#define CHK(x)                    \
+  do {                            \
+    int r_ = (x);                 \
+    if (r_ != ASX_OK) return r_;  \
+  } while (0)
+#define REQUIRE(cond, ...)        \
+  do {                            \
+    if (!(cond)) {                \
+      set_err(__VA_ARGS__);       \
+      return ASX_ERR_INVALID;     \
+    }                             \
+  } while (0)
+
+// ----------------------------------------------------------------------------
+// device buffer helper
+// ----------------------------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t n) {
+    if (n <= bytes) return ASX_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    HIPCHK(hipMalloc(&p, n));
+    bytes = n;
+    return ASX_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  float *f() const { return reinterpret_cast<float *>(p); }
+};
+
+// ----------------------------------------------------------------------------
+// packed layers
+// ----------------------------------------------------------------------------
+enum ConvKind { CK_3X3 = 0, CK_DOWN = 1, CK_1X1 = 2, CK_UP = 3 };
+
+struct ConvLayer {
+  int kind = CK_3X3;
+  int cin = 0, cout = 0;
+  int nrep = 0, kc = 0, cg = 0, nci = 0;
+  int relu = 1;
+  DevBuf w, b;
+};
+
+struct TdfLayer {
+  int n = 0, k = 0, c = 0;
+  bool has_bias = false;
+  DevBuf w, bias, scale, shift;
+};
+
+struct Block {
+  std::vector<ConvLayer> tfc;
+  TdfLayer tdf0, tdf1;
+  int c = 0, t = 0, f = 0;
+};
+
+struct ProfRec {
+  int cls;
+  hipEvent_t a, b;
+  double flops, bytes;
+};
+
+struct asx_engine {
+  int device = 0;
+  asx_mdx_config cfg{};
+  FftPlan plan{};
+  DevBuf d_window, d_tw, d_env;  // env for T = segment_size
+  // net
+  bool net_begun = false, net_ready = false;
+  asx_net_config net{};
+  std::map<std::string, std::vector<float>> host_tensors;
+  ConvLayer first, final_;
+  std::vector<Block> enc, dec;
+  Block mid;
+  std::vector<ConvLayer> ds, us;
+  // workspace
+  int ws_batch = 0;  // chunks the workspace is sized for
+  DevBuf spec_in, spec_out, R[3], H, frames, chunk_out, d_starts, d_nact;
+  std::vector<DevBuf> skip;
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> recs;
+};
+
+static int pick_batch(const asx_engine *e) { return e->cfg.max_batch > 0 ? e->cfg.max_batch : 16; }
+
+// ----------------------------------------------------------------------------
+// profiling wrapper
+// ----------------------------------------------------------------------------
+template <class F>
+static int timed(asx_engine *e, int cls, double flops, double bytes, hipStream_t s, F &&launch) {
+  if (!e->prof) {
+    launch();
+    HIPCHK(hipGetLastError());
+    return ASX_OK;
+  }
+  ProfRec r;
+  r.cls = cls;
+  r.flops = flops;
+  r.bytes = bytes;
+  HIPCHK(hipEventCreate(&r.a));
+  HIPCHK(hipEventCreate(&r.b));
+  HIPCHK(hipEventRecord(r.a, s));
+  launch();
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(r.b, s));
+  e->recs.push_back(r);
+  return ASX_OK;
+}
+
+// ----------------------------------------------------------------------------
+// FFT plan / tables
+// ----------------------------------------------------------------------------
+static bool make_plan(int n_fft, FftPlan *p) {
+  if (n_fft < 8 || (n_fft & 1)) return false;
+  p->n_fft = n_fft;
+  p->nh = n_fft / 2;
+  p->n_stage = 0;
+  int n = p->nh;
+  while (n % 4 == 0) {
+    p->radix[p->n_stage++] = 4;
+    n /= 4;
+  }
+  const int primes[3] = {2, 3, 5};
+  for (int q : primes)
+    while (n % q == 0) {
+      if (p->n_stage >= 16) return false;
+      p->radix[p->n_stage++] = q;
+      n /= q;
+    }
+  return n == 1;
+}
+
+static void host_window(int n, std::vector<float> &w) {
+  w.resize(n);
+  for (int k = 0; k < n; ++k) w[k] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)k / (double)n));
+}
+
+// sum of squared windows, accumulated in f32 in increasing frame order like torch.istft
+static void host_env(int n, int hop, int T, std::vector<float> &env) {
+  std::vector<float> w;
+  host_window(n, w);
+  env.assign((size_t)n + (size_t)hop * (T - 1), 0.f);
+  for (int t = 0; t < T; ++t)
+    for (int k = 0; k < n; ++k) env[(size_t)t * hop + k] += w[k] * w[k];
+}
+
+static size_t stft_lds(const FftPlan &p) { return (size_t)p.nh * 2 * sizeof(float2); }
+static size_t istft_lds(const FftPlan &p) { return ((size_t)p.nh * 3 + 1) * sizeof(float2); }
+
+// ----------------------------------------------------------------------------
+// kernel launchers
+// ----------------------------------------------------------------------------
+template <class CFG>
+static void launch_conv_t(const ConvArgs &a, int nblk, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<CFG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv_mfma_kernel<CFG>, dim3(nblk), dim3(256), CFG::LDS_BYTES, s, a);
+}
+
+static int conv_tile_h(int kind) { return kind == CK_UP ? 4 : 8; }
+
+static int pick_nrep_conv(int cout) {
+  const int ct = (cout + 15) / 16;
+  int best = 1, best_pad = 1 << 30;
+  for (int n = 3; n >= 1; --n) {
+    const int pad = ((ct + n - 1) / n) * n - ct;
+    if (pad < best_pad) {
+      best_pad = pad;
+      best = n;
+    }
+  }
+  return best;
+}
+static int pick_nrep_up(int cout) {
+  const int ct = (cout + 15) / 16;  // virtual tiles = 4*ct, pairs must stay together
+  if ((4 * ct) % 6 == 0) return 6;
+  if ((4 * ct) % 4 == 0) return 4;
+  return 2;
+}
+
+static int conv_setup(ConvLayer &L, int kind, int cin, int cout, int relu) {
+  L.kind = kind;
+  L.cin = cin;
+  L.cout = cout;
+  L.relu = relu;
+  if (kind == CK_UP) {
+    L.nrep = pick_nrep_up(cout);
+    L.kc = 8;
+    const int vt = 4 * ((cout + 15) / 16);
+    L.cg = (vt + L.nrep - 1) / L.nrep;
+  } else {
+    L.nrep = pick_nrep_conv(cout);
+    L.kc = (kind == CK_3X3) ? 8 : (kind == CK_DOWN ? 4 : (cin >= 16 ? 16 : 4));
+    L.cg = ((cout + 15) / 16 + L.nrep - 1) / L.nrep;
+  }
+  L.nci = (cin + L.kc - 1) / L.kc;
+  return ASX_OK;
+}
+
+// w layouts: 3x3 [cout,cin,3,3]; down [cout,cin,2,2]; 1x1 [cout,cin]; up [cin,cout,2,2]
+static int conv_pack(ConvLayer &L, const float *w, const float *b) {
+  const int ntap = L.kind == CK_3X3 ? 9 : (L.kind == CK_DOWN ? 4 : 1);
+  const int NW = 16 * L.nrep;
+  const size_t per_cg = (size_t)L.nci * ntap * L.kc * NW;
+  std::vector<float> wp(per_cg * L.cg, 0.f);
+  const int CT = (L.cout + 15) / 16;
+  for (int cg = 0; cg < L.cg; ++cg)
+    for (int ci = 0; ci < L.nci; ++ci)
+      for (int tap = 0; tap < ntap; ++tap)
+        for (int kc = 0; kc < L.kc; ++kc) {
+          const int c = ci * L.kc + kc;
+          if (c >= L.cin) continue;
+          float *dst = &wp[cg * per_cg + (((size_t)ci * ntap + tap) * L.kc + kc) * NW];
+          for (int n = 0; n < NW; ++n) {
+            float v = 0.f;
+            if (L.kind == CK_UP) {
+              const int nt = cg * L.nrep + n / 16;
+              const int pair = nt / 2, dx = nt & 1;
+              const int dy = pair / CT, ct = pair % CT;
+              const int co = ct * 16 + (n & 15);
+              if (dy < 2 && co < L.cout) v = w[(((size_t)c * L.cout + co) * 2 + dy) * 2 + dx];
+            } else {
+              const int co = cg * NW + n;
+              if (co < L.cout) v = w[((size_t)co * L.cin + c) * ntap + tap];
+            }
+            dst[n] = v;
+          }
+        }
+  const int nb = (L.kind == CK_UP) ? CT * 16 : L.cg * NW;
+  std::vector<float> bp(nb, 0.f);
+  for (int i = 0; i < L.cout; ++i) bp[i] = b ? b[i] : 0.f;
+  CHK(L.w.ensure(wp.size() * 4));
+  CHK(L.b.ensure(bp.size() * 4));
+  HIPCHK(hipMemcpy(L.w.p, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(L.b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+  return ASX_OK;
+}
+
+// x [B,cin,T,F] -> y ; returns output dims through To/Fo.
+static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const float *skip, float *y, int B, int T,
+                       int F, hipStream_t s) {
+  ConvArgs a{};
+  a.x = x;
+  a.wp = L.w.f();
+  a.bias = L.b.f();
+  a.skip = skip;
+  a.y = y;
+  a.B = B;
+  a.Cin = L.cin;
+  a.Cout = L.cout;
+  a.T = T;
+  a.F = F;
+  a.relu = L.relu;
+  a.CG = L.cg;
+  a.NCI = L.nci;
+  int cls = ASX_PROF_CONV3X3;
+  double taps = 9;
+  if (L.kind == CK_DOWN) {
+    a.To = T / 2;
+    a.Fo = F / 2;
+    cls = ASX_PROF_DOWN;
+    taps = 4;
+  } else {
+    a.To = T;
+    a.Fo = F;
+    if (L.kind == CK_1X1) {
+      cls = ASX_PROF_CONV1X1;
+      taps = 1;
+    } else if (L.kind == CK_UP) {
+      cls = ASX_PROF_UP;
+      taps = 4;
+    }
+  }
+  const int th = conv_tile_h(L.kind);
+  a.tilesT = (a.To + th - 1) / th;
+  a.tilesF = (a.Fo + 63) / 64;
+  const int nblk = a.CG * a.tilesT * a.tilesF * B;
+  if (nblk <= 0) return ASX_OK;
+  const double outpix = (double)B * a.To * a.Fo;
+  const double flops = 2.0 * taps * L.cin * L.cout * outpix;
+  double bytes = 4.0 * ((double)B * L.cin * T * F + (double)L.cout * outpix * (L.kind == CK_UP ? 4 : 1));
+  if (L.kind == CK_UP) bytes += 4.0 * (double)L.cout * outpix * 4;  // skip read
+  int bad = 0;
+  CHK(timed(e, cls, flops, bytes, s, [&]() {
+    switch (L.kind) {
+      case CK_3X3:
+        if (L.nrep == 3) launch_conv_t<ConvCfg<3, 3, 1, 1, 3, 8, 2, EPI_BIAS_ACT>>(a, nblk, s);
+        else if (L.nrep == 2) launch_conv_t<ConvCfg<3, 3, 1, 1, 2, 8, 2, EPI_BIAS_ACT>>(a, nblk, s);
+        else launch_conv_t<ConvCfg<3, 3, 1, 1, 1, 8, 2, EPI_BIAS_ACT>>(a, nblk, s);
+        break;
+      case CK_DOWN:
+        if (L.nrep == 3) launch_conv_t<ConvCfg<2, 2, 2, 0, 3, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
+        else if (L.nrep == 2) launch_conv_t<ConvCfg<2, 2, 2, 0, 2, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
+        else launch_conv_t<ConvCfg<2, 2, 2, 0, 1, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
+        break;
+      case CK_1X1:
+        if (L.kc == 16) {
+          if (L.nrep == 3) launch_conv_t<ConvCfg<1, 1, 1, 0, 3, 16, 2, EPI_BIAS_ACT>>(a, nblk, s);
+          else if (L.nrep == 2) launch_conv_t<ConvCfg<1, 1, 1, 0, 2, 16, 2, EPI_BIAS_ACT>>(a, nblk, s);
+          else launch_conv_t<ConvCfg<1, 1, 1, 0, 1, 16, 2, EPI_BIAS_ACT>>(a, nblk, s);
+        } else {
+          if (L.nrep == 3) launch_conv_t<ConvCfg<1, 1, 1, 0, 3, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
+          else if (L.nrep == 2) launch_conv_t<ConvCfg<1, 1, 1, 0, 2, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
+          else launch_conv_t<ConvCfg<1, 1, 1, 0, 1, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
+        }
+        break;
+      case CK_UP:
+        if (L.nrep == 6) launch_conv_t<ConvCfg<1, 1, 1, 0, 6, 8, 1, EPI_UP_MULSKIP>>(a, nblk, s);
+        else if (L.nrep == 4) launch_conv_t<ConvCfg<1, 1, 1, 0, 4, 8, 1, EPI_UP_MULSKIP>>(a, nblk, s);
+        else launch_conv_t<ConvCfg<1, 1, 1, 0, 2, 8, 1, EPI_UP_MULSKIP>>(a, nblk, s);
+        break;
+      default: bad = 1;
+    }
+  }));
+  if (bad) {
+    set_err("conv_launch: bad kind");
+    return ASX_ERR_INVALID;
+  }
+  return ASX_OK;
+}
+
+template <int NREP, int MREP>
+static void launch_tdf_t(const TdfArgs &a, hipStream_t s) {
+  using CFG = TdfCfg<NREP, MREP>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tdf_mfma_kernel<NREP, MREP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    attr_done = true;
+  }
+  const int64_t nbm = (a.M + CFG::BM - 1) / CFG::BM;
+  const int nbn = (a.N + CFG::BN - 1) / CFG::BN;
+  hipLaunchKernelGGL((tdf_mfma_kernel<NREP, MREP>), dim3((unsigned)(nbm * nbn)), dim3(256), CFG::LDS_BYTES, s, a);
+}
+
+static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const float *res, float *y, int64_t M,
+                      int T, hipStream_t s) {
+  TdfArgs a{};
+  a.x = x;
+  a.w = L.w.f();
+  a.bias = L.has_bias ? L.bias.f() : nullptr;
+  a.scale = L.scale.f();
+  a.shift = L.shift.f();
+  a.res = res;
+  a.y = y;
+  a.M = M;
+  a.N = L.n;
+  a.K = L.k;
+  a.C = L.c;
+  a.T = T;
+  if (M <= 0) return ASX_OK;
+  const double flops = 2.0 * (double)M * L.n * L.k;
+  const double bytes = 4.0 * ((double)M * L.k + (double)M * L.n * (res ? 2 : 1) + (double)L.n * L.k);
+  return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
+    if (L.n > 192) launch_tdf_t<6, 4>(a, s);
+    else if (L.n > 128) launch_tdf_t<3, 4>(a, s);
+    else if (L.n > 64) launch_tdf_t<2, 4>(a, s);
+    else launch_tdf_t<1, 4>(a, s);
+  });
+}
+
+static int tdf_pack(TdfLayer &L, int n, int k, int c, const float *w, const float *bias, const float *scale,
+                    const float *shift) {
+  L.n = n;
+  L.k = k;
+  L.c = c;
+  L.has_bias = bias != nullptr;
+  CHK(L.w.ensure((size_t)n * k * 4));
+  HIPCHK(hipMemcpy(L.w.p, w, (size_t)n * k * 4, hipMemcpyHostToDevice));
+  if (bias) {
+    CHK(L.bias.ensure((size_t)n * 4));
+    HIPCHK(hipMemcpy(L.bias.p, bias, (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  CHK(L.scale.ensure((size_t)c * 4));
+  CHK(L.shift.ensure((size_t)c * 4));
+  HIPCHK(hipMemcpy(L.scale.p, scale, (size_t)c * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(L.shift.p, shift, (size_t)c * 4, hipMemcpyHostToDevice));
+  return ASX_OK;
+}
+
+// ----------------------------------------------------------------------------
+// STFT / iSTFT launch helpers (device buffers)
+// ----------------------------------------------------------------------------
+static int stft_launch(asx_engine *e, const float *wave, const int64_t *d_starts, int64_t n_song, int B, int64_t C,
+                       int T, float *spec, int tf_layout, int zero_low, float sign, hipStream_t s) {
+  StftArgs a{};
+  a.wave = wave;
+  a.chunk_start = d_starts;
+  a.n_song = n_song;
+  a.trim = e->cfg.n_fft / 2;
+  a.C = C;
+  a.hop = e->cfg.hop_length;
+  a.T = T;
+  a.dim_f = e->cfg.dim_f;
+  a.zero_low = zero_low;
+  a.tf_layout = tf_layout;
+  a.spec = spec;
+  a.window = e->d_window.f();
+  a.tw = reinterpret_cast<const float2 *>(e->d_tw.p);
+  a.sign = sign;
+  const double bytes = 4.0 * ((double)B * 2 * C + (double)B * 4 * T * e->cfg.dim_f);
+  FftPlan p = e->plan;
+  return timed(e, ASX_PROF_STFT, 0.0, bytes, s, [&]() {
+    hipLaunchKernelGGL(stft_kernel, dim3(T, 2, B), dim3(256), stft_lds(p), s, a, p);
+  });
+}
+
+static int istft_launch(asx_engine *e, const float *spec, int B, int T, int tf_layout, int combine, float *frames,
+                        hipStream_t s) {
+  IstftArgs a{};
+  a.spec = spec;
+  a.T = T;
+  a.dim_f = e->cfg.dim_f;
+  a.tf_layout = tf_layout;
+  a.combine = combine;
+  a.frames = frames;
+  a.window = e->d_window.f();
+  a.tw = reinterpret_cast<const float2 *>(e->d_tw.p);
+  const double bytes = 4.0 * ((double)B * 4 * T * e->cfg.dim_f * (combine ? 2 : 1) + (double)B * 2 * T * e->cfg.n_fft);
+  FftPlan p = e->plan;
+  return timed(e, ASX_PROF_ISTFT, 0.0, bytes, s, [&]() {
+    hipLaunchKernelGGL(istft_kernel, dim3(T, 2, B), dim3(256), istft_lds(p), s, a, p);
+  });
+}
+
+static int ola_launch(asx_engine *e, const float *frames, const float *env, const int64_t *d_nact, int B, int T,
+                      int64_t C, float *out, hipStream_t s) {
+  const double bytes = 4.0 * ((double)B * 2 * T * e->cfg.n_fft + (double)B * 2 * C);
+  const int n_fft = e->cfg.n_fft, hop = e->cfg.hop_length;
+  return timed(e, ASX_PROF_OLA, 0.0, bytes, s, [&]() {
+    hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((C + 255) / 256), 2, B), dim3(256), 0, s, frames, env, d_nact,
+                       n_fft, hop, T, C, out);
+  });
+}
+
+// ----------------------------------------------------------------------------
+// net forward on device buffers: spec_in [B,4,T,F] (TF layout) -> spec_out
+// ----------------------------------------------------------------------------
+static int block_forward(asx_engine *e, const Block &blk, float *&cur, float *dest, int B, hipStream_t s) {
+  // TFC convs rotate through e->R; the TDF output goes to `dest` (or a free R buffer when dest == nullptr)
+  auto next_free = [&](const float *a, const float *b) -> float * {
+    for (int i = 0; i < 3; ++i)
+      if (e->R[i].f() != a && e->R[i].f() != b) return e->R[i].f();
+    return nullptr;
+  };
+  for (size_t j = 0; j < blk.tfc.size(); ++j) {
+    float *out = next_free(cur, nullptr);
+    CHK(conv_launch(e, blk.tfc[j], cur, nullptr, out, B, blk.t, blk.f, s));
+    cur = out;
+  }
+  const int64_t M = (int64_t)B * blk.c * blk.t;
+  CHK(tdf_launch(e, blk.tdf0, cur, nullptr, e->H.f(), M, blk.t, s));
+  float *out = dest ? dest : next_free(cur, nullptr);
+  CHK(tdf_launch(e, blk.tdf1, e->H.f(), cur, out, M, blk.t, s));
+  cur = out;
+  return ASX_OK;
+}
+
+static int net_forward_dev(asx_engine *e, const float *spec_in, float *spec_out, int B, hipStream_t s) {
+  if (!e->net_ready) {
+    set_err("net weights not committed");
+    return ASX_ERR_STATE;
+  }
+  const int T = e->net.dim_t, F = e->net.dim_f;
+  const int n = e->net.num_blocks / 2;
+  float *cur = e->R[0].f();
+  CHK(conv_launch(e, e->first, spec_in, nullptr, cur, B, T, F, s));
+  for (int i = 0; i < n; ++i) {
+    CHK(block_forward(e, e->enc[i], cur, e->skip[i].f(), B, s));
+    float *out = e->R[0].f();
+    CHK(conv_launch(e, e->ds[i], cur, nullptr, out, B, e->enc[i].t, e->enc[i].f, s));
+    cur = out;
+  }
+  CHK(block_forward(e, e->mid, cur, nullptr, B, s));
+  for (int i = 0; i < n; ++i) {
+    const Block &blk = e->dec[i];
+    float *out = nullptr;
+    for (int r = 0; r < 3; ++r)
+      if (e->R[r].f() != cur) {
+        out = e->R[r].f();
+        break;
+      }
+    // input at (t/2, f/2) -> (t, f), multiplied by the matching encoder output (mdxnet.py:113)
+    CHK(conv_launch(e, e->us[i], cur, e->skip[n - 1 - i].f(), out, B, blk.t / 2, blk.f / 2, s));
+    cur = out;
+    CHK(block_forward(e, blk, cur, nullptr, B, s));
+  }
+  CHK(conv_launch(e, e->final_, cur, nullptr, spec_out, B, T, F, s));
+  return ASX_OK;
+}
+
+// ----------------------------------------------------------------------------
+// workspace
+// ----------------------------------------------------------------------------
+static int ensure_workspace(asx_engine *e, int Bchunks, bool need_net) {
+  const int T = e->cfg.segment_size, Fq = e->cfg.dim_f;
+  const int mult = (need_net && e->cfg.enable_denoise) ? 2 : 1;
+  const size_t Bn = (size_t)Bchunks * mult;
+  CHK(e->spec_in.ensure(Bn * 4 * T * Fq * 4));
+  CHK(e->frames.ensure((size_t)Bchunks * 2 * T * e->cfg.n_fft * 4));
+  if (need_net) {
+    CHK(e->spec_out.ensure(Bn * 4 * T * Fq * 4));
+    const size_t lvl0 = Bn * e->net.g * T * Fq * 4;
+    for (int i = 0; i < 3; ++i) CHK(e->R[i].ensure(lvl0));
+    CHK(e->H.ensure(Bn * e->net.g * T * (Fq / std::max(1, e->net.bn)) * 4 + 256));
+    const int n = e->net.num_blocks / 2;
+    e->skip.resize(n);
+    for (int i = 0; i < n; ++i) {
+      const size_t c = (size_t)e->net.g * (i + 1), t = T >> i, f = Fq >> i;
+      CHK(e->skip[i].ensure(Bn * c * t * f * 4));
+    }
+  }
+  e->ws_batch = std::max(e->ws_batch, Bchunks);
+  return ASX_OK;
+}
+
+// ----------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------
+extern "C" {
+
+int asx_abi_version(void) { return ASX_ABI_VERSION; }
+const char *asx_last_error(void) { return g_err; }
+
+int asx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
+  REQUIRE(cfg && out, "asx_engine_create: null argument");
+  REQUIRE(cfg->n_fft >= 8 && cfg->n_fft % 2 == 0, "n_fft must be even and >= 8 (got %d)", cfg->n_fft);
+  REQUIRE(cfg->hop_length > 0 && cfg->segment_size >= 2, "bad hop_length/segment_size");
+  REQUIRE(cfg->dim_f > 0 && cfg->dim_f <= cfg->n_fft / 2 + 1, "dim_f %d out of range for n_fft %d", cfg->dim_f,
+          cfg->n_fft);
+  REQUIRE(cfg->overlap >= 0.f && cfg->overlap < 1.f, "overlap must be in [0,1)");
+  const int64_t C = (int64_t)cfg->hop_length * (cfg->segment_size - 1);
+  REQUIRE(C > cfg->n_fft / 2, "chunk_size %lld must exceed n_fft/2 (reflect padding)", (long long)C);
+  REQUIRE(C - cfg->n_fft > 0, "chunk_size %lld must exceed n_fft (gen_size > 0)", (long long)C);
+  FftPlan plan{};
+  REQUIRE(make_plan(cfg->n_fft, &plan), "n_fft/2 = %d must factor into {2,3,5}", cfg->n_fft / 2);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  REQUIRE(device >= 0 && device < ndev, "device %d not available (%d visible)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  asx_engine *e = new asx_engine();
+  e->device = device;
+  e->cfg = *cfg;
+  e->plan = plan;
+  std::vector<float> w;
+  host_window(cfg->n_fft, w);
+  std::vector<float> tw((size_t)cfg->n_fft * 2);
+  for (int j = 0; j < cfg->n_fft; ++j) {
+    const double ang = -2.0 * M_PI * (double)j / (double)cfg->n_fft;
+    tw[2 * j] = (float)cos(ang);
+    tw[2 * j + 1] = (float)sin(ang);
+  }
+  std::vector<float> env;
+  host_env(cfg->n_fft, cfg->hop_length, cfg->segment_size, env);
+  int rc = ASX_OK;
+  if ((rc = e->d_window.ensure(w.size() * 4)) == ASX_OK && (rc = e->d_tw.ensure(tw.size() * 4)) == ASX_OK &&
+      (rc = e->d_env.ensure(env.size() * 4)) == ASX_OK) {
+    if (hipMemcpy(e->d_window.p, w.data(), w.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->d_tw.p, tw.data(), tw.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->d_env.p, env.data(), env.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+      set_err("table upload failed");
+      rc = ASX_ERR_HIP;
+    }
+  }
+  if (rc == ASX_OK) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)stft_lds(plan));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&istft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)istft_lds(plan));
+  }
+  if (rc != ASX_OK) {
+    asx_engine_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return ASX_OK;
+}
+
+static void free_conv(ConvLayer &L) {
+  L.w.release();
+  L.b.release();
+}
+static void free_tdf(TdfLayer &L) {
+  L.w.release();
+  L.bias.release();
+  L.scale.release();
+  L.shift.release();
+}
+static void free_block(Block &b) {
+  for (auto &c : b.tfc) free_conv(c);
+  free_tdf(b.tdf0);
+  free_tdf(b.tdf1);
+}
+
+void asx_engine_destroy(asx_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  for (auto &r : e->recs) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  e->d_window.release();
+  e->d_tw.release();
+  e->d_env.release();
+  free_conv(e->first);
+  free_conv(e->final_);
+  for (auto &b : e->enc) free_block(b);
+  for (auto &b : e->dec) free_block(b);
+  free_block(e->mid);
+  for (auto &c : e->ds) free_conv(c);
+  for (auto &c : e->us) free_conv(c);
+  e->spec_in.release();
+  e->spec_out.release();
+  for (auto &r : e->R) r.release();
+  e->H.release();
+  e->frames.release();
+  e->chunk_out.release();
+  e->d_starts.release();
+  e->d_nact.release();
+  for (auto &sk : e->skip) sk.release();
+  delete e;
+}
+
+// ---- weights ---------------------------------------------------------------
+int asx_net_begin(asx_engine *e, const asx_net_config *cfg) {
+  REQUIRE(e && cfg, "asx_net_begin: null argument");
+  REQUIRE(cfg->dim_f == e->cfg.dim_f, "net dim_f %d != engine dim_f %d", cfg->dim_f, e->cfg.dim_f);
+  REQUIRE(cfg->dim_t == e->cfg.segment_size, "net dim_t %d != segment_size %d", cfg->dim_t, e->cfg.segment_size);
+  REQUIRE(cfg->k == 3, "only k=3 TFC kernels are supported (got %d)", cfg->k);
+  REQUIRE(cfg->dim_c > 0 && cfg->g > 0 && cfg->l > 0 && cfg->bn > 0, "bad net hyper-parameters");
+  REQUIRE(cfg->num_blocks >= 1 && cfg->num_blocks % 2 == 1, "num_blocks must be odd");
+  const int n = cfg->num_blocks / 2;
+  REQUIRE((cfg->dim_f % (1 << n)) == 0 && (cfg->dim_t % (1 << n)) == 0,
+          "dim_f and dim_t must be divisible by 2^%d", n);
+  REQUIRE(((cfg->dim_f >> n) % cfg->bn) == 0, "dim_f / 2^n must be divisible by bn");
+  e->net = *cfg;
+  e->host_tensors.clear();
+  e->net_begun = true;
+  e->net_ready = false;
+  return ASX_OK;
+}
+
+int asx_net_set_tensor(asx_engine *e, const char *name, const float *host, int64_t numel) {
+  REQUIRE(e && name && host && numel > 0, "asx_net_set_tensor: bad argument");
+  if (!e->net_begun) {
+    set_err("asx_net_set_tensor before asx_net_begin");
+    return ASX_ERR_STATE;
+  }
+  e->host_tensors[name].assign(host, host + numel);
+  return ASX_OK;
+}
+
+static int get_tensor(asx_engine *e, const std::string &name, int64_t numel, const float **out, bool optional = false) {
+  auto it = e->host_tensors.find(name);
+  if (it == e->host_tensors.end()) {
+    if (optional) {
+      *out = nullptr;
+      return ASX_OK;
+    }
+    set_err("missing tensor '%s'", name.c_str());
+    return ASX_ERR_INVALID;
+  }
+  if ((int64_t)it->second.size() != numel) {
+    set_err("tensor '%s': expected %lld elements, got %zu", name.c_str(), (long long)numel, it->second.size());
+    return ASX_ERR_INVALID;
+  }
+  *out = it->second.data();
+  return ASX_OK;
+}
+
+static int build_block(asx_engine *e, Block &blk, const std::string &pre, int c, int t, int f) {
+  const asx_net_config &n = e->net;
+  blk.c = c;
+  blk.t = t;
+  blk.f = f;
+  blk.tfc.resize(n.l);
+  for (int j = 0; j < n.l; ++j) {
+    const float *w, *b;
+    CHK(get_tensor(e, pre + ".tfc" + std::to_string(j) + ".w", (int64_t)c * c * 9, &w));
+    CHK(get_tensor(e, pre + ".tfc" + std::to_string(j) + ".b", c, &b));
+    CHK(conv_setup(blk.tfc[j], CK_3X3, c, c, 1));
+    CHK(conv_pack(blk.tfc[j], w, b));
+  }
+  const int fb = f / n.bn;
+  const float *w, *bias, *sc, *sh;
+  CHK(get_tensor(e, pre + ".tdf0.w", (int64_t)fb * f, &w));
+  CHK(get_tensor(e, pre + ".tdf0.bias", fb, &bias, !n.tdf_bias));
+  CHK(get_tensor(e, pre + ".tdf0.scale", c, &sc));
+  CHK(get_tensor(e, pre + ".tdf0.shift", c, &sh));
+  CHK(tdf_pack(blk.tdf0, fb, f, c, w, bias, sc, sh));
+  CHK(get_tensor(e, pre + ".tdf1.w", (int64_t)f * fb, &w));
+  CHK(get_tensor(e, pre + ".tdf1.bias", f, &bias, !n.tdf_bias));
+  CHK(get_tensor(e, pre + ".tdf1.scale", c, &sc));
+  CHK(get_tensor(e, pre + ".tdf1.shift", c, &sh));
+  CHK(tdf_pack(blk.tdf1, f, fb, c, w, bias, sc, sh));
+  return ASX_OK;
+}
+
+int asx_net_commit(asx_engine *e) {
+  REQUIRE(e, "asx_net_commit: null engine");
+  if (!e->net_begun) {
+    set_err("asx_net_commit before asx_net_begin");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  const asx_net_config &n = e->net;
+  const int nn = n.num_blocks / 2;
+  const float *w, *b;
+  CHK(get_tensor(e, "first.w", (int64_t)n.g * n.dim_c, &w));
+  CHK(get_tensor(e, "first.b", n.g, &b));
+  CHK(conv_setup(e->first, CK_1X1, n.dim_c, n.g, 1));
+  CHK(conv_pack(e->first, w, b));
+  e->enc.assign(nn, Block());
+  e->dec.assign(nn, Block());
+  e->ds.assign(nn, ConvLayer());
+  e->us.assign(nn, ConvLayer());
+  int c = n.g, t = n.dim_t, f = n.dim_f;
+  for (int i = 0; i < nn; ++i) {
+    CHK(build_block(e, e->enc[i], "enc" + std::to_string(i), c, t, f));
+    CHK(get_tensor(e, "ds" + std::to_string(i) + ".w", (int64_t)(c + n.g) * c * 4, &w));
+    CHK(get_tensor(e, "ds" + std::to_string(i) + ".b", c + n.g, &b));
+    CHK(conv_setup(e->ds[i], CK_DOWN, c, c + n.g, 1));
+    CHK(conv_pack(e->ds[i], w, b));
+    c += n.g;
+    t /= 2;
+    f /= 2;
+  }
+  CHK(build_block(e, e->mid, "mid", c, t, f));
+  for (int i = 0; i < nn; ++i) {
+    CHK(get_tensor(e, "us" + std::to_string(i) + ".w", (int64_t)c * (c - n.g) * 4, &w));
+    CHK(get_tensor(e, "us" + std::to_string(i) + ".b", c - n.g, &b));
+    CHK(conv_setup(e->us[i], CK_UP, c, c - n.g, 1));
+    CHK(conv_pack(e->us[i], w, b));
+    c -= n.g;
+    t *= 2;
+    f *= 2;
+    CHK(build_block(e, e->dec[i], "dec" + std::to_string(i), c, t, f));
+  }
+  CHK(get_tensor(e, "final.w", (int64_t)n.dim_c * n.g, &w));
+  CHK(get_tensor(e, "final.b", n.dim_c, &b));
+  CHK(conv_setup(e->final_, CK_1X1, n.g, n.dim_c, 0));
+  CHK(conv_pack(e->final_, w, b));
+  e->host_tensors.clear();
+  e->net_ready = true;
+  return ASX_OK;
+}
+
+double asx_net_flops(const asx_engine *e, int32_t batch) {
+  if (!e || !e->net_begun) return 0.0;
+  const asx_net_config &d = e->net;
+  const int n = d.num_blocks / 2;
+  double fl = 2.0 * d.dim_c * d.g * (double)d.dim_t * d.dim_f;
+  auto block = [&](double c, double t, double f) {
+    return d.l * 2.0 * 9.0 * c * c * t * f + 2.0 * 2.0 * c * t * f * (f / d.bn);
+  };
+  double c = d.g, t = d.dim_t, f = d.dim_f;
+  for (int i = 0; i < n; ++i) {
+    fl += block(c, t, f);
+    fl += 2.0 * 4.0 * c * (c + d.g) * (t / 2) * (f / 2);
+    c += d.g;
+    t /= 2;
+    f /= 2;
+  }
+  fl += block(c, t, f);
+  for (int i = 0; i < n; ++i) {
+    fl += 2.0 * 4.0 * c * (c - d.g) * t * f;
+    c -= d.g;
+    t *= 2;
+    f *= 2;
+    fl += block(c, t, f);
+  }
+  fl += 2.0 * d.g * d.dim_c * (double)d.dim_t * d.dim_f;
+  return fl * batch;
+}
+
+// ---- plan ------------------------------------------------------------------
+int asx_plan_query(const asx_engine *e, int64_t N, uint32_t flags, asx_plan *out) {
+  REQUIRE(e && out, "asx_plan_query: null argument");
+  REQUIRE(N >= 1, "n_samples must be >= 1 (an empty mix raises in the reference, common_separator.py:267)");
+  const bool match = (flags & ASX_FLAG_MATCH_MIX) != 0;
+  // python: overlap is a float (double); 0.02 for the match-mix pass (mdx_separator.py:311)
+  const double overlap = match ? 0.02 : (double)e->cfg.overlap;
+  asx_plan p{};
+  p.n_samples = N;
+  p.trim = e->cfg.n_fft / 2;
+  p.chunk_size = (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1);
+  p.gen_size = p.chunk_size - 2 * p.trim;
+  p.pad = p.gen_size + p.trim - (N % p.gen_size);
+  p.padded_len = p.trim + N + p.pad;
+  p.step = (int64_t)((1.0 - overlap) * (double)p.chunk_size);  // int() truncation (mdx_separator.py:335)
+  REQUIRE(p.step >= 1, "overlap too close to 1: step == 0");
+  p.n_chunks = (int32_t)((p.padded_len + p.step - 1) / p.step);
+  p.n_frames = e->cfg.segment_size;
+  *out = p;
+  return ASX_OK;
+}
+
+// ---- chunk batches -----------------------------------------------------------
+static bool windowed_mode(const asx_engine *e, uint32_t flags) {
+  return (flags & ASX_FLAG_MATCH_MIX) ? true : (e->cfg.overlap != 0.f);
+}
+
+int asx_demix_chunks_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t k0, int32_t k1,
+                         float *chunk_out_dev, uint32_t flags, void *stream) {
+  REQUIRE(e && mix_dev && chunk_out_dev, "asx_demix_chunks_dev: null argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  asx_plan p;
+  CHK(asx_plan_query(e, N, flags, &p));
+  REQUIRE(k0 >= 0 && k1 <= p.n_chunks && k0 <= k1, "chunk range [%d,%d) outside [0,%d)", k0, k1, p.n_chunks);
+  const bool match = (flags & ASX_FLAG_MATCH_MIX) != 0;
+  const bool need_net = !match;
+  if (need_net && !e->net_ready) {
+    set_err("asx_demix: net weights not committed");
+    return ASX_ERR_STATE;
+  }
+  const int nk = k1 - k0;
+  if (nk == 0) return ASX_OK;
+  const int maxB = pick_batch(e);
+  const int nbatch = (nk + maxB - 1) / maxB;
+  const int per = (nk + nbatch - 1) / nbatch;
+  CHK(ensure_workspace(e, per, need_net));
+  // chunk tables
+  std::vector<int64_t> starts(nk), nact(nk);
+  const bool win = windowed_mode(e, flags);
+  for (int i = 0; i < nk; ++i) {
+    const int64_t st = (int64_t)(k0 + i) * p.step;
+    starts[i] = st;
+    const int64_t na = std::min<int64_t>(p.chunk_size, p.padded_len - st);
+    nact[i] = win ? na : -1;  // negative: no chunk window (overlap == 0, mdx_separator.py:389-390)
+  }
+  CHK(e->d_starts.ensure((size_t)nk * 8));
+  CHK(e->d_nact.ensure((size_t)nk * 8));
+  HIPCHK(hipMemcpyAsync(e->d_starts.p, starts.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(e->d_nact.p, nact.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));  // host vectors go out of scope
+  const int T = e->cfg.segment_size;
+  const int64_t C = p.chunk_size;
+  const size_t spec_elems = (size_t)4 * T * e->cfg.dim_f;
+  for (int b0 = 0; b0 < nk; b0 += per) {
+    const int B = std::min(per, nk - b0);
+    const int64_t *ds = reinterpret_cast<const int64_t *>(e->d_starts.p) + b0;
+    const int64_t *dn = reinterpret_cast<const int64_t *>(e->d_nact.p) + b0;
+    CHK(stft_launch(e, mix_dev, ds, N, B, C, T, e->spec_in.f(), 1, 3, 1.0f, s));
+    const float *spec_final = e->spec_in.f();
+    int combine = 0;
+    if (need_net) {
+      int Bn = B;
+      if (e->cfg.enable_denoise) {
+        // second half of the batch: the negated spectrum (mdx_separator.py:437)
+        CHK(stft_launch(e, mix_dev, ds, N, B, C, T, e->spec_in.f() + (size_t)B * spec_elems, 1, 3, -1.0f, s));
+        Bn = 2 * B;
+        combine = B;
+      }
+      CHK(net_forward_dev(e, e->spec_in.f(), e->spec_out.f(), Bn, s));
+      spec_final = e->spec_out.f();
+    }
+    CHK(istft_launch(e, spec_final, B, T, 1, combine, e->frames.f(), s));
+    CHK(ola_launch(e, e->frames.f(), e->d_env.f(), dn, B, T, C, chunk_out_dev + (size_t)b0 * 2 * C, s));
+  }
+  return ASX_OK;
+}
+
+int asx_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t N, float *out_dev, uint32_t flags,
+                     void *stream) {
+  REQUIRE(e && chunk_out_dev && out_dev, "asx_finalize_dev: null argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  asx_plan p;
+  CHK(asx_plan_query(e, N, flags, &p));
+  const int win = windowed_mode(e, flags) ? 1 : 0;
+  const double bytes = 4.0 * ((double)p.n_chunks * 2 * p.chunk_size + 2.0 * N);
+  return timed(e, ASX_PROF_FINALIZE, 0.0, bytes, s, [&]() {
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, s, chunk_out_dev,
+                       p.n_chunks, p.chunk_size, p.step, p.padded_len, p.trim, N, win, out_dev);
+  });
+}
+
+int asx_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, float *out_dev, uint32_t flags, void *stream) {
+  REQUIRE(e && mix_dev && out_dev, "asx_demix_dev: null argument");
+  HIPCHK(hipSetDevice(e->device));
+  asx_plan p;
+  CHK(asx_plan_query(e, N, flags, &p));
+  CHK(e->chunk_out.ensure((size_t)p.n_chunks * 2 * p.chunk_size * 4));
+  CHK(asx_demix_chunks_dev(e, mix_dev, N, 0, p.n_chunks, e->chunk_out.f(), flags, stream));
+  CHK(asx_finalize_dev(e, e->chunk_out.f(), N, out_dev, flags, stream));
+  return ASX_OK;
+}
+
+int asx_demix(asx_engine *e, const float *mix_host, int64_t N, float *out_host, uint32_t flags) {
+  REQUIRE(e && mix_host && out_host, "asx_demix: null argument");
+  REQUIRE(N >= 1, "n_samples must be >= 1");
+  HIPCHK(hipSetDevice(e->device));
+  DevBuf dmix, dout;
+  int rc = dmix.ensure((size_t)2 * N * 4);
+  if (rc == ASX_OK) rc = dout.ensure((size_t)2 * N * 4);
+  if (rc == ASX_OK && hipMemcpy(dmix.p, mix_host, (size_t)2 * N * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    set_err("asx_demix: H2D copy failed");
+    rc = ASX_ERR_HIP;
+  }
+  if (rc == ASX_OK) rc = asx_demix_dev(e, dmix.f(), N, dout.f(), flags, nullptr);
+  if (rc == ASX_OK && hipStreamSynchronize(nullptr) != hipSuccess) {
+    set_err("asx_demix: device execution failed: %s", hipGetErrorString(hipGetLastError()));
+    rc = ASX_ERR_HIP;
+  }
+  if (rc == ASX_OK && hipMemcpy(out_host, dout.p, (size_t)2 * N * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+    set_err("asx_demix: D2H copy failed");
+    rc = ASX_ERR_HIP;
+  }
+  dmix.release();
+  dout.release();
+  return rc;
+}
+
+// ---- stage hooks -------------------------------------------------------------
+static int to_dev(DevBuf &d, const float *h, size_t n) {
+  CHK(d.ensure(n * 4));
+  HIPCHK(hipMemcpy(d.p, h, n * 4, hipMemcpyHostToDevice));
+  return ASX_OK;
+}
+static int to_host(float *h, const DevBuf &d, size_t n) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(h, d.p, n * 4, hipMemcpyDeviceToHost));
+  return ASX_OK;
+}
+struct BufGuard {
+  std::vector<DevBuf *> v;
+  ~BufGuard() {
+    for (auto *b : v) b->release();
+  }
+};
+
+static int transpose_launch(const float *in, float *out, int planes, int rows, int cols, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_last2_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, planes), dim3(32, 8), 0, s, in,
+                     out, rows, cols);
+  HIPCHK(hipGetLastError());
+  return ASX_OK;
+}
+
+int asx_stft(asx_engine *e, const float *wave_host, int32_t B, int64_t C, float *spec_host) {
+  REQUIRE(e && wave_host && spec_host && B > 0, "asx_stft: bad argument");
+  REQUIRE(C > e->cfg.n_fft / 2, "asx_stft: n_time %lld must exceed n_fft/2 (reflect padding)", (long long)C);
+  HIPCHK(hipSetDevice(e->device));
+  const int T = (int)(C / e->cfg.hop_length) + 1;
+  const size_t ns = (size_t)B * 4 * e->cfg.dim_f * T;
+  DevBuf dw, ds;
+  BufGuard g{{&dw, &ds}};
+  CHK(to_dev(dw, wave_host, (size_t)B * 2 * C));
+  CHK(ds.ensure(ns * 4));
+  CHK(stft_launch(e, dw.f(), nullptr, -1, B, C, T, ds.f(), 0, 0, 1.0f, nullptr));
+  CHK(to_host(spec_host, ds, ns));
+  return ASX_OK;
+}
+
+int asx_istft(asx_engine *e, const float *spec_host, int32_t B, int32_t T, float *wave_host) {
+  REQUIRE(e && spec_host && wave_host && B > 0 && T >= 1, "asx_istft: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  const int n = e->cfg.n_fft, hop = e->cfg.hop_length;
+  const int64_t C = (int64_t)hop * (T - 1);
+  REQUIRE(C > 0, "asx_istft: need at least 2 frames");
+  const size_t ns = (size_t)B * 4 * e->cfg.dim_f * T;
+  DevBuf dsp, dfr, denv, dout;
+  BufGuard g{{&dsp, &dfr, &denv, &dout}};
+  CHK(to_dev(dsp, spec_host, ns));
+  CHK(dfr.ensure((size_t)B * 2 * T * n * 4));
+  CHK(dout.ensure((size_t)B * 2 * C * 4));
+  std::vector<float> env;
+  host_env(n, hop, T, env);
+  CHK(to_dev(denv, env.data(), env.size()));
+  CHK(istft_launch(e, dsp.f(), B, T, 0, 0, dfr.f(), nullptr));
+  CHK(ola_launch(e, dfr.f(), denv.f(), nullptr, B, T, C, dout.f(), nullptr));
+  CHK(to_host(wave_host, dout, (size_t)B * 2 * C));
+  return ASX_OK;
+}
+
+int asx_net_forward(asx_engine *e, const float *spec_host, int32_t B, float *out_host) {
+  REQUIRE(e && spec_host && out_host && B > 0, "asx_net_forward: bad argument");
+  if (!e->net_ready) {
+    set_err("asx_net_forward: net weights not committed");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  const int T = e->net.dim_t, Fq = e->net.dim_f, dc = e->net.dim_c;
+  REQUIRE(dc == 4, "asx_net_forward: dim_c must be 4");
+  const bool den = e->cfg.enable_denoise;
+  e->cfg.enable_denoise = 0;  // size the workspace for exactly B
+  int rc = ensure_workspace(e, B, true);
+  e->cfg.enable_denoise = den;
+  CHK(rc);
+  const size_t ns = (size_t)B * dc * Fq * T;
+  DevBuf din, dout;
+  BufGuard g{{&din, &dout}};
+  CHK(to_dev(din, spec_host, ns));
+  CHK(dout.ensure(ns * 4));
+  // reference layout [B,4,F,T] -> engine layout [B,4,T,F]
+  CHK(transpose_launch(din.f(), e->spec_in.f(), B * dc, Fq, T, nullptr));
+  CHK(net_forward_dev(e, e->spec_in.f(), e->spec_out.f(), B, nullptr));
+  CHK(transpose_launch(e->spec_out.f(), dout.f(), B * dc, T, Fq, nullptr));
+  CHK(to_host(out_host, dout, ns));
+  return ASX_OK;
+}
+
+int asx_run_model(asx_engine *e, const float *wave_host, int32_t B, float *out_host, uint32_t flags) {
+  REQUIRE(e && wave_host && out_host && B > 0, "asx_run_model: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  const bool match = (flags & ASX_FLAG_MATCH_MIX) != 0;
+  if (!match && !e->net_ready) {
+    set_err("asx_run_model: net weights not committed");
+    return ASX_ERR_STATE;
+  }
+  const int T = e->cfg.segment_size;
+  const int64_t C = (int64_t)e->cfg.hop_length * (T - 1);
+  CHK(ensure_workspace(e, B, !match));
+  DevBuf dw, dout;
+  BufGuard g{{&dw, &dout}};
+  CHK(to_dev(dw, wave_host, (size_t)B * 2 * C));
+  CHK(dout.ensure((size_t)B * 2 * C * 4));
+  const size_t spec_elems = (size_t)4 * T * e->cfg.dim_f;
+  CHK(stft_launch(e, dw.f(), nullptr, -1, B, C, T, e->spec_in.f(), 1, 3, 1.0f, nullptr));
+  const float *spec_final = e->spec_in.f();
+  int combine = 0;
+  if (!match) {
+    int Bn = B;
+    if (e->cfg.enable_denoise) {
+      CHK(stft_launch(e, dw.f(), nullptr, -1, B, C, T, e->spec_in.f() + (size_t)B * spec_elems, 1, 3, -1.0f, nullptr));
+      Bn = 2 * B;
+      combine = B;
+    }
+    CHK(net_forward_dev(e, e->spec_in.f(), e->spec_out.f(), Bn, nullptr));
+    spec_final = e->spec_out.f();
+  }
+  CHK(istft_launch(e, spec_final, B, T, 1, combine, e->frames.f(), nullptr));
+  CHK(ola_launch(e, e->frames.f(), e->d_env.f(), nullptr, B, T, C, dout.f(), nullptr));
+  CHK(to_host(out_host, dout, (size_t)B * 2 * C));
+  return ASX_OK;
+}
+
+// ---- single-layer hooks --------------------------------------------------------
+int asx_op_conv(asx_engine *e, const char *op, const float *x_host, int32_t B, int32_t cin, int32_t t, int32_t f,
+                const float *w_host, const float *b_host, int32_t cout, const float *aux_host, int32_t relu,
+                float *y_host) {
+  REQUIRE(e && op && x_host && w_host && y_host && B > 0 && cin > 0 && cout > 0 && t > 0 && f > 0,
+          "asx_op_conv: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  int kind;
+  int to = t, fo = f;
+  if (!strcmp(op, "conv3x3")) kind = CK_3X3;
+  else if (!strcmp(op, "down")) {
+    kind = CK_DOWN;
+    to = t / 2;
+    fo = f / 2;
+  } else if (!strcmp(op, "conv1x1")) kind = CK_1X1;
+  else if (!strcmp(op, "up")) {
+    kind = CK_UP;
+    to = 2 * t;
+    fo = 2 * f;
+    REQUIRE(aux_host, "asx_op_conv(up): skip tensor required");
+  } else {
+    set_err("asx_op_conv: unknown op '%s'", op);
+    return ASX_ERR_INVALID;
+  }
+  ConvLayer L;
+  DevBuf dx, dy, dskip;
+  BufGuard g{{&dx, &dy, &dskip, &L.w, &L.b}};
+  CHK(conv_setup(L, kind, cin, cout, kind == CK_1X1 ? relu : 1));
+  CHK(conv_pack(L, w_host, b_host));
+  CHK(to_dev(dx, x_host, (size_t)B * cin * t * f));
+  const size_t ny = (size_t)B * cout * to * fo;
+  CHK(dy.ensure(ny * 4));
+  HIPCHK(hipMemset(dy.p, 0xff, ny * 4));  // NaN canary: every output element must be written
+  if (kind == CK_UP) CHK(to_dev(dskip, aux_host, ny));
+  CHK(conv_launch(e, L, dx.f(), dskip.f(), dy.f(), B, t, f, nullptr));
+  CHK(to_host(y_host, dy, ny));
+  return ASX_OK;
+}
+
+int asx_op_tdf(asx_engine *e, const float *x_host, int32_t B, int32_t c, int32_t t, int32_t k, const float *w_host,
+               const float *bias_host, int32_t n, const float *scale_host, const float *shift_host,
+               const float *res_host, float *y_host) {
+  REQUIRE(e && x_host && w_host && scale_host && shift_host && y_host && B > 0 && c > 0 && t > 0 && k > 0 && n > 0,
+          "asx_op_tdf: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  TdfLayer L;
+  DevBuf dx, dy, dres;
+  BufGuard g{{&dx, &dy, &dres, &L.w, &L.bias, &L.scale, &L.shift}};
+  CHK(tdf_pack(L, n, k, c, w_host, bias_host, scale_host, shift_host));
+  const int64_t M = (int64_t)B * c * t;
+  CHK(to_dev(dx, x_host, (size_t)M * k));
+  CHK(dy.ensure((size_t)M * n * 4));
+  HIPCHK(hipMemset(dy.p, 0xff, (size_t)M * n * 4));
+  if (res_host) CHK(to_dev(dres, res_host, (size_t)M * n));
+  CHK(tdf_launch(e, L, dx.f(), res_host ? dres.f() : nullptr, dy.f(), M, t, nullptr));
+  CHK(to_host(y_host, dy, (size_t)M * n));
+  return ASX_OK;
+}
+
+// ---- profiling -------------------------------------------------------------------
+int asx_profile_enable(asx_engine *e, int32_t on) {
+  REQUIRE(e, "asx_profile_enable: null engine");
+  for (auto &r : e->recs) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  e->recs.clear();
+  e->prof = on != 0;
+  return ASX_OK;
+}
+
+int asx_profile_read(asx_engine *e, asx_profile *out) {
+  REQUIRE(e && out, "asx_profile_read: null argument");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  memset(out, 0, sizeof(*out));
+  for (auto &r : e->recs) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+    out->launches[r.cls] += 1;
+    out->ms[r.cls] += ms;
+    out->flops[r.cls] += r.flops;
+    out->bytes[r.cls] += r.bytes;
+  }
+  return ASX_OK;
+}
+
+}  // extern "C"

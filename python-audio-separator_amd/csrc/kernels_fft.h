@@ -1,0 +1,380 @@
+// STFT / iSTFT / overlap-add kernels for gfx950 (wave64, LDS-staged Stockham FFT).
+//
+// Replaces torch.stft / torch.istft as used by uvr_lib_v5/stft.py:41,117 and the
+// host-side windowed overlap-add of mdx_separator.py:358-401.
+//
+// A real FFT of n_fft points is computed as one complex FFT of Nh = n_fft/2
+// points (packed even/odd samples) plus a split/merge pass, all inside LDS:
+// two float2[Nh] ping-pong buffers, mixed radix {4,2,3,5} autosort (Stockham)
+// stages so no bit-reversal pass is needed.  n_fft = 6144 -> Nh = 3072 =
+// 4^5 * 3, 48 KiB of LDS per workgroup, 3 workgroups per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asx {
+
+struct FftPlan {
+  int n_fft;
+  int nh;       // n_fft / 2
+  int n_stage;
+  int radix[16];
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -i (SIGN<0, forward) or +i (SIGN>0, inverse)
+template <int SIGN>
+__device__ __forceinline__ float2 crot(float2 a) {
+  return SIGN < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+
+template <int R, int SIGN>
+__device__ __forceinline__ void butterfly(float2 *v) {
+  if constexpr (R == 2) {
+    float2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+  } else if constexpr (R == 4) {
+    float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+    float2 t2 = cadd(v[1], v[3]), t3 = crot<SIGN>(csub(v[1], v[3]));
+    v[0] = cadd(t0, t2);
+    v[1] = cadd(t1, t3);
+    v[2] = csub(t0, t2);
+    v[3] = csub(t1, t3);
+  } else if constexpr (R == 3) {
+    const float s3 = 0.86602540378443864676f;
+    float2 s = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+    float2 m = make_float2(v[0].x - 0.5f * s.x, v[0].y - 0.5f * s.y);
+    float2 r = crot<SIGN>(make_float2(s3 * d.x, s3 * d.y));
+    v[0] = cadd(v[0], s);
+    v[1] = cadd(m, r);
+    v[2] = csub(m, r);
+  } else if constexpr (R == 5) {
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    float2 a = v[0];
+    float2 S1 = cadd(v[1], v[4]), S2 = cadd(v[2], v[3]);
+    float2 D1 = csub(v[1], v[4]), D2 = csub(v[2], v[3]);
+    float2 p1 = make_float2(a.x + c1 * S1.x + c2 * S2.x, a.y + c1 * S1.y + c2 * S2.y);
+    float2 p2 = make_float2(a.x + c2 * S1.x + c1 * S2.x, a.y + c2 * S1.y + c1 * S2.y);
+    float2 q1 = crot<SIGN>(make_float2(s1 * D1.x + s2 * D2.x, s1 * D1.y + s2 * D2.y));
+    float2 q2 = crot<SIGN>(make_float2(s2 * D1.x - s1 * D2.x, s2 * D1.y - s1 * D2.y));
+    v[0] = cadd(a, cadd(S1, S2));
+    v[1] = cadd(p1, q1);
+    v[4] = csub(p1, q1);
+    v[2] = cadd(p2, q2);
+    v[3] = csub(p2, q2);
+  }
+}
+
+// One Stockham stage.  tw[j] = exp(-2*pi*i*j / n_fft), j in [0, n_fft).
+template <int R, int SIGN>
+__device__ __forceinline__ void stockham_stage(const float2 *__restrict__ in, float2 *__restrict__ out, int nh,
+                                               int ns, const float2 *__restrict__ tw) {
+  const int nb = nh / R;
+  const int tstep = (nh / (ns * R)) * 2;
+  for (int j = threadIdx.x; j < nb; j += blockDim.x) {
+    const int q = j / ns;
+    const int k = j - q * ns;
+    float2 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = in[j + r * nb];
+    const int base = k * tstep;
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+      float2 w = tw[base * r];
+      if (SIGN > 0) w.y = -w.y;
+      v[r] = cmul(v[r], w);
+    }
+    butterfly<R, SIGN>(v);
+    const int j0 = q * ns * R + k;
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[j0 + r * ns] = v[r];
+  }
+}
+
+// Full complex FFT of nh points held in LDS buffer `a` (scratch `b`).
+// Returns the buffer that holds the result.  All threads of the block call it.
+template <int SIGN>
+__device__ float2 *fft_lds(float2 *a, float2 *b, const FftPlan &p, const float2 *__restrict__ tw) {
+  int ns = 1;
+  for (int s = 0; s < p.n_stage; ++s) {
+    const int R = p.radix[s];
+    __syncthreads();
+    switch (R) {
+      case 4: stockham_stage<4, SIGN>(a, b, p.nh, ns, tw); break;
+      case 2: stockham_stage<2, SIGN>(a, b, p.nh, ns, tw); break;
+      case 3: stockham_stage<3, SIGN>(a, b, p.nh, ns, tw); break;
+      default: stockham_stage<5, SIGN>(a, b, p.nh, ns, tw); break;
+    }
+    ns *= R;
+    float2 *t = a;
+    a = b;
+    b = t;
+  }
+  __syncthreads();
+  return a;
+}
+
+// ---------------------------------------------------------------------------
+// K1: STFT.  grid = (T, 2, B).  One workgroup per (frame, channel, chunk).
+//
+// The chunk waveform is either an explicit [B,2,C] buffer (song_len < 0) or a
+// window into the resident song mix [2,N] (mdx_separator.py:329-366): chunk b
+// starts at padded position chunk_start[b]; padded position j maps to
+// mix[j - trim] for trim <= j < trim + N and to 0 elsewhere (left `trim`
+// zeros, right padding, tail zero-fill of the last chunk).
+// torch.stft(center=True) reflect-pads each chunk by n_fft/2 (stft.py:41).
+//
+// Output layout: tf_layout=1 -> [B,4,T,F] (engine-internal, coalesced);
+//                tf_layout=0 -> [B,4,F,T] (reference layout, stft.py:44-56).
+// zero_low: bins [0, zero_low) are written as 0 (mdx_separator.py:425).
+// ---------------------------------------------------------------------------
+struct StftArgs {
+  const float *wave;          // [B,2,C] or song mix [2,N]
+  const int64_t *chunk_start; // [B] padded-domain start of each chunk (song mode) or nullptr
+  int64_t n_song;             // N (song mode) or -1
+  int trim;                   // n_fft/2 (song mode)
+  int64_t C;                  // samples per chunk
+  int hop;
+  int T;
+  int dim_f;
+  int zero_low;
+  int tf_layout;
+  float *spec;
+  const float *window;        // [n_fft] periodic Hann
+  const float2 *tw;           // [n_fft]
+  float sign;                 // +1, or -1 to emit the negated spectrum (denoise pass)
+};
+
+__global__ __launch_bounds__(256) void stft_kernel(StftArgs a, FftPlan p) {
+  extern __shared__ float2 lds[];
+  float2 *bufA = lds;
+  float2 *bufB = lds + p.nh;
+  const int t = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
+  const int half = p.nh;  // n_fft / 2
+  const int64_t C = a.C;
+  const float *src;
+  int64_t cstart = 0;
+  if (a.n_song >= 0) {
+    src = a.wave + (int64_t)ch * a.n_song;
+    cstart = a.chunk_start[b];
+  } else {
+    src = a.wave + ((int64_t)b * 2 + ch) * C;
+  }
+  // load + window; LDS float pairs (x[2m], x[2m+1]) are the packed complex input
+  float *fa = reinterpret_cast<float *>(bufA);
+  for (int e = threadIdx.x; e < p.n_fft; e += blockDim.x) {
+    int64_t q = (int64_t)t * a.hop + e - half;
+    if (q < 0) q = -q;
+    if (q >= C) q = 2 * (C - 1) - q;
+    float v;
+    if (a.n_song >= 0) {
+      const int64_t j = cstart + q - a.trim;  // index into the un-padded mix
+      v = (j >= 0 && j < a.n_song) ? src[j] : 0.0f;
+    } else {
+      v = src[q];
+    }
+    fa[e] = v * a.window[e];
+  }
+  float2 *Z = fft_lds<-1>(bufA, bufB, p, a.tw);
+  // split: X[k] = E + e^{-2 pi i k / n} * O,  E = (Z[k] + conj Z[Nh-k]) / 2,  O = -i (Z[k] - conj Z[Nh-k]) / 2
+  const int nh = p.nh;
+  for (int k = threadIdx.x; k < a.dim_f; k += blockDim.x) {
+    float re = 0.f, im = 0.f;
+    if (k >= a.zero_low) {
+      const float2 zk = Z[k == nh ? 0 : k];
+      float2 zc = Z[(k == 0 || k == nh) ? 0 : nh - k];
+      zc.y = -zc.y;
+      const float2 E = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+      const float2 D = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
+      const float2 O = make_float2(D.y, -D.x);
+      float2 w = (k == nh) ? make_float2(-1.f, 0.f) : a.tw[k];
+      const float2 X = cadd(E, cmul(w, O));
+      re = X.x * a.sign;
+      im = X.y * a.sign;
+    }
+    if (a.tf_layout) {
+      const int64_t base = (((int64_t)b * 4 + ch * 2) * a.T + t) * a.dim_f + k;
+      a.spec[base] = re;
+      a.spec[base + (int64_t)a.T * a.dim_f] = im;
+    } else {
+      const int64_t base = (((int64_t)b * 4 + ch * 2) * a.dim_f + k) * a.T + t;
+      a.spec[base] = re;
+      a.spec[base + (int64_t)a.dim_f * a.T] = im;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2: inverse FFT of every frame -> windowed frames [B,2,T,n_fft].
+// grid = (T, 2, B).  Bins >= dim_f are zero (stft.py:58-68); the imaginary
+// parts of DC and Nyquist are ignored (c2r semantics of torch.istft).
+// combine != 0: spectrum = 0.5 * spec[b] - 0.5 * spec[b + B]   (denoise,
+// mdx_separator.py:435-440; pass the positive batch first).
+// ---------------------------------------------------------------------------
+struct IstftArgs {
+  const float *spec;  // [B(,x2),4,T,F] (tf_layout=1) or [B,4,F,T]
+  int T;
+  int dim_f;
+  int tf_layout;
+  int combine;        // 0 or B (offset, in chunks, of the negated-input batch)
+  float *frames;      // [B,2,T,n_fft]
+  const float *window;
+  const float2 *tw;
+};
+
+__device__ __forceinline__ float2 load_bin(const IstftArgs &a, int b, int ch, int t, int k) {
+  if (k >= a.dim_f) return make_float2(0.f, 0.f);
+  float re, im;
+  if (a.tf_layout) {
+    const int64_t base = (((int64_t)b * 4 + ch * 2) * a.T + t) * a.dim_f + k;
+    re = a.spec[base];
+    im = a.spec[base + (int64_t)a.T * a.dim_f];
+  } else {
+    const int64_t base = (((int64_t)b * 4 + ch * 2) * a.dim_f + k) * a.T + t;
+    re = a.spec[base];
+    im = a.spec[base + (int64_t)a.dim_f * a.T];
+  }
+  return make_float2(re, im);
+}
+
+__global__ __launch_bounds__(256) void istft_kernel(IstftArgs a, FftPlan p) {
+  extern __shared__ float2 lds[];
+  float2 *bufA = lds;
+  float2 *bufB = lds + p.nh;
+  float2 *bufX = lds + 2 * p.nh;  // staged spectrum X[0..nh]
+  const int t = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
+  const int nh = p.nh;
+  for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
+    float2 x = load_bin(a, b, ch, t, k);
+    if (a.combine) {
+      const float2 xn = load_bin(a, b + a.combine, ch, t, k);
+      x.x = xn.x * -0.5f + x.x * 0.5f;
+      x.y = xn.y * -0.5f + x.y * 0.5f;
+    }
+    if (k == 0 || k == nh) x.y = 0.f;
+    bufX[k] = x;
+  }
+  __syncthreads();
+  // merge: Z[k] = E + i*O, E = (X[k] + conj X[Nh-k]) / 2, O = e^{+2 pi i k / n} (X[k] - conj X[Nh-k]) / 2
+  for (int k = threadIdx.x; k < nh; k += blockDim.x) {
+    const float2 xk = bufX[k];
+    float2 xc = bufX[nh - k];
+    xc.y = -xc.y;
+    const float2 E = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
+    const float2 D = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
+    float2 w = a.tw[k];
+    w.y = -w.y;
+    const float2 O = cmul(w, D);
+    bufA[k] = make_float2(E.x - O.y, E.y + O.x);
+  }
+  float2 *z = fft_lds<+1>(bufA, bufB, p, a.tw);
+  const float scale = 1.0f / (float)nh;
+  float2 *dst = reinterpret_cast<float2 *>(a.frames + (((int64_t)b * 2 + ch) * a.T + t) * p.n_fft);
+  const float2 *w2 = reinterpret_cast<const float2 *>(a.window);
+  for (int m = threadIdx.x; m < nh; m += blockDim.x) {
+    const float2 v = z[m];
+    const float2 w = w2[m];
+    dst[m] = make_float2((v.x * scale) * w.x, (v.y * scale) * w.y);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2b: fold the windowed frames (torch.istft overlap-add, / sum w^2, strip
+// n_fft/2) and, for the chunk loop, apply the symmetric Hann chunk window of
+// mdx_separator.py:358,387 (np.hanning in float64, product rounded to f32).
+//   out[b,ch,j] = (sum_t frames[b,ch,t,j + n/2 - t*hop]) / env[j + n/2]   (* v_b[j])
+// n_act[b] < 0: no chunk window (plain STFT.inverse / overlap == 0).
+// Samples j >= |n_act[b]| of a windowed chunk are written as 0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double hanning_f64(int64_t j, int64_t M) {
+  // numpy.hanning: 0.5 + 0.5*cos(pi*n/(M-1)), n = 2j + 1 - M
+  if (M == 1) return 1.0;
+  return 0.5 + 0.5 * cos(3.14159265358979323846 * (double)(2 * j + 1 - M) / (double)(M - 1));
+}
+
+__global__ __launch_bounds__(256) void ola_kernel(const float *__restrict__ frames, const float *__restrict__ env,
+                                                  const int64_t *__restrict__ n_act, int n_fft, int hop, int T,
+                                                  int64_t C, float *__restrict__ out) {
+  const int b = blockIdx.z, ch = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= C) return;
+  const int64_t m = j + n_fft / 2;
+  int64_t t_lo = (m - n_fft + hop) / hop;  // ceil((m - n + 1) / hop) for m - n + 1 > 0
+  if (m - n_fft + 1 <= 0) t_lo = 0;
+  int64_t t_hi = m / hop;
+  if (t_hi > T - 1) t_hi = T - 1;
+  const float *fr = frames + ((int64_t)b * 2 + ch) * T * n_fft;
+  float acc = 0.f;
+  for (int64_t t = t_lo; t <= t_hi; ++t) acc += fr[t * n_fft + (m - t * hop)];
+  float y = acc / env[m];
+  if (n_act != nullptr) {
+    const int64_t na = n_act[b];
+    if (na >= 0) {
+      if (j < na)
+        y = (float)((double)y * hanning_f64(j, na));
+      else
+        y = 0.f;
+    }
+  }
+  out[((int64_t)b * 2 + ch) * C + j] = y;
+}
+
+// ---------------------------------------------------------------------------
+// K4/K5: fold every windowed chunk into the song (mdx_separator.py:386-401):
+//   result[m] = sum_k yw_k[m - k*step]   divider[m] = sum_k v_k[m - k*step]
+//   out[ch,i] = result[i + trim] / divider[i + trim]
+// Gather form: each output sample visits its covering chunks in increasing k,
+// the reference's accumulation order, so the sum is reproducible.
+// windowed == 0 (overlap == 0): divider counts chunks.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__ chunk_out, int n_chunks, int64_t C,
+                                                       int64_t step, int64_t L, int trim, int64_t N, int windowed,
+                                                       float *__restrict__ out) {
+  const int ch = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int64_t m = i + trim;
+  int64_t k_hi = m / step;
+  if (k_hi > n_chunks - 1) k_hi = n_chunks - 1;
+  int64_t k_lo = 0;
+  if (m - C >= 0) k_lo = (m - C) / step + 1;
+  float acc = 0.f, div = 0.f;
+  for (int64_t k = k_lo; k <= k_hi; ++k) {
+    const int64_t s = k * step;
+    const int64_t j = m - s;
+    int64_t na = L - s;
+    if (na > C) na = C;
+    if (j >= na) continue;
+    acc += chunk_out[(k * 2 + ch) * C + j];
+    if (windowed)
+      div = (float)((double)div + hanning_f64(j, na));
+    else
+      div += 1.0f;
+  }
+  out[(int64_t)ch * N + i] = acc / div;
+}
+
+// [B,4,F,T] <-> [B,4,T,F] (test hooks only; the path itself stays in [.,T,F]).
+__global__ void transpose_last2_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int64_t plane = (int64_t)blockIdx.z * rows * cols;
+  int c = blockIdx.x * 32 + threadIdx.x;
+  for (int rr = threadIdx.y; rr < 32; rr += blockDim.y) {
+    int r = blockIdx.y * 32 + rr;
+    if (r < rows && c < cols) tile[rr][threadIdx.x] = in[plane + (int64_t)r * cols + c];
+  }
+  __syncthreads();
+  int r2 = blockIdx.y * 32 + threadIdx.x;
+  for (int cc = threadIdx.y; cc < 32; cc += blockDim.y) {
+    int c2 = blockIdx.x * 32 + cc;
+    if (r2 < rows && c2 < cols) out[plane + (int64_t)c2 * rows + r2] = tile[threadIdx.x][cc];
+  }
+}
+
+}  // namespace asx

@@ -1,0 +1,423 @@
+// ConvTDFNet kernels for gfx950: fp32-exact MFMA (v_mfma_f32_16x16x4_f32).
+//
+// Architecture spec: uvr_lib_v5/mdxnet.py:30-120, uvr_lib_v5/modules.py:5-74 (the
+// graph the reference runs through onnxruntime, mdx_separator.py:122-123).
+// Activations are [B, C, T, F] with F fastest (the layout the reference's convs
+// see after x.transpose(-1,-2), mdxnet.py:101).  BatchNorm is folded into the
+// weights by the host; ReLU, the residual add of TFC_TDF (modules.py:74) and the
+// skip multiply of the decoder (mdxnet.py:113) are fused into epilogues.
+//
+// Two kernel families:
+//   conv_mfma : K runs over channels (planes), M over 16 consecutive F positions.
+//               3x3/pad1 (TFC), 2x2/stride2 (ds), 1x1 (first/final) and the 2x2
+//               stride-2 transposed conv (us) as a 1x1 conv onto 4*Cout virtual
+//               channels with a pixel-shuffle epilogue.
+//   tdf_mfma  : K runs along F (contiguous), i.e. a row GEMM x[M,K] @ W[N,K]^T.
+//
+// MFMA 16x16x4 f32 operand maps (lane l, li = l & 15, lk = l >> 4):
+//   A[i=li][k=lk], B[k=lk][j=li], D[i=4*lk+r][j=li] for r in 0..3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ASX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// XCD-aware bijective remap of a 1-D grid: consecutive logical ids run on one XCD
+// (dispatcher places block b on XCD b % 8), so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+enum { EPI_BIAS_ACT = 0, EPI_UP_MULSKIP = 1 };
+
+template <int KH_, int KW_, int S_, int PAD_, int NREP_, int KC_, int RPW_, int EPI_>
+struct ConvCfg {
+  static constexpr int KH = KH_, KW = KW_, S = S_, PAD = PAD_, NREP = NREP_, KC = KC_, RPW = RPW_, EPI = EPI_;
+  static constexpr int TH = 4 * RPW, TW = 64;
+  static constexpr int IH = (TH - 1) * S + KH, IW = (TW - 1) * S + KW;
+  static constexpr int PS0 = IH * IW;
+  // plane stride: two planes read by one 32-lane group must hit disjoint banks
+  static constexpr int PS = (S == 1) ? (PS0 + ((16 - PS0 % 32) + 32) % 32) : (PS0 | 1);
+  static constexpr int NW = 16 * NREP;
+  static constexpr int NWP = (NREP % 2 == 0) ? NW + 16 : NW;  // row stride == 16 (mod 32) words
+  static constexpr int NTAP = KH * KW;
+  static constexpr int IN_ELEMS = KC * PS;
+  static constexpr int W_ROWS = NTAP * KC;
+  static constexpr int W_ELEMS = W_ROWS * NWP;
+  static constexpr int LDS_BYTES = (IN_ELEMS + W_ELEMS) * 4;
+  static constexpr int MREP = RPW * 4;
+  static constexpr int NIN = (KC * PS0 + 255) / 256;           // input elements per thread per stage
+  static constexpr int NWV = (W_ROWS * NW / 4 + 255) / 256;    // weight float4 per thread per stage
+};
+
+struct ConvArgs {
+  const float *x;     // [B, Cin, T, F]
+  const float *wp;    // packed [CG][NCI][NTAP][KC][NW]
+  const float *bias;  // padded per (virtual) output channel
+  const float *skip;  // EPI_UP_MULSKIP: [B, Cout, 2T, 2F]
+  float *y;
+  int B, Cin, Cout, T, F;    // input geometry; Cout = real output channels
+  int To, Fo;                // output spatial size handled by tiles (= T,F; T/2,F/2 for stride 2)
+  int tilesT, tilesF, CG, NCI;
+  int relu;
+};
+
+template <class CFG>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+  extern __shared__ float lds_f[];
+  float *in_s = lds_f;
+  float *w_s = lds_f + CFG::IN_ELEMS;
+  constexpr int KH = CFG::KH, KW = CFG::KW, S = CFG::S, PAD = CFG::PAD, NREP = CFG::NREP, KC = CFG::KC;
+  constexpr int RPW = CFG::RPW, MREP = CFG::MREP, IW = CFG::IW, IH = CFG::IH, PS = CFG::PS, PS0 = CFG::PS0;
+  constexpr int NW = CFG::NW, NWP = CFG::NWP, NIN = CFG::NIN, NWV = CFG::NWV, TH = CFG::TH, TW = CFG::TW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+
+  const int nblk = gridDim.x;
+  int lid = xcd_remap(blockIdx.x, nblk);
+  const int cg = lid % a.CG;
+  lid /= a.CG;
+  const int tf = lid % a.tilesF;
+  lid /= a.tilesF;
+  const int tt = lid % a.tilesT;
+  const int b = lid / a.tilesT;
+  const int to0 = tt * TH, fo0 = tf * TW;          // output tile origin
+  const int ti0 = to0 * S - PAD, fi0 = fo0 * S - PAD;  // input tile origin
+
+  const float *xb = a.x + (int64_t)b * a.Cin * a.T * a.F;
+  const float *wg = a.wp + (int64_t)cg * a.NCI * (CFG::W_ROWS * NW);
+
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int m = 0; m < MREP; ++m)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float rin[NIN];
+  float4 rw[NWV];
+
+  auto fetch = [&](int ci) {
+#pragma unroll
+    for (int it = 0; it < NIN; ++it) {
+      const int e = tid + it * 256;
+      float v = 0.f;
+      if (e < KC * PS0) {
+        const int pl = e / PS0;
+        const int rem = e - pl * PS0;
+        const int row = rem / IW;
+        const int col = rem - row * IW;
+        const int c = ci * KC + pl;
+        const int t = ti0 + row, f = fi0 + col;
+        if (c < a.Cin && t >= 0 && t < a.T && f >= 0 && f < a.F) v = xb[((int64_t)c * a.T + t) * a.F + f];
+      }
+      rin[it] = v;
+    }
+    const float4 *w4 = reinterpret_cast<const float4 *>(wg + (int64_t)ci * (CFG::W_ROWS * NW));
+#pragma unroll
+    for (int it = 0; it < NWV; ++it) {
+      const int e = tid + it * 256;
+      rw[it] = (e < CFG::W_ROWS * NW / 4) ? w4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NIN; ++it) {
+      const int e = tid + it * 256;
+      if (e < KC * PS0) {
+        const int pl = e / PS0;
+        const int rem = e - pl * PS0;
+        in_s[pl * PS + rem] = rin[it];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NWV; ++it) {
+      const int e = tid + it * 256;
+      if (e < CFG::W_ROWS * NW / 4) {
+        const int row = (e * 4) / NW;
+        const int col = (e * 4) - row * NW;
+        *reinterpret_cast<float4 *>(&w_s[row * NWP + col]) = rw[it];
+      }
+    }
+  };
+
+  fetch(0);
+  for (int ci = 0; ci < a.NCI; ++ci) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (ci + 1 < a.NCI) fetch(ci + 1);
+#pragma unroll
+    for (int tap = 0; tap < KH * KW; ++tap) {
+      const int dy = tap / KW, dx = tap % KW;
+#pragma unroll
+      for (int kq = 0; kq < KC / 4; ++kq) {
+        float bf[NREP];
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) bf[n] = w_s[(tap * KC + kq * 4 + lk) * NWP + n * 16 + li];
+        float af[MREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int rr = m >> 2, cc = m & 3;
+          af[m] = in_s[(kq * 4 + lk) * PS + ((wave * RPW + rr) * S + dy) * IW + (cc * 16 + li) * S + dx];
+        }
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) acc[m][n] = ASX_MFMA(af[m], bf[n], acc[m][n]);
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  if constexpr (CFG::EPI == EPI_BIAS_ACT) {
+    const bool vec = (a.Fo & 3) == 0;
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      const int co = cg * NW + n * 16 + li;
+      const float bv = a.bias[co];
+      if (co >= a.Cout) continue;
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) {
+        const int rr = m >> 2, cc = m & 3;
+        const int t = to0 + wave * RPW + rr;
+        const int f = fo0 + cc * 16 + lk * 4;
+        if (t >= a.To || f >= a.Fo) continue;
+        f32x4 v = acc[m][n];
+        v += bv;
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        float *dst = a.y + (((int64_t)b * a.Cout + co) * a.To + t) * a.Fo + f;
+        if (vec && f + 3 < a.Fo) {
+          *reinterpret_cast<f32x4 *>(dst) = v;
+        } else {
+          dst[0] = v.x;
+          if (f + 1 < a.Fo) dst[1] = v.y;
+          if (f + 2 < a.Fo) dst[2] = v.z;
+          if (f + 3 < a.Fo) dst[3] = v.w;
+        }
+      }
+    }
+  } else {
+    // virtual n-tile nt = cg*NREP + n;  pair = nt/2 -> (dy = pair / CT, ct = pair % CT), dx = nt & 1
+    const int CT = (a.Cout + 15) / 16;
+    const int To2 = a.T * 2, Fo2 = a.F * 2;
+#pragma unroll
+    for (int np = 0; np < NREP / 2; ++np) {
+      const int pair = (cg * NREP) / 2 + np;
+      const int dy = pair / CT, ct = pair - dy * CT;
+      if (dy >= 2) continue;
+      const int co = ct * 16 + li;
+      if (co >= a.Cout) continue;
+      const float bv = a.bias[co];
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) {
+        const int rr = m >> 2, cc = m & 3;
+        const int t = to0 + wave * RPW + rr;
+        const int f = fo0 + cc * 16 + lk * 4;
+        if (t >= a.T || f >= a.F) continue;
+        const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
+        float o[8] = {v0.x, v1.x, v0.y, v1.y, v0.z, v1.z, v0.w, v1.w};
+        const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
+        const float *sk = a.skip + off;
+        float *dst = a.y + off;
+        if (f + 3 < a.F) {
+          const f32x4 s0 = *reinterpret_cast<const f32x4 *>(sk);
+          const f32x4 s1 = *reinterpret_cast<const f32x4 *>(sk + 4);
+          f32x4 r0, r1;
+          r0.x = fmaxf(o[0] + bv, 0.f) * s0.x;
+          r0.y = fmaxf(o[1] + bv, 0.f) * s0.y;
+          r0.z = fmaxf(o[2] + bv, 0.f) * s0.z;
+          r0.w = fmaxf(o[3] + bv, 0.f) * s0.w;
+          r1.x = fmaxf(o[4] + bv, 0.f) * s1.x;
+          r1.y = fmaxf(o[5] + bv, 0.f) * s1.y;
+          r1.z = fmaxf(o[6] + bv, 0.f) * s1.z;
+          r1.w = fmaxf(o[7] + bv, 0.f) * s1.w;
+          *reinterpret_cast<f32x4 *>(dst) = r0;
+          *reinterpret_cast<f32x4 *>(dst + 4) = r1;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (f + (q >> 1) < a.F) dst[q] = fmaxf(o[q] + bv, 0.f) * sk[q];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// TDF row GEMM:  y[m, n] = relu(scale[c(m)] * (sum_k x[m,k] w[n,k] + bias[n]) + shift[c(m)]) (+ res[m,n])
+// rows m = ((b*C + c)*T + t), so c(m) = (m / T) % C.     (modules.py:57-74)
+// Block tile: BM = 16*MREP rows x BN = 64*NREP cols, 4 waves side by side along N.
+// The weight tile is the MFMA A operand (i -> n), the activation tile the B
+// operand (j -> m), so every lane ends up with 4 consecutive n of one row m.
+// Fragments are fetched with ds_read_b128 (4 consecutive k per lane); the k
+// order inside a 16-wide step is permuted identically for both operands.
+// ---------------------------------------------------------------------------
+struct TdfArgs {
+  const float *x;      // [M, K]
+  const float *w;      // [N, K]
+  const float *bias;   // [N] or nullptr
+  const float *scale;  // [C]
+  const float *shift;  // [C]
+  const float *res;    // [M, N] or nullptr
+  float *y;            // [M, N]
+  int64_t M;
+  int N, K, C, T;
+};
+
+template <int NREP, int MREP>
+struct TdfCfg {
+  static constexpr int BK = 32, RSW = BK + 8;
+  static constexpr int BM = 16 * MREP, BN = 64 * NREP;
+  static constexpr int LDS_BYTES = (BM + BN) * RSW * 4;
+  static constexpr int NXV = (BM * BK / 4 + 255) / 256;
+  static constexpr int NWV = (BN * BK / 4 + 255) / 256;
+};
+
+template <int NREP, int MREP>
+__global__ __launch_bounds__(256) void tdf_mfma_kernel(TdfArgs a) {
+  using CFG = TdfCfg<NREP, MREP>;
+  constexpr int BK = CFG::BK, RSW = CFG::RSW, BM = CFG::BM, BN = CFG::BN, NXV = CFG::NXV, NWV = CFG::NWV;
+  extern __shared__ float lds_f[];
+  float *xs = lds_f;             // [BM][RSW]
+  float *ws = lds_f + BM * RSW;  // [BN][RSW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+
+  const int nbn = (a.N + BN - 1) / BN;
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bn = lid % nbn;
+  const int64_t bm = lid / nbn;
+  const int64_t m0 = bm * BM;
+  const int n0 = bn * BN;
+  const bool kvec = (a.K & 3) == 0;
+
+  f32x4 acc[NREP][MREP];
+#pragma unroll
+  for (int n = 0; n < NREP; ++n)
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 rx[NXV], rw[NWV];
+
+  auto load4 = [&](const float *base, int64_t row, int64_t nrows, int k) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows) {
+      const float *p = base + row * a.K + k;
+      if (kvec && k + 3 < a.K) {
+        v = *reinterpret_cast<const float4 *>(p);
+      } else {
+        if (k < a.K) v.x = p[0];
+        if (k + 1 < a.K) v.y = p[1];
+        if (k + 2 < a.K) v.z = p[2];
+        if (k + 3 < a.K) v.w = p[3];
+      }
+    }
+    return v;
+  };
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) {
+      const int e = tid + it * 256;
+      const int row = e / (BK / 4), c4 = e % (BK / 4);
+      rx[it] = (e < BM * BK / 4) ? load4(a.x, m0 + row, a.M, k0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < NWV; ++it) {
+      const int e = tid + it * 256;
+      const int row = e / (BK / 4), c4 = e % (BK / 4);
+      rw[it] = (e < BN * BK / 4) ? load4(a.w, n0 + row, a.N, k0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) {
+      const int e = tid + it * 256;
+      if (e < BM * BK / 4) {
+        const int row = e / (BK / 4), c4 = e % (BK / 4);
+        *reinterpret_cast<float4 *>(&xs[row * RSW + c4 * 4]) = rx[it];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NWV; ++it) {
+      const int e = tid + it * 256;
+      if (e < BN * BK / 4) {
+        const int row = e / (BK / 4), c4 = e % (BK / 4);
+        *reinterpret_cast<float4 *>(&ws[row * RSW + c4 * 4]) = rw[it];
+      }
+    }
+  };
+
+  const int nk = (a.K + BK - 1) / BK;
+  fetch(0);
+  for (int ks = 0; ks < nk; ++ks) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (ks + 1 < nk) fetch((ks + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      f32x4 wa[NREP], xb[MREP];
+#pragma unroll
+      for (int n = 0; n < NREP; ++n)
+        wa[n] = *reinterpret_cast<const f32x4 *>(&ws[(wave * 16 * NREP + n * 16 + li) * RSW + kk * 16 + lk * 4]);
+#pragma unroll
+      for (int m = 0; m < MREP; ++m)
+        xb[m] = *reinterpret_cast<const f32x4 *>(&xs[(m * 16 + li) * RSW + kk * 16 + lk * 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+          for (int m = 0; m < MREP; ++m) acc[n][m] = ASX_MFMA(wa[n][j], xb[m][j], acc[n][m]);
+    }
+  }
+
+  const bool nvec = (a.N & 3) == 0;
+#pragma unroll
+  for (int m = 0; m < MREP; ++m) {
+    const int64_t row = m0 + m * 16 + li;
+    if (row >= a.M) continue;
+    const int c = (int)((row / a.T) % a.C);
+    const float sc = a.scale[c], sh = a.shift[c];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+      if (col >= a.N) continue;
+      f32x4 v = acc[n][m];
+      float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float bz = (a.bias != nullptr && col + r < a.N) ? a.bias[col + r] : 0.f;
+        o[r] = fmaxf(sc * (o[r] + bz) + sh, 0.f);
+      }
+      float *dst = a.y + row * a.N + col;
+      if (nvec && col + 3 < a.N) {
+        f32x4 out = {o[0], o[1], o[2], o[3]};
+        if (a.res != nullptr) out += *reinterpret_cast<const f32x4 *>(a.res + row * a.N + col);
+        *reinterpret_cast<f32x4 *>(dst) = out;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < a.N) dst[r] = o[r] + (a.res != nullptr ? a.res[row * a.N + col + r] : 0.f);
+      }
+    }
+  }
+}
+
+}  // namespace asx

@@ -1,0 +1,292 @@
+"""ctypes binding of libasx.so (C ABI: include/asx.h).
+
+This is the only bridge between host Python and the HIP engine.  There is no CPU
+fallback: if the shared library is missing or no GPU is visible, construction
+raises.  PyTorch is not needed here; device pointers are plain integers (e.g.
+``tensor.data_ptr()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+ASX_FLAG_MATCH_MIX = 1
+PROF_CLASSES = ["stft", "conv3x3", "tdf", "down", "up", "conv1x1", "istft", "ola", "finalize", "misc"]
+
+
+class AsxError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libasx.so")
+
+
+class _MdxCfg(C.Structure):
+    _fields_ = [("n_fft", C.c_int32), ("hop_length", C.c_int32), ("dim_f", C.c_int32), ("segment_size", C.c_int32),
+                ("overlap", C.c_float), ("enable_denoise", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class _NetCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim_c", "dim_f", "dim_t", "g", "l", "num_blocks", "k", "bn", "tdf_bias")]
+
+
+class _Plan(C.Structure):
+    _fields_ = [("n_samples", C.c_int64), ("padded_len", C.c_int64), ("chunk_size", C.c_int64),
+                ("gen_size", C.c_int64), ("pad", C.c_int64), ("step", C.c_int64), ("trim", C.c_int32),
+                ("n_chunks", C.c_int32), ("n_frames", C.c_int32), ("reserved", C.c_int32)]
+
+
+class _Profile(C.Structure):
+    _fields_ = [("launches", C.c_int64 * 10), ("ms", C.c_double * 10), ("flops", C.c_double * 10),
+                ("bytes", C.c_double * 10)]
+
+
+@dataclass
+class MDXConfig:
+    """Scalars of MDXSeparator that shape the path (mdx_separator.py:31-72)."""
+    n_fft: int = 6144
+    hop_length: int = 1024
+    dim_f: int = 3072
+    segment_size: int = 256
+    overlap: float = 0.25
+    enable_denoise: bool = False
+    max_batch: int = 0
+
+
+@dataclass
+class NetConfig:
+    """ConvTDFNet hyper-parameters (uvr_lib_v5/mdxnet.py:31-44)."""
+    dim_c: int = 4
+    dim_f: int = 3072
+    dim_t: int = 256
+    g: int = 48
+    l: int = 3
+    num_blocks: int = 11
+    k: int = 3
+    bn: int = 8
+    tdf_bias: bool = False
+
+
+_FP = C.POINTER(C.c_float)
+_lib = None
+
+# every symbol include/asx.h declares
+SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_create", "asx_engine_destroy",
+           "asx_net_begin", "asx_net_set_tensor", "asx_net_commit", "asx_net_flops", "asx_plan_query", "asx_demix",
+           "asx_demix_dev", "asx_demix_chunks_dev", "asx_finalize_dev", "asx_stft", "asx_istft", "asx_net_forward",
+           "asx_run_model", "asx_op_conv", "asx_op_tdf", "asx_profile_enable", "asx_profile_read"]
+
+
+def load_library():
+    """dlopen libasx.so and declare the signatures.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    try:
+        # torch-ROCm bundles its own libamdhip64 (same soname).  Importing it first makes the
+        # dynamic loader resolve libasx.so against that one runtime, so device pointers taken
+        # from torch tensors and the engine's own allocations live in the same HIP context.
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing, not a requirement of the engine
+        pass
+    if not os.path.exists(path):
+        raise AsxError(f"{path} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+                       "There is no CPU fallback for the demix path.")
+    lib = C.CDLL(path)
+    vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+    lib.asx_abi_version.restype = C.c_int
+    lib.asx_last_error.restype = C.c_char_p
+    lib.asx_device_count.restype = C.c_int
+    lib.asx_engine_create.argtypes = [C.c_int, C.POINTER(_MdxCfg), C.POINTER(vp)]
+    lib.asx_engine_destroy.argtypes = [vp]
+    lib.asx_engine_destroy.restype = None
+    lib.asx_net_begin.argtypes = [vp, C.POINTER(_NetCfg)]
+    lib.asx_net_set_tensor.argtypes = [vp, C.c_char_p, _FP, i64]
+    lib.asx_net_commit.argtypes = [vp]
+    lib.asx_net_flops.argtypes = [vp, i32]
+    lib.asx_net_flops.restype = C.c_double
+    lib.asx_plan_query.argtypes = [vp, i64, u32, C.POINTER(_Plan)]
+    lib.asx_demix.argtypes = [vp, _FP, i64, _FP, u32]
+    lib.asx_demix_dev.argtypes = [vp, vp, i64, vp, u32, vp]
+    lib.asx_demix_chunks_dev.argtypes = [vp, vp, i64, i32, i32, vp, u32, vp]
+    lib.asx_finalize_dev.argtypes = [vp, vp, i64, vp, u32, vp]
+    lib.asx_stft.argtypes = [vp, _FP, i32, i64, _FP]
+    lib.asx_istft.argtypes = [vp, _FP, i32, i32, _FP]
+    lib.asx_net_forward.argtypes = [vp, _FP, i32, _FP]
+    lib.asx_run_model.argtypes = [vp, _FP, i32, _FP, u32]
+    lib.asx_op_conv.argtypes = [vp, C.c_char_p, _FP, i32, i32, i32, i32, _FP, _FP, i32, _FP, i32, _FP]
+    lib.asx_op_tdf.argtypes = [vp, _FP, i32, i32, i32, i32, _FP, _FP, i32, _FP, _FP, _FP, _FP]
+    lib.asx_profile_enable.argtypes = [vp, i32]
+    lib.asx_profile_read.argtypes = [vp, C.POINTER(_Profile)]
+    for name in SYMBOLS:
+        getattr(lib, name)  # AttributeError if the library does not export what the header declares
+    _lib = lib
+    return lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(_FP)
+
+
+def _optptr(a):
+    return _ptr(a) if a is not None else None
+
+
+class Engine:
+    """One HIP engine bound to one GPU (asx_engine)."""
+
+    def __init__(self, cfg: MDXConfig, device: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.cfg = cfg
+        self.device = device
+        self.net_cfg = None
+        if self._lib.asx_device_count() <= 0:
+            raise AsxError("no HIP device visible: the demix path runs on MI355X only (no CPU fallback)")
+        c = _MdxCfg(cfg.n_fft, cfg.hop_length, cfg.dim_f, cfg.segment_size, float(cfg.overlap),
+                    int(bool(cfg.enable_denoise)), int(cfg.max_batch))
+        self._check(self._lib.asx_engine_create(device, C.byref(c), C.byref(self._h)))
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._lib.asx_last_error()
+            raise AsxError(f"asx error {rc}: {msg.decode() if msg else '?'}")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.asx_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights ------------------------------------------------------------
+    def load_net(self, net_cfg: NetConfig, tensors: dict):
+        """tensors: canonical name -> float32 array (see include/asx.h)."""
+        n = _NetCfg(net_cfg.dim_c, net_cfg.dim_f, net_cfg.dim_t, net_cfg.g, net_cfg.l, net_cfg.num_blocks, net_cfg.k,
+                    net_cfg.bn, int(bool(net_cfg.tdf_bias)))
+        self._check(self._lib.asx_net_begin(self._h, C.byref(n)))
+        for name, arr in tensors.items():
+            a = _f32(arr).reshape(-1)
+            self._check(self._lib.asx_net_set_tensor(self._h, name.encode(), _ptr(a), a.size))
+        self._check(self._lib.asx_net_commit(self._h))
+        self.net_cfg = net_cfg
+
+    def net_flops(self, batch: int = 1) -> float:
+        return float(self._lib.asx_net_flops(self._h, batch))
+
+    # -- plan ---------------------------------------------------------------
+    def plan(self, n_samples: int, is_match_mix: bool = False) -> dict:
+        p = _Plan()
+        self._check(self._lib.asx_plan_query(self._h, n_samples, ASX_FLAG_MATCH_MIX if is_match_mix else 0,
+                                             C.byref(p)))
+        return {k: getattr(p, k) for k, _ in _Plan._fields_ if k != "reserved"}
+
+    # -- the path -----------------------------------------------------------
+    def demix(self, mix: np.ndarray, is_match_mix: bool = False) -> np.ndarray:
+        mix = _f32(mix)
+        if mix.ndim != 2 or mix.shape[0] != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got shape {mix.shape}")
+        out = np.empty_like(mix)
+        self._check(self._lib.asx_demix(self._h, _ptr(mix), mix.shape[1], _ptr(out),
+                                        ASX_FLAG_MATCH_MIX if is_match_mix else 0))
+        return out
+
+    def demix_dev(self, mix_ptr: int, n_samples: int, out_ptr: int, is_match_mix: bool = False, stream: int = 0):
+        self._check(self._lib.asx_demix_dev(self._h, mix_ptr, n_samples, out_ptr,
+                                            ASX_FLAG_MATCH_MIX if is_match_mix else 0, stream or None))
+
+    def demix_chunks_dev(self, mix_ptr: int, n_samples: int, k0: int, k1: int, chunk_out_ptr: int,
+                         is_match_mix: bool = False, stream: int = 0):
+        self._check(self._lib.asx_demix_chunks_dev(self._h, mix_ptr, n_samples, k0, k1, chunk_out_ptr,
+                                                   ASX_FLAG_MATCH_MIX if is_match_mix else 0, stream or None))
+
+    def finalize_dev(self, chunk_out_ptr: int, n_samples: int, out_ptr: int, is_match_mix: bool = False,
+                     stream: int = 0):
+        self._check(self._lib.asx_finalize_dev(self._h, chunk_out_ptr, n_samples, out_ptr,
+                                               ASX_FLAG_MATCH_MIX if is_match_mix else 0, stream or None))
+
+    # -- stage hooks ----------------------------------------------------------
+    def stft(self, wave: np.ndarray) -> np.ndarray:
+        wave = _f32(wave)
+        B, ch, Cn = wave.shape
+        assert ch == 2
+        T = Cn // self.cfg.hop_length + 1
+        out = np.empty((B, 4, self.cfg.dim_f, T), np.float32)
+        self._check(self._lib.asx_stft(self._h, _ptr(wave), B, Cn, _ptr(out)))
+        return out
+
+    def istft(self, spec: np.ndarray) -> np.ndarray:
+        spec = _f32(spec)
+        B, c4, Fq, T = spec.shape
+        assert c4 == 4 and Fq == self.cfg.dim_f
+        out = np.empty((B, 2, self.cfg.hop_length * (T - 1)), np.float32)
+        self._check(self._lib.asx_istft(self._h, _ptr(spec), B, T, _ptr(out)))
+        return out
+
+    def net_forward(self, spec: np.ndarray) -> np.ndarray:
+        spec = _f32(spec)
+        out = np.empty_like(spec)
+        self._check(self._lib.asx_net_forward(self._h, _ptr(spec), spec.shape[0], _ptr(out)))
+        return out
+
+    def run_model(self, wave: np.ndarray, is_match_mix: bool = False) -> np.ndarray:
+        wave = _f32(wave)
+        out = np.empty_like(wave)
+        self._check(self._lib.asx_run_model(self._h, _ptr(wave), wave.shape[0], _ptr(out),
+                                            ASX_FLAG_MATCH_MIX if is_match_mix else 0))
+        return out
+
+    def op_conv(self, op: str, x, w, b, aux=None, relu=True) -> np.ndarray:
+        x, w, b = _f32(x), _f32(w), _f32(b)
+        B, cin, t, f = x.shape
+        if op == "up":
+            cout = w.shape[1]
+            shape = (B, cout, 2 * t, 2 * f)
+        elif op == "down":
+            cout = w.shape[0]
+            shape = (B, cout, t // 2, f // 2)
+        else:
+            cout = w.shape[0]
+            shape = (B, cout, t, f)
+        aux = _f32(aux) if aux is not None else None
+        y = np.empty(shape, np.float32)
+        self._check(self._lib.asx_op_conv(self._h, op.encode(), _ptr(x), B, cin, t, f, _ptr(w), _ptr(b), cout,
+                                          _optptr(aux), int(relu), _ptr(y)))
+        return y
+
+    def op_tdf(self, x, w, bias, scale, shift, res=None) -> np.ndarray:
+        x, w, scale, shift = _f32(x), _f32(w), _f32(scale), _f32(shift)
+        B, c, t, k = x.shape
+        n = w.shape[0]
+        bias = _f32(bias) if bias is not None else None
+        res = _f32(res) if res is not None else None
+        y = np.empty((B, c, t, n), np.float32)
+        self._check(self._lib.asx_op_tdf(self._h, _ptr(x), B, c, t, k, _ptr(w), _optptr(bias), n, _ptr(scale),
+                                         _ptr(shift), _optptr(res), _ptr(y)))
+        return y
+
+    # -- profiling --------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(self._lib.asx_profile_enable(self._h, int(on)))
+
+    def profile_read(self) -> dict:
+        p = _Profile()
+        self._check(self._lib.asx_profile_read(self._h, C.byref(p)))
+        return {name: {"launches": int(p.launches[i]), "ms": float(p.ms[i]), "flops": float(p.flops[i]),
+                       "bytes": float(p.bytes[i])} for i, name in enumerate(PROF_CLASSES)}

@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and
+exports every symbol include/asx.h declares; the product path refuses to run
+without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from audio_separator_amd import engine as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    entry.build()
+    return E.load_library()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "asx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(asx_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"libasx.so does not export {name}"
+    assert sorted(E.SYMBOLS) == declared
+
+
+def test_abi_version(lib):
+    assert lib.asx_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    # 7 x 4 bytes, 9 x 4 bytes, 6 x 8 + 4 x 4 bytes, 10 x (8 + 8 + 8 + 8)
+    import ctypes as C
+    assert C.sizeof(E._MdxCfg) == 28
+    assert C.sizeof(E._NetCfg) == 36
+    assert C.sizeof(E._Plan) == 64
+    assert C.sizeof(E._Profile) == 320
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert lib.asx_device_count() == 0
+    with pytest.raises(E.AsxError):
+        E.Engine(E.MDXConfig())
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "python-audio-separator_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
