@@ -374,3 +374,46 @@ def synth_mix(n_samples: int, seed: int = 0, sr: int = 44100) -> np.ndarray:
         out[ch] += 0.1 * rng.standard_normal(n_samples)
     out *= 0.9 / np.abs(out).max()
     return out.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# the chunk loop split into its two halves (what one GPU rank computes, and the
+# fold rank 0 does after the gather) -- used by the CPU multi-process tests
+# --------------------------------------------------------------------------
+
+def demix_chunks(mix: np.ndarray, p: MDXParams, model_run, k0: int, k1: int, is_match_mix: bool = False):
+    """Windowed outputs of chunks k0..k1-1 (mdx_separator.py:348-387), zero beyond n_act: [k1-k0, 2, C]."""
+    mix = np.asarray(mix, dtype=np.float32)
+    N = mix.shape[-1]
+    chunk_size, gen_size, pad, L, step, starts, overlap = chunk_plan(N, p, is_match_mix)
+    mixture = np.concatenate((np.zeros((2, p.trim), np.float32), mix, np.zeros((2, pad), np.float32)), 1)
+    out = np.zeros((k1 - k0, 2, chunk_size), dtype=np.float32)
+    for i, k in enumerate(range(k0, k1)):
+        start = starts[k]
+        end = min(start + chunk_size, L)
+        n_act = end - start
+        part = np.zeros((2, chunk_size), np.float32)
+        part[:, :n_act] = mixture[:, start:end]
+        tar = run_model(part[None], p, model_run, is_match_mix)[0]
+        if overlap != 0:
+            tar[:, :n_act] *= np.hanning(n_act)[None, :]
+        out[i, :, :n_act] = tar[:, :n_act]
+    return out
+
+
+def fold_chunks(chunks: np.ndarray, N: int, p: MDXParams, is_match_mix: bool = False) -> np.ndarray:
+    """result / divider, trim, [:N] (mdx_separator.py:388-401) from all windowed chunks."""
+    chunk_size, gen_size, pad, L, step, starts, overlap = chunk_plan(N, p, is_match_mix)
+    result = np.zeros((2, L), dtype=np.float32)
+    divider = np.zeros((2, L), dtype=np.float32)
+    for k, start in enumerate(starts):
+        end = min(start + chunk_size, L)
+        n_act = end - start
+        if overlap != 0:
+            divider[:, start:end] += np.hanning(n_act)[None, :]
+        else:
+            divider[:, start:end] += 1
+        result[:, start:end] += chunks[k][:, :n_act]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tar = result / divider
+    return tar[:, p.trim:-p.trim][:, :N]

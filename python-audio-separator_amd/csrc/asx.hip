@@ -371,18 +371,24 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
   return ASX_OK;
 }
 
-template <int NREP, int MREP>
-static void launch_tdf_t(const TdfArgs &a, hipStream_t s) {
+template <int NREP, int MREP, bool KVEC>
+static void launch_tdf_tt(const TdfArgs &a, hipStream_t s) {
   using CFG = TdfCfg<NREP, MREP>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tdf_mfma_kernel<NREP, MREP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tdf_mfma_kernel<NREP, MREP, KVEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
     attr_done = true;
   }
   const int64_t nbm = (a.M + CFG::BM - 1) / CFG::BM;
   const int nbn = (a.N + CFG::BN - 1) / CFG::BN;
-  hipLaunchKernelGGL((tdf_mfma_kernel<NREP, MREP>), dim3((unsigned)(nbm * nbn)), dim3(256), CFG::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((tdf_mfma_kernel<NREP, MREP, KVEC>), dim3((unsigned)(nbm * nbn)), dim3(256), CFG::LDS_BYTES, s,
+                     a);
+}
+template <int NREP, int MREP>
+static void launch_tdf_t(const TdfArgs &a, hipStream_t s) {
+  if ((a.K & 3) == 0 && a.K >= 4) launch_tdf_tt<NREP, MREP, true>(a, s);
+  else launch_tdf_tt<NREP, MREP, false>(a, s);
 }
 
 static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const float *res, float *y, int64_t M,
@@ -404,10 +410,9 @@ static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const fl
   const double flops = 2.0 * (double)M * L.n * L.k;
   const double bytes = 4.0 * ((double)M * L.k + (double)M * L.n * (res ? 2 : 1) + (double)L.n * L.k);
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
-    if (L.n > 192) launch_tdf_t<6, 4>(a, s);
-    else if (L.n > 128) launch_tdf_t<3, 4>(a, s);
-    else if (L.n > 64) launch_tdf_t<2, 4>(a, s);
-    else launch_tdf_t<1, 4>(a, s);
+    if (L.n > 128) launch_tdf_t<3, 8>(a, s);       // 128 rows x 192 cols per workgroup
+    else if (L.n > 64) launch_tdf_t<2, 4>(a, s);   //  64 x 128
+    else launch_tdf_t<1, 4>(a, s);                 //  64 x 64
   });
 }
 

@@ -53,7 +53,8 @@ struct ConvCfg {
   static constexpr int W_ELEMS = W_ROWS * NWP;
   static constexpr int LDS_BYTES = (IN_ELEMS + W_ELEMS) * 4;
   static constexpr int MREP = RPW * 4;
-  static constexpr int NIN = (KC * PS0 + 255) / 256;           // input elements per thread per stage
+  static constexpr int NPL = (PS0 + 255) / 256;                // staged elements per thread per plane
+  static constexpr int NIN = KC * NPL;                         // input elements per thread per stage
   static constexpr int NWV = (W_ROWS * NW / 4 + 255) / 256;    // weight float4 per thread per stage
 };
 
@@ -105,43 +106,55 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   float rin[NIN];
   float4 rw[NWV];
 
+  // Each thread stages the same NPL in-plane positions of every plane, so the spatial part of
+  // the address (and its validity) is computed once; loads are unconditional (clamped address +
+  // select) so that all of a stage's loads are in flight together.
+  constexpr int NPL = CFG::NPL;
+  int sp_off[NPL];
+  bool sp_ok[NPL];
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const int r = tid + j * 256;
+    const int row = r / IW, col = r - row * IW;
+    const int t = ti0 + row, f = fi0 + col;
+    sp_ok[j] = (r < PS0) && t >= 0 && t < a.T && f >= 0 && f < a.F;
+    const int tc = min(max(t, 0), a.T - 1), fc = min(max(f, 0), a.F - 1);
+    sp_off[j] = tc * a.F + fc;
+  }
+  const int64_t plane_sz = (int64_t)a.T * a.F;
+  constexpr int WV_TOTAL = CFG::W_ROWS * NW / 4;
+
   auto fetch = [&](int ci) {
 #pragma unroll
-    for (int it = 0; it < NIN; ++it) {
-      const int e = tid + it * 256;
-      float v = 0.f;
-      if (e < KC * PS0) {
-        const int pl = e / PS0;
-        const int rem = e - pl * PS0;
-        const int row = rem / IW;
-        const int col = rem - row * IW;
-        const int c = ci * KC + pl;
-        const int t = ti0 + row, f = fi0 + col;
-        if (c < a.Cin && t >= 0 && t < a.T && f >= 0 && f < a.F) v = xb[((int64_t)c * a.T + t) * a.F + f];
+    for (int pl = 0; pl < KC; ++pl) {
+      const int c = ci * KC + pl;
+      const float *xp = xb + (int64_t)min(c, a.Cin - 1) * plane_sz;
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        rin[pl * NPL + j] = xp[sp_off[j]];  // raw; masked at commit (keeps the load unconditional)
       }
-      rin[it] = v;
     }
     const float4 *w4 = reinterpret_cast<const float4 *>(wg + (int64_t)ci * (CFG::W_ROWS * NW));
 #pragma unroll
     for (int it = 0; it < NWV; ++it) {
       const int e = tid + it * 256;
-      rw[it] = (e < CFG::W_ROWS * NW / 4) ? w4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[it] = w4[min(e, WV_TOTAL - 1)];
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int ci) {
 #pragma unroll
-    for (int it = 0; it < NIN; ++it) {
-      const int e = tid + it * 256;
-      if (e < KC * PS0) {
-        const int pl = e / PS0;
-        const int rem = e - pl * PS0;
-        in_s[pl * PS + rem] = rin[it];
+    for (int pl = 0; pl < KC; ++pl) {
+      const bool cok = ci * KC + pl < a.Cin;
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const int r = tid + j * 256;
+        if (r < PS0) in_s[pl * PS + r] = (cok && sp_ok[j]) ? rin[pl * NPL + j] : 0.f;
       }
     }
 #pragma unroll
     for (int it = 0; it < NWV; ++it) {
       const int e = tid + it * 256;
-      if (e < CFG::W_ROWS * NW / 4) {
+      if (e < WV_TOTAL) {
         const int row = (e * 4) / NW;
         const int col = (e * 4) - row * NW;
         *reinterpret_cast<float4 *>(&w_s[row * NWP + col]) = rw[it];
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   fetch(0);
   for (int ci = 0; ci < a.NCI; ++ci) {
     __syncthreads();
-    commit();
+    commit(ci);
     __syncthreads();
     if (ci + 1 < a.NCI) fetch(ci + 1);
 #pragma unroll
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 
   // ---- epilogue ----
   if constexpr (CFG::EPI == EPI_BIAS_ACT) {
-    const bool vec = (a.Fo & 3) == 0;
+    const bool full = ((a.Fo & 3) == 0) && (to0 + TH <= a.To) && (fo0 + TW <= a.Fo);
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
       const int co = cg * NW + n * 16 + li;
@@ -190,7 +203,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const int rr = m >> 2, cc = m & 3;
         const int t = to0 + wave * RPW + rr;
         const int f = fo0 + cc * 16 + lk * 4;
-        if (t >= a.To || f >= a.Fo) continue;
         f32x4 v = acc[m][n];
         v += bv;
         if (a.relu) {
@@ -200,10 +212,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
           v.w = fmaxf(v.w, 0.f);
         }
         float *dst = a.y + (((int64_t)b * a.Cout + co) * a.To + t) * a.Fo + f;
-        if (vec && f + 3 < a.Fo) {
+        if (full) {
           *reinterpret_cast<f32x4 *>(dst) = v;
-        } else {
-          dst[0] = v.x;
+        } else if (t < a.To) {
+          if (f < a.Fo) dst[0] = v.x;
           if (f + 1 < a.Fo) dst[1] = v.y;
           if (f + 2 < a.Fo) dst[2] = v.z;
           if (f + 3 < a.Fo) dst[3] = v.w;
@@ -214,43 +226,59 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     // virtual n-tile nt = cg*NREP + n;  pair = nt/2 -> (dy = pair / CT, ct = pair % CT), dx = nt & 1
     const int CT = (a.Cout + 15) / 16;
     const int To2 = a.T * 2, Fo2 = a.F * 2;
+    const bool full = (to0 + TH <= a.T) && (fo0 + TW <= a.F);
 #pragma unroll
     for (int np = 0; np < NREP / 2; ++np) {
       const int pair = (cg * NREP) / 2 + np;
       const int dy = pair / CT, ct = pair - dy * CT;
       if (dy >= 2) continue;
       const int co = ct * 16 + li;
-      if (co >= a.Cout) continue;
       const float bv = a.bias[co];
+      if (co >= a.Cout) continue;
+      if (full) {
+        // unconditional skip loads for the whole tile column, then the math
+        f32x4 s0[MREP], s1[MREP];
 #pragma unroll
-      for (int m = 0; m < MREP; ++m) {
-        const int rr = m >> 2, cc = m & 3;
-        const int t = to0 + wave * RPW + rr;
-        const int f = fo0 + cc * 16 + lk * 4;
-        if (t >= a.T || f >= a.F) continue;
-        const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
-        float o[8] = {v0.x, v1.x, v0.y, v1.y, v0.z, v1.z, v0.w, v1.w};
-        const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
-        const float *sk = a.skip + off;
-        float *dst = a.y + off;
-        if (f + 3 < a.F) {
-          const f32x4 s0 = *reinterpret_cast<const f32x4 *>(sk);
-          const f32x4 s1 = *reinterpret_cast<const f32x4 *>(sk + 4);
+        for (int m = 0; m < MREP; ++m) {
+          const int rr = m >> 2, cc = m & 3;
+          const int t = to0 + wave * RPW + rr;
+          const int f = fo0 + cc * 16 + lk * 4;
+          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
+          s0[m] = *reinterpret_cast<const f32x4 *>(a.skip + off);
+          s1[m] = *reinterpret_cast<const f32x4 *>(a.skip + off + 4);
+        }
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int rr = m >> 2, cc = m & 3;
+          const int t = to0 + wave * RPW + rr;
+          const int f = fo0 + cc * 16 + lk * 4;
+          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
+          const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
           f32x4 r0, r1;
-          r0.x = fmaxf(o[0] + bv, 0.f) * s0.x;
-          r0.y = fmaxf(o[1] + bv, 0.f) * s0.y;
-          r0.z = fmaxf(o[2] + bv, 0.f) * s0.z;
-          r0.w = fmaxf(o[3] + bv, 0.f) * s0.w;
-          r1.x = fmaxf(o[4] + bv, 0.f) * s1.x;
-          r1.y = fmaxf(o[5] + bv, 0.f) * s1.y;
-          r1.z = fmaxf(o[6] + bv, 0.f) * s1.z;
-          r1.w = fmaxf(o[7] + bv, 0.f) * s1.w;
-          *reinterpret_cast<f32x4 *>(dst) = r0;
-          *reinterpret_cast<f32x4 *>(dst + 4) = r1;
-        } else {
+          r0.x = fmaxf(v0.x + bv, 0.f) * s0[m].x;
+          r0.y = fmaxf(v1.x + bv, 0.f) * s0[m].y;
+          r0.z = fmaxf(v0.y + bv, 0.f) * s0[m].z;
+          r0.w = fmaxf(v1.y + bv, 0.f) * s0[m].w;
+          r1.x = fmaxf(v0.z + bv, 0.f) * s1[m].x;
+          r1.y = fmaxf(v1.z + bv, 0.f) * s1[m].y;
+          r1.z = fmaxf(v0.w + bv, 0.f) * s1[m].z;
+          r1.w = fmaxf(v1.w + bv, 0.f) * s1[m].w;
+          *reinterpret_cast<f32x4 *>(a.y + off) = r0;
+          *reinterpret_cast<f32x4 *>(a.y + off + 4) = r1;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int rr = m >> 2, cc = m & 3;
+          const int t = to0 + wave * RPW + rr;
+          const int f = fo0 + cc * 16 + lk * 4;
+          if (t >= a.T || f >= a.F) continue;
+          const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
+          const float o[8] = {v0.x, v1.x, v0.y, v1.y, v0.z, v1.z, v0.w, v1.w};
+          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
 #pragma unroll
           for (int q = 0; q < 8; ++q)
-            if (f + (q >> 1) < a.F) dst[q] = fmaxf(o[q] + bv, 0.f) * sk[q];
+            if (f + (q >> 1) < a.F) a.y[off + q] = fmaxf(o[q] + bv, 0.f) * a.skip[off + q];
         }
       }
     }
@@ -287,8 +315,8 @@ struct TdfCfg {
   static constexpr int NWV = (BN * BK / 4 + 255) / 256;
 };
 
-template <int NREP, int MREP>
-__global__ __launch_bounds__(256) void tdf_mfma_kernel(TdfArgs a) {
+template <int NREP, int MREP, bool KVEC>
+__global__ __launch_bounds__(256, 2) void tdf_mfma_kernel(TdfArgs a) {
   using CFG = TdfCfg<NREP, MREP>;
   constexpr int BK = CFG::BK, RSW = CFG::RSW, BM = CFG::BM, BN = CFG::BN, NXV = CFG::NXV, NWV = CFG::NWV;
   extern __shared__ float lds_f[];
@@ -305,7 +333,6 @@ __global__ __launch_bounds__(256) void tdf_mfma_kernel(TdfArgs a) {
   const int64_t bm = lid / nbn;
   const int64_t m0 = bm * BM;
   const int n0 = bn * BN;
-  const bool kvec = (a.K & 3) == 0;
 
   f32x4 acc[NREP][MREP];
 #pragma unroll
@@ -315,42 +342,52 @@ __global__ __launch_bounds__(256) void tdf_mfma_kernel(TdfArgs a) {
 
   float4 rx[NXV], rw[NWV];
 
+  // Loads are unconditional (clamped addresses); out-of-range rows / the K tail are zeroed
+  // when the registers are committed to LDS, one barrier later, so the compiler cannot sink a
+  // load under its mask and every load of a stage is in flight at once.
   auto load4 = [&](const float *base, int64_t row, int64_t nrows, int k) -> float4 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows) {
-      const float *p = base + row * a.K + k;
-      if (kvec && k + 3 < a.K) {
-        v = *reinterpret_cast<const float4 *>(p);
-      } else {
-        if (k < a.K) v.x = p[0];
-        if (k + 1 < a.K) v.y = p[1];
-        if (k + 2 < a.K) v.z = p[2];
-        if (k + 3 < a.K) v.w = p[3];
-      }
+    const int64_t rc = row < nrows ? row : nrows - 1;
+    float4 v;
+    if constexpr (KVEC) {
+      v = *reinterpret_cast<const float4 *>(base + rc * a.K + min(k, a.K - 4));
+    } else {
+      const float *p = base + rc * a.K;
+      const int km = a.K - 1;
+      v.x = p[min(k, km)];
+      v.y = p[min(k + 1, km)];
+      v.z = p[min(k + 2, km)];
+      v.w = p[min(k + 3, km)];
     }
+    return v;
+  };
+  auto mask4 = [&](float4 v, bool rok, int k) -> float4 {
+    v.x = (rok && k < a.K) ? v.x : 0.f;
+    v.y = (rok && k + 1 < a.K) ? v.y : 0.f;
+    v.z = (rok && k + 2 < a.K) ? v.z : 0.f;
+    v.w = (rok && k + 3 < a.K) ? v.w : 0.f;
     return v;
   };
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int it = 0; it < NXV; ++it) {
-      const int e = tid + it * 256;
+      const int e = min(tid + it * 256, BM * BK / 4 - 1);
       const int row = e / (BK / 4), c4 = e % (BK / 4);
-      rx[it] = (e < BM * BK / 4) ? load4(a.x, m0 + row, a.M, k0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[it] = load4(a.x, m0 + row, a.M, k0 + c4 * 4);
     }
 #pragma unroll
     for (int it = 0; it < NWV; ++it) {
-      const int e = tid + it * 256;
+      const int e = min(tid + it * 256, BN * BK / 4 - 1);
       const int row = e / (BK / 4), c4 = e % (BK / 4);
-      rw[it] = (e < BN * BK / 4) ? load4(a.w, n0 + row, a.N, k0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[it] = load4(a.w, n0 + row, a.N, k0 + c4 * 4);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int k0) {
 #pragma unroll
     for (int it = 0; it < NXV; ++it) {
       const int e = tid + it * 256;
       if (e < BM * BK / 4) {
         const int row = e / (BK / 4), c4 = e % (BK / 4);
-        *reinterpret_cast<float4 *>(&xs[row * RSW + c4 * 4]) = rx[it];
+        *reinterpret_cast<float4 *>(&xs[row * RSW + c4 * 4]) = mask4(rx[it], m0 + row < a.M, k0 + c4 * 4);
       }
     }
 #pragma unroll
@@ -358,7 +395,7 @@ __global__ __launch_bounds__(256) void tdf_mfma_kernel(TdfArgs a) {
       const int e = tid + it * 256;
       if (e < BN * BK / 4) {
         const int row = e / (BK / 4), c4 = e % (BK / 4);
-        *reinterpret_cast<float4 *>(&ws[row * RSW + c4 * 4]) = rw[it];
+        *reinterpret_cast<float4 *>(&ws[row * RSW + c4 * 4]) = mask4(rw[it], n0 + row < a.N, k0 + c4 * 4);
       }
     }
   };
@@ -367,28 +404,79 @@ __global__ __launch_bounds__(256) void tdf_mfma_kernel(TdfArgs a) {
   fetch(0);
   for (int ks = 0; ks < nk; ++ks) {
     __syncthreads();
-    commit();
+    commit(ks * BK);
     __syncthreads();
     if (ks + 1 < nk) fetch((ks + 1) * BK);
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      f32x4 wa[NREP], xb[MREP];
+      f32x4 wa[NREP];
 #pragma unroll
       for (int n = 0; n < NREP; ++n)
         wa[n] = *reinterpret_cast<const f32x4 *>(&ws[(wave * 16 * NREP + n * 16 + li) * RSW + kk * 16 + lk * 4]);
+      // activation fragments in groups of 4 row-tiles to bound the live registers
 #pragma unroll
-      for (int m = 0; m < MREP; ++m)
-        xb[m] = *reinterpret_cast<const f32x4 *>(&xs[(m * 16 + li) * RSW + kk * 16 + lk * 4]);
+      for (int mg = 0; mg < MREP; mg += 4) {
+        f32x4 xb[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int m = 0; m < 4; ++m)
+          xb[m] = *reinterpret_cast<const f32x4 *>(&xs[((mg + m) * 16 + li) * RSW + kk * 16 + lk * 4]);
 #pragma unroll
-        for (int n = 0; n < NREP; ++n)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int m = 0; m < MREP; ++m) acc[n][m] = ASX_MFMA(wa[n][j], xb[m][j], acc[n][m]);
+          for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[n][mg + m] = ASX_MFMA(wa[n][j], xb[m][j], acc[n][mg + m]);
+      }
     }
   }
 
   const bool nvec = (a.N & 3) == 0;
+  // Fast path (block-uniform test): full tile, 16-byte aligned rows -> every load is
+  // unconditional, so the residual / bias / scale loads of the whole tile pipeline.
+  const bool full = nvec && (m0 + BM <= a.M) && (n0 + BN <= a.N);
+  if (full) {
+    f32x4 bz[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+      bz[n] = (a.bias != nullptr) ? *reinterpret_cast<const f32x4 *>(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int mg = 0; mg < MREP; mg += 4) {
+      float sc[4], sh[4];
+      f32x4 rs[4][NREP];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int64_t row = m0 + (mg + m) * 16 + li;
+        const int c = (int)((row / a.T) % a.C);
+        sc[m] = a.scale[c];
+        sh[m] = a.shift[c];
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+          const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+          rs[m][n] = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(a.res + row * a.N + col)
+                                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int64_t row = m0 + (mg + m) * 16 + li;
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+          const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+          const f32x4 v = acc[n][mg + m];
+          f32x4 o;
+          o.x = fmaxf(sc[m] * (v.x + bz[n].x) + sh[m], 0.f) + rs[m][n].x;
+          o.y = fmaxf(sc[m] * (v.y + bz[n].y) + sh[m], 0.f) + rs[m][n].y;
+          o.z = fmaxf(sc[m] * (v.z + bz[n].z) + sh[m], 0.f) + rs[m][n].z;
+          o.w = fmaxf(sc[m] * (v.w + bz[n].w) + sh[m], 0.f) + rs[m][n].w;
+          *reinterpret_cast<f32x4 *>(a.y + row * a.N + col) = o;
+        }
+      }
+    }
+    return;
+  }
+  // generic (ragged) path
 #pragma unroll
   for (int m = 0; m < MREP; ++m) {
     const int64_t row = m0 + m * 16 + li;
@@ -403,19 +491,13 @@ __global__ __launch_bounds__(256) void tdf_mfma_kernel(TdfArgs a) {
       float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float bz = (a.bias != nullptr && col + r < a.N) ? a.bias[col + r] : 0.f;
-        o[r] = fmaxf(sc * (o[r] + bz) + sh, 0.f);
+        const float bzz = (a.bias != nullptr && col + r < a.N) ? a.bias[col + r] : 0.f;
+        o[r] = fmaxf(sc * (o[r] + bzz) + sh, 0.f);
       }
       float *dst = a.y + row * a.N + col;
-      if (nvec && col + 3 < a.N) {
-        f32x4 out = {o[0], o[1], o[2], o[3]};
-        if (a.res != nullptr) out += *reinterpret_cast<const f32x4 *>(a.res + row * a.N + col);
-        *reinterpret_cast<f32x4 *>(dst) = out;
-      } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (col + r < a.N) dst[r] = o[r] + (a.res != nullptr ? a.res[row * a.N + col + r] : 0.f);
-      }
+      for (int r = 0; r < 4; ++r)
+        if (col + r < a.N) dst[r] = o[r] + (a.res != nullptr ? a.res[row * a.N + col + r] : 0.f);
     }
   }
 }
