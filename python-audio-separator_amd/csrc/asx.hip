@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -112,6 +113,7 @@ struct asx_engine {
   asx_mdx_config cfg{};
   FftPlan plan{};
   DevBuf d_window, d_tw, d_env;  // env for T = segment_size
+  DevBuf d_zeros;                // zero page: source of out-of-range DMA slots
   // net
   bool net_begun = false, net_ready = false;
   asx_net_config net{};
@@ -250,10 +252,13 @@ static int conv_setup(ConvLayer &L, int kind, int cin, int cout, int relu) {
 }
 
 // w layouts: 3x3 [cout,cin,3,3]; down [cout,cin,2,2]; 1x1 [cout,cin]; up [cin,cout,2,2]
+// packed: [CG][NCI][WSTAGE] with WSTAGE = roundup(ntap*kc*NWP, 256) floats; row (tap, kc) holds NWP floats
 static int conv_pack(ConvLayer &L, const float *w, const float *b) {
   const int ntap = L.kind == CK_3X3 ? 9 : (L.kind == CK_DOWN ? 4 : 1);
   const int NW = 16 * L.nrep;
-  const size_t per_cg = (size_t)L.nci * ntap * L.kc * NW;
+  const int NWP = (L.nrep % 2 == 0) ? NW + 16 : NW;
+  const size_t wstage = (((size_t)ntap * L.kc * NWP + 255) / 256) * 256;
+  const size_t per_cg = (size_t)L.nci * wstage;
   std::vector<float> wp(per_cg * L.cg, 0.f);
   const int CT = (L.cout + 15) / 16;
   for (int cg = 0; cg < L.cg; ++cg)
@@ -262,7 +267,7 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b) {
         for (int kc = 0; kc < L.kc; ++kc) {
           const int c = ci * L.kc + kc;
           if (c >= L.cin) continue;
-          float *dst = &wp[cg * per_cg + (((size_t)ci * ntap + tap) * L.kc + kc) * NW];
+          float *dst = &wp[cg * per_cg + ci * wstage + ((size_t)tap * L.kc + kc) * NWP];
           for (int n = 0; n < NW; ++n) {
             float v = 0.f;
             if (L.kind == CK_UP) {
@@ -286,6 +291,17 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b) {
   HIPCHK(hipMemcpy(L.w.p, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(L.b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
   return ASX_OK;
+}
+
+template <class CFG>
+static void launch_conv_dma_t(const ConvDmaArgs &a, int nblk, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_dma_kernel<CFG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv_dma_kernel<CFG>, dim3(nblk), dim3(256), CFG::LDS_BYTES, s, a);
 }
 
 // x [B,cin,T,F] -> y ; returns output dims through To/Fo.
@@ -333,42 +349,82 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
   double bytes = 4.0 * ((double)B * L.cin * T * F + (double)L.cout * outpix * (L.kind == CK_UP ? 4 : 1));
   if (L.kind == CK_UP) bytes += 4.0 * (double)L.cout * outpix * 4;  // skip read
   int bad = 0;
+  const bool dma = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && getenv("ASX_NO_DMA") == nullptr;
+  ConvDmaArgs d{};
+  d.x = a.x;
+  d.wp = a.wp;
+  d.bias = a.bias;
+  d.skip = a.skip;
+  d.zeros = e->d_zeros.f();
+  d.y = a.y;
+  d.B = a.B;
+  d.Cin = a.Cin;
+  d.Cout = a.Cout;
+  d.T = a.T;
+  d.F = a.F;
+  d.To = a.To;
+  d.Fo = a.Fo;
+  d.tilesT = a.tilesT;
+  d.tilesF = a.tilesF;
+  d.CG = a.CG;
+  d.NCI = a.NCI;
+  d.relu = a.relu;
+#define ASX_CONV_CASE(KH, KW, S, PAD, NR, KC, RPW, EPI)                                      \
+  do {                                                                                       \
+    if (dma) launch_conv_dma_t<ConvDmaCfg<KH, KW, S, PAD, NR, KC, RPW, EPI>>(d, nblk, s);    \
+    else launch_conv_t<ConvCfg<KH, KW, S, PAD, NR, KC, RPW, EPI>>(a, nblk, s);               \
+  } while (0)
   CHK(timed(e, cls, flops, bytes, s, [&]() {
     switch (L.kind) {
       case CK_3X3:
-        if (L.nrep == 3) launch_conv_t<ConvCfg<3, 3, 1, 1, 3, 8, 2, EPI_BIAS_ACT>>(a, nblk, s);
-        else if (L.nrep == 2) launch_conv_t<ConvCfg<3, 3, 1, 1, 2, 8, 2, EPI_BIAS_ACT>>(a, nblk, s);
-        else launch_conv_t<ConvCfg<3, 3, 1, 1, 1, 8, 2, EPI_BIAS_ACT>>(a, nblk, s);
+        if (L.nrep == 3) ASX_CONV_CASE(3, 3, 1, 1, 3, 8, 2, EPI_BIAS_ACT);
+        else if (L.nrep == 2) ASX_CONV_CASE(3, 3, 1, 1, 2, 8, 2, EPI_BIAS_ACT);
+        else ASX_CONV_CASE(3, 3, 1, 1, 1, 8, 2, EPI_BIAS_ACT);
         break;
       case CK_DOWN:
-        if (L.nrep == 3) launch_conv_t<ConvCfg<2, 2, 2, 0, 3, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
-        else if (L.nrep == 2) launch_conv_t<ConvCfg<2, 2, 2, 0, 2, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
-        else launch_conv_t<ConvCfg<2, 2, 2, 0, 1, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
+        if (L.nrep == 3) ASX_CONV_CASE(2, 2, 2, 0, 3, 4, 2, EPI_BIAS_ACT);
+        else if (L.nrep == 2) ASX_CONV_CASE(2, 2, 2, 0, 2, 4, 2, EPI_BIAS_ACT);
+        else ASX_CONV_CASE(2, 2, 2, 0, 1, 4, 2, EPI_BIAS_ACT);
         break;
       case CK_1X1:
         if (L.kc == 16) {
-          if (L.nrep == 3) launch_conv_t<ConvCfg<1, 1, 1, 0, 3, 16, 2, EPI_BIAS_ACT>>(a, nblk, s);
-          else if (L.nrep == 2) launch_conv_t<ConvCfg<1, 1, 1, 0, 2, 16, 2, EPI_BIAS_ACT>>(a, nblk, s);
-          else launch_conv_t<ConvCfg<1, 1, 1, 0, 1, 16, 2, EPI_BIAS_ACT>>(a, nblk, s);
+          if (L.nrep == 3) ASX_CONV_CASE(1, 1, 1, 0, 3, 16, 2, EPI_BIAS_ACT);
+          else if (L.nrep == 2) ASX_CONV_CASE(1, 1, 1, 0, 2, 16, 2, EPI_BIAS_ACT);
+          else ASX_CONV_CASE(1, 1, 1, 0, 1, 16, 2, EPI_BIAS_ACT);
         } else {
-          if (L.nrep == 3) launch_conv_t<ConvCfg<1, 1, 1, 0, 3, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
-          else if (L.nrep == 2) launch_conv_t<ConvCfg<1, 1, 1, 0, 2, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
-          else launch_conv_t<ConvCfg<1, 1, 1, 0, 1, 4, 2, EPI_BIAS_ACT>>(a, nblk, s);
+          if (L.nrep == 3) ASX_CONV_CASE(1, 1, 1, 0, 3, 4, 2, EPI_BIAS_ACT);
+          else if (L.nrep == 2) ASX_CONV_CASE(1, 1, 1, 0, 2, 4, 2, EPI_BIAS_ACT);
+          else ASX_CONV_CASE(1, 1, 1, 0, 1, 4, 2, EPI_BIAS_ACT);
         }
         break;
       case CK_UP:
-        if (L.nrep == 6) launch_conv_t<ConvCfg<1, 1, 1, 0, 6, 8, 1, EPI_UP_MULSKIP>>(a, nblk, s);
-        else if (L.nrep == 4) launch_conv_t<ConvCfg<1, 1, 1, 0, 4, 8, 1, EPI_UP_MULSKIP>>(a, nblk, s);
-        else launch_conv_t<ConvCfg<1, 1, 1, 0, 2, 8, 1, EPI_UP_MULSKIP>>(a, nblk, s);
+        if (L.nrep == 6) ASX_CONV_CASE(1, 1, 1, 0, 6, 8, 1, EPI_UP_MULSKIP);
+        else if (L.nrep == 4) ASX_CONV_CASE(1, 1, 1, 0, 4, 8, 1, EPI_UP_MULSKIP);
+        else ASX_CONV_CASE(1, 1, 1, 0, 2, 8, 1, EPI_UP_MULSKIP);
         break;
       default: bad = 1;
     }
   }));
+#undef ASX_CONV_CASE
   if (bad) {
     set_err("conv_launch: bad kind");
     return ASX_ERR_INVALID;
   }
   return ASX_OK;
+}
+
+template <int NREP, int MREP>
+static void launch_tdf_dma_t(const TdfDmaArgs &a, hipStream_t s) {
+  using CFG = TdfDmaCfg<NREP, MREP>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tdf_dma_kernel<NREP, MREP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    attr_done = true;
+  }
+  const int64_t nbm = (a.M + CFG::BM - 1) / CFG::BM;
+  const int nbn = (a.N + CFG::BN - 1) / CFG::BN;
+  hipLaunchKernelGGL((tdf_dma_kernel<NREP, MREP>), dim3((unsigned)(nbm * nbn)), dim3(256), CFG::LDS_BYTES, s, a);
 }
 
 template <int NREP, int MREP, bool KVEC>
@@ -409,10 +465,31 @@ static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const fl
   if (M <= 0) return ASX_OK;
   const double flops = 2.0 * (double)M * L.n * L.k;
   const double bytes = 4.0 * ((double)M * L.k + (double)M * L.n * (res ? 2 : 1) + (double)L.n * L.k);
+  const bool dma = (L.k % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && getenv("ASX_NO_DMA") == nullptr;
+  TdfDmaArgs d{};
+  d.x = a.x;
+  d.w = a.w;
+  d.bias = a.bias;
+  d.scale = a.scale;
+  d.shift = a.shift;
+  d.res = a.res;
+  d.zeros = e->d_zeros.f();
+  d.y = a.y;
+  d.M = a.M;
+  d.N = a.N;
+  d.K = a.K;
+  d.C = a.C;
+  d.T = a.T;
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
-    if (L.n > 128) launch_tdf_t<3, 8>(a, s);       // 128 rows x 192 cols per workgroup
-    else if (L.n > 64) launch_tdf_t<2, 4>(a, s);   //  64 x 128
-    else launch_tdf_t<1, 4>(a, s);                 //  64 x 64
+    if (dma) {
+      if (L.n > 128) launch_tdf_dma_t<3, 8>(d, s);       // 128 rows x 192 cols per workgroup
+      else if (L.n > 64) launch_tdf_dma_t<2, 4>(d, s);   //  64 x 128
+      else launch_tdf_dma_t<1, 4>(d, s);                 //  64 x 64
+    } else {
+      if (L.n > 128) launch_tdf_t<3, 8>(a, s);
+      else if (L.n > 64) launch_tdf_t<2, 4>(a, s);
+      else launch_tdf_t<1, 4>(a, s);
+    }
   });
 }
 
@@ -625,6 +702,11 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
       rc = ASX_ERR_HIP;
     }
   }
+  if (rc == ASX_OK) rc = e->d_zeros.ensure(256);
+  if (rc == ASX_OK && hipMemset(e->d_zeros.p, 0, 256) != hipSuccess) {
+    set_err("zero page init failed");
+    rc = ASX_ERR_HIP;
+  }
   if (rc == ASX_OK) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)stft_lds(plan));
@@ -665,6 +747,7 @@ void asx_engine_destroy(asx_engine *e) {
   e->d_window.release();
   e->d_tw.release();
   e->d_env.release();
+  e->d_zeros.release();
   free_conv(e->first);
   free_conv(e->final_);
   for (auto &b : e->enc) free_block(b);

@@ -51,16 +51,17 @@ struct ConvCfg {
   static constexpr int IN_ELEMS = KC * PS;
   static constexpr int W_ROWS = NTAP * KC;
   static constexpr int W_ELEMS = W_ROWS * NWP;
+  static constexpr int WSTAGE = ((W_ROWS * NWP + 255) / 256) * 256;  // packed weight floats per stage (global)
   static constexpr int LDS_BYTES = (IN_ELEMS + W_ELEMS) * 4;
   static constexpr int MREP = RPW * 4;
   static constexpr int NPL = (PS0 + 255) / 256;                // staged elements per thread per plane
   static constexpr int NIN = KC * NPL;                         // input elements per thread per stage
-  static constexpr int NWV = (W_ROWS * NW / 4 + 255) / 256;    // weight float4 per thread per stage
+  static constexpr int NWV = (W_ROWS * NWP / 4 + 255) / 256;   // weight float4 per thread per stage
 };
 
 struct ConvArgs {
   const float *x;     // [B, Cin, T, F]
-  const float *wp;    // packed [CG][NCI][NTAP][KC][NW]
+  const float *wp;    // packed [CG][NCI][WSTAGE]: rows (tap, kc) of NWP floats, zero padded
   const float *bias;  // padded per (virtual) output channel
   const float *skip;  // EPI_UP_MULSKIP: [B, Cout, 2T, 2F]
   float *y;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   const int ti0 = to0 * S - PAD, fi0 = fo0 * S - PAD;  // input tile origin
 
   const float *xb = a.x + (int64_t)b * a.Cin * a.T * a.F;
-  const float *wg = a.wp + (int64_t)cg * a.NCI * (CFG::W_ROWS * NW);
+  const float *wg = a.wp + (int64_t)cg * a.NCI * CFG::WSTAGE;
 
   f32x4 acc[MREP][NREP];
 #pragma unroll
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     sp_off[j] = tc * a.F + fc;
   }
   const int64_t plane_sz = (int64_t)a.T * a.F;
-  constexpr int WV_TOTAL = CFG::W_ROWS * NW / 4;
+  constexpr int WV_TOTAL = CFG::W_ROWS * NWP / 4;
 
   auto fetch = [&](int ci) {
 #pragma unroll
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         rin[pl * NPL + j] = xp[sp_off[j]];  // raw; masked at commit (keeps the load unconditional)
       }
     }
-    const float4 *w4 = reinterpret_cast<const float4 *>(wg + (int64_t)ci * (CFG::W_ROWS * NW));
+    const float4 *w4 = reinterpret_cast<const float4 *>(wg + (int64_t)ci * CFG::WSTAGE);
 #pragma unroll
     for (int it = 0; it < NWV; ++it) {
       const int e = tid + it * 256;
@@ -154,11 +155,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < NWV; ++it) {
       const int e = tid + it * 256;
-      if (e < WV_TOTAL) {
-        const int row = (e * 4) / NW;
-        const int col = (e * 4) - row * NW;
-        *reinterpret_cast<float4 *>(&w_s[row * NWP + col]) = rw[it];
-      }
+      if (e < WV_TOTAL) *reinterpret_cast<float4 *>(&w_s[e * 4]) = rw[it];
     }
   };
 
@@ -477,6 +474,434 @@ __global__ __launch_bounds__(256, 2) void tdf_mfma_kernel(TdfArgs a) {
     return;
   }
   // generic (ragged) path
+#pragma unroll
+  for (int m = 0; m < MREP; ++m) {
+    const int64_t row = m0 + m * 16 + li;
+    if (row >= a.M) continue;
+    const int c = (int)((row / a.T) % a.C);
+    const float sc = a.scale[c], sh = a.shift[c];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+      if (col >= a.N) continue;
+      f32x4 v = acc[n][m];
+      float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float bzz = (a.bias != nullptr && col + r < a.N) ? a.bias[col + r] : 0.f;
+        o[r] = fmaxf(sc * (o[r] + bzz) + sh, 0.f);
+      }
+      float *dst = a.y + row * a.N + col;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col + r < a.N) dst[r] = o[r] + (a.res != nullptr ? a.res[row * a.N + col + r] : 0.f);
+    }
+  }
+}
+
+
+// ===========================================================================
+// LDS-DMA variants (the production path).  Both operands of a stage are copied
+// global -> LDS with `global_load_lds_dwordx4` (no staging registers, no commit
+// pass); LDS is double buffered and a stage's DMA is issued one whole compute
+// phase before it is consumed, behind a single barrier per stage:
+//
+//     issue(stage 0)
+//     for ci: wait vmcnt(0); barrier; issue(stage ci+1 -> other buffer); compute(stage ci)
+//
+// The LDS image of a DMA is lane-linear (wave-uniform base + lane*16 B), so
+// padding is expressed through which lanes take part (EXEC-masked partial
+// issues) and, for the row GEMM, through an XOR swizzle applied to the SOURCE
+// address and again to the fragment read.  Out-of-range float4s are sourced from
+// a zero page in global memory.  Requirements (checked by the launcher, which
+// otherwise falls back to the register-staged kernels above): F % 4 == 0 for the
+// conv, K % 4 == 0 for the row GEMM, 16-byte aligned base pointers.
+// ===========================================================================
+#define ASX_GLDS16(gptr, lptr)                                                               \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),  \
+                                   (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+template <int KH_, int KW_, int S_, int PAD_, int NREP_, int KC_, int RPW_, int EPI_>
+struct ConvDmaCfg {
+  static constexpr int KH = KH_, KW = KW_, S = S_, PAD = PAD_, NREP = NREP_, KC = KC_, RPW = RPW_, EPI = EPI_;
+  static constexpr int TH = 4 * RPW, TW = 64;
+  static constexpr int IH = (TH - 1) * S + KH;
+  static constexpr int LP = (PAD == 0) ? 0 : 4 - PAD;                    // left shift so rows start 16-B aligned
+  static constexpr int IWA = ((LP + (TW - 1) * S + KW + 3) / 4) * 4;     // staged row width (floats)
+  static constexpr int C4 = IWA / 4;
+  static constexpr int SLOTS = IH * C4;                                  // float4 per plane
+  static constexpr int NI = (SLOTS + 63) / 64;                           // wave-issues per plane
+  static constexpr int PS0 = IH * IWA;
+  static constexpr int PS = (S == 1) ? (PS0 + ((16 - PS0 % 32) + 32) % 32) : PS0 + 4;
+  static constexpr int NW = 16 * NREP;
+  static constexpr int NWP = (NREP % 2 == 0) ? NW + 16 : NW;
+  static constexpr int NTAP = KH * KW;
+  static constexpr int W_ROWS = NTAP * KC;
+  static constexpr int WSTAGE = ((W_ROWS * NWP + 255) / 256) * 256;      // packed weight floats per stage
+  static constexpr int NWI = WSTAGE / 256;                               // weight wave-issues per stage
+  static constexpr int BUF = KC * PS + WSTAGE;                           // floats per LDS buffer
+  static constexpr int LDS_BYTES = 2 * BUF * 4;
+  static constexpr int MREP = RPW * 4;
+  static_assert(KC % 4 == 0, "KC must be a multiple of 4");
+  static_assert(PS % 4 == 0, "plane stride must keep 16-B alignment");
+};
+
+struct ConvDmaArgs {
+  const float *x;      // [B, Cin, T, F]
+  const float *wp;     // packed [CG][NCI][WSTAGE]
+  const float *bias;
+  const float *skip;
+  const float *zeros;  // >= 16 B of zeros
+  float *y;
+  int B, Cin, Cout, T, F, To, Fo;
+  int tilesT, tilesF, CG, NCI;
+  int relu;
+};
+
+template <class CFG>
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvDmaArgs a) {
+  extern __shared__ float lds_f[];
+  constexpr int KH = CFG::KH, KW = CFG::KW, S = CFG::S, PAD = CFG::PAD, NREP = CFG::NREP, KC = CFG::KC;
+  constexpr int RPW = CFG::RPW, MREP = CFG::MREP, IWA = CFG::IWA, C4 = CFG::C4, PS = CFG::PS, LP = CFG::LP;
+  constexpr int NW = CFG::NW, NWP = CFG::NWP, TH = CFG::TH, TW = CFG::TW, NI = CFG::NI, SLOTS = CFG::SLOTS;
+  constexpr int BUF = CFG::BUF, WSTAGE = CFG::WSTAGE, NWI = CFG::NWI;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cg = lid % a.CG;
+  lid /= a.CG;
+  const int tf = lid % a.tilesF;
+  lid /= a.tilesF;
+  const int tt = lid % a.tilesT;
+  const int b = lid / a.tilesT;
+  const int to0 = tt * TH, fo0 = tf * TW;
+  const int ti0 = to0 * S - PAD, fa0 = fo0 * S - PAD - LP;   // aligned input origin
+
+  const float *xb = a.x + (int64_t)b * a.Cin * a.T * a.F;
+  const float *wg = a.wp + (int64_t)cg * a.NCI * WSTAGE;
+  const int64_t plane_sz = (int64_t)a.T * a.F;
+
+  // per-lane source offsets of this lane's NI slots inside a plane (same for every plane / stage)
+  int sp_off[NI];
+  bool sp_ok[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int sidx = j * 64 + lane;
+    const int row = sidx / C4, c4 = sidx - row * C4;
+    const int t = ti0 + row, f = fa0 + c4 * 4;
+    sp_ok[j] = (sidx < SLOTS) && t >= 0 && t < a.T && f >= 0 && f < a.F;
+    sp_off[j] = t * a.F + f;
+  }
+
+  auto issue = [&](int ci, int buf) {
+    float *in_s = lds_f + buf * BUF;
+    float *w_s = in_s + KC * PS;
+#pragma unroll
+    for (int p = 0; p < KC / 4; ++p) {
+      const int pl = wave + 4 * p;
+      const int c = ci * KC + pl;
+      const float *xc = xb + (int64_t)c * plane_sz;
+      const bool cok = c < a.Cin;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const float *src = (cok && sp_ok[j]) ? xc + sp_off[j] : a.zeros;
+        if (j * 64 + lane < SLOTS) ASX_GLDS16(src, in_s + pl * PS + j * 256);
+      }
+    }
+    const float *ws = wg + (int64_t)ci * WSTAGE;
+#pragma unroll
+    for (int i = 0; i < (NWI + 3) / 4; ++i) {
+      const int q = wave + 4 * i;
+      if (q < NWI) ASX_GLDS16(ws + q * 256 + lane * 4, w_s + q * 256);
+    }
+  };
+
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int m = 0; m < MREP; ++m)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  for (int ci = 0; ci < a.NCI; ++ci) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ci + 1 < a.NCI) issue(ci + 1, (ci + 1) & 1);
+    const float *in_s = lds_f + (ci & 1) * BUF;
+    const float *w_s = in_s + KC * PS;
+#pragma unroll
+    for (int tap = 0; tap < KH * KW; ++tap) {
+      const int dy = tap / KW, dx = tap % KW;
+#pragma unroll
+      for (int kq = 0; kq < KC / 4; ++kq) {
+        float bf[NREP];
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) bf[n] = w_s[(tap * KC + kq * 4 + lk) * NWP + n * 16 + li];
+        float af[MREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int rr = m >> 2, cc = m & 3;
+          af[m] = in_s[(kq * 4 + lk) * PS + ((wave * RPW + rr) * S + dy) * IWA + LP + (cc * 16 + li) * S + dx];
+        }
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) acc[m][n] = ASX_MFMA(af[m], bf[n], acc[m][n]);
+      }
+    }
+  }
+
+  // ---- epilogue (same math as conv_mfma_kernel) ----
+  if constexpr (CFG::EPI == EPI_BIAS_ACT) {
+    const bool full = ((a.Fo & 3) == 0) && (to0 + TH <= a.To) && (fo0 + TW <= a.Fo);
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      const int co = cg * NW + n * 16 + li;
+      const float bv = a.bias[co];
+      if (co >= a.Cout) continue;
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) {
+        const int rr = m >> 2, cc = m & 3;
+        const int t = to0 + wave * RPW + rr;
+        const int f = fo0 + cc * 16 + lk * 4;
+        f32x4 v = acc[m][n];
+        v += bv;
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        float *dst = a.y + (((int64_t)b * a.Cout + co) * a.To + t) * a.Fo + f;
+        if (full) {
+          *reinterpret_cast<f32x4 *>(dst) = v;
+        } else if (t < a.To) {
+          if (f < a.Fo) dst[0] = v.x;
+          if (f + 1 < a.Fo) dst[1] = v.y;
+          if (f + 2 < a.Fo) dst[2] = v.z;
+          if (f + 3 < a.Fo) dst[3] = v.w;
+        }
+      }
+    }
+  } else {
+    const int CT = (a.Cout + 15) / 16;
+    const int To2 = a.T * 2, Fo2 = a.F * 2;
+    const bool full = (to0 + TH <= a.T) && (fo0 + TW <= a.F);
+#pragma unroll
+    for (int np = 0; np < NREP / 2; ++np) {
+      const int pair = (cg * NREP) / 2 + np;
+      const int dy = pair / CT, ct = pair - dy * CT;
+      if (dy >= 2) continue;
+      const int co = ct * 16 + li;
+      const float bv = a.bias[co];
+      if (co >= a.Cout) continue;
+      if (full) {
+        f32x4 s0[MREP], s1[MREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int rr = m >> 2, cc = m & 3;
+          const int t = to0 + wave * RPW + rr;
+          const int f = fo0 + cc * 16 + lk * 4;
+          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
+          s0[m] = *reinterpret_cast<const f32x4 *>(a.skip + off);
+          s1[m] = *reinterpret_cast<const f32x4 *>(a.skip + off + 4);
+        }
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int rr = m >> 2, cc = m & 3;
+          const int t = to0 + wave * RPW + rr;
+          const int f = fo0 + cc * 16 + lk * 4;
+          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
+          const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
+          f32x4 r0, r1;
+          r0.x = fmaxf(v0.x + bv, 0.f) * s0[m].x;
+          r0.y = fmaxf(v1.x + bv, 0.f) * s0[m].y;
+          r0.z = fmaxf(v0.y + bv, 0.f) * s0[m].z;
+          r0.w = fmaxf(v1.y + bv, 0.f) * s0[m].w;
+          r1.x = fmaxf(v0.z + bv, 0.f) * s1[m].x;
+          r1.y = fmaxf(v1.z + bv, 0.f) * s1[m].y;
+          r1.z = fmaxf(v0.w + bv, 0.f) * s1[m].z;
+          r1.w = fmaxf(v1.w + bv, 0.f) * s1[m].w;
+          *reinterpret_cast<f32x4 *>(a.y + off) = r0;
+          *reinterpret_cast<f32x4 *>(a.y + off + 4) = r1;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int rr = m >> 2, cc = m & 3;
+          const int t = to0 + wave * RPW + rr;
+          const int f = fo0 + cc * 16 + lk * 4;
+          if (t >= a.T || f >= a.F) continue;
+          const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
+          const float o[8] = {v0.x, v1.x, v0.y, v1.y, v0.z, v1.z, v0.w, v1.w};
+          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (f + (q >> 1) < a.F) a.y[off + q] = fmaxf(o[q] + bv, 0.f) * a.skip[off + q];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Row GEMM with LDS-DMA staging.  Tiles are stored UNPADDED, [rows][32 floats],
+// with the 16-byte chunk index XOR-swizzled by g(row) = (row >> 1) & 7 (applied to
+// the source address of the DMA and to the fragment read), which makes every
+// ds_read_b128 lane group hit 16 distinct 4-bank slots.
+// ---------------------------------------------------------------------------
+struct TdfDmaArgs {
+  const float *x, *w, *bias, *scale, *shift, *res, *zeros;
+  float *y;
+  int64_t M;
+  int N, K, C, T;
+};
+
+template <int NREP, int MREP>
+struct TdfDmaCfg {
+  static constexpr int BK = 32;
+  static constexpr int BM = 16 * MREP, BN = 64 * NREP;
+  static constexpr int BUF = (BM + BN) * BK;           // floats per LDS buffer
+  static constexpr int LDS_BYTES = 2 * BUF * 4;
+  static constexpr int NXI = BM / 8, NWI = BN / 8;     // wave-issues (8 rows each) per stage
+};
+
+template <int NREP, int MREP>
+__global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
+  using CFG = TdfDmaCfg<NREP, MREP>;
+  constexpr int BK = CFG::BK, BM = CFG::BM, BN = CFG::BN, BUF = CFG::BUF, NXI = CFG::NXI, NWI = CFG::NWI;
+  extern __shared__ float lds_f[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+
+  const int nbn = (a.N + BN - 1) / BN;
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bn = lid % nbn;
+  const int64_t bm = lid / nbn;
+  const int64_t m0 = bm * BM;
+  const int n0 = bn * BN;
+
+  // DMA lane role: row-in-issue = lane / 8, physical chunk p = lane % 8
+  const int lr = lane >> 3, lp = lane & 7;
+
+  auto issue = [&](int k0, int buf) {
+    float *xs = lds_f + buf * BUF;
+    float *ws = xs + BM * BK;
+#pragma unroll
+    for (int i = 0; i < (NXI + 3) / 4; ++i) {
+      const int q = wave + 4 * i;             // issue index -> rows 8q .. 8q+7
+      if (q < NXI) {
+        const int row = q * 8 + lr;
+        const int c = lp ^ ((row >> 1) & 7);   // logical chunk fetched into physical slot lp
+        const int k = k0 + c * 4;
+        const bool ok = (m0 + row < a.M) && (k < a.K);
+        const float *src = ok ? a.x + (m0 + row) * a.K + k : a.zeros;
+        ASX_GLDS16(src, xs + q * 256);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (NWI + 3) / 4; ++i) {
+      const int q = wave + 4 * i;
+      if (q < NWI) {
+        const int row = q * 8 + lr;
+        const int c = lp ^ ((row >> 1) & 7);
+        const int k = k0 + c * 4;
+        const bool ok = (n0 + row < a.N) && (k < a.K);
+        const float *src = ok ? a.w + (int64_t)(n0 + row) * a.K + k : a.zeros;
+        ASX_GLDS16(src, ws + q * 256);
+      }
+    }
+  };
+
+  f32x4 acc[NREP][MREP];
+#pragma unroll
+  for (int n = 0; n < NREP; ++n)
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (a.K + BK - 1) / BK;
+  const int sw = (li >> 1) & 7;   // fragment rows are (16*tile + li): g(row) = (li >> 1) & 7 since 16 | tile base
+  issue(0, 0);
+  for (int ks = 0; ks < nk; ++ks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ks + 1 < nk) issue((ks + 1) * BK, (ks + 1) & 1);
+    const float *xs = lds_f + (ks & 1) * BUF;
+    const float *ws = xs + BM * BK;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int pc = ((kk * 4 + lk) ^ sw) * 4;   // swizzled chunk -> float offset inside the row
+      f32x4 wa[NREP];
+#pragma unroll
+      for (int n = 0; n < NREP; ++n)
+        wa[n] = *reinterpret_cast<const f32x4 *>(&ws[(wave * 16 * NREP + n * 16 + li) * BK + pc]);
+#pragma unroll
+      for (int mg = 0; mg < MREP; mg += 4) {
+        f32x4 xb[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          xb[m] = *reinterpret_cast<const f32x4 *>(&xs[((mg + m) * 16 + li) * BK + pc]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[n][mg + m] = ASX_MFMA(wa[n][j], xb[m][j], acc[n][mg + m]);
+      }
+    }
+  }
+
+  const bool nvec = (a.N & 3) == 0;
+  const bool full = nvec && (m0 + BM <= a.M) && (n0 + BN <= a.N);
+  if (full) {
+    f32x4 bz[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+      bz[n] = (a.bias != nullptr) ? *reinterpret_cast<const f32x4 *>(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int mg = 0; mg < MREP; mg += 4) {
+      float sc[4], sh[4];
+      f32x4 rs[4][NREP];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int64_t row = m0 + (mg + m) * 16 + li;
+        const int c = (int)((row / a.T) % a.C);
+        sc[m] = a.scale[c];
+        sh[m] = a.shift[c];
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+          const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+          rs[m][n] = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(a.res + row * a.N + col)
+                                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int64_t row = m0 + (mg + m) * 16 + li;
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+          const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+          const f32x4 v = acc[n][mg + m];
+          f32x4 o;
+          o.x = fmaxf(sc[m] * (v.x + bz[n].x) + sh[m], 0.f) + rs[m][n].x;
+          o.y = fmaxf(sc[m] * (v.y + bz[n].y) + sh[m], 0.f) + rs[m][n].y;
+          o.z = fmaxf(sc[m] * (v.z + bz[n].z) + sh[m], 0.f) + rs[m][n].z;
+          o.w = fmaxf(sc[m] * (v.w + bz[n].w) + sh[m], 0.f) + rs[m][n].w;
+          *reinterpret_cast<f32x4 *>(a.y + row * a.N + col) = o;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < MREP; ++m) {
     const int64_t row = m0 + m * 16 + li;
