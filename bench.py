@@ -37,7 +37,9 @@ def cpu_baseline(seconds: float, seed: int):
     """The CPU oracle (restatement of the reference path) timed on this host."""
     import torch
     from oracle import mdx_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # torch-CPU collapses when oversubscribed on the 256-core GPU host (0.07x RT at 256 threads);
+    # 32 threads is where the conv-heavy net stops scaling.  `cores` reports what was used.
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     d = O.NetDims()
     sd = O.make_convtdf_state(d, seed=0)
     mix = O.synth_mix(int(SR * seconds), seed=seed)
@@ -59,7 +61,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--seconds", type=float, default=SONG_SECONDS)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="length of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -125,7 +127,7 @@ def main():
         eng.profile_enable(False)
         c = prof["conv3x3"]
         ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
-        roofline = {"kernel": "conv_mfma_kernel<3x3> (TFC convs)", "bound": "mfma", "achieved": round(ach, 2),
+        roofline = {"kernel": "conv_dma_kernel<3,3,1,1,3,8,2,0> (TFC 3x3 convs)", "bound": "mfma", "achieved": round(ach, 2),
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                     "traffic": None, "launches": c["launches"],
                     "avg_launch_ms": round(c["ms"] / max(1, c["launches"]), 4),
