@@ -127,9 +127,17 @@ def main():
         eng.profile_enable(False)
         c = prof["conv3x3"]
         ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+        # HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the gfx950
+        # correction + WRITE_SIZE), scaled by this run's algorithmic bytes per launch
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_conv3x3.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                traffic = round(json.load(fh)["traffic_over_algorithmic"] * c["bytes"] / max(1, c["launches"]), 1)
         roofline = {"kernel": "conv_dma_kernel<3,3,1,1,3,8,2,0> (TFC 3x3 convs)", "bound": "mfma", "achieved": round(ach, 2),
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": None, "launches": c["launches"],
+                    "traffic": traffic, "algorithmic_bytes_per_launch": c["bytes"] / max(1, c["launches"]),
+                    "launches": c["launches"],
                     "avg_launch_ms": round(c["ms"] / max(1, c["launches"]), 4),
                     "flops_per_launch": c["flops"] / max(1, c["launches"]),
                     "share_of_step_ms": round(c["ms"], 2)}
