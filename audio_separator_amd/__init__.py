@@ -9,3 +9,4 @@ __path__.append(_pkg)
 from .engine import Engine, AsxError, MDXConfig, NetConfig, lib_path  # noqa: E402,F401
 from .weights import fold_convtdf_state  # noqa: E402,F401
 from .mdx import STFT, MDXDemixer  # noqa: E402,F401
+from .onnx_reader import convtdf_from_onnx, OnnxFormatError  # noqa: E402,F401

@@ -158,6 +158,17 @@ int asx_demix_chunks_dev(asx_engine *e, const float *mix_dev, int64_t n_samples,
 int asx_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t n_samples, float *out_dev,
                      uint32_t flags, void *stream);
 
+/* The array part of MDXSeparator.separate (mdx_separator.py:155-182) without leaving the device:
+ *   peak = max|mix|; normalize(mix, max_peak, min_peak) IN PLACE (uvr_lib_v5/spec_utils.py:99-115);
+ *   primary = demix(mix).T * peak; secondary = (-primary * compensate) + mix.T.
+ * mix [2,N] is overwritten with the normalised mix (like the reference's in-place normalize);
+ * primary / secondary are [N,2] (interleaved stereo, the layout write_audio consumes,
+ * common_separator.py:330-337).  has_min_peak = 0 mirrors min_peak=None. */
+int asx_separate(asx_engine *e, float *mix_host, int64_t n_samples, float max_peak, float min_peak,
+                 int32_t has_min_peak, float compensate, float *primary_host, float *secondary_host);
+int asx_separate_dev(asx_engine *e, float *mix_dev, int64_t n_samples, float max_peak, float min_peak,
+                     int32_t has_min_peak, float compensate, float *primary_dev, float *secondary_dev, void *stream);
+
 /* ---- stage hooks (host buffers; mirror the reference's own test surface) ---- */
 /* STFT.__call__ (stft.py:20): wave [B,2,C] -> spec [B,4,dim_f,C/hop+1]. */
 int asx_stft(asx_engine *e, const float *wave_host, int32_t batch, int64_t n_time, float *spec_host);

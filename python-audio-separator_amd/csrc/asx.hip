@@ -124,7 +124,7 @@ struct asx_engine {
   std::vector<ConvLayer> ds, us;
   // workspace
   int ws_batch = 0;  // chunks the workspace is sized for
-  DevBuf spec_in, spec_out, R[3], H, frames, chunk_out, d_starts, d_nact;
+  DevBuf spec_in, spec_out, R[3], H, frames, chunk_out, d_starts, d_nact, d_peak, d_demixed;
   std::vector<DevBuf> skip;
   // profiling
   bool prof = false;
@@ -763,6 +763,8 @@ void asx_engine_destroy(asx_engine *e) {
   e->chunk_out.release();
   e->d_starts.release();
   e->d_nact.release();
+  e->d_peak.release();
+  e->d_demixed.release();
   for (auto &sk : e->skip) sk.release();
   delete e;
 }
@@ -1055,6 +1057,65 @@ int asx_demix(asx_engine *e, const float *mix_host, int64_t N, float *out_host, 
   }
   dmix.release();
   dout.release();
+  return rc;
+}
+
+// ---- stem algebra ------------------------------------------------------------
+int asx_separate_dev(asx_engine *e, float *mix_dev, int64_t N, float max_peak, float min_peak, int32_t has_min,
+                     float compensate, float *primary_dev, float *secondary_dev, void *stream) {
+  REQUIRE(e && mix_dev && primary_dev && secondary_dev, "asx_separate_dev: null argument");
+  REQUIRE(N >= 1, "n_samples must be >= 1");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  CHK(e->d_peak.ensure(256));
+  CHK(e->d_demixed.ensure((size_t)2 * N * 4));
+  unsigned int *pk = reinterpret_cast<unsigned int *>(e->d_peak.p);
+  HIPCHK(hipMemsetAsync(pk, 0, 4, s));
+  const int64_t n2 = 2 * N;
+  const unsigned nb = (unsigned)std::min<int64_t>((n2 + 255) / 256, 2048);
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 4.0 * n2, s, [&]() {
+    hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, s, mix_dev, n2, pk);
+  }));
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 8.0 * n2, s, [&]() {
+    hipLaunchKernelGGL(normalize_kernel, dim3(nb), dim3(256), 0, s, mix_dev, n2, pk, max_peak, min_peak, has_min);
+  }));
+  CHK(asx_demix_dev(e, mix_dev, N, e->d_demixed.f(), 0, stream));
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 4.0 * 4 * n2, s, [&]() {
+    hipLaunchKernelGGL(stems_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, e->d_demixed.f(), mix_dev, N,
+                       pk, compensate, primary_dev, secondary_dev);
+  }));
+  return ASX_OK;
+}
+
+int asx_separate(asx_engine *e, float *mix_host, int64_t N, float max_peak, float min_peak, int32_t has_min,
+                 float compensate, float *primary_host, float *secondary_host) {
+  REQUIRE(e && mix_host && primary_host && secondary_host, "asx_separate: null argument");
+  REQUIRE(N >= 1, "n_samples must be >= 1");
+  HIPCHK(hipSetDevice(e->device));
+  DevBuf dmix, dp, ds;
+  const size_t bytes = (size_t)2 * N * 4;
+  int rc = dmix.ensure(bytes);
+  if (rc == ASX_OK) rc = dp.ensure(bytes);
+  if (rc == ASX_OK) rc = ds.ensure(bytes);
+  if (rc == ASX_OK && hipMemcpy(dmix.p, mix_host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    set_err("asx_separate: H2D copy failed");
+    rc = ASX_ERR_HIP;
+  }
+  if (rc == ASX_OK)
+    rc = asx_separate_dev(e, dmix.f(), N, max_peak, min_peak, has_min, compensate, dp.f(), ds.f(), nullptr);
+  if (rc == ASX_OK && hipStreamSynchronize(nullptr) != hipSuccess) {
+    set_err("asx_separate: device execution failed: %s", hipGetErrorString(hipGetLastError()));
+    rc = ASX_ERR_HIP;
+  }
+  if (rc == ASX_OK && (hipMemcpy(mix_host, dmix.p, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+                       hipMemcpy(primary_host, dp.p, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+                       hipMemcpy(secondary_host, ds.p, bytes, hipMemcpyDeviceToHost) != hipSuccess)) {
+    set_err("asx_separate: D2H copy failed");
+    rc = ASX_ERR_HIP;
+  }
+  dmix.release();
+  dp.release();
+  ds.release();
   return rc;
 }
 

@@ -360,6 +360,53 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__
   out[(int64_t)ch * N + i] = acc / div;
 }
 
+// ---------------------------------------------------------------------------
+// Stem algebra of MDXSeparator.separate (mdx_separator.py:155-182) on the device:
+//   peak = max|mix|                               (absmax_kernel -> *peak_bits, float bits of a value >= 0)
+//   mix *= thr / peak  if peak > thr  (elif peak < amp: mix *= amp / peak)     spec_utils.py:99-115, in place
+//   primary[i, ch]   = demixed[ch, i] * peak                                   mdx_separator.py:159
+//   secondary[i, ch] = (-primary[i, ch] * compensate) + mix[ch, i]             mdx_separator.py:182
+// All arithmetic is float32 with one rounding per operation (numpy semantics; no fma contraction).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned int *peak_bits) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    atomicMax(peak_bits, __float_as_uint(m));   // non-negative floats order like their bit patterns
+  }
+}
+
+__global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ x, int64_t n, const unsigned int *peak_bits,
+                                                        float max_peak, float min_peak, int has_min) {
+  const float maxv = __uint_as_float(*peak_bits);
+  float scale;
+  if (maxv > max_peak) scale = __fdiv_rn(max_peak, maxv);
+  else if (has_min && maxv < min_peak) scale = __fdiv_rn(min_peak, maxv);
+  else return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = __fmul_rn(x[i], scale);
+}
+
+__global__ __launch_bounds__(256) void stems_kernel(const float *__restrict__ demixed, const float *__restrict__ mix,
+                                                    int64_t N, const unsigned int *peak_bits, float compensate,
+                                                    float *__restrict__ primary, float *__restrict__ secondary) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float peak = __uint_as_float(*peak_bits);
+  const float p0 = __fmul_rn(demixed[i], peak), p1 = __fmul_rn(demixed[N + i], peak);
+  const float s0 = __fadd_rn(__fmul_rn(-p0, compensate), mix[i]);
+  const float s1 = __fadd_rn(__fmul_rn(-p1, compensate), mix[N + i]);
+  reinterpret_cast<float2 *>(primary)[i] = make_float2(p0, p1);
+  reinterpret_cast<float2 *>(secondary)[i] = make_float2(s0, s1);
+}
+
 // [B,4,F,T] <-> [B,4,T,F] (test hooks only; the path itself stays in [.,T,F]).
 __global__ void transpose_last2_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
   __shared__ float tile[32][33];

@@ -79,7 +79,7 @@ _lib = None
 # every symbol include/asx.h declares
 SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_create", "asx_engine_destroy",
            "asx_net_begin", "asx_net_set_tensor", "asx_net_commit", "asx_net_flops", "asx_plan_query", "asx_demix",
-           "asx_demix_dev", "asx_demix_chunks_dev", "asx_finalize_dev", "asx_stft", "asx_istft", "asx_net_forward",
+           "asx_demix_dev", "asx_demix_chunks_dev", "asx_finalize_dev", "asx_separate", "asx_separate_dev", "asx_stft", "asx_istft", "asx_net_forward",
            "asx_run_model", "asx_op_conv", "asx_op_tdf", "asx_profile_enable", "asx_profile_read"]
 
 
@@ -117,6 +117,9 @@ def load_library():
     lib.asx_demix_dev.argtypes = [vp, vp, i64, vp, u32, vp]
     lib.asx_demix_chunks_dev.argtypes = [vp, vp, i64, i32, i32, vp, u32, vp]
     lib.asx_finalize_dev.argtypes = [vp, vp, i64, vp, u32, vp]
+    f32 = C.c_float
+    lib.asx_separate.argtypes = [vp, _FP, i64, f32, f32, i32, f32, _FP, _FP]
+    lib.asx_separate_dev.argtypes = [vp, vp, i64, f32, f32, i32, f32, vp, vp, vp]
     lib.asx_stft.argtypes = [vp, _FP, i32, i64, _FP]
     lib.asx_istft.argtypes = [vp, _FP, i32, i32, _FP]
     lib.asx_net_forward.argtypes = [vp, _FP, i32, _FP]
@@ -220,6 +223,27 @@ class Engine:
                      stream: int = 0):
         self._check(self._lib.asx_finalize_dev(self._h, chunk_out_ptr, n_samples, out_ptr,
                                                ASX_FLAG_MATCH_MIX if is_match_mix else 0, stream or None))
+
+    def separate(self, mix: np.ndarray, max_peak: float, min_peak, compensate: float):
+        """Stem algebra of MDXSeparator.separate on the device.  ``mix`` (float32 [2,N], C-contiguous) is
+        normalised IN PLACE like the reference does; returns (primary [N,2], secondary [N,2])."""
+        if mix.dtype != np.float32 or not mix.flags.c_contiguous or mix.ndim != 2 or mix.shape[0] != 2:
+            raise ValueError("mix must be a C-contiguous float32 array of shape [2, N]")
+        n = mix.shape[1]
+        primary = np.empty((n, 2), np.float32)
+        secondary = np.empty((n, 2), np.float32)
+        self._check(self._lib.asx_separate(self._h, _ptr(mix), n, float(max_peak),
+                                           float(min_peak) if min_peak is not None else 0.0,
+                                           int(min_peak is not None), float(compensate), _ptr(primary),
+                                           _ptr(secondary)))
+        return primary, secondary
+
+    def separate_dev(self, mix_ptr: int, n_samples: int, max_peak: float, min_peak, compensate: float,
+                     primary_ptr: int, secondary_ptr: int, stream: int = 0):
+        self._check(self._lib.asx_separate_dev(self._h, mix_ptr, n_samples, float(max_peak),
+                                               float(min_peak) if min_peak is not None else 0.0,
+                                               int(min_peak is not None), float(compensate), primary_ptr,
+                                               secondary_ptr, stream or None))
 
     # -- stage hooks ----------------------------------------------------------
     def stft(self, wave: np.ndarray) -> np.ndarray:

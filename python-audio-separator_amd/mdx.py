@@ -96,6 +96,7 @@ class MDXDemixer:
         self.logger = common_config.get("logger") or logging.getLogger(__name__)
         self.torch_device = common_config.get("torch_device")
         self.model_data = common_config.get("model_data") or {}
+        self.model_path = common_config.get("model_path")
         self.normalization_threshold = common_config.get("normalization_threshold", 0.9)
         self.amplification_threshold = common_config.get("amplification_threshold", 0.0)
         self.invert_using_spec = common_config.get("invert_using_spec", False)
@@ -122,20 +123,28 @@ class MDXDemixer:
         self.stft = None
         self.primary_source = None
         self.secondary_source = None
-        if state_dict is not None:
+        if state_dict is not None or self.model_path:
             self.load_model(state_dict, net_config)
 
-    def load_model(self, state_dict: dict, net_config: NetConfig | None = None):
-        """Replaces ort.InferenceSession(model_path) (mdx_separator.py:108-133)."""
+    def load_model(self, state_dict: dict | None = None, net_config: NetConfig | None = None):
+        """Replaces ort.InferenceSession(model_path) (mdx_separator.py:108-133).
+
+        With no ``state_dict`` the ``.onnx`` file at ``common_config["model_path"]`` is read
+        (onnx_reader.convtdf_from_onnx); a ConvTDFNet ``state_dict`` (torch as the weight
+        container) takes precedence when given."""
         if self.segment_size != self.dim_t:
             # the reference falls back to onnx2torch here; the graph is fully convolutional
             # except for the TDF linears, whose width is tied to dim_f only, so any segment works
             self.logger.warning("segment_size != dim_t: running the net on the requested segment size")
-        if net_config is None:
-            net_config = NetConfig(dim_f=self.dim_f, dim_t=self.segment_size)
+        if state_dict is None:
+            from .onnx_reader import convtdf_from_onnx
+            net_config, tensors = convtdf_from_onnx(self.model_path, dim_t=self.segment_size)
+        else:
+            if net_config is None:
+                net_config = NetConfig(dim_f=self.dim_f, dim_t=self.segment_size)
+            tensors = fold_convtdf_state(state_dict, net_config.num_blocks, net_config.l, net_config.tdf_bias)
         if net_config.dim_t != self.segment_size or net_config.dim_f != self.dim_f:
-            raise ValueError("net_config.dim_t/dim_f must match segment_size/dim_f")
-        tensors = fold_convtdf_state(state_dict, net_config.num_blocks, net_config.l, net_config.tdf_bias)
+            raise ValueError("net dim_t/dim_f must match segment_size/dim_f")
         self.engine.load_net(net_config, tensors)
         self.net_config = net_config
 
@@ -168,15 +177,13 @@ class MDXDemixer:
         ``mix`` [2, N] is normalised in place like the reference's
         spec_utils.normalize call; returns (primary [N,2], secondary [N,2]).
         """
-        peak = np.abs(mix).max()
-        maxv = peak
-        if maxv > self.normalization_threshold:
-            mix *= self.normalization_threshold / maxv
-        elif self.amplification_threshold is not None and maxv < self.amplification_threshold:
-            mix *= self.amplification_threshold / maxv
-        source = self.demix(mix) * peak
-        self.primary_source = source.T
         if self.invert_using_spec:
             raise NotImplementedError("invert_using_spec (spec_utils.invert_stem) is outside the accelerated path")
-        self.secondary_source = (-self.primary_source * self.compensate) + mix.T
+        self.initialize_model_settings()
+        if mix.ndim != 2 or mix.shape[0] != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got {mix.shape[0] if mix.ndim else 0} channels")
+        if mix.shape[1] == 0:
+            raise ValueError("Audio file is empty or not valid")
+        self.primary_source, self.secondary_source = self.engine.separate(
+            mix, self.normalization_threshold, self.amplification_threshold, self.compensate)
         return self.primary_source, self.secondary_source

@@ -1,0 +1,337 @@
+"""Minimal ONNX reader for MDX-Net (ConvTDFNet) model files.
+
+The reference hands ``model_path`` to ``ort.InferenceSession`` (mdx_separator.py:122)
+or ``onnx2torch.convert`` (:126-132).  This module replaces both for the weight
+side: it parses the protobuf wire format of an ``.onnx`` file directly (the image
+has neither ``onnx`` nor ``onnxruntime``), walks ``graph.node`` in execution order
+and maps the ConvTDFNet pattern (uvr_lib_v5/mdxnet.py:54-120) onto the engine's
+canonical tensors (include/asx.h), folding BatchNormalization nodes in float64.
+
+Only the ONNX features such exports use are understood: Conv, ConvTranspose,
+MatMul (+ optional bias Add), BatchNormalization, Relu, Add, Mul, Transpose; fp32
+initialisers stored as ``raw_data`` or ``float_data``.  Anything else raises
+``OnnxFormatError`` rather than guessing.
+
+Field numbers follow onnx.proto3 (ModelProto.graph = 7; GraphProto.node = 1,
+initializer = 5, input = 11; NodeProto.input = 1, output = 2, op_type = 4,
+attribute = 5; AttributeProto.name = 1, f = 2, i = 3, ints = 8; TensorProto.dims = 1,
+data_type = 2, float_data = 4, name = 8, raw_data = 9).
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .engine import NetConfig
+
+
+class OnnxFormatError(ValueError):
+    pass
+
+
+# ---------------------------------------------------------------------------
+# protobuf wire format
+# ---------------------------------------------------------------------------
+def _varint(b: bytes, i: int):
+    shift = 0
+    val = 0
+    while True:
+        c = b[i]
+        i += 1
+        val |= (c & 0x7F) << shift
+        if not c & 0x80:
+            return val, i
+        shift += 7
+        if shift > 70:
+            raise OnnxFormatError("varint too long")
+
+
+def _fields(b):
+    """Yield (field_number, wire_type, value) for one message."""
+    i, n = 0, len(b)
+    while i < n:
+        key, i = _varint(b, i)
+        fno, wt = key >> 3, key & 7
+        if wt == 0:
+            v, i = _varint(b, i)
+        elif wt == 1:
+            v = b[i:i + 8]
+            i += 8
+        elif wt == 2:
+            ln, i = _varint(b, i)
+            v = b[i:i + ln]
+            i += ln
+        elif wt == 5:
+            v = b[i:i + 4]
+            i += 4
+        else:
+            raise OnnxFormatError(f"unsupported wire type {wt}")
+        yield fno, wt, v
+
+
+def _packed_varints(v) -> list:
+    out, i = [], 0
+    while i < len(v):
+        x, i = _varint(v, i)
+        out.append(x)
+    return out
+
+
+def _sint64(x: int) -> int:
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+@dataclass
+class Node:
+    op: str = ""
+    inputs: list = field(default_factory=list)
+    outputs: list = field(default_factory=list)
+    attrs: dict = field(default_factory=dict)
+
+
+def _parse_tensor(b) -> tuple:
+    dims, dtype, name, raw, floats = [], 0, "", None, []
+    for fno, wt, v in _fields(b):
+        if fno == 1:
+            dims += _packed_varints(v) if wt == 2 else [v]
+        elif fno == 2:
+            dtype = v
+        elif fno == 8:
+            name = bytes(v).decode()
+        elif fno == 9:
+            raw = bytes(v)
+        elif fno == 4:
+            if wt == 2:
+                floats += list(struct.unpack(f"<{len(v) // 4}f", v))
+            else:
+                floats.append(struct.unpack("<f", v)[0])
+        elif fno in (13, 14) and v:
+            raise OnnxFormatError(f"initializer '{name}' uses external data, which is not supported")
+    if dtype == 1:      # FLOAT
+        arr = np.frombuffer(raw, dtype="<f4") if raw is not None else np.asarray(floats, dtype=np.float32)
+    elif dtype == 7:    # INT64 (shape constants etc.)
+        arr = np.frombuffer(raw, dtype="<i8") if raw is not None else np.zeros(0, np.int64)
+    else:
+        return name, None
+    shape = [int(_sint64(d)) for d in dims]
+    if shape and int(np.prod(shape)) != arr.size:
+        raise OnnxFormatError(f"initializer '{name}': {arr.size} values for shape {shape}")
+    return name, (arr.reshape(shape) if shape else arr)
+
+
+def _parse_attr(b):
+    name, val = "", None
+    ints = []
+    for fno, wt, v in _fields(b):
+        if fno == 1:
+            name = bytes(v).decode()
+        elif fno == 2:
+            val = struct.unpack("<f", v)[0]
+        elif fno == 3:
+            val = _sint64(v)
+        elif fno == 4:
+            val = bytes(v)
+        elif fno == 8:
+            ints += [_sint64(x) for x in _packed_varints(v)] if wt == 2 else [_sint64(v)]
+    return name, (ints if ints else val)
+
+
+def _parse_node(b) -> Node:
+    n = Node()
+    for fno, wt, v in _fields(b):
+        if fno == 1:
+            n.inputs.append(bytes(v).decode())
+        elif fno == 2:
+            n.outputs.append(bytes(v).decode())
+        elif fno == 4:
+            n.op = bytes(v).decode()
+        elif fno == 5:
+            k, val = _parse_attr(v)
+            n.attrs[k] = val
+    return n
+
+
+def _parse_value_info_shape(b):
+    """ValueInfoProto -> (name, [dims or None])."""
+    name, dims = "", None
+    for fno, wt, v in _fields(b):
+        if fno == 1:
+            name = bytes(v).decode()
+        elif fno == 2:                                   # TypeProto
+            for f2, _, v2 in _fields(v):
+                if f2 == 1:                              # tensor_type
+                    for f3, _, v3 in _fields(v2):
+                        if f3 == 2:                      # shape
+                            dims = []
+                            for f4, _, v4 in _fields(v3):
+                                if f4 == 1:              # dim
+                                    dv = None
+                                    for f5, w5, v5 in _fields(v4):
+                                        if f5 == 1 and w5 == 0:
+                                            dv = _sint64(v5)
+                                    dims.append(dv)
+    return name, dims
+
+
+def parse_onnx(path_or_bytes):
+    """-> (nodes in graph order, {initializer name: ndarray}, {graph input name: dims})."""
+    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    data = memoryview(bytes(data))
+    graph = None
+    for fno, wt, v in _fields(data):
+        if fno == 7 and wt == 2:
+            graph = v
+    if graph is None:
+        raise OnnxFormatError("no GraphProto (field 7) in the file: not an ONNX model")
+    nodes, inits, inputs = [], {}, {}
+    for fno, wt, v in _fields(graph):
+        if fno == 1:
+            nodes.append(_parse_node(v))
+        elif fno == 5:
+            name, arr = _parse_tensor(v)
+            if arr is not None:
+                inits[name] = arr
+        elif fno == 11:
+            name, dims = _parse_value_info_shape(v)
+            inputs[name] = dims
+    return nodes, inits, inputs
+
+
+# ---------------------------------------------------------------------------
+# ConvTDFNet pattern -> engine tensors
+# ---------------------------------------------------------------------------
+def _bn_affine(node: Node, inits):
+    g, b, m, v = (np.asarray(inits[n], np.float64) for n in node.inputs[1:5])
+    eps = float(node.attrs.get("epsilon", 1e-5))
+    scale = g / np.sqrt(v + eps)
+    return scale, b - m * scale
+
+
+def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
+    """Read an MDX-Net ``.onnx`` -> (NetConfig, {canonical name: float32 array}).
+
+    ``dim_t`` overrides the time size found in the graph input (the net is
+    convolutional in time; the reference re-exports through onnx2torch when
+    segment_size != dim_t, mdx_separator.py:126-132)."""
+    nodes, inits, ginputs = parse_onnx(path_or_bytes)
+    consumers: dict = {}
+    for idx, n in enumerate(nodes):
+        for i in n.inputs:
+            consumers.setdefault(i, []).append(idx)
+
+    def next_op(idx, op):
+        """The single consumer of node idx's output if it is `op` (else None)."""
+        outs = consumers.get(nodes[idx].outputs[0], [])
+        if len(outs) == 1 and nodes[outs[0]].op == op:
+            return outs[0]
+        return None
+
+    layers = []   # ("conv", k, stride, w[cout,cin,kh,kw], b) | ("convT", w[cin,cout,2,2], b) | ("lin", w[n,k], bias|None, scale, shift)
+    for idx, n in enumerate(nodes):
+        if n.op == "Conv":
+            w = np.asarray(inits[n.inputs[1]], np.float64)
+            b = np.asarray(inits[n.inputs[2]], np.float64) if len(n.inputs) > 2 else np.zeros(w.shape[0])
+            j = next_op(idx, "BatchNormalization")
+            if j is not None:
+                s, sh = _bn_affine(nodes[j], inits)
+                w, b = w * s[:, None, None, None], b * s + sh
+            ks = n.attrs.get("kernel_shape", list(w.shape[2:]))
+            st = n.attrs.get("strides", [1, 1])
+            if n.attrs.get("group", 1) != 1 or any(d != 1 for d in n.attrs.get("dilations", [1, 1])):
+                raise OnnxFormatError("grouped / dilated Conv is not part of ConvTDFNet")
+            layers.append(("conv", int(ks[0]), int(st[0]), w, b))
+        elif n.op == "ConvTranspose":
+            w = np.asarray(inits[n.inputs[1]], np.float64)
+            b = np.asarray(inits[n.inputs[2]], np.float64) if len(n.inputs) > 2 else np.zeros(w.shape[1])
+            j = next_op(idx, "BatchNormalization")
+            if j is not None:
+                s, sh = _bn_affine(nodes[j], inits)
+                w, b = w * s[None, :, None, None], b * s + sh
+            layers.append(("convT", w, b))
+        elif n.op == "MatMul":
+            wname = n.inputs[1] if n.inputs[1] in inits else (n.inputs[0] if n.inputs[0] in inits else None)
+            if wname is None:
+                raise OnnxFormatError("MatMul without a constant operand")
+            w = np.asarray(inits[wname], np.float64).T            # exporter stores W^T [in, out]
+            bias = None
+            j = idx
+            ja = next_op(idx, "Add")
+            if ja is not None and any(i in inits for i in nodes[ja].inputs):
+                bias = np.asarray(inits[[i for i in nodes[ja].inputs if i in inits][0]], np.float64)
+                j = ja
+            jb = next_op(j, "BatchNormalization")
+            if jb is None:
+                raise OnnxFormatError("TDF Linear without BatchNormalization (adamw/GroupNorm variant is unsupported)")
+            s, sh = _bn_affine(nodes[jb], inits)
+            layers.append(("lin", w, bias, s, sh))
+        elif n.op in ("Gemm", "GroupNormalization", "InstanceNormalization", "LSTM"):
+            raise OnnxFormatError(f"op {n.op} is not part of the BatchNorm ConvTDFNet this engine runs")
+
+    if len(layers) < 4 or layers[0][0] != "conv" or layers[0][1] != 1:
+        raise OnnxFormatError("graph does not start with the 1x1 first_conv of ConvTDFNet")
+    out: dict = {}
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    first = layers[0]
+    g, dim_c = first[3].shape[0], first[3].shape[1]
+    out["first.w"], out["first.b"] = f32(first[3].reshape(g, dim_c)), f32(first[4])
+    pos = 1
+
+    def take_block(dst):
+        nonlocal pos
+        l = 0
+        while pos < len(layers) and layers[pos][0] == "conv" and layers[pos][1] == 3:
+            out[f"{dst}.tfc{l}.w"], out[f"{dst}.tfc{l}.b"] = f32(layers[pos][3]), f32(layers[pos][4])
+            l += 1
+            pos += 1
+        dims = []
+        for t in range(2):
+            if pos >= len(layers) or layers[pos][0] != "lin":
+                raise OnnxFormatError(f"{dst}: expected TDF linear #{t}")
+            _, w, bias, s, sh = layers[pos]
+            out[f"{dst}.tdf{t}.w"] = f32(w)
+            if bias is not None:
+                out[f"{dst}.tdf{t}.bias"] = f32(bias)
+            out[f"{dst}.tdf{t}.scale"], out[f"{dst}.tdf{t}.shift"] = f32(s), f32(sh)
+            dims.append(w.shape)
+            pos += 1
+        return l, dims
+
+    l0, dims0 = take_block("enc0")
+    dim_f = dims0[0][1]
+    bn = dim_f // dims0[0][0]
+    has_bias = "enc0.tdf0.bias" in out
+    # encoder: blocks separated by 2x2 stride-2 convs
+    enc_blocks = 1
+    n = 0
+    while pos < len(layers) and layers[pos][0] == "conv" and layers[pos][1] == 2 and layers[pos][2] == 2:
+        out[f"ds{n}.w"], out[f"ds{n}.b"] = f32(layers[pos][3]), f32(layers[pos][4])
+        pos += 1
+        n += 1
+        name = f"enc{enc_blocks}"
+        take_block(name)
+        enc_blocks += 1
+    # the block after the last ds is the bottleneck: rename enc<n> -> mid
+    for k in [k for k in out if k.startswith(f"enc{n}.")]:
+        out["mid." + k.split(".", 1)[1]] = out.pop(k)
+    for i in range(n):
+        if pos >= len(layers) or layers[pos][0] != "convT":
+            raise OnnxFormatError(f"expected ConvTranspose us{i}")
+        out[f"us{i}.w"], out[f"us{i}.b"] = f32(layers[pos][1]), f32(layers[pos][2])
+        pos += 1
+        take_block(f"dec{i}")
+    if pos != len(layers) - 1 or layers[pos][0] != "conv" or layers[pos][1] != 1:
+        raise OnnxFormatError("graph does not end with the 1x1 final_conv of ConvTDFNet")
+    fw = layers[pos][3]
+    out["final.w"], out["final.b"] = f32(fw.reshape(fw.shape[0], fw.shape[1])), f32(layers[pos][4])
+
+    if dim_t is None:
+        for name, dims in ginputs.items():
+            if name not in inits and dims and len(dims) == 4 and dims[3]:
+                dim_t = int(dims[3])
+        if dim_t is None:
+            raise OnnxFormatError("time size not recorded in the graph input; pass dim_t")
+    cfg = NetConfig(dim_c=int(dim_c), dim_f=int(dim_f), dim_t=int(dim_t), g=int(g), l=int(l0),
+                    num_blocks=2 * n + 1, k=3, bn=int(bn), tdf_bias=bool(has_bias))
+    return cfg, out

@@ -385,3 +385,38 @@ def test_full_song_properties(A):
         eng.close()
     assert outs[0].shape == (2, N) and np.isfinite(outs[0]).all()
     assert np.array_equal(outs[0], outs[1])
+
+
+# ---------------------------------------------------------------------------
+# model-file loading (ONNX) and the device-side stem algebra
+# ---------------------------------------------------------------------------
+def test_onnx_model_file_end_to_end(A, golden_dir):
+    # an .onnx written by torch's exporter from the reference ConvTDFNet -> reader -> engine -> golden demix
+    g = np.load(os.path.join(golden_dir, "demix_small.npz"))
+    N = int(g["N"])
+    mix = (0.4 * np.random.default_rng(int(g["mix_seed"])).standard_normal((2, N))).astype(np.float32)
+    dm = A.MDXDemixer({"model_data": {"compensate": 1.0, "mdx_dim_f_set": 32, "mdx_dim_t_set": 4,
+                                       "mdx_n_fft_scale_set": 96}, "torch_device": 0,
+                       "model_path": os.path.join(golden_dir, "net_small.onnx")},
+                      {"segment_size": 16, "overlap": 0.25, "hop_length": 16, "enable_denoise": False})
+    assert (dm.net_config.g, dm.net_config.l, dm.net_config.num_blocks, dm.net_config.bn) == (8, 2, 5, 4)
+    out = dm.demix(mix)
+    assert rel_rms(out, g["ov25"]) < TOL_STEM, rel_rms(out, g["ov25"])
+
+
+def test_separate_on_device_bit_exact_algebra(A):
+    # normalisation and the stem algebra are single-rounding float32 ops: identical to numpy given the same demix
+    eng, sd, d = small_engine(A)
+    rng = np.random.default_rng(5)
+    for scale in (0.8, 0.2):                      # with and without normalisation kicking in
+        mix = (scale * rng.standard_normal((2, 2500))).astype(np.float32)
+        ref_mix = mix.copy()
+        peak = np.abs(ref_mix).max()
+        ref_mix = O.normalize(ref_mix, 0.9, 0.0)
+        dem = eng.demix(ref_mix)
+        ref_primary = (dem * peak).T
+        ref_secondary = (-ref_primary * 1.035) + ref_mix.T
+        primary, secondary = eng.separate(mix, 0.9, 0.0, 1.035)
+        assert np.array_equal(mix, ref_mix)
+        assert np.array_equal(primary, ref_primary)
+        assert np.array_equal(secondary, ref_secondary)

@@ -1,0 +1,45 @@
+"""ONNX reader (model-file loading stays drop-in) against .onnx files written by
+torch's own exporter from the reference ConvTDFNet class (tests/golden/make_onnx_fixture.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mdx_oracle as O
+from audio_separator_amd.onnx_reader import OnnxFormatError, convtdf_from_onnx, parse_onnx
+from audio_separator_amd.weights import fold_convtdf_state
+
+
+@pytest.mark.parametrize("fname,bias,seed", [("net_small.onnx", False, 3), ("net_small_bias.onnx", True, 4)])
+def test_reader_recovers_config_and_weights(golden_dir, fname, bias, seed):
+    cfg, tensors = convtdf_from_onnx(os.path.join(golden_dir, fname))
+    assert (cfg.dim_c, cfg.dim_f, cfg.dim_t, cfg.g, cfg.l, cfg.num_blocks, cfg.k, cfg.bn, cfg.tdf_bias) == \
+        (4, 32, 16, 8, 2, 5, 3, 4, bias)
+    d = O.NetDims(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=4, bias=bias)
+    want = fold_convtdf_state(O.make_convtdf_state(d, seed=seed), d.num_blocks, d.l, tdf_bias=bias)
+    assert sorted(tensors) == sorted(want)
+    for k in want:
+        assert tensors[k].shape == want[k].shape, k
+        assert tensors[k].dtype == np.float32
+        # the exporter folds conv+BN in float32, we fold in float64
+        assert np.allclose(tensors[k], want[k], rtol=2e-6, atol=2e-7), k
+
+
+def test_graph_structure(golden_dir):
+    nodes, inits, inputs = parse_onnx(os.path.join(golden_dir, "net_small.onnx"))
+    ops = [n.op for n in nodes]
+    assert ops[0] == "Conv" and ops[-1] == "Conv" and ops.count("ConvTranspose") == 2 and ops.count("MatMul") == 10
+    assert inputs["input"] == [1, 4, 32, 16]
+    assert all(a.dtype in (np.float32, np.int64) for a in inits.values())
+
+
+def test_dim_t_override(golden_dir):
+    cfg, _ = convtdf_from_onnx(os.path.join(golden_dir, "net_small.onnx"), dim_t=32)
+    assert cfg.dim_t == 32
+
+
+def test_rejects_garbage(tmp_path):
+    p = tmp_path / "x.onnx"
+    p.write_bytes(b"\x08\x01\x12\x03abc")          # a valid protobuf without a graph
+    with pytest.raises(OnnxFormatError):
+        convtdf_from_onnx(str(p))
