@@ -391,18 +391,20 @@ __global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ x, i
   else if (has_min && maxv < min_peak) scale = __fdiv_rn(min_peak, maxv);
   else return;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    x[i] = __fmul_rn(x[i], scale);
+    x[i] = x[i] * scale;
 }
 
 __global__ __launch_bounds__(256) void stems_kernel(const float *__restrict__ demixed, const float *__restrict__ mix,
                                                     int64_t N, const unsigned int *peak_bits, float compensate,
                                                     float *__restrict__ primary, float *__restrict__ secondary) {
+#pragma clang fp contract(off)  // numpy rounds the product before the add; an fma would differ by 1 ulp
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const float peak = __uint_as_float(*peak_bits);
-  const float p0 = __fmul_rn(demixed[i], peak), p1 = __fmul_rn(demixed[N + i], peak);
-  const float s0 = __fadd_rn(__fmul_rn(-p0, compensate), mix[i]);
-  const float s1 = __fadd_rn(__fmul_rn(-p1, compensate), mix[N + i]);
+  // plain operators: the pragma above only governs expressions written in this function
+  const float p0 = demixed[i] * peak, p1 = demixed[N + i] * peak;
+  const float t0 = -p0 * compensate, t1 = -p1 * compensate;
+  const float s0 = t0 + mix[i], s1 = t1 + mix[N + i];
   reinterpret_cast<float2 *>(primary)[i] = make_float2(p0, p1);
   reinterpret_cast<float2 *>(secondary)[i] = make_float2(s0, s1);
 }
