@@ -169,6 +169,39 @@ int asx_separate(asx_engine *e, float *mix_host, int64_t n_samples, float max_pe
 int asx_separate_dev(asx_engine *e, float *mix_dev, int64_t n_samples, float max_peak, float min_peak,
                      int32_t has_min_peak, float compensate, float *primary_dev, float *secondary_dev, void *stream);
 
+/* ---- MDXC / TFC-TDF v3 (MDX23C): uvr_lib_v5/tfc_tdf_v3.py + the TFC branch of MDXCSeparator.demix ----
+ * The engine's n_fft / hop_length / dim_f / segment_size (asx_mdx_config) are config.audio.* and
+ * inference.dim_t (or the overridden segment size, mdxc_separator.py:354-359).
+ *   norm: 0 = None, 1 = InstanceNorm (affine)          tfc_tdf_v3.py:55-69
+ *   act:  0 = relu, 1 = gelu                            tfc_tdf_v3.py:72-80
+ * Weights are handed over with asx_net_set_tensor() under the reference's own state_dict keys
+ * (e.g. "encoder_blocks.0.tfc_tdf.blocks.1.tfc1.2.weight"); scale is fixed to [2, 2]. */
+typedef struct asx_v3_config {
+  int32_t num_channels;         /* config.audio.num_channels (2)        */
+  int32_t num_subbands;         /* config.model.num_subbands            */
+  int32_t num_scales;           /* config.model.num_scales              */
+  int32_t num_blocks_per_scale; /* config.model.num_blocks_per_scale    */
+  int32_t num_channels_model;   /* config.model.num_channels            */
+  int32_t growth;               /* config.model.growth                  */
+  int32_t bottleneck_factor;    /* config.model.bottleneck_factor       */
+  int32_t norm;
+  int32_t act;
+  int32_t num_targets;          /* 1 if training.target_instrument else len(training.instruments) */
+} asx_v3_config;
+int asx_v3_begin(asx_engine *e, const asx_v3_config *cfg);
+int asx_v3_commit(asx_engine *e);
+double asx_v3_flops(const asx_engine *e, int32_t batch);
+/* TFC_TDF_net.forward (tfc_tdf_v3.py:230): wave [B,2,chunk] -> [B,S,2,chunk] (S = num_targets). */
+int asx_v3_forward(asx_engine *e, const float *wave_host, int32_t batch, float *out_host);
+/* Index arithmetic of the TFC branch (mdxc_separator.py:361-372): chunk_size, step = hop_size,
+ * pad = pad_size, trim = chunk_size - hop_size (front zeros), padded_len, n_chunks. */
+int asx_mdxc_plan(const asx_engine *e, int64_t n_samples, int32_t overlap, asx_plan *out);
+/* MDXCSeparator.demix, TFC branch (mdxc_separator.py:345-404): mix [2,N] -> out [S,2,N]
+ * (= accumulated[..., chunk-hop : -(pad+chunk-hop)] / overlap). */
+int asx_mdxc_demix(asx_engine *e, const float *mix_host, int64_t n_samples, int32_t overlap, float *out_host);
+int asx_mdxc_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t overlap, float *out_dev,
+                       void *stream);
+
 /* ---- stage hooks (host buffers; mirror the reference's own test surface) ---- */
 /* STFT.__call__ (stft.py:20): wave [B,2,C] -> spec [B,4,dim_f,C/hop+1]. */
 int asx_stft(asx_engine *e, const float *wave_host, int32_t batch, int64_t n_time, float *spec_host);

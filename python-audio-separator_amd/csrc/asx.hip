@@ -108,8 +108,11 @@ struct ProfRec {
   double flops, bytes;
 };
 
+struct V3Net;
+
 struct asx_engine {
   int device = 0;
+  V3Net *v3 = nullptr;
   asx_mdx_config cfg{};
   FftPlan plan{};
   DevBuf d_window, d_tw, d_env;  // env for T = segment_size
@@ -294,7 +297,7 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b) {
 }
 
 template <class CFG>
-static void launch_conv_dma_t(const ConvDmaArgs &a, int nblk, hipStream_t s) {
+static void launch_conv_dma_t(const ConvArgs &a, int nblk, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_dma_kernel<CFG>),
@@ -304,41 +307,59 @@ static void launch_conv_dma_t(const ConvDmaArgs &a, int nblk, hipStream_t s) {
   hipLaunchKernelGGL(conv_dma_kernel<CFG>, dim3(nblk), dim3(256), CFG::LDS_BYTES, s, a);
 }
 
-// x [B,cin,T,F] -> y ; returns output dims through To/Fo.
+// Optional view description of a conv's operands (channel slices of larger buffers).
+struct ConvView {
+  int64_t x_bstride = 0;    // 0 = dense [B, cin, T, F]
+  int64_t y_bstride = 0;    // 0 = dense [B, cout, To, Fo]
+  const float *res = nullptr;
+  int64_t aux_bstride = 0;  // of skip / res; 0 = dense
+  int act = -1;             // -1 = the layer's own activation
+};
+
+// x [B,cin,T,F] -> y
 static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const float *skip, float *y, int B, int T,
-                       int F, hipStream_t s) {
+                       int F, hipStream_t s, const ConvView &v = ConvView()) {
   ConvArgs a{};
   a.x = x;
   a.wp = L.w.f();
   a.bias = L.b.f();
   a.skip = skip;
+  a.res = v.res;
+  a.zeros = e->d_zeros.f();
   a.y = y;
   a.B = B;
   a.Cin = L.cin;
   a.Cout = L.cout;
   a.T = T;
   a.F = F;
-  a.relu = L.relu;
+  a.act = v.act >= 0 ? v.act : (L.relu ? ACT_RELU : ACT_NONE);
   a.CG = L.cg;
   a.NCI = L.nci;
   int cls = ASX_PROF_CONV3X3;
   double taps = 9;
+  int64_t out_plane;
   if (L.kind == CK_DOWN) {
     a.To = T / 2;
     a.Fo = F / 2;
     cls = ASX_PROF_DOWN;
     taps = 4;
+    out_plane = (int64_t)a.To * a.Fo;
   } else {
     a.To = T;
     a.Fo = F;
+    out_plane = (int64_t)T * F;
     if (L.kind == CK_1X1) {
       cls = ASX_PROF_CONV1X1;
       taps = 1;
     } else if (L.kind == CK_UP) {
       cls = ASX_PROF_UP;
       taps = 4;
+      out_plane = (int64_t)4 * T * F;
     }
   }
+  a.x_bstride = v.x_bstride ? v.x_bstride : (int64_t)L.cin * T * F;
+  a.y_bstride = v.y_bstride ? v.y_bstride : (int64_t)L.cout * out_plane;
+  a.aux_bstride = v.aux_bstride ? v.aux_bstride : (int64_t)L.cout * out_plane;
   const int th = conv_tile_h(L.kind);
   a.tilesT = (a.To + th - 1) / th;
   a.tilesF = (a.Fo + 63) / 64;
@@ -347,28 +368,12 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
   const double outpix = (double)B * a.To * a.Fo;
   const double flops = 2.0 * taps * L.cin * L.cout * outpix;
   double bytes = 4.0 * ((double)B * L.cin * T * F + (double)L.cout * outpix * (L.kind == CK_UP ? 4 : 1));
-  if (L.kind == CK_UP) bytes += 4.0 * (double)L.cout * outpix * 4;  // skip read
+  if (L.kind == CK_UP && skip) bytes += 4.0 * (double)L.cout * outpix * 4;  // skip read
+  if (v.res) bytes += 4.0 * (double)L.cout * outpix;
   int bad = 0;
-  const bool dma = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && getenv("ASX_NO_DMA") == nullptr;
-  ConvDmaArgs d{};
-  d.x = a.x;
-  d.wp = a.wp;
-  d.bias = a.bias;
-  d.skip = a.skip;
-  d.zeros = e->d_zeros.f();
-  d.y = a.y;
-  d.B = a.B;
-  d.Cin = a.Cin;
-  d.Cout = a.Cout;
-  d.T = a.T;
-  d.F = a.F;
-  d.To = a.To;
-  d.Fo = a.Fo;
-  d.tilesT = a.tilesT;
-  d.tilesF = a.tilesF;
-  d.CG = a.CG;
-  d.NCI = a.NCI;
-  d.relu = a.relu;
+  const bool dma = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (a.x_bstride % 4 == 0) &&
+                   getenv("ASX_NO_DMA") == nullptr;
+  const ConvArgs &d = a;
 #define ASX_CONV_CASE(KH, KW, S, PAD, NR, KC, RPW, EPI)                                      \
   do {                                                                                       \
     if (dma) launch_conv_dma_t<ConvDmaCfg<KH, KW, S, PAD, NR, KC, RPW, EPI>>(d, nblk, s);    \
@@ -448,13 +453,14 @@ static void launch_tdf_t(const TdfArgs &a, hipStream_t s) {
 }
 
 static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const float *res, float *y, int64_t M,
-                      int T, hipStream_t s) {
+                      int T, hipStream_t s, int relu = 1) {
   TdfArgs a{};
   a.x = x;
   a.w = L.w.f();
   a.bias = L.has_bias ? L.bias.f() : nullptr;
-  a.scale = L.scale.f();
-  a.shift = L.shift.f();
+  a.scale = L.scale.p ? L.scale.f() : nullptr;
+  a.shift = L.shift.p ? L.shift.f() : nullptr;
+  a.relu = relu;
   a.res = res;
   a.y = y;
   a.M = M;
@@ -480,6 +486,7 @@ static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const fl
   d.K = a.K;
   d.C = a.C;
   d.T = a.T;
+  d.relu = a.relu;
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
     if (dma) {
       if (L.n > 128) launch_tdf_dma_t<3, 8>(d, s);       // 128 rows x 192 cols per workgroup
@@ -505,10 +512,12 @@ static int tdf_pack(TdfLayer &L, int n, int k, int c, const float *w, const floa
     CHK(L.bias.ensure((size_t)n * 4));
     HIPCHK(hipMemcpy(L.bias.p, bias, (size_t)n * 4, hipMemcpyHostToDevice));
   }
-  CHK(L.scale.ensure((size_t)c * 4));
-  CHK(L.shift.ensure((size_t)c * 4));
-  HIPCHK(hipMemcpy(L.scale.p, scale, (size_t)c * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(L.shift.p, shift, (size_t)c * 4, hipMemcpyHostToDevice));
+  if (scale && shift) {
+    CHK(L.scale.ensure((size_t)c * 4));
+    CHK(L.shift.ensure((size_t)c * 4));
+    HIPCHK(hipMemcpy(L.scale.p, scale, (size_t)c * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(L.shift.p, shift, (size_t)c * 4, hipMemcpyHostToDevice));
+  }
   return ASX_OK;
 }
 
@@ -721,6 +730,7 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
   return ASX_OK;
 }
 
+static void v3_destroy(V3Net *n);
 static void free_conv(ConvLayer &L) {
   L.w.release();
   L.b.release();
@@ -766,6 +776,7 @@ void asx_engine_destroy(asx_engine *e) {
   e->d_peak.release();
   e->d_demixed.release();
   for (auto &sk : e->skip) sk.release();
+  if (e->v3) v3_destroy(e->v3);
   delete e;
 }
 
@@ -920,6 +931,8 @@ double asx_net_flops(const asx_engine *e, int32_t batch) {
   fl += 2.0 * d.g * d.dim_c * (double)d.dim_t * d.dim_f;
   return fl * batch;
 }
+
+#include "engine_v3.h"
 
 // ---- plan ------------------------------------------------------------------
 int asx_plan_query(const asx_engine *e, int64_t N, uint32_t flags, asx_plan *out) {
@@ -1298,6 +1311,164 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t B, int32_t c, int32_t
   if (res_host) CHK(to_dev(dres, res_host, (size_t)M * n));
   CHK(tdf_launch(e, L, dx.f(), res_host ? dres.f() : nullptr, dy.f(), M, t, nullptr));
   CHK(to_host(y_host, dy, (size_t)M * n));
+  return ASX_OK;
+}
+
+// ---- MDXC / TFC-TDF v3 --------------------------------------------------------------
+int asx_v3_begin(asx_engine *e, const asx_v3_config *cfg) {
+  REQUIRE(e && cfg, "asx_v3_begin: null argument");
+  REQUIRE(cfg->num_channels == 2, "only stereo (num_channels = 2) is supported");
+  REQUIRE(cfg->num_subbands >= 1 && e->cfg.dim_f % cfg->num_subbands == 0, "dim_f must be divisible by num_subbands");
+  REQUIRE(cfg->num_scales >= 1 && cfg->num_blocks_per_scale >= 1 && cfg->num_channels_model > 0 && cfg->growth >= 0 &&
+              cfg->bottleneck_factor >= 1 && cfg->num_targets >= 1,
+          "bad TFC-TDF v3 hyper-parameters");
+  REQUIRE(cfg->norm == 0 || cfg->norm == 1, "norm must be None (0) or InstanceNorm (1)");
+  REQUIRE(cfg->act == 0 || cfg->act == 1, "act must be relu (0) or gelu (1)");
+  const int fs = e->cfg.dim_f / cfg->num_subbands;
+  REQUIRE(fs % (1 << cfg->num_scales) == 0 && e->cfg.segment_size % (1 << cfg->num_scales) == 0,
+          "dim_f / num_subbands and segment_size must be divisible by 2^num_scales");
+  REQUIRE((fs >> cfg->num_scales) % cfg->bottleneck_factor == 0, "bottleneck_factor must divide the deepest dim_f");
+  if (!e->v3) e->v3 = new V3Net();
+  v3_free(*e->v3);
+  e->v3->cfg = *cfg;
+  e->v3->begun = true;
+  e->v3->ws_batch = 0;
+  e->host_tensors.clear();
+  e->net_begun = true;   // asx_net_set_tensor() is shared
+  return ASX_OK;
+}
+
+int asx_v3_commit(asx_engine *e) {
+  REQUIRE(e, "asx_v3_commit: null engine");
+  if (!e->v3 || !e->v3->begun) {
+    set_err("asx_v3_commit before asx_v3_begin");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  V3Net &n = *e->v3;
+  const asx_v3_config &cf = n.cfg;
+  const int k = cf.num_subbands, dim_c = k * cf.num_channels * 2;
+  int c = cf.num_channels_model, f = e->cfg.dim_f / k;
+  CHK(v3_load_conv(e, n.first, CK_1X1, "first_conv.weight", dim_c, c, 1));
+  n.enc.assign(cf.num_scales, {});
+  n.dec.assign(cf.num_scales, {});
+  n.ds.assign(cf.num_scales, ConvLayer());
+  n.us.assign(cf.num_scales, ConvLayer());
+  n.ds_n.assign(cf.num_scales, V3Norm());
+  n.us_n.assign(cf.num_scales, V3Norm());
+  for (int i = 0; i < cf.num_scales; ++i) {
+    const std::string p = "encoder_blocks." + std::to_string(i);
+    CHK(v3_load_tfc_tdf(e, n.enc[i], p + ".tfc_tdf", c, c, f));
+    CHK(v3_load_norm(e, n.ds_n[i], p + ".downscale.conv.0", c));
+    CHK(v3_load_conv(e, n.ds[i], CK_DOWN, p + ".downscale.conv.2.weight", c, c + cf.growth, 4));
+    c += cf.growth;
+    f /= 2;
+  }
+  CHK(v3_load_tfc_tdf(e, n.mid, "bottleneck_block", c, c, f));
+  for (int i = 0; i < cf.num_scales; ++i) {
+    const std::string p = "decoder_blocks." + std::to_string(i);
+    CHK(v3_load_norm(e, n.us_n[i], p + ".upscale.conv.0", c));
+    CHK(v3_load_conv(e, n.us[i], CK_UP, p + ".upscale.conv.2.weight", c, c - cf.growth, 4));
+    c -= cf.growth;
+    f *= 2;
+    CHK(v3_load_tfc_tdf(e, n.dec[i], p + ".tfc_tdf", 2 * c, c, f));
+  }
+  CHK(v3_load_conv(e, n.final0, CK_1X1, "final_conv.0.weight", c + dim_c, c, 1));
+  CHK(v3_load_conv(e, n.final1, CK_1X1, "final_conv.2.weight", c, cf.num_targets * dim_c, 1));
+  e->host_tensors.clear();
+  n.ready = true;
+  return ASX_OK;
+}
+
+double asx_v3_flops(const asx_engine *e, int32_t batch) { return e ? v3_flops(e, batch) : 0.0; }
+
+int asx_v3_forward(asx_engine *e, const float *wave_host, int32_t B, float *out_host) {
+  REQUIRE(e && wave_host && out_host && B > 0, "asx_v3_forward: bad argument");
+  if (!e->v3 || !e->v3->ready) {
+    set_err("asx_v3_forward: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  const int64_t C = (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1);
+  const int S = e->v3->cfg.num_targets;
+  DevBuf dw, dout;
+  BufGuard g{{&dw, &dout}};
+  CHK(to_dev(dw, wave_host, (size_t)B * 2 * C));
+  CHK(dout.ensure((size_t)B * S * 2 * C * 4));
+  CHK(v3_chunks_dev(e, dw.f(), nullptr, -1, 0, B, dout.f(), nullptr));
+  CHK(to_host(out_host, dout, (size_t)B * S * 2 * C));
+  return ASX_OK;
+}
+
+int asx_mdxc_plan(const asx_engine *e, int64_t N, int32_t overlap, asx_plan *out) {
+  REQUIRE(e && out, "asx_mdxc_plan: null argument");
+  REQUIRE(N >= 1 && overlap >= 1, "n_samples and overlap must be >= 1");
+  asx_plan p{};
+  p.n_samples = N;
+  p.chunk_size = (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1);
+  p.step = p.chunk_size / overlap;                       // hop_size (mdxc_separator.py:364)
+  REQUIRE(p.step >= 1, "overlap larger than chunk_size");
+  int64_t r = (N - p.chunk_size) % p.step;               // Python floor-mod (:368)
+  if (r < 0) r += p.step;
+  p.pad = p.step - r;
+  p.trim = (int32_t)(p.chunk_size - p.step);             // zeros in front (:371)
+  p.gen_size = p.step;
+  p.padded_len = p.trim + N + p.pad + p.chunk_size - p.step;
+  p.n_chunks = (int32_t)((p.padded_len - p.chunk_size) / p.step + 1);   // Tensor.unfold (:374)
+  p.n_frames = e->cfg.segment_size;
+  *out = p;
+  return ASX_OK;
+}
+
+int asx_mdxc_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t overlap, float *out_dev, void *stream) {
+  REQUIRE(e && mix_dev && out_dev, "asx_mdxc_demix_dev: null argument");
+  if (!e->v3 || !e->v3->ready) {
+    set_err("asx_mdxc_demix: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  asx_plan p;
+  CHK(asx_mdxc_plan(e, N, overlap, &p));
+  V3Net &n = *e->v3;
+  const int S = n.cfg.num_targets;
+  const int64_t C = p.chunk_size;
+  CHK(n.chunk_out.ensure((size_t)p.n_chunks * S * 2 * C * 4));
+  std::vector<int64_t> starts(p.n_chunks);
+  for (int k = 0; k < p.n_chunks; ++k) starts[k] = (int64_t)k * p.step;
+  CHK(n.d_starts.ensure((size_t)p.n_chunks * 8));
+  HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data(), (size_t)p.n_chunks * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const int maxB = e->cfg.max_batch > 0 ? e->cfg.max_batch : 8;
+  const int nbatch = (p.n_chunks + maxB - 1) / maxB;
+  const int per = (p.n_chunks + nbatch - 1) / nbatch;
+  for (int k0 = 0; k0 < p.n_chunks; k0 += per) {
+    const int B = std::min(per, p.n_chunks - k0);
+    CHK(v3_chunks_dev(e, mix_dev, reinterpret_cast<const int64_t *>(n.d_starts.p) + k0, N, p.trim, B,
+                      n.chunk_out.f() + (size_t)k0 * S * 2 * C, s));
+  }
+  const double bytes = 4.0 * ((double)p.n_chunks * S * 2 * C + (double)S * 2 * N);
+  return timed(e, ASX_PROF_FINALIZE, 0.0, bytes, s, [&]() {
+    hipLaunchKernelGGL(mdxc_finalize_kernel, dim3((unsigned)((N + 255) / 256), S * 2), dim3(256), 0, s,
+                       n.chunk_out.f(), p.n_chunks, S, C, p.step, (int64_t)p.trim, N, (float)overlap, out_dev);
+  });
+}
+
+int asx_mdxc_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t overlap, float *out_host) {
+  REQUIRE(e && mix_host && out_host, "asx_mdxc_demix: null argument");
+  REQUIRE(N >= 1, "n_samples must be >= 1");
+  if (!e->v3 || !e->v3->ready) {
+    set_err("asx_mdxc_demix: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  const int S = e->v3->cfg.num_targets;
+  DevBuf dmix, dout;
+  BufGuard g{{&dmix, &dout}};
+  CHK(to_dev(dmix, mix_host, (size_t)2 * N));
+  CHK(dout.ensure((size_t)S * 2 * N * 4));
+  CHK(asx_mdxc_demix_dev(e, dmix.f(), N, overlap, dout.f(), nullptr));
+  CHK(to_host(out_host, dout, (size_t)S * 2 * N));
   return ASX_OK;
 }
 

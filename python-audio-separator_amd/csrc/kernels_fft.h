@@ -149,6 +149,8 @@ struct StftArgs {
   const float *window;        // [n_fft] periodic Hann
   const float2 *tw;           // [n_fft]
   float sign;                 // +1, or -1 to emit the negated spectrum (denoise pass)
+  int subbands;               // k >= 1: bin j*F/k + f' of plane p goes to plane p*k + j (cac2cws, tfc_tdf_v3.py:216)
+  int64_t out_bstride;        // floats between batch items of spec (tf_layout only); 0 = dense
 };
 
 __global__ __launch_bounds__(256) void stft_kernel(StftArgs a, FftPlan p) {
@@ -199,9 +201,13 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a, FftPlan p) {
       im = X.y * a.sign;
     }
     if (a.tf_layout) {
-      const int64_t base = (((int64_t)b * 4 + ch * 2) * a.T + t) * a.dim_f + k;
+      const int kb = a.subbands > 1 ? a.subbands : 1;
+      const int fs = a.dim_f / kb;
+      const int j = k / fs, fp = k - j * fs;
+      const int64_t bst = a.out_bstride ? a.out_bstride : (int64_t)4 * a.T * a.dim_f;
+      const int64_t base = (int64_t)b * bst + (((int64_t)(ch * 2) * kb + j) * a.T + t) * fs + fp;
       a.spec[base] = re;
-      a.spec[base + (int64_t)a.T * a.dim_f] = im;
+      a.spec[base + (int64_t)kb * a.T * fs] = im;
     } else {
       const int64_t base = (((int64_t)b * 4 + ch * 2) * a.dim_f + k) * a.T + t;
       a.spec[base] = re;
@@ -226,15 +232,24 @@ struct IstftArgs {
   float *frames;      // [B,2,T,n_fft]
   const float *window;
   const float2 *tw;
+  int subbands;        // cws2cac (tfc_tdf_v3.py:223): plane p*k + j holds bins j*F/k ...
+  int n_inst;          // S >= 1 stems per batch item: blockIdx.z = b*S + s, planes [s*4k, (s+1)*4k)
+  int64_t in_bstride;  // floats between batch items of spec (tf_layout only); 0 = dense
 };
 
 __device__ __forceinline__ float2 load_bin(const IstftArgs &a, int b, int ch, int t, int k) {
   if (k >= a.dim_f) return make_float2(0.f, 0.f);
   float re, im;
   if (a.tf_layout) {
-    const int64_t base = (((int64_t)b * 4 + ch * 2) * a.T + t) * a.dim_f + k;
+    const int kb = a.subbands > 1 ? a.subbands : 1;
+    const int S = a.n_inst > 1 ? a.n_inst : 1;
+    const int fs = a.dim_f / kb;
+    const int j = k / fs, fp = k - j * fs;
+    const int bb = b / S, si = b - bb * S;
+    const int64_t bst = a.in_bstride ? a.in_bstride : (int64_t)S * 4 * a.T * a.dim_f;
+    const int64_t base = (int64_t)bb * bst + ((((int64_t)si * 4 + ch * 2) * kb + j) * a.T + t) * fs + fp;
     re = a.spec[base];
-    im = a.spec[base + (int64_t)a.T * a.dim_f];
+    im = a.spec[base + (int64_t)kb * a.T * fs];
   } else {
     const int64_t base = (((int64_t)b * 4 + ch * 2) * a.dim_f + k) * a.T + t;
     re = a.spec[base];
@@ -407,6 +422,119 @@ __global__ __launch_bounds__(256) void stems_kernel(const float *__restrict__ de
   const float s0 = t0 + mix[i], s1 = t1 + mix[N + i];
   reinterpret_cast<float2 *>(primary)[i] = make_float2(p0, p1);
   reinterpret_cast<float2 *>(secondary)[i] = make_float2(s0, s1);
+}
+
+// ---------------------------------------------------------------------------
+// MDXC (TFC branch) fold: accumulated[..., k*hop : k*hop+chunk] += out_k ; result = accumulated / overlap
+// (mdxc_separator.py:398-402).  Gather form over the covering chunks in increasing k.
+// chunk_out [n_chunks, S, 2, C];  out [S, 2, N];  sample i sits at padded position i + front.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mdxc_finalize_kernel(const float *__restrict__ chunk_out, int n_chunks, int S,
+                                                            int64_t C, int64_t hop, int64_t front, int64_t N,
+                                                            float overlap, float *__restrict__ out) {
+  const int sc = blockIdx.y;  // s*2 + ch
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int64_t m = i + front;
+  int64_t k_hi = m / hop;
+  if (k_hi > n_chunks - 1) k_hi = n_chunks - 1;
+  int64_t k_lo = 0;
+  if (m - C >= 0) k_lo = (m - C) / hop + 1;
+  float acc = 0.f;
+  for (int64_t k = k_lo; k <= k_hi; ++k) acc += chunk_out[((k * S * 2) + sc) * C + (m - k * hop)];
+  out[(int64_t)sc * N + i] = acc / overlap;
+}
+
+// ---------------------------------------------------------------------------
+// TFC-TDF v3 pre-activation blocks: InstanceNorm2d(affine) statistics and norm -> act.
+// x is a channel-slice view [B, C, P] (P = T*F) with batch stride x_bstride.
+// stats[b*C + c] = (mean, 1/sqrt(var + eps)), biased variance, accumulated in float64.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const float *__restrict__ x, int64_t x_bstride, int C,
+                                                             int64_t P, float eps, float2 *__restrict__ stats) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float *xp = x + (int64_t)b * x_bstride + (int64_t)c * P;
+  double s = 0.0, q = 0.0;
+  if ((P & 3) == 0) {
+    const float4 *x4 = reinterpret_cast<const float4 *>(xp);
+    for (int64_t i = threadIdx.x; i < P / 4; i += blockDim.x) {
+      const float4 v = x4[i];
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < P; i += blockDim.x) {
+      const double v = xp[i];
+      s += v;
+      q += v * v;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+  __shared__ double ws[4], wq[4];
+  if ((threadIdx.x & 63) == 0) {
+    ws[threadIdx.x >> 6] = s;
+    wq[threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = ws[0] + ws[1] + ws[2] + ws[3];
+    q = wq[0] + wq[1] + wq[2] + wq[3];
+    const double mean = s / (double)P;
+    double var = q / (double)P - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(int64_t)b * C + c] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+  }
+}
+
+__device__ __forceinline__ float v3_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+
+// y[b,c,:] = act((x - mean) * rstd * gamma[c] + beta[c]); stats == nullptr -> act only (norm = None).
+__global__ __launch_bounds__(256) void norm_act_kernel(const float *__restrict__ x, int64_t x_bstride, int C, int64_t P,
+                                                       const float2 *__restrict__ stats, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, int act, float *__restrict__ y) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float *xp = x + (int64_t)b * x_bstride + (int64_t)c * P;
+  float *yp = y + ((int64_t)b * C + c) * P;
+  float mean = 0.f, sc = 1.f, sh = 0.f;
+  if (stats != nullptr) {
+    const float2 st = stats[(int64_t)b * C + c];
+    mean = st.x;
+    sc = st.y * gamma[c];
+    sh = beta[c];
+  }
+  if ((P & 3) == 0) {
+    const float4 *x4 = reinterpret_cast<const float4 *>(xp);
+    float4 *y4 = reinterpret_cast<float4 *>(yp);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P / 4; i += (int64_t)gridDim.x * blockDim.x) {
+      float4 v = x4[i];
+      v.x = v3_act((v.x - mean) * sc + sh, act);
+      v.y = v3_act((v.y - mean) * sc + sh, act);
+      v.z = v3_act((v.z - mean) * sc + sh, act);
+      v.w = v3_act((v.w - mean) * sc + sh, act);
+      y4[i] = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x)
+      yp[i] = v3_act((xp[i] - mean) * sc + sh, act);
+  }
+}
+
+// y_view[b, c, :] = a[b, c, :] * m[b, c, :]   ("x * first_conv_out", tfc_tdf_v3.py:257), y is a channel-slice view
+__global__ __launch_bounds__(256) void mul_into_view_kernel(const float *__restrict__ a, const float *__restrict__ m,
+                                                            int64_t CP, float *__restrict__ y, int64_t y_bstride) {
+  const int b = blockIdx.y;
+  const float *ap = a + (int64_t)b * CP, *mp = m + (int64_t)b * CP;
+  float *yp = y + (int64_t)b * y_bstride;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < CP; i += (int64_t)gridDim.x * blockDim.x)
+    yp[i] = ap[i] * mp[i];
 }
 
 // [B,4,F,T] <-> [B,4,T,F] (test hooks only; the path itself stays in [.,T,F]).

@@ -59,17 +59,144 @@ struct ConvCfg {
   static constexpr int NWV = (W_ROWS * NWP / 4 + 255) / 256;   // weight float4 per thread per stage
 };
 
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // nn.GELU() (erf form)
+  return v;
+}
+
+// x / y / aux may be channel-slice views of larger [B, Ctot, T, F] buffers: the pointers are
+// pre-offset to the first channel of the view and the *_bstride fields give the distance (in
+// floats) between consecutive batch items.
 struct ConvArgs {
-  const float *x;     // [B, Cin, T, F]
-  const float *wp;    // packed [CG][NCI][WSTAGE]: rows (tap, kc) of NWP floats, zero padded
-  const float *bias;  // padded per (virtual) output channel
-  const float *skip;  // EPI_UP_MULSKIP: [B, Cout, 2T, 2F]
-  float *y;
+  const float *x;      // [B, Cin, T, F] view
+  const float *wp;     // packed [CG][NCI][WSTAGE]: rows (tap, kc) of NWP floats, zero padded
+  const float *bias;   // padded per (virtual) output channel
+  const float *skip;   // EPI_UP: optional [B, Cout, 2T, 2F] multiplier (mdxnet.py:113) or nullptr
+  const float *res;    // EPI_BIAS_ACT: optional residual [B, Cout, To, Fo] added after the activation, or nullptr
+  const float *zeros;  // >= 16 B of zeros (DMA source of out-of-range slots)
+  float *y;            // output view
   int B, Cin, Cout, T, F;    // input geometry; Cout = real output channels
   int To, Fo;                // output spatial size handled by tiles (= T,F; T/2,F/2 for stride 2)
   int tilesT, tilesF, CG, NCI;
-  int relu;
+  int act;
+  int64_t x_bstride, y_bstride, aux_bstride;
 };
+
+// Shared epilogue of both conv kernel families.
+template <class CFG>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x4 (&acc)[CFG::MREP][CFG::NREP], int b, int cg,
+                                              int to0, int fo0, int wave, int li, int lk) {
+  constexpr int NREP = CFG::NREP, MREP = CFG::MREP, RPW = CFG::RPW, NW = CFG::NW, TH = CFG::TH, TW = CFG::TW;
+  if constexpr (CFG::EPI == EPI_BIAS_ACT) {
+    const bool full = ((a.Fo & 3) == 0) && (to0 + TH <= a.To) && (fo0 + TW <= a.Fo);
+    float *yb = a.y + (int64_t)b * a.y_bstride;
+    const float *rb = a.res ? a.res + (int64_t)b * a.aux_bstride : nullptr;
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      const int co = cg * NW + n * 16 + li;
+      const float bv = a.bias[co];
+      if (co >= a.Cout) continue;
+      if (full) {
+        f32x4 rs[MREP];
+        if (rb != nullptr) {
+#pragma unroll
+          for (int m = 0; m < MREP; ++m) {
+            const int t = to0 + wave * RPW + (m >> 2), f = fo0 + (m & 3) * 16 + lk * 4;
+            rs[m] = *reinterpret_cast<const f32x4 *>(rb + ((int64_t)co * a.To + t) * a.Fo + f);
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int t = to0 + wave * RPW + (m >> 2), f = fo0 + (m & 3) * 16 + lk * 4;
+          f32x4 v = acc[m][n];
+          v.x = act_fn(v.x + bv, a.act);
+          v.y = act_fn(v.y + bv, a.act);
+          v.z = act_fn(v.z + bv, a.act);
+          v.w = act_fn(v.w + bv, a.act);
+          if (rb != nullptr) v += rs[m];
+          *reinterpret_cast<f32x4 *>(yb + ((int64_t)co * a.To + t) * a.Fo + f) = v;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int t = to0 + wave * RPW + (m >> 2), f = fo0 + (m & 3) * 16 + lk * 4;
+          if (t >= a.To) continue;
+          const f32x4 v = acc[m][n];
+          const float o[4] = {v.x, v.y, v.z, v.w};
+          const int64_t off = ((int64_t)co * a.To + t) * a.Fo + f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (f + r < a.Fo) yb[off + r] = act_fn(o[r] + bv, a.act) + (rb != nullptr ? rb[off + r] : 0.f);
+        }
+      }
+    }
+  } else {
+    // transposed 2x2/stride-2 conv as a 1x1 conv onto 4*Cout virtual channels:
+    // virtual n-tile nt = cg*NREP + n;  pair = nt/2 -> (dy = pair / CT, ct = pair % CT), dx = nt & 1
+    const int CT = (a.Cout + 15) / 16;
+    const int To2 = a.T * 2, Fo2 = a.F * 2;
+    const bool full = (to0 + TH <= a.T) && (fo0 + TW <= a.F);
+    float *yb = a.y + (int64_t)b * a.y_bstride;
+    const float *sb = a.skip ? a.skip + (int64_t)b * a.aux_bstride : nullptr;
+#pragma unroll
+    for (int np = 0; np < NREP / 2; ++np) {
+      const int pair = (cg * NREP) / 2 + np;
+      const int dy = pair / CT, ct = pair - dy * CT;
+      if (dy >= 2) continue;
+      const int co = ct * 16 + li;
+      const float bv = a.bias[co];
+      if (co >= a.Cout) continue;
+      if (full) {
+        f32x4 s0[MREP], s1[MREP];
+        if (sb != nullptr) {
+#pragma unroll
+          for (int m = 0; m < MREP; ++m) {
+            const int t = to0 + wave * RPW + (m >> 2), f = fo0 + (m & 3) * 16 + lk * 4;
+            const int64_t off = ((int64_t)co * To2 + (2 * t + dy)) * Fo2 + 2 * f;
+            s0[m] = *reinterpret_cast<const f32x4 *>(sb + off);
+            s1[m] = *reinterpret_cast<const f32x4 *>(sb + off + 4);
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int t = to0 + wave * RPW + (m >> 2), f = fo0 + (m & 3) * 16 + lk * 4;
+          const int64_t off = ((int64_t)co * To2 + (2 * t + dy)) * Fo2 + 2 * f;
+          const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
+          f32x4 r0, r1;
+          r0.x = act_fn(v0.x + bv, a.act);
+          r0.y = act_fn(v1.x + bv, a.act);
+          r0.z = act_fn(v0.y + bv, a.act);
+          r0.w = act_fn(v1.y + bv, a.act);
+          r1.x = act_fn(v0.z + bv, a.act);
+          r1.y = act_fn(v1.z + bv, a.act);
+          r1.z = act_fn(v0.w + bv, a.act);
+          r1.w = act_fn(v1.w + bv, a.act);
+          if (sb != nullptr) {
+            r0 *= s0[m];
+            r1 *= s1[m];
+          }
+          *reinterpret_cast<f32x4 *>(yb + off) = r0;
+          *reinterpret_cast<f32x4 *>(yb + off + 4) = r1;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int t = to0 + wave * RPW + (m >> 2), f = fo0 + (m & 3) * 16 + lk * 4;
+          if (t >= a.T || f >= a.F) continue;
+          const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
+          const float o[8] = {v0.x, v1.x, v0.y, v1.y, v0.z, v1.z, v0.w, v1.w};
+          const int64_t off = ((int64_t)co * To2 + (2 * t + dy)) * Fo2 + 2 * f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (f + (q >> 1) < a.F) yb[off + q] = act_fn(o[q] + bv, a.act) * (sb != nullptr ? sb[off + q] : 1.f);
+        }
+      }
+    }
+  }
+}
 
 template <class CFG>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
@@ -95,7 +222,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   const int to0 = tt * TH, fo0 = tf * TW;          // output tile origin
   const int ti0 = to0 * S - PAD, fi0 = fo0 * S - PAD;  // input tile origin
 
-  const float *xb = a.x + (int64_t)b * a.Cin * a.T * a.F;
+  const float *xb = a.x + (int64_t)b * a.x_bstride;
   const float *wg = a.wp + (int64_t)cg * a.NCI * CFG::WSTAGE;
 
   f32x4 acc[MREP][NREP];
@@ -187,99 +314,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     }
   }
 
-  // ---- epilogue ----
-  if constexpr (CFG::EPI == EPI_BIAS_ACT) {
-    const bool full = ((a.Fo & 3) == 0) && (to0 + TH <= a.To) && (fo0 + TW <= a.Fo);
-#pragma unroll
-    for (int n = 0; n < NREP; ++n) {
-      const int co = cg * NW + n * 16 + li;
-      const float bv = a.bias[co];
-      if (co >= a.Cout) continue;
-#pragma unroll
-      for (int m = 0; m < MREP; ++m) {
-        const int rr = m >> 2, cc = m & 3;
-        const int t = to0 + wave * RPW + rr;
-        const int f = fo0 + cc * 16 + lk * 4;
-        f32x4 v = acc[m][n];
-        v += bv;
-        if (a.relu) {
-          v.x = fmaxf(v.x, 0.f);
-          v.y = fmaxf(v.y, 0.f);
-          v.z = fmaxf(v.z, 0.f);
-          v.w = fmaxf(v.w, 0.f);
-        }
-        float *dst = a.y + (((int64_t)b * a.Cout + co) * a.To + t) * a.Fo + f;
-        if (full) {
-          *reinterpret_cast<f32x4 *>(dst) = v;
-        } else if (t < a.To) {
-          if (f < a.Fo) dst[0] = v.x;
-          if (f + 1 < a.Fo) dst[1] = v.y;
-          if (f + 2 < a.Fo) dst[2] = v.z;
-          if (f + 3 < a.Fo) dst[3] = v.w;
-        }
-      }
-    }
-  } else {
-    // virtual n-tile nt = cg*NREP + n;  pair = nt/2 -> (dy = pair / CT, ct = pair % CT), dx = nt & 1
-    const int CT = (a.Cout + 15) / 16;
-    const int To2 = a.T * 2, Fo2 = a.F * 2;
-    const bool full = (to0 + TH <= a.T) && (fo0 + TW <= a.F);
-#pragma unroll
-    for (int np = 0; np < NREP / 2; ++np) {
-      const int pair = (cg * NREP) / 2 + np;
-      const int dy = pair / CT, ct = pair - dy * CT;
-      if (dy >= 2) continue;
-      const int co = ct * 16 + li;
-      const float bv = a.bias[co];
-      if (co >= a.Cout) continue;
-      if (full) {
-        // unconditional skip loads for the whole tile column, then the math
-        f32x4 s0[MREP], s1[MREP];
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-          const int rr = m >> 2, cc = m & 3;
-          const int t = to0 + wave * RPW + rr;
-          const int f = fo0 + cc * 16 + lk * 4;
-          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
-          s0[m] = *reinterpret_cast<const f32x4 *>(a.skip + off);
-          s1[m] = *reinterpret_cast<const f32x4 *>(a.skip + off + 4);
-        }
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-          const int rr = m >> 2, cc = m & 3;
-          const int t = to0 + wave * RPW + rr;
-          const int f = fo0 + cc * 16 + lk * 4;
-          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
-          const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
-          f32x4 r0, r1;
-          r0.x = fmaxf(v0.x + bv, 0.f) * s0[m].x;
-          r0.y = fmaxf(v1.x + bv, 0.f) * s0[m].y;
-          r0.z = fmaxf(v0.y + bv, 0.f) * s0[m].z;
-          r0.w = fmaxf(v1.y + bv, 0.f) * s0[m].w;
-          r1.x = fmaxf(v0.z + bv, 0.f) * s1[m].x;
-          r1.y = fmaxf(v1.z + bv, 0.f) * s1[m].y;
-          r1.z = fmaxf(v0.w + bv, 0.f) * s1[m].z;
-          r1.w = fmaxf(v1.w + bv, 0.f) * s1[m].w;
-          *reinterpret_cast<f32x4 *>(a.y + off) = r0;
-          *reinterpret_cast<f32x4 *>(a.y + off + 4) = r1;
-        }
-      } else {
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-          const int rr = m >> 2, cc = m & 3;
-          const int t = to0 + wave * RPW + rr;
-          const int f = fo0 + cc * 16 + lk * 4;
-          if (t >= a.T || f >= a.F) continue;
-          const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
-          const float o[8] = {v0.x, v1.x, v0.y, v1.y, v0.z, v1.z, v0.w, v1.w};
-          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (f + (q >> 1) < a.F) a.y[off + q] = fmaxf(o[q] + bv, 0.f) * a.skip[off + q];
-        }
-      }
-    }
-  }
+  conv_epilogue<CFG>(a, acc, b, cg, to0, fo0, wave, li, lk);
 }
 
 // ---------------------------------------------------------------------------
@@ -291,6 +326,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 // Fragments are fetched with ds_read_b128 (4 consecutive k per lane); the k
 // order inside a 16-wide step is permuted identically for both operands.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ float tdf_act(float v, int relu) { return relu ? fmaxf(v, 0.f) : v; }
+
 struct TdfArgs {
   const float *x;      // [M, K]
   const float *w;      // [N, K]
@@ -301,6 +338,7 @@ struct TdfArgs {
   float *y;            // [M, N]
   int64_t M;
   int N, K, C, T;
+  int relu;            // 0: no activation (TFC-TDF v3 applies norm/act before the linear)
 };
 
 template <int NREP, int MREP>
@@ -446,8 +484,8 @@ __global__ __launch_bounds__(256, 2) void tdf_mfma_kernel(TdfArgs a) {
       for (int m = 0; m < 4; ++m) {
         const int64_t row = m0 + (mg + m) * 16 + li;
         const int c = (int)((row / a.T) % a.C);
-        sc[m] = a.scale[c];
-        sh[m] = a.shift[c];
+        sc[m] = a.scale ? a.scale[c] : 1.f;
+        sh[m] = a.shift ? a.shift[c] : 0.f;
 #pragma unroll
         for (int n = 0; n < NREP; ++n) {
           const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
@@ -463,10 +501,10 @@ __global__ __launch_bounds__(256, 2) void tdf_mfma_kernel(TdfArgs a) {
           const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
           const f32x4 v = acc[n][mg + m];
           f32x4 o;
-          o.x = fmaxf(sc[m] * (v.x + bz[n].x) + sh[m], 0.f) + rs[m][n].x;
-          o.y = fmaxf(sc[m] * (v.y + bz[n].y) + sh[m], 0.f) + rs[m][n].y;
-          o.z = fmaxf(sc[m] * (v.z + bz[n].z) + sh[m], 0.f) + rs[m][n].z;
-          o.w = fmaxf(sc[m] * (v.w + bz[n].w) + sh[m], 0.f) + rs[m][n].w;
+          o.x = tdf_act(sc[m] * (v.x + bz[n].x) + sh[m], a.relu) + rs[m][n].x;
+          o.y = tdf_act(sc[m] * (v.y + bz[n].y) + sh[m], a.relu) + rs[m][n].y;
+          o.z = tdf_act(sc[m] * (v.z + bz[n].z) + sh[m], a.relu) + rs[m][n].z;
+          o.w = tdf_act(sc[m] * (v.w + bz[n].w) + sh[m], a.relu) + rs[m][n].w;
           *reinterpret_cast<f32x4 *>(a.y + row * a.N + col) = o;
         }
       }
@@ -479,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void tdf_mfma_kernel(TdfArgs a) {
     const int64_t row = m0 + m * 16 + li;
     if (row >= a.M) continue;
     const int c = (int)((row / a.T) % a.C);
-    const float sc = a.scale[c], sh = a.shift[c];
+    const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
       const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
@@ -489,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void tdf_mfma_kernel(TdfArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float bzz = (a.bias != nullptr && col + r < a.N) ? a.bias[col + r] : 0.f;
-        o[r] = fmaxf(sc * (o[r] + bzz) + sh, 0.f);
+        o[r] = tdf_act(sc * (o[r] + bzz) + sh, a.relu);
       }
       float *dst = a.y + row * a.N + col;
 #pragma unroll
@@ -546,20 +584,8 @@ struct ConvDmaCfg {
   static_assert(PS % 4 == 0, "plane stride must keep 16-B alignment");
 };
 
-struct ConvDmaArgs {
-  const float *x;      // [B, Cin, T, F]
-  const float *wp;     // packed [CG][NCI][WSTAGE]
-  const float *bias;
-  const float *skip;
-  const float *zeros;  // >= 16 B of zeros
-  float *y;
-  int B, Cin, Cout, T, F, To, Fo;
-  int tilesT, tilesF, CG, NCI;
-  int relu;
-};
-
 template <class CFG>
-__global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvDmaArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
   extern __shared__ float lds_f[];
   constexpr int KH = CFG::KH, KW = CFG::KW, S = CFG::S, PAD = CFG::PAD, NREP = CFG::NREP, KC = CFG::KC;
   constexpr int RPW = CFG::RPW, MREP = CFG::MREP, IWA = CFG::IWA, C4 = CFG::C4, PS = CFG::PS, LP = CFG::LP;
@@ -581,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvDmaArgs a) {
   const int to0 = tt * TH, fo0 = tf * TW;
   const int ti0 = to0 * S - PAD, fa0 = fo0 * S - PAD - LP;   // aligned input origin
 
-  const float *xb = a.x + (int64_t)b * a.Cin * a.T * a.F;
+  const float *xb = a.x + (int64_t)b * a.x_bstride;
   const float *wg = a.wp + (int64_t)cg * a.NCI * WSTAGE;
   const int64_t plane_sz = (int64_t)a.T * a.F;
 
@@ -655,97 +681,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvDmaArgs a) {
     }
   }
 
-  // ---- epilogue (same math as conv_mfma_kernel) ----
-  if constexpr (CFG::EPI == EPI_BIAS_ACT) {
-    const bool full = ((a.Fo & 3) == 0) && (to0 + TH <= a.To) && (fo0 + TW <= a.Fo);
-#pragma unroll
-    for (int n = 0; n < NREP; ++n) {
-      const int co = cg * NW + n * 16 + li;
-      const float bv = a.bias[co];
-      if (co >= a.Cout) continue;
-#pragma unroll
-      for (int m = 0; m < MREP; ++m) {
-        const int rr = m >> 2, cc = m & 3;
-        const int t = to0 + wave * RPW + rr;
-        const int f = fo0 + cc * 16 + lk * 4;
-        f32x4 v = acc[m][n];
-        v += bv;
-        if (a.relu) {
-          v.x = fmaxf(v.x, 0.f);
-          v.y = fmaxf(v.y, 0.f);
-          v.z = fmaxf(v.z, 0.f);
-          v.w = fmaxf(v.w, 0.f);
-        }
-        float *dst = a.y + (((int64_t)b * a.Cout + co) * a.To + t) * a.Fo + f;
-        if (full) {
-          *reinterpret_cast<f32x4 *>(dst) = v;
-        } else if (t < a.To) {
-          if (f < a.Fo) dst[0] = v.x;
-          if (f + 1 < a.Fo) dst[1] = v.y;
-          if (f + 2 < a.Fo) dst[2] = v.z;
-          if (f + 3 < a.Fo) dst[3] = v.w;
-        }
-      }
-    }
-  } else {
-    const int CT = (a.Cout + 15) / 16;
-    const int To2 = a.T * 2, Fo2 = a.F * 2;
-    const bool full = (to0 + TH <= a.T) && (fo0 + TW <= a.F);
-#pragma unroll
-    for (int np = 0; np < NREP / 2; ++np) {
-      const int pair = (cg * NREP) / 2 + np;
-      const int dy = pair / CT, ct = pair - dy * CT;
-      if (dy >= 2) continue;
-      const int co = ct * 16 + li;
-      const float bv = a.bias[co];
-      if (co >= a.Cout) continue;
-      if (full) {
-        f32x4 s0[MREP], s1[MREP];
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-          const int rr = m >> 2, cc = m & 3;
-          const int t = to0 + wave * RPW + rr;
-          const int f = fo0 + cc * 16 + lk * 4;
-          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
-          s0[m] = *reinterpret_cast<const f32x4 *>(a.skip + off);
-          s1[m] = *reinterpret_cast<const f32x4 *>(a.skip + off + 4);
-        }
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-          const int rr = m >> 2, cc = m & 3;
-          const int t = to0 + wave * RPW + rr;
-          const int f = fo0 + cc * 16 + lk * 4;
-          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
-          const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
-          f32x4 r0, r1;
-          r0.x = fmaxf(v0.x + bv, 0.f) * s0[m].x;
-          r0.y = fmaxf(v1.x + bv, 0.f) * s0[m].y;
-          r0.z = fmaxf(v0.y + bv, 0.f) * s0[m].z;
-          r0.w = fmaxf(v1.y + bv, 0.f) * s0[m].w;
-          r1.x = fmaxf(v0.z + bv, 0.f) * s1[m].x;
-          r1.y = fmaxf(v1.z + bv, 0.f) * s1[m].y;
-          r1.z = fmaxf(v0.w + bv, 0.f) * s1[m].z;
-          r1.w = fmaxf(v1.w + bv, 0.f) * s1[m].w;
-          *reinterpret_cast<f32x4 *>(a.y + off) = r0;
-          *reinterpret_cast<f32x4 *>(a.y + off + 4) = r1;
-        }
-      } else {
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-          const int rr = m >> 2, cc = m & 3;
-          const int t = to0 + wave * RPW + rr;
-          const int f = fo0 + cc * 16 + lk * 4;
-          if (t >= a.T || f >= a.F) continue;
-          const f32x4 v0 = acc[m][2 * np], v1 = acc[m][2 * np + 1];
-          const float o[8] = {v0.x, v1.x, v0.y, v1.y, v0.z, v1.z, v0.w, v1.w};
-          const int64_t off = (((int64_t)b * a.Cout + co) * To2 + (2 * t + dy)) * Fo2 + 2 * f;
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (f + (q >> 1) < a.F) a.y[off + q] = fmaxf(o[q] + bv, 0.f) * a.skip[off + q];
-        }
-      }
-    }
-  }
+  conv_epilogue<CFG>(a, acc, b, cg, to0, fo0, wave, li, lk);
 }
 
 // ---------------------------------------------------------------------------
@@ -755,10 +691,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvDmaArgs a) {
 // ds_read_b128 lane group hit 16 distinct 4-bank slots.
 // ---------------------------------------------------------------------------
 struct TdfDmaArgs {
-  const float *x, *w, *bias, *scale, *shift, *res, *zeros;
+  const float *x, *w, *bias, *scale, *shift, *res, *zeros;   // scale/shift may be nullptr (identity)
   float *y;
   int64_t M;
   int N, K, C, T;
+  int relu;
 };
 
 template <int NREP, int MREP>
@@ -875,8 +812,8 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
       for (int m = 0; m < 4; ++m) {
         const int64_t row = m0 + (mg + m) * 16 + li;
         const int c = (int)((row / a.T) % a.C);
-        sc[m] = a.scale[c];
-        sh[m] = a.shift[c];
+        sc[m] = a.scale ? a.scale[c] : 1.f;
+        sh[m] = a.shift ? a.shift[c] : 0.f;
 #pragma unroll
         for (int n = 0; n < NREP; ++n) {
           const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
@@ -892,10 +829,10 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
           const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
           const f32x4 v = acc[n][mg + m];
           f32x4 o;
-          o.x = fmaxf(sc[m] * (v.x + bz[n].x) + sh[m], 0.f) + rs[m][n].x;
-          o.y = fmaxf(sc[m] * (v.y + bz[n].y) + sh[m], 0.f) + rs[m][n].y;
-          o.z = fmaxf(sc[m] * (v.z + bz[n].z) + sh[m], 0.f) + rs[m][n].z;
-          o.w = fmaxf(sc[m] * (v.w + bz[n].w) + sh[m], 0.f) + rs[m][n].w;
+          o.x = tdf_act(sc[m] * (v.x + bz[n].x) + sh[m], a.relu) + rs[m][n].x;
+          o.y = tdf_act(sc[m] * (v.y + bz[n].y) + sh[m], a.relu) + rs[m][n].y;
+          o.z = tdf_act(sc[m] * (v.z + bz[n].z) + sh[m], a.relu) + rs[m][n].z;
+          o.w = tdf_act(sc[m] * (v.w + bz[n].w) + sh[m], a.relu) + rs[m][n].w;
           *reinterpret_cast<f32x4 *>(a.y + row * a.N + col) = o;
         }
       }
@@ -907,7 +844,7 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
     const int64_t row = m0 + m * 16 + li;
     if (row >= a.M) continue;
     const int c = (int)((row / a.T) % a.C);
-    const float sc = a.scale[c], sh = a.shift[c];
+    const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
       const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
@@ -917,7 +854,7 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float bzz = (a.bias != nullptr && col + r < a.N) ? a.bias[col + r] : 0.f;
-        o[r] = fmaxf(sc * (o[r] + bzz) + sh, 0.f);
+        o[r] = tdf_act(sc * (o[r] + bzz) + sh, a.relu);
       }
       float *dst = a.y + row * a.N + col;
 #pragma unroll

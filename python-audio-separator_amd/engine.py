@@ -36,6 +36,12 @@ class _NetCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim_c", "dim_f", "dim_t", "g", "l", "num_blocks", "k", "bn", "tdf_bias")]
 
 
+class _V3Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_channels", "num_subbands", "num_scales", "num_blocks_per_scale",
+                                         "num_channels_model", "growth", "bottleneck_factor", "norm", "act",
+                                         "num_targets")]
+
+
 class _Plan(C.Structure):
     _fields_ = [("n_samples", C.c_int64), ("padded_len", C.c_int64), ("chunk_size", C.c_int64),
                 ("gen_size", C.c_int64), ("pad", C.c_int64), ("step", C.c_int64), ("trim", C.c_int32),
@@ -73,6 +79,22 @@ class NetConfig:
     tdf_bias: bool = False
 
 
+@dataclass
+class V3Config:
+    """TFC_TDF_net hyper-parameters (uvr_lib_v5/tfc_tdf_v3.py:151-214; the model YAML's
+    audio/model/training sections).  n_fft / hop_length / dim_f / dim_t live in MDXConfig."""
+    num_channels: int = 2
+    num_subbands: int = 4
+    num_scales: int = 5
+    num_blocks_per_scale: int = 2
+    num_channels_model: int = 128
+    growth: int = 128
+    bottleneck_factor: int = 4
+    norm: str | None = "InstanceNorm"
+    act: str = "gelu"
+    num_targets: int = 2
+
+
 _FP = C.POINTER(C.c_float)
 _lib = None
 
@@ -80,7 +102,8 @@ _lib = None
 SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_create", "asx_engine_destroy",
            "asx_net_begin", "asx_net_set_tensor", "asx_net_commit", "asx_net_flops", "asx_plan_query", "asx_demix",
            "asx_demix_dev", "asx_demix_chunks_dev", "asx_finalize_dev", "asx_separate", "asx_separate_dev", "asx_stft", "asx_istft", "asx_net_forward",
-           "asx_run_model", "asx_op_conv", "asx_op_tdf", "asx_profile_enable", "asx_profile_read"]
+           "asx_run_model", "asx_op_conv", "asx_op_tdf", "asx_profile_enable", "asx_profile_read", "asx_v3_begin",
+           "asx_v3_commit", "asx_v3_flops", "asx_v3_forward", "asx_mdxc_plan", "asx_mdxc_demix", "asx_mdxc_demix_dev"]
 
 
 def load_library():
@@ -126,6 +149,14 @@ def load_library():
     lib.asx_run_model.argtypes = [vp, _FP, i32, _FP, u32]
     lib.asx_op_conv.argtypes = [vp, C.c_char_p, _FP, i32, i32, i32, i32, _FP, _FP, i32, _FP, i32, _FP]
     lib.asx_op_tdf.argtypes = [vp, _FP, i32, i32, i32, i32, _FP, _FP, i32, _FP, _FP, _FP, _FP]
+    lib.asx_v3_begin.argtypes = [vp, C.POINTER(_V3Cfg)]
+    lib.asx_v3_commit.argtypes = [vp]
+    lib.asx_v3_flops.argtypes = [vp, i32]
+    lib.asx_v3_flops.restype = C.c_double
+    lib.asx_v3_forward.argtypes = [vp, _FP, i32, _FP]
+    lib.asx_mdxc_plan.argtypes = [vp, i64, i32, C.POINTER(_Plan)]
+    lib.asx_mdxc_demix.argtypes = [vp, _FP, i64, i32, _FP]
+    lib.asx_mdxc_demix_dev.argtypes = [vp, vp, i64, i32, vp, vp]
     lib.asx_profile_enable.argtypes = [vp, i32]
     lib.asx_profile_read.argtypes = [vp, C.POINTER(_Profile)]
     for name in SYMBOLS:
@@ -192,6 +223,50 @@ class Engine:
 
     def net_flops(self, batch: int = 1) -> float:
         return float(self._lib.asx_net_flops(self._h, batch))
+
+    # -- MDXC / TFC-TDF v3 ------------------------------------------------------
+    def load_v3(self, v3: V3Config, state_dict: dict):
+        """state_dict: the reference TFC_TDF_net's own keys -> float32 arrays / torch tensors."""
+        norm = {None: 0, "": 0, "None": 0, "InstanceNorm": 1}.get(v3.norm)
+        act = {"relu": 0, "gelu": 1}.get(v3.act)
+        if norm is None or act is None:
+            raise ValueError(f"unsupported norm/act for the HIP path: {v3.norm!r}/{v3.act!r}")
+        c = _V3Cfg(v3.num_channels, v3.num_subbands, v3.num_scales, v3.num_blocks_per_scale, v3.num_channels_model,
+                   v3.growth, v3.bottleneck_factor, norm, act, v3.num_targets)
+        self._check(self._lib.asx_v3_begin(self._h, C.byref(c)))
+        for name, t in state_dict.items():
+            if hasattr(t, "detach"):
+                t = t.detach().cpu().numpy()
+            a = _f32(t).reshape(-1)
+            self._check(self._lib.asx_net_set_tensor(self._h, name.encode(), _ptr(a), a.size))
+        self._check(self._lib.asx_v3_commit(self._h))
+        self.v3_cfg = v3
+
+    def v3_flops(self, batch: int = 1) -> float:
+        return float(self._lib.asx_v3_flops(self._h, batch))
+
+    def v3_forward(self, wave: np.ndarray) -> np.ndarray:
+        wave = _f32(wave)
+        B, ch, Cn = wave.shape
+        out = np.empty((B, self.v3_cfg.num_targets, 2, Cn), np.float32)
+        self._check(self._lib.asx_v3_forward(self._h, _ptr(wave), B, _ptr(out)))
+        return out
+
+    def mdxc_plan(self, n_samples: int, overlap: int) -> dict:
+        p = _Plan()
+        self._check(self._lib.asx_mdxc_plan(self._h, n_samples, overlap, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in _Plan._fields_ if k != "reserved"}
+
+    def mdxc_demix(self, mix: np.ndarray, overlap: int) -> np.ndarray:
+        mix = _f32(mix)
+        if mix.ndim != 2 or mix.shape[0] != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got shape {mix.shape}")
+        out = np.empty((self.v3_cfg.num_targets, 2, mix.shape[1]), np.float32)
+        self._check(self._lib.asx_mdxc_demix(self._h, _ptr(mix), mix.shape[1], int(overlap), _ptr(out)))
+        return out
+
+    def mdxc_demix_dev(self, mix_ptr: int, n_samples: int, overlap: int, out_ptr: int, stream: int = 0):
+        self._check(self._lib.asx_mdxc_demix_dev(self._h, mix_ptr, n_samples, int(overlap), out_ptr, stream or None))
 
     # -- plan ---------------------------------------------------------------
     def plan(self, n_samples: int, is_match_mix: bool = False) -> dict:

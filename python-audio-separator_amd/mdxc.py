@@ -1,0 +1,87 @@
+"""Host-side mirror of the MDXC plugin's TFC-TDF (MDX23C) demix path.
+
+Reference: architectures/mdxc_separator.py (MDXCSeparator.__init__ :22, load_model :76, demix
+:257 -- TFC branch :345-404 and the stem dictionary :406-468) and uvr_lib_v5/tfc_tdf_v3.py.
+The Roformer branch of the same class is not part of this mirror yet.  No CPU path.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from .engine import Engine, MDXConfig, V3Config
+from .mdx import _device_index
+
+
+def _get(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+class MDXCDemixer:
+    """``common_config["model_data"]`` is the parsed model YAML (separator.py:758-777)."""
+
+    def __init__(self, common_config: dict, arch_config: dict, state_dict: dict | None = None, max_batch: int = 0):
+        self.logger = common_config.get("logger") or logging.getLogger(__name__)
+        self.torch_device = common_config.get("torch_device")
+        self.model_data = common_config.get("model_data") or {}
+        self.model_path = common_config.get("model_path")
+        self.primary_stem_name = common_config.get("primary_stem_name")
+        self.secondary_stem_name = common_config.get("secondary_stem_name")
+        self.segment_size = arch_config.get("segment_size", 256)
+        self.override_model_segment_size = arch_config.get("override_model_segment_size", False)
+        self.overlap = arch_config.get("overlap", 8)
+        self.batch_size = arch_config.get("batch_size", 1)
+        self.pitch_shift = arch_config.get("pitch_shift", 0)
+        if self.pitch_shift != 0:
+            raise NotImplementedError("pitch_shift is outside the accelerated path")
+        if self.model_data.get("is_roformer"):
+            raise NotImplementedError("the Roformer branch of MDXCSeparator is not accelerated yet")
+        audio, model, training = (self.model_data.get(k, {}) for k in ("audio", "model", "training"))
+        self.instruments = list(training.get("instruments") or [])
+        self.target_instrument = training.get("target_instrument")
+        self.is_primary_stem_main_target = bool(self.target_instrument)
+        if self.primary_stem_name is None:
+            self.primary_stem_name = self.target_instrument or (self.instruments[0] if self.instruments else "Primary")
+        seg = self.segment_size if self.override_model_segment_size else _get(self.model_data, "inference", "dim_t")
+        self.mdx_segment_size = int(seg)
+        scale = list(model.get("scale", [2, 2]))
+        if scale != [2, 2]:
+            raise NotImplementedError(f"scale {scale} (only [2, 2] is supported)")
+        self.v3 = V3Config(num_channels=audio.get("num_channels", 2), num_subbands=model["num_subbands"],
+                           num_scales=model["num_scales"], num_blocks_per_scale=model["num_blocks_per_scale"],
+                           num_channels_model=model["num_channels"], growth=model["growth"],
+                           bottleneck_factor=model["bottleneck_factor"], norm=model.get("norm"),
+                           act=model.get("act", "gelu"),
+                           num_targets=1 if self.target_instrument else len(self.instruments))
+        self.engine = Engine(MDXConfig(n_fft=audio["n_fft"], hop_length=audio["hop_length"], dim_f=audio["dim_f"],
+                                       segment_size=self.mdx_segment_size, overlap=0.0, max_batch=max_batch),
+                             device=_device_index(self.torch_device))
+        if state_dict is not None or self.model_path:
+            self.load_model(state_dict)
+
+    def load_model(self, state_dict: dict | None = None):
+        """torch.load(model_path) + load_state_dict (mdxc_separator.py:107-110) -> engine tensors."""
+        if state_dict is None:
+            import torch
+            state_dict = torch.load(self.model_path, map_location="cpu")
+        self.engine.load_v3(self.v3, state_dict)
+
+    def demix(self, mix: np.ndarray):
+        """mdxc_separator.py:257-468 for TFC-TDF models: dict of stems, or the primary array."""
+        mix = np.asarray(mix, dtype=np.float32)
+        if mix.ndim != 2 or mix.shape[0] != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got {mix.shape[0] if mix.ndim else 0} channels")
+        if mix.shape[1] == 0:
+            raise ValueError("Audio file is empty or not valid")
+        out = self.engine.mdxc_demix(mix, int(self.overlap))
+        if self.v3.num_targets > 1:
+            return {k: out[i] for i, k in enumerate(self.instruments)}
+        primary = out[0]
+        if self.is_primary_stem_main_target:
+            return {self.primary_stem_name: primary, self.secondary_stem_name: mix - primary}
+        return primary
