@@ -6,7 +6,7 @@ import os as _os
 _pkg = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "python-audio-separator_amd")
 __path__.append(_pkg)
 
-from .engine import Engine, AsxError, MDXConfig, NetConfig, V3Config, lib_path  # noqa: E402,F401
+from .engine import Engine, AsxError, MDXConfig, NetConfig, RofConfig, V3Config, lib_path  # noqa: E402,F401
 from .weights import fold_convtdf_state  # noqa: E402,F401
 from .mdx import STFT, MDXDemixer  # noqa: E402,F401
 from .onnx_reader import convtdf_from_onnx, OnnxFormatError  # noqa: E402,F401

@@ -202,6 +202,31 @@ int asx_mdxc_demix(asx_engine *e, const float *mix_host, int64_t n_samples, int3
 int asx_mdxc_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t overlap, float *out_dev,
                        void *stream);
 
+/* ---- BS-Roformer: uvr_lib_v5/roformer/bs_roformer.py + the Roformer branch of MDXCSeparator.demix ----
+ * Engine geometry (asx_mdx_config): n_fft = stft_n_fft (= stft_win_length), hop_length =
+ * stft_hop_length, dim_f = n_fft/2 + 1, segment_size = inference.dim_t (mdxc_separator.py:276-300).
+ * Weights come in under the reference's own state_dict keys.  dim_head must be 64. */
+typedef struct asx_rof_config {
+  int32_t dim, depth, heads, dim_head;        /* roformer_loader.py:123-135 */
+  int32_t num_stems;
+  int32_t time_depth, freq_depth;             /* time_/freq_transformer_depth */
+  int32_t mlp_expansion_factor, mask_estimator_depth;
+  int32_t n_bands;
+  int32_t n_out;                              /* len(training.instruments): rows of the result (mdxc_separator.py:316) */
+  int32_t freqs_per_bands[128];
+} asx_rof_config;
+int asx_rof_begin(asx_engine *e, const asx_rof_config *cfg);
+int asx_rof_commit(asx_engine *e);
+double asx_rof_flops(const asx_engine *e, int32_t batch);
+/* BSRoformer.forward (bs_roformer.py:418): wave [B,2,chunk] -> [B,S,2,chunk]. */
+int asx_rof_forward(asx_engine *e, const float *wave_host, int32_t batch, float *out_host);
+/* Roformer branch of MDXCSeparator.demix (mdxc_separator.py:272-343): Hamming-weighted fold with the last
+ * chunk re-anchored at the tail; `step` = min(int(overlap * sample_rate), chunk_size) in samples.
+ * mix [2,N] (N >= chunk_size) -> out [n_out,2,N]. */
+int asx_rof_demix(asx_engine *e, const float *mix_host, int64_t n_samples, int64_t step, float *out_host);
+int asx_rof_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int64_t step, float *out_dev,
+                      void *stream);
+
 /* ---- stage hooks (host buffers; mirror the reference's own test surface) ---- */
 /* STFT.__call__ (stft.py:20): wave [B,2,C] -> spec [B,4,dim_f,C/hop+1]. */
 int asx_stft(asx_engine *e, const float *wave_host, int32_t batch, int64_t n_time, float *spec_host);

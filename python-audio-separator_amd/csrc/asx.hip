@@ -20,6 +20,7 @@
 #include "../../include/asx.h"
 #include "kernels_fft.h"
 #include "kernels_net.h"
+#include "kernels_rof.h"
 
 using namespace asx;
 
@@ -109,10 +110,12 @@ struct ProfRec {
 };
 
 struct V3Net;
+struct RofNet;
 
 struct asx_engine {
   int device = 0;
   V3Net *v3 = nullptr;
+  RofNet *rof = nullptr;
   asx_mdx_config cfg{};
   FftPlan plan{};
   DevBuf d_window, d_tw, d_env;  // env for T = segment_size
@@ -733,6 +736,7 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
 }
 
 static void v3_destroy(V3Net *n);
+static void rof_destroy(RofNet *n);
 static void free_conv(ConvLayer &L) {
   L.w.release();
   L.b.release();
@@ -779,6 +783,7 @@ void asx_engine_destroy(asx_engine *e) {
   e->d_demixed.release();
   for (auto &sk : e->skip) sk.release();
   if (e->v3) v3_destroy(e->v3);
+  if (e->rof) rof_destroy(e->rof);
   delete e;
 }
 
@@ -935,6 +940,7 @@ double asx_net_flops(const asx_engine *e, int32_t batch) {
 }
 
 #include "engine_v3.h"
+#include "engine_rof.h"
 
 // ---- plan ------------------------------------------------------------------
 int asx_plan_query(const asx_engine *e, int64_t N, uint32_t flags, asx_plan *out) {
@@ -1471,6 +1477,173 @@ int asx_mdxc_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t over
   CHK(dout.ensure((size_t)S * 2 * N * 4));
   CHK(asx_mdxc_demix_dev(e, dmix.f(), N, overlap, dout.f(), nullptr));
   CHK(to_host(out_host, dout, (size_t)S * 2 * N));
+  return ASX_OK;
+}
+
+// ---- BS-Roformer ------------------------------------------------------------------
+int asx_rof_begin(asx_engine *e, const asx_rof_config *cfg) {
+  REQUIRE(e && cfg, "asx_rof_begin: null argument");
+  REQUIRE(cfg->dim_head == 64, "dim_head must be 64 (got %d)", cfg->dim_head);
+  REQUIRE(cfg->dim > 0 && cfg->dim % 4 == 0 && cfg->depth >= 1 && cfg->heads >= 1 && cfg->num_stems >= 1 &&
+              cfg->time_depth >= 1 && cfg->freq_depth >= 1 && cfg->mlp_expansion_factor >= 1 &&
+              cfg->mask_estimator_depth >= 1 && cfg->n_out >= 1,
+          "bad BS-Roformer hyper-parameters");
+  REQUIRE(cfg->n_bands >= 2 && cfg->n_bands <= 128, "n_bands must be in [2, 128]");
+  int sum = 0;
+  for (int j = 0; j < cfg->n_bands; ++j) {
+    REQUIRE(cfg->freqs_per_bands[j] >= 1, "freqs_per_bands must be positive");
+    sum += cfg->freqs_per_bands[j];
+  }
+  REQUIRE(sum == e->cfg.dim_f && e->cfg.dim_f == e->cfg.n_fft / 2 + 1,
+          "sum(freqs_per_bands) = %d must equal dim_f = n_fft/2 + 1 = %d", sum, e->cfg.n_fft / 2 + 1);
+  if (!e->rof) e->rof = new RofNet();
+  rof_free(*e->rof);
+  RofNet &n = *e->rof;
+  n.cfg = *cfg;
+  n.band_dim.clear();
+  n.band_off.clear();
+  int off = 0;
+  for (int j = 0; j < cfg->n_bands; ++j) {
+    n.band_dim.push_back(4 * cfg->freqs_per_bands[j]);   // 2 (complex) * 2 (stereo) * freqs
+    n.band_off.push_back(off);
+    off += 4 * cfg->freqs_per_bands[j];
+  }
+  n.W = off;
+  n.begun = true;
+  e->host_tensors.clear();
+  e->net_begun = true;
+  return ASX_OK;
+}
+
+int asx_rof_commit(asx_engine *e) {
+  REQUIRE(e, "asx_rof_commit: null engine");
+  if (!e->rof || !e->rof->begun) {
+    set_err("asx_rof_commit before asx_rof_begin");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  RofNet &n = *e->rof;
+  const asx_rof_config &c = n.cfg;
+  const int T = e->cfg.segment_size, Fb = c.n_bands, D = c.dim;
+  n.bs_gamma.assign(Fb, DevBuf());
+  n.bs_lin.assign(Fb, RofLin());
+  for (int j = 0; j < Fb; ++j) {
+    const std::string p = "band_split.to_features." + std::to_string(j);
+    CHK(rof_upload(e, n.bs_gamma[j], p + ".0.gamma", n.band_dim[j]));
+    CHK(rof_load_lin(e, n.bs_lin[j], p + ".1", D, n.band_dim[j], true));
+  }
+  n.time_l.assign(c.depth, {});
+  n.freq_l.assign(c.depth, {});
+  for (int i = 0; i < c.depth; ++i) {
+    n.time_l[i].assign(c.time_depth, RofLayer());
+    n.freq_l[i].assign(c.freq_depth, RofLayer());
+    for (int j = 0; j < c.time_depth; ++j)
+      CHK(rof_load_layer(e, n.time_l[i][j], "layers." + std::to_string(i) + ".0.layers." + std::to_string(j), T));
+    for (int j = 0; j < c.freq_depth; ++j)
+      CHK(rof_load_layer(e, n.freq_l[i][j], "layers." + std::to_string(i) + ".1.layers." + std::to_string(j), Fb));
+  }
+  CHK(rof_upload(e, n.final_g, "final_norm.gamma", D));
+  const int hid = D * c.mlp_expansion_factor;
+  n.mask.assign(c.num_stems, {});
+  for (int st = 0; st < c.num_stems; ++st) {
+    n.mask[st].assign(Fb, {});
+    for (int j = 0; j < Fb; ++j) {
+      auto &mlp = n.mask[st][j];
+      mlp.assign(c.mask_estimator_depth, RofLin());
+      int in = D;
+      for (int li = 0; li < c.mask_estimator_depth; ++li) {
+        const int out = (li + 1 == c.mask_estimator_depth) ? 2 * n.band_dim[j] : hid;
+        CHK(rof_load_lin(e, mlp[li],
+                         "mask_estimators." + std::to_string(st) + ".to_freqs." + std::to_string(j) + ".0." +
+                             std::to_string(2 * li),
+                         out, in, true));
+        in = out;
+      }
+    }
+  }
+  // Hamming fold window (scipy.signal.windows.hamming(chunk), float64 -> float32, mdxc_separator.py:310)
+  const int64_t C = (int64_t)e->cfg.hop_length * (T - 1);
+  std::vector<float> w((size_t)C);
+  for (int64_t i = 0; i < C; ++i)
+    w[i] = (float)(C == 1 ? 1.0 : 0.54 - 0.46 * cos(2.0 * M_PI * (double)i / (double)(C - 1)));
+  CHK(n.d_window.ensure((size_t)C * 4));
+  HIPCHK(hipMemcpy(n.d_window.p, w.data(), (size_t)C * 4, hipMemcpyHostToDevice));
+  e->host_tensors.clear();
+  n.ready = true;
+  return ASX_OK;
+}
+
+double asx_rof_flops(const asx_engine *e, int32_t batch) { return e ? rof_flops(e, batch) : 0.0; }
+
+int asx_rof_forward(asx_engine *e, const float *wave_host, int32_t B, float *out_host) {
+  REQUIRE(e && wave_host && out_host && B > 0, "asx_rof_forward: bad argument");
+  if (!e->rof || !e->rof->ready) {
+    set_err("asx_rof_forward: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  const int64_t C = (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1);
+  const int S = e->rof->cfg.num_stems;
+  DevBuf dw, dout;
+  BufGuard g{{&dw, &dout}};
+  CHK(to_dev(dw, wave_host, (size_t)B * 2 * C));
+  CHK(dout.ensure((size_t)B * S * 2 * C * 4));
+  CHK(rof_chunks_dev(e, dw.f(), nullptr, -1, B, dout.f(), nullptr));
+  CHK(to_host(out_host, dout, (size_t)B * S * 2 * C));
+  return ASX_OK;
+}
+
+int asx_rof_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int64_t step, float *out_dev, void *stream) {
+  REQUIRE(e && mix_dev && out_dev, "asx_rof_demix_dev: null argument");
+  if (!e->rof || !e->rof->ready) {
+    set_err("asx_rof_demix: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  RofNet &n = *e->rof;
+  const int S = n.cfg.num_stems;
+  const int64_t C = (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1);
+  REQUIRE(N >= C, "mix (%lld samples) shorter than one chunk (%lld): not supported on the Roformer path", (long long)N,
+          (long long)C);
+  REQUIRE(step >= 1 && step <= C, "step must be in [1, chunk_size]");
+  std::vector<int64_t> starts;
+  for (int64_t i = 0; i < N; i += step) starts.push_back(i + C > N ? N - C : i);   // tail re-anchored (:323-336)
+  const int nk = (int)starts.size();
+  CHK(n.chunk_out.ensure((size_t)nk * S * 2 * C * 4));
+  CHK(n.d_starts.ensure((size_t)nk * 8));
+  HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const int maxB = e->cfg.max_batch > 0 ? e->cfg.max_batch : 8;
+  const int nbatch = (nk + maxB - 1) / maxB;
+  const int per = (nk + nbatch - 1) / nbatch;
+  for (int k0 = 0; k0 < nk; k0 += per) {
+    const int B = std::min(per, nk - k0);
+    CHK(rof_chunks_dev(e, mix_dev, reinterpret_cast<const int64_t *>(n.d_starts.p) + k0, N, B,
+                       n.chunk_out.f() + (size_t)k0 * S * 2 * C, s));
+  }
+  const int n_out = n.cfg.n_out;
+  return timed(e, ASX_PROF_FINALIZE, 0.0, 4.0 * ((double)nk * S * 2 * C + 2.0 * n_out * N), s, [&]() {
+    hipLaunchKernelGGL(roformer_finalize_kernel, dim3((unsigned)((N + 255) / 256), n_out * 2), dim3(256), 0, s,
+                       n.chunk_out.f(), reinterpret_cast<const int64_t *>(n.d_starts.p), nk, S, C, n.d_window.f(), N,
+                       out_dev);
+  });
+}
+
+int asx_rof_demix(asx_engine *e, const float *mix_host, int64_t N, int64_t step, float *out_host) {
+  REQUIRE(e && mix_host && out_host, "asx_rof_demix: null argument");
+  if (!e->rof || !e->rof->ready) {
+    set_err("asx_rof_demix: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  const int n_out = e->rof->cfg.n_out;
+  DevBuf dmix, dout;
+  BufGuard g{{&dmix, &dout}};
+  CHK(to_dev(dmix, mix_host, (size_t)2 * N));
+  CHK(dout.ensure((size_t)n_out * 2 * N * 4));
+  CHK(asx_rof_demix_dev(e, dmix.f(), N, step, dout.f(), nullptr));
+  CHK(to_host(out_host, dout, (size_t)n_out * 2 * N));
   return ASX_OK;
 }
 

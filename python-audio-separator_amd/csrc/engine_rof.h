@@ -1,0 +1,392 @@
+// BS-Roformer on the engine: uvr_lib_v5/roformer/bs_roformer.py:300-522 and the Roformer branch of
+// MDXCSeparator.demix (architectures/mdxc_separator.py:272-343).  Included by asx.hip (one TU).
+#pragma once
+
+struct RofLin {
+  int n = 0, k = 0;
+  DevBuf w, b;   // w [n, k] (nn.Linear layout), optional bias [n]
+  bool has_bias = false;
+};
+
+struct RofAttn {
+  DevBuf norm_g;
+  RofLin qkv, gates, out;
+  DevBuf rot_tab;   // [n_pos, dh/2] (cos, sin)
+};
+
+struct RofFF {
+  DevBuf norm_g;
+  RofLin l1, l2;
+};
+
+struct RofLayer {
+  RofAttn attn;
+  RofFF ff;
+};
+
+struct RofNet {
+  asx_rof_config cfg{};
+  bool begun = false, ready = false;
+  std::vector<int> band_dim, band_off;   // per band: 2 * f * channels, offset inside the (f s c) vector
+  int W = 0;                              // sum of band dims = 2 * 2 * n_bins
+  std::vector<DevBuf> bs_gamma;
+  std::vector<RofLin> bs_lin;
+  std::vector<std::vector<RofLayer>> time_l, freq_l;   // [depth][transformer depth]
+  DevBuf final_g;
+  std::vector<std::vector<std::vector<RofLin>>> mask;  // [stem][band][mlp layer]
+  // workspace
+  int ws_batch = 0;
+  DevBuf X0, XB, TOK, XN, QKV, ATT, GATE, FFH, HID, GLU, MASK, frames, chunk_out, d_starts, d_window;
+};
+
+static void rof_free_lin(RofLin &l) {
+  l.w.release();
+  l.b.release();
+}
+static void rof_free_layer(RofLayer &l) {
+  l.attn.norm_g.release();
+  rof_free_lin(l.attn.qkv);
+  rof_free_lin(l.attn.gates);
+  rof_free_lin(l.attn.out);
+  l.attn.rot_tab.release();
+  l.ff.norm_g.release();
+  rof_free_lin(l.ff.l1);
+  rof_free_lin(l.ff.l2);
+}
+static void rof_free(RofNet &n) {
+  for (auto &g : n.bs_gamma) g.release();
+  for (auto &l : n.bs_lin) rof_free_lin(l);
+  for (auto &d : n.time_l)
+    for (auto &l : d) rof_free_layer(l);
+  for (auto &d : n.freq_l)
+    for (auto &l : d) rof_free_layer(l);
+  n.final_g.release();
+  for (auto &s : n.mask)
+    for (auto &b : s)
+      for (auto &l : b) rof_free_lin(l);
+  DevBuf *bufs[] = {&n.X0, &n.XB, &n.TOK, &n.XN, &n.QKV, &n.ATT, &n.GATE, &n.FFH, &n.HID, &n.GLU,
+                    &n.MASK, &n.frames, &n.chunk_out, &n.d_starts, &n.d_window};
+  for (auto *b : bufs) b->release();
+  n.ready = false;
+  n.ws_batch = 0;
+}
+static void rof_destroy(RofNet *n) {
+  rof_free(*n);
+  delete n;
+}
+
+static int rof_upload(asx_engine *e, DevBuf &d, const std::string &name, int64_t numel) {
+  const float *p;
+  CHK(get_tensor(e, name, numel, &p));
+  CHK(d.ensure((size_t)numel * 4));
+  HIPCHK(hipMemcpy(d.p, p, (size_t)numel * 4, hipMemcpyHostToDevice));
+  return ASX_OK;
+}
+
+static int rof_load_lin(asx_engine *e, RofLin &l, const std::string &name, int n, int k, bool bias) {
+  l.n = n;
+  l.k = k;
+  l.has_bias = bias;
+  CHK(rof_upload(e, l.w, name + ".weight", (int64_t)n * k));
+  if (bias) CHK(rof_upload(e, l.b, name + ".bias", n));
+  return ASX_OK;
+}
+
+// cos/sin table exactly as torch builds it: angle = float32(pos) * float32(freq) (one float32
+// rounding), then cos/sin of that float32 angle.
+static int rof_rot_table(asx_engine *e, DevBuf &tab, const std::string &name, int n_pos, int half) {
+  const float *fr;
+  CHK(get_tensor(e, name, half, &fr));
+  std::vector<float> t((size_t)n_pos * half * 2);
+  for (int p = 0; p < n_pos; ++p)
+    for (int i = 0; i < half; ++i) {
+      const float ang = (float)p * fr[i];
+      t[((size_t)p * half + i) * 2] = (float)cos((double)ang);
+      t[((size_t)p * half + i) * 2 + 1] = (float)sin((double)ang);
+    }
+  CHK(tab.ensure(t.size() * 4));
+  HIPCHK(hipMemcpy(tab.p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+  return ASX_OK;
+}
+
+static int rof_load_layer(asx_engine *e, RofLayer &L, const std::string &p, int n_pos) {
+  const asx_rof_config &c = e->rof->cfg;
+  const int d = c.dim, inner = c.heads * c.dim_head;
+  CHK(rof_upload(e, L.attn.norm_g, p + ".0.norm.gamma", d));
+  CHK(rof_load_lin(e, L.attn.qkv, p + ".0.to_qkv", 3 * inner, d, false));
+  CHK(rof_load_lin(e, L.attn.gates, p + ".0.to_gates", c.heads, d, true));
+  CHK(rof_load_lin(e, L.attn.out, p + ".0.to_out.0", d, inner, false));
+  CHK(rof_rot_table(e, L.attn.rot_tab, p + ".0.rotary_embed.freqs", n_pos, c.dim_head / 2));
+  CHK(rof_upload(e, L.ff.norm_g, p + ".1.net.0.gamma", d));
+  CHK(rof_load_lin(e, L.ff.l1, p + ".1.net.1", 4 * d, d, true));
+  CHK(rof_load_lin(e, L.ff.l2, p + ".1.net.4", d, 4 * d, true));
+  return ASX_OK;
+}
+
+// y[M, n] (row stride ldy) = act(x[M, k] (row stride lda) @ w^T + b) (+ res)
+static int rof_gemm(asx_engine *e, const RofLin &L, const float *x, int64_t lda, int64_t M, float *y, int64_t ldy,
+                    int act, const float *res, int64_t ldr, hipStream_t s) {
+  if (M <= 0) return ASX_OK;
+  if ((L.k & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) {
+    set_err("rof_gemm: K and the row stride must be multiples of 4 floats (K=%d lda=%lld)", L.k, (long long)lda);
+    return ASX_ERR_INVALID;
+  }
+  TdfDmaArgs d{};
+  d.x = x;
+  d.w = L.w.f();
+  d.bias = L.has_bias ? L.b.f() : nullptr;
+  d.scale = nullptr;
+  d.shift = nullptr;
+  d.res = res;
+  d.zeros = e->d_zeros.f();
+  d.y = y;
+  d.M = M;
+  d.N = L.n;
+  d.K = L.k;
+  d.C = 1;
+  d.T = 1;
+  d.relu = act;
+  d.lda = lda;
+  // the float4 epilogue needs 16-byte aligned rows; otherwise force the scalar epilogue by an odd N check inside
+  d.ldy = ldy;
+  d.ldr = ldr;
+  const bool vec_ok = (ldy % 4 == 0) && (res == nullptr || ldr % 4 == 0) && (L.n % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+                      (res == nullptr || (reinterpret_cast<uintptr_t>(res) & 15) == 0);
+  if (!vec_ok) {
+    set_err("rof_gemm: output rows must be 16-byte aligned (N=%d ldy=%lld)", L.n, (long long)ldy);
+    return ASX_ERR_INVALID;
+  }
+  const double flops = 2.0 * (double)M * L.n * L.k;
+  const double bytes = 4.0 * ((double)M * L.k + (double)M * L.n * (res ? 2 : 1) + (double)L.n * L.k);
+  return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
+    if (L.n > 128) launch_tdf_dma_t<3, 8>(d, s);
+    else if (L.n > 64) launch_tdf_dma_t<2, 4>(d, s);
+    else launch_tdf_dma_t<1, 4>(d, s);
+  });
+}
+
+static int rof_rmsnorm(asx_engine *e, const float *x, int64_t lda, int d, const float *g, float *y, int64_t ldy,
+                       int64_t M, hipStream_t s) {
+  return timed(e, ASX_PROF_MISC, 0.0, 8.0 * M * d, s, [&]() {
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, lda, d, g, y, ldy, M);
+  });
+}
+
+// one Transformer (bs_roformer.py:136-160, norm_output = False) over the token matrix TOK [M, D]
+static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool time_axis, int B, hipStream_t s) {
+  RofNet &n = *e->rof;
+  const asx_rof_config &c = n.cfg;
+  const int T = e->cfg.segment_size, Fb = c.n_bands, D = c.dim, H = c.heads, inner = H * c.dim_head;
+  const int64_t M = (int64_t)B * T * Fb;
+  for (auto &L : layers) {
+    // attention: x = attn(x) + x
+    CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.attn.norm_g.f(), n.XN.f(), D, M, s));
+    CHK(rof_gemm(e, L.attn.qkv, n.XN.f(), D, M, n.QKV.f(), 3 * inner, 0, nullptr, 0, s));
+    {
+      const int64_t tot = M * 2 * H * (c.dim_head / 2);
+      const int64_t pos_div = time_axis ? Fb : 1;
+      const int pos_mod = time_axis ? T : Fb;
+      float2 *tab = reinterpret_cast<float2 *>(L.attn.rot_tab.p);
+      CHK(timed(e, ASX_PROF_MISC, 0.0, 16.0 * tot, s, [&]() {
+        hipLaunchKernelGGL(rotary_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n.QKV.f(),
+                           (int64_t)3 * inner, M, H, c.dim_head, tab, pos_div, pos_mod);
+      }));
+    }
+    {
+      // gates: [M, heads]; rows are padded to a multiple of 4 floats
+      const int gl = (H + 3) / 4 * 4;
+      RofLin &G = L.attn.gates;
+      if (H % 4 == 0) {
+        CHK(rof_gemm(e, G, n.XN.f(), D, M, n.GATE.f(), gl, 0, nullptr, 0, s));
+      } else {
+        // tiny head counts (tests): scalar epilogue through the generic register-staged kernel
+        TdfArgs a{};
+        a.x = n.XN.f();
+        a.w = G.w.f();
+        a.bias = G.b.f();
+        a.scale = nullptr;
+        a.shift = nullptr;
+        a.res = nullptr;
+        a.y = n.GATE.f();
+        a.M = M;
+        a.N = H;
+        a.K = D;
+        a.C = 1;
+        a.T = 1;
+        a.relu = 0;
+        CHK(timed(e, ASX_PROF_TDF, 2.0 * M * H * D, 4.0 * M * (D + H), s, [&]() { launch_tdf_t<1, 4>(a, s); }));
+      }
+      AttnArgs aa{};
+      aa.qkv = n.QKV.f();
+      aa.gate = n.GATE.f();
+      aa.out = n.ATT.f();
+      aa.heads = H;
+      aa.gate_ld = (H % 4 == 0) ? gl : H;
+      aa.scale = 1.0f / sqrtf((float)c.dim_head);
+      int64_t nseq;
+      if (time_axis) {
+        aa.len = T;
+        aa.row_stride = Fb;
+        aa.inner_cnt = Fb;
+        aa.outer_stride = (int64_t)T * Fb;
+        aa.inner_stride = 1;
+        nseq = (int64_t)B * Fb;
+      } else {
+        aa.len = Fb;
+        aa.row_stride = 1;
+        aa.inner_cnt = 1;
+        aa.outer_stride = Fb;
+        aa.inner_stride = 0;
+        nseq = (int64_t)B * T;
+      }
+      const int qtiles = (aa.len + 63) / 64;
+      const double fl = 4.0 * (double)nseq * H * (double)aa.len * aa.len * c.dim_head;
+      CHK(timed(e, ASX_PROF_CONV1X1, fl, 4.0 * M * 4 * inner, s, [&]() {
+        hipLaunchKernelGGL(attention_kernel, dim3(qtiles, H, (unsigned)nseq), dim3(256), 0, s, aa);
+      }));
+    }
+    CHK(rof_gemm(e, L.attn.out, n.ATT.f(), inner, M, n.TOK.f(), D, 0, n.TOK.f(), D, s));   // + x (in place: each
+    // output element depends only on ATT and on the same TOK element it overwrites)
+    // feed-forward: x = ff(x) + x
+    CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.ff.norm_g.f(), n.XN.f(), D, M, s));
+    CHK(rof_gemm(e, L.ff.l1, n.XN.f(), D, M, n.FFH.f(), 4 * D, 2, nullptr, 0, s));          // GELU
+    CHK(rof_gemm(e, L.ff.l2, n.FFH.f(), 4 * D, M, n.TOK.f(), D, 0, n.TOK.f(), D, s));
+  }
+  return ASX_OK;
+}
+
+static int rof_ensure_workspace(asx_engine *e, int B) {
+  RofNet &n = *e->rof;
+  if (B <= n.ws_batch) return ASX_OK;
+  const asx_rof_config &c = n.cfg;
+  const int T = e->cfg.segment_size, Fb = c.n_bands, D = c.dim, inner = c.heads * c.dim_head;
+  const size_t M = (size_t)B * T * Fb, BT = (size_t)B * T;
+  const int hid = D * c.mlp_expansion_factor;
+  int maxd = 0;
+  for (int d : n.band_dim) maxd = std::max(maxd, d);
+  CHK(n.X0.ensure(BT * n.W * 4));
+  CHK(n.XB.ensure(BT * maxd * 4 + 256));
+  CHK(n.TOK.ensure(M * D * 4));
+  CHK(n.XN.ensure(M * D * 4));
+  CHK(n.QKV.ensure(M * 3 * inner * 4));
+  CHK(n.ATT.ensure(M * inner * 4));
+  CHK(n.GATE.ensure(M * ((c.heads + 3) / 4 * 4) * 4));
+  CHK(n.FFH.ensure(M * 4 * D * 4));
+  CHK(n.HID.ensure(BT * hid * 4));
+  CHK(n.GLU.ensure(BT * 2 * maxd * 4));
+  CHK(n.MASK.ensure(BT * c.num_stems * n.W * 4));
+  CHK(n.frames.ensure((size_t)B * c.num_stems * 2 * T * e->cfg.n_fft * 4));
+  n.ws_batch = B;
+  return ASX_OK;
+}
+
+// wave chunks -> separated chunks [B, S, 2, C]
+static int rof_chunks_dev(asx_engine *e, const float *wave, const int64_t *d_starts, int64_t n_song, int B, float *out,
+                          hipStream_t s) {
+  RofNet &n = *e->rof;
+  const asx_rof_config &c = n.cfg;
+  const int T = e->cfg.segment_size, Fb = c.n_bands, D = c.dim, S = c.num_stems;
+  const int64_t C = (int64_t)e->cfg.hop_length * (T - 1);
+  const int64_t BT = (int64_t)B * T, M = BT * Fb;
+  CHK(rof_ensure_workspace(e, B));
+  {
+    StftArgs a{};
+    a.wave = wave;
+    a.chunk_start = d_starts;
+    a.n_song = n_song;
+    a.trim = 0;
+    a.C = C;
+    a.hop = e->cfg.hop_length;
+    a.T = T;
+    a.dim_f = e->cfg.dim_f;
+    a.zero_low = 0;
+    a.tf_layout = 2;
+    a.spec = n.X0.f();
+    a.window = e->d_window.f();
+    a.tw = reinterpret_cast<const float2 *>(e->d_tw.p);
+    a.sign = 1.0f;
+    FftPlan p = e->plan;
+    CHK(timed(e, ASX_PROF_STFT, 0.0, 4.0 * ((double)B * 2 * C + (double)BT * n.W), s, [&]() {
+      hipLaunchKernelGGL(stft_kernel, dim3(T, 2, B), dim3(256), stft_lds(p), s, a, p);
+    }));
+  }
+  // band split (bs_roformer.py:163-185): per band RMSNorm + Linear -> TOK[(b t), band, :]
+  for (int j = 0; j < Fb; ++j) {
+    const int din = n.band_dim[j];
+    CHK(rof_rmsnorm(e, n.X0.f() + n.band_off[j], n.W, din, n.bs_gamma[j].f(), n.XB.f(), din, BT, s));
+    CHK(rof_gemm(e, n.bs_lin[j], n.XB.f(), din, BT, n.TOK.f() + (int64_t)j * D, (int64_t)Fb * D, 0, nullptr, 0, s));
+  }
+  for (int i = 0; i < c.depth; ++i) {
+    CHK(rof_transformer(e, n.time_l[i], true, B, s));
+    CHK(rof_transformer(e, n.freq_l[i], false, B, s));
+  }
+  CHK(rof_rmsnorm(e, n.TOK.f(), D, D, n.final_g.f(), n.XN.f(), D, M, s));
+  // mask estimators (bs_roformer.py:205-229): per stem, per band MLP (tanh) + GLU -> MASK[b, stem, t, band slice]
+  for (int st = 0; st < S; ++st)
+    for (int j = 0; j < Fb; ++j) {
+      const int din = n.band_dim[j];
+      auto &mlp = n.mask[st][j];
+      const float *cur = n.XN.f() + (int64_t)j * D;
+      int64_t ld = (int64_t)Fb * D;
+      for (size_t li = 0; li + 1 < mlp.size(); ++li) {
+        float *dst = (li & 1) ? n.FFH.f() : n.HID.f();
+        CHK(rof_gemm(e, mlp[li], cur, ld, BT, dst, mlp[li].n, 3, nullptr, 0, s));   // tanh
+        cur = dst;
+        ld = mlp[li].n;
+      }
+      CHK(rof_gemm(e, mlp.back(), cur, ld, BT, n.GLU.f(), 2 * din, 0, nullptr, 0, s));
+      {
+        const int64_t tot = BT * din;
+        float *dst = n.MASK.f() + n.band_off[j];
+        const float *src = n.GLU.f();
+        const int64_t Wl = n.W;
+        CHK(timed(e, ASX_PROF_MISC, 0.0, 12.0 * tot, s, [&]() {
+          hipLaunchKernelGGL(glu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, din, BT, T, S, st, dst,
+                             Wl);
+        }));
+      }
+    }
+  {
+    IstftArgs a{};
+    a.spec = n.X0.f();
+    a.mask = n.MASK.f();
+    a.T = T;
+    a.dim_f = e->cfg.dim_f;
+    a.tf_layout = 2;
+    a.combine = 0;
+    a.frames = n.frames.f();
+    a.window = e->d_window.f();
+    a.tw = reinterpret_cast<const float2 *>(e->d_tw.p);
+    a.n_inst = S;
+    FftPlan p = e->plan;
+    CHK(timed(e, ASX_PROF_ISTFT, 0.0, 4.0 * ((double)BT * n.W * (1 + S) + (double)B * S * 2 * T * e->cfg.n_fft), s,
+              [&]() { hipLaunchKernelGGL(istft_kernel, dim3(T, 2, B * S), dim3(256), istft_lds(p), s, a, p); }));
+  }
+  CHK(ola_launch(e, n.frames.f(), e->d_env.f(), nullptr, B * S, T, C, out, s));
+  return ASX_OK;
+}
+
+static double rof_flops(const asx_engine *e, int batch) {
+  if (!e->rof || !e->rof->begun) return 0.0;
+  const RofNet &n = *e->rof;
+  const asx_rof_config &c = n.cfg;
+  const double T = e->cfg.segment_size, Fb = c.n_bands, D = c.dim, inner = c.heads * c.dim_head;
+  const double M = T * Fb;
+  double fl = 0;
+  for (int d : n.band_dim) fl += 2.0 * T * d * D;
+  const double per_layer = 2.0 * M * (D * 3 * inner + D * c.heads + inner * D + 2 * D * 4 * D);
+  const double att_t = 4.0 * Fb * c.heads * T * T * c.dim_head, att_f = 4.0 * T * c.heads * Fb * Fb * c.dim_head;
+  fl += c.depth * (c.time_depth * (per_layer + att_t) + c.freq_depth * (per_layer + att_f));
+  const double hid = D * c.mlp_expansion_factor;
+  for (int d : n.band_dim) {
+    double m = 0, in = D;
+    for (int li = 0; li + 1 < c.mask_estimator_depth; ++li) {
+      m += 2.0 * T * in * hid;
+      in = hid;
+    }
+    m += 2.0 * T * in * 2 * d;
+    fl += c.num_stems * m;
+  }
+  return fl * batch;
+}

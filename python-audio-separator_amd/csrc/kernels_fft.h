@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a, FftPlan p) {
       re = X.x * a.sign;
       im = X.y * a.sign;
     }
-    if (a.tf_layout) {
+    if (a.tf_layout == 2) {
+      // BS-Roformer: b t (f s c) -- frequency-major with the stereo channel interleaved (bs_roformer.py:455-459)
+      reinterpret_cast<float2 *>(a.spec)[(((int64_t)b * a.T + t) * a.dim_f + k) * 2 + ch] = make_float2(re, im);
+    } else if (a.tf_layout) {
       const int kb = a.subbands > 1 ? a.subbands : 1;
       const int fs = a.dim_f / kb;
       const int j = k / fs, fp = k - j * fs;
@@ -235,12 +238,19 @@ struct IstftArgs {
   int subbands;        // cws2cac (tfc_tdf_v3.py:223): plane p*k + j holds bins j*F/k ...
   int n_inst;          // S >= 1 stems per batch item: blockIdx.z = b*S + s, planes [s*4k, (s+1)*4k)
   int64_t in_bstride;  // floats between batch items of spec (tf_layout only); 0 = dense
+  const float *mask;   // tf_layout == 2 (BS-Roformer): complex mask [B, S, T, (f s c)] multiplied in (bs_roformer.py:503-506)
 };
 
 __device__ __forceinline__ float2 load_bin(const IstftArgs &a, int b, int ch, int t, int k) {
   if (k >= a.dim_f) return make_float2(0.f, 0.f);
   float re, im;
-  if (a.tf_layout) {
+  if (a.tf_layout == 2) {
+    const int S = a.n_inst > 1 ? a.n_inst : 1;
+    const int bb = b / S, si = b - bb * S;
+    const float2 x = reinterpret_cast<const float2 *>(a.spec)[(((int64_t)bb * a.T + t) * a.dim_f + k) * 2 + ch];
+    const float2 m = reinterpret_cast<const float2 *>(a.mask)[((((int64_t)bb * S + si) * a.T + t) * a.dim_f + k) * 2 + ch];
+    return make_float2(x.x * m.x - x.y * m.y, x.x * m.y + x.y * m.x);
+  } else if (a.tf_layout) {
     const int kb = a.subbands > 1 ? a.subbands : 1;
     const int S = a.n_inst > 1 ? a.n_inst : 1;
     const int fs = a.dim_f / kb;

@@ -326,7 +326,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 // Fragments are fetched with ds_read_b128 (4 consecutive k per lane); the k
 // order inside a 16-wide step is permuted identically for both operands.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float tdf_act(float v, int relu) { return relu ? fmaxf(v, 0.f) : v; }
+// row-GEMM activations: 0 none, 1 relu, 2 gelu (erf), 3 tanh
+__device__ __forceinline__ float tdf_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == 3) return tanhf(v);
+  return v;
+}
 
 struct TdfArgs {
   const float *x;      // [M, K]
@@ -695,7 +701,8 @@ struct TdfDmaArgs {
   float *y;
   int64_t M;
   int N, K, C, T;
-  int relu;
+  int relu;                 // activation enum of tdf_act()
+  int64_t lda, ldy, ldr;    // row strides (floats) of x, y, res; 0 = dense (K, N, N)
 };
 
 template <int NREP, int MREP>
@@ -724,6 +731,7 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
   const int64_t bm = lid / nbn;
   const int64_t m0 = bm * BM;
   const int n0 = bn * BN;
+  const int64_t lda = a.lda ? a.lda : a.K, ldy = a.ldy ? a.ldy : a.N, ldr = a.ldr ? a.ldr : a.N;
 
   // DMA lane role: row-in-issue = lane / 8, physical chunk p = lane % 8
   const int lr = lane >> 3, lp = lane & 7;
@@ -739,7 +747,7 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
         const int c = lp ^ ((row >> 1) & 7);   // logical chunk fetched into physical slot lp
         const int k = k0 + c * 4;
         const bool ok = (m0 + row < a.M) && (k < a.K);
-        const float *src = ok ? a.x + (m0 + row) * a.K + k : a.zeros;
+        const float *src = ok ? a.x + (m0 + row) * lda + k : a.zeros;
         ASX_GLDS16(src, xs + q * 256);
       }
     }
@@ -817,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
 #pragma unroll
         for (int n = 0; n < NREP; ++n) {
           const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
-          rs[m][n] = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(a.res + row * a.N + col)
+          rs[m][n] = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(a.res + row * ldr + col)
                                         : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
           o.y = tdf_act(sc[m] * (v.y + bz[n].y) + sh[m], a.relu) + rs[m][n].y;
           o.z = tdf_act(sc[m] * (v.z + bz[n].z) + sh[m], a.relu) + rs[m][n].z;
           o.w = tdf_act(sc[m] * (v.w + bz[n].w) + sh[m], a.relu) + rs[m][n].w;
-          *reinterpret_cast<f32x4 *>(a.y + row * a.N + col) = o;
+          *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = o;
         }
       }
     }
@@ -856,10 +864,10 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
         const float bzz = (a.bias != nullptr && col + r < a.N) ? a.bias[col + r] : 0.f;
         o[r] = tdf_act(sc * (o[r] + bzz) + sh, a.relu);
       }
-      float *dst = a.y + row * a.N + col;
+      float *dst = a.y + row * ldy + col;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (col + r < a.N) dst[r] = o[r] + (a.res != nullptr ? a.res[row * a.N + col + r] : 0.f);
+        if (col + r < a.N) dst[r] = o[r] + (a.res != nullptr ? a.res[row * ldr + col + r] : 0.f);
     }
   }
 }

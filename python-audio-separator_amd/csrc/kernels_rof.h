@@ -1,0 +1,252 @@
+// BS-Roformer kernels for gfx950 (uvr_lib_v5/roformer/bs_roformer.py, attend.py).
+//
+// Tokens live as rows of a [M, D] matrix, M = B * T * Fb ordered (b, t, band); every linear is
+// the row GEMM of kernels_net.h.  The axial attention never permutes the token matrix: a
+// sequence is (base row, row stride, length) -- time attention walks rows with stride Fb,
+// frequency attention walks consecutive rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asx {
+
+// ---------------------------------------------------------------------------
+// RMSNorm (bs_roformer.py:42-52): y = x / max(||x||_2, 1e-12) * sqrt(d) * gamma, one wave per row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float *__restrict__ x, int64_t lda, int d,
+                                                      const float *__restrict__ gamma, float *__restrict__ y,
+                                                      int64_t ldy, int64_t M) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float *xp = x + row * lda;
+  float ss = 0.f;
+  for (int i = lane; i < d; i += 64) {
+    const float v = xp[i];
+    ss += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  const float denom = fmaxf(sqrtf(ss), 1e-12f);
+  const float scale = sqrtf((float)d);
+  float *yp = y + row * ldy;
+  for (int i = lane; i < d; i += 64) yp[i] = xp[i] / denom * scale * gamma[i];
+}
+
+// ---------------------------------------------------------------------------
+// Rotary embedding on the q and k thirds of the qkv matrix, in place
+// (rotary_embedding_torch.apply_rotary_emb: t*cos + rotate_half(t)*sin, interleaved pairs).
+// tab[pos][i] = (cos, sin) of float32(pos) * freqs[i];  pos(row) = (row / pos_div) % pos_mod.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rotary_kernel(float *__restrict__ qkv, int64_t ld, int64_t M, int heads, int dh,
+                                                     const float2 *__restrict__ tab, int64_t pos_div, int pos_mod) {
+  const int half = dh / 2;
+  const int per_row = 2 * heads * half;  // q and k pairs
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * per_row) return;
+  const int64_t row = idx / per_row;
+  const int r = (int)(idx - row * per_row);
+  const int which = r / (heads * half);          // 0 = q, 1 = k
+  const int hp = r - which * heads * half;
+  const int h = hp / half, i = hp - h * half;
+  const int pos = (int)((row / pos_div) % pos_mod);
+  const float2 cs = tab[(int64_t)pos * half + i];
+  float2 *p = reinterpret_cast<float2 *>(qkv + row * ld + (int64_t)which * heads * dh + h * dh + 2 * i);
+  const float2 v = *p;
+  *p = make_float2(v.x * cs.x - v.y * cs.y, v.y * cs.x + v.x * cs.y);
+}
+
+// ---------------------------------------------------------------------------
+// Softmax attention with per-head sigmoid gates (bs_roformer.py:86-103, attend.py:100-112):
+//   out[i, h, :] = softmax_j(q_i . k_j * dh^-0.5) v_j * sigmoid(gate[i, h])
+// dh = 64, fp32 MFMA 16x16x4.  Workgroup = 64 queries of one (sequence, head); 4 waves x 16 queries.
+// Per 64-key tile:  S^T = K Q^T  (keys on the MFMA M axis, queries on N), online softmax per
+// query column (registers + 2 cross-lane steps), then O^T += V^T P^T with P^T taken straight from
+// the S^T accumulator registers: lane (li, lk) holds P[query li][key 4*lk + r], which is exactly the
+// B operand of step r when the key order inside a 16-key tile is permuted the same way for V.
+// ---------------------------------------------------------------------------
+struct AttnArgs {
+  const float *qkv;   // [M, 3*heads*64]  (q | k | v), rotary already applied
+  const float *gate;  // [M, heads] pre-sigmoid
+  float *out;         // [M, heads*64]
+  int heads;
+  int gate_ld;        // row stride of gate
+  int len;            // sequence length
+  int64_t row_stride; // rows between consecutive sequence positions
+  int64_t inner_cnt;  // sequence s -> base row = (s / inner_cnt) * outer_stride + (s % inner_cnt) * inner_stride
+  int64_t outer_stride, inner_stride;
+  float scale;
+};
+
+constexpr int ATT_QS = 66;  // LDS row strides (floats): Q/K == 2 (mod 32), V == 4 (mod 8)
+constexpr int ATT_VS = 68;
+constexpr int ATT_LDS_BYTES = (64 * ATT_QS * 2 + 64 * ATT_VS) * 4;
+
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+  __shared__ float lds[64 * ATT_QS * 2 + 64 * ATT_VS];
+  float *Qs = lds, *Ks = lds + 64 * ATT_QS, *Vs = lds + 128 * ATT_QS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int qt = blockIdx.x, h = blockIdx.y;
+  const int64_t sq = blockIdx.z;
+  const int64_t base = (sq / a.inner_cnt) * a.outer_stride + (sq % a.inner_cnt) * a.inner_stride;
+  const int inner = a.heads * 64;
+  const int64_t ld = 3 * (int64_t)inner;
+  const int q0 = qt * 64;
+
+  // stage the Q tile (rows beyond len are zero)
+  for (int e = tid; e < 64 * 16; e += 256) {
+    const int r = e >> 4, c4 = e & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q0 + r < a.len)
+      v = *reinterpret_cast<const float4 *>(a.qkv + (base + (int64_t)(q0 + r) * a.row_stride) * ld + h * 64 + c4 * 4);
+    float *d = &Qs[r * ATT_QS + c4 * 4];
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+    d[3] = v.w;
+  }
+
+  f32x4 acc_o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc_o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nkt = (a.len + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int k0 = kt * 64;
+    __syncthreads();  // previous tile fully consumed (and Q staged on the first pass)
+    for (int e = tid; e < 64 * 16; e += 256) {
+      const int r = e >> 4, c4 = e & 15;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (k0 + r < a.len) {
+        const float *rowp = a.qkv + (base + (int64_t)(k0 + r) * a.row_stride) * ld + h * 64 + c4 * 4;
+        kv = *reinterpret_cast<const float4 *>(rowp + inner);
+        vv = *reinterpret_cast<const float4 *>(rowp + 2 * inner);
+      }
+      float *dk = &Ks[r * ATT_QS + c4 * 4];
+      dk[0] = kv.x;
+      dk[1] = kv.y;
+      dk[2] = kv.z;
+      dk[3] = kv.w;
+      *reinterpret_cast<float4 *>(&Vs[r * ATT_VS + c4 * 4]) = vv;
+    }
+    __syncthreads();
+
+    // S^T[key, query] for this wave's 16 queries
+    f32x4 st[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float b = Qs[(wave * 16 + li) * ATT_QS + 4 * kk + lk];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const float av = Ks[(mt * 16 + li) * ATT_QS + 4 * kk + lk];
+        st[mt] = ASX_MFMA(av, b, st[mt]);
+      }
+    }
+    // scale, mask keys beyond len, online softmax for query (wave*16 + li)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + mt * 16 + 4 * lk + r;
+        const float s = (key < a.len) ? st[mt][r] * a.scale : -INFINITY;
+        st[mt][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = (st[mt][r] == -INFINITY) ? 0.f : expf(st[mt][r] - m_new);
+        st[mt][r] = p;
+        psum += p;
+      }
+    }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc_o[dt] *= corr;
+    // O^T[d, query] += V^T[d, key] P^T[key, query]
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pb = st[mt][r];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const float av = Vs[(mt * 16 + 4 * lk + r) * ATT_VS + dt * 16 + li];
+          acc_o[dt] = ASX_MFMA(av, pb, acc_o[dt]);
+        }
+      }
+    }
+  }
+
+  const int q = q0 + wave * 16 + li;
+  if (q < a.len) {
+    const int64_t row = base + (int64_t)q * a.row_stride;
+    const float g = a.gate[row * a.gate_ld + h];
+    const float gs = 1.0f / (1.0f + expf(-g));
+    const float inv = gs / l_run;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 o = acc_o[dt];
+      o *= inv;
+      *reinterpret_cast<f32x4 *>(a.out + row * inner + h * 64 + dt * 16 + 4 * lk) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// GLU of the mask MLP output (bs_roformer.py:216) scattered into the mask tensor [B, S, T, W]:
+//   mask[b, st, t, off + j] = a[m, j] * sigmoid(a[m, din + j]),   m = b*T + t
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void glu_kernel(const float *__restrict__ a, int din, int64_t M, int T, int S, int st,
+                                                  float *__restrict__ y, int64_t W) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * din) return;
+  const int64_t m = idx / din;
+  const int j = (int)(idx - m * din);
+  const int64_t b = m / T, t = m - b * T;
+  const float x = a[m * 2 * din + j], g = a[m * 2 * din + din + j];
+  y[((b * S + st) * T + t) * W + j] = x * (1.0f / (1.0f + expf(-g)));
+}
+
+// ---------------------------------------------------------------------------
+// Roformer chunk fold (mdxc_separator.py:320-343): result += x * w, counter += w,
+// out = result / clamp(counter, 1e-10); chunk k covers [starts[k], starts[k] + C).
+// chunk_out [n_chunks, S, 2, C];  out [n_out, 2, N] where stem row o reads chunk stem (o % S)
+// (the reference broadcasts a single-stem output over len(instruments) rows).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roformer_finalize_kernel(const float *__restrict__ chunk_out,
+                                                                const int64_t *__restrict__ starts, int n_chunks, int S,
+                                                                int64_t C, const float *__restrict__ window, int64_t N,
+                                                                float *__restrict__ out) {
+  const int oc = blockIdx.y;  // o*2 + ch
+  const int o = oc >> 1, ch = oc & 1;
+  const int s = o % S;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float acc = 0.f, cnt = 0.f;
+  for (int k = 0; k < n_chunks; ++k) {
+    const int64_t j = i - starts[k];
+    if (j < 0 || j >= C) continue;
+    const float w = window[j];
+    acc += chunk_out[(((int64_t)k * S + s) * 2 + ch) * C + j] * w;
+    cnt += w;
+  }
+  out[(int64_t)oc * N + i] = acc / fmaxf(cnt, 1e-10f);
+}
+
+}  // namespace asx

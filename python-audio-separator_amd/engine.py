@@ -42,6 +42,12 @@ class _V3Cfg(C.Structure):
                                          "num_targets")]
 
 
+class _RofCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "heads", "dim_head", "num_stems", "time_depth", "freq_depth",
+                                         "mlp_expansion_factor", "mask_estimator_depth", "n_bands", "n_out")] + \
+               [("freqs_per_bands", C.c_int32 * 128)]
+
+
 class _Plan(C.Structure):
     _fields_ = [("n_samples", C.c_int64), ("padded_len", C.c_int64), ("chunk_size", C.c_int64),
                 ("gen_size", C.c_int64), ("pad", C.c_int64), ("step", C.c_int64), ("trim", C.c_int32),
@@ -95,6 +101,22 @@ class V3Config:
     num_targets: int = 2
 
 
+@dataclass
+class RofConfig:
+    """BSRoformer constructor arguments (roformer_loader.py:123-150); n_fft / hop / dim_t live in MDXConfig."""
+    dim: int = 512
+    depth: int = 12
+    heads: int = 8
+    dim_head: int = 64
+    num_stems: int = 1
+    time_transformer_depth: int = 1
+    freq_transformer_depth: int = 1
+    mlp_expansion_factor: int = 4
+    mask_estimator_depth: int = 2
+    freqs_per_bands: tuple = ()
+    n_out: int = 2
+
+
 _FP = C.POINTER(C.c_float)
 _lib = None
 
@@ -103,7 +125,8 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_net_begin", "asx_net_set_tensor", "asx_net_commit", "asx_net_flops", "asx_plan_query", "asx_demix",
            "asx_demix_dev", "asx_demix_chunks_dev", "asx_finalize_dev", "asx_separate", "asx_separate_dev", "asx_stft", "asx_istft", "asx_net_forward",
            "asx_run_model", "asx_op_conv", "asx_op_tdf", "asx_profile_enable", "asx_profile_read", "asx_v3_begin",
-           "asx_v3_commit", "asx_v3_flops", "asx_v3_forward", "asx_mdxc_plan", "asx_mdxc_demix", "asx_mdxc_demix_dev"]
+           "asx_v3_commit", "asx_v3_flops", "asx_v3_forward", "asx_mdxc_plan", "asx_mdxc_demix", "asx_mdxc_demix_dev",
+           "asx_rof_begin", "asx_rof_commit", "asx_rof_flops", "asx_rof_forward", "asx_rof_demix", "asx_rof_demix_dev"]
 
 
 def load_library():
@@ -157,6 +180,13 @@ def load_library():
     lib.asx_mdxc_plan.argtypes = [vp, i64, i32, C.POINTER(_Plan)]
     lib.asx_mdxc_demix.argtypes = [vp, _FP, i64, i32, _FP]
     lib.asx_mdxc_demix_dev.argtypes = [vp, vp, i64, i32, vp, vp]
+    lib.asx_rof_begin.argtypes = [vp, C.POINTER(_RofCfg)]
+    lib.asx_rof_commit.argtypes = [vp]
+    lib.asx_rof_flops.argtypes = [vp, i32]
+    lib.asx_rof_flops.restype = C.c_double
+    lib.asx_rof_forward.argtypes = [vp, _FP, i32, _FP]
+    lib.asx_rof_demix.argtypes = [vp, _FP, i64, i64, _FP]
+    lib.asx_rof_demix_dev.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.asx_profile_enable.argtypes = [vp, i32]
     lib.asx_profile_read.argtypes = [vp, C.POINTER(_Profile)]
     for name in SYMBOLS:
@@ -267,6 +297,45 @@ class Engine:
 
     def mdxc_demix_dev(self, mix_ptr: int, n_samples: int, overlap: int, out_ptr: int, stream: int = 0):
         self._check(self._lib.asx_mdxc_demix_dev(self._h, mix_ptr, n_samples, int(overlap), out_ptr, stream or None))
+
+    # -- BS-Roformer ------------------------------------------------------------
+    def load_rof(self, rc: RofConfig, state_dict: dict):
+        if len(rc.freqs_per_bands) > 128:
+            raise ValueError("at most 128 bands")
+        c = _RofCfg(rc.dim, rc.depth, rc.heads, rc.dim_head, rc.num_stems, rc.time_transformer_depth,
+                    rc.freq_transformer_depth, rc.mlp_expansion_factor, rc.mask_estimator_depth,
+                    len(rc.freqs_per_bands), rc.n_out)
+        for i, f in enumerate(rc.freqs_per_bands):
+            c.freqs_per_bands[i] = int(f)
+        self._check(self._lib.asx_rof_begin(self._h, C.byref(c)))
+        for name, t in state_dict.items():
+            if hasattr(t, "detach"):
+                t = t.detach().cpu().numpy()
+            a = _f32(t).reshape(-1)
+            self._check(self._lib.asx_net_set_tensor(self._h, name.encode(), _ptr(a), a.size))
+        self._check(self._lib.asx_rof_commit(self._h))
+        self.rof_cfg = rc
+
+    def rof_flops(self, batch: int = 1) -> float:
+        return float(self._lib.asx_rof_flops(self._h, batch))
+
+    def rof_forward(self, wave: np.ndarray) -> np.ndarray:
+        wave = _f32(wave)
+        B, ch, Cn = wave.shape
+        out = np.empty((B, self.rof_cfg.num_stems, 2, Cn), np.float32)
+        self._check(self._lib.asx_rof_forward(self._h, _ptr(wave), B, _ptr(out)))
+        return out
+
+    def rof_demix(self, mix: np.ndarray, step: int) -> np.ndarray:
+        mix = _f32(mix)
+        if mix.ndim != 2 or mix.shape[0] != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got shape {mix.shape}")
+        out = np.empty((self.rof_cfg.n_out, 2, mix.shape[1]), np.float32)
+        self._check(self._lib.asx_rof_demix(self._h, _ptr(mix), mix.shape[1], int(step), _ptr(out)))
+        return out
+
+    def rof_demix_dev(self, mix_ptr: int, n_samples: int, step: int, out_ptr: int, stream: int = 0):
+        self._check(self._lib.asx_rof_demix_dev(self._h, mix_ptr, n_samples, int(step), out_ptr, stream or None))
 
     # -- plan ---------------------------------------------------------------
     def plan(self, n_samples: int, is_match_mix: bool = False) -> dict:

@@ -10,7 +10,7 @@ import logging
 
 import numpy as np
 
-from .engine import Engine, MDXConfig, V3Config
+from .engine import Engine, MDXConfig, RofConfig, V3Config
 from .mdx import _device_index
 
 
@@ -39,9 +39,8 @@ class MDXCDemixer:
         self.pitch_shift = arch_config.get("pitch_shift", 0)
         if self.pitch_shift != 0:
             raise NotImplementedError("pitch_shift is outside the accelerated path")
-        if self.model_data.get("is_roformer"):
-            raise NotImplementedError("the Roformer branch of MDXCSeparator is not accelerated yet")
         audio, model, training = (self.model_data.get(k, {}) for k in ("audio", "model", "training"))
+        self.is_roformer = bool(self.model_data.get("is_roformer"))
         self.instruments = list(training.get("instruments") or [])
         self.target_instrument = training.get("target_instrument")
         self.is_primary_stem_main_target = bool(self.target_instrument)
@@ -49,6 +48,10 @@ class MDXCDemixer:
             self.primary_stem_name = self.target_instrument or (self.instruments[0] if self.instruments else "Primary")
         seg = self.segment_size if self.override_model_segment_size else _get(self.model_data, "inference", "dim_t")
         self.mdx_segment_size = int(seg)
+        self.sample_rate = audio.get("sample_rate", common_config.get("sample_rate", 44100))
+        if self.is_roformer:
+            self._init_roformer(audio, model, state_dict, max_batch)
+            return
         scale = list(model.get("scale", [2, 2]))
         if scale != [2, 2]:
             raise NotImplementedError(f"scale {scale} (only [2, 2] is supported)")
@@ -64,12 +67,42 @@ class MDXCDemixer:
         if state_dict is not None or self.model_path:
             self.load_model(state_dict)
 
+    def _init_roformer(self, audio, model, state_dict, max_batch):
+        """BS-Roformer models (roformer_loader.py:123-150; mel-band Roformers are not accelerated)."""
+        if "freqs_per_bands" not in model:
+            raise NotImplementedError("only BS-Roformer (freqs_per_bands) is accelerated, not Mel-Band-Roformer")
+        n_fft = model.get("stft_n_fft", 2048)
+        if model.get("stft_win_length", n_fft) != n_fft:
+            raise NotImplementedError("stft_win_length != stft_n_fft")
+        hop = model.get("stft_hop_length") or audio["hop_length"]           # mdxc_separator.py:289-296
+        self.rof = RofConfig(dim=model["dim"], depth=model["depth"], heads=model.get("heads", 8),
+                             dim_head=model.get("dim_head", 64), num_stems=model.get("num_stems", 2),
+                             time_transformer_depth=model.get("time_transformer_depth", 2),
+                             freq_transformer_depth=model.get("freq_transformer_depth", 2),
+                             mlp_expansion_factor=model.get("mlp_expansion_factor", 4),
+                             mask_estimator_depth=model.get("mask_estimator_depth", 2),
+                             freqs_per_bands=tuple(model["freqs_per_bands"]), n_out=max(1, len(self.instruments)))
+        if not model.get("stereo", False):
+            raise NotImplementedError("mono Roformer models")
+        self.engine = Engine(MDXConfig(n_fft=n_fft, hop_length=hop, dim_f=n_fft // 2 + 1,
+                                       segment_size=self.mdx_segment_size, overlap=0.0, max_batch=max_batch),
+                             device=_device_index(self.torch_device))
+        if state_dict is not None or self.model_path:
+            self.load_model(state_dict)
+
     def load_model(self, state_dict: dict | None = None):
-        """torch.load(model_path) + load_state_dict (mdxc_separator.py:107-110) -> engine tensors."""
+        """torch.load(model_path) + load_state_dict (mdxc_separator.py:107-110, roformer_loader.py:97-104)."""
         if state_dict is None:
             import torch
             state_dict = torch.load(self.model_path, map_location="cpu")
-        self.engine.load_v3(self.v3, state_dict)
+            if isinstance(state_dict, dict) and "state_dict" in state_dict:
+                state_dict = state_dict["state_dict"]
+            elif isinstance(state_dict, dict) and "model" in state_dict:
+                state_dict = state_dict["model"]
+        if self.is_roformer:
+            self.engine.load_rof(self.rof, state_dict)
+        else:
+            self.engine.load_v3(self.v3, state_dict)
 
     def demix(self, mix: np.ndarray):
         """mdxc_separator.py:257-468 for TFC-TDF models: dict of stems, or the primary array."""
@@ -78,8 +111,24 @@ class MDXCDemixer:
             raise ValueError(f"Expected a 2-channel audio signal, but got {mix.shape[0] if mix.ndim else 0} channels")
         if mix.shape[1] == 0:
             raise ValueError("Audio file is empty or not valid")
+        if self.is_roformer:
+            return self._demix_roformer(mix)
         out = self.engine.mdxc_demix(mix, int(self.overlap))
         if self.v3.num_targets > 1:
+            return {k: out[i] for i, k in enumerate(self.instruments)}
+        primary = out[0]
+        if self.is_primary_stem_main_target:
+            return {self.primary_stem_name: primary, self.secondary_stem_name: mix - primary}
+        return primary
+
+    def _demix_roformer(self, mix: np.ndarray):
+        """mdxc_separator.py:272-343 + :406-468 for Roformer models."""
+        chunk_size = self.engine.cfg.hop_length * (self.mdx_segment_size - 1)
+        desired_step = int(self.overlap * self.sample_rate)
+        step = chunk_size if desired_step <= 0 else min(desired_step, chunk_size)
+        out = self.engine.rof_demix(mix, step)                       # [len(instruments), 2, N]
+        num_stems = 1 if self.target_instrument else len(self.instruments)
+        if num_stems > 1:
             return {k: out[i] for i, k in enumerate(self.instruments)}
         primary = out[0]
         if self.is_primary_stem_main_target:

@@ -64,7 +64,7 @@ def main():
     from audio_separator.separator.architectures.mdxc_separator import MDXCSeparator
 
     out = {}
-    cfg = R.RoformerConfig(dim=32, depth=2, heads=2, dim_head=16, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
+    cfg = R.RoformerConfig(dim=32, depth=2, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
                            stft_hop_length=16, stft_win_length=64, dim_t=21, sample_rate=100, mlp_expansion_factor=2)
     sd = R.make_roformer_state(cfg, 7)
     net = BSRoformer(**cfg.model_kwargs(), flash_attn=False)
@@ -80,7 +80,7 @@ def main():
     with torch.no_grad():
         out["fwd1_flash"] = netf(torch.tensor(w)).numpy()
     # two stems, deeper transformers
-    cfg2 = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=16, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
+    cfg2 = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
                             stft_hop_length=16, stft_win_length=64, dim_t=21, sample_rate=100, num_stems=2,
                             time_transformer_depth=2, freq_transformer_depth=2, target_instrument=None)
     sd2 = R.make_roformer_state(cfg2, 8)

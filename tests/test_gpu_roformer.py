@@ -1,0 +1,94 @@
+"""GPU parity of the BS-Roformer path against golden vectors written by the reference BSRoformer /
+MDXCSeparator classes and against the CPU oracle.  Bar: 1e-4 relative RMS on stems."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import roformer_oracle as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+CFG = R.RoformerConfig(dim=32, depth=2, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
+                       stft_hop_length=16, stft_win_length=64, dim_t=21, sample_rate=100, mlp_expansion_factor=2)
+CFG2 = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
+                        stft_hop_length=16, stft_win_length=64, dim_t=21, sample_rate=100, num_stems=2,
+                        time_transformer_depth=2, freq_transformer_depth=2, target_instrument=None)
+
+
+def rel_rms(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(np.sqrt(np.mean(b ** 2)), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def A():
+    import audio_separator_amd as A
+    return A
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "roformer_small.npz"))
+
+
+def demixer(A, cfg, seed, overlap, max_batch=0):
+    return A.MDXCDemixer({"model_data": cfg.as_model_data(), "torch_device": 0,
+                          "secondary_stem_name": cfg.instruments[1]},
+                         {"overlap": overlap}, state_dict=R.make_roformer_state(cfg, seed), max_batch=max_batch)
+
+
+def test_forward_golden(A, g):
+    w = (0.4 * np.random.default_rng(81).standard_normal((2, 2, 320))).astype(np.float32)
+    y = demixer(A, CFG, 7, 8).engine.rof_forward(w)
+    assert y.shape == (2, 1, 2, 320)
+    assert rel_rms(y[:, 0], g["fwd1"]) < TOL, rel_rms(y[:, 0], g["fwd1"])
+    y2 = demixer(A, CFG2, 8, 8).engine.rof_forward(w)
+    assert rel_rms(y2, g["fwd2"]) < TOL, rel_rms(y2, g["fwd2"])
+
+
+@pytest.mark.parametrize("name,n,ov", [("n1000_ov8", 1000, 8), ("n1000_ov2", 1000, 2), ("n320_ov1", 320, 1),
+                                       ("n777_ov2", 777, 2.5)])
+def test_demix_single_stem_golden(A, g, name, n, ov):
+    mix = (0.4 * np.random.default_rng(90 + n).standard_normal((2, n))).astype(np.float32)
+    out = demixer(A, CFG, 7, ov, max_batch=3).demix(mix)
+    assert rel_rms(out["vocals"], g[f"demix1_{name}_primary"]) < TOL, rel_rms(out["vocals"], g[f"demix1_{name}_primary"])
+    assert rel_rms(out["other"], g[f"demix1_{name}_secondary"]) < TOL
+
+
+def test_demix_two_stems_golden(A, g):
+    mix = (0.4 * np.random.default_rng(1090).standard_normal((2, 1000))).astype(np.float32)
+    out = demixer(A, CFG2, 8, 2).demix(mix)
+    got = np.stack([out[k] for k in CFG2.instruments])
+    assert rel_rms(got, g["demix2"]) < TOL, rel_rms(got, g["demix2"])
+
+
+def test_short_mix_is_rejected(A):
+    with pytest.raises(A.AsxError):
+        demixer(A, CFG, 7, 8).demix(np.zeros((2, 100), np.float32))
+
+
+def test_ep317_shape_excerpt_vs_oracle(A):
+    # the public ep_317 layout (dim 512-class heads of 64, 62 bands, n_fft 2048, hop 441) with reduced width / depth /
+    # frames so that the CPU oracle finishes: sequence lengths straddle the 64-wide attention tiles (T = 161, 62 bands)
+    cfg = R.RoformerConfig(dim=128, depth=2, heads=4, dim_head=64, freqs_per_bands=R.DEFAULT_FREQS_PER_BANDS,
+                           dim_t=161, mlp_expansion_factor=2)
+    sd = R.make_roformer_state(cfg, 2)
+    n = 441 * 160 * 2 + 3000
+    mix = (0.3 * np.random.default_rng(10).standard_normal((2, n))).astype(np.float32)
+    dm = A.MDXCDemixer({"model_data": cfg.as_model_data(), "torch_device": 0, "secondary_stem_name": "other"},
+                       {"overlap": 1}, state_dict=sd)
+    out = dm.demix(mix)
+    ref = R.roformer_demix(mix, sd, cfg, overlap=1)
+    e = rel_rms(out["vocals"], ref[0])
+    print("ep317-shaped excerpt rel-RMS:", e)
+    assert e < TOL, e
+    assert dm.engine.rof_flops(1) > 0
+
+
+def test_batching_is_invisible(A):
+    mix = (0.4 * np.random.default_rng(13).standard_normal((2, 1500))).astype(np.float32)
+    outs = [demixer(A, CFG, 7, 2, max_batch=mb).demix(mix)["vocals"] for mb in (1, 2, 64)]
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])

@@ -13,9 +13,9 @@ def rel_rms(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)) / max(np.sqrt(np.mean(b ** 2)), 1e-30))
 
 
-CFG = R.RoformerConfig(dim=32, depth=2, heads=2, dim_head=16, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
+CFG = R.RoformerConfig(dim=32, depth=2, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
                        stft_hop_length=16, stft_win_length=64, dim_t=21, sample_rate=100, mlp_expansion_factor=2)
-CFG2 = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=16, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
+CFG2 = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
                         stft_hop_length=16, stft_win_length=64, dim_t=21, sample_rate=100, num_stems=2,
                         time_transformer_depth=2, freq_transformer_depth=2, target_instrument=None)
 
