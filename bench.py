@@ -72,10 +72,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # BENCH_FORCE_DIST=1 exercises the RCCL code path (init, gather, all_reduce, barrier) with a single rank
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
@@ -88,17 +91,17 @@ def main():
     N = int(SR * args.seconds)
     mix = torch.from_numpy(O.synth_mix(N, seed=rank)).to(dev)       # resident in HBM before timing
     out = torch.empty_like(mix)
-    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty_like(out) for _ in range(world)] if (use_dist and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
     plan = eng.plan(N)
 
     def step():
         eng.demix_dev(mix.data_ptr(), N, out.data_ptr(), stream=stream)
-        if world > 1:
+        if use_dist:
             dist.gather(out, gathered, dst=0)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -110,7 +113,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -171,7 +174,7 @@ def main():
         if prof is not None:
             res["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

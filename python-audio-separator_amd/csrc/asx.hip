@@ -423,20 +423,6 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
   return ASX_OK;
 }
 
-template <int NREP, int MREP>
-static void launch_tdf_dma_t(const TdfDmaArgs &a, hipStream_t s) {
-  using CFG = TdfDmaCfg<NREP, MREP>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tdf_dma_kernel<NREP, MREP>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-    attr_done = true;
-  }
-  const int64_t nbm = (a.M + CFG::BM - 1) / CFG::BM;
-  const int nbn = (a.N + CFG::BN - 1) / CFG::BN;
-  hipLaunchKernelGGL((tdf_dma_kernel<NREP, MREP>), dim3((unsigned)(nbm * nbn)), dim3(256), CFG::LDS_BYTES, s, a);
-}
-
 template <int NREP, int MREP, bool KVEC>
 static void launch_tdf_tt(const TdfArgs &a, hipStream_t s) {
   using CFG = TdfCfg<NREP, MREP>;
@@ -455,6 +441,26 @@ template <int NREP, int MREP>
 static void launch_tdf_t(const TdfArgs &a, hipStream_t s) {
   if ((a.K & 3) == 0 && a.K >= 4) launch_tdf_tt<NREP, MREP, true>(a, s);
   else launch_tdf_tt<NREP, MREP, false>(a, s);
+}
+
+template <int NREP, int MREP, int BK>
+static void launch_tdf_dma_tt(const TdfDmaArgs &a, hipStream_t s) {
+  using CFG = TdfDmaCfg<NREP, MREP, BK>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tdf_dma_kernel<NREP, MREP, BK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    attr_done = true;
+  }
+  const int64_t nbm = (a.M + CFG::BM - 1) / CFG::BM;
+  const int nbn = (a.N + CFG::BN - 1) / CFG::BN;
+  hipLaunchKernelGGL((tdf_dma_kernel<NREP, MREP, BK>), dim3((unsigned)(nbm * nbn)), dim3(256), CFG::LDS_BYTES, s, a);
+}
+template <int NREP, int MREP>
+static void launch_tdf_dma_t(const TdfDmaArgs &a, hipStream_t s) {
+  static const bool bk64 = getenv("ASX_GEMM_BK64") != nullptr;
+  if (bk64 && NREP == 3 && MREP == 8 && a.K >= 128) launch_tdf_dma_tt<3, 8, 64>(a, s);
+  else launch_tdf_dma_tt<NREP, MREP, 32>(a, s);
 }
 
 static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const float *res, float *y, int64_t M,

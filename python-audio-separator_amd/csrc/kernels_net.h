@@ -705,19 +705,24 @@ struct TdfDmaArgs {
   int64_t lda, ldy, ldr;    // row strides (floats) of x, y, res; 0 = dense (K, N, N)
 };
 
-template <int NREP, int MREP>
+template <int NREP, int MREP, int BK_ = 32>
 struct TdfDmaCfg {
-  static constexpr int BK = 32;
+  static constexpr int BK = BK_;                       // 32 (two workgroups per CU) or 64 (one, longer stages)
+  static constexpr int CPR = BK / 4;                   // 16-byte chunks per row
+  static constexpr int RPI = 64 / CPR;                 // rows per wave-issue
   static constexpr int BM = 16 * MREP, BN = 64 * NREP;
   static constexpr int BUF = (BM + BN) * BK;           // floats per LDS buffer
   static constexpr int LDS_BYTES = 2 * BUF * 4;
-  static constexpr int NXI = BM / 8, NWI = BN / 8;     // wave-issues (8 rows each) per stage
+  static constexpr int NXI = BM / RPI, NWI = BN / RPI; // wave-issues per stage
+  // chunk swizzle g(row): BK=32 rows are 128 B (two rows per bank sweep), BK=64 rows are a full 256 B sweep
+  __device__ static constexpr int g(int row) { return BK == 32 ? ((row >> 1) & 7) : (row & 15); }
 };
 
-template <int NREP, int MREP>
-__global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
-  using CFG = TdfDmaCfg<NREP, MREP>;
+template <int NREP, int MREP, int BK_ = 32>
+__global__ __launch_bounds__(256, (BK_ == 32 ? 2 : 1)) void tdf_dma_kernel(TdfDmaArgs a) {
+  using CFG = TdfDmaCfg<NREP, MREP, BK_>;
   constexpr int BK = CFG::BK, BM = CFG::BM, BN = CFG::BN, BUF = CFG::BUF, NXI = CFG::NXI, NWI = CFG::NWI;
+  constexpr int CPR = CFG::CPR, RPI = CFG::RPI;
   extern __shared__ float lds_f[];
 
   const int tid = threadIdx.x;
@@ -733,18 +738,18 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
   const int n0 = bn * BN;
   const int64_t lda = a.lda ? a.lda : a.K, ldy = a.ldy ? a.ldy : a.N, ldr = a.ldr ? a.ldr : a.N;
 
-  // DMA lane role: row-in-issue = lane / 8, physical chunk p = lane % 8
-  const int lr = lane >> 3, lp = lane & 7;
+  // DMA lane role: row-in-issue = lane / CPR, physical chunk p = lane % CPR
+  const int lr = lane / CPR, lp = lane % CPR;
 
   auto issue = [&](int k0, int buf) {
     float *xs = lds_f + buf * BUF;
     float *ws = xs + BM * BK;
 #pragma unroll
     for (int i = 0; i < (NXI + 3) / 4; ++i) {
-      const int q = wave + 4 * i;             // issue index -> rows 8q .. 8q+7
+      const int q = wave + 4 * i;             // issue index -> rows RPI*q .. RPI*q + RPI - 1
       if (q < NXI) {
-        const int row = q * 8 + lr;
-        const int c = lp ^ ((row >> 1) & 7);   // logical chunk fetched into physical slot lp
+        const int row = q * RPI + lr;
+        const int c = lp ^ CFG::g(row);        // logical chunk fetched into physical slot lp
         const int k = k0 + c * 4;
         const bool ok = (m0 + row < a.M) && (k < a.K);
         const float *src = ok ? a.x + (m0 + row) * lda + k : a.zeros;
@@ -755,8 +760,8 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
     for (int i = 0; i < (NWI + 3) / 4; ++i) {
       const int q = wave + 4 * i;
       if (q < NWI) {
-        const int row = q * 8 + lr;
-        const int c = lp ^ ((row >> 1) & 7);
+        const int row = q * RPI + lr;
+        const int c = lp ^ CFG::g(row);
         const int k = k0 + c * 4;
         const bool ok = (n0 + row < a.N) && (k < a.K);
         const float *src = ok ? a.w + (int64_t)(n0 + row) * a.K + k : a.zeros;
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(256, 2) void tdf_dma_kernel(TdfDmaArgs a) {
     for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = (a.K + BK - 1) / BK;
-  const int sw = (li >> 1) & 7;   // fragment rows are (16*tile + li): g(row) = (li >> 1) & 7 since 16 | tile base
+  const int sw = CFG::g(li);      // fragment rows are (16*tile + li) and g only looks at the low 4 bits
   issue(0, 0);
   for (int ks = 0; ks < nk; ++ks) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
