@@ -252,6 +252,11 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
                const float *w_host, const float *bias_host, int32_t n, const float *scale_host,
                const float *shift_host, const float *res_host, float *y_host);
 
+/* ---- options ------------------------------------------------------------ */
+/* "winograd" = 1: run the 3x3 TFC convolutions with the Winograd F(2x2,3x3) kernel (fp32, 2.25x fewer
+ * multiply-accumulates; results differ from the direct kernel by a few float32 ulps per layer). */
+int asx_set_option(asx_engine *e, const char *key, int32_t value);
+
 /* ---- profiling ---------------------------------------------------------- */
 int asx_profile_enable(asx_engine *e, int32_t on); /* clears the counters */
 int asx_profile_read(asx_engine *e, asx_profile *out); /* synchronises the device */

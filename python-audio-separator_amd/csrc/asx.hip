@@ -89,6 +89,8 @@ struct ConvLayer {
   int nrep = 0, kc = 0, cg = 0, nci = 0;
   int relu = 1;
   DevBuf w, b;
+  DevBuf wu;       // CK_3X3 only: Winograd F(2x2,3x3) transformed weights [CG48][NCI8][xi][pair][48][2]
+  int wu_cg = 0, wu_nci = 0;
 };
 
 struct TdfLayer {
@@ -132,6 +134,7 @@ struct asx_engine {
   int ws_batch = 0;  // chunks the workspace is sized for
   DevBuf spec_in, spec_out, R[3], H, frames, chunk_out, d_starts, d_nact, d_peak, d_demixed;
   std::vector<DevBuf> skip;
+  bool winograd = false;  // use conv_wino_kernel for the 3x3 convs (asx_set_option)
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -291,7 +294,29 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b) {
             dst[n] = v;
           }
         }
-  const int nb = (L.kind == CK_UP) ? CT * 16 : L.cg * NW;
+  if (L.kind == CK_3X3) {
+    // U = G g G^T in float64, laid out [cg48][ci8][xi][pair][cout 48][2]
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    L.wu_cg = (L.cout + 47) / 48;
+    L.wu_nci = (L.cin + 7) / 8;
+    std::vector<float> wu((size_t)L.wu_cg * L.wu_nci * WinoCfg::USTAGE, 0.f);
+    for (int co = 0; co < L.cout; ++co)
+      for (int c = 0; c < L.cin; ++c) {
+        const float *g = &w[((size_t)co * L.cin + c) * 9];
+        double t[4][3], U[4][4];
+        for (int a = 0; a < 4; ++a)
+          for (int j = 0; j < 3; ++j) t[a][j] = G[a][0] * g[0 * 3 + j] + G[a][1] * g[1 * 3 + j] + G[a][2] * g[2 * 3 + j];
+        for (int a = 0; a < 4; ++a)
+          for (int bb = 0; bb < 4; ++bb) U[a][bb] = t[a][0] * G[bb][0] + t[a][1] * G[bb][1] + t[a][2] * G[bb][2];
+        const int cgi = co / 48, col = co % 48, ci = c / 8, pair = (c % 8) / 2, e = c & 1;
+        float *dst = &wu[((size_t)cgi * L.wu_nci + ci) * WinoCfg::USTAGE];
+        for (int a = 0; a < 4; ++a)
+          for (int bb = 0; bb < 4; ++bb) dst[(((a * 4 + bb) * 4 + pair) * 48 + col) * 2 + e] = (float)U[a][bb];
+      }
+    CHK(L.wu.ensure(wu.size() * 4));
+    HIPCHK(hipMemcpy(L.wu.p, wu.data(), wu.size() * 4, hipMemcpyHostToDevice));
+  }
+  const int nb = (L.kind == CK_UP) ? CT * 16 : std::max(L.cg * NW, ((L.cout + 47) / 48) * 48);
   std::vector<float> bp(nb, 0.f);
   for (int i = 0; i < L.cout; ++i) bp[i] = b ? b[i] : 0.f;
   CHK(L.w.ensure(wp.size() * 4));
@@ -379,6 +404,24 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
   const bool dma = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (a.x_bstride % 4 == 0) &&
                    getenv("ASX_NO_DMA") == nullptr;
   const ConvArgs &d = a;
+  if (L.kind == CK_3X3 && e->winograd && dma && L.wu.p != nullptr) {
+    ConvArgs wa = a;
+    wa.wp = L.wu.f();
+    wa.CG = L.wu_cg;
+    wa.NCI = L.wu_nci;
+    wa.tilesT = (a.To + WinoCfg::TH - 1) / WinoCfg::TH;
+    wa.tilesF = (a.Fo + WinoCfg::TW - 1) / WinoCfg::TW;
+    const int nb = wa.CG * wa.tilesT * wa.tilesF * B;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, WinoCfg::LDS_BYTES);
+      attr_done = true;
+    }
+    return timed(e, cls, flops, bytes, s, [&]() {
+      hipLaunchKernelGGL(conv_wino_kernel, dim3(nb), dim3(256), WinoCfg::LDS_BYTES, s, wa);
+    });
+  }
 #define ASX_CONV_CASE(KH, KW, S, PAD, NR, KC, RPW, EPI)                                      \
   do {                                                                                       \
     if (dma) launch_conv_dma_t<ConvDmaCfg<KH, KW, S, PAD, NR, KC, RPW, EPI>>(d, nblk, s);    \
@@ -746,6 +789,7 @@ static void rof_destroy(RofNet *n);
 static void free_conv(ConvLayer &L) {
   L.w.release();
   L.b.release();
+  L.wu.release();
 }
 static void free_tdf(TdfLayer &L) {
   L.w.release();
@@ -1651,6 +1695,17 @@ int asx_rof_demix(asx_engine *e, const float *mix_host, int64_t N, int64_t step,
   CHK(asx_rof_demix_dev(e, dmix.f(), N, step, dout.f(), nullptr));
   CHK(to_host(out_host, dout, (size_t)n_out * 2 * N));
   return ASX_OK;
+}
+
+// ---- options -----------------------------------------------------------------------
+int asx_set_option(asx_engine *e, const char *key, int32_t value) {
+  REQUIRE(e && key, "asx_set_option: null argument");
+  if (!strcmp(key, "winograd")) {
+    e->winograd = value != 0;
+    return ASX_OK;
+  }
+  set_err("asx_set_option: unknown option '%s'", key);
+  return ASX_ERR_INVALID;
 }
 
 // ---- profiling -------------------------------------------------------------------

@@ -877,4 +877,204 @@ __global__ __launch_bounds__(256, (BK_ == 32 ? 2 : 1)) void tdf_dma_kernel(TdfDm
   }
 }
 
+
+// ===========================================================================
+// Winograd F(2x2, 3x3) variant of the 3x3 / pad-1 convolution (optional, fp32).
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        (Lavin & Gray 2016)
+//
+// 2.25x fewer multiply-accumulates than the direct form; the sixteen transform-domain products are
+// sixteen independent [tiles x cin] x [cin x cout] GEMMs on v_mfma_f32_16x16x4_f32.
+// Workgroup: 64 output tiles (4 tile-rows x 16 tile-cols = 8 x 32 pixels) x 48 output channels, 4 waves;
+// wave w owns tile-row w (one MFMA M tile) for ALL 16 transform positions x 3 N tiles = 48 accumulator
+// tiles (192 VGPRs), so the output transform A^T m A is lane-local.
+// Per 8-channel stage: the haloed raw input tile (10 x 40, rows 16-B aligned) and the pre-transformed
+// weights U (host, fp64) arrive by LDS-DMA (double buffered); each thread transforms one
+// (tile, channel pair) into V; fragments are fetched with ds_read_b64, the two k slots a lane
+// supplies being channels (2*lk, 2*lk + 1) for both operands.
+// LDS: 2 x (raw 12.8 KB + U 24 KB) + V 40 KB = 113.6 KB -> one workgroup per CU.
+// ===========================================================================
+struct WinoCfg {
+  static constexpr int KC = 8, NREP = 3, NW = 48;
+  static constexpr int TR = 4, TC = 16;              // tile rows / cols per workgroup
+  static constexpr int TH = 2 * TR, TW = 2 * TC;     // 8 x 32 output pixels
+  static constexpr int IH = TH + 2, LP = 3, IWA = 40, C4 = IWA / 4;
+  static constexpr int SLOTS = IH * C4;              // 100 float4 per plane
+  static constexpr int NI = (SLOTS + 63) / 64;       // 2 wave-issues per plane
+  static constexpr int PS = IH * IWA;                // 400 floats per raw plane
+  static constexpr int RAW = KC * PS;                // 3200
+  static constexpr int USTAGE = 16 * 4 * NW * 2;     // [xi][pair][cout][2] = 6144 floats
+  static constexpr int UWI = USTAGE / 256;           // 24 wave-issues
+  static constexpr int VPS = 64 * 2 + 32;            // pair-plane stride (floats), +32 keeps lk = 0/1 on different bank halves
+  static constexpr int VSZ = 16 * 4 * VPS;           // 10240 floats
+  static constexpr int BUF = RAW + USTAGE;           // per DMA buffer
+  static constexpr int LDS_BYTES = (2 * BUF + VSZ) * 4;
+};
+
+__device__ __forceinline__ void wino_bt(float a, float b, float c, float d, float *o) {
+  o[0] = a - c;
+  o[1] = b + c;
+  o[2] = c - b;
+  o[3] = b - d;
+}
+
+__global__ __launch_bounds__(256) void conv_wino_kernel(ConvArgs a) {
+  using CFG = WinoCfg;
+  extern __shared__ float lds_f[];
+  float *Vs = lds_f + 2 * CFG::BUF;
+  constexpr int KC = CFG::KC, NREP = CFG::NREP, NW = CFG::NW, IWA = CFG::IWA, C4 = CFG::C4, PS = CFG::PS, LP = CFG::LP;
+  constexpr int NI = CFG::NI, SLOTS = CFG::SLOTS, VPS = CFG::VPS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cg = lid % a.CG;
+  lid /= a.CG;
+  const int tf = lid % a.tilesF;
+  lid /= a.tilesF;
+  const int tt = lid % a.tilesT;
+  const int b = lid / a.tilesT;
+  const int to0 = tt * CFG::TH, fo0 = tf * CFG::TW;
+  const int ti0 = to0 - 1, fa0 = fo0 - 1 - LP;   // aligned input origin (fo0 % 32 == 0 -> fa0 % 4 == 0)
+
+  const float *xb = a.x + (int64_t)b * a.x_bstride;
+  const float *ug = a.wp + (int64_t)cg * a.NCI * CFG::USTAGE;
+  const int64_t plane_sz = (int64_t)a.T * a.F;
+
+  int sp_off[NI];
+  bool sp_ok[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int sidx = j * 64 + lane;
+    const int row = sidx / C4, c4 = sidx - row * C4;
+    const int t = ti0 + row, f = fa0 + c4 * 4;
+    sp_ok[j] = (sidx < SLOTS) && t >= 0 && t < a.T && f >= 0 && f < a.F;
+    sp_off[j] = t * a.F + f;
+  }
+
+  auto issue = [&](int ci, int buf) {
+    float *raw = lds_f + buf * CFG::BUF;
+    float *us = raw + CFG::RAW;
+#pragma unroll
+    for (int p = 0; p < KC / 4; ++p) {
+      const int pl = wave + 4 * p;
+      const int c = ci * KC + pl;
+      const float *xc = xb + (int64_t)c * plane_sz;
+      const bool cok = c < a.Cin;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const float *src = (cok && sp_ok[j]) ? xc + sp_off[j] : a.zeros;
+        if (j * 64 + lane < SLOTS) ASX_GLDS16(src, raw + pl * PS + j * 256);
+      }
+    }
+    const float *ws = ug + (int64_t)ci * CFG::USTAGE;
+#pragma unroll
+    for (int i = 0; i < CFG::UWI / 4; ++i) {
+      const int q = wave + 4 * i;
+      ASX_GLDS16(ws + q * 256 + lane * 4, us + q * 256);
+    }
+  };
+
+  f32x4 acc[16][NREP];
+#pragma unroll
+  for (int x = 0; x < 16; ++x)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) acc[x][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // input-transform role: one (tile, channel pair) per thread; tile = lane, pair = wave
+  const int ty = lane >> 4, tx = lane & 15;
+
+  issue(0, 0);
+  for (int ci = 0; ci < a.NCI; ++ci) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // stage ci landed; every wave is done with V of stage ci-1
+    if (ci + 1 < a.NCI) issue(ci + 1, (ci + 1) & 1);
+    const float *raw = lds_f + (ci & 1) * CFG::BUF;
+    const float *us = raw + CFG::RAW;
+    // ---- V = B^T d B for this thread's (tile, 2 channels) ----
+    {
+      float v[2][16];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float *pl = raw + (2 * wave + q) * PS + (2 * ty) * IWA + LP + 2 * tx;
+        float r[4][4];   // r[col][a] = (B^T d)[a][col]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wino_bt(pl[j], pl[IWA + j], pl[2 * IWA + j], pl[3 * IWA + j], r[j]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) wino_bt(r[0][x], r[1][x], r[2][x], r[3][x], &v[q][4 * x]);
+      }
+#pragma unroll
+      for (int x = 0; x < 16; ++x)
+        *reinterpret_cast<float2 *>(&Vs[(x * 4 + wave) * VPS + lane * 2]) = make_float2(v[0][x], v[1][x]);
+    }
+    __syncthreads();
+    // ---- sixteen GEMMs: M_xi[tile, cout] += V_xi[tile, cin] U_xi[cin, cout] ----
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const float2 av = *reinterpret_cast<const float2 *>(&Vs[(x * 4 + lk) * VPS + (wave * 16 + li) * 2]);
+      float2 bv[NREP];
+#pragma unroll
+      for (int n = 0; n < NREP; ++n)
+        bv[n] = *reinterpret_cast<const float2 *>(&us[((x * 4 + lk) * NW + n * 16 + li) * 2]);
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) {
+        acc[x][n] = ASX_MFMA(av.x, bv[n].x, acc[x][n]);
+        acc[x][n] = ASX_MFMA(av.y, bv[n].y, acc[x][n]);
+      }
+    }
+  }
+
+  // ---- Y = A^T m A, bias, activation, store: lane holds tiles (tile-row = wave, tile-col = 4*lk + r) of cout li ----
+  float *yb = a.y + (int64_t)b * a.y_bstride;
+  const float *rb = a.res ? a.res + (int64_t)b * a.aux_bstride : nullptr;
+  const int t0 = to0 + 2 * wave;
+  const int f0 = fo0 + 8 * lk;
+  const bool full = ((a.Fo & 3) == 0) && (to0 + CFG::TH <= a.To) && (fo0 + CFG::TW <= a.Fo);
+#pragma unroll
+  for (int n = 0; n < NREP; ++n) {
+    const int co = cg * NW + n * 16 + li;
+    const float bv = a.bias[co];
+    if (co >= a.Cout) continue;
+    float o[2][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float c[4][2];   // c[col][p] = (A^T m)[p][col]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m0 = acc[j][n][r], m1 = acc[4 + j][n][r], m2 = acc[8 + j][n][r], m3 = acc[12 + j][n][r];
+        c[j][0] = m0 + m1 + m2;
+        c[j][1] = m1 - m2 - m3;
+      }
+#pragma unroll
+      for (int pq = 0; pq < 2; ++pq) {
+        o[pq][2 * r] = c[0][pq] + c[1][pq] + c[2][pq];
+        o[pq][2 * r + 1] = c[1][pq] - c[2][pq] - c[3][pq];
+      }
+    }
+#pragma unroll
+    for (int pq = 0; pq < 2; ++pq) {
+      const int t = t0 + pq;
+      const int64_t off = ((int64_t)co * a.To + t) * a.Fo + f0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[pq][q] = act_fn(o[pq][q] + bv, a.act);
+      if (full) {
+        f32x4 v0 = {o[pq][0], o[pq][1], o[pq][2], o[pq][3]}, v1 = {o[pq][4], o[pq][5], o[pq][6], o[pq][7]};
+        if (rb != nullptr) {
+          v0 += *reinterpret_cast<const f32x4 *>(rb + off);
+          v1 += *reinterpret_cast<const f32x4 *>(rb + off + 4);
+        }
+        *reinterpret_cast<f32x4 *>(yb + off) = v0;
+        *reinterpret_cast<f32x4 *>(yb + off + 4) = v1;
+      } else if (t < a.To) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (f0 + q < a.Fo) yb[off + q] = o[pq][q] + (rb != nullptr ? rb[off + q] : 0.f);
+      }
+    }
+  }
+}
+
 }  // namespace asx

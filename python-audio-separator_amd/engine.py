@@ -126,7 +126,7 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_demix_dev", "asx_demix_chunks_dev", "asx_finalize_dev", "asx_separate", "asx_separate_dev", "asx_stft", "asx_istft", "asx_net_forward",
            "asx_run_model", "asx_op_conv", "asx_op_tdf", "asx_profile_enable", "asx_profile_read", "asx_v3_begin",
            "asx_v3_commit", "asx_v3_flops", "asx_v3_forward", "asx_mdxc_plan", "asx_mdxc_demix", "asx_mdxc_demix_dev",
-           "asx_rof_begin", "asx_rof_commit", "asx_rof_flops", "asx_rof_forward", "asx_rof_demix", "asx_rof_demix_dev"]
+           "asx_set_option", "asx_rof_begin", "asx_rof_commit", "asx_rof_flops", "asx_rof_forward", "asx_rof_demix", "asx_rof_demix_dev"]
 
 
 def load_library():
@@ -187,6 +187,7 @@ def load_library():
     lib.asx_rof_forward.argtypes = [vp, _FP, i32, _FP]
     lib.asx_rof_demix.argtypes = [vp, _FP, i64, i64, _FP]
     lib.asx_rof_demix_dev.argtypes = [vp, vp, i64, i64, vp, vp]
+    lib.asx_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.asx_profile_enable.argtypes = [vp, i32]
     lib.asx_profile_read.argtypes = [vp, C.POINTER(_Profile)]
     for name in SYMBOLS:
@@ -238,6 +239,9 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, key: str, value: int):
+        self._check(self._lib.asx_set_option(self._h, key.encode(), int(value)))
 
     # -- weights ------------------------------------------------------------
     def load_net(self, net_cfg: NetConfig, tensors: dict):

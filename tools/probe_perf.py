@@ -18,6 +18,9 @@ N = int(44100 * secs)
 mix = torch.tensor(O.synth_mix(N, seed=0)).cuda()
 out = torch.empty_like(mix)
 eng = A.Engine(A.MDXConfig(max_batch=mb))
+import os
+if os.environ.get('WINO'):
+    eng.set_option('winograd', 1)
 eng.load_net(A.NetConfig(), A.fold_convtdf_state(sd, d.num_blocks, d.l))
 s = torch.cuda.current_stream().cuda_stream
 eng.demix_dev(mix.data_ptr(), N, out.data_ptr(), stream=s)
