@@ -227,6 +227,42 @@ int asx_rof_demix(asx_engine *e, const float *mix_host, int64_t n_samples, int64
 int asx_rof_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int64_t step, float *out_dev,
                       void *stream);
 
+/* ---- Demucs v4 / HTDemucs -----------------------------------------------------
+ * Replaces HTDemucs(**kwargs) + load_state_dict (uvr_lib_v5/demucs/htdemucs.py:32-382, demucs_separator.py:121-134),
+ * HTDemucs.forward (htdemucs.py:483-620), apply_model (uvr_lib_v5/demucs/apply.py:124-260) and
+ * DemucsSeparator.demix_demucs (architectures/demucs_separator.py:162-194).
+ * The engine's asx_mdx_config is not used by this path.  Built structure: every layer a frequency layer
+ * (nfft/2 / stride^depth > 1), kernel 8 / stride 4, DConv in the encoders, CaC, sinusoidal embeddings, norm_first
+ * transformer with LayerScale and norm_out, head dim 48 or 64.  Weights come in under the checkpoint's own
+ * state_dict keys; optional "pos_emb_freq" [T*Fr, C] / "pos_emb_time" [L, C] override the sinusoidal tables. */
+typedef struct asx_ht_config {
+  int32_t n_sources;                     /* len(sources) */
+  int32_t channels, growth, nfft, depth; /* htdemucs.py:40-47 */
+  int32_t kernel_size, stride;           /* 8, 4 */
+  int32_t dconv_depth, dconv_comp;       /* 2, 8 */
+  int32_t bottom_channels;               /* 0 = none */
+  int32_t t_layers, t_heads, t_hidden;   /* t_hidden = int(C * t_hidden_scale) */
+  int32_t samplerate;
+  int32_t segment_samples;               /* int(segment * samplerate): training length = split segment */
+  float freq_emb_scale;                  /* freq_emb (0.2); 0 = no embedding */
+  int32_t max_batch;                     /* segments per forward batch (0 = 8) */
+} asx_ht_config;
+#define ASX_HT_STANDARDIZE 1u /* (mix - ref.mean()) / ref.std() before, * std + mean after (demucs_separator.py:171-185) */
+#define ASX_HT_SWAP01 2u      /* sources[[0, 1]] = sources[[1, 0]] (demucs_separator.py:187) */
+int asx_ht_begin(asx_engine *e, const asx_ht_config *cfg);
+int asx_ht_commit(asx_engine *e);
+double asx_ht_flops(const asx_engine *e);   /* 2*MAC of one segment */
+/* HTDemucs.forward: mix [B, 2, length] (length <= segment_samples, zero padded like htdemucs.py:497-502)
+ * -> out [B, S, 2, length]. */
+int asx_ht_forward(asx_engine *e, const float *mix_host, int32_t batch, int64_t length, float *out_host);
+/* apply_model(model, mix[None], shifts, split=True, overlap) (+ the demix_demucs framing selected by `flags`):
+ * mix [2, N] -> out [S, 2, N].  offsets[shifts]: the random.randint(0, samplerate/2) draws (apply.py:209) made by
+ * the host; shifts = 0 -> no shift trick. */
+int asx_ht_demix(asx_engine *e, const float *mix_host, int64_t n_samples, int32_t shifts, const int64_t *offsets,
+                 double overlap, uint32_t flags, float *out_host);
+int asx_ht_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t shifts, const int64_t *offsets,
+                     double overlap, uint32_t flags, float *out_dev, void *stream);
+
 /* ---- stage hooks (host buffers; mirror the reference's own test surface) ---- */
 /* STFT.__call__ (stft.py:20): wave [B,2,C] -> spec [B,4,dim_f,C/hop+1]. */
 int asx_stft(asx_engine *e, const float *wave_host, int32_t batch, int64_t n_time, float *spec_host);

@@ -6,8 +6,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "asx.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "kernels_fft.h"), os.path.join(HERE, "csrc", "kernels_net.h"),
-        os.path.join(os.path.dirname(HERE), "include", "asx.h")]
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("kernels_fft.h", "kernels_net.h", "kernels_rof.h", "kernels_ht.h",
+                                                         "engine_v3.h", "engine_rof.h", "engine_ht.h")] + \
+       [os.path.join(os.path.dirname(HERE), "include", "asx.h")]
 OUT = os.path.join(HERE, "libasx.so")
 
 

@@ -21,6 +21,7 @@
 #include "kernels_fft.h"
 #include "kernels_net.h"
 #include "kernels_rof.h"
+#include "kernels_ht.h"
 
 using namespace asx;
 
@@ -113,11 +114,13 @@ struct ProfRec {
 
 struct V3Net;
 struct RofNet;
+struct HtNet;
 
 struct asx_engine {
   int device = 0;
   V3Net *v3 = nullptr;
   RofNet *rof = nullptr;
+  HtNet *ht = nullptr;
   asx_mdx_config cfg{};
   FftPlan plan{};
   DevBuf d_window, d_tw, d_env;  // env for T = segment_size
@@ -786,6 +789,7 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
 
 static void v3_destroy(V3Net *n);
 static void rof_destroy(RofNet *n);
+static void ht_destroy(HtNet *n);
 static void free_conv(ConvLayer &L) {
   L.w.release();
   L.b.release();
@@ -834,6 +838,7 @@ void asx_engine_destroy(asx_engine *e) {
   for (auto &sk : e->skip) sk.release();
   if (e->v3) v3_destroy(e->v3);
   if (e->rof) rof_destroy(e->rof);
+  if (e->ht) ht_destroy(e->ht);
   delete e;
 }
 
@@ -991,6 +996,7 @@ double asx_net_flops(const asx_engine *e, int32_t batch) {
 
 #include "engine_v3.h"
 #include "engine_rof.h"
+#include "engine_ht.h"
 
 // ---- plan ------------------------------------------------------------------
 int asx_plan_query(const asx_engine *e, int64_t N, uint32_t flags, asx_plan *out) {
@@ -1698,6 +1704,97 @@ int asx_rof_demix(asx_engine *e, const float *mix_host, int64_t N, int64_t step,
 }
 
 // ---- options -----------------------------------------------------------------------
+// ---- Demucs v4 ---------------------------------------------------------------------
+int asx_ht_begin(asx_engine *e, const asx_ht_config *cfg) {
+  REQUIRE(e && cfg, "asx_ht_begin: null argument");
+  REQUIRE(cfg->n_sources >= 1 && cfg->channels >= 4 && cfg->growth >= 1 && cfg->depth >= 1 && cfg->depth <= 8,
+          "bad HTDemucs hyper-parameters");
+  REQUIRE(cfg->kernel_size == 8 && cfg->stride == 4, "only kernel_size 8 / stride 4 is built (got %d / %d)",
+          cfg->kernel_size, cfg->stride);
+  REQUIRE(cfg->dconv_depth >= 0 && cfg->dconv_depth <= 4 && cfg->dconv_comp >= 1 && cfg->channels % cfg->dconv_comp == 0,
+          "bad DConv hyper-parameters");
+  REQUIRE(cfg->nfft >= 64 && cfg->nfft % 8 == 0, "bad nfft %d", cfg->nfft);
+  REQUIRE(cfg->t_layers >= 0 && (cfg->t_layers == 0 || (cfg->t_heads >= 1 && cfg->t_hidden >= 4 && cfg->t_hidden % 4 == 0)),
+          "bad transformer hyper-parameters");
+  REQUIRE(cfg->samplerate > 0 && cfg->segment_samples > 0, "bad samplerate / segment");
+  if (!e->ht) e->ht = new HtNet();
+  ht_free(*e->ht);
+  e->ht->cfg = *cfg;
+  e->ht->begun = true;
+  e->host_tensors.clear();
+  e->net_begun = true;
+  return ASX_OK;
+}
+
+int asx_ht_commit(asx_engine *e) {
+  REQUIRE(e, "asx_ht_commit: null engine");
+  if (!e->ht || !e->ht->begun) {
+    set_err("asx_ht_commit before asx_ht_begin");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  const int rc = ht_commit(e);
+  e->host_tensors.clear();
+  return rc;
+}
+
+double asx_ht_flops(const asx_engine *e) { return (e && e->ht && e->ht->ready) ? ht_flops(e) : 0.0; }
+
+int asx_ht_forward(asx_engine *e, const float *mix_host, int32_t B, int64_t length, float *out_host) {
+  REQUIRE(e && mix_host && out_host && B > 0, "asx_ht_forward: bad argument");
+  if (!e->ht || !e->ht->ready) {
+    set_err("asx_ht_forward: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  const int64_t TL = e->ht->L[0];
+  const int S = e->ht->cfg.n_sources;
+  REQUIRE(length >= 1 && length <= TL, "length %lld outside [1, %lld]", (long long)length, (long long)TL);
+  DevBuf din, dout;
+  BufGuard g{{&din, &dout}};
+  CHK(din.ensure((size_t)B * 2 * TL * 4));
+  CHK(dout.ensure((size_t)B * S * 2 * TL * 4));
+  HIPCHK(hipMemset(din.p, 0, (size_t)B * 2 * TL * 4));
+  HIPCHK(hipMemcpy2D(din.p, (size_t)TL * 4, mix_host, (size_t)length * 4, (size_t)length * 4, (size_t)B * 2,
+                     hipMemcpyHostToDevice));
+  CHK(ht_forward_dev(e, din.f(), B, dout.f(), nullptr));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy2D(out_host, (size_t)length * 4, dout.p, (size_t)TL * 4, (size_t)length * 4, (size_t)B * S * 2,
+                     hipMemcpyDeviceToHost));
+  return ASX_OK;
+}
+
+int asx_ht_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t shifts, const int64_t *offsets, double overlap,
+                     uint32_t flags, float *out_dev, void *stream) {
+  REQUIRE(e && mix_dev && out_dev && N >= 2, "asx_ht_demix_dev: bad argument");
+  REQUIRE(shifts >= 0 && (shifts == 0 || offsets), "shifts > 0 needs the offsets array");
+  REQUIRE(overlap >= 0.0 && overlap < 1.0, "overlap must be in [0, 1)");
+  if (!e->ht || !e->ht->ready) {
+    set_err("asx_ht_demix: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  return ht_demix_dev(e, mix_dev, N, shifts, offsets, overlap, flags, out_dev, reinterpret_cast<hipStream_t>(stream));
+}
+
+int asx_ht_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t shifts, const int64_t *offsets, double overlap,
+                 uint32_t flags, float *out_host) {
+  REQUIRE(e && mix_host && out_host && N >= 2, "asx_ht_demix: bad argument");
+  if (!e->ht || !e->ht->ready) {
+    set_err("asx_ht_demix: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  const int S = e->ht->cfg.n_sources;
+  DevBuf dm, dout;
+  BufGuard g{{&dm, &dout}};
+  CHK(to_dev(dm, mix_host, (size_t)2 * N));
+  CHK(dout.ensure((size_t)S * 2 * N * 4));
+  CHK(asx_ht_demix_dev(e, dm.f(), N, shifts, offsets, overlap, flags, dout.f(), nullptr));
+  CHK(to_host(out_host, dout, (size_t)S * 2 * N));
+  return ASX_OK;
+}
+
 int asx_set_option(asx_engine *e, const char *key, int32_t value) {
   REQUIRE(e && key, "asx_set_option: null argument");
   if (!strcmp(key, "winograd")) {

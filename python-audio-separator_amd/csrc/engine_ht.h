@@ -1,0 +1,976 @@
+// Demucs v4 (HTDemucs) on the engine: uvr_lib_v5/demucs/htdemucs.py:483-620 (forward), apply.py:124-260
+// (apply_model: shifts + split with triangular fold) and DemucsSeparator.demix_demucs
+// (architectures/demucs_separator.py:162-194).  Included by asx.hip (one TU).
+//
+// Layout: spectrogram branch [B, T, F_i, C_i], waveform branch [B, 1, L_i, C_i], both channels-last; see
+// kernels_ht.h.  Every conv / linear is one gg_kernel or tdf_dma_kernel launch:
+//   encoder i : conv k8/s4 + GELU | DConv x depth { k3 dilated -> GroupNorm+GELU -> 1x1 -> GroupNorm+GLU+LayerScale+res }
+//               | rewrite 1x1 + GLU (+ frequency embedding on layer 0)
+//   transformer: norm_in + sinusoidal table | {self | cross} layers with LayerScale folded into out_proj / linear2
+//   decoder i : (x + skip fused into the producer) rewrite 3x3 / k3 + GLU | ConvTranspose k8/s4 as a 2-tap GEMM with
+//               a 4-position scatter epilogue (+ GELU + next skip)
+#pragma once
+
+struct HtGemm {
+  DevBuf w, b;
+  int n = 0, k = 0;
+};
+struct HtDconv {
+  HtGemm c1, c2;
+  DevBuf g1w, g1b, g2w, g2b, ls;
+  int hid = 0, hp = 0;
+};
+struct HtEnc {
+  HtGemm conv, rewrite;
+  std::vector<HtDconv> dc;
+  int cin = 0, cout = 0;
+};
+struct HtDec {
+  HtGemm rewrite, convtr;
+  int cin = 0, cout = 0;   // cin = channels entering the layer (= encoder cout), cout = channels leaving it
+};
+struct HtTLayer {
+  bool cross = false;
+  DevBuf n1w, n1b, n2w, n2b, n3w, n3b, now, nob;
+  HtGemm q, kv, out, l1, l2;   // self: q holds the packed in_proj (N = 3C)
+};
+
+struct HtNet {
+  asx_ht_config cfg{};
+  bool begun = false, ready = false;
+  FftPlan plan{};
+  DevBuf window, tw, env_hop, fold_w;
+  int T = 0, Ct = 0, hidden = 0;
+  std::vector<int> F, C;        // F[0..D], C[0..D-1] (C[i] = channels of encoder i's output)
+  std::vector<int64_t> L;       // L[0..D]
+  std::vector<HtEnc> enc, tenc;
+  std::vector<HtDec> dec, tdec; // indexed by encoder level i (decoder of level i undoes encoder i)
+  DevBuf femb;
+  HtGemm up, up_t, down, down_t;
+  DevBuf nin_w, nin_b, nint_w, nint_b, pos_f, pos_t;
+  std::vector<HtTLayer> lay, lay_t;
+  // workspace
+  int ws_batch = 0;
+  DevBuf ws, acc, chunk_out, d_starts, seg, ref, ref_acc;
+  struct {
+    float *xf0, *xt0, *yf, *yt, *h, *z, *rw, *tokf, *tokt, *xn, *xn2, *qkv, *kvb, *attf, *attt, *ffh, *frames;
+    std::vector<float *> skf, skt, df, dt;
+    double *acc_f, *acc_t, *acc_g;
+  } b;
+};
+
+static void ht_free(HtNet &n) {
+  auto fg = [](HtGemm &g) {
+    g.w.release();
+    g.b.release();
+  };
+  for (auto *v : {&n.enc, &n.tenc})
+    for (auto &e : *v) {
+      fg(e.conv);
+      fg(e.rewrite);
+      for (auto &d : e.dc) {
+        fg(d.c1);
+        fg(d.c2);
+        for (DevBuf *p : {&d.g1w, &d.g1b, &d.g2w, &d.g2b, &d.ls}) p->release();
+      }
+    }
+  for (auto *v : {&n.dec, &n.tdec})
+    for (auto &d : *v) {
+      fg(d.rewrite);
+      fg(d.convtr);
+    }
+  for (auto *v : {&n.lay, &n.lay_t})
+    for (auto &l : *v) {
+      for (DevBuf *p : {&l.n1w, &l.n1b, &l.n2w, &l.n2b, &l.n3w, &l.n3b, &l.now, &l.nob}) p->release();
+      for (HtGemm *g : {&l.q, &l.kv, &l.out, &l.l1, &l.l2}) fg(*g);
+    }
+  for (HtGemm *g : {&n.up, &n.up_t, &n.down, &n.down_t}) fg(*g);
+  for (DevBuf *p : {&n.window, &n.tw, &n.env_hop, &n.fold_w, &n.femb, &n.nin_w, &n.nin_b, &n.nint_w, &n.nint_b, &n.pos_f,
+                    &n.pos_t, &n.ws, &n.acc, &n.chunk_out, &n.d_starts, &n.seg, &n.ref, &n.ref_acc})
+    p->release();
+  n.enc.clear();
+  n.tenc.clear();
+  n.dec.clear();
+  n.tdec.clear();
+  n.lay.clear();
+  n.lay_t.clear();
+  n.ready = false;
+  n.ws_batch = 0;
+}
+static void ht_destroy(HtNet *n) {
+  ht_free(*n);
+  delete n;
+}
+
+static int ht_up(DevBuf &d, const std::vector<float> &h) {
+  CHK(d.ensure(h.size() * 4));
+  HIPCHK(hipMemcpy(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  return ASX_OK;
+}
+static int ht_up_named(asx_engine *e, DevBuf &d, const std::string &name, int64_t numel) {
+  const float *p;
+  CHK(get_tensor(e, name, numel, &p));
+  CHK(d.ensure((size_t)numel * 4));
+  HIPCHK(hipMemcpy(d.p, p, (size_t)numel * 4, hipMemcpyHostToDevice));
+  return ASX_OK;
+}
+
+// rows (a_2q, a_2q+1, g_2q, g_2q+1): a lane of the GEMM epilogue holds both halves of two GLU outputs
+static void ht_glu_perm(std::vector<float> &w, std::vector<float> &b, int c, int k) {
+  std::vector<float> w2(w.size()), b2(b.size());
+  for (int q = 0; q < c / 2; ++q)
+    for (int r = 0; r < 4; ++r) {
+      const int src = (r < 2) ? 2 * q + r : c + 2 * q + (r - 2);
+      const int dst = 4 * q + r;
+      std::copy(w.begin() + (size_t)src * k, w.begin() + (size_t)(src + 1) * k, w2.begin() + (size_t)dst * k);
+      b2[dst] = b[src];
+    }
+  w.swap(w2);
+  b.swap(b2);
+}
+
+// torch conv weight [Cout, Cin, KA, KB] (KB = 1 for 1-D) -> [Npad, (to*KI + ti)*CinP + ci];
+// inner_first: the first kernel axis (KA) is the inner (frequency) tap, the second the outer (time) tap
+static int ht_pack_conv(asx_engine *e, HtGemm &g, const std::string &name, int cout, int cin, int ka, int kb,
+                        bool glu, int npad = 0, int cinp = 0) {
+  const float *w, *b;
+  CHK(get_tensor(e, name + ".weight", (int64_t)cout * cin * ka * kb, &w));
+  CHK(get_tensor(e, name + ".bias", cout, &b));
+  if (!npad) npad = cout;
+  if (!cinp) cinp = cin;
+  const int K = ka * kb * cinp;
+  std::vector<float> pw((size_t)npad * K, 0.f), pb((size_t)npad, 0.f);
+  for (int n = 0; n < cout; ++n) {
+    pb[n] = b[n];
+    for (int ci = 0; ci < cin; ++ci)
+      for (int a = 0; a < ka; ++a)
+        for (int c = 0; c < kb; ++c)
+          pw[(size_t)n * K + ((size_t)c * ka + a) * cinp + ci] = w[(((size_t)n * cin + ci) * ka + a) * kb + c];
+  }
+  if (glu) ht_glu_perm(pw, pb, cout / 2, K);
+  g.n = npad;
+  g.k = K;
+  CHK(ht_up(g.w, pw));
+  CHK(ht_up(g.b, pb));
+  return ASX_OK;
+}
+
+// ConvTranspose weight [Cin, Cout, 8(,1)], stride 4: W[(r, co)][tap*Cin + ci] = w[ci][co][r + 4*(1 - tap)]
+static int ht_pack_convtr(asx_engine *e, HtGemm &g, const std::string &name, int cin, int cout, int ksz, int stride) {
+  const float *w, *b;
+  CHK(get_tensor(e, name + ".weight", (int64_t)cin * cout * ksz, &w));
+  CHK(get_tensor(e, name + ".bias", cout, &b));
+  const int N = stride * cout, K = 2 * cin;
+  std::vector<float> pw((size_t)N * K), pb((size_t)N);
+  for (int r = 0; r < stride; ++r)
+    for (int co = 0; co < cout; ++co) {
+      pb[(size_t)r * cout + co] = b[co];
+      for (int tap = 0; tap < 2; ++tap)
+        for (int ci = 0; ci < cin; ++ci)
+          pw[((size_t)r * cout + co) * K + (size_t)tap * cin + ci] = w[((size_t)ci * cout + co) * ksz + r + stride * (1 - tap)];
+    }
+  g.n = N;
+  g.k = K;
+  CHK(ht_up(g.w, pw));
+  CHK(ht_up(g.b, pb));
+  return ASX_OK;
+}
+
+// nn.Linear rows [r0, r1) of `name` (+ per-output-row scale: LayerScale folded in, transformer.py:258,263)
+static int ht_pack_linear(asx_engine *e, HtGemm &g, const std::string &wname, const std::string &bname, int rows_total,
+                          int r0, int r1, int k, const float *scale) {
+  const float *w, *b;
+  CHK(get_tensor(e, wname, (int64_t)rows_total * k, &w));
+  CHK(get_tensor(e, bname, rows_total, &b));
+  const int n = r1 - r0;
+  std::vector<float> pw((size_t)n * k), pb((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const float sc = scale ? scale[i] : 1.0f;
+    pb[i] = b[r0 + i] * sc;
+    for (int j = 0; j < k; ++j) pw[(size_t)i * k + j] = w[(size_t)(r0 + i) * k + j] * sc;
+  }
+  g.n = n;
+  g.k = k;
+  CHK(ht_up(g.w, pw));
+  CHK(ht_up(g.b, pb));
+  return ASX_OK;
+}
+
+static int ht_load_dconv(asx_engine *e, HtDconv &d, const std::string &p, int ch, int comp, int idx) {
+  d.hid = ch / comp;
+  d.hp = (d.hid + 3) & ~3;
+  const std::string q = p + ".layers." + std::to_string(idx);
+  CHK(ht_pack_conv(e, d.c1, q + ".0", d.hid, ch, 3, 1, false, d.hp, 0));
+  CHK(ht_pack_conv(e, d.c2, q + ".3", 2 * ch, d.hid, 1, 1, false, 0, d.hp));
+  const float *g, *b;
+  CHK(get_tensor(e, q + ".1.weight", d.hid, &g));
+  CHK(get_tensor(e, q + ".1.bias", d.hid, &b));
+  std::vector<float> gw(d.hp, 0.f), gb(d.hp, 0.f);
+  std::copy(g, g + d.hid, gw.begin());
+  std::copy(b, b + d.hid, gb.begin());
+  CHK(ht_up(d.g1w, gw));
+  CHK(ht_up(d.g1b, gb));
+  CHK(ht_up_named(e, d.g2w, q + ".4.weight", 2 * ch));
+  CHK(ht_up_named(e, d.g2b, q + ".4.bias", 2 * ch));
+  CHK(ht_up_named(e, d.ls, q + ".6.scale", ch));
+  return ASX_OK;
+}
+
+static int ht_load_tlayer(asx_engine *e, HtTLayer &L, const std::string &p, bool cross, int C, int hidden) {
+  L.cross = cross;
+  const std::string at = p + (cross ? ".cross_attn" : ".self_attn");
+  const float *g1, *g2;
+  CHK(get_tensor(e, p + ".gamma_1.scale", C, &g1));
+  CHK(get_tensor(e, p + ".gamma_2.scale", C, &g2));
+  if (cross) {
+    CHK(ht_pack_linear(e, L.q, at + ".in_proj_weight", at + ".in_proj_bias", 3 * C, 0, C, C, nullptr));
+    CHK(ht_pack_linear(e, L.kv, at + ".in_proj_weight", at + ".in_proj_bias", 3 * C, C, 3 * C, C, nullptr));
+  } else {
+    CHK(ht_pack_linear(e, L.q, at + ".in_proj_weight", at + ".in_proj_bias", 3 * C, 0, 3 * C, C, nullptr));
+  }
+  CHK(ht_pack_linear(e, L.out, at + ".out_proj.weight", at + ".out_proj.bias", C, 0, C, C, g1));
+  CHK(ht_pack_linear(e, L.l1, p + ".linear1.weight", p + ".linear1.bias", hidden, 0, hidden, C, nullptr));
+  CHK(ht_pack_linear(e, L.l2, p + ".linear2.weight", p + ".linear2.bias", C, 0, C, hidden, g2));
+  CHK(ht_up_named(e, L.n1w, p + ".norm1.weight", C));
+  CHK(ht_up_named(e, L.n1b, p + ".norm1.bias", C));
+  CHK(ht_up_named(e, L.n2w, p + ".norm2.weight", C));
+  CHK(ht_up_named(e, L.n2b, p + ".norm2.bias", C));
+  if (cross) {
+    CHK(ht_up_named(e, L.n3w, p + ".norm3.weight", C));
+    CHK(ht_up_named(e, L.n3b, p + ".norm3.bias", C));
+  }
+  CHK(ht_up_named(e, L.now, p + ".norm_out.weight", C));
+  CHK(ht_up_named(e, L.nob, p + ".norm_out.bias", C));
+  return ASX_OK;
+}
+
+// sinusoidal tables in float32 with torch's operation order (transformer.py:18-46); the host may override them
+// with tables it computed itself (tensors "pos_emb_freq" [T*Fr, C] and "pos_emb_time" [L, C])
+static void ht_sin_1d(int length, int dim, std::vector<float> &t) {
+  const int half = dim / 2;
+  t.assign((size_t)length * dim, 0.f);
+  for (int p = 0; p < length; ++p)
+    for (int i = 0; i < half; ++i) {
+      const float ex = (float)i / (float)(half - 1);
+      const float den = powf(10000.0f, ex);
+      const float ph = (float)p / den;
+      t[(size_t)p * dim + i] = cosf(ph);
+      t[(size_t)p * dim + half + i] = sinf(ph);
+    }
+}
+static void ht_sin_2d(int C, int Fr, int T1, std::vector<float> &t) {   // rows (t1, fr)
+  const int dm = C / 2;
+  t.assign((size_t)T1 * Fr * C, 0.f);
+  const float k = -(logf(10000.0f) / (float)dm);
+  for (int i = 0; i < dm; i += 2) {
+    const float div = expf((float)i * k);
+    for (int t1 = 0; t1 < T1; ++t1)
+      for (int fr = 0; fr < Fr; ++fr) {
+        float *row = &t[((size_t)t1 * Fr + fr) * C];
+        row[i] = sinf((float)t1 * div);
+        row[i + 1] = cosf((float)t1 * div);
+        row[dm + i] = sinf((float)fr * div);
+        row[dm + i + 1] = cosf((float)fr * div);
+      }
+  }
+}
+
+static int ht_commit(asx_engine *e) {
+  HtNet &n = *e->ht;
+  const asx_ht_config &c = n.cfg;
+  const int D = c.depth, S = c.n_sources, AC = 2;
+  REQUIRE(make_plan(c.nfft, &n.plan), "nfft/2 = %d must factor into {2,3,5}", c.nfft / 2);
+  const int hop = c.nfft / 4;
+  const int64_t TL = c.segment_samples;
+  REQUIRE(TL % 2 == 0 && TL > c.nfft, "segment length %lld must be even and exceed nfft", (long long)TL);
+  n.T = (int)((TL + hop - 1) / hop);
+  n.F.assign(D + 1, 0);
+  n.L.assign(D + 1, 0);
+  n.C.assign(D, 0);
+  n.F[0] = c.nfft / 2;
+  n.L[0] = TL;
+  int ch = c.channels;
+  for (int i = 0; i < D; ++i) {
+    REQUIRE(n.F[i] > c.kernel_size && n.F[i] % c.stride == 0,
+            "layer %d: %d frequency rows -- only the all-frequency-layer structure (nfft/2 / stride^depth > 1) is built", i,
+            n.F[i]);
+    n.F[i + 1] = n.F[i] / c.stride;
+    n.L[i + 1] = (n.L[i] + c.stride - 1) / c.stride;
+    n.C[i] = ch;
+    REQUIRE(ch % 4 == 0, "channel counts must be multiples of 4 (layer %d has %d)", i, ch);
+    ch *= c.growth;
+  }
+  // tables
+  {
+    std::vector<float> w;
+    host_window(c.nfft, w);
+    CHK(ht_up(n.window, w));
+    std::vector<float> tw((size_t)c.nfft * 2);
+    for (int j = 0; j < c.nfft; ++j) {
+      const double ang = -2.0 * M_PI * (double)j / (double)c.nfft;
+      tw[2 * j] = (float)cos(ang);
+      tw[2 * j + 1] = (float)sin(ang);
+    }
+    CHK(ht_up(n.tw, tw));
+    std::vector<float> env((size_t)hop, 0.f);
+    for (int r = 0; r < hop; ++r)
+      for (int i = c.nfft / hop - 1; i >= 0; --i) env[r] += w[r + i * hop] * w[r + i * hop];   // frame order of torch's fold
+    CHK(ht_up(n.env_hop, env));
+    // triangular transition window (apply.py:226-231), float32 like torch
+    std::vector<float> fw((size_t)TL);
+    const int64_t h1 = TL / 2, h2 = TL - TL / 2;
+    const float mx = (float)std::max(h1, h2);
+    for (int64_t i = 0; i < h1; ++i) fw[i] = (float)(i + 1) / mx;
+    for (int64_t i = 0; i < h2; ++i) fw[h1 + i] = (float)(h2 - i) / mx;
+    CHK(ht_up(n.fold_w, fw));
+  }
+  n.enc.assign(D, HtEnc());
+  n.tenc.assign(D, HtEnc());
+  n.dec.assign(D, HtDec());
+  n.tdec.assign(D, HtDec());
+  for (int i = 0; i < D; ++i) {
+    const int cin_z = i == 0 ? 2 * AC : n.C[i - 1], cin_t = i == 0 ? AC : n.C[i - 1], co = n.C[i];
+    const std::string si = std::to_string(i), sj = std::to_string(D - 1 - i);
+    HtEnc &E = n.enc[i], &Et = n.tenc[i];
+    E.cin = cin_z;
+    E.cout = co;
+    Et.cin = cin_t;
+    Et.cout = co;
+    CHK(ht_pack_conv(e, E.conv, "encoder." + si + ".conv", co, cin_z, c.kernel_size, 1, false));
+    CHK(ht_pack_conv(e, Et.conv, "tencoder." + si + ".conv", co, cin_t, c.kernel_size, 1, false));
+    CHK(ht_pack_conv(e, E.rewrite, "encoder." + si + ".rewrite", 2 * co, co, 1, 1, true));
+    CHK(ht_pack_conv(e, Et.rewrite, "tencoder." + si + ".rewrite", 2 * co, co, 1, 1, true));
+    E.dc.assign(c.dconv_depth, HtDconv());
+    Et.dc.assign(c.dconv_depth, HtDconv());
+    for (int d = 0; d < c.dconv_depth; ++d) {
+      CHK(ht_load_dconv(e, E.dc[d], "encoder." + si + ".dconv", co, c.dconv_comp, d));
+      CHK(ht_load_dconv(e, Et.dc[d], "tencoder." + si + ".dconv", co, c.dconv_comp, d));
+    }
+    const int out_z = i == 0 ? 2 * AC * S : n.C[i - 1], out_t = i == 0 ? AC * S : n.C[i - 1];
+    HtDec &Dz = n.dec[i], &Dt = n.tdec[i];
+    Dz.cin = co;
+    Dz.cout = out_z;
+    Dt.cin = co;
+    Dt.cout = out_t;
+    REQUIRE(out_z % 4 == 0 && out_t % 4 == 0, "decoder output channels must be multiples of 4");
+    CHK(ht_pack_conv(e, Dz.rewrite, "decoder." + sj + ".rewrite", 2 * co, co, 3, 3, true));
+    CHK(ht_pack_conv(e, Dt.rewrite, "tdecoder." + sj + ".rewrite", 2 * co, co, 3, 1, true));
+    CHK(ht_pack_convtr(e, Dz.convtr, "decoder." + sj + ".conv_tr", co, out_z, c.kernel_size, c.stride));
+    CHK(ht_pack_convtr(e, Dt.convtr, "tdecoder." + sj + ".conv_tr", co, out_t, c.kernel_size, c.stride));
+  }
+  if (c.freq_emb_scale != 0.f) {
+    const float *w;
+    CHK(get_tensor(e, "freq_emb.embedding.weight", (int64_t)n.F[1] * n.C[0], &w));
+    std::vector<float> fe((size_t)n.F[1] * n.C[0]);
+    for (size_t i = 0; i < fe.size(); ++i) fe[i] = c.freq_emb_scale * (w[i] * 10.0f);   // ScaledEmbedding.scale = 10
+    CHK(ht_up(n.femb, fe));
+  }
+  const int Cb = n.C[D - 1];
+  n.Ct = c.bottom_channels > 0 ? c.bottom_channels : Cb;
+  n.hidden = c.t_hidden;
+  if (c.t_layers > 0) {
+    const int Ct = n.Ct;
+    REQUIRE(Ct % c.t_heads == 0 && (Ct / c.t_heads == 48 || Ct / c.t_heads == 64),
+            "transformer head dim %d: only 48 and 64 are built", Ct / c.t_heads);
+    if (c.bottom_channels > 0) {
+      CHK(ht_pack_conv(e, n.up, "channel_upsampler", Ct, Cb, 1, 1, false));
+      CHK(ht_pack_conv(e, n.up_t, "channel_upsampler_t", Ct, Cb, 1, 1, false));
+      CHK(ht_pack_conv(e, n.down, "channel_downsampler", Cb, Ct, 1, 1, false));
+      CHK(ht_pack_conv(e, n.down_t, "channel_downsampler_t", Cb, Ct, 1, 1, false));
+    }
+    CHK(ht_up_named(e, n.nin_w, "crosstransformer.norm_in.weight", Ct));
+    CHK(ht_up_named(e, n.nin_b, "crosstransformer.norm_in.bias", Ct));
+    CHK(ht_up_named(e, n.nint_w, "crosstransformer.norm_in_t.weight", Ct));
+    CHK(ht_up_named(e, n.nint_b, "crosstransformer.norm_in_t.bias", Ct));
+    const int Fr = n.F[D], T1 = n.T;
+    const int64_t T2 = n.L[D];
+    const float *pf = nullptr, *pt = nullptr;
+    CHK(get_tensor(e, "pos_emb_freq", (int64_t)T1 * Fr * Ct, &pf, true));
+    CHK(get_tensor(e, "pos_emb_time", T2 * Ct, &pt, true));
+    std::vector<float> tf, tt;
+    if (pf) tf.assign(pf, pf + (size_t)T1 * Fr * Ct);
+    else ht_sin_2d(Ct, Fr, T1, tf);
+    if (pt) tt.assign(pt, pt + (size_t)T2 * Ct);
+    else ht_sin_1d((int)T2, Ct, tt);
+    CHK(ht_up(n.pos_f, tf));
+    CHK(ht_up(n.pos_t, tt));
+    n.lay.assign(c.t_layers, HtTLayer());
+    n.lay_t.assign(c.t_layers, HtTLayer());
+    for (int i = 0; i < c.t_layers; ++i) {
+      CHK(ht_load_tlayer(e, n.lay[i], "crosstransformer.layers." + std::to_string(i), i % 2 == 1, Ct, n.hidden));
+      CHK(ht_load_tlayer(e, n.lay_t[i], "crosstransformer.layers_t." + std::to_string(i), i % 2 == 1, Ct, n.hidden));
+    }
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ht_stft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)stft_lds(n.plan));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ht_istft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)istft_lds(n.plan));
+  n.ready = true;
+  return ASX_OK;
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------------------------
+struct HtGeom {
+  int O = 1, I = 1, Cin = 0, ldc = 0;
+  int KO = 1, KI = 1, DO = 1, DI = 1, PO = 0, PI = 0, SI = 1;
+  int IR = 1;
+};
+
+// y = epilogue(gather(x) @ W^T + b)
+static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q, int64_t rows_outer, float *y, int64_t ldy,
+                 int mode, int act, const float *res, int64_t ldr, int res_mod, int Iout, int Cout, hipStream_t s) {
+  GgArgs a{};
+  a.x = x;
+  a.w = g.w.f();
+  a.bias = g.b.f();
+  a.res = res;
+  a.zeros = e->d_zeros.f();
+  a.y = y;
+  a.M = rows_outer * q.IR;
+  a.N = g.n;
+  a.K = g.k;
+  a.O = q.O;
+  a.I = q.I;
+  a.Cin = q.Cin;
+  a.ldc = q.ldc;
+  a.KO = q.KO;
+  a.KI = q.KI;
+  a.DO = q.DO;
+  a.DI = q.DI;
+  a.PO = q.PO;
+  a.PI = q.PI;
+  a.SI = q.SI;
+  a.IR = q.IR;
+  a.inv_cin = 1.0f / (float)q.Cin;
+  a.mode = mode;
+  a.act = act;
+  a.Iout = Iout;
+  a.Cout = Cout;
+  a.crop = 2;
+  a.So = 4;
+  a.ldy = ldy;
+  a.ldr = ldr;
+  a.res_mod = res_mod;
+  if (g.k != q.KO * q.KI * q.Cin || (q.Cin & 3) || (q.ldc & 3) || (g.n & 3) || (ldy & 1) || a.M <= 0) {
+    set_err("ht_gg: bad geometry (K=%d taps=%dx%d Cin=%d ldc=%d N=%d)", g.k, q.KO, q.KI, q.Cin, q.ldc, g.n);
+    return ASX_ERR_INVALID;
+  }
+  const double flops = 2.0 * (double)a.M * g.n * g.k;
+  const double bytes = 4.0 * ((double)rows_outer * q.I * q.Cin + (double)a.M * g.n / (mode == GG_GLU ? 2 : 1) +
+                              (double)g.n * g.k + (res ? (double)a.M * g.n / (mode == GG_GLU ? 2 : 1) : 0.0));
+  const int cls = mode == GG_CONVT ? ASX_PROF_UP : (q.SI > 1 ? ASX_PROF_DOWN : ASX_PROF_CONV3X3);
+  return timed(e, cls, flops, bytes, s, [&]() {
+    if (g.n > 64) ht_launch_gg<2, 8>(a, s);
+    else ht_launch_gg<1, 8>(a, s);
+  });
+}
+
+// plain linear through the tuned row GEMM of kernels_net.h
+static int ht_linear(asx_engine *e, const HtGemm &g, const float *x, int64_t lda, int64_t M, float *y, int64_t ldy, int act,
+                     const float *res, int64_t ldr, hipStream_t s) {
+  TdfDmaArgs d{};
+  d.x = x;
+  d.w = g.w.f();
+  d.bias = g.b.f();
+  d.res = res;
+  d.zeros = e->d_zeros.f();
+  d.y = y;
+  d.M = M;
+  d.N = g.n;
+  d.K = g.k;
+  d.C = 1;
+  d.T = 1;
+  d.relu = act;
+  d.lda = lda;
+  d.ldy = ldy;
+  d.ldr = ldr;
+  if ((g.k & 3) || (lda & 3) || (ldy & 3) || (g.n & 3) || (res && (ldr & 3))) {
+    set_err("ht_linear: K, N and row strides must be multiples of 4 floats");
+    return ASX_ERR_INVALID;
+  }
+  const double flops = 2.0 * (double)M * g.n * g.k;
+  const double bytes = 4.0 * ((double)M * g.k + (double)M * g.n * (res ? 2 : 1) + (double)g.n * g.k);
+  return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
+    if (g.n > 128) launch_tdf_dma_t<3, 8>(d, s);
+    else if (g.n > 64) launch_tdf_dma_t<2, 4>(d, s);
+    else launch_tdf_dma_t<1, 4>(d, s);
+  });
+}
+
+static int ht_ln(asx_engine *e, const float *x, int C, const DevBuf &g, const DevBuf &b, const float *pos, int64_t pos_mod,
+                 float *y, int64_t M, hipStream_t s) {
+  return timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)M * C, s, [&]() {
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, (int64_t)C, C, g.f(), b.f(),
+                       pos, pos_mod, y, (int64_t)C, M, 1e-5f);
+  });
+}
+
+// statistics of x viewed as [G1, R, P]; groups of gdiv consecutive plane elements; acc must hold G1*G2*2 doubles
+static int ht_stats(asx_engine *e, const float *x, int G1, int64_t R, int64_t P, int64_t gdiv, int ld, int Cn, int G2,
+                    double *acc, hipStream_t s) {
+  HIPCHK(hipMemsetAsync(acc, 0, (size_t)G1 * G2 * 16, s));
+  int64_t rsplit = R / 96;
+  if (rsplit < 1) rsplit = 1;
+  if (rsplit > 1024) rsplit = 1024;
+  const unsigned gx = P >= 256 ? (unsigned)((P + 255) / 256) : 1u;
+  return timed(e, ASX_PROF_MISC, 0.0, 4.0 * (double)G1 * R * P, s, [&]() {
+    hipLaunchKernelGGL(gstats_kernel, dim3(gx, (unsigned)rsplit, (unsigned)G1), dim3(256), 0, s, x, R, P, gdiv, ld, Cn, G2,
+                       acc);
+  });
+}
+
+static int ht_gn(asx_engine *e, float *x, int G1, int64_t R, int G2, int ld, int Cn, const double *acc, const float *gam,
+                 const float *bet, int mode, float *dst, int dst_ld, const float *ls, hipStream_t s) {
+  const int Ce = mode == 1 ? Cn / 2 : Cn;
+  const int64_t total = (int64_t)G1 * R * G2 * Ce;
+  return timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)total, s, [&]() {
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, R, G2, ld, Cn, acc, gam,
+                       bet, 1e-5f, mode, dst, dst_ld, ls, total);
+  });
+}
+
+static int ht_mha(asx_engine *e, const float *q, int64_t ldq, const float *k, const float *v, int64_t ldkv, float *out,
+                  int64_t ldo, int B, int nq, int nk, int heads, int dh, hipStream_t s) {
+  MhaArgs a{};
+  a.q = q;
+  a.k = k;
+  a.v = v;
+  a.out = out;
+  a.ldq = ldq;
+  a.ldk = ldkv;
+  a.ldv = ldkv;
+  a.ldo = ldo;
+  a.nq = nq;
+  a.nk = nk;
+  a.scale = 1.0f / sqrtf((float)dh);
+  const double flops = 4.0 * (double)B * heads * (double)nq * nk * dh;
+  const double bytes = 4.0 * (double)B * heads * dh * (2.0 * nq + 2.0 * nk);
+  const dim3 grid((unsigned)((nq + 63) / 64), (unsigned)heads, (unsigned)B);
+  return timed(e, ASX_PROF_CONV1X1, flops, bytes, s, [&]() {   // profile class shared with the Roformer attention
+    if (dh == 48) hipLaunchKernelGGL((mha_kernel<3>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mha_kernel<4>), grid, dim3(256), 0, s, a);
+  });
+}
+
+// ---- workspace --------------------------------------------------------------------------------------------------
+static int ht_ensure_workspace(asx_engine *e, int B) {
+  HtNet &n = *e->ht;
+  if (B <= n.ws_batch) return ASX_OK;
+  const asx_ht_config &c = n.cfg;
+  const int D = c.depth, S = c.n_sources, T = n.T;
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    const size_t o = off;
+    off += (floats * 4 + 255) & ~(size_t)255;
+    return o;
+  };
+  std::vector<std::pair<float **, size_t>> plan;
+  auto want = [&](float *&p, size_t floats) { plan.push_back({&p, take(floats)}); };
+  auto &b = n.b;
+  const size_t BT = (size_t)B * T;
+  want(b.xf0, BT * n.F[0] * 4);
+  want(b.xt0, (size_t)B * n.L[0] * 2);
+  size_t yf = 0, yt = 0, h = 0, z = 0, rw = 0;
+  for (int i = 0; i < D; ++i) {
+    const int hp = (n.C[i] / c.dconv_comp + 3) & ~3;
+    yf = std::max(yf, BT * n.F[i + 1] * n.C[i]);
+    yt = std::max(yt, (size_t)B * n.L[i + 1] * n.C[i]);
+    h = std::max(h, std::max(BT * n.F[i + 1], (size_t)B * n.L[i + 1]) * hp);
+    z = std::max(z, std::max(BT * n.F[i + 1], (size_t)B * n.L[i + 1]) * 2 * n.C[i]);
+    rw = std::max(rw, std::max(BT * n.F[i + 1], (size_t)B * n.L[i + 1]) * n.C[i]);
+  }
+  want(b.yf, yf);
+  want(b.yt, yt);
+  want(b.h, h);
+  want(b.z, z);
+  want(b.rw, rw);
+  b.skf.assign(D, nullptr);
+  b.skt.assign(D, nullptr);
+  b.df.assign(D + 1, nullptr);
+  b.dt.assign(D + 1, nullptr);
+  for (int i = 0; i < D; ++i) {
+    want(b.skf[i], BT * n.F[i + 1] * n.C[i]);
+    want(b.skt[i], (size_t)B * n.L[i + 1] * n.C[i]);
+  }
+  // decoder inputs: df[i] feeds decoder i (shape of skf[i]); df[0]' = final output, kept in df[D] slot as "out"
+  for (int i = 0; i < D; ++i) {
+    want(b.df[i + 1], BT * n.F[i + 1] * n.C[i]);
+    want(b.dt[i + 1], (size_t)B * n.L[i + 1] * n.C[i]);
+  }
+  want(b.df[0], BT * n.F[0] * 4 * S);
+  want(b.dt[0], (size_t)B * n.L[0] * 2 * S);
+  if (c.t_layers > 0) {
+    const size_t NF = BT * n.F[D], NT = (size_t)B * n.L[D], NM = std::max(NF, NT);
+    want(b.tokf, NF * n.Ct);
+    want(b.tokt, NT * n.Ct);
+    want(b.xn, NM * n.Ct);
+    want(b.xn2, NM * n.Ct);
+    want(b.qkv, NM * 3 * n.Ct);
+    want(b.kvb, NM * 2 * n.Ct);
+    want(b.attf, NM * n.Ct);
+    want(b.attt, NM * n.Ct);
+    want(b.ffh, NM * n.hidden);
+  }
+  want(b.frames, (size_t)B * S * 2 * T * c.nfft);
+  CHK(n.ws.ensure(off));
+  for (auto &pr : plan) *pr.first = reinterpret_cast<float *>(reinterpret_cast<char *>(n.ws.p) + pr.second);
+  // float64 accumulators: per-sample (freq, time) + group-norm groups (max B * F[1])
+  const size_t ng = (size_t)B * std::max(n.F[1], 1);
+  CHK(n.acc.ensure((2 * (size_t)B + ng) * 16));
+  b.acc_f = reinterpret_cast<double *>(n.acc.p);
+  b.acc_t = b.acc_f + 2 * (size_t)B;
+  b.acc_g = b.acc_t + 2 * (size_t)B;
+  n.ws_batch = B;
+  return ASX_OK;
+}
+
+// DConv residual branch (demucs.py:99-179) on y [B, O, I, C] in place; along_outer: the conv runs over the outer axis
+static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I, bool along_outer, hipStream_t s) {
+  HtNet &n = *e->ht;
+  const int C = E.cout;
+  for (size_t d = 0; d < E.dc.size(); ++d) {
+    const HtDconv &dc = E.dc[d];
+    const int dil = 1 << d;
+    HtGeom g;
+    g.O = O;
+    g.I = I;
+    g.Cin = C;
+    g.ldc = C;
+    g.IR = I;
+    if (along_outer) {
+      g.KO = 3;
+      g.DO = dil;
+      g.PO = dil;
+    } else {
+      g.KI = 3;
+      g.DI = dil;
+      g.PI = dil;
+    }
+    CHK(ht_gg(e, dc.c1, y, g, (int64_t)B * O, n.b.h, dc.hp, GG_DENSE, 0, nullptr, 0, 0, 0, 0, s));
+    // GroupNorm(1, hid) per conv batch item: (b, f) over (t, c) on the spectrogram branch, b over (l, c) on the waveform
+    const int G2 = along_outer ? I : 1;
+    const int64_t R = along_outer ? O : I;
+    CHK(ht_stats(e, n.b.h, B, R, (int64_t)G2 * dc.hp, dc.hp, dc.hp, dc.hid, G2, n.b.acc_g, s));
+    CHK(ht_gn(e, n.b.h, B, R, G2, dc.hp, dc.hid, n.b.acc_g, dc.g1w.f(), dc.g1b.f(), 0, nullptr, 0, nullptr, s));
+    HtGeom g1;
+    g1.O = O;
+    g1.I = I;
+    g1.Cin = dc.hp;
+    g1.ldc = dc.hp;
+    g1.IR = I;
+    CHK(ht_gg(e, dc.c2, n.b.h, g1, (int64_t)B * O, n.b.z, 2 * C, GG_DENSE, 0, nullptr, 0, 0, 0, 0, s));
+    CHK(ht_stats(e, n.b.z, B, R, (int64_t)G2 * 2 * C, 2 * C, 2 * C, 2 * C, G2, n.b.acc_g, s));
+    CHK(ht_gn(e, n.b.z, B, R, G2, 2 * C, 2 * C, n.b.acc_g, dc.g2w.f(), dc.g2b.f(), 1, y, C, dc.ls.f(), s));
+  }
+  return ASX_OK;
+}
+
+static int ht_tlayer_ff(asx_engine *e, const HtTLayer &L, float *x, int B, int64_t N, const DevBuf &nw, const DevBuf &nb,
+                        hipStream_t s) {
+  HtNet &n = *e->ht;
+  const int C = n.Ct;
+  const int64_t M = (int64_t)B * N;
+  CHK(ht_ln(e, x, C, nw, nb, nullptr, 1, n.b.xn, M, s));
+  CHK(ht_linear(e, L.l1, n.b.xn, C, M, n.b.ffh, n.hidden, 2, nullptr, 0, s));
+  CHK(ht_linear(e, L.l2, n.b.ffh, n.hidden, M, x, C, 0, x, C, s));
+  // norm_out = MyGroupNorm(1, C) over the whole (tokens, channels) sample (transformer.py:181-187, 265)
+  CHK(ht_stats(e, x, B, N, C, C, C, C, 1, n.b.acc_g, s));
+  CHK(ht_gn(e, x, B, N, 1, C, C, n.b.acc_g, L.now.f(), L.nob.f(), 2, nullptr, 0, nullptr, s));
+  return ASX_OK;
+}
+
+static int ht_self_layer(asx_engine *e, const HtTLayer &L, float *x, int B, int64_t N, hipStream_t s) {
+  HtNet &n = *e->ht;
+  const int C = n.Ct, H = n.cfg.t_heads;
+  const int64_t M = (int64_t)B * N;
+  CHK(ht_ln(e, x, C, L.n1w, L.n1b, nullptr, 1, n.b.xn, M, s));
+  CHK(ht_linear(e, L.q, n.b.xn, C, M, n.b.qkv, 3 * C, 0, nullptr, 0, s));
+  CHK(ht_mha(e, n.b.qkv, 3 * C, n.b.qkv + C, n.b.qkv + 2 * C, 3 * C, n.b.attf, C, B, (int)N, (int)N, H, C / H, s));
+  CHK(ht_linear(e, L.out, n.b.attf, C, M, x, C, 0, x, C, s));
+  return ht_tlayer_ff(e, L, x, B, N, L.n2w, L.n2b, s);
+}
+
+// attention half of a cross layer: att = MHA(norm1(q), norm2(k), norm2(k)) (transformer.py:379-383)
+static int ht_cross_attn(asx_engine *e, const HtTLayer &L, const float *q, int64_t Nq, const float *k, int64_t Nk, float *att,
+                         int B, hipStream_t s) {
+  HtNet &n = *e->ht;
+  const int C = n.Ct, H = n.cfg.t_heads;
+  CHK(ht_ln(e, q, C, L.n1w, L.n1b, nullptr, 1, n.b.xn, (int64_t)B * Nq, s));
+  CHK(ht_ln(e, k, C, L.n2w, L.n2b, nullptr, 1, n.b.xn2, (int64_t)B * Nk, s));
+  CHK(ht_linear(e, L.q, n.b.xn, C, (int64_t)B * Nq, n.b.qkv, C, 0, nullptr, 0, s));
+  CHK(ht_linear(e, L.kv, n.b.xn2, C, (int64_t)B * Nk, n.b.kvb, 2 * C, 0, nullptr, 0, s));
+  return ht_mha(e, n.b.qkv, C, n.b.kvb, n.b.kvb + C, 2 * C, att, C, B, (int)Nq, (int)Nk, H, C / H, s);
+}
+
+// ---- HTDemucs.forward on B full-length segments: seg [B, 2, TL] -> out [B, S, 2, TL] ----------------------------------
+static int ht_forward_dev(asx_engine *e, const float *seg, int B, float *out, hipStream_t s) {
+  HtNet &n = *e->ht;
+  const asx_ht_config &c = n.cfg;
+  CHK(ht_ensure_workspace(e, B));
+  auto &b = n.b;
+  const int D = c.depth, S = c.n_sources, T = n.T, hop = c.nfft / 4;
+  const int64_t TL = n.L[0];
+  const int F0 = n.F[0];
+  // spectrogram + per-sample standardisation of both branches (htdemucs.py:505-519)
+  CHK(timed(e, ASX_PROF_STFT, 0.0, 4.0 * (double)B * (2.0 * TL + 4.0 * T * F0), s, [&]() {
+    hipLaunchKernelGGL(ht_stft_kernel, dim3(T, 2, B), dim3(256), stft_lds(n.plan), s, seg, TL, hop, T, b.xf0, n.window.f(),
+                       reinterpret_cast<const float2 *>(n.tw.p), n.plan);
+  }));
+  const int64_t nf = (int64_t)T * F0 * 4;
+  CHK(ht_stats(e, b.xf0, B, T, (int64_t)F0 * 4, (int64_t)F0 * 4, 4, 4, 1, b.acc_f, s));
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)B * nf, s, [&]() {
+    hipLaunchKernelGGL(std_norm_kernel, dim3((unsigned)((nf + 255) / 256), B), dim3(256), 0, s, b.xf0, nf, b.acc_f);
+  }));
+  CHK(ht_stats(e, seg, B, 1, 2 * TL, 2 * TL, 1, 1, 1, b.acc_t, s));
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 16.0 * (double)B * TL, s, [&]() {
+    hipLaunchKernelGGL(time_norm_kernel, dim3((unsigned)((TL + 255) / 256), B), dim3(256), 0, s, seg, TL, b.acc_t, b.xt0);
+  }));
+  // encoders
+  for (int i = 0; i < D; ++i) {
+    const HtEnc &E = n.enc[i], &Et = n.tenc[i];
+    const int C = n.C[i];
+    {   // spectrogram branch (hdemucs.py:139-170, freq=True)
+      HtGeom g;
+      g.O = T;
+      g.I = n.F[i];
+      g.Cin = E.cin;
+      g.ldc = E.cin;
+      g.KI = c.kernel_size;
+      g.PI = c.kernel_size / 4;
+      g.SI = c.stride;
+      g.IR = n.F[i + 1];
+      CHK(ht_gg(e, E.conv, i == 0 ? b.xf0 : b.skf[i - 1], g, (int64_t)B * T, b.yf, C, GG_DENSE, 2, nullptr, 0, 0, 0, 0, s));
+      CHK(ht_dconv(e, E, b.yf, B, T, n.F[i + 1], true, s));
+      HtGeom r;
+      r.O = T;
+      r.I = n.F[i + 1];
+      r.Cin = C;
+      r.ldc = C;
+      r.IR = n.F[i + 1];
+      const bool emb = i == 0 && c.freq_emb_scale != 0.f;
+      CHK(ht_gg(e, E.rewrite, b.yf, r, (int64_t)B * T, b.skf[i], C, GG_GLU, 0, emb ? n.femb.f() : nullptr, C,
+                emb ? n.F[1] : 0, 0, 0, s));
+    }
+    {   // waveform branch (freq=False); layer 0 reads the stereo signal as pairs of samples x 2 channels
+      HtGeom g;
+      g.O = 1;
+      if (i == 0) {
+        g.I = (int)(TL / 2);
+        g.Cin = 4;
+        g.ldc = 4;
+        g.KI = c.kernel_size / 2;
+        g.PI = c.kernel_size / 8;
+        g.SI = c.stride / 2;
+      } else {
+        g.I = (int)n.L[i];
+        g.Cin = Et.cin;
+        g.ldc = Et.cin;
+        g.KI = c.kernel_size;
+        g.PI = c.kernel_size / 4;
+        g.SI = c.stride;
+      }
+      g.IR = (int)n.L[i + 1];
+      CHK(ht_gg(e, Et.conv, i == 0 ? b.xt0 : b.skt[i - 1], g, B, b.yt, C, GG_DENSE, 2, nullptr, 0, 0, 0, 0, s));
+      CHK(ht_dconv(e, Et, b.yt, B, 1, (int)n.L[i + 1], false, s));
+      HtGeom r;
+      r.I = (int)n.L[i + 1];
+      r.Cin = C;
+      r.ldc = C;
+      r.IR = (int)n.L[i + 1];
+      CHK(ht_gg(e, Et.rewrite, b.yt, r, B, b.skt[i], C, GG_GLU, 0, nullptr, 0, 0, 0, 0, s));
+    }
+  }
+  // cross transformer (transformer.py:520-548)
+  const int Cb = n.C[D - 1];
+  const int64_t NF = (int64_t)T * n.F[D], NT = n.L[D];
+  float *xin_f = b.df[D], *xin_t = b.dt[D];   // decoder inputs of the deepest level
+  if (c.t_layers > 0) {
+    const int Ct = n.Ct;
+    const float *xf = b.skf[D - 1], *xt = b.skt[D - 1];
+    if (c.bottom_channels > 0) {
+      CHK(ht_linear(e, n.up, xf, Cb, B * NF, b.xn, Ct, 0, nullptr, 0, s));
+      CHK(ht_ln(e, b.xn, Ct, n.nin_w, n.nin_b, n.pos_f.f(), NF, b.tokf, B * NF, s));
+      CHK(ht_linear(e, n.up_t, xt, Cb, B * NT, b.xn, Ct, 0, nullptr, 0, s));
+      CHK(ht_ln(e, b.xn, Ct, n.nint_w, n.nint_b, n.pos_t.f(), NT, b.tokt, B * NT, s));
+    } else {
+      CHK(ht_ln(e, xf, Ct, n.nin_w, n.nin_b, n.pos_f.f(), NF, b.tokf, B * NF, s));
+      CHK(ht_ln(e, xt, Ct, n.nint_w, n.nint_b, n.pos_t.f(), NT, b.tokt, B * NT, s));
+    }
+    for (int i = 0; i < c.t_layers; ++i) {
+      const HtTLayer &Lf = n.lay[i], &Lt = n.lay_t[i];
+      if (!Lf.cross) {
+        CHK(ht_self_layer(e, Lf, b.tokf, B, NF, s));
+        CHK(ht_self_layer(e, Lt, b.tokt, B, NT, s));
+      } else {
+        // both attentions read the pre-layer tokens (transformer.py:543-545), then each branch updates in place
+        CHK(ht_cross_attn(e, Lf, b.tokf, NF, b.tokt, NT, b.attf, B, s));
+        CHK(ht_cross_attn(e, Lt, b.tokt, NT, b.tokf, NF, b.attt, B, s));
+        CHK(ht_linear(e, Lf.out, b.attf, Ct, B * NF, b.tokf, Ct, 0, b.tokf, Ct, s));
+        CHK(ht_tlayer_ff(e, Lf, b.tokf, B, NF, Lf.n3w, Lf.n3b, s));
+        CHK(ht_linear(e, Lt.out, b.attt, Ct, B * NT, b.tokt, Ct, 0, b.tokt, Ct, s));
+        CHK(ht_tlayer_ff(e, Lt, b.tokt, B, NT, Lt.n3w, Lt.n3b, s));
+      }
+    }
+    if (c.bottom_channels > 0) {   // + skip of the deepest level fused as the residual (hdemucs.py:305)
+      CHK(ht_linear(e, n.down, b.tokf, Ct, B * NF, xin_f, Cb, 0, b.skf[D - 1], Cb, s));
+      CHK(ht_linear(e, n.down_t, b.tokt, Ct, B * NT, xin_t, Cb, 0, b.skt[D - 1], Cb, s));
+    } else {
+      HIPCHK(hipMemcpyAsync(xin_f, b.tokf, (size_t)B * NF * Cb * 4, hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(xin_t, b.tokt, (size_t)B * NT * Cb * 4, hipMemcpyDeviceToDevice, s));
+    }
+  } else {
+    HIPCHK(hipMemcpyAsync(xin_f, b.skf[D - 1], (size_t)B * NF * Cb * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(xin_t, b.skt[D - 1], (size_t)B * NT * Cb * 4, hipMemcpyDeviceToDevice, s));
+  }
+  if (c.t_layers == 0 || c.bottom_channels == 0) {
+    const int64_t n1 = (int64_t)B * NF * Cb, n2 = (int64_t)B * NT * Cb;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, xin_f, b.skf[D - 1], n1);
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, xin_t, b.skt[D - 1], n2);
+    HIPCHK(hipGetLastError());
+  }
+  // decoders, deepest first (hdemucs.py:303-330); the input already holds x + skip
+  for (int i = D - 1; i >= 0; --i) {
+    const HtDec &Dz = n.dec[i], &Dt = n.tdec[i];
+    const int C = n.C[i];
+    {
+      HtGeom g;
+      g.O = T;
+      g.I = n.F[i + 1];
+      g.Cin = C;
+      g.ldc = C;
+      g.KO = 3;
+      g.KI = 3;
+      g.PO = 1;
+      g.PI = 1;
+      g.IR = n.F[i + 1];
+      CHK(ht_gg(e, Dz.rewrite, b.df[i + 1], g, (int64_t)B * T, b.rw, C, GG_GLU, 0, nullptr, 0, 0, 0, 0, s));
+      HtGeom t;
+      t.O = T;
+      t.I = n.F[i + 1];
+      t.Cin = C;
+      t.ldc = C;
+      t.KI = 2;
+      t.PI = 1;
+      t.IR = n.F[i + 1] + 1;
+      CHK(ht_gg(e, Dz.convtr, b.rw, t, (int64_t)B * T, b.df[i], Dz.cout, GG_CONVT, i == 0 ? 0 : 2,
+                i == 0 ? nullptr : b.skf[i - 1], Dz.cout, 0, n.F[i], Dz.cout, s));
+    }
+    {
+      HtGeom g;
+      g.I = (int)n.L[i + 1];
+      g.Cin = C;
+      g.ldc = C;
+      g.KI = 3;
+      g.PI = 1;
+      g.IR = (int)n.L[i + 1];
+      CHK(ht_gg(e, Dt.rewrite, b.dt[i + 1], g, B, b.rw, C, GG_GLU, 0, nullptr, 0, 0, 0, 0, s));
+      HtGeom t;
+      t.I = (int)n.L[i + 1];
+      t.Cin = C;
+      t.ldc = C;
+      t.KI = 2;
+      t.PI = 1;
+      t.IR = (int)n.L[i + 1] + 1;
+      CHK(ht_gg(e, Dt.convtr, b.rw, t, B, b.dt[i], Dt.cout, GG_CONVT, i == 0 ? 0 : 2, i == 0 ? nullptr : b.skt[i - 1],
+                Dt.cout, 0, (int)n.L[i], Dt.cout, s));
+    }
+  }
+  // CaC -> iSTFT, + waveform branch (htdemucs.py:589-612)
+  CHK(timed(e, ASX_PROF_ISTFT, 0.0, 4.0 * (double)B * S * 2 * T * (2.0 * F0 + c.nfft), s, [&]() {
+    hipLaunchKernelGGL(ht_istft_kernel, dim3(T, S * 2, B), dim3(256), istft_lds(n.plan), s, b.df[0], T, 4 * S, b.acc_f,
+                       (double)nf, b.frames, n.window.f(), reinterpret_cast<const float2 *>(n.tw.p), n.plan);
+  }));
+  return timed(e, ASX_PROF_OLA, 0.0, 4.0 * (double)B * S * 2 * (T * (double)c.nfft + 2.0 * TL), s, [&]() {
+    hipLaunchKernelGGL(ht_ola_kernel, dim3((unsigned)((TL + 255) / 256), S * 2, B), dim3(256), 0, s, b.frames,
+                       n.env_hop.f(), c.nfft, hop, T, TL, b.dt[0], 2 * S, b.acc_t, out);
+  });
+}
+
+// 2*MAC per segment of the GEMM-shaped work
+static double ht_flops(const asx_engine *e) {
+  const HtNet &n = *e->ht;
+  const asx_ht_config &c = n.cfg;
+  const int D = c.depth;
+  double f = 0.0;
+  for (int i = 0; i < D; ++i) {
+    const double pf = (double)n.T * n.F[i + 1], pt = (double)n.L[i + 1];
+    const double C = n.C[i], hid = n.C[i] / c.dconv_comp;
+    const double cin_z = i == 0 ? 4 : n.C[i - 1], cin_t = i == 0 ? 2 : n.C[i - 1];
+    const double out_z = i == 0 ? 4.0 * c.n_sources : n.C[i - 1], out_t = i == 0 ? 2.0 * c.n_sources : n.C[i - 1];
+    f += 2.0 * pf * C * cin_z * c.kernel_size + 2.0 * pt * C * cin_t * c.kernel_size;        // encoder conv
+    f += (pf + pt) * c.dconv_depth * 2.0 * (3.0 * C * hid + hid * 2.0 * C);                 // DConv
+    f += (pf + pt) * 2.0 * C * 2.0 * C;                                                       // rewrite
+    f += pf * 2.0 * 9.0 * C * 2.0 * C + pt * 2.0 * 3.0 * C * 2.0 * C;                         // decoder rewrite
+    f += (pf * out_z + pt * out_t) * 2.0 * C * c.kernel_size;                                 // transposed conv
+  }
+  if (c.t_layers > 0) {
+    const double NF = (double)n.T * n.F[D], NT = (double)n.L[D], Ct = n.Ct, H = n.hidden, Cb = n.C[D - 1];
+    if (c.bottom_channels > 0) f += (NF + NT) * 4.0 * Cb * Ct;
+    for (int i = 0; i < c.t_layers; ++i) {
+      f += (NF + NT) * (2.0 * 4.0 * Ct * Ct + 4.0 * Ct * H);
+      if (i % 2 == 0) f += 4.0 * Ct * (NF * NF + NT * NT);
+      else f += 8.0 * Ct * NF * NT;
+    }
+  }
+  return f;
+}
+
+// ---- apply_model + demix_demucs ---------------------------------------------------------------------------------------
+// mix_dev [2, N] -> out_dev [S, 2, N].  offsets: `shifts` draws of random.randint(0, samplerate/2) made by the host
+// (apply.py:209); shifts == 0 runs the plain split path.
+static int ht_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t shifts, const int64_t *offsets, double overlap,
+                        uint32_t flags, float *out_dev, hipStream_t s) {
+  HtNet &n = *e->ht;
+  const asx_ht_config &c = n.cfg;
+  const int S = c.n_sources;
+  const int64_t TL = n.L[0], segment = TL;
+  const int64_t stride = (int64_t)((1.0 - overlap) * (double)segment);   // int((1 - overlap) * segment), apply.py:220
+  REQUIRE(stride >= 1 && stride <= segment, "overlap %g gives a bad stride", overlap);
+  const int standardize = (flags & ASX_HT_STANDARDIZE) ? 1 : 0;
+  const int swap01 = (flags & ASX_HT_SWAP01) ? 1 : 0;
+  const int64_t max_shift = shifts > 0 ? c.samplerate / 2 : 0;
+  if (standardize) {   // ref = mix.mean(0); mean / unbiased std of ref (demucs_separator.py:171-173)
+    CHK(n.ref.ensure((size_t)N * 4));
+    CHK(n.ref_acc.ensure(16));
+    hipLaunchKernelGGL(ht_mono_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, mix_dev, N, n.ref.f());
+    HIPCHK(hipGetLastError());
+    CHK(ht_stats(e, n.ref.f(), 1, 1, N, N, 1, 1, 1, reinterpret_cast<double *>(n.ref_acc.p), s));
+  }
+  const int nsh = shifts > 0 ? shifts : 1;
+  const int maxB = c.max_batch > 0 ? c.max_batch : 8;
+  for (int si = 0; si < nsh; ++si) {
+    const int64_t offset = shifts > 0 ? offsets[si] : 0;
+    REQUIRE(offset >= 0 && offset <= max_shift, "shift offset %lld outside [0, %lld]", (long long)offset, (long long)max_shift);
+    // view = padded_mix[offset : offset + N + max_shift - offset]; padded index p <-> song index p - max_shift
+    const int64_t VL = N + max_shift - offset;
+    std::vector<int64_t> starts;
+    for (int64_t off = 0; off < VL; off += stride) {
+      const int64_t clen = std::min(VL - off, segment);
+      const int64_t delta = TL - clen;
+      starts.push_back(offset + off - delta / 2 - max_shift);   // song index of model-input sample 0
+    }
+    const int nk = (int)starts.size();
+    CHK(n.chunk_out.ensure((size_t)nk * S * 2 * TL * 4));
+    CHK(n.d_starts.ensure((size_t)nk * 8));
+    HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int nbatch = (nk + maxB - 1) / maxB;
+    const int per = (nk + nbatch - 1) / nbatch;
+    CHK(n.seg.ensure((size_t)per * 2 * TL * 4));
+    for (int k0 = 0; k0 < nk; k0 += per) {
+      const int B = std::min(per, nk - k0);
+      hipLaunchKernelGGL(ht_gather_kernel, dim3((unsigned)((TL + 255) / 256), 2, B), dim3(256), 0, s, mix_dev, N,
+                         reinterpret_cast<const int64_t *>(n.d_starts.p) + k0, TL,
+                         reinterpret_cast<const double *>(n.ref_acc.p), standardize, n.seg.f());
+      HIPCHK(hipGetLastError());
+      CHK(ht_forward_dev(e, n.seg.f(), B, n.chunk_out.f() + (size_t)k0 * S * 2 * TL, s));
+    }
+    CHK(timed(e, ASX_PROF_FINALIZE, 0.0, 4.0 * ((double)nk * S * 2 * TL + 2.0 * S * 2 * N), s, [&]() {
+      hipLaunchKernelGGL(ht_fold_kernel, dim3((unsigned)((N + 255) / 256), S * 2), dim3(256), 0, s, n.chunk_out.f(), nk,
+                         S * 2, TL, stride, segment, VL, max_shift - offset, n.fold_w.f(), si == 0 ? 1 : 0,
+                         si == nsh - 1 ? 1 : 0, nsh, reinterpret_cast<const double *>(n.ref_acc.p), standardize, swap01, N,
+                         out_dev);
+    }));
+  }
+  return ASX_OK;
+}

@@ -1,0 +1,693 @@
+// Demucs v4 (HTDemucs) kernels for gfx950 (uvr_lib_v5/demucs/htdemucs.py, hdemucs.py, demucs.py,
+// transformer.py, spec.py).
+//
+// Every activation is CHANNELS-LAST: the spectrogram branch is [B, T, F, C] (time frames outer,
+// frequency rows inner -- which is also the `b (t1 fr) c` token order of the cross transformer,
+// transformer.py:524), the waveform branch is [B, 1, L, C].  In that layout every convolution of the
+// network is a row GEMM whose A rows are GATHERED from KO x KI taps of C contiguous floats:
+//   Conv2d (8,1)/(4,1)  and Conv1d 8/4          : taps along the inner axis, stride 4
+//   ConvTranspose 8/4                           : two taps (j-1, j) -> 4*Cout columns scattered to 4 positions
+//   3x3 / k3 rewrite, DConv dilated k3, 1x1     : taps along inner and/or outer axis
+// (gg_kernel).  The A tile is fetched by LDS-DMA exactly like tdf_dma_kernel (kernels_net.h); only the
+// source address of each 16-byte chunk differs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asx {
+
+enum { GG_DENSE = 0, GG_GLU = 1, GG_CONVT = 2 };
+
+struct GgArgs {
+  const float *x, *w, *bias, *res, *zeros;
+  float *y;
+  int64_t M;                    // rows = (B*O) * IR
+  int N, K;                     // K = KO*KI*Cin; w is [N, K] dense
+  int O, I, Cin, ldc;           // input [B, O, I, ldc], Cin (% 4 == 0) channels used
+  int KO, KI, DO, DI, PO, PI, SI;
+  int IR;                       // rows per (b, o) line
+  float inv_cin;
+  int mode, act;
+  int Iout, Cout, crop, So;     // GG_CONVT: column (r, co) of row j -> position So*j - crop + r, r < N/Cout
+  int64_t ldy, ldr;
+  int res_mod;                  // > 0: residual row = row % res_mod (frequency embedding table)
+};
+
+template <int NREP, int MREP>
+__global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
+  constexpr int BK = 32, CPR = 8, RPI = 8;
+  constexpr int BM = 16 * MREP, BN = 64 * NREP, BUF = (BM + BN) * BK;
+  constexpr int NXI = BM / RPI, NWI = BN / RPI, NXL = (NXI + 3) / 4;
+  extern __shared__ float lds_f[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+
+  const int nbn = (a.N + BN - 1) / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bn = lid % nbn;
+  const int64_t m0 = (int64_t)(lid / nbn) * BM;
+  const int n0 = bn * BN;
+
+  const int lr = lane / CPR, lp = lane % CPR;
+  // swizzle g(row) = (row >> 1) & 7 with row = q*8 + lr, q = wave + 4i: depends on (wave & 1, lr) only
+  const int cl = lp ^ ((((wave & 1) << 2) + (lr >> 1)) & 7);   // logical chunk this lane fetches
+
+  int64_t xb[NXL];
+  int xo[NXL], xi[NXL];
+#pragma unroll
+  for (int i = 0; i < NXL; ++i) {
+    const int q = wave + 4 * i;
+    const int64_t row = m0 + q * RPI + lr;
+    if (q < NXI && row < a.M) {
+      const int64_t bo = row / a.IR;
+      const int j = (int)(row - bo * a.IR);
+      const int o = (int)(bo % a.O);
+      xb[i] = (bo - o) * (int64_t)a.I * a.ldc;
+      xo[i] = o - a.PO;
+      xi[i] = j * a.SI - a.PI;
+    } else {
+      xb[i] = 0;
+      xo[i] = -(1 << 29);
+      xi[i] = 0;
+    }
+  }
+
+  auto issue = [&](int k0, int buf) {
+    float *xs = lds_f + buf * BUF;
+    float *ws = xs + BM * BK;
+    const int k = k0 + cl * 4;
+    const int tap = (int)(((float)k + 0.5f) * a.inv_cin);
+    const int ci = k - tap * a.Cin;
+    const int to = (tap >= a.KI) + (tap >= 2 * a.KI);
+    const int ti = tap - to * a.KI;
+    const int od = to * a.DO, id = ti * a.DI;
+    const bool kok = k < a.K;
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      const int q = wave + 4 * i;
+      if (q < NXI) {
+        const int o = xo[i] + od, ii = xi[i] + id;
+        const bool ok = kok && ((unsigned)o < (unsigned)a.O) && ((unsigned)ii < (unsigned)a.I);
+        const float *src = ok ? a.x + xb[i] + ((int64_t)o * a.I + ii) * a.ldc + ci : a.zeros;
+        ASX_GLDS16(src, xs + q * 256);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (NWI + 3) / 4; ++i) {
+      const int q = wave + 4 * i;
+      if (q < NWI) {
+        const int row = q * RPI + lr;
+        const bool ok = (n0 + row < a.N) && kok;
+        const float *src = ok ? a.w + (int64_t)(n0 + row) * a.K + k : a.zeros;
+        ASX_GLDS16(src, ws + q * 256);
+      }
+    }
+  };
+
+  f32x4 acc[NREP][MREP];
+#pragma unroll
+  for (int n = 0; n < NREP; ++n)
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (a.K + BK - 1) / BK;
+  const int sw = (li >> 1) & 7;
+  issue(0, 0);
+  for (int ks = 0; ks < nk; ++ks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ks + 1 < nk) issue((ks + 1) * BK, (ks + 1) & 1);
+    const float *xs = lds_f + (ks & 1) * BUF;
+    const float *ws = xs + BM * BK;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int pc = ((kk * 4 + lk) ^ sw) * 4;
+      f32x4 wa[NREP];
+#pragma unroll
+      for (int n = 0; n < NREP; ++n)
+        wa[n] = *reinterpret_cast<const f32x4 *>(&ws[(wave * 16 * NREP + n * 16 + li) * BK + pc]);
+#pragma unroll
+      for (int mg = 0; mg < MREP; mg += 4) {
+        f32x4 xf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const f32x4 *>(&xs[((mg + m) * 16 + li) * BK + pc]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[n][mg + m] = ASX_MFMA(wa[n][j], xf[m][j], acc[n][mg + m]);
+      }
+    }
+  }
+
+  // epilogue: lane (li, lk) holds 4 consecutive columns of row m*16 + li
+#pragma unroll
+  for (int m = 0; m < MREP; ++m) {
+    const int64_t row = m0 + m * 16 + li;
+    if (row >= a.M) continue;
+    const int64_t rrow = a.res_mod > 0 ? row % a.res_mod : row;
+    int64_t bo = 0;
+    int j = 0;
+    if (a.mode == GG_CONVT) {
+      bo = row / a.IR;
+      j = (int)(row - bo * a.IR);
+    }
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+      if (col >= a.N) continue;
+      f32x4 v = acc[n][m];
+      if (a.bias != nullptr) v += *reinterpret_cast<const f32x4 *>(a.bias + col);
+      if (a.mode == GG_GLU) {
+        float2 o = make_float2(v.x * (1.0f / (1.0f + expf(-v.z))), v.y * (1.0f / (1.0f + expf(-v.w))));
+        const int c2 = col >> 1;
+        if (a.res != nullptr) {
+          const float2 r = *reinterpret_cast<const float2 *>(a.res + rrow * a.ldr + c2);
+          o.x += r.x;
+          o.y += r.y;
+        }
+        *reinterpret_cast<float2 *>(a.y + row * a.ldy + c2) = o;
+      } else {
+        f32x4 o;
+        o.x = tdf_act(v.x, a.act);
+        o.y = tdf_act(v.y, a.act);
+        o.z = tdf_act(v.z, a.act);
+        o.w = tdf_act(v.w, a.act);
+        int64_t off, roff;
+        if (a.mode == GG_CONVT) {
+          const int r = col / a.Cout;
+          const int co = col - r * a.Cout;
+          const int pos = j * a.So - a.crop + r;
+          if ((unsigned)pos >= (unsigned)a.Iout) continue;
+          off = (bo * a.Iout + pos) * a.ldy + co;
+          roff = (bo * a.Iout + pos) * a.ldr + co;
+        } else {
+          off = row * a.ldy + col;
+          roff = rrow * a.ldr + col;
+        }
+        if (a.res != nullptr) o += *reinterpret_cast<const f32x4 *>(a.res + roff);
+        *reinterpret_cast<f32x4 *>(a.y + off) = o;
+      }
+    }
+  }
+}
+
+template <int NREP, int MREP>
+static void ht_launch_gg(const GgArgs &a, hipStream_t s) {
+  constexpr int BM = 16 * MREP, BN = 64 * NREP;
+  constexpr int lds = 2 * (BM + BN) * 32 * 4;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gg_kernel<NREP, MREP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    once = true;
+  }
+  const int64_t nbm = (a.M + BM - 1) / BM;
+  const int nbn = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gg_kernel<NREP, MREP>), dim3((unsigned)(nbm * nbn)), dim3(256), lds, s, a);
+}
+
+// ---------------------------------------------------------------------------
+// Multi-head softmax attention (torch.nn.MultiheadAttention, transformer.py:213,305), head dim
+// DH = 16*DT (48 for htdemucs: 384 / 8).  q / k / v are separate row matrices (slices of the packed
+// in_proj output), queries and keys may differ in count (cross attention).  Same register scheme as
+// kernels_rof.h::attention_kernel: S^T = K Q^T, online softmax per query column, O^T += V^T P^T.
+// grid = (ceil(nq / 64), heads, B).
+// ---------------------------------------------------------------------------
+struct MhaArgs {
+  const float *q, *k, *v;
+  float *out;
+  int64_t ldq, ldk, ldv, ldo;
+  int nq, nk;
+  float scale;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void mha_kernel(MhaArgs a) {
+  constexpr int DH = 16 * DT, QS = DH + 2, VS = DH + 4, C4 = DH / 4;
+  __shared__ float lds[64 * QS * 2 + 64 * VS];
+  float *Qs = lds, *Ks = lds + 64 * QS, *Vs = lds + 128 * QS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = qt * 64;
+  const float *qp = a.q + (int64_t)b * a.nq * a.ldq + h * DH;
+  const float *kp = a.k + (int64_t)b * a.nk * a.ldk + h * DH;
+  const float *vp = a.v + (int64_t)b * a.nk * a.ldv + h * DH;
+
+  for (int e = tid; e < 64 * C4; e += 256) {
+    const int r = e / C4, c4 = e - r * C4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q0 + r < a.nq) v = *reinterpret_cast<const float4 *>(qp + (int64_t)(q0 + r) * a.ldq + c4 * 4);
+    float *d = &Qs[r * QS + c4 * 4];
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+    d[3] = v.w;
+  }
+
+  f32x4 acc_o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc_o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nkt = (a.nk + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int k0 = kt * 64;
+    __syncthreads();
+    for (int e = tid; e < 64 * C4; e += 256) {
+      const int r = e / C4, c4 = e - r * C4;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (k0 + r < a.nk) {
+        kv = *reinterpret_cast<const float4 *>(kp + (int64_t)(k0 + r) * a.ldk + c4 * 4);
+        vv = *reinterpret_cast<const float4 *>(vp + (int64_t)(k0 + r) * a.ldv + c4 * 4);
+      }
+      float *dk = &Ks[r * QS + c4 * 4];
+      dk[0] = kv.x;
+      dk[1] = kv.y;
+      dk[2] = kv.z;
+      dk[3] = kv.w;
+      *reinterpret_cast<float4 *>(&Vs[r * VS + c4 * 4]) = vv;
+    }
+    __syncthreads();
+
+    f32x4 st[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < DH / 4; ++kk) {
+      const float bq = Qs[(wave * 16 + li) * QS + 4 * kk + lk];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const float av = Ks[(mt * 16 + li) * QS + 4 * kk + lk];
+        st[mt] = ASX_MFMA(av, bq, st[mt]);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + mt * 16 + 4 * lk + r;
+        const float s = (key < a.nk) ? st[mt][r] * a.scale : -INFINITY;
+        st[mt][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = (st[mt][r] == -INFINITY) ? 0.f : expf(st[mt][r] - m_new);
+        st[mt][r] = p;
+        psum += p;
+      }
+    }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc_o[dt] *= corr;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pb = st[mt][r];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const float av = Vs[(mt * 16 + 4 * lk + r) * VS + dt * 16 + li];
+          acc_o[dt] = ASX_MFMA(av, pb, acc_o[dt]);
+        }
+      }
+    }
+  }
+
+  const int q = q0 + wave * 16 + li;
+  if (q < a.nq) {
+    const float inv = 1.0f / l_run;
+    float *op = a.out + ((int64_t)b * a.nq + q) * a.ldo + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      f32x4 o = acc_o[dt];
+      o *= inv;
+      *reinterpret_cast<f32x4 *>(op + dt * 16 + 4 * lk) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over the channel axis of a row matrix (+ optional positional table added after the affine,
+// transformer.py:528,536): y = (x - mean) * rsqrt(var + eps) * g + b (+ pos[row % pos_mod]).
+// One wave per row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int64_t lda, int C,
+                                                        const float *__restrict__ g, const float *__restrict__ bta,
+                                                        const float *__restrict__ pos, int64_t pos_mod,
+                                                        float *__restrict__ y, int64_t ldy, int64_t M, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float *xp = x + row * lda;
+  float s = 0.f;
+  for (int i = lane; i < C; i += 64) s += xp[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)C;
+  float ss = 0.f;
+  for (int i = lane; i < C; i += 64) {
+    const float d = xp[i] - mean;
+    ss += d * d;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  const float rstd = 1.0f / sqrtf(ss / (float)C + eps);
+  float *yp = y + row * ldy;
+  const float *pp = pos != nullptr ? pos + (row % pos_mod) * C : nullptr;
+  for (int i = lane; i < C; i += 64) {
+    float v = (xp[i] - mean) * rstd * g[i] + bta[i];
+    if (pp != nullptr) v += pp[i];
+    yp[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Group statistics.  x is viewed as [G1, R, P] (P = contiguous plane of G2 groups x ld floats, of which
+// the first Cn of every ld are data); group (g1, e / gdiv) accumulates sum and sum of squares in
+// float64: acc[(g1*G2 + g2)*2 + {0,1}] (zeroed by the caller).  grid = (ceil(P/256) or 1, rsplit, G1).
+//   GroupNorm(1, C) of DConv on the spectrogram branch: G1 = B, R = T, P = F*ld, gdiv = ld   (per (b, f))
+//   GroupNorm(1, C) over a whole sample / the mean-std of htdemucs.py:511,518: P = row, gdiv >= P
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gstats_kernel(const float *__restrict__ x, int64_t R, int64_t P, int64_t gdiv,
+                                                     int ld, int Cn, int G2, double *__restrict__ acc) {
+  __shared__ double sh[66][2];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 66 * 2; i += 256) (&sh[0][0])[i] = 0.0;
+  __syncthreads();
+  int64_t e;
+  int rr = 0, rpb = 1;
+  if (P >= 256) {
+    e = (int64_t)blockIdx.x * 256 + tid;
+  } else {
+    rpb = (int)(256 / P);
+    rr = tid / (int)P;
+    e = tid - rr * (int)P;
+    if (rr >= rpb) e = P;   // idle
+  }
+  const int64_t g1 = blockIdx.z;
+  const int64_t rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  const int64_t r1 = (r0 + rows_per < R) ? r0 + rows_per : R;
+  const int64_t gfirst = ((int64_t)blockIdx.x * 256) / gdiv;
+  if (e < P && (int)(e % ld) < Cn) {
+    double s = 0.0, ss = 0.0;
+    const float *xp = x + g1 * R * P + e;
+    for (int64_t r = r0 + rr; r < r1; r += rpb) {
+      const double v = (double)xp[r * P];
+      s += v;
+      ss += v * v;
+    }
+    const int lg = (int)(e / gdiv - (P >= 256 ? gfirst : 0));
+    atomicAdd(&sh[lg][0], s);
+    atomicAdd(&sh[lg][1], ss);
+  }
+  __syncthreads();
+  const int64_t gbase = (P >= 256) ? gfirst : 0;
+  if (tid < 66) {
+    const int64_t g2 = gbase + tid;
+    if (g2 < G2 && (sh[tid][0] != 0.0 || sh[tid][1] != 0.0)) {
+      atomicAdd(&acc[(g1 * G2 + g2) * 2], sh[tid][0]);
+      atomicAdd(&acc[(g1 * G2 + g2) * 2 + 1], sh[tid][1]);
+    }
+  }
+}
+
+__device__ __forceinline__ void group_mean_rstd(const double *acc, int64_t g, double n, float eps, float &mean,
+                                                float &rstd) {
+  const double m = acc[g * 2] / n;
+  double var = acc[g * 2 + 1] / n - m * m;
+  if (var < 0.0) var = 0.0;
+  mean = (float)m;
+  rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// GroupNorm(1, Cn) apply over [G1, R, G2, ld] with the statistics of gstats_kernel.
+//   mode 0: y = gelu(norm(x))                         in place on x       (DConv, demucs.py:150-157)
+//   mode 1: dst[.., c] += ls[c] * glu(norm(x))[c]     x has 2*Ch channels (DConv + LayerScale, demucs.py:178)
+//   mode 2: y = norm(x)                               in place            (MyGroupNorm norm_out, transformer.py:181)
+__global__ __launch_bounds__(256) void gn_apply_kernel(float *__restrict__ x, int64_t R, int G2, int ld, int Cn,
+                                                       const double *__restrict__ acc, const float *__restrict__ gam,
+                                                       const float *__restrict__ bet, float eps, int mode,
+                                                       float *__restrict__ dst, int dst_ld,
+                                                       const float *__restrict__ ls, int64_t total) {
+  const int Ce = (mode == 1) ? Cn / 2 : Cn;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;          // total = G1*R*G2*Ce
+  const int c = (int)(idx % Ce);
+  const int64_t pos = idx / Ce;       // (g1, r, g2)
+  const int g2 = (int)(pos % G2);
+  const int64_t g1 = pos / G2 / R;
+  float mean, rstd;
+  group_mean_rstd(acc, g1 * G2 + g2, (double)R * Cn, eps, mean, rstd);
+  float *xp = x + pos * ld;
+  if (mode == 1) {
+    const float na = (xp[c] - mean) * rstd * gam[c] + bet[c];
+    const float ng = (xp[c + Ce] - mean) * rstd * gam[c + Ce] + bet[c + Ce];
+    dst[pos * dst_ld + c] += ls[c] * (na * (1.0f / (1.0f + expf(-ng))));
+  } else {
+    float v = (xp[c] - mean) * rstd * gam[c] + bet[c];
+    if (mode == 0) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    xp[c] = v;
+  }
+}
+
+// x = (x - mean) / (1e-5 + std), std unbiased (htdemucs.py:511-513), in place over [G1, n] with per-g1 stats.
+__device__ __forceinline__ void sample_mean_std(const double *acc, int64_t g, double n, float &mean, float &stdv) {
+  const double m = acc[g * 2] / n;
+  double var = (acc[g * 2 + 1] - n * m * m) / (n - 1.0);
+  if (var < 0.0) var = 0.0;
+  mean = (float)m;
+  stdv = (float)sqrt(var);
+}
+
+__global__ __launch_bounds__(256) void std_norm_kernel(float *__restrict__ x, int64_t n, const double *__restrict__ acc) {
+  const int64_t g = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float mean, stdv;
+  sample_mean_std(acc, g, (double)n, mean, stdv);
+  x[g * n + i] = (x[g * n + i] - mean) / (1e-5f + stdv);
+}
+
+// waveform branch input (htdemucs.py:516-519): seg [B, 2, L] -> xt [B, L, 2] = (seg - mean) / (1e-5 + std), channels
+// last; the first encoder layer reads it as [B, L/2, 4] (pairs of samples) so that its taps are 16-byte chunks.
+__global__ __launch_bounds__(256) void time_norm_kernel(const float *__restrict__ seg, int64_t L,
+                                                        const double *__restrict__ acc, float *__restrict__ xt) {
+  const int64_t b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  float mean, stdv;
+  sample_mean_std(acc, b, (double)(2 * L), mean, stdv);
+  const float d = 1e-5f + stdv;
+  const float l = (seg[(b * 2) * L + i] - mean) / d, r = (seg[(b * 2 + 1) * L + i] - mean) / d;
+  reinterpret_cast<float2 *>(xt)[b * L + i] = make_float2(l, r);
+}
+
+__global__ __launch_bounds__(256) void add_kernel(float *__restrict__ y, const float *__restrict__ a, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += a[i];
+}
+
+// ---------------------------------------------------------------------------
+// HTDemucs._spec (htdemucs.py:383-403) -> [B, T, F, 4] with channel = ch*2 + {re, im}.
+// Frame t covers samples [t*hop - 3*hop/2, ... + n_fft) of the segment, reflected at both ends (pad1d reflect
+// then the centre padding of torch.stft, which frames 2 .. 2+le never touch), window = periodic Hann,
+// normalized=True (x n_fft^-0.5); the Nyquist bin is dropped.  grid = (T, 2, B).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ht_stft_kernel(const float *__restrict__ seg, int64_t L, int hop, int T,
+                                                      float *__restrict__ spec, const float *__restrict__ window,
+                                                      const float2 *__restrict__ tw, FftPlan p) {
+  extern __shared__ float2 lds[];
+  float2 *bufA = lds;
+  float2 *bufB = lds + p.nh;
+  const int t = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
+  const float *src = seg + ((int64_t)b * 2 + ch) * L;
+  const int pad = hop / 2 * 3;
+  float *fa = reinterpret_cast<float *>(bufA);
+  for (int e = threadIdx.x; e < p.n_fft; e += blockDim.x) {
+    int64_t q = (int64_t)t * hop + e - pad;
+    if (q < 0) q = -q;
+    if (q >= L) q = 2 * (L - 1) - q;
+    fa[e] = src[q] * window[e];
+  }
+  float2 *Z = fft_lds<-1>(bufA, bufB, p, tw);
+  const int nh = p.nh;
+  const float sc = 1.0f / sqrtf((float)p.n_fft);
+  for (int k = threadIdx.x; k < nh; k += blockDim.x) {
+    const float2 zk = Z[k];
+    float2 zc = Z[k == 0 ? 0 : nh - k];
+    zc.y = -zc.y;
+    const float2 E = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+    const float2 D = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
+    const float2 O = make_float2(D.y, -D.x);
+    const float2 X = cadd(E, cmul(tw[k], O));
+    reinterpret_cast<float2 *>(spec)[(((int64_t)b * T + t) * nh + k) * 2 + ch] = make_float2(X.x * sc, X.y * sc);
+  }
+}
+
+// HTDemucs._ispec frames (htdemucs.py:405-413, 600-606): spectrum of (b, source s, channel c) = CaC output
+// x[b, t, f, s*4 + c*2 + {re, im}] * std + mean (htdemucs.py:590), Nyquist = 0; windowed inverse frames
+// [B, S*2, T, n_fft] scaled by sqrt(n_fft) (normalized=True).  grid = (T, S*2, B).
+__global__ __launch_bounds__(256) void ht_istft_kernel(const float *__restrict__ x, int T, int CH,
+                                                       const double *__restrict__ acc, double n_stat,
+                                                       float *__restrict__ frames, const float *__restrict__ window,
+                                                       const float2 *__restrict__ tw, FftPlan p) {
+  extern __shared__ float2 lds[];
+  float2 *bufA = lds;
+  float2 *bufB = lds + p.nh;
+  float2 *bufX = lds + 2 * p.nh;
+  const int t = blockIdx.x, sc_ = blockIdx.y, b = blockIdx.z;
+  const int nh = p.nh;
+  float mean, stdv;
+  sample_mean_std(acc, b, n_stat, mean, stdv);
+  for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
+    float2 v = make_float2(0.f, 0.f);
+    if (k < nh) {
+      const float2 r = *reinterpret_cast<const float2 *>(x + (((int64_t)b * T + t) * nh + k) * CH + sc_ * 2);
+      v = make_float2(r.x * stdv + mean, r.y * stdv + mean);
+    }
+    if (k == 0) v.y = 0.f;
+    bufX[k] = v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nh; k += blockDim.x) {
+    const float2 xk = bufX[k];
+    float2 xc = bufX[nh - k];
+    xc.y = -xc.y;
+    const float2 E = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
+    const float2 D = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
+    float2 w = tw[k];
+    w.y = -w.y;
+    const float2 O = cmul(w, D);
+    bufA[k] = make_float2(E.x - O.y, E.y + O.x);
+  }
+  float2 *z = fft_lds<+1>(bufA, bufB, p, tw);
+  const float scale = sqrtf((float)p.n_fft) / (float)nh;
+  float2 *dst = reinterpret_cast<float2 *>(frames + (((int64_t)b * gridDim.y + sc_) * T + t) * p.n_fft);
+  const float2 *w2 = reinterpret_cast<const float2 *>(window);
+  for (int m = threadIdx.x; m < nh; m += blockDim.x) {
+    const float2 v = z[m];
+    const float2 w = w2[m];
+    dst[m] = make_float2((v.x * scale) * w.x, (v.y * scale) * w.y);
+  }
+}
+
+// Overlap-add of the frames (torch.istft with two zero frames either side, / window envelope, htdemucs.py:405-413)
+// plus the waveform branch: out[b, s, c, n] = xt[b, n, s*2 + c] * stdt + meant + ispec (htdemucs.py:608-612).
+// env_hop[r] = sum_i w^2[r + i*hop] (every output sample is covered by n_fft/hop real-or-zero frames).
+__global__ __launch_bounds__(256) void ht_ola_kernel(const float *__restrict__ frames, const float *__restrict__ env_hop,
+                                                     int n_fft, int hop, int T, int64_t L,
+                                                     const float *__restrict__ xt, int xt_ld,
+                                                     const double *__restrict__ acc_t, float *__restrict__ out) {
+  const int b = blockIdx.z, sc_ = blockIdx.y;
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= L) return;
+  const int64_t m = n + hop / 2 * 3;           // offset inside the run of real frames
+  int64_t t_hi = m / hop;
+  int64_t t_lo = (m - n_fft + hop) / hop;
+  if (m - n_fft + 1 <= 0) t_lo = 0;
+  if (t_hi > T - 1) t_hi = T - 1;
+  const float *fr = frames + ((int64_t)b * gridDim.y + sc_) * T * n_fft;
+  float a = 0.f;
+  for (int64_t t = t_lo; t <= t_hi; ++t) a += fr[t * n_fft + (m - t * hop)];
+  const float y = a / env_hop[m % hop];
+  float mean, stdv;
+  sample_mean_std(acc_t, b, (double)(2 * L), mean, stdv);
+  const float tv = xt[((int64_t)b * L + n) * xt_ld + sc_] * stdv + mean;
+  out[((int64_t)b * gridDim.y + sc_) * L + n] = tv + y;
+}
+
+// ---------------------------------------------------------------------------
+// apply_model (apply.py:124-260) around the model.
+// gather: seg[b, ch, i] = song[ch, start[b] + i] standardised ((x - mean) / std, demucs_separator.py:171-173),
+//         0 outside the song (TensorChunk.padded, apply.py:96-107).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ht_gather_kernel(const float *__restrict__ song, int64_t N,
+                                                        const int64_t *__restrict__ start, int64_t L,
+                                                        const double *__restrict__ ref_acc, int standardize,
+                                                        float *__restrict__ seg) {
+  const int b = blockIdx.z, ch = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  const int64_t j = start[b] + i;
+  float v = 0.f;
+  if (j >= 0 && j < N) {
+    v = song[(int64_t)ch * N + j];
+    if (standardize) {
+      float mean, stdv;
+      sample_mean_std(ref_acc, 0, (double)N, mean, stdv);
+      v = (v - mean) / stdv;
+    }
+  }
+  seg[((int64_t)b * 2 + ch) * L + i] = v;
+}
+
+// mono reference: ref[i] = mean over channels (demucs_separator.py:171)
+__global__ __launch_bounds__(256) void ht_mono_kernel(const float *__restrict__ song, int64_t N, float *__restrict__ ref) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) ref[i] = (song[i] + song[N + i]) / 2.0f;
+}
+
+// fold of one shift (apply.py:215-250 then :207-213): view sample u = n + lead is covered by chunks k with
+// view offset k*stride; so = sum_k w[u - k*stride] * y_k[trim_k + u - k*stride] / sum_k w[..];
+// out = (first ? 0 : out) + so; the last shift divides by `shifts` and de-standardises (* std + mean).
+__global__ __launch_bounds__(256) void ht_fold_kernel(const float *__restrict__ chunk_out, int n_chunks, int SC,
+                                                      int64_t TL, int64_t stride, int64_t segment, int64_t VL,
+                                                      int64_t lead, const float *__restrict__ weight, int first,
+                                                      int last, int shifts, const double *__restrict__ ref_acc,
+                                                      int standardize, int swap01, int64_t N, float *__restrict__ out) {
+  const int sc_ = blockIdx.y;
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int64_t u = n + lead;
+  int64_t k_hi = u / stride;
+  if (k_hi > n_chunks - 1) k_hi = n_chunks - 1;
+  int64_t k_lo = (u - segment + stride) / stride;
+  if (u - segment + 1 <= 0) k_lo = 0;
+  float num = 0.f, den = 0.f;
+  for (int64_t k = k_lo; k <= k_hi; ++k) {
+    const int64_t off = k * stride;
+    const int64_t clen = (VL - off < segment) ? VL - off : segment;
+    const int64_t j = u - off;
+    if (j < 0 || j >= clen) continue;
+    const int64_t trim = (TL - clen) / 2;
+    const float w = weight[j];
+    num += w * chunk_out[((int64_t)k * SC + sc_) * TL + trim + j];
+    den += w;
+  }
+  int so_ = sc_;
+  if (swap01 && (sc_ >> 1) < 2) so_ = ((1 - (sc_ >> 1)) << 1) | (sc_ & 1);
+  float *op = out + (int64_t)so_ * N + n;
+  float v = num / den;
+  if (!first) v = *op + v;
+  if (last) {
+    v = v / (float)shifts;
+    if (standardize) {
+      float mean, stdv;
+      sample_mean_std(ref_acc, 0, (double)N, mean, stdv);
+      v = v * stdv + mean;
+    }
+  }
+  *op = v;
+}
+
+}  // namespace asx

@@ -1,0 +1,119 @@
+"""Host-side mirror of the reference Demucs plugin's array path (architectures/demucs_separator.py).
+
+``DemucsDemixer(common_config, arch_config, models=[...])`` follows ``DemucsSeparator.__init__`` (:32-81) for the
+arch_config keys (segment_size, shifts, overlap, segments_enabled) and ``demix_demucs`` (:162-194) for the call:
+``demix(mix [2, N]) -> sources [S, 2, N]`` with stems 0/1 swapped exactly like the reference.  All sample-domain
+work -- standardisation, shift trick, segment split, HTDemucs forward, triangular fold -- runs in libasx.so
+(asx_ht_demix); the host only draws the random shift offsets, because the reference draws them from Python's
+``random`` (uvr_lib_v5/demucs/apply.py:209).
+
+A bag of models (BagOfModels, apply.py:26-66,169-196: htdemucs_ft, htdemucs_6s ...) is a list of
+(HTConfig, state_dict, per-source weights); the per-model results are combined on the host with the reference's
+weighted average.  Only HTDemucs (Demucs v4) checkpoints are accelerated; v1-v3 raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+
+from .engine import Engine, HTConfig, MDXConfig
+
+
+def htconfig_from_kwargs(kwargs: dict, max_batch: int = 0) -> HTConfig:
+    """HTConfig from the `kwargs` a Demucs v4 checkpoint package stores (states.py:load_model: klass(*args, **kwargs)).
+    Raises NotImplementedError for structures the engine does not build."""
+    k = dict(kwargs)
+    unsupported = {"cac": True, "wiener_iters": 0, "end_iters": 0, "multi_freqs": None, "dconv_mode": 1, "time_stride": 2, "context": 1, "context_enc": 0, "rewrite": True,
+                   "t_emb": "sin", "t_norm_first": True, "t_norm_in": True, "t_norm_out": True, "t_layer_scale": True,
+                   "t_gelu": True, "t_cross_first": False, "t_sparse_self_attn": False, "t_sparse_cross_attn": False,
+                   "t_norm_in_group": False, "t_group_norm": False, "channels_time": None, "audio_channels": 2,
+                   "t_weight_pos_embed": 1.0, "t_sin_random_shift": 0, "use_train_segment": True}
+    for name, want in unsupported.items():
+        if name in k and k[name] != want and not (want is None and not k[name]):
+            raise NotImplementedError(f"HTDemucs option {name}={k[name]!r} is not built (only {want!r})")
+    depth = k.get("depth", 4)
+    if k.get("norm_starts", 4) < depth or k.get("dconv_attn", 4) < depth or k.get("dconv_lstm", 4) < depth:
+        raise NotImplementedError("GroupNorm / attention / LSTM inside the encoder layers is not built")
+    return HTConfig(sources=tuple(k["sources"]), channels=k.get("channels", 48), growth=k.get("growth", 2),
+                    nfft=k.get("nfft", 4096), depth=depth, kernel_size=k.get("kernel_size", 8), stride=k.get("stride", 4),
+                    dconv_depth=k.get("dconv_depth", 2), dconv_comp=k.get("dconv_comp", 8), freq_emb=k.get("freq_emb", 0.2),
+                    bottom_channels=k.get("bottom_channels", 0), t_layers=k.get("t_layers", 5), t_heads=k.get("t_heads", 8),
+                    t_hidden_scale=k.get("t_hidden_scale", 4.0), samplerate=k.get("samplerate", 44100),
+                    segment=k.get("segment", 10), max_batch=max_batch)
+
+
+class DemucsDemixer:
+    def __init__(self, common_config: dict, arch_config: dict, models, weights=None):
+        """models: list of (HTConfig, state_dict); weights: per-model list of per-source weights (BagOfModels.weights)."""
+        self.shifts = arch_config.get("shifts", 2)
+        self.overlap = arch_config.get("overlap", 0.25)
+        self.segments_enabled = arch_config.get("segments_enabled", True)
+        self.segment_size = arch_config.get("segment_size", "Default")
+        if self.segment_size not in ("Default", None):
+            # demucs_segments (apply.py:263-300) never changes the model's segment (`segment` stays None on every path)
+            pass
+        if not self.segments_enabled:
+            raise NotImplementedError("segments_enabled=False (split=False) is only defined for inputs up to one segment; "
+                                      "use the engine's ht_forward for that")
+        dev = common_config.get("torch_device", 0)
+        self.device = getattr(dev, "index", dev) or 0
+        self.models = list(models)
+        if not self.models:
+            raise ValueError("at least one (HTConfig, state_dict) model is required")
+        S = len(self.models[0][0].sources)
+        self.weights = weights if weights is not None else [[1.0] * S for _ in self.models]
+        if len(self.weights) != len(self.models) or any(len(w) != S for w in self.weights):
+            raise ValueError("weights must give one value per source for every model")
+        self.engine = None
+        self._loaded = None
+
+    def _load(self, idx: int):
+        if self._loaded == idx:
+            return
+        hc, sd = self.models[idx]
+        if self.engine is None:
+            # the MDX geometry of the engine is unused on this path; any valid one will do
+            self.engine = Engine(MDXConfig(n_fft=hc.nfft, hop_length=hc.nfft // 4, dim_f=hc.nfft // 2, segment_size=8),
+                                 device=self.device)
+        self.engine.load_ht(hc, sd)
+        self._loaded = idx
+
+    def demix(self, mix: np.ndarray, offsets=None) -> np.ndarray:
+        """demix_demucs: [2, N] -> [S, 2, N].  offsets (optional) pins the shift draws, one list per model."""
+        mix = np.ascontiguousarray(mix, np.float32)
+        if mix.ndim != 2 or mix.shape[0] != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got shape {mix.shape}")
+        est = None
+        totals = np.zeros(len(self.models[0][0].sources), np.float64)
+        single = len(self.models) == 1
+        for i in range(len(self.models)):
+            self._load(i)
+            hc = self.models[i][0]
+            offs = None
+            if self.shifts:
+                offs = offsets[i] if offsets is not None else [random.randint(0, int(0.5 * hc.samplerate))
+                                                               for _ in range(self.shifts)]
+            # a single model is de-standardised and swapped inside the engine; a bag is combined first (apply.py:186-196)
+            out = self.engine.ht_demix(mix, shifts=self.shifts, offsets=offs, overlap=self.overlap, standardize=single,
+                                       swap01=single) if single else self._bag_member(mix, offs)
+            if single:
+                return out
+            w = np.asarray(self.weights[i], np.float32)
+            out *= w[:, None, None]
+            totals += w
+            est = out if est is None else est + out
+        est /= totals.astype(np.float32)[:, None, None]
+        ref = mix.mean(0)
+        import torch
+        rt = torch.from_numpy(ref)
+        est = est * float(rt.std()) + float(rt.mean())
+        est[[0, 1]] = est[[1, 0]]
+        return est
+
+    def _bag_member(self, mix, offs):
+        import torch
+        t = torch.from_numpy(mix)
+        ref = t.mean(0)
+        std_mix = ((t - ref.mean()) / ref.std()).numpy()
+        return self.engine.ht_demix(std_mix, shifts=self.shifts, offsets=offs, overlap=self.overlap)

@@ -48,6 +48,13 @@ class _RofCfg(C.Structure):
                [("freqs_per_bands", C.c_int32 * 128)]
 
 
+class _HtCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_sources", "channels", "growth", "nfft", "depth", "kernel_size", "stride",
+                                         "dconv_depth", "dconv_comp", "bottom_channels", "t_layers", "t_heads",
+                                         "t_hidden", "samplerate", "segment_samples")] + \
+               [("freq_emb_scale", C.c_float), ("max_batch", C.c_int32)]
+
+
 class _Plan(C.Structure):
     _fields_ = [("n_samples", C.c_int64), ("padded_len", C.c_int64), ("chunk_size", C.c_int64),
                 ("gen_size", C.c_int64), ("pad", C.c_int64), ("step", C.c_int64), ("trim", C.c_int32),
@@ -117,6 +124,36 @@ class RofConfig:
     n_out: int = 2
 
 
+@dataclass
+class HTConfig:
+    """HTDemucs constructor arguments (uvr_lib_v5/demucs/htdemucs.py:32-110) the engine builds."""
+    sources: tuple = ("drums", "bass", "other", "vocals")
+    channels: int = 48
+    growth: int = 2
+    nfft: int = 4096
+    depth: int = 4
+    kernel_size: int = 8
+    stride: int = 4
+    dconv_depth: int = 2
+    dconv_comp: int = 8
+    freq_emb: float = 0.2
+    bottom_channels: int = 0
+    t_layers: int = 5
+    t_heads: int = 8
+    t_hidden_scale: float = 4.0
+    samplerate: int = 44100
+    segment: object = 7.8          # seconds (Fraction in the checkpoints)
+    max_batch: int = 0
+
+    @property
+    def segment_samples(self) -> int:
+        return int(self.segment * self.samplerate)
+
+    @property
+    def transformer_dim(self) -> int:
+        return self.bottom_channels or self.channels * self.growth ** (self.depth - 1)
+
+
 _FP = C.POINTER(C.c_float)
 _lib = None
 
@@ -126,7 +163,8 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_demix_dev", "asx_demix_chunks_dev", "asx_finalize_dev", "asx_separate", "asx_separate_dev", "asx_stft", "asx_istft", "asx_net_forward",
            "asx_run_model", "asx_op_conv", "asx_op_tdf", "asx_profile_enable", "asx_profile_read", "asx_v3_begin",
            "asx_v3_commit", "asx_v3_flops", "asx_v3_forward", "asx_mdxc_plan", "asx_mdxc_demix", "asx_mdxc_demix_dev",
-           "asx_set_option", "asx_rof_begin", "asx_rof_commit", "asx_rof_flops", "asx_rof_forward", "asx_rof_demix", "asx_rof_demix_dev"]
+           "asx_set_option", "asx_rof_begin", "asx_rof_commit", "asx_rof_flops", "asx_rof_forward", "asx_rof_demix", "asx_rof_demix_dev",
+           "asx_ht_begin", "asx_ht_commit", "asx_ht_flops", "asx_ht_forward", "asx_ht_demix", "asx_ht_demix_dev"]
 
 
 def load_library():
@@ -188,12 +226,50 @@ def load_library():
     lib.asx_rof_demix.argtypes = [vp, _FP, i64, i64, _FP]
     lib.asx_rof_demix_dev.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.asx_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.asx_ht_begin.argtypes = [vp, C.POINTER(_HtCfg)]
+    lib.asx_ht_commit.argtypes = [vp]
+    lib.asx_ht_flops.argtypes = [vp]
+    lib.asx_ht_flops.restype = C.c_double
+    lib.asx_ht_forward.argtypes = [vp, _FP, i32, i64, _FP]
+    lib.asx_ht_demix.argtypes = [vp, _FP, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, _FP]
+    lib.asx_ht_demix_dev.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, vp, vp]
     lib.asx_profile_enable.argtypes = [vp, i32]
     lib.asx_profile_read.argtypes = [vp, C.POINTER(_Profile)]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the library does not export what the header declares
     _lib = lib
     return lib
+
+
+def ht_pos_tables(hc: "HTConfig") -> dict:
+    """The two sinusoidal tables of CrossTransformerEncoder (transformer.py:18-46, 522-537) in torch float32 on the
+    host, in the engine's token order: "pos_emb_freq" rows (t1, fr), "pos_emb_time" rows t2."""
+    import math
+
+    import torch
+    Ct = hc.transformer_dim
+    hop = hc.nfft // 4
+    T1 = -(-hc.segment_samples // hop)
+    Fr = hc.nfft // 2 // hc.stride ** hc.depth
+    T2 = hc.segment_samples
+    for _ in range(hc.depth):
+        T2 = -(-T2 // hc.stride)
+    pe = torch.zeros(Ct, Fr, T1)
+    dm = Ct // 2
+    div = torch.exp(torch.arange(0.0, dm, 2) * -(math.log(10000.0) / dm))
+    pw = torch.arange(0.0, T1).unsqueeze(1)
+    ph = torch.arange(0.0, Fr).unsqueeze(1)
+    pe[0:dm:2] = torch.sin(pw * div).transpose(0, 1).unsqueeze(1).repeat(1, Fr, 1)
+    pe[1:dm:2] = torch.cos(pw * div).transpose(0, 1).unsqueeze(1).repeat(1, Fr, 1)
+    pe[dm::2] = torch.sin(ph * div).transpose(0, 1).unsqueeze(2).repeat(1, 1, T1)
+    pe[dm + 1::2] = torch.cos(ph * div).transpose(0, 1).unsqueeze(2).repeat(1, 1, T1)
+    half = Ct // 2
+    pos = torch.arange(T2).view(-1, 1)
+    adim = torch.arange(half).view(1, -1)
+    phase = pos / (10000.0 ** (adim / (half - 1)))
+    pt = torch.cat([torch.cos(phase), torch.sin(phase)], dim=-1)
+    return {"pos_emb_freq": pe.permute(2, 1, 0).reshape(T1 * Fr, Ct).contiguous().numpy(),
+            "pos_emb_time": pt.contiguous().numpy()}
 
 
 def _f32(a) -> np.ndarray:
@@ -340,6 +416,60 @@ class Engine:
 
     def rof_demix_dev(self, mix_ptr: int, n_samples: int, step: int, out_ptr: int, stream: int = 0):
         self._check(self._lib.asx_rof_demix_dev(self._h, mix_ptr, n_samples, int(step), out_ptr, stream or None))
+
+    # -- Demucs v4 ----------------------------------------------------------------
+    def load_ht(self, hc: HTConfig, state_dict: dict, pos_tables: bool = True):
+        """HTDemucs(**kwargs) + load_state_dict.  pos_tables: compute the sinusoidal tables with torch on the host
+        (bit-identical to transformer.py:18-46 on CPU) and hand them over; otherwise the engine builds them itself."""
+        C_t = hc.transformer_dim
+        c = _HtCfg(len(hc.sources), hc.channels, hc.growth, hc.nfft, hc.depth, hc.kernel_size, hc.stride, hc.dconv_depth,
+                   hc.dconv_comp, hc.bottom_channels, hc.t_layers, hc.t_heads, int(C_t * hc.t_hidden_scale),
+                   hc.samplerate, hc.segment_samples, float(hc.freq_emb), hc.max_batch)
+        self._check(self._lib.asx_ht_begin(self._h, C.byref(c)))
+        tensors = dict(state_dict)
+        if pos_tables and hc.t_layers > 0:
+            tensors.update(ht_pos_tables(hc))
+        for name, t in tensors.items():
+            if hasattr(t, "detach"):
+                t = t.detach().cpu().numpy()
+            a = _f32(t).reshape(-1)
+            self._check(self._lib.asx_net_set_tensor(self._h, name.encode(), _ptr(a), a.size))
+        self._check(self._lib.asx_ht_commit(self._h))
+        self.ht_cfg = hc
+
+    def ht_flops(self) -> float:
+        return float(self._lib.asx_ht_flops(self._h))
+
+    def ht_forward(self, mix: np.ndarray) -> np.ndarray:
+        mix = _f32(mix)
+        B, ch, L = mix.shape
+        if ch != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got {ch} channels")
+        out = np.empty((B, len(self.ht_cfg.sources), 2, L), np.float32)
+        self._check(self._lib.asx_ht_forward(self._h, _ptr(mix), B, L, _ptr(out)))
+        return out
+
+    def ht_demix(self, mix: np.ndarray, shifts: int = 0, offsets=None, overlap: float = 0.25, standardize: bool = False,
+                 swap01: bool = False) -> np.ndarray:
+        mix = _f32(mix)
+        if mix.ndim != 2 or mix.shape[0] != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got shape {mix.shape}")
+        out = np.empty((len(self.ht_cfg.sources), 2, mix.shape[1]), np.float32)
+        offs = None
+        if shifts:
+            if offsets is None or len(offsets) != shifts:
+                raise ValueError("shifts > 0 needs one offset per shift")
+            offs = (C.c_int64 * shifts)(*[int(o) for o in offsets])
+        flags = (1 if standardize else 0) | (2 if swap01 else 0)
+        self._check(self._lib.asx_ht_demix(self._h, _ptr(mix), mix.shape[1], int(shifts), offs, float(overlap), flags,
+                                           _ptr(out)))
+        return out
+
+    def ht_demix_dev(self, mix_ptr: int, n_samples: int, out_ptr: int, shifts: int = 0, offsets=None,
+                     overlap: float = 0.25, flags: int = 0, stream: int = 0):
+        offs = (C.c_int64 * shifts)(*[int(o) for o in offsets]) if shifts else None
+        self._check(self._lib.asx_ht_demix_dev(self._h, mix_ptr, n_samples, int(shifts), offs, float(overlap), flags,
+                                               out_ptr, stream or None))
 
     # -- plan ---------------------------------------------------------------
     def plan(self, n_samples: int, is_match_mix: bool = False) -> dict:
