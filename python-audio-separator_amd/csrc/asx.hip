@@ -1822,9 +1822,11 @@ int asx_profile_read(asx_engine *e, asx_profile *out) {
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipDeviceSynchronize());
   memset(out, 0, sizeof(*out));
+  static const bool dump = getenv("ASX_PROF_DUMP") != nullptr;   // one line per launch on stderr (tuning aid)
   for (auto &r : e->recs) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+    if (dump) fprintf(stderr, "asx_prof cls=%d ms=%.4f gflop=%.3f mbytes=%.2f\n", r.cls, ms, r.flops * 1e-9, r.bytes * 1e-6);
     out->launches[r.cls] += 1;
     out->ms[r.cls] += ms;
     out->flops[r.cls] += r.flops;
