@@ -1,0 +1,526 @@
+"""CPU oracle for the VR (vocal-remover) path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/mdx_oracle.py for the rules).  Restates, in numpy / scipy / torch-CPU:
+``architectures/vr_separator.py`` (loading_mix :255-291, inference_vr :293-366, spec_to_wav :368-375),
+``uvr_lib_v5/spec_utils.py`` (preprocess :74, make_padding :86, merge_artifacts :180, combine_spectrograms
+:250-281, wave_to_spectrogram :284-312, spectrogram_to_wave :315-338, cmb_spectrogram_to_wave :341-396,
+get_lp/hp_filter_mask :399-408, fft_lp/hp_filter :411-429, adjust_aggr :472-492) and
+``uvr_lib_v5/vr_network/nets.py`` / ``layers.py`` (CascadedASPPNet, BaseASPPNet, Encoder, Decoder, ASPPModule).
+
+Third-party arithmetic the reference delegates to libraries that are ABSENT here:
+  * librosa 0.11.0 ``stft`` / ``istft`` (spec_utils.py:304,319): restated below (`lr_stft`, `lr_istft`) from the
+    published algorithm -- centre padding with zeros (``pad_mode="constant"``), periodic Hann from
+    scipy.signal.get_window, float64 window multiply and pocketfft rfft rounded to complex64 for float32 input;
+    istft = irfft * window, overlap-add, division by the squared-window sum, centre trim, length hop*(T-1).
+    PARITY UNPINNED for these two functions against librosa itself; cross-checked against scipy.signal.stft / istft
+    (an independent implementation of the same transform) in tests/test_oracle_vr.py.
+  * librosa.resample: ``res_type="polyphase"`` is scipy.signal.resample_poly (present, called here exactly as librosa
+    calls it: up/down = target/orig over their gcd, then fix_length to ceil(n * ratio)).  The ``sinc_*`` types are
+    libsamplerate (absent).  The synthesis chain of the reference hard-codes ``wav_resolution = "sinc_fastest"`` off
+    ARM / MPS and "polyphase" on them (spec_utils.py:33-38, vr_separator.py:266-267); this oracle (and the engine)
+    implement the polyphase chain, i.e. the reference's ARM / MPS behaviour, for every platform.
+
+Everything else (spec_utils band logic, nets) is pinned on golden vectors written by the reference's own functions
+and classes, driven with a stand-in `librosa` module that exposes the three restatements above
+(tests/golden/make_golden_vr.py -> vr_small.npz).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from math import gcd
+
+import numpy as np
+import scipy.signal
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# librosa restatements
+# --------------------------------------------------------------------------
+def hann_periodic(n: int) -> np.ndarray:
+    return scipy.signal.get_window("hann", n, fftbins=True)
+
+
+def lr_stft(y, n_fft=2048, hop_length=None, **_):
+    """librosa.stft(y, n_fft, hop_length) with the 0.10+ defaults (center=True, pad_mode="constant", hann)."""
+    y = np.asarray(y)
+    hop = hop_length if hop_length is not None else n_fft // 4
+    w = hann_periodic(n_fft)
+    yp = np.pad(y, (n_fft // 2, n_fft // 2), mode="constant")
+    n_frames = 1 + (len(yp) - n_fft) // hop
+    idx = np.arange(n_fft)[:, None] + hop * np.arange(n_frames)[None, :]
+    frames = yp[idx]                                   # [n_fft, T]
+    out = np.fft.rfft(w[:, None] * frames, axis=0)     # float64 product -> complex128
+    cdtype = np.complex64 if y.dtype == np.float32 else np.complex128
+    return out.astype(cdtype)
+
+
+def lr_istft(S, hop_length=None, n_fft=None, **_):
+    """librosa.istft(S, hop_length) (center=True, hann, length=None)."""
+    S = np.asarray(S)
+    n_fft = n_fft or 2 * (S.shape[0] - 1)
+    hop = hop_length if hop_length is not None else n_fft // 4
+    T = S.shape[1]
+    w = hann_periodic(n_fft)
+    rdtype = np.float32 if S.dtype == np.complex64 else np.float64
+    frames = np.fft.irfft(S, n=n_fft, axis=0) * w[:, None]
+    n = n_fft + hop * (T - 1)
+    y = np.zeros(n, dtype=rdtype)
+    ss = np.zeros(n, dtype=rdtype)
+    wsq = (w ** 2).astype(rdtype)
+    for t in range(T):
+        y[t * hop: t * hop + n_fft] += frames[:, t].astype(rdtype)
+        ss[t * hop: t * hop + n_fft] += wsq
+    nz = ss > np.finfo(rdtype).tiny
+    y[nz] /= ss[nz]
+    return y[n_fft // 2: n_fft // 2 + hop * (T - 1)]
+
+
+def lr_resample(y, orig_sr=None, target_sr=None, res_type="polyphase", axis=-1, **_):
+    """librosa.resample(..., res_type="polyphase") (see the header for the sinc_* types)."""
+    if orig_sr == target_sr:
+        return y
+    ratio = float(target_sr) / orig_sr
+    n_samples = int(np.ceil(y.shape[axis] * ratio))
+    g = gcd(int(orig_sr), int(target_sr))
+    y_hat = scipy.signal.resample_poly(y, int(target_sr) // g, int(orig_sr) // g, axis=axis)
+    n = y_hat.shape[axis]
+    if n > n_samples:
+        sl = [slice(None)] * y_hat.ndim
+        sl[axis] = slice(0, n_samples)
+        y_hat = y_hat[tuple(sl)]
+    elif n < n_samples:
+        pw = [(0, 0)] * y_hat.ndim
+        pw[axis] = (0, n_samples - n)
+        y_hat = np.pad(y_hat, pw)
+    return np.asarray(y_hat, dtype=y.dtype)
+
+
+# --------------------------------------------------------------------------
+# model parameters (model_param_init.py:48-71)
+# --------------------------------------------------------------------------
+class ModelParams:
+    def __init__(self, param: dict):
+        self.param = dict(param)
+        for k in ("mid_side", "mid_side_b", "mid_side_b2", "stereo_w", "stereo_n", "reverse"):
+            self.param.setdefault(k, False)
+        if "n_bins" in self.param:
+            self.param["bins"] = self.param["n_bins"]
+
+    @staticmethod
+    def from_json(path: str) -> "ModelParams":
+        def int_keys(pairs):
+            return {(int(k) if k.isdigit() else k): v for k, v in pairs}
+        with open(path) as f:
+            return ModelParams(json.loads(f.read(), object_pairs_hook=int_keys))
+
+
+def small_params() -> ModelParams:
+    """A 3-band layout with the structure of 4band_44100.json scaled down (bins 96, sr 8000)."""
+    return ModelParams({
+        "bins": 96, "unstable_bins": 2, "reduction_bins": 80,
+        "band": {
+            1: {"sr": 2000, "hl": 16, "n_fft": 128, "crop_start": 0, "crop_stop": 30, "lpf_start": 12, "lpf_stop": 24,
+                "res_type": "polyphase"},
+            2: {"sr": 4000, "hl": 32, "n_fft": 64, "crop_start": 8, "crop_stop": 30, "hpf_start": 12, "hpf_stop": 6,
+                "lpf_start": 22, "lpf_stop": 30, "res_type": "polyphase"},
+            3: {"sr": 8000, "hl": 64, "n_fft": 96, "crop_start": 4, "crop_stop": 48, "hpf_start": 10, "hpf_stop": 6,
+                "res_type": "polyphase"},
+        },
+        "sr": 8000, "pre_filter_start": 90, "pre_filter_stop": 96})
+
+
+# --------------------------------------------------------------------------
+# analysis (vr_separator.py:255-291, spec_utils.py:250-312)
+# --------------------------------------------------------------------------
+def wave_to_spectrogram(wave, hop_length, n_fft, mp: ModelParams):
+    if mp.param["reverse"]:
+        l, r = np.flip(wave[0]), np.flip(wave[1])
+    elif mp.param["mid_side"]:
+        l, r = np.add(wave[0], wave[1]) / 2, np.subtract(wave[0], wave[1])
+    elif mp.param["mid_side_b2"]:
+        l, r = np.add(wave[1], wave[0] * 0.5), np.subtract(wave[0], wave[1] * 0.5)
+    else:
+        l, r = wave[0], wave[1]
+    return np.asarray([lr_stft(np.ascontiguousarray(l), n_fft, hop_length), lr_stft(np.ascontiguousarray(r), n_fft, hop_length)])
+
+
+def combine_spectrograms(specs: dict, mp: ModelParams):
+    l = min(specs[i].shape[2] for i in specs)
+    spec_c = np.zeros((2, mp.param["bins"] + 1, l), dtype=np.complex64)
+    offset = 0
+    bands_n = len(mp.param["band"])
+    for d in range(1, bands_n + 1):
+        bp = mp.param["band"][d]
+        h = bp["crop_stop"] - bp["crop_start"]
+        spec_c[:, offset:offset + h, :l] = specs[d][:, bp["crop_start"]:bp["crop_stop"], :l]
+        offset += h
+    if offset > mp.param["bins"]:
+        raise ValueError("Too much bins")
+    if mp.param["pre_filter_start"] > 0:
+        if bands_n == 1:
+            spec_c = fft_lp_filter(spec_c, mp.param["pre_filter_start"], mp.param["pre_filter_stop"])
+        else:
+            gp = 1
+            for b in range(mp.param["pre_filter_start"] + 1, mp.param["pre_filter_stop"]):
+                g = math.pow(10, -(b - mp.param["pre_filter_start"]) * (3.5 - gp) / 20.0)
+                gp = g
+                spec_c[:, b, :] *= g
+    return spec_c
+
+
+def loading_mix(wave: np.ndarray, mp: ModelParams):
+    """wave = librosa.load(file, sr=band[N].sr, mono=False) as float32 [2, n] (decode stays with the reference)."""
+    bands_n = len(mp.param["band"])
+    X_wave, X_spec_s = {}, {}
+    for d in range(bands_n, 0, -1):
+        bp = mp.param["band"][d]
+        if d == bands_n:
+            X_wave[d] = np.asarray(wave, np.float32)
+        else:
+            X_wave[d] = lr_resample(X_wave[d + 1], orig_sr=mp.param["band"][d + 1]["sr"], target_sr=bp["sr"], res_type=bp["res_type"])
+        X_spec_s[d] = wave_to_spectrogram(X_wave[d], bp["hl"], bp["n_fft"], mp)
+    return combine_spectrograms(X_spec_s, mp)
+
+
+def fft_lp_filter(spec, bin_start, bin_stop):
+    g = 1.0
+    for b in range(bin_start, bin_stop):
+        g -= 1 / (bin_stop - bin_start)
+        spec[:, b, :] = g * spec[:, b, :]
+    spec[:, bin_stop:, :] *= 0
+    return spec
+
+
+def fft_hp_filter(spec, bin_start, bin_stop):
+    g = 1.0
+    for b in range(bin_start, bin_stop, -1):
+        g -= 1 / (bin_start - bin_stop)
+        spec[:, b, :] = g * spec[:, b, :]
+    spec[:, 0:bin_stop + 1, :] *= 0
+    return spec
+
+
+# --------------------------------------------------------------------------
+# synthesis (spec_utils.py:315-396), polyphase chain
+# --------------------------------------------------------------------------
+def spectrogram_to_wave(spec, hop_length, mp: ModelParams):
+    wl, wr = lr_istft(spec[0], hop_length), lr_istft(spec[1], hop_length)
+    if mp.param["reverse"]:
+        return np.asarray([np.flip(wl), np.flip(wr)])
+    if mp.param["mid_side"]:
+        return np.asarray([np.add(wl, wr / 2), np.subtract(wl, wr / 2)])
+    if mp.param["mid_side_b2"]:
+        return np.asarray([np.add(wr / 1.25, 0.4 * wl), np.subtract(wl / 1.25, 0.4 * wr)])
+    return np.asarray([wl, wr])
+
+
+def cmb_spectrogram_to_wave(spec_m, mp: ModelParams, res_type="polyphase"):
+    bands_n = len(mp.param["band"])
+    offset = 0
+    wave = None
+    for d in range(1, bands_n + 1):
+        bp = mp.param["band"][d]
+        spec_s = np.zeros((2, bp["n_fft"] // 2 + 1, spec_m.shape[2]), dtype=complex)
+        h = bp["crop_stop"] - bp["crop_start"]
+        spec_s[:, bp["crop_start"]:bp["crop_stop"], :] = spec_m[:, offset:offset + h, :]
+        offset += h
+        if d == bands_n:
+            if bp.get("hpf_start", 0) > 0:
+                spec_s = fft_hp_filter(spec_s, bp["hpf_start"], bp["hpf_stop"] - 1)
+            if bands_n == 1:
+                wave = spectrogram_to_wave(spec_s, bp["hl"], mp)
+            else:
+                wave = np.add(wave, spectrogram_to_wave(spec_s, bp["hl"], mp))
+        else:
+            sr = mp.param["band"][d + 1]["sr"]
+            if d == 1:
+                spec_s = fft_lp_filter(spec_s, bp["lpf_start"], bp["lpf_stop"])
+                wave = lr_resample(spectrogram_to_wave(spec_s, bp["hl"], mp), orig_sr=bp["sr"], target_sr=sr, res_type=res_type)
+            else:
+                spec_s = fft_hp_filter(spec_s, bp["hpf_start"], bp["hpf_stop"] - 1)
+                spec_s = fft_lp_filter(spec_s, bp["lpf_start"], bp["lpf_stop"])
+                wave2 = np.add(wave, spectrogram_to_wave(spec_s, bp["hl"], mp))
+                wave = lr_resample(wave2, orig_sr=bp["sr"], target_sr=sr, res_type=res_type)
+    return wave
+
+
+# --------------------------------------------------------------------------
+# mask post-processing (spec_utils.py:180-222, 472-492)
+# --------------------------------------------------------------------------
+def adjust_aggr(mask, is_non_accom_stem, aggressiveness):
+    aggr = aggressiveness["value"] * 2
+    if aggr != 0:
+        if is_non_accom_stem:
+            aggr = 1 - aggr
+        aggr = [aggr, aggr]
+        if aggressiveness.get("aggr_correction") is not None:
+            aggr[0] += aggressiveness["aggr_correction"]["left"]
+            aggr[1] += aggressiveness["aggr_correction"]["right"]
+        sb = aggressiveness["split_bin"]
+        for ch in range(2):
+            mask[ch, :sb] = np.power(mask[ch, :sb], 1 + aggr[ch] / 3)
+            mask[ch, sb:] = np.power(mask[ch, sb:], 1 + aggr[ch])
+    return mask
+
+
+def artifact_weight(frame_min: np.ndarray, n_frames: int, thres=0.01, min_range=64, fade_size=32) -> np.ndarray:
+    """The per-frame weight of merge_artifacts (spec_utils.py:187-211) from min over (channel, bin) of the mask.
+    Raises like the reference would inside its try block (which then leaves the mask unchanged)."""
+    idx = np.where(frame_min > thres)[0]
+    start_idx = np.insert(idx[np.where(np.diff(idx) != 1)[0] + 1], 0, idx[0])
+    end_idx = np.append(idx[np.where(np.diff(idx) != 1)[0]], idx[-1])
+    artifact_idx = np.where(end_idx - start_idx > min_range)[0]
+    weight = np.zeros(n_frames, dtype=frame_min.dtype)
+    if len(artifact_idx) > 0:
+        start_idx = start_idx[artifact_idx]
+        end_idx = end_idx[artifact_idx]
+        old_e = None
+        for s, e in zip(start_idx, end_idx):
+            if old_e is not None and s - old_e < fade_size:
+                s = old_e - fade_size * 2
+            if s != 0:
+                weight[s:s + fade_size] = np.linspace(0, 1, fade_size)
+            else:
+                s -= fade_size
+            if e != n_frames:
+                weight[e - fade_size:e] = np.linspace(1, 0, fade_size)
+            else:
+                e += fade_size
+            weight[s + fade_size:e - fade_size] = 1
+            old_e = e
+    return weight
+
+
+def merge_artifacts(y_mask, thres=0.01, min_range=64, fade_size=32):
+    try:
+        w = artifact_weight(y_mask.min(axis=(0, 1)), y_mask.shape[2], thres, min_range, fade_size)
+    except Exception:
+        return y_mask
+    v_mask = 1 - y_mask
+    y_mask += w[None, None, :] * v_mask
+    return y_mask
+
+
+# --------------------------------------------------------------------------
+# nets.py / layers.py, functional from a state_dict
+# --------------------------------------------------------------------------
+ARCH_SP = (31191, 33966, 129605)
+ARCH_HP = (123821, 123812)
+ARCH_HP2 = (537238, 537227)
+
+
+def capacity(arch: int):
+    if arch in ARCH_SP:
+        return [(2, 16), (2, 16), (18, 8, 1, 1, 0), (8, 16), (34, 16, 1, 1, 0), (16, 32), (32, 2, 1), (16, 2, 1), (16, 2, 1)]
+    if arch in ARCH_HP:
+        return [(2, 32), (2, 32), (34, 16, 1, 1, 0), (16, 32), (66, 32, 1, 1, 0), (32, 64), (64, 2, 1), (32, 2, 1), (32, 2, 1)]
+    if arch in ARCH_HP2:
+        return [(2, 64), (2, 64), (66, 32, 1, 1, 0), (32, 64), (130, 64, 1, 1, 0), (64, 128), (128, 2, 1), (64, 2, 1), (64, 2, 1)]
+    raise ValueError(f"unknown VR architecture size {arch}")
+
+
+def aspp_branches(arch: int) -> int:
+    return 6 if arch == 129605 else (7 if arch in (537238, 537227, 33966) else 5)
+
+
+def make_vr_state(arch: int, seed: int = 0, cap=None) -> dict:
+    """Seeded synthetic weights with CascadedASPPNet's state_dict names and shapes; `cap` overrides the capacity table
+    (small test nets)."""
+    gen = torch.Generator().manual_seed(seed)
+    sd: dict = {}
+    cap = cap or capacity(arch)
+
+    def cba(p, nin, nout, k):
+        sd[p + ".conv.0.weight"] = torch.randn(nout, nin, k, k, generator=gen) * math.sqrt(2.0 / (nin * k * k))
+        bn(p + ".conv.1", nout)
+
+    def bn(p, c):
+        sd[p + ".weight"] = 0.8 + 0.4 * torch.rand(c, generator=gen)
+        sd[p + ".bias"] = 0.1 * torch.randn(c, generator=gen)
+        sd[p + ".running_mean"] = 0.1 * torch.randn(c, generator=gen)
+        sd[p + ".running_var"] = 0.6 + 0.8 * torch.rand(c, generator=gen)
+        sd[p + ".num_batches_tracked"] = torch.tensor(0.0)
+
+    def sep(p, nin, nout):
+        sd[p + ".conv.0.weight"] = torch.randn(nin, 1, 3, 3, generator=gen) * math.sqrt(2.0 / 9)
+        sd[p + ".conv.1.weight"] = torch.randn(nout, nin, 1, 1, generator=gen) * math.sqrt(2.0 / nin)
+        bn(p + ".conv.2", nout)
+
+    def base(p, nin, ch):
+        chans = [nin, ch, ch * 2, ch * 4, ch * 8] + ([ch * 16] if arch == 129605 else [])
+        for i in range(1, len(chans)):
+            cba(f"{p}.enc{i}.conv1", chans[i - 1], chans[i], 3)
+            cba(f"{p}.enc{i}.conv2", chans[i], chans[i], 3)
+        ca = chans[-1]
+        cba(f"{p}.aspp.conv1.1", ca, ca, 1)
+        cba(f"{p}.aspp.conv2", ca, ca, 1)
+        nb = aspp_branches(arch)
+        for j in range(3, 6):
+            sep(f"{p}.aspp.conv{j}", ca, ca)
+        if nb >= 6:
+            sep(f"{p}.aspp.conv6", ca, ca)
+        if nb == 7:     # conv6 and conv7 are the same module (layers.py:236-243)
+            for k in [k for k in sd if k.startswith(f"{p}.aspp.conv6.")]:
+                sd[k.replace(".conv6.", ".conv7.")] = sd[k]
+        cba(f"{p}.aspp.bottleneck.0", ca * nb, ca * 2, 1)
+        if arch == 129605:
+            cba(f"{p}.dec5.conv", ch * (16 + 32), ch * 16, 3)
+        cba(f"{p}.dec4.conv", ch * (8 + 16), ch * 8, 3)
+        cba(f"{p}.dec3.conv", ch * (4 + 8), ch * 4, 3)
+        cba(f"{p}.dec2.conv", ch * (2 + 4), ch * 2, 3)
+        cba(f"{p}.dec1.conv", ch * (1 + 2), ch, 3)
+
+    base("stg1_low_band_net", *cap[0])
+    base("stg1_high_band_net", *cap[1])
+    cba("stg2_bridge", cap[2][0], cap[2][1], 1)
+    base("stg2_full_band_net", *cap[3])
+    cba("stg3_bridge", cap[4][0], cap[4][1], 1)
+    base("stg3_full_band_net", *cap[5])
+    sd["out.weight"] = torch.randn(cap[6][1], cap[6][0], 1, 1, generator=gen) * math.sqrt(1.0 / cap[6][0])
+    sd["aux1_out.weight"] = torch.randn(cap[7][1], cap[7][0], 1, 1, generator=gen) * 0.1
+    sd["aux2_out.weight"] = torch.randn(cap[8][1], cap[8][0], 1, 1, generator=gen) * 0.1
+    return {k: v.float().contiguous() for k, v in sd.items()}
+
+
+def _cba(x, sd, p, stride=1, pad=1, dilation=1, leaky=False):
+    y = F.conv2d(x, sd[p + ".conv.0.weight"], None, stride, pad, dilation)
+    y = F.batch_norm(y, sd[p + ".conv.1.running_mean"], sd[p + ".conv.1.running_var"], sd[p + ".conv.1.weight"],
+                     sd[p + ".conv.1.bias"], False, 0.0, 1e-5)
+    return F.leaky_relu(y, 0.01) if leaky else F.relu(y)
+
+
+def _sep(x, sd, p, dilation):
+    y = F.conv2d(x, sd[p + ".conv.0.weight"], None, 1, dilation, dilation, groups=x.shape[1])
+    y = F.conv2d(y, sd[p + ".conv.1.weight"])
+    y = F.batch_norm(y, sd[p + ".conv.2.running_mean"], sd[p + ".conv.2.running_var"], sd[p + ".conv.2.weight"],
+                     sd[p + ".conv.2.bias"], False, 0.0, 1e-5)
+    return F.relu(y)
+
+
+def _base(x, sd, p, arch, dilations=(4, 8, 16)):
+    """BaseASPPNet.__call__ (nets.py:46-62)."""
+    skips = []
+    n_enc = 5 if arch == 129605 else 4
+    h = x
+    for i in range(1, n_enc + 1):
+        s = _cba(h, sd, f"{p}.enc{i}.conv1", 1, 1, leaky=True)
+        h = _cba(s, sd, f"{p}.enc{i}.conv2", 2, 1, leaky=True)
+        skips.append(s)
+    a = f"{p}.aspp"
+    _, _, hh, ww = h.shape
+    f1 = F.interpolate(_cba(F.adaptive_avg_pool2d(h, (1, None)), sd, a + ".conv1.1", 1, 0), size=(hh, ww), mode="bilinear",
+                       align_corners=True)
+    feats = [f1, _cba(h, sd, a + ".conv2", 1, 0)]
+    feats += [_sep(h, sd, a + f".conv{j}", dilations[j - 3]) for j in (3, 4, 5)]
+    nb = aspp_branches(arch)
+    if nb >= 6:
+        feats.append(_sep(h, sd, a + ".conv6", dilations[2]))
+    if nb == 7:
+        feats.append(_sep(h, sd, a + ".conv7", dilations[2]))
+    h = _cba(torch.cat(feats, dim=1), sd, a + ".bottleneck.0", 1, 0)
+    for i in range(n_enc, 0, -1):
+        h = F.interpolate(h, scale_factor=2, mode="bilinear", align_corners=True)
+        s = skips[i - 1]
+        d = s.shape[3] - h.shape[3]
+        if d < 0:
+            raise ValueError("h1_shape[3] must be greater than h2_shape[3]")
+        if d:
+            st = d // 2
+            s = s[:, :, :, st:st + h.shape[3]]
+        h = _cba(torch.cat([h, s], dim=1), sd, f"{p}.dec{i}.conv", 1, 1)
+    return h
+
+
+@torch.no_grad()
+def cascaded_forward(x, sd: dict, arch: int, n_fft_bins: int):
+    """CascadedASPPNet.forward, eval (nets.py:132-161): [B, 2, bins+1, W] -> mask [B, 2, bins+1, W]."""
+    x = torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32)
+    max_bin = n_fft_bins // 2
+    out_bin = n_fft_bins // 2 + 1
+    x = x[:, :, :max_bin]
+    bw = x.shape[2] // 2
+    aux1 = torch.cat([_base(x[:, :, :bw], sd, "stg1_low_band_net", arch), _base(x[:, :, bw:], sd, "stg1_high_band_net", arch)], dim=2)
+    h = torch.cat([x, aux1], dim=1)
+    aux2 = _base(_cba(h, sd, "stg2_bridge", 1, 0), sd, "stg2_full_band_net", arch)
+    h = torch.cat([x, aux1, aux2], dim=1)
+    h = _base(_cba(h, sd, "stg3_bridge", 1, 0), sd, "stg3_full_band_net", arch)
+    mask = torch.sigmoid(F.conv2d(h, sd["out.weight"]))
+    mask = F.pad(mask, (0, 0, 0, out_bin - mask.shape[2]), mode="replicate")
+    return mask.numpy()
+
+
+def predict_mask(x, sd, arch, n_fft_bins, offset=128):
+    m = cascaded_forward(x, sd, arch, n_fft_bins)
+    return m[:, :, :, offset:-offset] if offset > 0 else m
+
+
+# --------------------------------------------------------------------------
+# inference_vr (vr_separator.py:293-366) and the whole array path
+# --------------------------------------------------------------------------
+def make_padding(width, cropsize, offset):
+    left = offset
+    roi_size = cropsize - offset * 2
+    if roi_size == 0:
+        roi_size = cropsize
+    right = roi_size - (width % roi_size) + left
+    return left, right, roi_size
+
+
+def inference_vr(X_spec, mask_fn, window_size, offset, batch_size, aggressiveness, is_non_accom_stem=False, enable_tta=False,
+                 enable_post_process=False, post_process_threshold=0.2):
+    def _execute(X_mag_pad, roi_size):
+        patches = (X_mag_pad.shape[2] - 2 * offset) // roi_size
+        ds = np.asarray([X_mag_pad[:, :, i * roi_size: i * roi_size + window_size] for i in range(patches)])
+        mask = []
+        for i in range(0, patches, batch_size):
+            pred = mask_fn(ds[i:i + batch_size])
+            if not pred.shape[3] > 0:
+                raise ValueError("Window size error: h1_shape[3] must be greater than h2_shape[3]")
+            mask.append(np.concatenate(pred, axis=2))
+        if len(mask) == 0:
+            raise ValueError("Window size error: h1_shape[3] must be greater than h2_shape[3]")
+        return np.concatenate(mask, axis=2)
+
+    X_mag, X_phase = np.abs(X_spec), np.angle(X_spec)
+    n_frame = X_mag.shape[2]
+    pad_l, pad_r, roi_size = make_padding(n_frame, window_size, offset)
+    X_mag_pad = np.pad(X_mag, ((0, 0), (0, 0), (pad_l, pad_r)), mode="constant")
+    X_mag_pad /= X_mag_pad.max()
+    mask = _execute(X_mag_pad, roi_size)
+    if enable_tta:
+        pad_l += roi_size // 2
+        pad_r += roi_size // 2
+        X_mag_pad = np.pad(X_mag, ((0, 0), (0, 0), (pad_l, pad_r)), mode="constant")
+        X_mag_pad /= X_mag_pad.max()
+        mask_tta = _execute(X_mag_pad, roi_size)[:, :, roi_size // 2:]
+        mask = (mask[:, :, :n_frame] + mask_tta[:, :, :n_frame]) * 0.5
+    else:
+        mask = mask[:, :, :n_frame]
+    mask = adjust_aggr(mask, is_non_accom_stem, aggressiveness)
+    if enable_post_process:
+        mask = merge_artifacts(mask, thres=post_process_threshold)
+    y_spec = mask * X_mag * np.exp(1.0j * X_phase)
+    v_spec = (1 - mask) * X_mag * np.exp(1.0j * X_phase)
+    return y_spec, v_spec
+
+
+def vr_separate(wave, sd, arch, mp: ModelParams, window_size=512, batch_size=1, aggression=5, is_non_accom_stem=False,
+                enable_tta=False, enable_post_process=False, post_process_threshold=0.2, offset=128):
+    """VRSeparator.separate on arrays (vr_separator.py:168-236): wave [2, n] at mp sr -> (primary [n', 2], secondary)."""
+    aggr = {"value": float(int(aggression) / 100), "split_bin": mp.param["band"][1]["crop_stop"],
+            "aggr_correction": mp.param.get("aggr_correction")}
+    X_spec = loading_mix(wave, mp)
+    nb = mp.param["bins"] * 2
+    y_spec, v_spec = inference_vr(X_spec, lambda x: predict_mask(x, sd, arch, nb, offset), window_size, offset, batch_size, aggr,
+                                  is_non_accom_stem, enable_tta, enable_post_process, post_process_threshold)
+    y_spec = np.nan_to_num(y_spec, nan=0.0, posinf=0.0, neginf=0.0)
+    v_spec = np.nan_to_num(v_spec, nan=0.0, posinf=0.0, neginf=0.0)
+    return cmb_spectrogram_to_wave(y_spec, mp).T, cmb_spectrogram_to_wave(v_spec, mp).T
+
+
+def params_path(name: str) -> str:
+    return os.path.join("/root/reference/audio_separator/separator/uvr_lib_v5/vr_network/modelparams", name + ".json")
