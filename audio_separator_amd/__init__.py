@@ -12,3 +12,4 @@ from .mdx import STFT, MDXDemixer  # noqa: E402,F401
 from .onnx_reader import convtdf_from_onnx, OnnxFormatError  # noqa: E402,F401
 from .mdxc import MDXCDemixer  # noqa: E402,F401
 from .demucs import DemucsDemixer, htconfig_from_kwargs  # noqa: E402,F401
+from .vr import VRDemixer, load_model_params, model_capacity  # noqa: E402,F401

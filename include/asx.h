@@ -263,6 +263,56 @@ int asx_ht_demix(asx_engine *e, const float *mix_host, int64_t n_samples, int32_
 int asx_ht_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t shifts, const int64_t *offsets,
                      double overlap, uint32_t flags, float *out_dev, void *stream);
 
+/* ---- VR architecture -----------------------------------------------------------------
+ * Replaces nets.determine_model_capacity(...) + load_state_dict (architectures/vr_separator.py:168-176,
+ * uvr_lib_v5/vr_network/nets.py:65-93), VRSeparator.loading_mix (:255-291), inference_vr (:293-366) and spec_to_wav
+ * (:368-375) with the spec_utils functions they call (wave_to_spectrogram, combine_spectrograms, preprocess,
+ * make_padding, adjust_aggr, merge_artifacts, cmb_spectrogram_to_wave, spectrogram_to_wave, fft_lp/hp_filter).
+ * band[d-1] = modelparams JSON "band"[d] (uvr_lib_v5/vr_network/modelparams/ *.json); resampling between bands is the
+ * polyphase path (scipy.signal.resample_poly) -- the reference's behaviour on ARM / MPS (spec_utils.py:33-38).
+ * Not built: VR 5.1 models (nets_new.CascadedNet), high_end_process. */
+typedef struct asx_vr_band {
+  int32_t sr, hl, n_fft, crop_start, crop_stop, hpf_start, hpf_stop, lpf_start, lpf_stop;
+} asx_vr_band;
+typedef struct asx_vr_config {
+  int32_t bins, n_bands, pre_filter_start, pre_filter_stop;
+  int32_t channel_mode;   /* 0 stereo, 1 mid_side, 2 mid_side_b2, 3 reverse (model_param_init.py:62-65) */
+  int32_t arch;           /* nn_arch_size (vr_separator.py:161-164) */
+  int32_t cap[6];         /* stage-1 width, stage-2 bridge out, stage-2 width, stage-3 bridge out, stage-3 width, 0 (nets.py:74-86) */
+  int32_t window_size;    /* arch_config["window_size"] */
+  int32_t offset;         /* CascadedASPPNet.offset = 128 */
+  int32_t max_batch;      /* patches per forward batch (0 = 4); no effect on the result */
+  asx_vr_band band[8];
+} asx_vr_config;
+typedef struct asx_vr_params {
+  float aggr_value;        /* aggressiveness["value"] = int(aggression) / 100 */
+  int32_t split_bin;       /* band[1].crop_stop */
+  int32_t is_non_accom;    /* primary stem in CommonSeparator.NON_ACCOM_STEMS */
+  int32_t has_corr;
+  float corr_left, corr_right;   /* aggr_correction */
+  int32_t enable_tta, enable_post_process;
+  float post_thres;
+} asx_vr_params;
+int asx_vr_begin(asx_engine *e, const asx_vr_config *cfg);
+int asx_vr_commit(asx_engine *e);
+double asx_vr_flops(const asx_engine *e);   /* 2*MAC of the net on one window */
+/* frames of the combined spectrogram and length of the separated waves for n_samples input samples */
+int asx_vr_plan(const asx_engine *e, int64_t n_samples, int32_t *n_frames, int64_t *n_out);
+/* CascadedASPPNet.forward, eval (nets.py:132-161): x [B, 2, bins+1, window_size] -> mask, same shape. */
+int asx_vr_forward(asx_engine *e, const float *x_host, int32_t batch, float *out_host);
+/* loading_mix: wave [2, n] (float32 at the top band's rate) -> X_spec [2, n_frames, bins+1] complex64 (re, im pairs;
+ * note: frames outer, bins inner -- the transpose of the reference's [2, bins+1, n_frames]). */
+int asx_vr_analysis(asx_engine *e, const float *wave_host, int64_t n_samples, float *spec_host);
+/* the array part of VRSeparator.separate: wave [2, n] -> spec_to_wav(y_spec) [2, n_out], spec_to_wav(v_spec) [2, n_out]
+ * (either output may be NULL). */
+int asx_vr_separate(asx_engine *e, const float *wave_host, int64_t n_samples, const asx_vr_params *params, float *primary_host,
+                    float *secondary_host);
+int asx_vr_separate_dev(asx_engine *e, const float *wave_dev, int64_t n_samples, const asx_vr_params *params, float *primary_dev,
+                        float *secondary_dev, void *stream);
+
+/* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host. */
+int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel);
+
 /* ---- stage hooks (host buffers; mirror the reference's own test surface) ---- */
 /* STFT.__call__ (stft.py:20): wave [B,2,C] -> spec [B,4,dim_f,C/hop+1]. */
 int asx_stft(asx_engine *e, const float *wave_host, int32_t batch, int64_t n_time, float *spec_host);

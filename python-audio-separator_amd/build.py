@@ -6,8 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "asx.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("kernels_fft.h", "kernels_net.h", "kernels_rof.h", "kernels_ht.h",
-                                                         "engine_v3.h", "engine_rof.h", "engine_ht.h")] + \
+DEPS = [SRC] + sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")) + \
        [os.path.join(os.path.dirname(HERE), "include", "asx.h")]
 OUT = os.path.join(HERE, "libasx.so")
 

@@ -22,6 +22,7 @@
 #include "kernels_net.h"
 #include "kernels_rof.h"
 #include "kernels_ht.h"
+#include "kernels_vr.h"
 
 using namespace asx;
 
@@ -115,12 +116,14 @@ struct ProfRec {
 struct V3Net;
 struct RofNet;
 struct HtNet;
+struct VrNet;
 
 struct asx_engine {
   int device = 0;
   V3Net *v3 = nullptr;
   RofNet *rof = nullptr;
   HtNet *ht = nullptr;
+  VrNet *vr = nullptr;
   asx_mdx_config cfg{};
   FftPlan plan{};
   DevBuf d_window, d_tw, d_env;  // env for T = segment_size
@@ -790,6 +793,7 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
 static void v3_destroy(V3Net *n);
 static void rof_destroy(RofNet *n);
 static void ht_destroy(HtNet *n);
+static void vr_destroy(VrNet *n);
 static void free_conv(ConvLayer &L) {
   L.w.release();
   L.b.release();
@@ -839,6 +843,7 @@ void asx_engine_destroy(asx_engine *e) {
   if (e->v3) v3_destroy(e->v3);
   if (e->rof) rof_destroy(e->rof);
   if (e->ht) ht_destroy(e->ht);
+  if (e->vr) vr_destroy(e->vr);
   delete e;
 }
 
@@ -994,9 +999,12 @@ double asx_net_flops(const asx_engine *e, int32_t batch) {
   return fl * batch;
 }
 
+}  // extern "C" (the engine headers below define templates)
 #include "engine_v3.h"
 #include "engine_rof.h"
 #include "engine_ht.h"
+#include "engine_vr.h"
+extern "C" {
 
 // ---- plan ------------------------------------------------------------------
 int asx_plan_query(const asx_engine *e, int64_t N, uint32_t flags, asx_plan *out) {
@@ -1792,6 +1800,155 @@ int asx_ht_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t shifts
   CHK(dout.ensure((size_t)S * 2 * N * 4));
   CHK(asx_ht_demix_dev(e, dm.f(), N, shifts, offsets, overlap, flags, dout.f(), nullptr));
   CHK(to_host(out_host, dout, (size_t)S * 2 * N));
+  return ASX_OK;
+}
+
+// ---- VR ------------------------------------------------------------------------------
+int asx_vr_begin(asx_engine *e, const asx_vr_config *cfg) {
+  REQUIRE(e && cfg, "asx_vr_begin: null argument");
+  REQUIRE(cfg->n_bands >= 1 && cfg->n_bands <= 8 && cfg->bins >= 32, "bad band layout");
+  REQUIRE(cfg->channel_mode >= 0 && cfg->channel_mode <= 3, "bad channel_mode");
+  for (int i = 0; i < 5; ++i) REQUIRE(cfg->cap[i] >= 4 && cfg->cap[i] % 4 == 0, "net widths must be multiples of 4");
+  REQUIRE(cfg->window_size >= 16 && cfg->offset >= 0, "bad window_size / offset");
+  for (int d = 0; d < cfg->n_bands; ++d)
+    REQUIRE(cfg->band[d].sr > 0 && cfg->band[d].hl > 0 && cfg->band[d].n_fft >= 8 && cfg->band[d].n_fft % 2 == 0, "band %d: bad sr / hl / n_fft",
+            d + 1);
+  if (!e->vr) e->vr = new VrNet();
+  vr_free(*e->vr);
+  e->vr->cfg = *cfg;
+  e->vr->begun = true;
+  e->host_tensors.clear();
+  e->net_begun = true;
+  return ASX_OK;
+}
+
+int asx_vr_commit(asx_engine *e) {
+  REQUIRE(e, "asx_vr_commit: null engine");
+  if (!e->vr || !e->vr->begun) {
+    set_err("asx_vr_commit before asx_vr_begin");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  const int rc = vr_commit(e);
+  e->host_tensors.clear();
+  return rc;
+}
+
+double asx_vr_flops(const asx_engine *e) { return (e && e->vr && e->vr->ready) ? vr_flops_patch(e) : 0.0; }
+
+#define VR_READY(fn)                                   \
+  do {                                                 \
+    if (!e->vr || !e->vr->ready) {                     \
+      set_err(fn ": weights not committed");           \
+      return ASX_ERR_STATE;                            \
+    }                                                  \
+  } while (0)
+
+int asx_vr_plan(const asx_engine *e, int64_t n_samples, int32_t *n_frames, int64_t *n_out) {
+  REQUIRE(e && n_frames && n_out && n_samples > 0, "asx_vr_plan: bad argument");
+  VR_READY("asx_vr_plan");
+  int T;
+  CHK(vr_plan(*e->vr, n_samples, &T, n_out));
+  *n_frames = T;
+  return ASX_OK;
+}
+
+int asx_vr_forward(asx_engine *e, const float *x_host, int32_t B, float *out_host) {
+  REQUIRE(e && x_host && out_host && B > 0, "asx_vr_forward: bad argument");
+  VR_READY("asx_vr_forward");
+  HIPCHK(hipSetDevice(e->device));
+  VrNet &n = *e->vr;
+  const int W = n.cfg.window_size;
+  const size_t numel = (size_t)B * 2 * n.nb1 * W;
+  DevBuf dx, dy;
+  BufGuard g{{&dx, &dy}};
+  CHK(to_dev(dx, x_host, numel));
+  CHK(dy.ensure(numel * 4));
+  CHK(vr_ensure_workspace(e, B));
+  const int64_t P = (int64_t)B * n.max_bin * W;
+  hipLaunchKernelGGL(vr_from_nchw_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, nullptr, dx.f(), n.nb1, n.max_bin, W, n.ctot,
+                     n.b.hc, P);
+  HIPCHK(hipGetLastError());
+  CHK(vr_net_dev(e, B, nullptr));
+  hipLaunchKernelGGL(vr_to_nchw_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, nullptr, n.b.mk, n.nb1, n.max_bin, W, dy.f(),
+                     (int64_t)numel);
+  HIPCHK(hipGetLastError());
+  CHK(to_host(out_host, dy, numel));
+  return ASX_OK;
+}
+
+int asx_vr_analysis(asx_engine *e, const float *wave_host, int64_t n_samples, float *spec_host) {
+  REQUIRE(e && wave_host && spec_host && n_samples > 0, "asx_vr_analysis: bad argument");
+  VR_READY("asx_vr_analysis");
+  HIPCHK(hipSetDevice(e->device));
+  VrNet &n = *e->vr;
+  int T;
+  int64_t n_out;
+  CHK(vr_plan(n, n_samples, &T, &n_out));
+  DevBuf dw;
+  BufGuard g{{&dw}};
+  CHK(to_dev(dw, wave_host, (size_t)2 * n_samples));
+  CHK(vr_analysis_dev(e, dw.f(), n_samples, T, nullptr));
+  CHK(to_host(spec_host, n.X, (size_t)2 * T * n.nb1 * 2));
+  return ASX_OK;
+}
+
+int asx_vr_separate_dev(asx_engine *e, const float *wave_dev, int64_t n_samples, const asx_vr_params *params, float *primary_dev,
+                        float *secondary_dev, void *stream) {
+  REQUIRE(e && wave_dev && params && n_samples > 0, "asx_vr_separate_dev: bad argument");
+  VR_READY("asx_vr_separate");
+  HIPCHK(hipSetDevice(e->device));
+  return vr_separate_dev(e, wave_dev, n_samples, params, primary_dev, secondary_dev, reinterpret_cast<hipStream_t>(stream));
+}
+
+int asx_vr_separate(asx_engine *e, const float *wave_host, int64_t n_samples, const asx_vr_params *params, float *primary_host,
+                    float *secondary_host) {
+  REQUIRE(e && wave_host && params && n_samples > 0, "asx_vr_separate: bad argument");
+  VR_READY("asx_vr_separate");
+  HIPCHK(hipSetDevice(e->device));
+  int T;
+  int64_t n_out;
+  CHK(vr_plan(*e->vr, n_samples, &T, &n_out));
+  DevBuf dw, dp, ds;
+  BufGuard g{{&dw, &dp, &ds}};
+  CHK(to_dev(dw, wave_host, (size_t)2 * n_samples));
+  if (primary_host) CHK(dp.ensure((size_t)2 * n_out * 4));
+  if (secondary_host) CHK(ds.ensure((size_t)2 * n_out * 4));
+  CHK(vr_separate_dev(e, dw.f(), n_samples, params, primary_host ? dp.f() : nullptr, secondary_host ? ds.f() : nullptr, nullptr));
+  if (primary_host) CHK(to_host(primary_host, dp, (size_t)2 * n_out));
+  if (secondary_host) CHK(to_host(secondary_host, ds, (size_t)2 * n_out));
+  return ASX_OK;
+}
+
+// debug hook: copy `numel` floats of a named engine workspace buffer to the host (tests / bring-up only)
+int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel) {
+  REQUIRE(e && name && host && numel > 0, "asx_debug_fetch: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  const float *src = nullptr;
+  const std::string nm(name);
+  if (e->vr && e->vr->ws_batch > 0) {
+    auto &b = e->vr->b;
+    if (nm == "vr.hc") src = b.hc;
+    else if (nm == "vr.y2") src = b.y2;
+    else if (nm == "vr.y3") src = b.y3;
+    else if (nm == "vr.h3") src = b.h3;
+    else if (nm == "vr.mk") src = b.mk;
+    else if (nm == "vr.cat") src = b.cat;
+    else if (nm == "vr.bn") src = b.bn;
+    else if (nm == "vr.pool") src = b.pool;
+    else if (nm == "vr.pool2") src = b.pool2;
+    else if (nm == "vr.tmp") src = b.tmp;
+    else if (nm.size() == 5 && nm.compare(0, 3, "vr.") == 0 && nm[4] >= '0' && nm[4] < '0' + (int)b.D.size()) {
+      const int i = nm[4] - '0';
+      src = nm[3] == 'D' ? b.D[i] : (nm[3] == 'E' ? b.E[i] : (nm[3] == 'O' ? b.O[i] : nullptr));
+    }
+  }
+  if (!src) {
+    set_err("asx_debug_fetch: unknown buffer '%s'", name);
+    return ASX_ERR_INVALID;
+  }
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host, src, (size_t)numel * 4, hipMemcpyDeviceToHost));
   return ASX_OK;
 }
 

@@ -414,6 +414,8 @@ struct HtGeom {
   int O = 1, I = 1, Cin = 0, ldc = 0;
   int KO = 1, KI = 1, DO = 1, DI = 1, PO = 0, PI = 0, SI = 1;
   int IR = 1;
+  int SO = 1, OR = 0;            // OR = 0: same as O
+  int64_t x_bs = 0, y_bs = 0;    // 0: dense
 };
 
 // y = epilogue(gather(x) @ W^T + b)
@@ -426,7 +428,7 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
   a.res = res;
   a.zeros = e->d_zeros.f();
   a.y = y;
-  a.M = rows_outer * q.IR;
+  a.M = rows_outer * q.IR;   // rows_outer = B * (output rows on the outer axis)
   a.N = g.n;
   a.K = g.k;
   a.O = q.O;
@@ -441,6 +443,10 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
   a.PI = q.PI;
   a.SI = q.SI;
   a.IR = q.IR;
+  a.SO = q.SO;
+  a.OR = q.OR ? q.OR : q.O;
+  a.x_bs = q.x_bs ? q.x_bs : (int64_t)q.O * q.I * q.ldc;
+  a.y_bs = q.y_bs ? q.y_bs : (int64_t)a.OR * q.IR * ldy;
   a.inv_cin = 1.0f / (float)q.Cin;
   a.mode = mode;
   a.act = act;

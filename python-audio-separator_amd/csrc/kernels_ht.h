@@ -25,6 +25,8 @@ struct GgArgs {
   int N, K;                     // K = KO*KI*Cin; w is [N, K] dense
   int O, I, Cin, ldc;           // input [B, O, I, ldc], Cin (% 4 == 0) channels used
   int KO, KI, DO, DI, PO, PI, SI;
+  int SO, OR;                   // outer-axis stride and output rows on the outer axis (OR = O when SO = 1)
+  int64_t x_bs, y_bs;           // floats between batch items of x / y (views into larger tensors)
   int IR;                       // rows per (b, o) line
   float inv_cin;
   int mode, act;
@@ -64,9 +66,9 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
     if (q < NXI && row < a.M) {
       const int64_t bo = row / a.IR;
       const int j = (int)(row - bo * a.IR);
-      const int o = (int)(bo % a.O);
-      xb[i] = (bo - o) * (int64_t)a.I * a.ldc;
-      xo[i] = o - a.PO;
+      const int oo = (int)(bo % a.OR);
+      xb[i] = (bo / a.OR) * a.x_bs;
+      xo[i] = oo * a.SO - a.PO;
       xi[i] = j * a.SI - a.PI;
     } else {
       xb[i] = 0;
@@ -150,12 +152,9 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
     const int64_t row = m0 + m * 16 + li;
     if (row >= a.M) continue;
     const int64_t rrow = a.res_mod > 0 ? row % a.res_mod : row;
-    int64_t bo = 0;
-    int j = 0;
-    if (a.mode == GG_CONVT) {
-      bo = row / a.IR;
-      j = (int)(row - bo * a.IR);
-    }
+    const int64_t bo = row / a.IR;
+    const int j = (int)(row - bo * a.IR);
+    const int64_t yrow = (bo / a.OR) * a.y_bs + ((bo % a.OR) * a.IR + j) * a.ldy;   // DENSE / GLU destination row
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
       const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
           o.x += r.x;
           o.y += r.y;
         }
-        *reinterpret_cast<float2 *>(a.y + row * a.ldy + c2) = o;
+        *reinterpret_cast<float2 *>(a.y + yrow + c2) = o;
       } else {
         f32x4 o;
         o.x = tdf_act(v.x, a.act);
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
           off = (bo * a.Iout + pos) * a.ldy + co;
           roff = (bo * a.Iout + pos) * a.ldr + co;
         } else {
-          off = row * a.ldy + col;
+          off = yrow + col;
           roff = rrow * a.ldr + col;
         }
         if (a.res != nullptr) o += *reinterpret_cast<const f32x4 *>(a.res + roff);

@@ -326,11 +326,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 // Fragments are fetched with ds_read_b128 (4 consecutive k per lane); the k
 // order inside a 16-wide step is permuted identically for both operands.
 // ---------------------------------------------------------------------------
-// row-GEMM activations: 0 none, 1 relu, 2 gelu (erf), 3 tanh
+// row-GEMM activations: 0 none, 1 relu, 2 gelu (erf), 3 tanh, 4 leaky relu (slope 0.01), 5 sigmoid
 __device__ __forceinline__ float tdf_act(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
   if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
   if (act == 3) return tanhf(v);
+  if (act == 4) return v > 0.f ? v : 0.01f * v;
+  if (act == 5) return 1.0f / (1.0f + expf(-v));
   return v;
 }
 

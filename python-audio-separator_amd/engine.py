@@ -55,6 +55,23 @@ class _HtCfg(C.Structure):
                [("freq_emb_scale", C.c_float), ("max_batch", C.c_int32)]
 
 
+class _VrBand(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("sr", "hl", "n_fft", "crop_start", "crop_stop", "hpf_start", "hpf_stop", "lpf_start",
+                                         "lpf_stop")]
+
+
+class _VrCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("bins", "n_bands", "pre_filter_start", "pre_filter_stop", "channel_mode", "arch")] + \
+               [("cap", C.c_int32 * 6), ("window_size", C.c_int32), ("offset", C.c_int32), ("max_batch", C.c_int32),
+                ("band", _VrBand * 8)]
+
+
+class _VrParams(C.Structure):
+    _fields_ = [("aggr_value", C.c_float), ("split_bin", C.c_int32), ("is_non_accom", C.c_int32), ("has_corr", C.c_int32),
+                ("corr_left", C.c_float), ("corr_right", C.c_float), ("enable_tta", C.c_int32),
+                ("enable_post_process", C.c_int32), ("post_thres", C.c_float)]
+
+
 class _Plan(C.Structure):
     _fields_ = [("n_samples", C.c_int64), ("padded_len", C.c_int64), ("chunk_size", C.c_int64),
                 ("gen_size", C.c_int64), ("pad", C.c_int64), ("step", C.c_int64), ("trim", C.c_int32),
@@ -164,7 +181,9 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_run_model", "asx_op_conv", "asx_op_tdf", "asx_profile_enable", "asx_profile_read", "asx_v3_begin",
            "asx_v3_commit", "asx_v3_flops", "asx_v3_forward", "asx_mdxc_plan", "asx_mdxc_demix", "asx_mdxc_demix_dev",
            "asx_set_option", "asx_rof_begin", "asx_rof_commit", "asx_rof_flops", "asx_rof_forward", "asx_rof_demix", "asx_rof_demix_dev",
-           "asx_ht_begin", "asx_ht_commit", "asx_ht_flops", "asx_ht_forward", "asx_ht_demix", "asx_ht_demix_dev"]
+           "asx_ht_begin", "asx_ht_commit", "asx_ht_flops", "asx_ht_forward", "asx_ht_demix", "asx_ht_demix_dev",
+           "asx_vr_begin", "asx_vr_commit", "asx_vr_flops", "asx_vr_plan", "asx_vr_forward", "asx_vr_analysis",
+           "asx_vr_separate", "asx_vr_separate_dev", "asx_debug_fetch"]
 
 
 def load_library():
@@ -233,6 +252,16 @@ def load_library():
     lib.asx_ht_forward.argtypes = [vp, _FP, i32, i64, _FP]
     lib.asx_ht_demix.argtypes = [vp, _FP, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, _FP]
     lib.asx_ht_demix_dev.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, vp, vp]
+    lib.asx_vr_begin.argtypes = [vp, C.POINTER(_VrCfg)]
+    lib.asx_vr_commit.argtypes = [vp]
+    lib.asx_vr_flops.argtypes = [vp]
+    lib.asx_vr_flops.restype = C.c_double
+    lib.asx_vr_plan.argtypes = [vp, i64, C.POINTER(i32), C.POINTER(i64)]
+    lib.asx_vr_forward.argtypes = [vp, _FP, i32, _FP]
+    lib.asx_vr_analysis.argtypes = [vp, _FP, i64, _FP]
+    lib.asx_vr_separate.argtypes = [vp, _FP, i64, C.POINTER(_VrParams), _FP, _FP]
+    lib.asx_vr_separate_dev.argtypes = [vp, vp, i64, C.POINTER(_VrParams), vp, vp, vp]
+    lib.asx_debug_fetch.argtypes = [vp, C.c_char_p, _FP, i64]
     lib.asx_profile_enable.argtypes = [vp, i32]
     lib.asx_profile_read.argtypes = [vp, C.POINTER(_Profile)]
     for name in SYMBOLS:
@@ -470,6 +499,76 @@ class Engine:
         offs = (C.c_int64 * shifts)(*[int(o) for o in offsets]) if shifts else None
         self._check(self._lib.asx_ht_demix_dev(self._h, mix_ptr, n_samples, int(shifts), offs, float(overlap), flags,
                                                out_ptr, stream or None))
+
+    # -- VR -----------------------------------------------------------------------
+    def load_vr(self, model_params: dict, arch: int, capacity, state_dict: dict, window_size: int = 512, offset: int = 128,
+                max_batch: int = 0):
+        """nets.determine_model_capacity(bins * 2, arch) + load_state_dict.  model_params: the modelparams JSON dict
+        (int band keys); capacity: the model_capacity_data table of nets.py:74-86."""
+        mp = model_params
+        mode = 3 if mp.get("reverse") else (1 if mp.get("mid_side") else (2 if mp.get("mid_side_b2") else 0))
+        nb = len(mp["band"])
+        c = _VrCfg(mp["bins"], nb, mp["pre_filter_start"], mp["pre_filter_stop"], mode, int(arch))
+        for i, v in enumerate((capacity[0][1], capacity[2][1], capacity[3][1], capacity[4][1], capacity[5][1], 0)):
+            c.cap[i] = int(v)
+        c.window_size, c.offset, c.max_batch = int(window_size), int(offset), int(max_batch)
+        for d in range(1, nb + 1):
+            bp = mp["band"][d]
+            c.band[d - 1] = _VrBand(bp["sr"], bp["hl"], bp["n_fft"], bp["crop_start"], bp["crop_stop"], bp.get("hpf_start", 0),
+                                    bp.get("hpf_stop", 0), bp.get("lpf_start", 0), bp.get("lpf_stop", 0))
+        self._check(self._lib.asx_vr_begin(self._h, C.byref(c)))
+        for name, t in state_dict.items():
+            if hasattr(t, "detach"):
+                t = t.detach().cpu().numpy()
+            a = _f32(t).reshape(-1)
+            self._check(self._lib.asx_net_set_tensor(self._h, name.encode(), _ptr(a), a.size))
+        self._check(self._lib.asx_vr_commit(self._h))
+        self.vr_bins = mp["bins"]
+        self.vr_window = int(window_size)
+
+    def vr_flops(self) -> float:
+        return float(self._lib.asx_vr_flops(self._h))
+
+    def vr_plan(self, n_samples: int):
+        t, n = C.c_int32(), C.c_int64()
+        self._check(self._lib.asx_vr_plan(self._h, int(n_samples), C.byref(t), C.byref(n)))
+        return t.value, n.value
+
+    def vr_forward(self, x: np.ndarray) -> np.ndarray:
+        x = _f32(x)
+        if x.ndim != 4 or x.shape[1] != 2 or x.shape[2] != self.vr_bins + 1 or x.shape[3] != self.vr_window:
+            raise ValueError(f"expected [B, 2, {self.vr_bins + 1}, {self.vr_window}], got {x.shape}")
+        out = np.empty_like(x)
+        self._check(self._lib.asx_vr_forward(self._h, _ptr(x), x.shape[0], _ptr(out)))
+        return out
+
+    def vr_analysis(self, wave: np.ndarray) -> np.ndarray:
+        """loading_mix: [2, n] -> complex64 [2, bins+1, n_frames] (transposed back to the reference layout)."""
+        wave = _f32(wave)
+        T, _ = self.vr_plan(wave.shape[1])
+        buf = np.empty((2, T, self.vr_bins + 1, 2), np.float32)
+        self._check(self._lib.asx_vr_analysis(self._h, _ptr(wave), wave.shape[1], _ptr(buf)))
+        return np.ascontiguousarray(buf.view(np.complex64)[..., 0].transpose(0, 2, 1))
+
+    def vr_separate(self, wave: np.ndarray, aggr_value: float, split_bin: int, is_non_accom: bool = False, aggr_correction=None,
+                    enable_tta: bool = False, enable_post_process: bool = False, post_thres: float = 0.2):
+        wave = _f32(wave)
+        if wave.ndim != 2 or wave.shape[0] != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got shape {wave.shape}")
+        _, n_out = self.vr_plan(wave.shape[1])
+        corr = aggr_correction or {}
+        pr = _VrParams(float(aggr_value), int(split_bin), int(bool(is_non_accom)), int(aggr_correction is not None),
+                       float(corr.get("left", 0.0)), float(corr.get("right", 0.0)), int(bool(enable_tta)),
+                       int(bool(enable_post_process)), float(post_thres))
+        p = np.empty((2, n_out), np.float32)
+        q = np.empty((2, n_out), np.float32)
+        self._check(self._lib.asx_vr_separate(self._h, _ptr(wave), wave.shape[1], C.byref(pr), _ptr(p), _ptr(q)))
+        return p, q
+
+    def debug_fetch(self, name: str, shape) -> np.ndarray:
+        out = np.empty(shape, np.float32)
+        self._check(self._lib.asx_debug_fetch(self._h, name.encode(), _ptr(out), out.size))
+        return out
 
     # -- plan ---------------------------------------------------------------
     def plan(self, n_samples: int, is_match_mix: bool = False) -> dict:

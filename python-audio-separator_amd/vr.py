@@ -1,0 +1,96 @@
+"""Host-side mirror of the reference VR plugin's array path (architectures/vr_separator.py).
+
+``VRDemixer(common_config, arch_config, state_dict, nn_arch_size)`` follows ``VRSeparator.__init__`` (:27-113) for the
+configuration (model_data -> vr_model_param JSON, enable_tta, enable_post_process, post_process_threshold, batch_size,
+window_size, aggression) and ``separate`` (:115-253) for the arrays: ``separate_stems(wave [2, n]) -> (primary [n', 2],
+secondary [n', 2])`` where wave is what ``librosa.load(file, sr=band[N].sr, mono=False)`` returns (decode stays with the
+reference).  Multiband analysis, patching, the CascadedASPPNet, mask post-processing and the multiband synthesis all run
+in libasx.so (asx_vr_separate).
+
+Resampling between bands uses the polyphase path on every platform (the reference's ARM / MPS behaviour); VR 5.1
+checkpoints (nets_new.CascadedNet) and high_end_process raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from .engine import Engine, MDXConfig
+
+NON_ACCOM_STEMS = ("Vocals", "Other", "Bass", "Drums", "Guitar", "Piano", "Synthesizer", "Strings", "Woodwinds", "Brass",
+                   "Wind Inst")   # common_separator.py:46
+NN_ARCH_SIZES = [31191, 33966, 56817, 123821, 123812, 129605, 218409, 537238, 537227]
+VR_5_1 = (56817, 218409)
+
+
+def load_model_params(path_or_dict) -> dict:
+    """ModelParameters.__init__ (uvr_lib_v5/vr_network/model_param_init.py:48-71)."""
+    if isinstance(path_or_dict, dict):
+        p = dict(path_or_dict)
+    else:
+        with open(path_or_dict, "r") as f:
+            p = json.loads(f.read(), object_pairs_hook=lambda kv: {(int(k) if k.isdigit() else k): v for k, v in kv})
+    for k in ("mid_side", "mid_side_b", "mid_side_b2", "stereo_w", "stereo_n", "reverse"):
+        p.setdefault(k, False)
+    if "n_bins" in p:
+        p["bins"] = p["n_bins"]
+    return p
+
+
+def model_capacity(nn_architecture: int):
+    """nets.determine_model_capacity (nets.py:65-93)."""
+    if nn_architecture in (31191, 33966, 129605):
+        return [(2, 16), (2, 16), (18, 8, 1, 1, 0), (8, 16), (34, 16, 1, 1, 0), (16, 32), (32, 2, 1), (16, 2, 1), (16, 2, 1)]
+    if nn_architecture in (123821, 123812):
+        return [(2, 32), (2, 32), (34, 16, 1, 1, 0), (16, 32), (66, 32, 1, 1, 0), (32, 64), (64, 2, 1), (32, 2, 1), (32, 2, 1)]
+    if nn_architecture in (537238, 537227):
+        return [(2, 64), (2, 64), (66, 32, 1, 1, 0), (32, 64), (130, 64, 1, 1, 0), (64, 128), (128, 2, 1), (64, 2, 1), (64, 2, 1)]
+    raise NotImplementedError(f"VR architecture size {nn_architecture} is not a CascadedASPPNet (VR 5.1 models are not built)")
+
+
+def nn_arch_size_from_file(model_path: str) -> int:
+    """vr_separator.py:161-164: nearest known size to ceil(file bytes / 1024)."""
+    import math
+    model_size = math.ceil(os.stat(model_path).st_size / 1024)
+    return min(NN_ARCH_SIZES, key=lambda x: abs(x - model_size))
+
+
+class VRDemixer:
+    def __init__(self, common_config: dict, arch_config: dict, state_dict: dict, nn_arch_size: int, capacity=None,
+                 offset: int = 128, max_batch: int = 0):
+        md = common_config.get("model_data", {})
+        if "nout" in md and "nout_lstm" in md or nn_arch_size in VR_5_1:
+            raise NotImplementedError("VR 5.1 models (nets_new.CascadedNet) are not built")
+        mp = common_config.get("model_params")
+        if mp is None:
+            here = common_config["vr_params_dir"]
+            mp = os.path.join(here, f"{md['vr_model_param']}.json")
+        self.model_params = load_model_params(mp)
+        self.primary_stem_name = common_config.get("primary_stem_name", md.get("primary_stem", "Instrumental"))
+        self.enable_tta = arch_config.get("enable_tta", False)
+        self.enable_post_process = arch_config.get("enable_post_process", False)
+        self.post_process_threshold = arch_config.get("post_process_threshold", 0.2)
+        self.batch_size = arch_config.get("batch_size", 1)
+        self.window_size = arch_config.get("window_size", 512)
+        if arch_config.get("high_end_process", False):
+            raise NotImplementedError("high_end_process (mirroring) is not built")
+        self.aggression = float(int(arch_config.get("aggression", 5)) / 100)
+        self.aggressiveness = {"value": self.aggression, "split_bin": self.model_params["band"][1]["crop_stop"],
+                               "aggr_correction": self.model_params.get("aggr_correction")}
+        self.model_samplerate = self.model_params["sr"]
+        dev = common_config.get("torch_device", 0)
+        bins = self.model_params["bins"]
+        self.engine = Engine(MDXConfig(n_fft=2 * bins, hop_length=bins // 2, dim_f=bins, segment_size=8),
+                             device=getattr(dev, "index", dev) or 0)
+        self.engine.load_vr(self.model_params, nn_arch_size, capacity or model_capacity(nn_arch_size), state_dict,
+                            window_size=self.window_size, offset=offset, max_batch=max_batch or max(self.batch_size, 4))
+
+    def separate_stems(self, wave: np.ndarray):
+        """(primary_source, secondary_source) as [n', 2] arrays (vr_separator.py:211-236, before final_process)."""
+        p, s = self.engine.vr_separate(wave, self.aggressiveness["value"], self.aggressiveness["split_bin"],
+                                       is_non_accom=self.primary_stem_name in NON_ACCOM_STEMS,
+                                       aggr_correction=self.aggressiveness["aggr_correction"], enable_tta=self.enable_tta,
+                                       enable_post_process=self.enable_post_process, post_thres=self.post_process_threshold)
+        return p.T, s.T

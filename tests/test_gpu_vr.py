@@ -1,0 +1,108 @@
+"""GPU parity of the VR path against golden vectors written by the reference's spec_utils functions / nets.py classes
+(tests/golden/make_golden_vr.py) and against the CPU oracle.  Bars: 1e-4 relative RMS on separated waves and masks,
+2e-5 on the analysis spectrogram."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vr_oracle as V
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+SMALL_CAP = [(2, 4), (2, 4), (6, 4, 1, 1, 0), (4, 4), (10, 4, 1, 1, 0), (4, 8), (8, 2, 1), (4, 2, 1), (4, 2, 1)]
+
+
+def rel_rms(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return float(np.sqrt(np.mean(np.abs(a - b) ** 2)) / max(np.sqrt(np.mean(np.abs(b) ** 2)), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def A():
+    import audio_separator_amd as A
+    return A
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "vr_small.npz"))
+
+
+def demixer(A, arch=123821, seed=5, params=None, max_batch=0, **arch_cfg):
+    mp = params or V.small_params().param
+    cfg = {"window_size": 64, "batch_size": 2, "aggression": 5}
+    cfg.update(arch_cfg)
+    return A.VRDemixer({"model_params": mp, "primary_stem_name": "Instrumental", "torch_device": 0}, cfg,
+                       state_dict=V.make_vr_state(arch, seed, SMALL_CAP), nn_arch_size=arch, capacity=SMALL_CAP, offset=16,
+                       max_batch=max_batch)
+
+
+@pytest.mark.parametrize("tag,arch,seed", [("hp", 123821, 5), ("sp7", 33966, 6)])
+def test_net_golden(A, g, tag, arch, seed):
+    dm = demixer(A, arch, seed)
+    y = dm.engine.vr_forward(g[f"{tag}_net_in"])
+    assert rel_rms(y, g[f"{tag}_net_out"]) < TOL, rel_rms(y, g[f"{tag}_net_out"])
+
+
+def test_analysis_golden(A, g):
+    dm = demixer(A)
+    X = dm.engine.vr_analysis(g["wave"])
+    assert X.shape == g["X_spec"].shape
+    assert rel_rms(X, g["X_spec"]) < 2e-5, rel_rms(X, g["X_spec"])
+    pm = dict(V.small_params().param)
+    pm["mid_side"] = True
+    Xm = demixer(A, params=pm).engine.vr_analysis(g["wave"])
+    assert rel_rms(Xm, g["ms_X_spec"]) < 2e-5, rel_rms(Xm, g["ms_X_spec"])
+
+
+@pytest.mark.parametrize("max_batch", [0, 3])
+def test_separate_golden(A, g, max_batch):
+    p, s = demixer(A, max_batch=max_batch).separate_stems(g["wave"])
+    assert p.shape == g["wav_y"].T.shape
+    assert rel_rms(p, g["wav_y"].T) < TOL, rel_rms(p, g["wav_y"].T)
+    assert rel_rms(s, g["wav_v"].T) < TOL, rel_rms(s, g["wav_v"].T)
+
+
+@pytest.mark.parametrize("kw", [dict(enable_tta=True), dict(enable_post_process=True), dict(aggression=0),
+                                dict(aggression=20, enable_tta=True, enable_post_process=True, post_process_threshold=0.1)])
+def test_separate_options_oracle(A, g, kw):
+    """TTA / merge_artifacts / aggression variants against the oracle (itself pinned on the reference for each of them)"""
+    mp = V.small_params()
+    sd = V.make_vr_state(123821, 5, SMALL_CAP)
+    okw = dict(window_size=64, batch_size=2, aggression=kw.get("aggression", 5), enable_tta=kw.get("enable_tta", False),
+               enable_post_process=kw.get("enable_post_process", False), post_process_threshold=kw.get("post_process_threshold", 0.2),
+               offset=16)
+    wp, ws = V.vr_separate(g["wave"], sd, 123821, mp, **okw)
+    p, s = demixer(A, **kw).separate_stems(g["wave"])
+    assert rel_rms(p, wp) < TOL, rel_rms(p, wp)
+    assert rel_rms(s, ws) < TOL, rel_rms(s, ws)
+
+
+def test_mid_side_and_non_accom(A, g):
+    pm = dict(V.small_params().param)
+    pm["mid_side"] = True
+    pm["aggr_correction"] = {"left": 0.02, "right": -0.03}
+    mp = V.ModelParams(pm)
+    sd = V.make_vr_state(123821, 5, SMALL_CAP)
+    wave = g["wave"][:, :9001]
+    wp, ws = V.vr_separate(wave, sd, 123821, mp, window_size=64, batch_size=1, aggression=10, is_non_accom_stem=True, offset=16)
+    dm = A.VRDemixer({"model_params": pm, "primary_stem_name": "Vocals", "torch_device": 0},
+                     {"window_size": 64, "batch_size": 1, "aggression": 10}, state_dict=sd, nn_arch_size=123821,
+                     capacity=SMALL_CAP, offset=16)
+    p, s = dm.separate_stems(wave)
+    assert rel_rms(p, wp) < TOL, rel_rms(p, wp)
+    assert rel_rms(s, ws) < TOL, rel_rms(s, ws)
+
+
+def test_error_paths(A):
+    with pytest.raises(NotImplementedError):
+        demixer(A, arch=56817)
+    with pytest.raises(NotImplementedError):
+        demixer(A, high_end_process=True)
+    dm = demixer(A)
+    with pytest.raises(ValueError):
+        dm.separate_stems(np.zeros((1, 1000), np.float32))
+    with pytest.raises(A.AsxError):
+        demixer(A, window_size=60)      # not a multiple of 16
