@@ -245,7 +245,7 @@ typedef struct asx_ht_config {
   int32_t samplerate;
   int32_t segment_samples;               /* int(segment * samplerate): training length = split segment */
   float freq_emb_scale;                  /* freq_emb (0.2); 0 = no embedding */
-  int32_t max_batch;                     /* segments per forward batch (0 = 8) */
+  int32_t max_batch;                     /* segments per forward batch (0 = 16) */
 } asx_ht_config;
 #define ASX_HT_STANDARDIZE 1u /* (mix - ref.mean()) / ref.std() before, * std + mean after (demucs_separator.py:171-185) */
 #define ASX_HT_SWAP01 2u      /* sources[[0, 1]] = sources[[1, 0]] (demucs_separator.py:187) */

@@ -565,6 +565,14 @@ class Engine:
         self._check(self._lib.asx_vr_separate(self._h, _ptr(wave), wave.shape[1], C.byref(pr), _ptr(p), _ptr(q)))
         return p, q
 
+    def vr_separate_dev(self, wave_ptr: int, n_samples: int, primary_ptr: int, secondary_ptr: int, aggr_value: float,
+                        split_bin: int, is_non_accom: bool = False, enable_tta: bool = False, enable_post_process: bool = False,
+                        post_thres: float = 0.2, stream: int = 0):
+        pr = _VrParams(float(aggr_value), int(split_bin), int(bool(is_non_accom)), 0, 0.0, 0.0, int(bool(enable_tta)),
+                       int(bool(enable_post_process)), float(post_thres))
+        self._check(self._lib.asx_vr_separate_dev(self._h, wave_ptr, n_samples, C.byref(pr), primary_ptr or None,
+                                                  secondary_ptr or None, stream or None))
+
     def debug_fetch(self, name: str, shape) -> np.ndarray:
         out = np.empty(shape, np.float32)
         self._check(self._lib.asx_debug_fetch(self._h, name.encode(), _ptr(out), out.size))

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Throughput of the sibling segment loops (BASELINE.json configs 0, 2, 3 and MDX23C) in bench.py's JSON schema.
+
+    python tools/bench_siblings.py [--workloads vr,htdemucs,roformer,mdx23c] [--seconds 240] [--steps 3] [--cpu 1]
+
+One JSON line per workload: whole-song RTF with the input resident in HBM, the roofline fraction of the kernel class
+that dominates the step (in-engine hipEvent profile), and the CPU oracle timed on a bounded sample beside it.
+bench.py (the driver's contract) stays on the headline MDX metric; these lines are kept under profiles/.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from fractions import Fraction
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import audio_separator_amd as A  # noqa: E402
+
+SR = 44100
+PEAK = 157.3
+VR_MP = {"bins": 768, "unstable_bins": 7, "reduction_bins": 668, "sr": 44100, "pre_filter_start": 740, "pre_filter_stop": 768,
+         "band": {1: {"sr": 11025, "hl": 128, "n_fft": 1024, "crop_start": 0, "crop_stop": 186, "lpf_start": 37, "lpf_stop": 73, "res_type": "polyphase"},
+                  2: {"sr": 11025, "hl": 128, "n_fft": 512, "crop_start": 4, "crop_stop": 185, "hpf_start": 36, "hpf_stop": 18, "lpf_start": 93, "lpf_stop": 185, "res_type": "polyphase"},
+                  3: {"sr": 22050, "hl": 256, "n_fft": 512, "crop_start": 46, "crop_stop": 186, "hpf_start": 93, "hpf_stop": 46, "lpf_start": 164, "lpf_stop": 186, "res_type": "polyphase"},
+                  4: {"sr": 44100, "hl": 512, "n_fft": 768, "crop_start": 121, "crop_stop": 382, "hpf_start": 138, "hpf_stop": 123, "res_type": "sinc_medium"}}}
+
+
+def synth(n, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / SR
+    x = sum(rng.uniform(0.02, 0.1) * np.sin(2 * np.pi * rng.uniform(60, 8000) * t + rng.uniform(0, 6.28)) for _ in range(8))
+    return (np.stack([x, 0.8 * x]) + 0.1 * rng.standard_normal((2, n))).astype(np.float32)
+
+
+def rel_rms(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(np.sqrt(np.mean(b ** 2)), 1e-30))
+
+
+def timed(step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def dominant(eng, step, names):
+    eng.profile_enable(True)
+    step()
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    k, v = max(((k, v) for k, v in prof.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
+    tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+    return {"kernel": names.get(k, k), "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK, 4), "traffic": None, "launches": v["launches"], "share_of_step_ms": round(v["ms"], 2)}, \
+        {names.get(k, k): round(v["ms"], 2) for k, v in prof.items() if v["launches"]}
+
+
+def line(workload, secs, dt, steps, warmup, roof, kms, cpu, extra):
+    return {"metric": "audio-sec separated / wall-sec (RTF)", "value": round(secs / dt, 2), "unit": "audio-s/wall-s", "n_gpus": 1,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": dict({"workload": workload}, **extra),
+            "roofline": roof, "cpu_baseline": cpu, "kernel_ms": kms}
+
+
+def run_vr(args):
+    from oracle import vr_oracle as V
+    arch = 123821
+    sd = V.make_vr_state(arch, 0)
+    dm = A.VRDemixer({"model_params": VR_MP, "primary_stem_name": "Instrumental", "torch_device": 0},
+                     {"window_size": 512, "batch_size": 8, "aggression": 5}, state_dict=sd, nn_arch_size=arch, max_batch=8)
+    eng = dm.engine
+    n = int(SR * args.seconds)
+    wave = synth(n)
+    T, n_out = eng.vr_plan(n)
+    dw = torch.from_numpy(wave).cuda()
+    p = torch.empty((2, n_out), dtype=torch.float32, device="cuda")
+    s = torch.empty_like(p)
+    st = torch.cuda.current_stream().cuda_stream
+    step = lambda: eng.vr_separate_dev(dw.data_ptr(), n, p.data_ptr(), s.data_ptr(), 0.05, 186, stream=st)  # noqa: E731
+    dt = timed(step, args.steps, args.warmup)
+    roof, kms = dominant(eng, step, {"conv3x3": "gg_kernel (3x3 / 1x1 convs)", "down": "gg_kernel (stride-2 convs)"})
+    cpu = None
+    if args.cpu:
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        cs = 10.0
+        w = wave[:, : int(SR * cs)]
+        t0 = time.perf_counter()
+        op, osec = V.vr_separate(w, sd, arch, V.ModelParams(VR_MP), window_size=512, batch_size=4, aggression=5)
+        cdt = time.perf_counter() - t0
+        gp, _ = dm.separate_stems(w)
+        cpu = {"value": round(cs / cdt, 3), "unit": "audio-s/wall-s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{cs:g} s clip (BASELINE config 0), numpy/scipy/torch-CPU oracle, {cdt:.1f} s wall",
+               "parity_rel_rms": rel_rms(gp, op)}
+    return line("VR arch, 4band_44100 layout, HP-size CascadedASPPNet (31.65 M params, 2_HP-UVR shape), window 512, synthetic weights",
+                args.seconds, dt, args.steps, args.warmup, roof, kms, cpu,
+                {"windows": T // 256 + 1, "gflop_per_window": round(eng.vr_flops() / 1e9, 1)})
+
+
+def run_htdemucs(args):
+    from oracle import demucs_oracle as D
+    oc = D.HTConfig()
+    sd = D.make_ht_state(oc, 0)
+    hc = A.HTConfig(segment=Fraction(39, 5))
+    eng = A.Engine(A.MDXConfig(n_fft=4096, hop_length=1024, dim_f=2048, segment_size=8))
+    eng.load_ht(hc, sd)
+    n = int(SR * args.seconds)
+    mixh = synth(n)
+    mix = torch.from_numpy(mixh).cuda()
+    out = torch.empty((4, 2, n), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    offs = [11025, 3000]
+    step = lambda: eng.ht_demix_dev(mix.data_ptr(), n, out.data_ptr(), shifts=2, offsets=offs, flags=3, stream=st)  # noqa: E731
+    dt = timed(step, args.steps, args.warmup)
+    roof, kms = dominant(eng, step, {"conv3x3": "gg_kernel (rewrite 3x3 / DConv / 1x1)", "tdf": "tdf_dma_kernel (transformer linears)",
+                                     "conv1x1": "mha_kernel<3>", "down": "gg_kernel (k8/s4 convs)", "up": "gg_kernel (transposed convs)"})
+    TL = hc.segment_samples
+    nseg = sum(len(range(0, n + 22050 - o, int(0.75 * TL))) for o in offs)
+    cpu = None
+    if args.cpu:
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        cs = 12.0
+        m = mixh[:, : int(SR * cs)]
+        t0 = time.perf_counter()
+        want = D.demix_demucs(m, sd, oc, shifts=1, overlap=0.25, offsets=[11025])
+        cdt = time.perf_counter() - t0
+        got = eng.ht_demix(m, shifts=1, offsets=[11025], overlap=0.25, standardize=True, swap01=True)
+        cpu = {"value": round(cs / cdt / 2, 3), "unit": "audio-s/wall-s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{cs:g} s with shifts=1 ({cdt:.1f} s wall), halved to the shifts=2 rate of the GPU line; torch-CPU oracle",
+               "parity_rel_rms": rel_rms(got, want)}
+    return line("htdemucs layout (26.9 M params, 4 sources, nfft 4096, 5-layer cross transformer, 7.8-s segments), shifts=2, overlap 0.25, synthetic weights",
+                args.seconds, dt, args.steps, args.warmup, roof, kms, cpu,
+                {"segment_forwards": nseg, "gflop_per_segment": round(eng.ht_flops() / 1e9, 1),
+                 "net_tflops_per_s": round(eng.ht_flops() * nseg / dt / 1e12, 1)})
+
+
+def run_roformer(args):
+    from oracle import roformer_oracle as R
+    cfg = R.RoformerConfig(freqs_per_bands=R.DEFAULT_FREQS_PER_BANDS)
+    sd = R.make_roformer_state(cfg, 0)
+    dm = A.MDXCDemixer({"model_data": cfg.as_model_data(), "torch_device": 0, "secondary_stem_name": "other"}, {"overlap": 8},
+                       state_dict=sd, max_batch=8)
+    eng = dm.engine
+    n = int(SR * args.seconds)
+    mixh = synth(n)
+    mix = torch.from_numpy(mixh).cuda()
+    out = torch.empty((2, 2, n), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    C = 441 * 800
+    step = lambda: eng.rof_demix_dev(mix.data_ptr(), n, C, out.data_ptr(), stream=st)  # noqa: E731
+    dt = timed(step, args.steps, args.warmup)
+    roof, kms = dominant(eng, step, {"tdf": "tdf_dma_kernel (linears)", "conv1x1": "attention_kernel"})
+    nch = len(R.roformer_plan(n, cfg, 8)[2])
+    cpu = None
+    if args.cpu:
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        m = mixh[:, :C]
+        t0 = time.perf_counter()
+        want = R.roformer_forward(m[None], sd, cfg)
+        cdt = time.perf_counter() - t0
+        got = eng.rof_forward(m[None])
+        cpu = {"value": round(C / SR / cdt, 3), "unit": "audio-s/wall-s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"one 8-s chunk forward, torch-CPU oracle, {cdt:.1f} s wall", "parity_rel_rms": rel_rms(got, want)}
+    return line("BS-Roformer ep_317 layout (159.8 M params, dim 512, depth 12, 62 bands, 8-s chunks, step = chunk), synthetic weights",
+                args.seconds, dt, args.steps, args.warmup, roof, kms, cpu,
+                {"chunks": nch, "tflop_per_chunk": round(eng.rof_flops(1) / 1e12, 2),
+                 "net_tflops_per_s": round(eng.rof_flops(nch) / dt / 1e12, 1)})
+
+
+def run_mdx23c(args):
+    from oracle import mdxc_oracle as M
+    cfg = M.V3Config()
+    sd = M.make_v3_state(cfg, 0)
+    ov = 2
+    dm = A.MDXCDemixer({"model_data": cfg.as_model_data(), "torch_device": 0}, {"overlap": ov}, state_dict=sd, max_batch=8)
+    eng = dm.engine
+    n = int(SR * args.seconds)
+    mixh = synth(n)
+    mix = torch.from_numpy(mixh).cuda()
+    out = torch.empty((2, 2, n), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    step = lambda: eng.mdxc_demix_dev(mix.data_ptr(), n, ov, out.data_ptr(), stream=st)  # noqa: E731
+    dt = timed(step, args.steps, args.warmup)
+    roof, kms = dominant(eng, step, {"conv3x3": "conv_dma_kernel (3x3 convs)"})
+    plan = eng.mdxc_plan(n, ov)
+    cpu = None
+    if args.cpu:
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        Cn = plan["chunk_size"]
+        m = mixh[:, :Cn]
+        t0 = time.perf_counter()
+        want = M.v3_forward(m[None], sd, cfg)
+        cdt = time.perf_counter() - t0
+        got = eng.v3_forward(m[None])
+        cpu = {"value": round(Cn / SR / cdt / ov, 3), "unit": "audio-s/wall-s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"one chunk forward ({cdt:.1f} s wall) / overlap {ov}; torch-CPU oracle", "parity_rel_rms": rel_rms(got, want)}
+    return line(f"MDX23C layout (112 M params, n_fft 8192, 4 subbands, 5 scales), overlap {ov}, synthetic weights", args.seconds, dt,
+                args.steps, args.warmup, roof, kms, cpu,
+                {"chunks": plan["n_chunks"], "tflop_per_chunk": round(eng.v3_flops(1) / 1e12, 2),
+                 "net_tflops_per_s": round(eng.v3_flops(plan["n_chunks"]) / dt / 1e12, 1)})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workloads", default="vr,htdemucs,roformer,mdx23c")
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu", type=int, default=1)
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    fns = {"vr": run_vr, "htdemucs": run_htdemucs, "roformer": run_roformer, "mdx23c": run_mdx23c}
+    for w in args.workloads.split(","):
+        print(json.dumps(fns[w](args)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
