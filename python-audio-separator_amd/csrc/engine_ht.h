@@ -55,7 +55,8 @@ struct HtNet {
   struct {
     float *xf0, *xt0, *yf, *yt, *h, *z, *rw, *tokf, *tokt, *xn, *xn2, *qkv, *kvb, *attf, *attt, *ffh, *frames;
     std::vector<float *> skf, skt, df, dt;
-    double *acc_f, *acc_t, *acc_g;
+    double *acc_f, *acc_t, *acc_g, *acc_g2;
+    float *rowstat, *mr_g;
   } b;
 };
 
@@ -201,7 +202,7 @@ static int ht_load_dconv(asx_engine *e, HtDconv &d, const std::string &p, int ch
   d.hp = (d.hid + 3) & ~3;
   const std::string q = p + ".layers." + std::to_string(idx);
   CHK(ht_pack_conv(e, d.c1, q + ".0", d.hid, ch, 3, 1, false, d.hp, 0));
-  CHK(ht_pack_conv(e, d.c2, q + ".3", 2 * ch, d.hid, 1, 1, false, 0, d.hp));
+  CHK(ht_pack_conv(e, d.c2, q + ".3", 2 * ch, d.hid, 1, 1, true, 0, d.hp));   // GLU row order for the fused epilogue
   const float *g, *b;
   CHK(get_tensor(e, q + ".1.weight", d.hid, &g));
   CHK(get_tensor(e, q + ".1.bias", d.hid, &b));
@@ -210,8 +211,15 @@ static int ht_load_dconv(asx_engine *e, HtDconv &d, const std::string &p, int ch
   std::copy(b, b + d.hid, gb.begin());
   CHK(ht_up(d.g1w, gw));
   CHK(ht_up(d.g1b, gb));
-  CHK(ht_up_named(e, d.g2w, q + ".4.weight", 2 * ch));
-  CHK(ht_up_named(e, d.g2b, q + ".4.bias", 2 * ch));
+  {
+    const float *g2, *b2;
+    CHK(get_tensor(e, q + ".4.weight", 2 * ch, &g2));
+    CHK(get_tensor(e, q + ".4.bias", 2 * ch, &b2));
+    std::vector<float> pg(g2, g2 + 2 * ch), pb2(b2, b2 + 2 * ch);
+    ht_glu_perm(pg, pb2, ch, 1);     // (weights, "bias") = (gamma, beta), one float per row
+    CHK(ht_up(d.g2w, pg));
+    CHK(ht_up(d.g2b, pb2));
+  }
   CHK(ht_up_named(e, d.ls, q + ".6.scale", ch));
   return ASX_OK;
 }
@@ -418,9 +426,19 @@ struct HtGeom {
   int64_t x_bs = 0, y_bs = 0;    // 0: dense
 };
 
+// GroupNorm fusion of the DConv GEMMs (kernels_ht.h: GgArgs::stat_acc ...)
+struct HtFuse {
+  float2 *row_stat = nullptr;
+  const float2 *stat_in = nullptr;
+  int64_t g_outer = 1;
+  int g_mod = 1;
+  const float *gamma = nullptr, *beta = nullptr, *ls = nullptr;
+};
+
 // y = epilogue(gather(x) @ W^T + b)
 static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q, int64_t rows_outer, float *y, int64_t ldy,
-                 int mode, int act, const float *res, int64_t ldr, int res_mod, int Iout, int Cout, hipStream_t s) {
+                 int mode, int act, const float *res, int64_t ldr, int res_mod, int Iout, int Cout, hipStream_t s,
+                 const HtFuse *fz = nullptr) {
   GgArgs a{};
   a.x = x;
   a.w = g.w.f();
@@ -457,13 +475,25 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
   a.ldy = ldy;
   a.ldr = ldr;
   a.res_mod = res_mod;
+  if (fz) {
+    a.row_stat = fz->row_stat;
+    a.stat_in = fz->stat_in;
+    a.g_outer = fz->g_outer;
+    a.g_mod = fz->g_mod;
+    a.gamma = fz->gamma;
+    a.beta = fz->beta;
+    a.ls = fz->ls;
+  } else {
+    a.g_outer = 1;
+    a.g_mod = 1;
+  }
   if (g.k != q.KO * q.KI * q.Cin || (q.Cin & 3) || (q.ldc & 3) || (g.n & 3) || (ldy & 1) || a.M <= 0) {
     set_err("ht_gg: bad geometry (K=%d taps=%dx%d Cin=%d ldc=%d N=%d)", g.k, q.KO, q.KI, q.Cin, q.ldc, g.n);
     return ASX_ERR_INVALID;
   }
   const double flops = 2.0 * (double)a.M * g.n * g.k;
-  const double bytes = 4.0 * ((double)rows_outer * q.I * q.Cin + (double)a.M * g.n / (mode == GG_GLU ? 2 : 1) +
-                              (double)g.n * g.k + (res ? (double)a.M * g.n / (mode == GG_GLU ? 2 : 1) : 0.0));
+  const double out_elems = mode == GG_STATS ? 0.0 : (mode == GG_GNGLU ? (double)a.M * g.n : (double)a.M * g.n / (mode == GG_GLU ? 2 : 1));
+  const double bytes = 4.0 * ((double)rows_outer * q.I * q.Cin + out_elems + (double)g.n * g.k + (res ? out_elems : 0.0));
   const int cls = mode == GG_CONVT ? ASX_PROF_UP : (q.SI > 1 ? ASX_PROF_DOWN : ASX_PROF_CONV3X3);
   return timed(e, cls, flops, bytes, s, [&]() {
     if (g.n > 64) ht_launch_gg<2, 8>(a, s);
@@ -576,19 +606,17 @@ static int ht_ensure_workspace(asx_engine *e, int B) {
   const size_t BT = (size_t)B * T;
   want(b.xf0, BT * n.F[0] * 4);
   want(b.xt0, (size_t)B * n.L[0] * 2);
-  size_t yf = 0, yt = 0, h = 0, z = 0, rw = 0;
+  size_t yf = 0, yt = 0, h = 0, rw = 0;
   for (int i = 0; i < D; ++i) {
     const int hp = (n.C[i] / c.dconv_comp + 3) & ~3;
     yf = std::max(yf, BT * n.F[i + 1] * n.C[i]);
     yt = std::max(yt, (size_t)B * n.L[i + 1] * n.C[i]);
     h = std::max(h, std::max(BT * n.F[i + 1], (size_t)B * n.L[i + 1]) * hp);
-    z = std::max(z, std::max(BT * n.F[i + 1], (size_t)B * n.L[i + 1]) * 2 * n.C[i]);
     rw = std::max(rw, std::max(BT * n.F[i + 1], (size_t)B * n.L[i + 1]) * n.C[i]);
   }
   want(b.yf, yf);
   want(b.yt, yt);
   want(b.h, h);
-  want(b.z, z);
   want(b.rw, rw);
   b.skf.assign(D, nullptr);
   b.skt.assign(D, nullptr);
@@ -618,14 +646,24 @@ static int ht_ensure_workspace(asx_engine *e, int B) {
     want(b.ffh, NM * n.hidden);
   }
   want(b.frames, (size_t)B * S * 2 * T * c.nfft);
+  {   // per-row GroupNorm partials of the DConv GEMMs: [N tiles][rows][2]
+    size_t rsz = 0;
+    for (int i = 0; i < D; ++i) {
+      const size_t tiles = (2 * (size_t)n.C[i] + 127) / 128;
+      rsz = std::max(rsz, std::max(BT * n.F[i + 1], (size_t)B * n.L[i + 1]) * tiles * 2);
+    }
+    want(b.rowstat, rsz);
+    want(b.mr_g, (size_t)B * std::max(n.F[1], 1) * 2);
+  }
   CHK(n.ws.ensure(off));
   for (auto &pr : plan) *pr.first = reinterpret_cast<float *>(reinterpret_cast<char *>(n.ws.p) + pr.second);
   // float64 accumulators: per-sample (freq, time) + group-norm groups (max B * F[1])
   const size_t ng = (size_t)B * std::max(n.F[1], 1);
-  CHK(n.acc.ensure((2 * (size_t)B + ng) * 16));
+  CHK(n.acc.ensure((2 * (size_t)B + 2 * ng) * 16));
   b.acc_f = reinterpret_cast<double *>(n.acc.p);
   b.acc_t = b.acc_f + 2 * (size_t)B;
   b.acc_g = b.acc_t + 2 * (size_t)B;
+  b.acc_g2 = b.acc_g + 2 * ng;
   n.ws_batch = B;
   return ASX_OK;
 }
@@ -652,11 +690,26 @@ static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I
       g.DI = dil;
       g.PI = dil;
     }
-    CHK(ht_gg(e, dc.c1, y, g, (int64_t)B * O, n.b.h, dc.hp, GG_DENSE, 0, nullptr, 0, 0, 0, 0, s));
-    // GroupNorm(1, hid) per conv batch item: (b, f) over (t, c) on the spectrogram branch, b over (l, c) on the waveform
+    // GroupNorm(1, .) per conv batch item: (b, f) over (t, c) on the spectrogram branch, b over (l, c) on the waveform.
+    // Statistics are accumulated by the producing GEMM's epilogue; the 1x1 conv runs twice (K = C/8 is tiny) --
+    // once for the statistics, once to normalise + GLU + LayerScale + add into y -- so its 2C-wide output never
+    // reaches HBM.
     const int G2 = along_outer ? I : 1;
     const int64_t R = along_outer ? O : I;
-    CHK(ht_stats(e, n.b.h, B, R, (int64_t)G2 * dc.hp, dc.hp, dc.hp, dc.hid, G2, n.b.acc_g, s));
+    const int64_t M = (int64_t)B * O * I;
+    auto fold = [&](int ncols, double count, double *acc, float2 *mr) {
+      const int ntile = (ncols + (ncols > 64 ? 128 : 64) - 1) / (ncols > 64 ? 128 : 64);   // N tiles of ht_gg's launch choice
+      return timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)M * ntile, s, [&]() {
+        hipLaunchKernelGGL(rowstat_reduce_kernel, dim3((unsigned)(G2 > 1 ? (G2 + 63) / 64 : 1), (unsigned)B), dim3(256), 0, s,
+                           reinterpret_cast<const float2 *>(n.b.rowstat), M, ntile, (int64_t)O * I, G2, R, count, 1e-5f, acc, mr);
+      });
+    };
+    HtFuse f1;
+    f1.row_stat = reinterpret_cast<float2 *>(n.b.rowstat);
+    f1.g_outer = (int64_t)O * I;
+    f1.g_mod = G2;
+    CHK(ht_gg(e, dc.c1, y, g, (int64_t)B * O, n.b.h, dc.hp, GG_DENSE, 0, nullptr, 0, 0, 0, 0, s, &f1));
+    CHK(fold(dc.hp, (double)R * dc.hid, n.b.acc_g, reinterpret_cast<float2 *>(n.b.mr_g)));
     CHK(ht_gn(e, n.b.h, B, R, G2, dc.hp, dc.hid, n.b.acc_g, dc.g1w.f(), dc.g1b.f(), 0, nullptr, 0, nullptr, s));
     HtGeom g1;
     g1.O = O;
@@ -664,9 +717,15 @@ static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I
     g1.Cin = dc.hp;
     g1.ldc = dc.hp;
     g1.IR = I;
-    CHK(ht_gg(e, dc.c2, n.b.h, g1, (int64_t)B * O, n.b.z, 2 * C, GG_DENSE, 0, nullptr, 0, 0, 0, 0, s));
-    CHK(ht_stats(e, n.b.z, B, R, (int64_t)G2 * 2 * C, 2 * C, 2 * C, 2 * C, G2, n.b.acc_g, s));
-    CHK(ht_gn(e, n.b.z, B, R, G2, 2 * C, 2 * C, n.b.acc_g, dc.g2w.f(), dc.g2b.f(), 1, y, C, dc.ls.f(), s));
+    CHK(ht_gg(e, dc.c2, n.b.h, g1, (int64_t)B * O, nullptr, 2 * C, GG_STATS, 0, nullptr, 0, 0, 0, 0, s, &f1));
+    CHK(fold(2 * C, (double)R * 2 * C, n.b.acc_g2, reinterpret_cast<float2 *>(n.b.mr_g)));
+    HtFuse f3 = f1;
+    f3.row_stat = nullptr;
+    f3.stat_in = reinterpret_cast<const float2 *>(n.b.mr_g);
+    f3.gamma = dc.g2w.f();
+    f3.beta = dc.g2b.f();
+    f3.ls = dc.ls.f();
+    CHK(ht_gg(e, dc.c2, n.b.h, g1, (int64_t)B * O, y, C, GG_GNGLU, 0, nullptr, 0, 0, 0, 0, s, &f3));
   }
   return ASX_OK;
 }

@@ -16,7 +16,7 @@
 
 namespace asx {
 
-enum { GG_DENSE = 0, GG_GLU = 1, GG_CONVT = 2 };
+enum { GG_DENSE = 0, GG_GLU = 1, GG_CONVT = 2, GG_STATS = 3, GG_GNGLU = 4 };
 
 struct GgArgs {
   const float *x, *w, *bias, *res, *zeros;
@@ -33,6 +33,12 @@ struct GgArgs {
   int Iout, Cout, crop, So;     // GG_CONVT: column (r, co) of row j -> position So*j - crop + r, r < N/Cout
   int64_t ldy, ldr;
   int res_mod;                  // > 0: residual row = row % res_mod (frequency embedding table)
+  // GroupNorm(1, N) fusion (DConv, demucs.py:146-157): group of a row = (row / g_outer) * g_mod + row % g_mod
+  float2 *row_stat;             // GG_DENSE / GG_STATS: [N tiles][M] (sum, sum of squares) of each row's act-less outputs; may be null
+  const float2 *stat_in;        // GG_GNGLU: (mean, rstd) per group (rowstat_reduce_kernel)
+  int64_t g_outer;
+  int g_mod;
+  const float *gamma, *beta, *ls;   // GG_GNGLU: GroupNorm affine (row order of w) and the LayerScale of the GLU outputs
 };
 
 template <int NREP, int MREP>
@@ -147,8 +153,51 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
   }
 
   // epilogue: lane (li, lk) holds 4 consecutive columns of row m*16 + li
+  const bool want_stats = a.row_stat != nullptr;
+  if (a.mode == GG_GNGLU) {
+    // y[row, c] += ls[c] * glu(groupnorm(z))[c]; all read-modify-write loads are issued before the first store
+    float2 old[MREP][NREP];
+    float2 mr[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+      const int64_t row = m0 + m * 16 + li;
+      mr[m] = make_float2(0.f, 1.f);
+      if (row < a.M) mr[m] = a.stat_in[(row / a.g_outer) * a.g_mod + row % a.g_mod];
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) {
+        const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+        old[m][n] = make_float2(0.f, 0.f);
+        if (row < a.M && col < a.N) old[m][n] = *reinterpret_cast<const float2 *>(a.y + row * a.ldy + (col >> 1));
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+      if (col >= a.N) continue;
+      const f32x4 bz = *reinterpret_cast<const f32x4 *>(a.bias + col);
+      const f32x4 ga = *reinterpret_cast<const f32x4 *>(a.gamma + col), be = *reinterpret_cast<const f32x4 *>(a.beta + col);
+      const float2 l2 = *reinterpret_cast<const float2 *>(a.ls + (col >> 1));
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) {
+        const int64_t row = m0 + m * 16 + li;
+        if (row >= a.M) continue;
+        const f32x4 v = acc[n][m] + bz;
+        const float gm = mr[m].x, gr = mr[m].y;
+        const float nx = (v.x - gm) * gr * ga.x + be.x, ny = (v.y - gm) * gr * ga.y + be.y;
+        const float nz = (v.z - gm) * gr * ga.z + be.z, nw = (v.w - gm) * gr * ga.w + be.w;
+        float2 o = old[m][n];
+        o.x += l2.x * (nx * (1.0f / (1.0f + expf(-nz))));
+        o.y += l2.y * (ny * (1.0f / (1.0f + expf(-nw))));
+        *reinterpret_cast<float2 *>(a.y + row * a.ldy + (col >> 1)) = o;
+      }
+    }
+    return;
+  }
+  float rs[MREP], rss[MREP];
 #pragma unroll
   for (int m = 0; m < MREP; ++m) {
+    rs[m] = 0.f;
+    rss[m] = 0.f;
     const int64_t row = m0 + m * 16 + li;
     if (row >= a.M) continue;
     const int64_t rrow = a.res_mod > 0 ? row % a.res_mod : row;
@@ -161,6 +210,11 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
       if (col >= a.N) continue;
       f32x4 v = acc[n][m];
       if (a.bias != nullptr) v += *reinterpret_cast<const f32x4 *>(a.bias + col);
+      if (want_stats) {
+        rs[m] += (v.x + v.y) + (v.z + v.w);
+        rss[m] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+      if (a.mode == GG_STATS) continue;
       if (a.mode == GG_GLU) {
         float2 o = make_float2(v.x * (1.0f / (1.0f + expf(-v.z))), v.y * (1.0f / (1.0f + expf(-v.w))));
         const int c2 = col >> 1;
@@ -192,6 +246,102 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
         *reinterpret_cast<f32x4 *>(a.y + off) = o;
       }
     }
+  }
+  if (want_stats) {
+    // per-row sums: over the 4 column groups of a wave (lk), then over the 4 waves through LDS; one float2 per
+    // (N tile, row) goes to row_stat and rowstat_reduce_kernel folds rows into groups (no atomics, reproducible)
+    __syncthreads();   // the K loop's LDS tiles are dead
+    float *sh = lds_f;                 // [4 waves][BM][2]
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+      float s1 = rs[m], s2 = rss[m];
+      s1 += __shfl_xor(s1, 16);
+      s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lk == 0) {
+        sh[(wave * BM + m * 16 + li) * 2] = s1;
+        sh[(wave * BM + m * 16 + li) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BM && m0 + tid < a.M) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        s1 += sh[(w * BM + tid) * 2];
+        s2 += sh[(w * BM + tid) * 2 + 1];
+      }
+      a.row_stat[(int64_t)bn * a.M + m0 + tid] = make_float2(s1, s2);
+    }
+  }
+}
+
+// fold the per-row sums of gg_kernel into GroupNorm statistics: group g = (b, g2) owns rows b*g_outer + r*g_mod + g2,
+// r < R, of every N tile.  acc[g] = (sum, sum of squares) in float64 (for gn_apply_kernel), mr[g] = (mean, rstd).
+// g_mod > 1: grid = (ceil(G2 / 64), B), a workgroup folds 64 adjacent groups (coalesced 512-byte rows), 4 row slices;
+// g_mod == 1: grid = (1, B), all 256 threads stride over the rows of the single group.
+__global__ __launch_bounds__(256) void rowstat_reduce_kernel(const float2 *__restrict__ row_stat, int64_t M, int ntile,
+                                                             int64_t g_outer, int g_mod, int64_t R, double count, float eps,
+                                                             double *__restrict__ acc, float2 *__restrict__ mr) {
+  const int64_t b = blockIdx.y;
+  __shared__ double sh[4][64][2];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  double s1 = 0.0, s2 = 0.0;
+  if (g_mod > 1) {
+    const int g2 = blockIdx.x * 64 + lane;
+    if (g2 < g_mod)
+      for (int t = 0; t < ntile; ++t) {
+        const float2 *p = row_stat + (int64_t)t * M + b * g_outer + g2;
+        for (int64_t r = sl; r < R; r += 4) {
+          const float2 v = p[r * g_mod];
+          s1 += (double)v.x;
+          s2 += (double)v.y;
+        }
+      }
+    sh[sl][lane][0] = s1;
+    sh[sl][lane][1] = s2;
+    __syncthreads();
+    if (sl == 0 && g2 < g_mod) {
+      s1 = (sh[0][lane][0] + sh[1][lane][0]) + (sh[2][lane][0] + sh[3][lane][0]);
+      s2 = (sh[0][lane][1] + sh[1][lane][1]) + (sh[2][lane][1] + sh[3][lane][1]);
+      const int64_t g = b * g_mod + g2;
+      acc[g * 2] = s1;
+      acc[g * 2 + 1] = s2;
+      const double mu = s1 / count;
+      double var = s2 / count - mu * mu;
+      if (var < 0.0) var = 0.0;
+      mr[g] = make_float2((float)mu, (float)(1.0 / sqrt(var + (double)eps)));
+    }
+    return;
+  }
+  for (int t = 0; t < ntile; ++t) {
+    const float2 *p = row_stat + (int64_t)t * M + b * g_outer;
+    for (int64_t r = threadIdx.x; r < R; r += blockDim.x) {
+      const float2 v = p[r];
+      s1 += (double)v.x;
+      s2 += (double)v.y;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_xor(s1, off);
+    s2 += __shfl_xor(s2, off);
+  }
+  if (lane == 0) {
+    sh[sl][0][0] = s1;
+    sh[sl][0][1] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1 = (sh[0][0][0] + sh[1][0][0]) + (sh[2][0][0] + sh[3][0][0]);
+    s2 = (sh[0][0][1] + sh[1][0][1]) + (sh[2][0][1] + sh[3][0][1]);
+    acc[b * 2] = s1;
+    acc[b * 2 + 1] = s2;
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mr[b] = make_float2((float)mu, (float)(1.0 / sqrt(var + (double)eps)));
   }
 }
 
