@@ -16,6 +16,9 @@
 
 namespace asx {
 
+// sigmoid on the hardware exp / rcp units (2 ulp each; the GLU gates sit far inside the 1e-4 parity bar)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
 enum { GG_DENSE = 0, GG_GLU = 1, GG_CONVT = 2, GG_STATS = 3, GG_GNGLU = 4 };
 
 struct GgArgs {
@@ -63,23 +66,44 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
   // swizzle g(row) = (row >> 1) & 7 with row = q*8 + lr, q = wave + 4i: depends on (wave & 1, lr) only
   const int cl = lp ^ ((((wave & 1) << 2) + (lr >> 1)) & 7);   // logical chunk this lane fetches
 
+  // row -> (batch b, outer row oo, inner position j): one 64-bit division per lane, then incremental carries
+  // (64-bit divisions cost thousands of cycles per lane -- they dominated the small-K, memory-bound launches)
+  auto split = [&](int64_t row, int64_t &b, int &oo, int &j) {
+    const int64_t bo = row / a.IR;
+    j = (int)(row - bo * a.IR);
+    b = bo / a.OR;
+    oo = (int)(bo - b * a.OR);
+  };
+  auto advance = [&](int step, int64_t &b, int &oo, int &j) {
+    j += step;
+    while (j >= a.IR) {
+      j -= a.IR;
+      if (++oo >= a.OR) {
+        oo = 0;
+        ++b;
+      }
+    }
+  };
   int64_t xb[NXL];
   int xo[NXL], xi[NXL];
+  {
+    int64_t b;
+    int oo, j;
+    split(m0 + wave * RPI + lr, b, oo, j);
 #pragma unroll
-  for (int i = 0; i < NXL; ++i) {
-    const int q = wave + 4 * i;
-    const int64_t row = m0 + q * RPI + lr;
-    if (q < NXI && row < a.M) {
-      const int64_t bo = row / a.IR;
-      const int j = (int)(row - bo * a.IR);
-      const int oo = (int)(bo % a.OR);
-      xb[i] = (bo / a.OR) * a.x_bs;
-      xo[i] = oo * a.SO - a.PO;
-      xi[i] = j * a.SI - a.PI;
-    } else {
-      xb[i] = 0;
-      xo[i] = -(1 << 29);
-      xi[i] = 0;
+    for (int i = 0; i < NXL; ++i) {
+      const int q = wave + 4 * i;
+      const int64_t row = m0 + q * RPI + lr;
+      if (q < NXI && row < a.M) {
+        xb[i] = b * a.x_bs;
+        xo[i] = oo * a.SO - a.PO;
+        xi[i] = j * a.SI - a.PI;
+      } else {
+        xb[i] = 0;
+        xo[i] = -(1 << 29);
+        xi[i] = 0;
+      }
+      advance(4 * RPI, b, oo, j);
     }
   }
 
@@ -132,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
     const float *ws = xs + BM * BK;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
+      if (ks * BK + kk * 16 >= a.K) break;   // the tail of the last stage is zero padding (K = 8 .. 48 for the DConv 1x1)
       const int pc = ((kk * 4 + lk) ^ sw) * 4;
       f32x4 wa[NREP];
 #pragma unroll
@@ -158,11 +183,21 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
     // y[row, c] += ls[c] * glu(groupnorm(z))[c]; all read-modify-write loads are issued before the first store
     float2 old[MREP][NREP];
     float2 mr[MREP];
+    int64_t gb = (m0 + li) / a.g_outer;
+    int64_t gr = (m0 + li) - gb * a.g_outer;     // row inside the batch item
+    int gm = (int)(gr % a.g_mod);
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
       const int64_t row = m0 + m * 16 + li;
       mr[m] = make_float2(0.f, 1.f);
-      if (row < a.M) mr[m] = a.stat_in[(row / a.g_outer) * a.g_mod + row % a.g_mod];
+      if (row < a.M) mr[m] = a.stat_in[gb * a.g_mod + gm];
+      gr += 16;
+      gm += 16;
+      while (gm >= a.g_mod) gm -= a.g_mod;
+      if (gr >= a.g_outer) {
+        gr -= a.g_outer;
+        ++gb;
+      }
 #pragma unroll
       for (int n = 0; n < NREP; ++n) {
         const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
@@ -186,24 +221,33 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
         const float nx = (v.x - gm) * gr * ga.x + be.x, ny = (v.y - gm) * gr * ga.y + be.y;
         const float nz = (v.z - gm) * gr * ga.z + be.z, nw = (v.w - gm) * gr * ga.w + be.w;
         float2 o = old[m][n];
-        o.x += l2.x * (nx * (1.0f / (1.0f + expf(-nz))));
-        o.y += l2.y * (ny * (1.0f / (1.0f + expf(-nw))));
+        o.x += l2.x * (nx * fast_sigmoid(nz));
+        o.y += l2.y * (ny * fast_sigmoid(nw));
         *reinterpret_cast<float2 *>(a.y + row * a.ldy + (col >> 1)) = o;
       }
     }
     return;
   }
   float rs[MREP], rss[MREP];
+  int64_t eb;
+  int eoo, ej;
+  split(m0 + li, eb, eoo, ej);
+  int rmod = a.res_mod > 0 ? (int)((m0 + li) % a.res_mod) : 0;
 #pragma unroll
   for (int m = 0; m < MREP; ++m) {
     rs[m] = 0.f;
     rss[m] = 0.f;
     const int64_t row = m0 + m * 16 + li;
+    const int64_t rrow = a.res_mod > 0 ? rmod : row;
+    const int64_t bo = eb * a.OR + eoo;
+    const int j = ej;
+    const int64_t yrow = eb * a.y_bs + ((int64_t)eoo * a.IR + ej) * a.ldy;   // DENSE / GLU destination row
+    advance(16, eb, eoo, ej);
+    if (a.res_mod > 0) {
+      rmod += 16;
+      while (rmod >= a.res_mod) rmod -= a.res_mod;
+    }
     if (row >= a.M) continue;
-    const int64_t rrow = a.res_mod > 0 ? row % a.res_mod : row;
-    const int64_t bo = row / a.IR;
-    const int j = (int)(row - bo * a.IR);
-    const int64_t yrow = (bo / a.OR) * a.y_bs + ((bo % a.OR) * a.IR + j) * a.ldy;   // DENSE / GLU destination row
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
       const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
@@ -216,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
       }
       if (a.mode == GG_STATS) continue;
       if (a.mode == GG_GLU) {
-        float2 o = make_float2(v.x * (1.0f / (1.0f + expf(-v.z))), v.y * (1.0f / (1.0f + expf(-v.w))));
+        float2 o = make_float2(v.x * fast_sigmoid(v.z), v.y * fast_sigmoid(v.w));
         const int c2 = col >> 1;
         if (a.res != nullptr) {
           const float2 r = *reinterpret_cast<const float2 *>(a.res + rrow * a.ldr + c2);
