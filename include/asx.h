@@ -205,7 +205,8 @@ int asx_mdxc_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, i
 /* ---- BS-Roformer: uvr_lib_v5/roformer/bs_roformer.py + the Roformer branch of MDXCSeparator.demix ----
  * Engine geometry (asx_mdx_config): n_fft = stft_n_fft (= stft_win_length), hop_length =
  * stft_hop_length, dim_f = n_fft/2 + 1, segment_size = inference.dim_t (mdxc_separator.py:276-300).
- * Weights come in under the reference's own state_dict keys.  dim_head must be 64. */
+ * Weights come in under the reference's own state_dict keys.  dim_head must be 64.  Covers BSRoformer and
+ * MelBandRoformer (cfg.mel). */
 typedef struct asx_rof_config {
   int32_t dim, depth, heads, dim_head;        /* roformer_loader.py:123-135 */
   int32_t num_stems;
@@ -214,6 +215,13 @@ typedef struct asx_rof_config {
   int32_t n_bands;
   int32_t n_out;                              /* len(training.instruments): rows of the result (mdxc_separator.py:316) */
   int32_t freqs_per_bands[128];
+  /* Mel-Band Roformer (uvr_lib_v5/roformer/mel_band_roformer.py): overlapping mel bands -- band j covers frequency bins
+   * [band_start[j], band_start[j] + freqs_per_bands[j]) (the support of librosa.filters.mel, computed by the host); band
+   * masks are summed onto their bins and divided by the number of covering bands (:404-416); every Transformer ends
+   * with its own RMSNorm ("layers.i.k.norm.gamma") instead of one final_norm; the mask MLP has depth+1 linears of
+   * hidden width 4*dim. */
+  int32_t mel;
+  int32_t band_start[128];
 } asx_rof_config;
 int asx_rof_begin(asx_engine *e, const asx_rof_config *cfg);
 int asx_rof_commit(asx_engine *e);

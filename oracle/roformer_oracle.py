@@ -71,6 +71,17 @@ class RoformerConfig:
     sample_rate: int = 44100
     instruments: tuple = ("vocals", "other")
     target_instrument: str | None = "vocals"
+    mel: bool = False            # MelBandRoformer (mel_band_roformer.py): overlapping mel bands, see mel_band_layout
+    num_bands: int = 60
+    band_starts: tuple = ()      # mel only: first frequency bin of each band
+
+    @staticmethod
+    def mel_config(**kw) -> "RoformerConfig":
+        c = RoformerConfig(mel=True, mask_estimator_depth=kw.pop("mask_estimator_depth", 1), **kw)
+        starts, counts = mel_band_layout(c.sample_rate, c.stft_n_fft, c.num_bands)
+        c.freqs_per_bands = tuple(counts)
+        c.band_starts = tuple(starts)
+        return c
 
     @property
     def audio_channels(self):
@@ -81,6 +92,13 @@ class RoformerConfig:
         return tuple(2 * f * self.audio_channels for f in self.freqs_per_bands)
 
     def model_kwargs(self) -> dict:
+        if self.mel:
+            return dict(dim=self.dim, depth=self.depth, stereo=self.stereo, num_stems=self.num_stems,
+                        time_transformer_depth=self.time_transformer_depth, freq_transformer_depth=self.freq_transformer_depth,
+                        num_bands=self.num_bands, dim_head=self.dim_head, heads=self.heads,
+                        mlp_expansion_factor=self.mlp_expansion_factor, dim_freqs_in=self.stft_n_fft // 2 + 1,
+                        sample_rate=self.sample_rate, stft_n_fft=self.stft_n_fft, stft_hop_length=self.stft_hop_length,
+                        stft_win_length=self.stft_win_length, mask_estimator_depth=self.mask_estimator_depth)
         return dict(dim=self.dim, depth=self.depth, stereo=self.stereo, num_stems=self.num_stems,
                     time_transformer_depth=self.time_transformer_depth,
                     freq_transformer_depth=self.freq_transformer_depth, freqs_per_bands=tuple(self.freqs_per_bands),
@@ -90,11 +108,70 @@ class RoformerConfig:
 
     def as_model_data(self) -> dict:
         m = self.model_kwargs()
-        m["freqs_per_bands"] = list(self.freqs_per_bands)
+        if not self.mel:
+            m["freqs_per_bands"] = list(self.freqs_per_bands)
         return {"audio": {"sample_rate": self.sample_rate, "hop_length": self.stft_hop_length, "n_fft": self.stft_n_fft,
                           "num_channels": 2, "dim_f": self.stft_n_fft // 2, "chunk_size": self.stft_hop_length * (self.dim_t - 1)},
                 "model": m, "training": {"instruments": list(self.instruments), "target_instrument": self.target_instrument},
                 "inference": {"dim_t": self.dim_t}, "is_roformer": True}
+
+
+def mel_band_layout(sr: int, n_fft: int, n_mels: int):
+    """(first bin, bin count) of every band of MelBandRoformer (mel_band_roformer.py:279-300): the support of
+    librosa.filters.mel(sr, n_fft, n_mels) (librosa absent -- restated from its published definition: Slaney mel scale,
+    triangular filters between consecutive mel points, `> 0` pattern only; PARITY UNPINNED against librosa itself), with
+    bin 0 forced into the first band and the last bin into the last.  Raises if a band is not one contiguous run."""
+    def hz_to_mel(f):
+        f = np.asarray(f, np.float64)
+        f_sp = 200.0 / 3
+        mels = f / f_sp
+        min_log_hz = 1000.0
+        min_log_mel = min_log_hz / f_sp
+        logstep = np.log(6.4) / 27.0
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, mels)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, np.float64)
+        f_sp = 200.0 / 3
+        min_log_hz = 1000.0
+        min_log_mel = min_log_hz / f_sp
+        logstep = np.log(6.4) / 27.0
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0, float(sr) / 2, int(1 + n_fft // 2), endpoint=True)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(0.0), hz_to_mel(float(sr) / 2), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, len(fftfreqs)), dtype=np.float32)
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    weights *= enorm[:, np.newaxis].astype(np.float32)
+    weights[0][0] = 1.0
+    weights[-1, -1] = 1.0
+    pattern = weights > 0
+    if not pattern.any(axis=0).all():
+        raise ValueError("all frequencies need to be covered by all bands for now")
+    starts, counts = [], []
+    for i in range(n_mels):
+        idx = np.nonzero(pattern[i])[0]
+        if len(idx) == 0 or idx[-1] - idx[0] + 1 != len(idx):
+            raise ValueError(f"mel band {i} is empty or not contiguous")
+        starts.append(int(idx[0]))
+        counts.append(int(len(idx)))
+    return starts, counts
+
+
+def mel_filter_stub(sr, n_fft, n_mels):
+    """stand-in for librosa.filters.mel used by the golden script: a float32 matrix with the same `> 0` support"""
+    starts, counts = mel_band_layout(sr, n_fft, n_mels)
+    w = np.zeros((n_mels, n_fft // 2 + 1), np.float32)
+    for i, (s0, c) in enumerate(zip(starts, counts)):
+        w[i, s0:s0 + c] = 1.0
+    # the reference itself forces [0][0] and [-1, -1]; leave them as the true filterbank would have them
+    return w
 
 
 DEFAULT_FREQS_PER_BANDS = (2,) * 24 + (4,) * 12 + (12,) * 8 + (24,) * 8 + (48,) * 8 + (128, 129)
@@ -127,15 +204,21 @@ def make_roformer_state(cfg: RoformerConfig, seed: int = 0) -> dict:
                 gamma(f"{p}.1.net.0.gamma", d)
                 lin(f"{p}.1.net.1", d * 4, d)
                 lin(f"{p}.1.net.4", d, d * 4, scale=0.5)
-    gamma("final_norm.gamma", d)
+    if cfg.mel:
+        for i in range(cfg.depth):
+            for k in range(2):
+                gamma(f"layers.{i}.{k}.norm.gamma", d)     # Transformer(norm_output=True), mel_band_roformer.py:111
+    else:
+        gamma("final_norm.gamma", d)
     for j, din in enumerate(cfg.band_dims):
         gamma(f"band_split.to_features.{j}.0.gamma", din)
         lin(f"band_split.to_features.{j}.1", d, din)
-    hid = d * cfg.mlp_expansion_factor
+    # MelBandRoformer builds its MaskEstimator without passing mlp_expansion_factor (mel_band_roformer.py:312): always 4
+    hid = d * (4 if cfg.mel else cfg.mlp_expansion_factor)
     for s in range(cfg.num_stems):
         for j, din in enumerate(cfg.band_dims):
             p = f"mask_estimators.{s}.to_freqs.{j}.0"
-            dims = (d,) + (hid,) * (cfg.mask_estimator_depth - 1) + (din * 2,)
+            dims = (d,) + (hid,) * (cfg.mask_estimator_depth - (0 if cfg.mel else 1)) + (din * 2,)
             for li, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
                 lin(f"{p}.{2 * li}", b, a)
     return {k: v.float().contiguous() for k, v in sd.items()}
@@ -172,7 +255,9 @@ def _transformer(x, sd, prefix, depth, cfg):
     for j in range(depth):
         x = _attention(x, sd, f"{prefix}.layers.{j}.0", cfg) + x
         x = _ff(x, sd, f"{prefix}.layers.{j}.1") + x
-    return x                                                               # norm_output=False (:362)
+    if cfg.mel:
+        return _rms(x, sd[f"{prefix}.norm.gamma"])                         # norm_output=True (mel_band_roformer.py:111,120)
+    return x                                                               # norm_output=False (bs_roformer.py:362)
 
 
 @torch.no_grad()
@@ -187,7 +272,10 @@ def roformer_forward(wave, sd: dict, cfg: RoformerConfig):
     stft_repr = st.permute(0, 2, 1, 3, 4).reshape(b, -1, st.shape[3], 2)           # b (f s) t c
     x = stft_repr.permute(0, 2, 1, 3).reshape(b, stft_repr.shape[2], -1)            # b t (f c)
     outs, off = [], 0
+    per_bin = 2 * s
     for j, din in enumerate(cfg.band_dims):
+        if cfg.mel:
+            off = cfg.band_starts[j] * per_bin                                      # gather x[freq_indices] (:368-372)
         xb = _rms(x[..., off:off + din], sd[f"band_split.to_features.{j}.0.gamma"])
         outs.append(F.linear(xb, sd[f"band_split.to_features.{j}.1.weight"], sd[f"band_split.to_features.{j}.1.bias"]))
         off += din
@@ -200,14 +288,15 @@ def roformer_forward(wave, sd: dict, cfg: RoformerConfig):
         xf = x.reshape(bb * tt, ff, dd)
         xf = _transformer(xf, sd, f"layers.{i}.1", cfg.freq_transformer_depth, cfg)
         x = xf.reshape(bb, tt, ff, dd)
-    x = _rms(x, sd["final_norm.gamma"])
+    if not cfg.mel:
+        x = _rms(x, sd["final_norm.gamma"])
     masks = []
     for sidx in range(cfg.num_stems):
         outs = []
         for j, din in enumerate(cfg.band_dims):
             p = f"mask_estimators.{sidx}.to_freqs.{j}.0"
             y = x[:, :, j]
-            nl = cfg.mask_estimator_depth
+            nl = cfg.mask_estimator_depth + (1 if cfg.mel else 0)
             for li in range(nl):
                 y = F.linear(y, sd[f"{p}.{2 * li}.weight"], sd[f"{p}.{2 * li}.bias"])
                 if li < nl - 1:
@@ -215,6 +304,18 @@ def roformer_forward(wave, sd: dict, cfg: RoformerConfig):
             outs.append(F.glu(y, dim=-1))
         masks.append(torch.cat(outs, dim=-1))
     mask = torch.stack(masks, dim=1)                                                # b n t (f c)
+    if cfg.mel:
+        # scatter_add of the band masks onto their bins, averaged by the number of covering bands (:404-416)
+        nbin = stft_repr.shape[1]                                                   # (f s)
+        summed = torch.zeros(b, cfg.num_stems, mask.shape[2], nbin * 2)
+        count = torch.zeros(nbin)
+        off = 0
+        for j, din in enumerate(cfg.band_dims):
+            lo = cfg.band_starts[j] * s
+            summed[..., lo * 2: lo * 2 + din] += mask[..., off:off + din]
+            count[lo: lo + din // 2] += 1
+            off += din
+        mask = summed / count.clamp(min=1e-8).repeat_interleave(2)
     mask = mask.reshape(b, cfg.num_stems, mask.shape[2], -1, 2).permute(0, 1, 3, 2, 4)   # b n f t c
     z = torch.view_as_complex(stft_repr.unsqueeze(1).contiguous()) * torch.view_as_complex(mask.contiguous())
     z = z.reshape(b, cfg.num_stems, -1, s, z.shape[-1]).permute(0, 1, 3, 2, 4)      # b n s f t

@@ -1558,21 +1558,33 @@ int asx_rof_begin(asx_engine *e, const asx_rof_config *cfg) {
     REQUIRE(cfg->freqs_per_bands[j] >= 1, "freqs_per_bands must be positive");
     sum += cfg->freqs_per_bands[j];
   }
-  REQUIRE(sum == e->cfg.dim_f && e->cfg.dim_f == e->cfg.n_fft / 2 + 1,
-          "sum(freqs_per_bands) = %d must equal dim_f = n_fft/2 + 1 = %d", sum, e->cfg.n_fft / 2 + 1);
+  REQUIRE(e->cfg.dim_f == e->cfg.n_fft / 2 + 1, "dim_f must be n_fft/2 + 1 = %d", e->cfg.n_fft / 2 + 1);
+  if (cfg->mel) {
+    for (int j = 0; j < cfg->n_bands; ++j) {
+      REQUIRE(cfg->band_start[j] >= 0 && cfg->band_start[j] + cfg->freqs_per_bands[j] <= e->cfg.dim_f, "mel band %d out of range", j);
+      REQUIRE(j == 0 || (cfg->band_start[j] >= cfg->band_start[j - 1] &&
+                         cfg->band_start[j] + cfg->freqs_per_bands[j] >= cfg->band_start[j - 1] + cfg->freqs_per_bands[j - 1]),
+              "mel bands must be ordered");
+    }
+  } else {
+    REQUIRE(sum == e->cfg.dim_f, "sum(freqs_per_bands) = %d must equal dim_f = n_fft/2 + 1 = %d", sum, e->cfg.dim_f);
+  }
   if (!e->rof) e->rof = new RofNet();
   rof_free(*e->rof);
   RofNet &n = *e->rof;
   n.cfg = *cfg;
   n.band_dim.clear();
   n.band_off.clear();
+  n.mask_off.clear();
   int off = 0;
   for (int j = 0; j < cfg->n_bands; ++j) {
     n.band_dim.push_back(4 * cfg->freqs_per_bands[j]);   // 2 (complex) * 2 (stereo) * freqs
-    n.band_off.push_back(off);
+    n.band_off.push_back(cfg->mel ? 4 * cfg->band_start[j] : off);
+    n.mask_off.push_back(off);
     off += 4 * cfg->freqs_per_bands[j];
   }
-  n.W = off;
+  n.W = 4 * e->cfg.dim_f;   // width of the per-frame spectrum vector (f s c)
+  n.MW = off;               // width of the concatenated band masks (= W unless the bands overlap)
   n.begun = true;
   e->host_tensors.clear();
   e->net_begun = true;
@@ -1606,17 +1618,52 @@ int asx_rof_commit(asx_engine *e) {
     for (int j = 0; j < c.freq_depth; ++j)
       CHK(rof_load_layer(e, n.freq_l[i][j], "layers." + std::to_string(i) + ".1.layers." + std::to_string(j), Fb));
   }
-  CHK(rof_upload(e, n.final_g, "final_norm.gamma", D));
-  const int hid = D * c.mlp_expansion_factor;
+  if (c.mel) {
+    n.tnorm_t.assign(c.depth, DevBuf());
+    n.tnorm_f.assign(c.depth, DevBuf());
+    for (int i = 0; i < c.depth; ++i) {
+      CHK(rof_upload(e, n.tnorm_t[i], "layers." + std::to_string(i) + ".0.norm.gamma", D));
+      CHK(rof_upload(e, n.tnorm_f[i], "layers." + std::to_string(i) + ".1.norm.gamma", D));
+    }
+    // bins -> covering band range (bands are ordered, so the covering set is one run of bands)
+    const int F = e->cfg.dim_f;
+    std::vector<int> jlo(F, Fb), jhi(F, -1), bst(Fb), mo(Fb);
+    for (int j = 0; j < Fb; ++j) {
+      bst[j] = c.band_start[j];
+      mo[j] = n.mask_off[j];
+      for (int f = c.band_start[j]; f < c.band_start[j] + c.freqs_per_bands[j]; ++f) {
+        jlo[f] = std::min(jlo[f], j);
+        jhi[f] = std::max(jhi[f], j);
+      }
+    }
+    for (int f = 0; f < F; ++f) {
+      REQUIRE(jhi[f] >= jlo[f], "all frequencies need to be covered by all bands for now (bin %d is not)", f);
+      for (int j = jlo[f]; j <= jhi[f]; ++j)
+        REQUIRE(f >= c.band_start[j] && f < c.band_start[j] + c.freqs_per_bands[j], "mel bands covering bin %d are not one run", f);
+    }
+    auto upi = [&](DevBuf &d, const std::vector<int> &v) -> int {
+      CHK(d.ensure(v.size() * 4));
+      HIPCHK(hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+      return ASX_OK;
+    };
+    CHK(upi(n.d_bstart, bst));
+    CHK(upi(n.d_moff, mo));
+    CHK(upi(n.d_jlo, jlo));
+    CHK(upi(n.d_jhi, jhi));
+  } else {
+    CHK(rof_upload(e, n.final_g, "final_norm.gamma", D));
+  }
+  const int hid = D * (c.mel ? 4 : c.mlp_expansion_factor);   // mel: MaskEstimator is built with the default factor 4
+  const int n_lin = c.mask_estimator_depth + (c.mel ? 1 : 0);  // mel MLP: dims = (in, hidden * depth, out)
   n.mask.assign(c.num_stems, {});
   for (int st = 0; st < c.num_stems; ++st) {
     n.mask[st].assign(Fb, {});
     for (int j = 0; j < Fb; ++j) {
       auto &mlp = n.mask[st][j];
-      mlp.assign(c.mask_estimator_depth, RofLin());
+      mlp.assign(n_lin, RofLin());
       int in = D;
-      for (int li = 0; li < c.mask_estimator_depth; ++li) {
-        const int out = (li + 1 == c.mask_estimator_depth) ? 2 * n.band_dim[j] : hid;
+      for (int li = 0; li < n_lin; ++li) {
+        const int out = (li + 1 == n_lin) ? 2 * n.band_dim[j] : hid;
         CHK(rof_load_lin(e, mlp[li],
                          "mask_estimators." + std::to_string(st) + ".to_freqs." + std::to_string(j) + ".0." +
                              std::to_string(2 * li),

@@ -27,8 +27,12 @@ struct RofLayer {
 struct RofNet {
   asx_rof_config cfg{};
   bool begun = false, ready = false;
-  std::vector<int> band_dim, band_off;   // per band: 2 * f * channels, offset inside the (f s c) vector
-  int W = 0;                              // sum of band dims = 2 * 2 * n_bins
+  std::vector<int> band_dim, band_off;   // per band: 2 * f * channels, offset inside the (f s c) spectrum vector
+  std::vector<int> mask_off;             // per band: offset inside the concatenated band masks
+  int W = 0;                              // 2 * 2 * n_bins: width of the spectrum vector
+  int MW = 0;                             // sum of band dims (> W for overlapping mel bands)
+  std::vector<DevBuf> tnorm_t, tnorm_f;   // mel: output RMSNorm of every time / frequency Transformer
+  DevBuf d_bstart, d_moff, d_jlo, d_jhi, MASKB;
   std::vector<DevBuf> bs_gamma;
   std::vector<RofLin> bs_lin;
   std::vector<std::vector<RofLayer>> time_l, freq_l;   // [depth][transformer depth]
@@ -61,6 +65,9 @@ static void rof_free(RofNet &n) {
   for (auto &d : n.freq_l)
     for (auto &l : d) rof_free_layer(l);
   n.final_g.release();
+  for (auto &g : n.tnorm_t) g.release();
+  for (auto &g : n.tnorm_f) g.release();
+  for (DevBuf *b : {&n.d_bstart, &n.d_moff, &n.d_jlo, &n.d_jhi, &n.MASKB}) b->release();
   for (auto &s : n.mask)
     for (auto &b : s)
       for (auto &l : b) rof_free_lin(l);
@@ -174,7 +181,8 @@ static int rof_rmsnorm(asx_engine *e, const float *x, int64_t lda, int d, const 
 }
 
 // one Transformer (bs_roformer.py:136-160, norm_output = False) over the token matrix TOK [M, D]
-static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool time_axis, int B, hipStream_t s) {
+static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool time_axis, int B, hipStream_t s,
+                           const DevBuf *out_norm = nullptr) {
   RofNet &n = *e->rof;
   const asx_rof_config &c = n.cfg;
   const int T = e->cfg.segment_size, Fb = c.n_bands, D = c.dim, H = c.heads, inner = H * c.dim_head;
@@ -253,6 +261,8 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
     CHK(rof_gemm(e, L.ff.l1, n.XN.f(), D, M, n.FFH.f(), 4 * D, 2, nullptr, 0, s));          // GELU
     CHK(rof_gemm(e, L.ff.l2, n.FFH.f(), 4 * D, M, n.TOK.f(), D, 0, n.TOK.f(), D, s));
   }
+  // MelBandRoformer: Transformer(norm_output=True) (mel_band_roformer.py:111,120); in place (a row is read, then written)
+  if (out_norm) CHK(rof_rmsnorm(e, n.TOK.f(), D, D, out_norm->f(), n.TOK.f(), D, M, s));
   return ASX_OK;
 }
 
@@ -262,7 +272,7 @@ static int rof_ensure_workspace(asx_engine *e, int B) {
   const asx_rof_config &c = n.cfg;
   const int T = e->cfg.segment_size, Fb = c.n_bands, D = c.dim, inner = c.heads * c.dim_head;
   const size_t M = (size_t)B * T * Fb, BT = (size_t)B * T;
-  const int hid = D * c.mlp_expansion_factor;
+  const int hid = D * (c.mel ? 4 : c.mlp_expansion_factor);
   int maxd = 0;
   for (int d : n.band_dim) maxd = std::max(maxd, d);
   CHK(n.X0.ensure(BT * n.W * 4));
@@ -276,6 +286,7 @@ static int rof_ensure_workspace(asx_engine *e, int B) {
   CHK(n.HID.ensure(BT * hid * 4));
   CHK(n.GLU.ensure(BT * 2 * maxd * 4));
   CHK(n.MASK.ensure(BT * c.num_stems * n.W * 4));
+  if (c.mel) CHK(n.MASKB.ensure(BT * c.num_stems * n.MW * 4));
   CHK(n.frames.ensure((size_t)B * c.num_stems * 2 * T * e->cfg.n_fft * 4));
   n.ws_batch = B;
   return ASX_OK;
@@ -318,16 +329,20 @@ static int rof_chunks_dev(asx_engine *e, const float *wave, const int64_t *d_sta
     CHK(rof_gemm(e, n.bs_lin[j], n.XB.f(), din, BT, n.TOK.f() + (int64_t)j * D, (int64_t)Fb * D, 0, nullptr, 0, s));
   }
   for (int i = 0; i < c.depth; ++i) {
-    CHK(rof_transformer(e, n.time_l[i], true, B, s));
-    CHK(rof_transformer(e, n.freq_l[i], false, B, s));
+    CHK(rof_transformer(e, n.time_l[i], true, B, s, c.mel ? &n.tnorm_t[i] : nullptr));
+    CHK(rof_transformer(e, n.freq_l[i], false, B, s, c.mel ? &n.tnorm_f[i] : nullptr));
   }
-  CHK(rof_rmsnorm(e, n.TOK.f(), D, D, n.final_g.f(), n.XN.f(), D, M, s));
+  const float *feat = n.TOK.f();
+  if (!c.mel) {
+    CHK(rof_rmsnorm(e, n.TOK.f(), D, D, n.final_g.f(), n.XN.f(), D, M, s));
+    feat = n.XN.f();
+  }
   // mask estimators (bs_roformer.py:205-229): per stem, per band MLP (tanh) + GLU -> MASK[b, stem, t, band slice]
   for (int st = 0; st < S; ++st)
     for (int j = 0; j < Fb; ++j) {
       const int din = n.band_dim[j];
       auto &mlp = n.mask[st][j];
-      const float *cur = n.XN.f() + (int64_t)j * D;
+      const float *cur = feat + (int64_t)j * D;
       int64_t ld = (int64_t)Fb * D;
       for (size_t li = 0; li + 1 < mlp.size(); ++li) {
         float *dst = (li & 1) ? n.FFH.f() : n.HID.f();
@@ -338,15 +353,23 @@ static int rof_chunks_dev(asx_engine *e, const float *wave, const int64_t *d_sta
       CHK(rof_gemm(e, mlp.back(), cur, ld, BT, n.GLU.f(), 2 * din, 0, nullptr, 0, s));
       {
         const int64_t tot = BT * din;
-        float *dst = n.MASK.f() + n.band_off[j];
+        float *dst = c.mel ? n.MASKB.f() + n.mask_off[j] : n.MASK.f() + n.band_off[j];
         const float *src = n.GLU.f();
-        const int64_t Wl = n.W;
+        const int64_t Wl = c.mel ? n.MW : n.W;
         CHK(timed(e, ASX_PROF_MISC, 0.0, 12.0 * tot, s, [&]() {
           hipLaunchKernelGGL(glu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, din, BT, T, S, st, dst,
                              Wl);
         }));
       }
     }
+  if (c.mel) {   // band masks -> per-bin masks: sum over the covering bands / their number (mel_band_roformer.py:404-416)
+    const int64_t tot = BT * S * n.W;
+    CHK(timed(e, ASX_PROF_MISC, 0.0, 4.0 * (double)BT * S * (n.W + n.MW), s, [&]() {
+      hipLaunchKernelGGL(mel_mask_merge_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n.MASKB.f(), n.MW, n.W,
+                         reinterpret_cast<const int *>(n.d_bstart.p), reinterpret_cast<const int *>(n.d_moff.p),
+                         reinterpret_cast<const int *>(n.d_jlo.p), reinterpret_cast<const int *>(n.d_jhi.p), n.MASK.f(), tot);
+    }));
+  }
   {
     IstftArgs a{};
     a.spec = n.X0.f();
@@ -378,10 +401,10 @@ static double rof_flops(const asx_engine *e, int batch) {
   const double per_layer = 2.0 * M * (D * 3 * inner + D * c.heads + inner * D + 2 * D * 4 * D);
   const double att_t = 4.0 * Fb * c.heads * T * T * c.dim_head, att_f = 4.0 * T * c.heads * Fb * Fb * c.dim_head;
   fl += c.depth * (c.time_depth * (per_layer + att_t) + c.freq_depth * (per_layer + att_f));
-  const double hid = D * c.mlp_expansion_factor;
+  const double hid = D * (c.mel ? 4 : c.mlp_expansion_factor);
   for (int d : n.band_dim) {
     double m = 0, in = D;
-    for (int li = 0; li + 1 < c.mask_estimator_depth; ++li) {
+    for (int li = 0; li + 1 < c.mask_estimator_depth + (c.mel ? 1 : 0); ++li) {
       m += 2.0 * T * in * hid;
       in = hid;
     }

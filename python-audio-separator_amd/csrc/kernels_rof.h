@@ -224,6 +224,27 @@ __global__ __launch_bounds__(256) void glu_kernel(const float *__restrict__ a, i
 }
 
 // ---------------------------------------------------------------------------
+// Mel-Band Roformer mask merge (mel_band_roformer.py:404-416): band masks maskb [R, MW] (R = B*S*T rows, band j at
+// moff[j], (f s c) order inside) -> per-bin masks mask [R, W]: sum over the bands jlo[f] .. jhi[f] that cover bin f,
+// divided by their number (scatter_add_ then / num_bands_per_freq.clamp(1e-8)).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mel_mask_merge_kernel(const float *__restrict__ maskb, int MW, int W,
+                                                             const int *__restrict__ bstart, const int *__restrict__ moff,
+                                                             const int *__restrict__ jlo, const int *__restrict__ jhi,
+                                                             float *__restrict__ mask, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t row = idx / W;
+  const int e = (int)(idx - row * W);
+  const int f = e >> 2, sc = e & 3;
+  const float *src = maskb + row * MW;
+  float acc = 0.f;
+  const int j0 = jlo[f], j1 = jhi[f];
+  for (int j = j0; j <= j1; ++j) acc += src[moff[j] + (f - bstart[j]) * 4 + sc];
+  mask[idx] = acc / fmaxf((float)(j1 - j0 + 1), 1e-8f);
+}
+
+// ---------------------------------------------------------------------------
 // Roformer chunk fold (mdxc_separator.py:320-343): result += x * w, counter += w,
 // out = result / clamp(counter, 1e-10); chunk k covers [starts[k], starts[k] + C).
 // chunk_out [n_chunks, S, 2, C];  out [n_out, 2, N] where stem row o reads chunk stem (o % S)

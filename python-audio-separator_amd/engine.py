@@ -45,7 +45,7 @@ class _V3Cfg(C.Structure):
 class _RofCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "heads", "dim_head", "num_stems", "time_depth", "freq_depth",
                                          "mlp_expansion_factor", "mask_estimator_depth", "n_bands", "n_out")] + \
-               [("freqs_per_bands", C.c_int32 * 128)]
+               [("freqs_per_bands", C.c_int32 * 128), ("mel", C.c_int32), ("band_start", C.c_int32 * 128)]
 
 
 class _HtCfg(C.Structure):
@@ -139,6 +139,8 @@ class RofConfig:
     mask_estimator_depth: int = 2
     freqs_per_bands: tuple = ()
     n_out: int = 2
+    mel: bool = False           # MelBandRoformer: band j covers bins [band_starts[j], + freqs_per_bands[j])
+    band_starts: tuple = ()
 
 
 @dataclass
@@ -416,6 +418,12 @@ class Engine:
                     len(rc.freqs_per_bands), rc.n_out)
         for i, f in enumerate(rc.freqs_per_bands):
             c.freqs_per_bands[i] = int(f)
+        c.mel = int(bool(rc.mel))
+        if rc.mel:
+            if len(rc.band_starts) != len(rc.freqs_per_bands):
+                raise ValueError("mel: one band start per band")
+            for i, f in enumerate(rc.band_starts):
+                c.band_start[i] = int(f)
         self._check(self._lib.asx_rof_begin(self._h, C.byref(c)))
         for name, t in state_dict.items():
             if hasattr(t, "detach"):

@@ -14,6 +14,46 @@ from .engine import Engine, MDXConfig, RofConfig, V3Config
 from .mdx import _device_index
 
 
+def mel_band_layout(sr: int, n_fft: int, n_mels: int):
+    """(first bin, bin count) of every band of MelBandRoformer (uvr_lib_v5/roformer/mel_band_roformer.py:279-300): the
+    support of librosa.filters.mel(sr=sr, n_fft=n_fft, n_mels=n_mels) -- Slaney mel scale, triangles between consecutive
+    mel points -- with bin 0 forced into the first band and the last bin into the last."""
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+
+    def hz_to_mel(f):
+        f = np.asarray(f, np.float64)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, np.float64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0, float(sr) / 2, int(1 + n_fft // 2), endpoint=True)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(0.0), hz_to_mel(float(sr) / 2), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, len(fftfreqs)), dtype=np.float32)
+    for i in range(n_mels):
+        weights[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+    weights *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, np.newaxis].astype(np.float32)
+    weights[0][0] = 1.0
+    weights[-1, -1] = 1.0
+    pattern = weights > 0
+    if not pattern.any(axis=0).all():
+        raise ValueError("all frequencies need to be covered by all bands for now")
+    starts, counts = [], []
+    for i in range(n_mels):
+        idx = np.nonzero(pattern[i])[0]
+        if len(idx) == 0 or idx[-1] - idx[0] + 1 != len(idx):
+            raise NotImplementedError(f"mel band {i} is empty or not one contiguous run of bins")
+        starts.append(int(idx[0]))
+        counts.append(int(len(idx)))
+    return starts, counts
+
+
 def _get(d, *path, default=None):
     for k in path:
         if not isinstance(d, dict) or k not in d:
@@ -68,20 +108,26 @@ class MDXCDemixer:
             self.load_model(state_dict)
 
     def _init_roformer(self, audio, model, state_dict, max_batch):
-        """BS-Roformer models (roformer_loader.py:123-150; mel-band Roformers are not accelerated)."""
-        if "freqs_per_bands" not in model:
-            raise NotImplementedError("only BS-Roformer (freqs_per_bands) is accelerated, not Mel-Band-Roformer")
+        """BS-Roformer (freqs_per_bands) and Mel-Band Roformer (num_bands) models (roformer_loader.py:123-195)."""
         n_fft = model.get("stft_n_fft", 2048)
         if model.get("stft_win_length", n_fft) != n_fft:
             raise NotImplementedError("stft_win_length != stft_n_fft")
         hop = model.get("stft_hop_length") or audio["hop_length"]           # mdxc_separator.py:289-296
+        mel = "freqs_per_bands" not in model
+        if mel:
+            if "num_bands" not in model:
+                raise ValueError("Roformer model config has neither freqs_per_bands nor num_bands")
+            starts, counts = mel_band_layout(model.get("sample_rate", 44100), n_fft, model["num_bands"])
+        else:
+            starts, counts = (), tuple(model["freqs_per_bands"])
         self.rof = RofConfig(dim=model["dim"], depth=model["depth"], heads=model.get("heads", 8),
-                             dim_head=model.get("dim_head", 64), num_stems=model.get("num_stems", 2),
+                             dim_head=model.get("dim_head", 64), num_stems=model.get("num_stems", 1 if mel else 2),
                              time_transformer_depth=model.get("time_transformer_depth", 2),
                              freq_transformer_depth=model.get("freq_transformer_depth", 2),
                              mlp_expansion_factor=model.get("mlp_expansion_factor", 4),
-                             mask_estimator_depth=model.get("mask_estimator_depth", 2),
-                             freqs_per_bands=tuple(model["freqs_per_bands"]), n_out=max(1, len(self.instruments)))
+                             mask_estimator_depth=model.get("mask_estimator_depth", 1 if mel else 2),
+                             freqs_per_bands=tuple(counts), n_out=max(1, len(self.instruments)), mel=mel,
+                             band_starts=tuple(starts))
         if not model.get("stereo", False):
             raise NotImplementedError("mono Roformer models")
         self.engine = Engine(MDXConfig(n_fft=n_fft, hop_length=hop, dim_f=n_fft // 2 + 1,

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Golden vectors for the Mel-Band Roformer path from the REFERENCE classes (build container only).
+
+Absent third-party deps as in make_golden_roformer.py; additionally `librosa.filters.mel` -> the restated mel filterbank
+support of oracle/roformer_oracle.py (mel_filter_stub; flagged there as unpinned against librosa itself).
+
+    python tests/golden/make_golden_melroformer.py
+"""
+import importlib.machinery
+import logging
+import os
+import sys
+import types
+import typing
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+class ConfigDict(dict):
+    def __init__(self, d=None):
+        super().__init__()
+        for k, v in (d or {}).items():
+            self[k] = ConfigDict(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def main():
+    sys.path.insert(0, ROOT)
+    from oracle import roformer_oracle as R
+    for name in ["onnx", "onnxruntime", "onnx2torch", "soundfile", "audioread"]:
+        _stub(name)
+    filt = _stub("librosa.filters", mel=lambda sr, n_fft, n_mels: R.mel_filter_stub(sr, n_fft, n_mels))
+    _stub("librosa", filters=filt)
+    _stub("pydub", AudioSegment=object)
+    _stub("ml_collections", ConfigDict=ConfigDict)
+    _stub("beartype", beartype=lambda f: f)
+    _stub("beartype.typing", Tuple=typing.Tuple, Optional=typing.Optional, List=typing.List, Callable=typing.Callable)
+    _stub("rotary_embedding_torch", RotaryEmbedding=R.RotaryEmbedding)
+    for name, path in [("audio_separator", REF + "/audio_separator"), ("audio_separator.separator", REF + "/audio_separator/separator")]:
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [path]
+        pkg.__spec__ = importlib.machinery.ModuleSpec(name, None, is_package=True)
+        sys.modules[name] = pkg
+    from audio_separator.separator.uvr_lib_v5.roformer.mel_band_roformer import MelBandRoformer
+    from audio_separator.separator.architectures.mdxc_separator import MDXCSeparator
+
+    out = {}
+    cfg = R.RoformerConfig.mel_config(dim=32, depth=2, heads=2, dim_head=64, num_bands=6, stft_n_fft=64, stft_hop_length=16,
+                                      stft_win_length=64, dim_t=21, sample_rate=100, mlp_expansion_factor=2)
+    sd = R.make_roformer_state(cfg, 17)
+    net = MelBandRoformer(**cfg.model_kwargs(), flash_attn=False)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    w = (0.4 * np.random.default_rng(181).standard_normal((2, 2, 320))).astype(np.float32)
+    with torch.no_grad():
+        out["fwd1"] = net(torch.tensor(w)).numpy()
+    cfg2 = R.RoformerConfig.mel_config(dim=32, depth=1, heads=2, dim_head=64, num_bands=8, stft_n_fft=64, stft_hop_length=16,
+                                       stft_win_length=64, dim_t=21, sample_rate=100, num_stems=2, time_transformer_depth=2,
+                                       freq_transformer_depth=1, target_instrument=None, mask_estimator_depth=2)
+    sd2 = R.make_roformer_state(cfg2, 18)
+    net2 = MelBandRoformer(**cfg2.model_kwargs(), flash_attn=False)
+    net2.load_state_dict(sd2, strict=True)
+    net2.eval()
+    with torch.no_grad():
+        out["fwd2"] = net2(torch.tensor(w)).numpy()
+
+    def ref_demix(model, c, mix, overlap):
+        s = MDXCSeparator.__new__(MDXCSeparator)
+        s.logger = logging.getLogger("golden")
+        s.pitch_shift = 0
+        s.is_roformer = True
+        s.model_run = model
+        s.torch_device = torch.device("cpu")
+        s.model_data_cfgdict = ConfigDict(c.as_model_data())
+        s.overlap = overlap
+        s.batch_size = 1
+        s.override_model_segment_size = False
+        s.segment_size = None
+        s.sample_rate = c.sample_rate
+        s.is_primary_stem_main_target = bool(c.target_instrument)
+        s.primary_stem_name = c.target_instrument or c.instruments[0]
+        s.secondary_stem_name = c.instruments[1]
+        return s.demix(mix)
+
+    mix = (0.4 * np.random.default_rng(2090).standard_normal((2, 1000))).astype(np.float32)
+    d = ref_demix(net, cfg, mix, 2)
+    out["demix1_primary"] = np.asarray(d["vocals"], np.float32)
+    out["demix1_secondary"] = np.asarray(d["other"], np.float32)
+    d = ref_demix(net2, cfg2, mix, 8)
+    out["demix2"] = np.stack([d[k] for k in cfg2.instruments]).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "melroformer_small.npz"), **out)
+    print({k: v.shape for k, v in out.items()}, os.path.getsize(os.path.join(HERE, "melroformer_small.npz")))
+
+
+if __name__ == "__main__":
+    main()

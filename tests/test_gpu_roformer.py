@@ -92,3 +92,44 @@ def test_batching_is_invisible(A):
     mix = (0.4 * np.random.default_rng(13).standard_normal((2, 1500))).astype(np.float32)
     outs = [demixer(A, CFG, 7, 2, max_batch=mb).demix(mix)["vocals"] for mb in (1, 2, 64)]
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+# ---- Mel-Band Roformer ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gm(golden_dir):
+    return np.load(os.path.join(golden_dir, "melroformer_small.npz"))
+
+
+def mel_cfgs():
+    c1 = R.RoformerConfig.mel_config(dim=32, depth=2, heads=2, dim_head=64, num_bands=6, stft_n_fft=64, stft_hop_length=16,
+                                     stft_win_length=64, dim_t=21, sample_rate=100, mlp_expansion_factor=2)
+    c2 = R.RoformerConfig.mel_config(dim=32, depth=1, heads=2, dim_head=64, num_bands=8, stft_n_fft=64, stft_hop_length=16,
+                                     stft_win_length=64, dim_t=21, sample_rate=100, num_stems=2, time_transformer_depth=2,
+                                     freq_transformer_depth=1, target_instrument=None, mask_estimator_depth=2)
+    return c1, c2
+
+
+def test_mel_layout_matches_oracle(A):
+    from audio_separator_amd.mdxc import mel_band_layout
+    for args in ((44100, 2048, 60), (100, 64, 6), (44100, 2048, 64)):
+        assert mel_band_layout(*args) == R.mel_band_layout(*args)
+
+
+def test_mel_forward_golden(A, gm):
+    c1, c2 = mel_cfgs()
+    w = (0.4 * np.random.default_rng(181).standard_normal((2, 2, 320))).astype(np.float32)
+    y = demixer(A, c1, 17, 2).engine.rof_forward(w)
+    assert rel_rms(y[:, 0], gm["fwd1"]) < TOL, rel_rms(y[:, 0], gm["fwd1"])
+    y2 = demixer(A, c2, 18, 8).engine.rof_forward(w)
+    assert rel_rms(y2, gm["fwd2"]) < TOL, rel_rms(y2, gm["fwd2"])
+
+
+def test_mel_demix_golden(A, gm):
+    c1, c2 = mel_cfgs()
+    mix = (0.4 * np.random.default_rng(2090).standard_normal((2, 1000))).astype(np.float32)
+    out = demixer(A, c1, 17, 2, max_batch=3).demix(mix)
+    assert rel_rms(out["vocals"], gm["demix1_primary"]) < TOL, rel_rms(out["vocals"], gm["demix1_primary"])
+    assert rel_rms(out["other"], gm["demix1_secondary"]) < TOL
+    out2 = demixer(A, c2, 18, 8).demix(mix)
+    got = np.stack([out2[k] for k in c2.instruments])
+    assert rel_rms(got, gm["demix2"]) < TOL, rel_rms(got, gm["demix2"])
