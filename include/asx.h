@@ -278,9 +278,10 @@ int asx_ht_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int
  * make_padding, adjust_aggr, merge_artifacts, cmb_spectrogram_to_wave, spectrogram_to_wave, fft_lp/hp_filter).
  * band[d-1] = modelparams JSON "band"[d] (uvr_lib_v5/vr_network/modelparams/ *.json); resampling between bands is the
  * polyphase path (scipy.signal.resample_poly) -- the reference's behaviour on ARM / MPS (spec_utils.py:33-38).
- * Not built: VR 5.1 models (nets_new.CascadedNet), high_end_process. */
+ * Not built: high_end_process. */
 typedef struct asx_vr_band {
   int32_t sr, hl, n_fft, crop_start, crop_stop, hpf_start, hpf_stop, lpf_start, lpf_stop;
+  int32_t convert;        /* VR 5.1 "convert_channels" (spec_utils.py:232-247): 0 none, 1 mid_side, 4 mid_side_c, 5 stereo_n */
 } asx_vr_band;
 typedef struct asx_vr_config {
   int32_t bins, n_bands, pre_filter_start, pre_filter_stop;
@@ -290,6 +291,8 @@ typedef struct asx_vr_config {
   int32_t window_size;    /* arch_config["window_size"] */
   int32_t offset;         /* CascadedASPPNet.offset = 128 */
   int32_t max_batch;      /* patches per forward batch (0 = 4); no effect on the result */
+  int32_t v51;            /* 1: VR 5.1 -- nets_new.CascadedNet(n_fft, nn_arch_size, nout = cap[0], nout_lstm = cap[1]) and the
+                             is_v51_model branches of spec_utils (per-band convert_channels, get_lp/hp_filter_mask); offset 64 */
   asx_vr_band band[8];
 } asx_vr_config;
 typedef struct asx_vr_params {

@@ -524,3 +524,262 @@ def vr_separate(wave, sd, arch, mp: ModelParams, window_size=512, batch_size=1, 
 
 def params_path(name: str) -> str:
     return os.path.join("/root/reference/audio_separator/separator/uvr_lib_v5/vr_network/modelparams", name + ".json")
+
+
+# ==========================================================================
+# VR 5.1: nets_new.CascadedNet (uvr_lib_v5/vr_network/nets_new.py, layers_new.py) and the is_v51_model branches of
+# spec_utils (convert_channels :232, get_lp/hp_filter_mask :399-408, combine_spectrograms :266-268,
+# spectrogram_to_wave :322-329, cmb_spectrogram_to_wave :357-383)
+# ==========================================================================
+def convert_channels(spec, mp: ModelParams, band: int):
+    cc = mp.param["band"][band].get("convert_channels")
+    if cc == "mid_side_c":
+        return np.asarray([np.add(spec[0], spec[1] * 0.25), np.subtract(spec[1], spec[0] * 0.25)])
+    if cc == "mid_side":
+        return np.asarray([np.add(spec[0], spec[1]) / 2, np.subtract(spec[0], spec[1])])
+    if cc == "stereo_n":
+        return np.asarray([np.add(spec[0], spec[1] * 0.25) / 0.9375, np.add(spec[1], spec[0] * 0.25) / 0.9375])
+    return spec
+
+
+def get_lp_filter_mask(n_bins, bin_start, bin_stop):
+    return np.concatenate([np.ones((bin_start - 1, 1)), np.linspace(1, 0, bin_stop - bin_start + 1)[:, None], np.zeros((n_bins - bin_stop, 1))], axis=0)
+
+
+def get_hp_filter_mask(n_bins, bin_start, bin_stop):
+    return np.concatenate([np.zeros((bin_stop + 1, 1)), np.linspace(0, 1, 1 + bin_start - bin_stop)[:, None], np.ones((n_bins - bin_start - 2, 1))], axis=0)
+
+
+def loading_mix_v51(wave: np.ndarray, mp: ModelParams):
+    bands_n = len(mp.param["band"])
+    X_wave, X_spec_s = {}, {}
+    for d in range(bands_n, 0, -1):
+        bp = mp.param["band"][d]
+        if d == bands_n:
+            X_wave[d] = np.asarray(wave, np.float32)
+        else:
+            X_wave[d] = lr_resample(X_wave[d + 1], orig_sr=mp.param["band"][d + 1]["sr"], target_sr=bp["sr"], res_type=bp["res_type"])
+        spec = np.asarray([lr_stft(np.ascontiguousarray(X_wave[d][0]), bp["n_fft"], bp["hl"]),
+                           lr_stft(np.ascontiguousarray(X_wave[d][1]), bp["n_fft"], bp["hl"])])
+        X_spec_s[d] = convert_channels(spec, mp, d)
+    l = min(X_spec_s[i].shape[2] for i in X_spec_s)
+    spec_c = np.zeros((2, mp.param["bins"] + 1, l), dtype=np.complex64)
+    offset = 0
+    for d in range(1, bands_n + 1):
+        bp = mp.param["band"][d]
+        h = bp["crop_stop"] - bp["crop_start"]
+        spec_c[:, offset:offset + h, :l] = X_spec_s[d][:, bp["crop_start"]:bp["crop_stop"], :l]
+        offset += h
+    if offset > mp.param["bins"]:
+        raise ValueError("Too much bins")
+    if mp.param["pre_filter_start"] > 0:
+        spec_c *= get_lp_filter_mask(spec_c.shape[1], mp.param["pre_filter_start"], mp.param["pre_filter_stop"])   # stays complex64
+    return spec_c
+
+
+def spectrogram_to_wave_v51(spec, hop_length, mp: ModelParams, band: int):
+    wl, wr = lr_istft(spec[0], hop_length), lr_istft(spec[1], hop_length)
+    cc = mp.param["band"][band].get("convert_channels")
+    if cc == "mid_side_c":
+        return np.asarray([np.subtract(wl / 1.0625, wr / 4.25), np.add(wr / 1.0625, wl / 4.25)])
+    if cc == "mid_side":
+        return np.asarray([np.add(wl, wr / 2), np.subtract(wl, wr / 2)])
+    if cc == "stereo_n":
+        return np.asarray([np.subtract(wl, wr * 0.25), np.subtract(wr, wl * 0.25)])
+    return np.asarray([wl, wr])
+
+
+def cmb_spectrogram_to_wave_v51(spec_m, mp: ModelParams, res_type="polyphase"):
+    bands_n = len(mp.param["band"])
+    offset = 0
+    wave = None
+    for d in range(1, bands_n + 1):
+        bp = mp.param["band"][d]
+        spec_s = np.zeros((2, bp["n_fft"] // 2 + 1, spec_m.shape[2]), dtype=complex)
+        h = bp["crop_stop"] - bp["crop_start"]
+        spec_s[:, bp["crop_start"]:bp["crop_stop"], :] = spec_m[:, offset:offset + h, :]
+        offset += h
+        if d == bands_n:
+            if bp.get("hpf_start", 0) > 0:
+                spec_s = spec_s * get_hp_filter_mask(spec_s.shape[1], bp["hpf_start"], bp["hpf_stop"] - 1)
+            w = spectrogram_to_wave_v51(spec_s, bp["hl"], mp, d)
+            wave = w if bands_n == 1 else np.add(wave, w)
+        else:
+            sr = mp.param["band"][d + 1]["sr"]
+            if d == 1:
+                spec_s = spec_s * get_lp_filter_mask(spec_s.shape[1], bp["lpf_start"], bp["lpf_stop"])
+                wave = lr_resample(spectrogram_to_wave_v51(spec_s, bp["hl"], mp, d), orig_sr=bp["sr"], target_sr=sr, res_type=res_type)
+            else:
+                spec_s = spec_s * get_hp_filter_mask(spec_s.shape[1], bp["hpf_start"], bp["hpf_stop"] - 1)
+                spec_s = spec_s * get_lp_filter_mask(spec_s.shape[1], bp["lpf_start"], bp["lpf_stop"])
+                wave2 = np.add(wave, spectrogram_to_wave_v51(spec_s, bp["hl"], mp, d))
+                wave = lr_resample(wave2, orig_sr=bp["sr"], target_sr=sr, res_type=res_type)
+    return wave
+
+
+def small_params_v51() -> ModelParams:
+    p = small_params().param
+    p = {k: (dict(v) if isinstance(v, dict) else v) for k, v in p.items()}
+    p["band"] = {d: dict(b) for d, b in p["band"].items()}
+    p["band"][1]["convert_channels"] = "mid_side_c"
+    p["band"][2]["convert_channels"] = "mid_side"
+    p["band"][3]["convert_channels"] = "stereo_n"
+    return ModelParams(p)
+
+
+def make_vr51_state(n_fft_bins: int, nout: int, nout_lstm: int, seed: int = 0) -> dict:
+    """Seeded synthetic weights with nets_new.CascadedNet's state_dict names and shapes."""
+    gen = torch.Generator().manual_seed(seed)
+    sd: dict = {}
+    max_bin = n_fft_bins // 2
+    nin_lstm = max_bin // 2
+
+    def bn(p, c):
+        sd[p + ".weight"] = 0.8 + 0.4 * torch.rand(c, generator=gen)
+        sd[p + ".bias"] = 0.1 * torch.randn(c, generator=gen)
+        sd[p + ".running_mean"] = 0.1 * torch.randn(c, generator=gen)
+        sd[p + ".running_var"] = 0.6 + 0.8 * torch.rand(c, generator=gen)
+        sd[p + ".num_batches_tracked"] = torch.tensor(0.0)
+
+    def cba(p, nin, nout_, k):
+        sd[p + ".conv.0.weight"] = torch.randn(nout_, nin, k, k, generator=gen) * math.sqrt(2.0 / (nin * k * k))
+        bn(p + ".conv.1", nout_)
+
+    def base(p, nin, no, nlstm_in, nlstm_out):
+        cba(f"{p}.enc1", nin, no, 3)
+        chans = [no, no * 2, no * 4, no * 6, no * 8]
+        for i in range(2, 6):
+            cba(f"{p}.enc{i}.conv1", chans[i - 2], chans[i - 1], 3)
+            cba(f"{p}.enc{i}.conv2", chans[i - 1], chans[i - 1], 3)
+        ca = no * 8
+        cba(f"{p}.aspp.conv1.1", ca, ca, 1)
+        cba(f"{p}.aspp.conv2", ca, ca, 1)
+        for j in (3, 4, 5):
+            cba(f"{p}.aspp.conv{j}", ca, ca, 3)
+        cba(f"{p}.aspp.bottleneck", ca * 5, ca, 1)
+        cba(f"{p}.dec4.conv1", no * (6 + 8), no * 6, 3)
+        cba(f"{p}.dec3.conv1", no * (4 + 6), no * 4, 3)
+        cba(f"{p}.dec2.conv1", no * (2 + 4), no * 2, 3)
+        cba(f"{p}.lstm_dec2.conv", no * 2, 1, 1)
+        hs = nlstm_out // 2
+        for sfx in ("", "_reverse"):
+            sd[f"{p}.lstm_dec2.lstm.weight_ih_l0{sfx}"] = torch.randn(4 * hs, nlstm_in, generator=gen) * math.sqrt(1.0 / nlstm_in)
+            sd[f"{p}.lstm_dec2.lstm.weight_hh_l0{sfx}"] = torch.randn(4 * hs, hs, generator=gen) * math.sqrt(1.0 / hs)
+            sd[f"{p}.lstm_dec2.lstm.bias_ih_l0{sfx}"] = 0.1 * torch.randn(4 * hs, generator=gen)
+            sd[f"{p}.lstm_dec2.lstm.bias_hh_l0{sfx}"] = 0.1 * torch.randn(4 * hs, generator=gen)
+        sd[f"{p}.lstm_dec2.dense.0.weight"] = torch.randn(nlstm_in, nlstm_out, generator=gen) * math.sqrt(2.0 / nlstm_out)
+        sd[f"{p}.lstm_dec2.dense.0.bias"] = 0.1 * torch.randn(nlstm_in, generator=gen)
+        bn(f"{p}.lstm_dec2.dense.1", nlstm_in)
+        cba(f"{p}.dec1.conv1", no * (1 + 2) + 1, no, 3)
+
+    base("stg1_low_band_net.0", 2, nout // 2, nin_lstm // 2, nout_lstm)
+    cba("stg1_low_band_net.1", nout // 2, nout // 4, 1)
+    base("stg1_high_band_net", 2, nout // 4, nin_lstm // 2, nout_lstm // 2)
+    base("stg2_low_band_net.0", nout // 4 + 2, nout, nin_lstm // 2, nout_lstm)
+    cba("stg2_low_band_net.1", nout, nout // 2, 1)
+    base("stg2_high_band_net", nout // 4 + 2, nout // 2, nin_lstm // 2, nout_lstm // 2)
+    base("stg3_full_band_net", 3 * nout // 4 + 2, nout, nin_lstm, nout_lstm)
+    sd["out.weight"] = torch.randn(2, nout, 1, 1, generator=gen) * math.sqrt(1.0 / nout)
+    sd["aux_out.weight"] = torch.randn(2, 3 * nout // 4, 1, 1, generator=gen) * 0.1
+    return {k: v.float().contiguous() for k, v in sd.items()}
+
+
+def _cba51(x, sd, p, stride=1, pad=1, dilation=1, leaky=False):
+    return _cba(x, sd, p, stride, pad, dilation, leaky)
+
+
+def _lstm51(x, sd, p):
+    """LSTMModule.forward (layers_new.py:139-149): [N, C, nbins, nframes] -> [N, 1, nbins, nframes]."""
+    N, _, nbins, nframes = x.shape
+    h = _cba51(x, sd, p + ".conv", 1, 0)[:, 0].permute(2, 0, 1)            # nframes, N, nbins
+    hs = sd[p + ".lstm.weight_hh_l0"].shape[1]
+    outs = []
+    for sfx, rev in (("", False), ("_reverse", True)):
+        wih, whh = sd[p + f".lstm.weight_ih_l0{sfx}"], sd[p + f".lstm.weight_hh_l0{sfx}"]
+        bias = sd[p + f".lstm.bias_ih_l0{sfx}"] + sd[p + f".lstm.bias_hh_l0{sfx}"]
+        ht = torch.zeros(N, hs)
+        ct = torch.zeros(N, hs)
+        seq = []
+        steps = range(nframes - 1, -1, -1) if rev else range(nframes)
+        for t in steps:
+            g = F.linear(h[t], wih) + F.linear(ht, whh) + bias
+            i, f, gg, o = g.chunk(4, dim=1)
+            ct = torch.sigmoid(f) * ct + torch.sigmoid(i) * torch.tanh(gg)
+            ht = torch.sigmoid(o) * torch.tanh(ct)
+            seq.append(ht)
+        if rev:
+            seq = seq[::-1]
+        outs.append(torch.stack(seq))
+    y = torch.cat(outs, dim=-1).reshape(-1, 2 * hs)
+    y = F.linear(y, sd[p + ".dense.0.weight"], sd[p + ".dense.0.bias"])
+    y = F.relu(F.batch_norm(y, sd[p + ".dense.1.running_mean"], sd[p + ".dense.1.running_var"], sd[p + ".dense.1.weight"],
+                            sd[p + ".dense.1.bias"], False, 0.0, 1e-5))
+    return y.reshape(nframes, N, 1, nbins).permute(1, 2, 3, 0)
+
+
+def _base51(x, sd, p, dilations=((4, 2), (8, 4), (12, 6))):
+    """BaseNet.__call__ (nets_new.py:40-56)."""
+    def dec(h, skip, name):
+        h = F.interpolate(h, scale_factor=2, mode="bilinear", align_corners=True)
+        d = skip.shape[3] - h.shape[3]
+        if d < 0:
+            raise ValueError("h1_shape[3] must be greater than h2_shape[3]")
+        if d:
+            skip = skip[:, :, :, d // 2: d // 2 + h.shape[3]]
+        return _cba51(torch.cat([h, skip], dim=1), sd, f"{p}.{name}.conv1", 1, 1)
+
+    e1 = _cba51(x, sd, f"{p}.enc1", 1, 1)
+    es = [e1]
+    h = e1
+    for i in range(2, 6):
+        h = _cba51(h, sd, f"{p}.enc{i}.conv1", 2, 1, leaky=True)
+        h = _cba51(h, sd, f"{p}.enc{i}.conv2", 1, 1, leaky=True)
+        es.append(h)
+    a = f"{p}.aspp"
+    _, _, hh, ww = h.shape
+    f1 = F.interpolate(_cba51(F.adaptive_avg_pool2d(h, (1, None)), sd, a + ".conv1.1", 1, 0), size=(hh, ww), mode="bilinear", align_corners=True)
+    feats = [f1, _cba51(h, sd, a + ".conv2", 1, 0)] + [_cba51(h, sd, a + f".conv{j}", 1, dilations[j - 3], dilations[j - 3]) for j in (3, 4, 5)]
+    h = _cba51(torch.cat(feats, dim=1), sd, a + ".bottleneck", 1, 0)
+    h = dec(h, es[3], "dec4")
+    h = dec(h, es[2], "dec3")
+    h = dec(h, es[1], "dec2")
+    h = torch.cat([h, _lstm51(h, sd, f"{p}.lstm_dec2")], dim=1)
+    return dec(h, es[0], "dec1")
+
+
+@torch.no_grad()
+def cascaded51_forward(x, sd: dict, n_fft_bins: int):
+    """CascadedNet.forward, eval (nets_new.py:115-150)."""
+    x = torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32)
+    max_bin = n_fft_bins // 2
+    out_bin = n_fft_bins // 2 + 1
+    x = x[:, :, :max_bin]
+    bw = x.shape[2] // 2
+    l1_in, h1_in = x[:, :, :bw], x[:, :, bw:]
+    l1 = _cba51(_base51(l1_in, sd, "stg1_low_band_net.0"), sd, "stg1_low_band_net.1", 1, 0)
+    h1 = _base51(h1_in, sd, "stg1_high_band_net")
+    aux1 = torch.cat([l1, h1], dim=2)
+    l2 = _cba51(_base51(torch.cat([l1_in, l1], dim=1), sd, "stg2_low_band_net.0"), sd, "stg2_low_band_net.1", 1, 0)
+    h2 = _base51(torch.cat([h1_in, h1], dim=1), sd, "stg2_high_band_net")
+    aux2 = torch.cat([l2, h2], dim=2)
+    f3 = _base51(torch.cat([x, aux1, aux2], dim=1), sd, "stg3_full_band_net")
+    mask = torch.sigmoid(F.conv2d(f3, sd["out.weight"]))
+    return F.pad(mask, (0, 0, 0, out_bin - mask.shape[2]), mode="replicate").numpy()
+
+
+def predict_mask51(x, sd, n_fft_bins, offset=64):
+    m = cascaded51_forward(x, sd, n_fft_bins)
+    return m[:, :, :, offset:-offset] if offset > 0 else m
+
+
+def vr_separate_v51(wave, sd, mp: ModelParams, window_size=512, batch_size=1, aggression=5, is_non_accom_stem=False,
+                    enable_tta=False, enable_post_process=False, post_process_threshold=0.2, offset=64):
+    aggr = {"value": float(int(aggression) / 100), "split_bin": mp.param["band"][1]["crop_stop"],
+            "aggr_correction": mp.param.get("aggr_correction")}
+    X_spec = loading_mix_v51(wave, mp)
+    nb = mp.param["bins"] * 2
+    y_spec, v_spec = inference_vr(X_spec, lambda x: predict_mask51(x, sd, nb, offset), window_size, offset, batch_size, aggr,
+                                  is_non_accom_stem, enable_tta, enable_post_process, post_process_threshold)
+    y_spec = np.nan_to_num(y_spec, nan=0.0, posinf=0.0, neginf=0.0)
+    v_spec = np.nan_to_num(v_spec, nan=0.0, posinf=0.0, neginf=0.0)
+    return cmb_spectrogram_to_wave_v51(y_spec, mp).T, cmb_spectrogram_to_wave_v51(v_spec, mp).T

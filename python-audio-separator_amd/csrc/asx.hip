@@ -1855,7 +1855,7 @@ int asx_vr_begin(asx_engine *e, const asx_vr_config *cfg) {
   REQUIRE(e && cfg, "asx_vr_begin: null argument");
   REQUIRE(cfg->n_bands >= 1 && cfg->n_bands <= 8 && cfg->bins >= 32, "bad band layout");
   REQUIRE(cfg->channel_mode >= 0 && cfg->channel_mode <= 3, "bad channel_mode");
-  for (int i = 0; i < 5; ++i) REQUIRE(cfg->cap[i] >= 4 && cfg->cap[i] % 4 == 0, "net widths must be multiples of 4");
+  for (int i = 0; i < (cfg->v51 ? 2 : 5); ++i) REQUIRE(cfg->cap[i] >= 4 && cfg->cap[i] % 4 == 0, "net widths must be multiples of 4");
   REQUIRE(cfg->window_size >= 16 && cfg->offset >= 0, "bad window_size / offset");
   for (int d = 0; d < cfg->n_bands; ++d)
     REQUIRE(cfg->band[d].sr > 0 && cfg->band[d].hl > 0 && cfg->band[d].n_fft >= 8 && cfg->band[d].n_fft % 2 == 0, "band %d: bad sr / hl / n_fft",
@@ -1911,12 +1911,12 @@ int asx_vr_forward(asx_engine *e, const float *x_host, int32_t B, float *out_hos
   BufGuard g{{&dx, &dy}};
   CHK(to_dev(dx, x_host, numel));
   CHK(dy.ensure(numel * 4));
-  CHK(vr_ensure_workspace(e, B));
+  CHK(n.cfg.v51 ? vr51_ensure_workspace(e, B) : vr_ensure_workspace(e, B));
   const int64_t P = (int64_t)B * n.max_bin * W;
   hipLaunchKernelGGL(vr_from_nchw_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, nullptr, dx.f(), n.nb1, n.max_bin, W, n.ctot,
                      n.b.hc, P);
   HIPCHK(hipGetLastError());
-  CHK(vr_net_dev(e, B, nullptr));
+  CHK(n.cfg.v51 ? vr51_net_dev(e, B, nullptr) : vr_net_dev(e, B, nullptr));
   hipLaunchKernelGGL(vr_to_nchw_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, nullptr, n.b.mk, n.nb1, n.max_bin, W, dy.f(),
                      (int64_t)numel);
   HIPCHK(hipGetLastError());

@@ -30,8 +30,26 @@ struct VrBand {
   VrFilt ana, syn;    // ana: band d+1 -> d (float32); syn: band d -> d+1 (float64 accumulate)
 };
 
+// VR 5.1 (nets_new.py, layers_new.py)
+struct Vr51Lstm {
+  VrConv conv;          // 2n -> 1 (padded to 4)
+  HtGemm ih, dense;     // [8*hs, nbins] (both directions, b_ih + b_hh), [nbins, 2*hs] with BatchNorm1d folded
+  DevBuf whh;           // [2, 4*hs, hs]
+  int hs = 0, nbins = 0;
+};
+struct Vr51Base {
+  int nin_p = 0, n = 0;
+  VrConv enc1, e1[4], e2[4], aspp1, aspp2, aspp3[3], bott, dec[4];   // dec[0] = dec1 ... dec[3] = dec4
+  Vr51Lstm lstm;
+};
+
 struct VrNet {
   asx_vr_config cfg{};
+  Vr51Base b1l, b1h, b2l, b2h, b3;
+  VrConv c1l, c2l;
+  struct {
+    float *D[4], *T[4], *e5, *o4, *o3, *ol, *hcv, *xs, *xp, *hsq, *ys, *yt;
+  } w51{};
   bool begun = false, ready = false;
   VrBase s1l, s1h, s2, s3;
   VrConv br2, br3, outc;
@@ -72,6 +90,26 @@ static void vr_free(VrNet &n) {
   fc(n.br2);
   fc(n.br3);
   fc(n.outc);
+  for (Vr51Base *bs : {&n.b1l, &n.b1h, &n.b2l, &n.b2h, &n.b3}) {
+    fc(bs->enc1);
+    for (int i = 0; i < 4; ++i) {
+      fc(bs->e1[i]);
+      fc(bs->e2[i]);
+      fc(bs->dec[i]);
+    }
+    for (int i = 0; i < 3; ++i) fc(bs->aspp3[i]);
+    fc(bs->aspp1);
+    fc(bs->aspp2);
+    fc(bs->bott);
+    fc(bs->lstm.conv);
+    for (HtGemm *g : {&bs->lstm.ih, &bs->lstm.dense}) {
+      g->w.release();
+      g->b.release();
+    }
+    bs->lstm.whh.release();
+  }
+  fc(n.c1l);
+  fc(n.c2l);
   for (auto &b : n.band) {
     for (DevBuf *p : {&b.window, &b.tw, &b.gain_syn, &b.ana.h32, &b.ana.h64, &b.syn.h32, &b.syn.h64}) p->release();
   }
@@ -238,26 +276,32 @@ static int vr_design_filter(VrFilt &f, int orig_sr, int target_sr) {
   return ASX_OK;
 }
 
+static int vr51_commit_net(asx_engine *e);
+
 static int vr_commit(asx_engine *e) {
   VrNet &n = *e->vr;
   const asx_vr_config &c = n.cfg;
   n.nb1 = c.bins + 1;
   n.max_bin = c.bins;          // CascadedASPPNet(n_fft = bins * 2): max_bin = n_fft // 2
-  const int ch1 = c.cap[0], c2b = c.cap[1], ch2 = c.cap[2], c3b = c.cap[3], ch3 = c.cap[4];
-  const int lev = c.arch == 129605 ? 5 : 4;
-  REQUIRE(c.bins % (2 << lev) == 0, "bins %d: each half band must halve %d times", c.bins, lev);
-  REQUIRE(c.window_size % (1 << lev) == 0 && c.window_size > 2 * c.offset, "window_size %d must be a multiple of %d and exceed 2*offset",
-          c.window_size, 1 << lev);
-  n.ctot = 4 + ch1 + ch2;
-  CHK(vr_load_base(e, n.s1l, "stg1_low_band_net", 2, ch1, c.arch));
-  CHK(vr_load_base(e, n.s1h, "stg1_high_band_net", 2, ch1, c.arch));
-  CHK(vr_pack_conv(e, n.br2, "stg2_bridge.conv.0.weight", "stg2_bridge.conv.1", c2b, 2 + ch1, 1, vr_xmap(2 + ch1), 4 + ch1, 1));
-  CHK(vr_load_base(e, n.s2, "stg2_full_band_net", c2b, ch2, c.arch));
-  CHK(vr_pack_conv(e, n.br3, "stg3_bridge.conv.0.weight", "stg3_bridge.conv.1", c3b, 2 + ch1 + ch2, 1, vr_xmap(2 + ch1 + ch2),
-                   4 + ch1 + ch2, 1));
-  CHK(vr_load_base(e, n.s3, "stg3_full_band_net", c3b, ch3, c.arch));
-  CHK(vr_pack_conv(e, n.outc, "out.weight", "", 2, ch3, 1, vr_ident(ch3), ch3, 5, 4));
-  REQUIRE(c2b % 4 == 0 && c3b % 4 == 0, "bridge widths must be multiples of 4");
+  if (c.v51) {
+    CHK(vr51_commit_net(e));
+  } else {
+    const int ch1 = c.cap[0], c2b = c.cap[1], ch2 = c.cap[2], c3b = c.cap[3], ch3 = c.cap[4];
+    const int lev = c.arch == 129605 ? 5 : 4;
+    REQUIRE(c.bins % (2 << lev) == 0, "bins %d: each half band must halve %d times", c.bins, lev);
+    REQUIRE(c.window_size % (1 << lev) == 0 && c.window_size > 2 * c.offset, "window_size %d must be a multiple of %d and exceed 2*offset",
+            c.window_size, 1 << lev);
+    n.ctot = 4 + ch1 + ch2;
+    CHK(vr_load_base(e, n.s1l, "stg1_low_band_net", 2, ch1, c.arch));
+    CHK(vr_load_base(e, n.s1h, "stg1_high_band_net", 2, ch1, c.arch));
+    CHK(vr_pack_conv(e, n.br2, "stg2_bridge.conv.0.weight", "stg2_bridge.conv.1", c2b, 2 + ch1, 1, vr_xmap(2 + ch1), 4 + ch1, 1));
+    CHK(vr_load_base(e, n.s2, "stg2_full_band_net", c2b, ch2, c.arch));
+    CHK(vr_pack_conv(e, n.br3, "stg3_bridge.conv.0.weight", "stg3_bridge.conv.1", c3b, 2 + ch1 + ch2, 1, vr_xmap(2 + ch1 + ch2),
+                     4 + ch1 + ch2, 1));
+    CHK(vr_load_base(e, n.s3, "stg3_full_band_net", c3b, ch3, c.arch));
+    CHK(vr_pack_conv(e, n.outc, "out.weight", "", 2, ch3, 1, vr_ident(ch3), ch3, 5, 4));
+    REQUIRE(c2b % 4 == 0 && c3b % 4 == 0, "bridge widths must be multiples of 4");
+  }
   // bands
   const int NB = c.n_bands;
   n.band.assign(NB, VrBand());
@@ -296,7 +340,35 @@ static int vr_commit(asx_engine *e) {
       }
       for (int b = std::max(be, 0); b < nbin; ++b) g[b] = 0.0;
     };
-    if (d == NB - 1) {
+    // VR 5.1: get_hp_filter_mask / get_lp_filter_mask (spec_utils.py:399-408) instead
+    auto hp51 = [&](int bs, int be) {
+      for (int b = 0; b < nbin; ++b) {
+        double m;
+        if (b <= be) m = 0.0;
+        else if (b <= bs + 1) m = (bs - be) > 0 ? (double)(b - be - 1) / (double)(bs - be) : 1.0;   // linspace(0, 1, 1 + bs - be)
+        else m = 1.0;
+        g[b] *= m;
+      }
+    };
+    auto lp51 = [&](int bs, int be) {
+      for (int b = 0; b < nbin; ++b) {
+        double m;
+        if (b < bs - 1) m = 1.0;
+        else if (b < be) m = (be - bs) > 0 ? 1.0 - (double)(b - (bs - 1)) / (double)(be - bs) : 0.0;   // linspace(1, 0, be - bs + 1)
+        else m = 0.0;
+        g[b] *= m;
+      }
+    };
+    if (c.v51) {
+      if (d == NB - 1) {
+        if (B.b.hpf_start > 0) hp51(B.b.hpf_start, B.b.hpf_stop - 1);
+      } else if (d == 0) {
+        lp51(B.b.lpf_start, B.b.lpf_stop);
+      } else {
+        hp51(B.b.hpf_start, B.b.hpf_stop - 1);
+        lp51(B.b.lpf_start, B.b.lpf_stop);
+      }
+    } else if (d == NB - 1) {
       if (B.b.hpf_start > 0) hp(B.b.hpf_start, B.b.hpf_stop - 1);
     } else if (d == 0) {
       lp(B.b.lpf_start, B.b.lpf_stop);
@@ -316,7 +388,14 @@ static int vr_commit(asx_engine *e) {
   // analysis gains over the combined rows (combine_spectrograms, spec_utils.py:266-279), float32 like complex64 *= float
   {
     std::vector<float> g((size_t)n.nb1, 1.0f);
-    if (c.pre_filter_start > 0) {
+    if (c.pre_filter_start > 0 && c.v51) {   // spec_c *= get_lp_filter_mask(bins + 1, start, stop) (spec_utils.py:267-268)
+      const int bs = c.pre_filter_start, be = c.pre_filter_stop;
+      for (int b = 0; b < n.nb1; ++b) {
+        if (b < bs - 1) g[b] = 1.f;
+        else if (b < be) g[b] = (float)((be - bs) > 0 ? 1.0 - (double)(b - (bs - 1)) / (double)(be - bs) : 0.0);
+        else g[b] = 0.f;
+      }
+    } else if (c.pre_filter_start > 0) {
       if (NB == 1) {
         double gg = 1.0;
         for (int b = c.pre_filter_start; b < c.pre_filter_stop; ++b) {
@@ -348,7 +427,7 @@ static int vr_commit(asx_engine *e) {
 
 // ---- net ----------------------------------------------------------------------------------------------------------
 static int vr_conv(asx_engine *e, const VrConv &c, const float *x, int ldc, int64_t x_bs, int B, int H, int W, int stride, float *y,
-                   int ldy, int64_t y_bs, hipStream_t s) {
+                   int ldy, int64_t y_bs, hipStream_t s, int dil_o = 1, int dil_i = 1) {
   HtGeom g;
   g.O = H;
   g.I = W;
@@ -356,8 +435,10 @@ static int vr_conv(asx_engine *e, const VrConv &c, const float *x, int ldc, int6
   g.ldc = ldc;
   g.KO = c.k;
   g.KI = c.k;
-  g.PO = c.k / 2;
-  g.PI = c.k / 2;
+  g.DO = dil_o;
+  g.DI = dil_i;
+  g.PO = (c.k / 2) * dil_o;
+  g.PI = (c.k / 2) * dil_i;
   g.SO = stride;
   g.SI = stride;
   g.OR = H / stride;
@@ -484,9 +565,276 @@ static int vr_net_dev(asx_engine *e, int B, hipStream_t s) {
   return vr_conv(e, n.outc, b.h3, c.cap[4], 0, B, F, W, 1, b.mk, 4, 0, s);
 }
 
+
+// ---- VR 5.1 --------------------------------------------------------------------------------------------------------
+static int vr51_load_base(asx_engine *e, Vr51Base &bs, const std::string &p, int nin, int n, int nbins, int nout_lstm) {
+  bs.n = n;
+  bs.nin_p = nin == 2 ? 4 : nin + 2;     // [x(2) pad(2) | rest]
+  REQUIRE(n % 4 == 0 && nbins % 4 == 0 && nout_lstm % 2 == 0, "VR 5.1 widths must be multiples of 4 (n=%d, lstm bins=%d)", n, nbins);
+  const int cw[5] = {n, 2 * n, 4 * n, 6 * n, 8 * n};
+  CHK(vr_pack_conv(e, bs.enc1, p + ".enc1.conv.0.weight", p + ".enc1.conv.1", n, nin, 3, vr_xmap(nin), bs.nin_p, 1));
+  for (int i = 0; i < 4; ++i) {
+    const std::string en = p + ".enc" + std::to_string(i + 2);
+    CHK(vr_pack_conv(e, bs.e1[i], en + ".conv1.conv.0.weight", en + ".conv1.conv.1", cw[i + 1], cw[i], 3, vr_ident(cw[i]), cw[i], 4));
+    CHK(vr_pack_conv(e, bs.e2[i], en + ".conv2.conv.0.weight", en + ".conv2.conv.1", cw[i + 1], cw[i + 1], 3, vr_ident(cw[i + 1]), cw[i + 1], 4));
+  }
+  const int ca = cw[4];
+  const std::string a = p + ".aspp";
+  CHK(vr_pack_conv(e, bs.aspp1, a + ".conv1.1.conv.0.weight", a + ".conv1.1.conv.1", ca, ca, 1, vr_ident(ca), ca, 1));
+  CHK(vr_pack_conv(e, bs.aspp2, a + ".conv2.conv.0.weight", a + ".conv2.conv.1", ca, ca, 1, vr_ident(ca), ca, 1));
+  for (int j = 0; j < 3; ++j) {
+    const std::string c = a + ".conv" + std::to_string(j + 3);
+    CHK(vr_pack_conv(e, bs.aspp3[j], c + ".conv.0.weight", c + ".conv.1", ca, ca, 3, vr_ident(ca), ca, 1));
+  }
+  CHK(vr_pack_conv(e, bs.bott, a + ".bottleneck.conv.0.weight", a + ".bottleneck.conv.1", ca, 5 * ca, 1, vr_ident(5 * ca), 5 * ca, 1));
+  // decoders: input = [upsampled | skip]
+  for (int i = 3; i >= 1; --i) {   // dec4, dec3, dec2
+    const std::string dn = p + ".dec" + std::to_string(i + 1) + ".conv1";
+    const int cin = cw[i + 1] + cw[i];
+    CHK(vr_pack_conv(e, bs.dec[i], dn + ".conv.0.weight", dn + ".conv.1", cw[i], cin, 3, vr_ident(cin), cin, 1));
+  }
+  {   // dec1: [dec2 out (2n) | lstm (1) pad (3) | enc1 (n)]
+    const int cin = 3 * n + 1;
+    std::vector<int> m(cin);
+    for (int c = 0; c < cin; ++c) m[c] = c <= 2 * n ? c : c + 3;
+    CHK(vr_pack_conv(e, bs.dec[0], p + ".dec1.conv1.conv.0.weight", p + ".dec1.conv1.conv.1", n, cin, 3, m, 3 * n + 4, 1));
+  }
+  // LSTMModule
+  Vr51Lstm &L = bs.lstm;
+  L.hs = nout_lstm / 2;
+  L.nbins = nbins;
+  REQUIRE(L.hs == 4 || L.hs == 8 || L.hs == 16 || L.hs == 32 || L.hs == 64 || L.hs == 128, "LSTM hidden size %d per direction is not built", L.hs);
+  const std::string lp = p + ".lstm_dec2";
+  CHK(vr_pack_conv(e, L.conv, lp + ".conv.conv.0.weight", lp + ".conv.conv.1", 1, 2 * n, 1, vr_ident(2 * n), 2 * n, 1, 4));
+  {
+    const int hs = L.hs, G = 4 * hs;
+    std::vector<float> wih((size_t)2 * G * nbins), bih((size_t)2 * G), whh((size_t)2 * G * hs);
+    const char *sfx[2] = {"", "_reverse"};
+    for (int d = 0; d < 2; ++d) {
+      const float *wi, *wh, *bi, *bh;
+      CHK(get_tensor(e, lp + ".lstm.weight_ih_l0" + sfx[d], (int64_t)G * nbins, &wi));
+      CHK(get_tensor(e, lp + ".lstm.weight_hh_l0" + sfx[d], (int64_t)G * hs, &wh));
+      CHK(get_tensor(e, lp + ".lstm.bias_ih_l0" + sfx[d], G, &bi));
+      CHK(get_tensor(e, lp + ".lstm.bias_hh_l0" + sfx[d], G, &bh));
+      std::copy(wi, wi + (size_t)G * nbins, wih.begin() + (size_t)d * G * nbins);
+      std::copy(wh, wh + (size_t)G * hs, whh.begin() + (size_t)d * G * hs);
+      for (int g = 0; g < G; ++g) bih[(size_t)d * G + g] = bi[g] + bh[g];
+    }
+    L.ih.n = 2 * G;
+    L.ih.k = nbins;
+    CHK(ht_up(L.ih.w, wih));
+    CHK(ht_up(L.ih.b, bih));
+    CHK(ht_up(L.whh, whh));
+    const float *dw, *db, *gam, *bet, *mu, *var;
+    CHK(get_tensor(e, lp + ".dense.0.weight", (int64_t)nbins * 2 * hs, &dw));
+    CHK(get_tensor(e, lp + ".dense.0.bias", nbins, &db));
+    CHK(get_tensor(e, lp + ".dense.1.weight", nbins, &gam));
+    CHK(get_tensor(e, lp + ".dense.1.bias", nbins, &bet));
+    CHK(get_tensor(e, lp + ".dense.1.running_mean", nbins, &mu));
+    CHK(get_tensor(e, lp + ".dense.1.running_var", nbins, &var));
+    std::vector<float> w2((size_t)nbins * 2 * hs), b2((size_t)nbins);
+    for (int r = 0; r < nbins; ++r) {
+      const double sc = (double)gam[r] / sqrt((double)var[r] + 1e-5);
+      b2[r] = (float)(((double)db[r] - (double)mu[r]) * sc + (double)bet[r]);
+      for (int k = 0; k < 2 * hs; ++k) w2[(size_t)r * 2 * hs + k] = (float)((double)dw[(size_t)r * 2 * hs + k] * sc);
+    }
+    L.dense.n = nbins;
+    L.dense.k = 2 * hs;
+    CHK(ht_up(L.dense.w, w2));
+    CHK(ht_up(L.dense.b, b2));
+  }
+  return ASX_OK;
+}
+
+static int vr51_commit_net(asx_engine *e) {
+  VrNet &n = *e->vr;
+  const asx_vr_config &c = n.cfg;
+  const int no = c.arch == 218409 ? 64 : c.cap[0];   // nets_new.py:103
+  const int nl = c.cap[1];
+  REQUIRE(no % 16 == 0, "VR 5.1 nout %d must be a multiple of 16", no);
+  REQUIRE(c.bins % 32 == 0 && c.window_size % 16 == 0 && c.window_size > 2 * c.offset, "bins %d / window_size %d do not halve 4 times", c.bins,
+          c.window_size);
+  const int nin_lstm = n.max_bin / 2;
+  n.ctot = 4 + no / 4 + no / 2;
+  CHK(vr51_load_base(e, n.b1l, "stg1_low_band_net.0", 2, no / 2, nin_lstm / 2, nl));
+  CHK(vr_pack_conv(e, n.c1l, "stg1_low_band_net.1.conv.0.weight", "stg1_low_band_net.1.conv.1", no / 4, no / 2, 1, vr_ident(no / 2), no / 2, 1));
+  CHK(vr51_load_base(e, n.b1h, "stg1_high_band_net", 2, no / 4, nin_lstm / 2, nl / 2));
+  CHK(vr51_load_base(e, n.b2l, "stg2_low_band_net.0", no / 4 + 2, no, nin_lstm / 2, nl));
+  CHK(vr_pack_conv(e, n.c2l, "stg2_low_band_net.1.conv.0.weight", "stg2_low_band_net.1.conv.1", no / 2, no, 1, vr_ident(no), no, 1));
+  CHK(vr51_load_base(e, n.b2h, "stg2_high_band_net", no / 4 + 2, no / 2, nin_lstm / 2, nl / 2));
+  CHK(vr51_load_base(e, n.b3, "stg3_full_band_net", 3 * no / 4 + 2, no, nin_lstm, nl));
+  CHK(vr_pack_conv(e, n.outc, "out.weight", "", 2, no, 1, vr_ident(no), no, 5, 4));
+  return ASX_OK;
+}
+
+template <int HS>
+static void vr51_launch_lstm(const float *xp, const float *whh, int W, int B, float *out, hipStream_t s) {
+  hipLaunchKernelGGL((vr_lstm_seq_kernel<HS>), dim3((unsigned)B, 2), dim3(4 * HS), 0, s, xp, whh, W, B, out);
+}
+
+// BaseNet.__call__ (nets_new.py:40-56): x view [B, H, W, nin_p] -> y view [B, H, W, n]
+static int vr51_base(asx_engine *e, const Vr51Base &bs, const float *x, int x_ld, int64_t x_bs, int B, int H, int W, float *y, int y_ld,
+                     int64_t y_bs, hipStream_t s) {
+  VrNet &nn = *e->vr;
+  auto &w = nn.w51;
+  const int n = bs.n;
+  const int cw[5] = {n, 2 * n, 4 * n, 6 * n, 8 * n};
+  const int up_w[4] = {2 * n + 4, 4 * n, 6 * n, 8 * n};   // width of the upsampled slice of D[i]
+  // D[i] (level i) = [upsampled (up_w[i]) | skip (cw[i])]
+  int hs_[5], ws_[5];
+  for (int i = 0; i < 5; ++i) {
+    hs_[i] = H >> i;
+    ws_[i] = W >> i;
+  }
+  CHK(vr_conv(e, bs.enc1, x, x_ld, x_bs, B, H, W, 1, w.D[0] + up_w[0], up_w[0] + cw[0], 0, s));
+  for (int i = 0; i < 4; ++i) {
+    const int ld_in = up_w[i] + cw[i];
+    CHK(vr_conv(e, bs.e1[i], w.D[i] + up_w[i], ld_in, (int64_t)hs_[i] * ws_[i] * ld_in, B, hs_[i], ws_[i], 2, w.T[i], cw[i + 1], 0, s));
+    if (i < 3) CHK(vr_conv(e, bs.e2[i], w.T[i], cw[i + 1], 0, B, hs_[i + 1], ws_[i + 1], 1, w.D[i + 1] + up_w[i + 1], up_w[i + 1] + cw[i + 1], 0, s));
+    else CHK(vr_conv(e, bs.e2[i], w.T[i], cw[i + 1], 0, B, hs_[4], ws_[4], 1, w.e5, cw[4], 0, s));
+  }
+  // ASPP (layers_new.py:95-126), dilations ((4, 2), (8, 4), (12, 6))
+  const int h = hs_[4], ww = ws_[4], ca = cw[4], catc = 5 * ca;
+  auto &b = nn.b;
+  CHK(vr_ew(e, s, (int64_t)B * ww * ca, 4.0 * B * h * ww * ca, vr_rowmean_kernel, (const float *)w.e5, h, ww, ca, b.pool));
+  CHK(vr_conv(e, bs.aspp1, b.pool, ca, 0, B, 1, ww, 1, b.pool2, ca, 0, s));
+  CHK(vr_ew(e, s, (int64_t)B * h * ww * ca, 4.0 * B * h * ww * ca, vr_bcast_rows_kernel, (const float *)b.pool2, h, ww, ca, b.cat, catc));
+  CHK(vr_conv(e, bs.aspp2, w.e5, ca, 0, B, h, ww, 1, b.cat + ca, catc, 0, s));
+  const int dil[3][2] = {{4, 2}, {8, 4}, {12, 6}};
+  for (int j = 0; j < 3; ++j) CHK(vr_conv(e, bs.aspp3[j], w.e5, ca, 0, B, h, ww, 1, b.cat + (2 + j) * ca, catc, 0, s, dil[j][0], dil[j][1]));
+  CHK(vr_conv(e, bs.bott, b.cat, catc, 0, B, h, ww, 1, b.bn, ca, 0, s));
+  // decoders dec4 .. dec2
+  const float *prev = b.bn;
+  int prev_c = ca;
+  float *outs[4] = {nullptr, w.ol, w.o3, w.o4};
+  const int out_ld[4] = {0, 2 * n + 4, 4 * n, 6 * n};
+  for (int i = 3; i >= 1; --i) {
+    const int ld = up_w[i] + cw[i];
+    CHK(vr_ew(e, s, (int64_t)B * hs_[i] * ws_[i] * (prev_c / 4), 4.0 * B * 5.0 * hs_[i + 1] * ws_[i + 1] * prev_c, vr_upsample2x_kernel, prev,
+              hs_[i + 1], ws_[i + 1], prev_c, i == 3 ? ca : out_ld[i + 1], w.D[i], ld));
+    CHK(vr_conv(e, bs.dec[i], w.D[i], ld, 0, B, hs_[i], ws_[i], 1, outs[i], out_ld[i], 0, s));
+    prev = outs[i];
+    prev_c = cw[i];
+  }
+  // LSTMModule on the dec2 output (level 1)
+  {
+    const Vr51Lstm &L = bs.lstm;
+    const int H1 = hs_[1], W1 = ws_[1], old_ = 2 * n + 4;
+    if (L.nbins != H1) {
+      set_err("VR 5.1 LSTM expects %d frequency rows, the net has %d at that level", L.nbins, H1);
+      return ASX_ERR_INVALID;
+    }
+    CHK(vr_conv(e, L.conv, w.ol, old_, 0, B, H1, W1, 1, w.hcv, 4, 0, s));
+    CHK(vr_ew(e, s, (int64_t)W1 * B * H1, 8.0 * W1 * B * H1, vr_lstm_in_kernel, (const float *)w.hcv, B, H1, W1, 4, w.xs));
+    CHK(ht_linear(e, L.ih, w.xs, H1, (int64_t)W1 * B, w.xp, 8 * L.hs, 0, nullptr, 0, s));
+    CHK(timed(e, ASX_PROF_MISC, 0.0, 4.0 * W1 * B * 10.0 * L.hs, s, [&]() {
+      switch (L.hs) {
+        case 4: vr51_launch_lstm<4>(w.xp, L.whh.f(), W1, B, w.hsq, s); break;
+        case 8: vr51_launch_lstm<8>(w.xp, L.whh.f(), W1, B, w.hsq, s); break;
+        case 16: vr51_launch_lstm<16>(w.xp, L.whh.f(), W1, B, w.hsq, s); break;
+        case 32: vr51_launch_lstm<32>(w.xp, L.whh.f(), W1, B, w.hsq, s); break;
+        case 64: vr51_launch_lstm<64>(w.xp, L.whh.f(), W1, B, w.hsq, s); break;
+        default: vr51_launch_lstm<128>(w.xp, L.whh.f(), W1, B, w.hsq, s); break;
+      }
+    }));
+    CHK(ht_linear(e, L.dense, w.hsq, 2 * L.hs, (int64_t)W1 * B, w.ys, H1, 1, nullptr, 0, s));
+    CHK(vr_ew(e, s, (int64_t)B * H1 * W1, 8.0 * B * H1 * W1, vr_lstm_out_kernel, (const float *)w.ys, B, H1, W1, w.ol, old_, 2 * n));
+  }
+  // dec1
+  {
+    const int ld = up_w[0] + cw[0];
+    CHK(vr_ew(e, s, (int64_t)B * H * W * (up_w[0] / 4), 4.0 * B * 5.0 * hs_[1] * ws_[1] * up_w[0], vr_upsample2x_kernel, (const float *)w.ol, hs_[1], ws_[1],
+              up_w[0], up_w[0], w.D[0], ld));
+    CHK(vr_conv(e, bs.dec[0], w.D[0], ld, 0, B, H, W, 1, y, y_ld, y_bs, s));
+  }
+  return ASX_OK;
+}
+
+static int vr51_ensure_workspace(asx_engine *e, int B) {
+  VrNet &n = *e->vr;
+  if (B <= n.ws_batch) return ASX_OK;
+  const asx_vr_config &c = n.cfg;
+  const int no = c.arch == 218409 ? 64 : c.cap[0];
+  const size_t P = (size_t)B * n.max_bin * c.window_size;
+  size_t off = 0;
+  std::vector<std::pair<float **, size_t>> plan;
+  auto want = [&](float *&p, size_t floats) {
+    plan.push_back({&p, off});
+    off += (floats * 4 + 255) & ~(size_t)255;
+  };
+  auto &b = n.b;
+  auto &w = n.w51;
+  const size_t nm = no;   // widest BaseNet
+  want(b.hc, P * n.ctot);
+  want(b.h3, P * nm);
+  want(b.mk, P * 4);
+  want(w.yt, P * nm);
+  const size_t upw[4] = {2 * nm + 4, 4 * nm, 6 * nm, 8 * nm}, cw[5] = {nm, 2 * nm, 4 * nm, 6 * nm, 8 * nm};
+  for (int i = 0; i < 4; ++i) {
+    want(w.D[i], (P >> (2 * i)) * (upw[i] + cw[i]));
+    want(w.T[i], (P >> (2 * (i + 1))) * cw[i + 1]);
+  }
+  want(w.e5, (P >> 8) * cw[4]);
+  want(w.o4, (P >> 6) * cw[3]);
+  want(w.o3, (P >> 4) * cw[2]);
+  want(w.ol, (P >> 2) * (2 * nm + 4));
+  want(w.hcv, (P >> 2) * 4);
+  const size_t seq = (size_t)B * (c.window_size / 2);
+  const size_t hsmax = std::max(c.cap[1] / 2, 4);
+  want(w.xs, (P >> 2));
+  want(w.xp, seq * 8 * hsmax);
+  want(w.hsq, seq * 2 * hsmax);
+  want(w.ys, (P >> 2));
+  want(b.pool, (size_t)B * c.window_size * cw[4]);
+  want(b.pool2, (size_t)B * c.window_size * cw[4]);
+  want(b.cat, (P >> 8) * 5 * cw[4]);
+  want(b.bn, (P >> 8) * cw[4]);
+  CHK(n.ws.ensure(off));
+  for (auto &pr : plan) *pr.first = reinterpret_cast<float *>(reinterpret_cast<char *>(n.ws.p) + pr.second);
+  n.ws_batch = B;
+  return ASX_OK;
+}
+
+// CascadedNet.forward (nets_new.py:115-150) on B windows already in hc[..., 0:4]
+static int vr51_net_dev(asx_engine *e, int B, hipStream_t s) {
+  VrNet &n = *e->vr;
+  const asx_vr_config &c = n.cfg;
+  auto &b = n.b;
+  const int no = c.arch == 218409 ? 64 : c.cap[0];
+  const int F = n.max_bin, W = c.window_size, ct = n.ctot, bw = F / 2;
+  const int64_t hc_bs = (int64_t)F * W * ct, hi = (int64_t)bw * W * ct;
+  const int a1 = 4, a2 = 4 + no / 4;
+  CHK(vr51_base(e, n.b1l, b.hc, ct, hc_bs, B, bw, W, n.w51.yt, no / 2, 0, s));
+  CHK(vr_conv(e, n.c1l, n.w51.yt, no / 2, 0, B, bw, W, 1, b.hc + a1, ct, hc_bs, s));
+  CHK(vr51_base(e, n.b1h, b.hc + hi, ct, hc_bs, B, bw, W, b.hc + hi + a1, ct, hc_bs, s));
+  CHK(vr51_base(e, n.b2l, b.hc, ct, hc_bs, B, bw, W, n.w51.yt, no, 0, s));
+  CHK(vr_conv(e, n.c2l, n.w51.yt, no, 0, B, bw, W, 1, b.hc + a2, ct, hc_bs, s));
+  CHK(vr51_base(e, n.b2h, b.hc + hi, ct, hc_bs, B, bw, W, b.hc + hi + a2, ct, hc_bs, s));
+  CHK(vr51_base(e, n.b3, b.hc, ct, hc_bs, B, F, W, b.h3, no, 0, s));
+  return vr_conv(e, n.outc, b.h3, no, 0, B, F, W, 1, b.mk, 4, 0, s);
+}
+
 static double vr_flops_patch(const asx_engine *e) {
   const VrNet &n = *e->vr;
   const asx_vr_config &c = n.cfg;
+  if (c.v51) {
+    auto cf = [](const VrConv &v, double pos) { return 2.0 * pos * v.g.n * (double)v.g.k; };
+    auto base51 = [&](const Vr51Base &bs, double P) {
+      double f = cf(bs.enc1, P) + cf(bs.dec[0], P);
+      for (int i = 0; i < 4; ++i) {
+        const double pi = P / (double)(1 << (2 * (i + 1)));
+        f += cf(bs.e1[i], pi) + cf(bs.e2[i], pi);
+        if (i < 3) f += cf(bs.dec[i + 1], pi);
+      }
+      const double pa = P / 256.0;
+      f += cf(bs.aspp2, pa) + cf(bs.bott, pa);
+      for (int j = 0; j < 3; ++j) f += cf(bs.aspp3[j], pa);
+      return f;
+    };
+    const double P = (double)n.max_bin * c.window_size;
+    return base51(n.b1l, P / 2) + base51(n.b1h, P / 2) + base51(n.b2l, P / 2) + base51(n.b2h, P / 2) + base51(n.b3, P) +
+           cf(n.c1l, P / 2) + cf(n.c2l, P / 2);
+  }
   auto base = [&](const VrBase &bs, double P) {
     double f = 0.0;
     double p = P;
@@ -551,7 +899,7 @@ static int vr_analysis_dev(asx_engine *e, const float *wave, int64_t n_samples, 
       len = lo;
     }
     CHK(timed(e, ASX_PROF_STFT, 0.0, 8.0 * len + 16.0 * T * (B.b.crop_stop - B.b.crop_start), s, [&]() {
-      hipLaunchKernelGGL(vr_stft_kernel, dim3(T, 2), dim3(256), stft_lds(B.plan), s, cur, len, B.b.hl, n.cfg.channel_mode,
+      hipLaunchKernelGGL(vr_stft_kernel, dim3(T, 2), dim3(256), stft_lds(B.plan), s, cur, len, B.b.hl, n.cfg.v51 ? B.b.convert : n.cfg.channel_mode,
                          B.b.crop_start, B.b.crop_stop, row_off[d], n.nb1, n.gain_ana.f(), reinterpret_cast<float2 *>(n.X.p),
                          B.window.f(), reinterpret_cast<const float2 *>(B.tw.p), B.plan);
     }));
@@ -565,12 +913,12 @@ static int vr_mask_pass(asx_engine *e, int T, int pad_l, int shift, int patches,
   const asx_vr_config &c = n.cfg;
   const int W = c.window_size, roi = W - 2 * c.offset;
   const int maxB = c.max_batch > 0 ? c.max_batch : 4;
-  CHK(vr_ensure_workspace(e, std::min(maxB, patches)));
+  CHK(c.v51 ? vr51_ensure_workspace(e, std::min(maxB, patches)) : vr_ensure_workspace(e, std::min(maxB, patches)));
   for (int k0 = 0; k0 < patches; k0 += maxB) {
     const int B = std::min(maxB, patches - k0);
     CHK(vr_ew(e, s, (int64_t)B * n.max_bin * W, 16.0 * B * n.max_bin * W, vr_patch_kernel, reinterpret_cast<const float2 *>(n.X.p), T, n.nb1,
               n.max_bin, W, k0, roi, pad_l, reinterpret_cast<const unsigned int *>(n.peak.p), n.b.hc, n.ctot));
-    CHK(vr_net_dev(e, B, s));
+    CHK(c.v51 ? vr51_net_dev(e, B, s) : vr_net_dev(e, B, s));
     CHK(vr_ew(e, s, (int64_t)B * roi * n.nb1, 16.0 * B * roi * n.nb1, vr_mask_kernel, (const float *)n.b.mk, B, n.max_bin, W, c.offset, k0, roi,
               shift, T, n.nb1, tta, M));
   }
@@ -679,7 +1027,7 @@ static int vr_synthesis_dev(asx_engine *e, int which, const float *M, int T, flo
     }
     CHK(timed(e, ASX_PROF_OLA, 0.0, 4.0 * 2 * (T * (double)nf + 2.0 * len), s, [&]() {
       hipLaunchKernelGGL(vr_ola_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, n.frames.f(), n.wss.f(), nf, hop, T, len,
-                         n.cfg.channel_mode, lower, dst);
+                         n.cfg.v51 ? B.b.convert : n.cfg.channel_mode, lower, dst);
     }));
     if (d < NB - 1) {
       if (B.syn.up == 1 && B.syn.down == 1) {

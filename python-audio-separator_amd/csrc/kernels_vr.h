@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void vr_resample_kernel(const float *__restric
 // librosa.stft (centre, zero padding, periodic Hann) of one band, written straight into the combined spectrogram
 // (combine_spectrograms, spec_utils.py:250-281): bins [crop_start, crop_stop) * gain[bin] -> rows row_off + ...
 // of X [2, Tmin, bins+1] (bin fastest).  Channel conversion of wave_to_spectrogram (spec_utils.py:289-300) on load:
-// mode 0 L/R, 1 mid_side ((L+R)/2, L-R), 2 mid_side_b2 (R + L/2, L - R/2), 3 reverse.  grid = (Tmin, 2).
+// mode 0 L/R, 1 mid_side ((L+R)/2, L-R), 2 mid_side_b2 (R + L/2, L - R/2), 3 reverse; VR 5.1 convert_channels
+// (spec_utils.py:232-247, applied to the waveform -- the STFT is linear): 4 mid_side_c, 5 stereo_n.  grid = (Tmin, 2).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vr_stft_kernel(const float *__restrict__ wave, int64_t n, int hop, int mode,
                                                       int crop_start, int crop_stop, int row_off, int nbins1,
@@ -152,6 +153,8 @@ __global__ __launch_bounds__(256) void vr_stft_kernel(const float *__restrict__ 
       const float l = wave[q], r = wave[n + q];
       if (mode == 1) v = ch == 0 ? (l + r) / 2.0f : l - r;
       else if (mode == 2) v = ch == 0 ? r + l * 0.5f : l - r * 0.5f;
+      else if (mode == 4) v = ch == 0 ? l + r * 0.25f : r - l * 0.25f;                       // mid_side_c (spec_utils.py:235)
+      else if (mode == 5) v = ch == 0 ? (l + r * 0.25f) / 0.9375f : (r + l * 0.25f) / 0.9375f;   // stereo_n (:241)
       else v = ch == 0 ? l : r;
     }
     fa[e] = v * window[e];
@@ -360,6 +363,12 @@ __global__ __launch_bounds__(256) void vr_ola_kernel(const float *__restrict__ f
     r = a[0] / 1.25f - 0.4f * a[1];
   } else if (mode == 3) {
     jo = len - 1 - j;
+  } else if (mode == 4) {   // mid_side_c (spec_utils.py:325)
+    l = a[0] / 1.0625f - a[1] / 4.25f;
+    r = a[1] / 1.0625f + a[0] / 4.25f;
+  } else if (mode == 5) {   // stereo_n (:329)
+    l = a[0] - a[1] * 0.25f;
+    r = a[1] - a[0] * 0.25f;
   }
   if (lower != nullptr) {
     l += lower[jo];
@@ -395,6 +404,67 @@ __global__ __launch_bounds__(256) void vr_to_nchw_kernel(const float *__restrict
   const int64_t b = p / 2;
   const int fs = f < max_bin ? f : max_bin - 1;
   y[idx] = m[((b * max_bin + fs) * W + t) * 4 + ch];
+}
+
+// ---------------------------------------------------------------------------
+// VR 5.1 LSTMModule (layers_new.py:129-149).
+// ---------------------------------------------------------------------------
+// hc [B, H, W, ld] channel 0 -> xs [W, B, H]   (hidden.permute(2, 0, 1): nframes, N, nbins)
+__global__ __launch_bounds__(256) void vr_lstm_in_kernel(const float *__restrict__ hc, int B, int H, int W, int ld,
+                                                         float *__restrict__ xs, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over W * B * H, h fastest
+  if (idx >= total) return;
+  const int h = (int)(idx % H);
+  int64_t p = idx / H;
+  const int b = (int)(p % B);
+  const int t = (int)(p / B);
+  xs[idx] = hc[(((int64_t)b * H + h) * W + t) * ld];
+}
+
+// ys [W, B, H] -> dst[b, h, t, ch0] (row stride ld), channels ch0+1 .. ch0+3 zeroed (padding of the concat slot)
+__global__ __launch_bounds__(256) void vr_lstm_out_kernel(const float *__restrict__ ys, int B, int H, int W, float *__restrict__ dst,
+                                                          int ld, int ch0, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * H * W, t fastest
+  if (idx >= total) return;
+  const int t = (int)(idx % W);
+  int64_t p = idx / W;
+  const int h = (int)(p % H);
+  const int b = (int)(p / H);
+  *reinterpret_cast<float4 *>(dst + idx * ld + ch0) = make_float4(ys[((int64_t)t * B + b) * H + h], 0.f, 0.f, 0.f);
+}
+
+// one direction of nn.LSTM over the whole sequence: xp [W, B, 2, 4*hs] = x W_ih^T + b_ih + b_hh (gate order i, f, g, o),
+// whh [2, 4*hs, hs]; out [W, B, 2*hs] (forward half | reverse half).  grid = (B, 2), block = 4*hs threads (hs <= 128):
+// thread g keeps row g of W_hh in registers, h and the gate pre-activations live in LDS.
+template <int HS>
+__global__ __launch_bounds__(4 * HS) void vr_lstm_seq_kernel(const float *__restrict__ xp, const float *__restrict__ whh, int W, int B,
+                                                             float *__restrict__ out) {
+  __shared__ float hsh[HS];
+  __shared__ float gsh[4 * HS];
+  const int b = blockIdx.x, dir = blockIdx.y, g = threadIdx.x;
+  float wr[HS];
+#pragma unroll
+  for (int k = 0; k < HS; ++k) wr[k] = whh[((int64_t)dir * 4 * HS + g) * HS + k];
+  if (g < HS) hsh[g] = 0.f;
+  float c = 0.f;
+  __syncthreads();
+  for (int s = 0; s < W; ++s) {
+    const int t = dir ? W - 1 - s : s;
+    float a = xp[(((int64_t)t * B + b) * 2 + dir) * 4 * HS + g];
+#pragma unroll
+    for (int k = 0; k < HS; ++k) a += wr[k] * hsh[k];
+    gsh[g] = a;
+    __syncthreads();
+    if (g < HS) {
+      const float ig = 1.0f / (1.0f + expf(-gsh[g])), fg = 1.0f / (1.0f + expf(-gsh[HS + g]));
+      const float gg = tanhf(gsh[2 * HS + g]), og = 1.0f / (1.0f + expf(-gsh[3 * HS + g]));
+      c = fg * c + ig * gg;
+      const float h = og * tanhf(c);
+      hsh[g] = h;
+      out[((int64_t)t * B + b) * 2 * HS + dir * HS + g] = h;
+    }
+    __syncthreads();
+  }
 }
 
 }  // namespace asx

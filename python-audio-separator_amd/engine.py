@@ -57,13 +57,13 @@ class _HtCfg(C.Structure):
 
 class _VrBand(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("sr", "hl", "n_fft", "crop_start", "crop_stop", "hpf_start", "hpf_stop", "lpf_start",
-                                         "lpf_stop")]
+                                         "lpf_stop", "convert")]
 
 
 class _VrCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("bins", "n_bands", "pre_filter_start", "pre_filter_stop", "channel_mode", "arch")] + \
                [("cap", C.c_int32 * 6), ("window_size", C.c_int32), ("offset", C.c_int32), ("max_batch", C.c_int32),
-                ("band", _VrBand * 8)]
+                ("v51", C.c_int32), ("band", _VrBand * 8)]
 
 
 class _VrParams(C.Structure):
@@ -510,20 +510,26 @@ class Engine:
 
     # -- VR -----------------------------------------------------------------------
     def load_vr(self, model_params: dict, arch: int, capacity, state_dict: dict, window_size: int = 512, offset: int = 128,
-                max_batch: int = 0):
+                max_batch: int = 0, v51=None):
         """nets.determine_model_capacity(bins * 2, arch) + load_state_dict.  model_params: the modelparams JSON dict
-        (int band keys); capacity: the model_capacity_data table of nets.py:74-86."""
+        (int band keys); capacity: the model_capacity_data table of nets.py:74-86.  v51 = (nout, nout_lstm) selects
+        nets_new.CascadedNet and the is_v51_model branches instead (capacity is then ignored)."""
         mp = model_params
         mode = 3 if mp.get("reverse") else (1 if mp.get("mid_side") else (2 if mp.get("mid_side_b2") else 0))
         nb = len(mp["band"])
-        c = _VrCfg(mp["bins"], nb, mp["pre_filter_start"], mp["pre_filter_stop"], mode, int(arch))
-        for i, v in enumerate((capacity[0][1], capacity[2][1], capacity[3][1], capacity[4][1], capacity[5][1], 0)):
+        c = _VrCfg(mp["bins"], nb, mp["pre_filter_start"], mp["pre_filter_stop"], 0 if v51 else mode, int(arch))
+        caps = (v51[0], v51[1], 0, 0, 0, 0) if v51 else (capacity[0][1], capacity[2][1], capacity[3][1], capacity[4][1], capacity[5][1], 0)
+        for i, v in enumerate(caps):
             c.cap[i] = int(v)
-        c.window_size, c.offset, c.max_batch = int(window_size), int(offset), int(max_batch)
+        c.window_size, c.offset, c.max_batch, c.v51 = int(window_size), int(offset), int(max_batch), int(bool(v51))
+        conv = {None: 0, "mid_side": 1, "mid_side_c": 4, "stereo_n": 5}
         for d in range(1, nb + 1):
             bp = mp["band"][d]
+            cc = bp.get("convert_channels") if v51 else None
+            if cc not in conv:
+                raise NotImplementedError(f"convert_channels {cc!r}")
             c.band[d - 1] = _VrBand(bp["sr"], bp["hl"], bp["n_fft"], bp["crop_start"], bp["crop_stop"], bp.get("hpf_start", 0),
-                                    bp.get("hpf_stop", 0), bp.get("lpf_start", 0), bp.get("lpf_stop", 0))
+                                    bp.get("hpf_stop", 0), bp.get("lpf_start", 0), bp.get("lpf_stop", 0), conv[cc])
         self._check(self._lib.asx_vr_begin(self._h, C.byref(c)))
         for name, t in state_dict.items():
             if hasattr(t, "detach"):

@@ -7,8 +7,9 @@ secondary [n', 2])`` where wave is what ``librosa.load(file, sr=band[N].sr, mono
 reference).  Multiband analysis, patching, the CascadedASPPNet, mask post-processing and the multiband synthesis all run
 in libasx.so (asx_vr_separate).
 
-Resampling between bands uses the polyphase path on every platform (the reference's ARM / MPS behaviour); VR 5.1
-checkpoints (nets_new.CascadedNet) and high_end_process raise NotImplementedError.
+Resampling between bands uses the polyphase path on every platform (the reference's ARM / MPS behaviour).  VR 5.1
+checkpoints (nets_new.CascadedNet: model_data with nout / nout_lstm, or file sizes 56817 / 218409) take the same path
+with the is_v51_model branches; high_end_process raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -59,10 +60,18 @@ def nn_arch_size_from_file(model_path: str) -> int:
 
 class VRDemixer:
     def __init__(self, common_config: dict, arch_config: dict, state_dict: dict, nn_arch_size: int, capacity=None,
-                 offset: int = 128, max_batch: int = 0):
+                 offset: int | None = None, max_batch: int = 0):
         md = common_config.get("model_data", {})
-        if "nout" in md and "nout_lstm" in md or nn_arch_size in VR_5_1:
-            raise NotImplementedError("VR 5.1 models (nets_new.CascadedNet) are not built")
+        # vr_separator.py:38-43,161-170: VR 5.1 = model_data carries nout / nout_lstm, or the file size says so
+        self.model_capacity = (32, 128)
+        self.is_vr_51_model = False
+        if "nout" in md and "nout_lstm" in md:
+            self.model_capacity = (md["nout"], md["nout_lstm"])
+            self.is_vr_51_model = True
+        if nn_arch_size in VR_5_1:
+            self.is_vr_51_model = True
+        if offset is None:
+            offset = 64 if self.is_vr_51_model else 128        # nets_new.py:101 / nets.py:130
         mp = common_config.get("model_params")
         if mp is None:
             here = common_config["vr_params_dir"]
@@ -84,8 +93,10 @@ class VRDemixer:
         bins = self.model_params["bins"]
         self.engine = Engine(MDXConfig(n_fft=2 * bins, hop_length=bins // 2, dim_f=bins, segment_size=8),
                              device=getattr(dev, "index", dev) or 0)
-        self.engine.load_vr(self.model_params, nn_arch_size, capacity or model_capacity(nn_arch_size), state_dict,
-                            window_size=self.window_size, offset=offset, max_batch=max_batch or max(self.batch_size, 4))
+        self.engine.load_vr(self.model_params, nn_arch_size,
+                            None if self.is_vr_51_model else (capacity or model_capacity(nn_arch_size)), state_dict,
+                            window_size=self.window_size, offset=offset, max_batch=max_batch or max(self.batch_size, 4),
+                            v51=self.model_capacity if self.is_vr_51_model else None)
 
     def separate_stems(self, wave: np.ndarray):
         """(primary_source, secondary_source) as [n', 2] arrays (vr_separator.py:211-236, before final_process)."""

@@ -157,6 +157,46 @@ def main():
     out["ms_X_spec"] = Xm
     out["ms_wav"] = spec_utils.cmb_spectrogram_to_wave(Xm.copy(), mpm, is_v51_model=False)
     np.savez_compressed(os.path.join(HERE, "vr_small.npz"), **out)
+    main_v51(wave)
+    print({k: (v.shape, str(v.dtype)) for k, v in out.items()})
+
+
+def main_v51(wave):
+    """VR 5.1: nets_new.CascadedNet + the is_v51_model branches of spec_utils -> vr51_small.npz"""
+    from audio_separator.separator.uvr_lib_v5.vr_network import nets_new
+    out = {}
+    mpo = V.small_params_v51()
+    mp = MP(mpo.param)
+    rng = np.random.default_rng(13)
+    X_wave, X_spec_s = {}, {}
+    bands_n = len(mp.param["band"])
+    for d in range(bands_n, 0, -1):
+        bp = mp.param["band"][d]
+        if d == bands_n:
+            X_wave[d] = wave
+        else:
+            X_wave[d] = sys.modules["librosa"].resample(X_wave[d + 1], orig_sr=mp.param["band"][d + 1]["sr"], target_sr=bp["sr"],
+                                                        res_type=bp["res_type"])
+        X_spec_s[d] = spec_utils.wave_to_spectrogram(X_wave[d], bp["hl"], bp["n_fft"], mp, band=d, is_v51_model=True)
+    X_spec = spec_utils.combine_spectrograms(X_spec_s, mp, is_v51_model=True)
+    out["X_spec"] = X_spec
+    nout, nout_lstm = 16, 16
+    model = nets_new.CascadedNet(mp.param["bins"] * 2, 51000, nout=nout, nout_lstm=nout_lstm)
+    sd = V.make_vr51_state(mp.param["bins"] * 2, nout, nout_lstm, 9)
+    assert set(model.state_dict().keys()) == set(sd.keys()), sorted(set(model.state_dict().keys()) ^ set(sd.keys()))[:6]
+    model.load_state_dict(sd)
+    model.eval()
+    model.offset = 16
+    x = np.abs(rng.standard_normal((2, 2, mp.param["bins"] + 1, 64))).astype(np.float32)
+    with torch.no_grad():
+        out["net_in"] = x
+        out["net_out"] = model.forward(torch.from_numpy(x)).numpy()
+    aggr = {"value": 0.05, "split_bin": mp.param["band"][1]["crop_stop"], "aggr_correction": None}
+    y, v, mask = ref_inference(X_spec, model, 64, 2, aggr, False, False, 0.2)
+    out["inf_mask"] = mask.astype(np.float32)
+    out["wav_y"] = spec_utils.cmb_spectrogram_to_wave(y, mp, is_v51_model=True)
+    out["wav_v"] = spec_utils.cmb_spectrogram_to_wave(v, mp, is_v51_model=True)
+    np.savez_compressed(os.path.join(HERE, "vr51_small.npz"), **out)
     print({k: (v.shape, str(v.dtype)) for k, v in out.items()})
 
 

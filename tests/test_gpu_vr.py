@@ -98,11 +98,46 @@ def test_mid_side_and_non_accom(A, g):
 
 def test_error_paths(A):
     with pytest.raises(NotImplementedError):
-        demixer(A, arch=56817)
-    with pytest.raises(NotImplementedError):
         demixer(A, high_end_process=True)
     dm = demixer(A)
     with pytest.raises(ValueError):
         dm.separate_stems(np.zeros((1, 1000), np.float32))
     with pytest.raises(A.AsxError):
         demixer(A, window_size=60)      # not a multiple of 16
+
+
+# ---- VR 5.1 (nets_new.CascadedNet + is_v51_model branches) --------------------------------------------------------------
+@pytest.fixture(scope="module")
+def g51(golden_dir):
+    return np.load(os.path.join(golden_dir, "vr51_small.npz"))
+
+
+def demixer51(A, **arch_cfg):
+    cfg = {"window_size": 64, "batch_size": 2, "aggression": 5}
+    cfg.update(arch_cfg)
+    return A.VRDemixer({"model_params": V.small_params_v51().param, "primary_stem_name": "Instrumental", "torch_device": 0,
+                        "model_data": {"nout": 16, "nout_lstm": 16}}, cfg, state_dict=V.make_vr51_state(192, 16, 16, 9),
+                       nn_arch_size=56817, offset=16)
+
+
+def test_v51_net_and_analysis_golden(A, g, g51):
+    dm = demixer51(A)
+    y = dm.engine.vr_forward(g51["net_in"])
+    assert rel_rms(y, g51["net_out"]) < TOL, rel_rms(y, g51["net_out"])
+    X = dm.engine.vr_analysis(g["wave"])
+    assert rel_rms(X, g51["X_spec"]) < 2e-5, rel_rms(X, g51["X_spec"])
+
+
+def test_v51_separate_golden(A, g, g51):
+    p, s = demixer51(A).separate_stems(g["wave"])
+    assert rel_rms(p, g51["wav_y"].T) < TOL, rel_rms(p, g51["wav_y"].T)
+    assert rel_rms(s, g51["wav_v"].T) < TOL, rel_rms(s, g51["wav_v"].T)
+
+
+def test_v51_tta_oracle(A, g):
+    mp = V.small_params_v51()
+    sd = V.make_vr51_state(192, 16, 16, 9)
+    wp, ws = V.vr_separate_v51(g["wave"][:, :12001], sd, mp, window_size=64, batch_size=2, aggression=10, enable_tta=True, offset=16)
+    p, s = demixer51(A, aggression=10, enable_tta=True).separate_stems(g["wave"][:, :12001])
+    assert rel_rms(p, wp) < TOL, rel_rms(p, wp)
+    assert rel_rms(s, ws) < TOL, rel_rms(s, ws)

@@ -79,3 +79,22 @@ def test_separate_end_to_end():
     p, s = V.vr_separate(G["wave"], sd, 123821, mp, window_size=64, batch_size=2, aggression=5, offset=16)
     close(p.T, G["wav_y"], 1e-5)
     close(s.T, G["wav_v"], 1e-5)
+
+
+# ---- VR 5.1 (nets_new.CascadedNet, is_v51_model branches) --------------------------------------------------------------
+G51 = np.load(os.path.join(ROOT, "tests", "golden", "vr51_small.npz"))
+
+
+def test_v51_analysis_and_net_golden():
+    mp = V.small_params_v51()
+    close(V.loading_mix_v51(G["wave"], mp), G51["X_spec"], 1e-6)
+    sd = V.make_vr51_state(192, 16, 16, 9)
+    close(V.cascaded51_forward(G51["net_in"], sd, 192), G51["net_out"])
+
+
+def test_v51_separate_golden():
+    mp = V.small_params_v51()
+    sd = V.make_vr51_state(192, 16, 16, 9)
+    p, s = V.vr_separate_v51(G["wave"], sd, mp, window_size=64, batch_size=2, aggression=5, offset=16)
+    close(p.T, G51["wav_y"], 1e-5)
+    close(s.T, G51["wav_v"], 1e-5)
