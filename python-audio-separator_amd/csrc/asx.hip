@@ -512,6 +512,29 @@ static void launch_tdf_dma_t(const TdfDmaArgs &a, hipStream_t s) {
   else launch_tdf_dma_tt<NREP, MREP, 32>(a, s);
 }
 
+// tile choice for the LDS-DMA row GEMM: 128 x 192 or 128 x 128 for wide outputs, by a two-term cost model -- padding of
+// the last column tile and wave quantisation over the 512 workgroup slots (2 per CU); the narrower tile moves 20 % more
+// bytes per flop, charged as 4 %.  Measured: N = 512 out-proj / FF2 of BS-Roformer 103 -> 111 TFLOP/s (a third 192-wide tile
+// would be 1/3 empty); HTDemucs transformer linears (43 k rows, N = 384 .. 1536) 73 -> 92 TFLOP/s.
+// ASX_GEMM_T128=0 forces 128 x 192, =2 forces 128 x 128 (tuning aid).
+static void launch_tdf_dma_auto(const TdfDmaArgs &d, hipStream_t s) {
+  static const int t128 = getenv("ASX_GEMM_T128") ? atoi(getenv("ASX_GEMM_T128")) : 1;
+  if (d.N > 128) {
+    const double rows = (double)((d.M + 127) / 128);
+    auto cost = [&](int bn, double eff) {
+      const double blocks = rows * (double)((d.N + bn - 1) / bn);
+      return ceil(blocks / 512.0) * bn / eff;
+    };
+    const bool narrow = t128 == 2 || (t128 == 1 && cost(128, 0.96) < cost(192, 1.0));
+    if (narrow) launch_tdf_dma_t<2, 8>(d, s);
+    else launch_tdf_dma_t<3, 8>(d, s);
+  } else if (d.N > 64) {
+    launch_tdf_dma_t<2, 4>(d, s);
+  } else {
+    launch_tdf_dma_t<1, 4>(d, s);
+  }
+}
+
 static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const float *res, float *y, int64_t M,
                       int T, hipStream_t s, int relu = 1) {
   TdfArgs a{};
@@ -549,9 +572,7 @@ static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const fl
   d.relu = a.relu;
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
     if (dma) {
-      if (L.n > 128) launch_tdf_dma_t<3, 8>(d, s);       // 128 rows x 192 cols per workgroup
-      else if (L.n > 64) launch_tdf_dma_t<2, 4>(d, s);   //  64 x 128
-      else launch_tdf_dma_t<1, 4>(d, s);                 //  64 x 64
+      launch_tdf_dma_auto(d, s);
     } else {
       if (L.n > 128) launch_tdf_t<3, 8>(a, s);
       else if (L.n > 64) launch_tdf_t<2, 4>(a, s);

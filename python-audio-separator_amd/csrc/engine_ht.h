@@ -527,9 +527,7 @@ static int ht_linear(asx_engine *e, const HtGemm &g, const float *x, int64_t lda
   const double flops = 2.0 * (double)M * g.n * g.k;
   const double bytes = 4.0 * ((double)M * g.k + (double)M * g.n * (res ? 2 : 1) + (double)g.n * g.k);
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
-    if (g.n > 128) launch_tdf_dma_t<3, 8>(d, s);
-    else if (g.n > 64) launch_tdf_dma_t<2, 4>(d, s);
-    else launch_tdf_dma_t<1, 4>(d, s);
+    launch_tdf_dma_auto(d, s);
   });
 }
 

@@ -167,9 +167,7 @@ static int rof_gemm(asx_engine *e, const RofLin &L, const float *x, int64_t lda,
   const double flops = 2.0 * (double)M * L.n * L.k;
   const double bytes = 4.0 * ((double)M * L.k + (double)M * L.n * (res ? 2 : 1) + (double)L.n * L.k);
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
-    if (L.n > 128) launch_tdf_dma_t<3, 8>(d, s);
-    else if (L.n > 64) launch_tdf_dma_t<2, 4>(d, s);
-    else launch_tdf_dma_t<1, 4>(d, s);
+    launch_tdf_dma_auto(d, s);
   });
 }
 
