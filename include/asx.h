@@ -278,7 +278,7 @@ int asx_ht_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int
  * make_padding, adjust_aggr, merge_artifacts, cmb_spectrogram_to_wave, spectrogram_to_wave, fft_lp/hp_filter).
  * band[d-1] = modelparams JSON "band"[d] (uvr_lib_v5/vr_network/modelparams/ *.json); resampling between bands is the
  * polyphase path (scipy.signal.resample_poly) -- the reference's behaviour on ARM / MPS (spec_utils.py:33-38).
- * Not built: high_end_process. */
+ */
 typedef struct asx_vr_band {
   int32_t sr, hl, n_fft, crop_start, crop_stop, hpf_start, hpf_stop, lpf_start, lpf_stop;
   int32_t convert;        /* VR 5.1 "convert_channels" (spec_utils.py:232-247): 0 none, 1 mid_side, 4 mid_side_c, 5 stereo_n */
@@ -303,6 +303,7 @@ typedef struct asx_vr_params {
   float corr_left, corr_right;   /* aggr_correction */
   int32_t enable_tta, enable_post_process;
   float post_thres;
+  int32_t high_end_process;   /* arch_config["high_end_process"]: spec_utils.mirroring("mirroring") of the input's high end */
 } asx_vr_params;
 int asx_vr_begin(asx_engine *e, const asx_vr_config *cfg);
 int asx_vr_commit(asx_engine *e);

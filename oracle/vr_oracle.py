@@ -218,7 +218,24 @@ def spectrogram_to_wave(spec, hop_length, mp: ModelParams):
     return np.asarray([wl, wr])
 
 
-def cmb_spectrogram_to_wave(spec_m, mp: ModelParams, res_type="polyphase"):
+def mirroring(spec_m, input_high_end, mp: ModelParams):
+    """spec_utils.mirroring("mirroring", ...) (spec_utils.py:457-462)."""
+    pre = mp.param["pre_filter_start"]
+    mirror = np.flip(np.abs(spec_m[:, pre - 10 - input_high_end.shape[1]: pre - 10, :]), 1)
+    mirror = mirror * np.exp(1.0j * np.angle(input_high_end))
+    return np.where(np.abs(input_high_end) <= np.abs(mirror), input_high_end, mirror)
+
+
+def high_end(wave, mp: ModelParams):
+    """(input_high_end_h, input_high_end) of loading_mix with high_end_process (vr_separator.py:286-288)."""
+    bands_n = len(mp.param["band"])
+    bp = mp.param["band"][bands_n]
+    spec = wave_to_spectrogram(np.asarray(wave, np.float32), bp["hl"], bp["n_fft"], mp)
+    h = (bp["n_fft"] // 2 - bp["crop_stop"]) + (mp.param["pre_filter_stop"] - mp.param["pre_filter_start"])
+    return h, spec[:, bp["n_fft"] // 2 - h: bp["n_fft"] // 2, :]
+
+
+def cmb_spectrogram_to_wave(spec_m, mp: ModelParams, res_type="polyphase", extra_bins_h=None, extra_bins=None):
     bands_n = len(mp.param["band"])
     offset = 0
     wave = None
@@ -229,6 +246,9 @@ def cmb_spectrogram_to_wave(spec_m, mp: ModelParams, res_type="polyphase"):
         spec_s[:, bp["crop_start"]:bp["crop_stop"], :] = spec_m[:, offset:offset + h, :]
         offset += h
         if d == bands_n:
+            if extra_bins_h:
+                max_bin = bp["n_fft"] // 2
+                spec_s[:, max_bin - extra_bins_h: max_bin, :] = extra_bins[:, :extra_bins_h, :]
             if bp.get("hpf_start", 0) > 0:
                 spec_s = fft_hp_filter(spec_s, bp["hpf_start"], bp["hpf_stop"] - 1)
             if bands_n == 1:
@@ -509,7 +529,7 @@ def inference_vr(X_spec, mask_fn, window_size, offset, batch_size, aggressivenes
 
 
 def vr_separate(wave, sd, arch, mp: ModelParams, window_size=512, batch_size=1, aggression=5, is_non_accom_stem=False,
-                enable_tta=False, enable_post_process=False, post_process_threshold=0.2, offset=128):
+                enable_tta=False, enable_post_process=False, post_process_threshold=0.2, offset=128, high_end_process=False):
     """VRSeparator.separate on arrays (vr_separator.py:168-236): wave [2, n] at mp sr -> (primary [n', 2], secondary)."""
     aggr = {"value": float(int(aggression) / 100), "split_bin": mp.param["band"][1]["crop_stop"],
             "aggr_correction": mp.param.get("aggr_correction")}
@@ -519,6 +539,10 @@ def vr_separate(wave, sd, arch, mp: ModelParams, window_size=512, batch_size=1, 
                                   is_non_accom_stem, enable_tta, enable_post_process, post_process_threshold)
     y_spec = np.nan_to_num(y_spec, nan=0.0, posinf=0.0, neginf=0.0)
     v_spec = np.nan_to_num(v_spec, nan=0.0, posinf=0.0, neginf=0.0)
+    if high_end_process:
+        h, ihe = high_end(wave, mp)
+        return (cmb_spectrogram_to_wave(y_spec, mp, extra_bins_h=h, extra_bins=mirroring(y_spec, ihe, mp)).T,
+                cmb_spectrogram_to_wave(v_spec, mp, extra_bins_h=h, extra_bins=mirroring(v_spec, ihe, mp)).T)
     return cmb_spectrogram_to_wave(y_spec, mp).T, cmb_spectrogram_to_wave(v_spec, mp).T
 
 

@@ -1956,6 +1956,7 @@ int asx_vr_analysis(asx_engine *e, const float *wave_host, int64_t n_samples, fl
   DevBuf dw;
   BufGuard g{{&dw}};
   CHK(to_dev(dw, wave_host, (size_t)2 * n_samples));
+  n.he_n = 0;
   CHK(vr_analysis_dev(e, dw.f(), n_samples, T, nullptr));
   CHK(to_host(spec_host, n.X, (size_t)2 * T * n.nb1 * 2));
   return ASX_OK;

@@ -63,7 +63,8 @@ struct VrNet {
     float *hc, *y2, *y3, *h3, *mk, *pool, *pool2, *tmp, *cat, *bn;
     std::vector<float *> D, E, O;
   } b;
-  DevBuf X, M, M2, peak, fmin, wgt, frames, wss;
+  DevBuf X, M, M2, peak, fmin, wgt, frames, wss, HE;
+  int he_n = 0;   // rows kept for high_end_process (0 = off for the current call)
   std::vector<DevBuf> wav_ana, wav_syn, wav_up;
 };
 
@@ -114,7 +115,7 @@ static void vr_free(VrNet &n) {
     for (DevBuf *p : {&b.window, &b.tw, &b.gain_syn, &b.ana.h32, &b.ana.h64, &b.syn.h32, &b.syn.h64}) p->release();
   }
   n.band.clear();
-  for (DevBuf *p : {&n.gain_ana, &n.ws, &n.X, &n.M, &n.M2, &n.peak, &n.fmin, &n.wgt, &n.frames, &n.wss}) p->release();
+  for (DevBuf *p : {&n.gain_ana, &n.ws, &n.X, &n.M, &n.M2, &n.peak, &n.fmin, &n.wgt, &n.frames, &n.wss, &n.HE}) p->release();
   for (auto *v : {&n.wav_ana, &n.wav_syn, &n.wav_up})
     for (auto &d : *v) d.release();
   n.ready = false;
@@ -901,7 +902,8 @@ static int vr_analysis_dev(asx_engine *e, const float *wave, int64_t n_samples, 
     CHK(timed(e, ASX_PROF_STFT, 0.0, 8.0 * len + 16.0 * T * (B.b.crop_stop - B.b.crop_start), s, [&]() {
       hipLaunchKernelGGL(vr_stft_kernel, dim3(T, 2), dim3(256), stft_lds(B.plan), s, cur, len, B.b.hl, n.cfg.v51 ? B.b.convert : n.cfg.channel_mode,
                          B.b.crop_start, B.b.crop_stop, row_off[d], n.nb1, n.gain_ana.f(), reinterpret_cast<float2 *>(n.X.p),
-                         B.window.f(), reinterpret_cast<const float2 *>(B.tw.p), B.plan);
+                         B.window.f(), reinterpret_cast<const float2 *>(B.tw.p), B.plan,
+                         (d == NB - 1 && n.he_n > 0) ? reinterpret_cast<float2 *>(n.HE.p) : nullptr, n.he_n);
     }));
   }
   return ASX_OK;
@@ -1017,7 +1019,9 @@ static int vr_synthesis_dev(asx_engine *e, int which, const float *M, int T, flo
     CHK(timed(e, ASX_PROF_ISTFT, 0.0, 4.0 * 2 * T * (3.0 * (B.b.crop_stop - B.b.crop_start) + nf), s, [&]() {
       hipLaunchKernelGGL(vr_istft_kernel, dim3(T, 2), dim3(256), istft_lds(B.plan), s, reinterpret_cast<const float2 *>(n.X.p), M, which,
                          n.nb1, B.b.crop_start, B.b.crop_stop, row_off, B.gain_syn.f(), n.frames.f(), B.window.f(),
-                         reinterpret_cast<const float2 *>(B.tw.p), B.plan);
+                         reinterpret_cast<const float2 *>(B.tw.p), B.plan,
+                         (d == NB - 1 && n.he_n > 0) ? reinterpret_cast<const float2 *>(n.HE.p) : nullptr, n.he_n,
+                         n.cfg.pre_filter_start - 10 - n.he_n);
     }));
     row_off += B.b.crop_stop - B.b.crop_start;
     float *dst = d == NB - 1 ? out : nullptr;
@@ -1054,6 +1058,18 @@ static int vr_separate_dev(asx_engine *e, const float *wave, int64_t n_samples, 
   int64_t n_out;
   CHK(vr_plan(n, n_samples, &T, &n_out));
   REQUIRE(T >= 2, "input too short: %d frames", T);
+  n.he_n = 0;
+  if (pr->high_end_process) {
+    // input_high_end_h (vr_separator.py:287): bins above the top band's crop + the pre-filter ramp
+    const asx_vr_band &tb = c.band[c.n_bands - 1];
+    const int h = (tb.n_fft / 2 - tb.crop_stop) + (c.pre_filter_stop - c.pre_filter_start);
+    REQUIRE(h > 0 && h <= tb.n_fft / 2 && c.pre_filter_start - 10 - h >= 0, "high_end_process: %d mirrored rows do not fit below pre_filter_start - 10",
+            h);
+    const int t_top = (int)(1 + n_samples / tb.hl);
+    REQUIRE(t_top == T, "high_end_process needs the top band's frame count (%d) to equal the combined spectrogram's (%d)", t_top, T);
+    n.he_n = h;
+    CHK(n.HE.ensure((size_t)2 * T * h * 8));
+  }
   CHK(vr_analysis_dev(e, wave, n_samples, T, s));
   CHK(n.peak.ensure(4));
   HIPCHK(hipMemsetAsync(n.peak.p, 0, 4, s));

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void vr_stft_kernel(const float *__restrict__ 
                                                       int crop_start, int crop_stop, int row_off, int nbins1,
                                                       const float *__restrict__ gain, float2 *__restrict__ X,
                                                       const float *__restrict__ window, const float2 *__restrict__ tw,
-                                                      FftPlan p) {
+                                                      FftPlan p, float2 *__restrict__ he, int he_n) {
   extern __shared__ float2 lds[];
   float2 *bufA = lds;
   float2 *bufB = lds + p.nh;
@@ -174,6 +174,18 @@ __global__ __launch_bounds__(256) void vr_stft_kernel(const float *__restrict__ 
     const float g = gain[row];
     X[((int64_t)ch * T + t) * nbins1 + row] = make_float2(v.x * g, v.y * g);
   }
+  // high_end_process (vr_separator.py:286-288): keep bins [n_fft/2 - he_n, n_fft/2) of the top band, he [2, T, he_n]
+  if (he != nullptr)
+    for (int i = threadIdx.x; i < he_n; i += blockDim.x) {
+      const int k = nh - he_n + i;
+      const float2 zk = Z[k];
+      float2 zc = Z[k == 0 ? 0 : nh - k];
+      zc.y = -zc.y;
+      const float2 E = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+      const float2 D = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
+      const float2 O = make_float2(D.y, -D.x);
+      he[((int64_t)ch * T + t) * he_n + i] = cadd(E, cmul(tw[k], O));
+    }
 }
 
 // max |X| (np.abs of complex64 = hypotf) -> float bits via atomicMax; X has n complex elements
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(256) void vr_istft_kernel(const float2 *__restrict_
                                                        int nbins1, int crop_start, int crop_stop, int row_off,
                                                        const float *__restrict__ gain, float *__restrict__ frames,
                                                        const float *__restrict__ window, const float2 *__restrict__ tw,
-                                                       FftPlan p) {
+                                                       FftPlan p, const float2 *__restrict__ he, int he_n, int mirror_row) {
   extern __shared__ float2 lds[];
   float2 *bufA = lds;
   float2 *bufB = lds + p.nh;
@@ -305,6 +317,30 @@ __global__ __launch_bounds__(256) void vr_istft_kernel(const float2 *__restrict_
       v = make_float2(mk * x.x * g, mk * x.y * g);
       if (!isfinite(v.x)) v.x = 0.f;
       if (!isfinite(v.y)) v.y = 0.f;
+    }
+    if (he != nullptr && k >= nh - he_n && k < nh) {
+      // spec_utils.mirroring("mirroring") + the extra_bins splice of cmb_spectrogram_to_wave (:351-354): bin i of the
+      // kept high end competes with the flipped magnitude of the separated spectrogram below pre_filter_start - 10,
+      // carried on the input's phase; the smaller magnitude wins
+      const int i = k - (nh - he_n);
+      const int64_t src = ((int64_t)ch * T + t) * nbins1 + mirror_row + (he_n - 1 - i);
+      float mk = 1.0f;
+      if (M != nullptr) {
+        mk = M[src];
+        if (which) mk = 1.0f - mk;
+      }
+      const float2 x = X[src];
+      float2 sm = make_float2(mk * x.x, mk * x.y);
+      if (!isfinite(sm.x)) sm.x = 0.f;
+      if (!isfinite(sm.y)) sm.y = 0.f;
+      const float mag = hypotf(sm.x, sm.y);
+      const float2 ie = he[((int64_t)ch * T + t) * he_n + i];
+      const float ia = hypotf(ie.x, ie.y);
+      const float ang = atan2f(ie.y, ie.x);
+      const float2 mir = make_float2(mag * cosf(ang), mag * sinf(ang));
+      const float2 o = (ia <= hypotf(mir.x, mir.y)) ? ie : mir;
+      const float g = gain[k];
+      v = make_float2(o.x * g, o.y * g);
     }
     if (k == 0 || k == nh) v.y = 0.f;
     bufX[k] = v;

@@ -69,7 +69,7 @@ class _VrCfg(C.Structure):
 class _VrParams(C.Structure):
     _fields_ = [("aggr_value", C.c_float), ("split_bin", C.c_int32), ("is_non_accom", C.c_int32), ("has_corr", C.c_int32),
                 ("corr_left", C.c_float), ("corr_right", C.c_float), ("enable_tta", C.c_int32),
-                ("enable_post_process", C.c_int32), ("post_thres", C.c_float)]
+                ("enable_post_process", C.c_int32), ("post_thres", C.c_float), ("high_end_process", C.c_int32)]
 
 
 class _Plan(C.Structure):
@@ -565,7 +565,8 @@ class Engine:
         return np.ascontiguousarray(buf.view(np.complex64)[..., 0].transpose(0, 2, 1))
 
     def vr_separate(self, wave: np.ndarray, aggr_value: float, split_bin: int, is_non_accom: bool = False, aggr_correction=None,
-                    enable_tta: bool = False, enable_post_process: bool = False, post_thres: float = 0.2):
+                    enable_tta: bool = False, enable_post_process: bool = False, post_thres: float = 0.2,
+                    high_end_process: bool = False):
         wave = _f32(wave)
         if wave.ndim != 2 or wave.shape[0] != 2:
             raise ValueError(f"Expected a 2-channel audio signal, but got shape {wave.shape}")
@@ -573,7 +574,7 @@ class Engine:
         corr = aggr_correction or {}
         pr = _VrParams(float(aggr_value), int(split_bin), int(bool(is_non_accom)), int(aggr_correction is not None),
                        float(corr.get("left", 0.0)), float(corr.get("right", 0.0)), int(bool(enable_tta)),
-                       int(bool(enable_post_process)), float(post_thres))
+                       int(bool(enable_post_process)), float(post_thres), int(bool(high_end_process)))
         p = np.empty((2, n_out), np.float32)
         q = np.empty((2, n_out), np.float32)
         self._check(self._lib.asx_vr_separate(self._h, _ptr(wave), wave.shape[1], C.byref(pr), _ptr(p), _ptr(q)))
@@ -583,7 +584,7 @@ class Engine:
                         split_bin: int, is_non_accom: bool = False, enable_tta: bool = False, enable_post_process: bool = False,
                         post_thres: float = 0.2, stream: int = 0):
         pr = _VrParams(float(aggr_value), int(split_bin), int(bool(is_non_accom)), 0, 0.0, 0.0, int(bool(enable_tta)),
-                       int(bool(enable_post_process)), float(post_thres))
+                       int(bool(enable_post_process)), float(post_thres), 0)
         self._check(self._lib.asx_vr_separate_dev(self._h, wave_ptr, n_samples, C.byref(pr), primary_ptr or None,
                                                   secondary_ptr or None, stream or None))
 

@@ -9,7 +9,7 @@ in libasx.so (asx_vr_separate).
 
 Resampling between bands uses the polyphase path on every platform (the reference's ARM / MPS behaviour).  VR 5.1
 checkpoints (nets_new.CascadedNet: model_data with nout / nout_lstm, or file sizes 56817 / 218409) take the same path
-with the is_v51_model branches; high_end_process raises NotImplementedError.
+with the is_v51_model branches.
 """
 from __future__ import annotations
 
@@ -83,8 +83,7 @@ class VRDemixer:
         self.post_process_threshold = arch_config.get("post_process_threshold", 0.2)
         self.batch_size = arch_config.get("batch_size", 1)
         self.window_size = arch_config.get("window_size", 512)
-        if arch_config.get("high_end_process", False):
-            raise NotImplementedError("high_end_process (mirroring) is not built")
+        self.high_end_process = bool(arch_config.get("high_end_process", False))
         self.aggression = float(int(arch_config.get("aggression", 5)) / 100)
         self.aggressiveness = {"value": self.aggression, "split_bin": self.model_params["band"][1]["crop_stop"],
                                "aggr_correction": self.model_params.get("aggr_correction")}
@@ -103,5 +102,6 @@ class VRDemixer:
         p, s = self.engine.vr_separate(wave, self.aggressiveness["value"], self.aggressiveness["split_bin"],
                                        is_non_accom=self.primary_stem_name in NON_ACCOM_STEMS,
                                        aggr_correction=self.aggressiveness["aggr_correction"], enable_tta=self.enable_tta,
-                                       enable_post_process=self.enable_post_process, post_thres=self.post_process_threshold)
+                                       enable_post_process=self.enable_post_process, post_thres=self.post_process_threshold,
+                                       high_end_process=self.high_end_process)
         return p.T, s.T

@@ -149,6 +149,13 @@ def main():
                 if name == "plain":
                     out["wav_y"] = spec_utils.cmb_spectrogram_to_wave(y, mp, is_v51_model=False)
                     out["wav_v"] = spec_utils.cmb_spectrogram_to_wave(v, mp, is_v51_model=False)
+                    # high_end_process (vr_separator.py:286-288, 368-372)
+                    bp = mp.param["band"][3]
+                    top = spec_utils.wave_to_spectrogram(wave, bp["hl"], bp["n_fft"], mp, band=3, is_v51_model=False)
+                    h = (bp["n_fft"] // 2 - bp["crop_stop"]) + (mp.param["pre_filter_stop"] - mp.param["pre_filter_start"])
+                    ihe = top[:, bp["n_fft"] // 2 - h: bp["n_fft"] // 2, :]
+                    out["he_wav_y"] = spec_utils.cmb_spectrogram_to_wave(y, mp, h, spec_utils.mirroring("mirroring", y, ihe, mp), is_v51_model=False)
+                    out["he_wav_v"] = spec_utils.cmb_spectrogram_to_wave(v, mp, h, spec_utils.mirroring("mirroring", v, ihe, mp), is_v51_model=False)
     # a mid-side parameter set through analysis + synthesis
     pm = dict(mp_o.param)
     pm["mid_side"] = True

@@ -97,8 +97,6 @@ def test_mid_side_and_non_accom(A, g):
 
 
 def test_error_paths(A):
-    with pytest.raises(NotImplementedError):
-        demixer(A, high_end_process=True)
     dm = demixer(A)
     with pytest.raises(ValueError):
         dm.separate_stems(np.zeros((1, 1000), np.float32))
@@ -141,3 +139,9 @@ def test_v51_tta_oracle(A, g):
     p, s = demixer51(A, aggression=10, enable_tta=True).separate_stems(g["wave"][:, :12001])
     assert rel_rms(p, wp) < TOL, rel_rms(p, wp)
     assert rel_rms(s, ws) < TOL, rel_rms(s, ws)
+
+
+def test_high_end_process_golden(A, g):
+    p, s = demixer(A, high_end_process=True).separate_stems(g["wave"])
+    assert rel_rms(p, g["he_wav_y"].T) < TOL, rel_rms(p, g["he_wav_y"].T)
+    assert rel_rms(s, g["he_wav_v"].T) < TOL, rel_rms(s, g["he_wav_v"].T)

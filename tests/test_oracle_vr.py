@@ -98,3 +98,12 @@ def test_v51_separate_golden():
     p, s = V.vr_separate_v51(G["wave"], sd, mp, window_size=64, batch_size=2, aggression=5, offset=16)
     close(p.T, G51["wav_y"], 1e-5)
     close(s.T, G51["wav_v"], 1e-5)
+
+
+def test_high_end_process_golden():
+    mp = V.small_params()
+    sd = V.make_vr_state(123821, 5, SMALL_CAP)
+    p, s = V.vr_separate(G["wave"], sd, 123821, mp, window_size=64, batch_size=2, aggression=5, offset=16, high_end_process=True)
+    close(p.T, G["he_wav_y"], 1e-5)
+    close(s.T, G["he_wav_v"], 1e-5)
+    assert np.abs(G["he_wav_y"] - G["wav_y"]).max() > 1e-4     # the option changes the result
