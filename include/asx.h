@@ -199,6 +199,10 @@ int asx_mdxc_plan(const asx_engine *e, int64_t n_samples, int32_t overlap, asx_p
 /* MDXCSeparator.demix, TFC branch (mdxc_separator.py:345-404): mix [2,N] -> out [S,2,N]
  * (= accumulated[..., chunk-hop : -(pad+chunk-hop)] / overlap). */
 int asx_mdxc_demix(asx_engine *e, const float *mix_host, int64_t n_samples, int32_t overlap, float *out_host);
+/* halves of asx_mdxc_demix_dev for multi-GPU sharding: chunk_out [n_chunks (asx_mdxc_plan), S, 2, chunk_size] */
+int asx_mdxc_chunks_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t overlap, int32_t k0, int32_t k1,
+                        float *chunk_out_dev, void *stream);
+int asx_mdxc_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t n_samples, int32_t overlap, float *out_dev, void *stream);
 int asx_mdxc_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t overlap, float *out_dev,
                        void *stream);
 
@@ -234,6 +238,11 @@ int asx_rof_forward(asx_engine *e, const float *wave_host, int32_t batch, float 
 int asx_rof_demix(asx_engine *e, const float *mix_host, int64_t n_samples, int64_t step, float *out_host);
 int asx_rof_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int64_t step, float *out_dev,
                       void *stream);
+/* halves of asx_rof_demix_dev for multi-GPU sharding: chunk_out [n_chunks, S, 2, chunk_size] */
+int asx_rof_plan(const asx_engine *e, int64_t n_samples, int64_t step, int32_t *n_chunks, int64_t *chunk_size);
+int asx_rof_chunks_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int64_t step, int32_t k0, int32_t k1,
+                       float *chunk_out_dev, void *stream);
+int asx_rof_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t n_samples, int64_t step, float *out_dev, void *stream);
 
 /* ---- Demucs v4 / HTDemucs -----------------------------------------------------
  * Replaces HTDemucs(**kwargs) + load_state_dict (uvr_lib_v5/demucs/htdemucs.py:32-382, demucs_separator.py:121-134),
@@ -270,6 +279,15 @@ int asx_ht_demix(asx_engine *e, const float *mix_host, int64_t n_samples, int32_
                  double overlap, uint32_t flags, float *out_host);
 int asx_ht_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t shifts, const int64_t *offsets,
                      double overlap, uint32_t flags, float *out_dev, void *stream);
+/* The two halves of asx_ht_demix_dev for multi-GPU sharding: the segment-forwards of a call form one list
+ * (shift 0's chunks, shift 1's, ...; asx_ht_plan gives its length); a rank runs any sub-range, the folding rank needs all
+ * of them: chunk_out [n_segments, S, 2, segment_samples]. */
+int asx_ht_plan(const asx_engine *e, int64_t n_samples, int32_t shifts, const int64_t *offsets, double overlap, int32_t *n_segments,
+                int64_t *segment_samples);
+int asx_ht_segments_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t shifts, const int64_t *offsets, double overlap,
+                        uint32_t flags, int32_t k0, int32_t k1, float *chunk_out_dev, void *stream);
+int asx_ht_fold_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t shifts, const int64_t *offsets, double overlap,
+                    uint32_t flags, const float *chunk_out_dev, float *out_dev, void *stream);
 
 /* ---- VR architecture -----------------------------------------------------------------
  * Replaces nets.determine_model_capacity(...) + load_state_dict (architectures/vr_separator.py:168-176,

@@ -485,3 +485,65 @@ def demix_demucs(mix: np.ndarray, sd: dict, cfg: HTConfig, shifts=2, overlap=0.2
     src = (src * ref.std() + ref.mean()).numpy()
     src[[0, 1]] = src[[1, 0]]
     return src
+
+
+# --------------------------------------------------------------------------
+# segment-list form of demix_demucs (test double of asx_ht_plan / asx_ht_segments_dev / asx_ht_fold_dev)
+# --------------------------------------------------------------------------
+def segment_plan(n: int, cfg: HTConfig, shifts, offsets, overlap=0.25):
+    """[(shift index, view base, view length, chunk offset, chunk length)] in the reference's order"""
+    seg = cfg.training_length
+    stride = int((1 - overlap) * seg)
+    max_shift = int(0.5 * cfg.samplerate) if shifts else 0
+    plan = []
+    for si in range(max(shifts, 1)):
+        off = offsets[si] if shifts else 0
+        vl = n + max_shift - off
+        for o in range(0, vl, stride):
+            plan.append((si, off, vl, o, min(vl - o, seg)))
+    return plan, stride, max_shift
+
+
+def _standardized(mix):
+    m = torch.tensor(np.asarray(mix, np.float32))
+    ref = m.mean(0)
+    return (m - ref.mean()) / ref.std(), ref
+
+
+def demucs_segments(mix, sd, cfg: HTConfig, shifts, offsets, overlap, k0, k1):
+    m, _ = _standardized(mix)
+    n = m.shape[1]
+    plan, _, max_shift = segment_plan(n, cfg, shifts, offsets, overlap)
+    padded = F.pad(m, (max_shift, max_shift))
+    outs = []
+    for (si, off, vl, o, clen) in plan[k0:k1]:
+        x, _ = _padded(padded[None], off + o, clen, cfg.training_length)
+        outs.append(ht_forward(x.numpy(), sd, cfg)[0])
+    S = len(cfg.sources)
+    return np.stack(outs).astype(np.float32) if outs else np.zeros((0, S, 2, cfg.training_length), np.float32)
+
+
+def demucs_fold(mix, chunks, cfg: HTConfig, shifts, offsets, overlap):
+    m, ref = _standardized(mix)
+    n = m.shape[1]
+    plan, stride, max_shift = segment_plan(n, cfg, shifts, offsets, overlap)
+    seg = cfg.training_length
+    S = len(cfg.sources)
+    weight = torch.cat([torch.arange(1, seg // 2 + 1), torch.arange(seg - seg // 2, 0, -1)])
+    weight = (weight / weight.max()) ** 1.0
+    total = 0
+    for si in range(max(shifts, 1)):
+        items = [(k, p) for k, p in enumerate(plan) if p[0] == si]
+        off, vl = items[0][1][1], items[0][1][2]
+        out = torch.zeros(S, 2, vl)
+        sw = torch.zeros(vl)
+        for k, (_, _, _, o, clen) in items:
+            y = _center_trim(torch.tensor(chunks[k]), clen)
+            out[..., o:o + seg] += weight[:clen] * y
+            sw[o:o + seg] += weight[:clen]
+        out = out / sw
+        total = total + out[..., max_shift - off:]
+    src = total / max(shifts, 1)
+    src = (src * ref.std() + ref.mean()).numpy()
+    src[[0, 1]] = src[[1, 0]]
+    return src

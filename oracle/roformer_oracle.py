@@ -357,3 +357,31 @@ def roformer_demix(mix: np.ndarray, sd: dict, cfg: RoformerConfig, overlap=8, se
         result[..., st:st + safe] += x[..., :safe] * window[:safe]
         counter[..., st:st + safe] += window[:safe]
     return (result / counter.clamp(min=1e-10)).numpy()
+
+
+def roformer_chunks(mix: np.ndarray, sd: dict, cfg: RoformerConfig, overlap, k0: int, k1: int) -> np.ndarray:
+    """model outputs of chunks [k0, k1) of roformer_demix's loop: [k1-k0, S, 2, chunk] (test double of asx_rof_chunks_dev)"""
+    n = mix.shape[1]
+    chunk_size, step, starts = roformer_plan(n, cfg, overlap)
+    outs = []
+    for st in starts[k0:k1]:
+        x = roformer_forward(np.asarray(mix[None, :, st:st + chunk_size], np.float32), sd, cfg)[0]
+        outs.append(x[None] if x.ndim == 2 else x)
+    return np.stack(outs).astype(np.float32) if outs else np.zeros((0, cfg.num_stems, 2, chunk_size), np.float32)
+
+
+def roformer_fold(chunks: np.ndarray, n: int, cfg: RoformerConfig, overlap) -> np.ndarray:
+    """the Hamming fold of roformer_demix over precomputed chunk outputs (test double of asx_rof_finalize_dev)"""
+    chunk_size, step, starts = roformer_plan(n, cfg, overlap)
+    window = torch.tensor(scipy.signal.windows.hamming(chunk_size), dtype=torch.float32)
+    req = (len(cfg.instruments), 2, n)
+    result = torch.zeros(req)
+    counter = torch.zeros(req)
+    for k, st in enumerate(starts):
+        x = torch.tensor(chunks[k])
+        if cfg.num_stems == 1:
+            x = x[0]
+        safe = min(chunk_size, x.shape[-1], window.shape[0])
+        result[..., st:st + safe] += x[..., :safe] * window[:safe]
+        counter[..., st:st + safe] += window[:safe]
+    return (result / counter.clamp(min=1e-10)).numpy()

@@ -1513,8 +1513,10 @@ int asx_mdxc_plan(const asx_engine *e, int64_t N, int32_t overlap, asx_plan *out
   return ASX_OK;
 }
 
-int asx_mdxc_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t overlap, float *out_dev, void *stream) {
-  REQUIRE(e && mix_dev && out_dev, "asx_mdxc_demix_dev: null argument");
+// chunks [k0, k1) of the unfold loop (mdxc_separator.py:374-392) -> chunk_out [k1-k0, S, 2, chunk]
+int asx_mdxc_chunks_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t overlap, int32_t k0, int32_t k1, float *chunk_out_dev,
+                        void *stream) {
+  REQUIRE(e && mix_dev && chunk_out_dev, "asx_mdxc_chunks_dev: null argument");
   if (!e->v3 || !e->v3->ready) {
     set_err("asx_mdxc_demix: weights not committed");
     return ASX_ERR_STATE;
@@ -1523,28 +1525,60 @@ int asx_mdxc_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t o
   HIPCHK(hipSetDevice(e->device));
   asx_plan p;
   CHK(asx_mdxc_plan(e, N, overlap, &p));
+  REQUIRE(k0 >= 0 && k0 <= k1 && k1 <= p.n_chunks, "chunk range [%d, %d) outside [0, %d)", k0, k1, p.n_chunks);
+  if (k1 == k0) return ASX_OK;
   V3Net &n = *e->v3;
   const int S = n.cfg.num_targets;
   const int64_t C = p.chunk_size;
-  CHK(n.chunk_out.ensure((size_t)p.n_chunks * S * 2 * C * 4));
-  std::vector<int64_t> starts(p.n_chunks);
-  for (int k = 0; k < p.n_chunks; ++k) starts[k] = (int64_t)k * p.step;
-  CHK(n.d_starts.ensure((size_t)p.n_chunks * 8));
-  HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data(), (size_t)p.n_chunks * 8, hipMemcpyHostToDevice, s));
+  const int nk = k1 - k0;
+  std::vector<int64_t> starts(nk);
+  for (int k = 0; k < nk; ++k) starts[k] = (int64_t)(k0 + k) * p.step;
+  CHK(n.d_starts.ensure((size_t)nk * 8));
+  HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
   const int maxB = e->cfg.max_batch > 0 ? e->cfg.max_batch : 8;
-  const int nbatch = (p.n_chunks + maxB - 1) / maxB;
-  const int per = (p.n_chunks + nbatch - 1) / nbatch;
-  for (int k0 = 0; k0 < p.n_chunks; k0 += per) {
-    const int B = std::min(per, p.n_chunks - k0);
-    CHK(v3_chunks_dev(e, mix_dev, reinterpret_cast<const int64_t *>(n.d_starts.p) + k0, N, p.trim, B,
-                      n.chunk_out.f() + (size_t)k0 * S * 2 * C, s));
+  const int nbatch = (nk + maxB - 1) / maxB;
+  const int per = (nk + nbatch - 1) / nbatch;
+  for (int j = 0; j < nk; j += per) {
+    const int B = std::min(per, nk - j);
+    CHK(v3_chunks_dev(e, mix_dev, reinterpret_cast<const int64_t *>(n.d_starts.p) + j, N, p.trim, B,
+                      chunk_out_dev + (size_t)j * S * 2 * C, s));
   }
+  return ASX_OK;
+}
+
+// uniform fold of ALL chunks, / overlap (mdxc_separator.py:246-255, 394-404): chunk_out [n_chunks, S, 2, chunk] -> out [S, 2, N]
+int asx_mdxc_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t N, int32_t overlap, float *out_dev, void *stream) {
+  REQUIRE(e && chunk_out_dev && out_dev, "asx_mdxc_finalize_dev: null argument");
+  if (!e->v3 || !e->v3->ready) {
+    set_err("asx_mdxc_demix: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  asx_plan p;
+  CHK(asx_mdxc_plan(e, N, overlap, &p));
+  const int S = e->v3->cfg.num_targets;
+  const int64_t C = p.chunk_size;
   const double bytes = 4.0 * ((double)p.n_chunks * S * 2 * C + (double)S * 2 * N);
   return timed(e, ASX_PROF_FINALIZE, 0.0, bytes, s, [&]() {
-    hipLaunchKernelGGL(mdxc_finalize_kernel, dim3((unsigned)((N + 255) / 256), S * 2), dim3(256), 0, s,
-                       n.chunk_out.f(), p.n_chunks, S, C, p.step, (int64_t)p.trim, N, (float)overlap, out_dev);
+    hipLaunchKernelGGL(mdxc_finalize_kernel, dim3((unsigned)((N + 255) / 256), S * 2), dim3(256), 0, s, chunk_out_dev, p.n_chunks, S, C,
+                       p.step, (int64_t)p.trim, N, (float)overlap, out_dev);
   });
+}
+
+int asx_mdxc_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t overlap, float *out_dev, void *stream) {
+  REQUIRE(e && mix_dev && out_dev, "asx_mdxc_demix_dev: null argument");
+  if (!e->v3 || !e->v3->ready) {
+    set_err("asx_mdxc_demix: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  asx_plan p;
+  CHK(asx_mdxc_plan(e, N, overlap, &p));
+  V3Net &n = *e->v3;
+  CHK(n.chunk_out.ensure((size_t)p.n_chunks * n.cfg.num_targets * 2 * p.chunk_size * 4));
+  CHK(asx_mdxc_chunks_dev(e, mix_dev, N, overlap, 0, p.n_chunks, n.chunk_out.f(), stream));
+  return asx_mdxc_finalize_dev(e, n.chunk_out.f(), N, overlap, out_dev, stream);
 }
 
 int asx_mdxc_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t overlap, float *out_host) {
@@ -1725,8 +1759,28 @@ int asx_rof_forward(asx_engine *e, const float *wave_host, int32_t B, float *out
   return ASX_OK;
 }
 
-int asx_rof_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int64_t step, float *out_dev, void *stream) {
-  REQUIRE(e && mix_dev && out_dev, "asx_rof_demix_dev: null argument");
+static int rof_starts(asx_engine *e, int64_t N, int64_t step, std::vector<int64_t> &starts) {
+  const int64_t C = (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1);
+  REQUIRE(N >= C, "mix (%lld samples) shorter than one chunk (%lld): not supported on the Roformer path", (long long)N, (long long)C);
+  REQUIRE(step >= 1 && step <= C, "step must be in [1, chunk_size]");
+  starts.clear();
+  for (int64_t i = 0; i < N; i += step) starts.push_back(i + C > N ? N - C : i);   // tail re-anchored (:323-336)
+  return ASX_OK;
+}
+
+int asx_rof_plan(const asx_engine *e, int64_t N, int64_t step, int32_t *n_chunks, int64_t *chunk_size) {
+  REQUIRE(e && n_chunks && chunk_size, "asx_rof_plan: null argument");
+  std::vector<int64_t> starts;
+  CHK(rof_starts(const_cast<asx_engine *>(e), N, step, starts));
+  *n_chunks = (int32_t)starts.size();
+  *chunk_size = (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1);
+  return ASX_OK;
+}
+
+// chunks [k0, k1) of the Roformer loop (mdxc_separator.py:318-336) -> chunk_out [k1-k0, S, 2, chunk]
+int asx_rof_chunks_dev(asx_engine *e, const float *mix_dev, int64_t N, int64_t step, int32_t k0, int32_t k1, float *chunk_out_dev,
+                       void *stream) {
+  REQUIRE(e && mix_dev && chunk_out_dev, "asx_rof_chunks_dev: null argument");
   if (!e->rof || !e->rof->ready) {
     set_err("asx_rof_demix: weights not committed");
     return ASX_ERR_STATE;
@@ -1736,30 +1790,62 @@ int asx_rof_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int64_t st
   RofNet &n = *e->rof;
   const int S = n.cfg.num_stems;
   const int64_t C = (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1);
-  REQUIRE(N >= C, "mix (%lld samples) shorter than one chunk (%lld): not supported on the Roformer path", (long long)N,
-          (long long)C);
-  REQUIRE(step >= 1 && step <= C, "step must be in [1, chunk_size]");
   std::vector<int64_t> starts;
-  for (int64_t i = 0; i < N; i += step) starts.push_back(i + C > N ? N - C : i);   // tail re-anchored (:323-336)
-  const int nk = (int)starts.size();
-  CHK(n.chunk_out.ensure((size_t)nk * S * 2 * C * 4));
-  CHK(n.d_starts.ensure((size_t)nk * 8));
-  HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
+  CHK(rof_starts(e, N, step, starts));
+  REQUIRE(k0 >= 0 && k0 <= k1 && k1 <= (int)starts.size(), "chunk range [%d, %d) outside [0, %d)", k0, k1, (int)starts.size());
+  if (k1 == k0) return ASX_OK;
+  const int nk = k1 - k0;
+  CHK(n.d_starts.ensure((size_t)starts.size() * 8));
+  HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data() + k0, (size_t)nk * 8, hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
   const int maxB = e->cfg.max_batch > 0 ? e->cfg.max_batch : 8;
   const int nbatch = (nk + maxB - 1) / maxB;
   const int per = (nk + nbatch - 1) / nbatch;
-  for (int k0 = 0; k0 < nk; k0 += per) {
-    const int B = std::min(per, nk - k0);
-    CHK(rof_chunks_dev(e, mix_dev, reinterpret_cast<const int64_t *>(n.d_starts.p) + k0, N, B,
-                       n.chunk_out.f() + (size_t)k0 * S * 2 * C, s));
+  for (int j = 0; j < nk; j += per) {
+    const int B = std::min(per, nk - j);
+    CHK(rof_chunks_dev(e, mix_dev, reinterpret_cast<const int64_t *>(n.d_starts.p) + j, N, B, chunk_out_dev + (size_t)j * S * 2 * C, s));
   }
+  return ASX_OK;
+}
+
+// Hamming-weighted fold of ALL chunks / counter.clamp(1e-10) (mdxc_separator.py:310-343)
+int asx_rof_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t N, int64_t step, float *out_dev, void *stream) {
+  REQUIRE(e && chunk_out_dev && out_dev, "asx_rof_finalize_dev: null argument");
+  if (!e->rof || !e->rof->ready) {
+    set_err("asx_rof_demix: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  RofNet &n = *e->rof;
+  const int S = n.cfg.num_stems;
+  const int64_t C = (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1);
+  std::vector<int64_t> starts;
+  CHK(rof_starts(e, N, step, starts));
+  const int nk = (int)starts.size();
+  CHK(n.d_starts.ensure((size_t)nk * 8));
+  HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
   const int n_out = n.cfg.n_out;
   return timed(e, ASX_PROF_FINALIZE, 0.0, 4.0 * ((double)nk * S * 2 * C + 2.0 * n_out * N), s, [&]() {
-    hipLaunchKernelGGL(roformer_finalize_kernel, dim3((unsigned)((N + 255) / 256), n_out * 2), dim3(256), 0, s,
-                       n.chunk_out.f(), reinterpret_cast<const int64_t *>(n.d_starts.p), nk, S, C, n.d_window.f(), N,
-                       out_dev);
+    hipLaunchKernelGGL(roformer_finalize_kernel, dim3((unsigned)((N + 255) / 256), n_out * 2), dim3(256), 0, s, chunk_out_dev,
+                       reinterpret_cast<const int64_t *>(n.d_starts.p), nk, S, C, n.d_window.f(), N, out_dev);
   });
+}
+
+int asx_rof_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int64_t step, float *out_dev, void *stream) {
+  REQUIRE(e && mix_dev && out_dev, "asx_rof_demix_dev: null argument");
+  if (!e->rof || !e->rof->ready) {
+    set_err("asx_rof_demix: weights not committed");
+    return ASX_ERR_STATE;
+  }
+  RofNet &n = *e->rof;
+  std::vector<int64_t> starts;
+  CHK(rof_starts(e, N, step, starts));
+  const int64_t C = (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1);
+  CHK(n.chunk_out.ensure(starts.size() * n.cfg.num_stems * 2 * C * 4));
+  CHK(asx_rof_chunks_dev(e, mix_dev, N, step, 0, (int32_t)starts.size(), n.chunk_out.f(), stream));
+  return asx_rof_finalize_dev(e, n.chunk_out.f(), N, step, out_dev, stream);
 }
 
 int asx_rof_demix(asx_engine *e, const float *mix_host, int64_t N, int64_t step, float *out_host) {
@@ -1851,6 +1937,46 @@ int asx_ht_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t shi
   }
   HIPCHK(hipSetDevice(e->device));
   return ht_demix_dev(e, mix_dev, N, shifts, offsets, overlap, flags, out_dev, reinterpret_cast<hipStream_t>(stream));
+}
+
+#define HT_READY(fn)                                   \
+  do {                                                 \
+    if (!e->ht || !e->ht->ready) {                     \
+      set_err(fn ": weights not committed");           \
+      return ASX_ERR_STATE;                            \
+    }                                                  \
+  } while (0)
+
+int asx_ht_plan(const asx_engine *e, int64_t N, int32_t shifts, const int64_t *offsets, double overlap, int32_t *n_segments,
+                int64_t *segment_samples) {
+  REQUIRE(e && n_segments && segment_samples && N >= 2 && shifts >= 0 && (shifts == 0 || offsets), "asx_ht_plan: bad argument");
+  HT_READY("asx_ht_plan");
+  HtPlan p;
+  CHK(ht_plan(e, N, shifts, offsets, overlap, p));
+  *n_segments = (int32_t)p.starts.size();
+  *segment_samples = p.segment;
+  return ASX_OK;
+}
+
+int asx_ht_segments_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t shifts, const int64_t *offsets, double overlap,
+                        uint32_t flags, int32_t k0, int32_t k1, float *chunk_out_dev, void *stream) {
+  REQUIRE(e && mix_dev && chunk_out_dev && N >= 2 && shifts >= 0 && (shifts == 0 || offsets), "asx_ht_segments_dev: bad argument");
+  HT_READY("asx_ht_segments_dev");
+  HIPCHK(hipSetDevice(e->device));
+  HtPlan p;
+  CHK(ht_plan(e, N, shifts, offsets, overlap, p));
+  REQUIRE(k0 >= 0 && k0 <= k1 && k1 <= (int)p.starts.size(), "segment range [%d, %d) outside [0, %d)", k0, k1, (int)p.starts.size());
+  return ht_segments_dev(e, mix_dev, N, p, flags, k0, k1, chunk_out_dev, reinterpret_cast<hipStream_t>(stream));
+}
+
+int asx_ht_fold_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t shifts, const int64_t *offsets, double overlap, uint32_t flags,
+                    const float *chunk_out_dev, float *out_dev, void *stream) {
+  REQUIRE(e && mix_dev && chunk_out_dev && out_dev && N >= 2 && shifts >= 0 && (shifts == 0 || offsets), "asx_ht_fold_dev: bad argument");
+  HT_READY("asx_ht_fold_dev");
+  HIPCHK(hipSetDevice(e->device));
+  HtPlan p;
+  CHK(ht_plan(e, N, shifts, offsets, overlap, p));
+  return ht_fold_dev(e, mix_dev, N, p, flags, chunk_out_dev, out_dev, reinterpret_cast<hipStream_t>(stream));
 }
 
 int asx_ht_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t shifts, const int64_t *offsets, double overlap,

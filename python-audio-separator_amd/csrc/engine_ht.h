@@ -979,61 +979,113 @@ static double ht_flops(const asx_engine *e) {
 }
 
 // ---- apply_model + demix_demucs ---------------------------------------------------------------------------------------
+// The segment-forwards of one call, in the reference's order: shift 0's chunks, shift 1's chunks, ...
+struct HtShift {
+  int64_t offset, VL;
+  int first, nk;          // range inside the global segment list
+};
+struct HtPlan {
+  int64_t stride, segment, max_shift;
+  std::vector<HtShift> shifts;
+  std::vector<int64_t> starts;   // song index of model-input sample 0 of every segment
+};
+
+static int ht_plan(const asx_engine *e, int64_t N, int32_t shifts, const int64_t *offsets, double overlap, HtPlan &p) {
+  const HtNet &n = *e->ht;
+  const int64_t TL = n.L[0];
+  p.segment = TL;
+  p.stride = (int64_t)((1.0 - overlap) * (double)TL);   // int((1 - overlap) * segment), apply.py:220
+  REQUIRE(p.stride >= 1 && p.stride <= TL, "overlap %g gives a bad stride", overlap);
+  p.max_shift = shifts > 0 ? n.cfg.samplerate / 2 : 0;
+  p.shifts.clear();
+  p.starts.clear();
+  const int nsh = shifts > 0 ? shifts : 1;
+  for (int si = 0; si < nsh; ++si) {
+    HtShift sh;
+    sh.offset = shifts > 0 ? offsets[si] : 0;
+    REQUIRE(sh.offset >= 0 && sh.offset <= p.max_shift, "shift offset %lld outside [0, %lld]", (long long)sh.offset, (long long)p.max_shift);
+    // view = padded_mix[offset : offset + N + max_shift - offset]; padded index q <-> song index q - max_shift
+    sh.VL = N + p.max_shift - sh.offset;
+    sh.first = (int)p.starts.size();
+    for (int64_t off = 0; off < sh.VL; off += p.stride) {
+      const int64_t clen = std::min(sh.VL - off, TL);
+      p.starts.push_back(sh.offset + off - (TL - clen) / 2 - p.max_shift);
+    }
+    sh.nk = (int)p.starts.size() - sh.first;
+    p.shifts.push_back(sh);
+  }
+  return ASX_OK;
+}
+
+static int ht_ref_stats(asx_engine *e, const float *mix_dev, int64_t N, hipStream_t s) {
+  // ref = mix.mean(0); mean / unbiased std of ref (demucs_separator.py:171-173)
+  HtNet &n = *e->ht;
+  CHK(n.ref.ensure((size_t)N * 4));
+  CHK(n.ref_acc.ensure(16));
+  hipLaunchKernelGGL(ht_mono_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, mix_dev, N, n.ref.f());
+  HIPCHK(hipGetLastError());
+  return ht_stats(e, n.ref.f(), 1, 1, N, N, 1, 1, 1, reinterpret_cast<double *>(n.ref_acc.p), s);
+}
+
+// segment-forwards [k0, k1) of the global list -> chunk_out [k1-k0, S, 2, TL]
+static int ht_segments_dev(asx_engine *e, const float *mix_dev, int64_t N, const HtPlan &p, uint32_t flags, int k0, int k1, float *chunk_out,
+                           hipStream_t s) {
+  HtNet &n = *e->ht;
+  const asx_ht_config &c = n.cfg;
+  const int S = c.n_sources;
+  const int64_t TL = n.L[0];
+  const int standardize = (flags & ASX_HT_STANDARDIZE) ? 1 : 0;
+  if (k1 <= k0) return ASX_OK;
+  if (standardize) CHK(ht_ref_stats(e, mix_dev, N, s));
+  const int nk = k1 - k0;
+  CHK(n.d_starts.ensure((size_t)nk * 8));
+  HIPCHK(hipMemcpyAsync(n.d_starts.p, p.starts.data() + k0, (size_t)nk * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const int maxB = c.max_batch > 0 ? c.max_batch : 16;   // 611 vs 536x real time against batches of 8 (4-min song)
+  const int nbatch = (nk + maxB - 1) / maxB;
+  const int per = (nk + nbatch - 1) / nbatch;
+  CHK(n.seg.ensure((size_t)per * 2 * TL * 4));
+  for (int j = 0; j < nk; j += per) {
+    const int B = std::min(per, nk - j);
+    hipLaunchKernelGGL(ht_gather_kernel, dim3((unsigned)((TL + 255) / 256), 2, B), dim3(256), 0, s, mix_dev, N,
+                       reinterpret_cast<const int64_t *>(n.d_starts.p) + j, TL, reinterpret_cast<const double *>(n.ref_acc.p), standardize,
+                       n.seg.f());
+    HIPCHK(hipGetLastError());
+    CHK(ht_forward_dev(e, n.seg.f(), B, chunk_out + (size_t)j * S * 2 * TL, s));
+  }
+  return ASX_OK;
+}
+
+// triangular fold per shift, mean over shifts, de-standardise, stem swap: chunk_out [all segments, S, 2, TL] -> out [S, 2, N]
+static int ht_fold_dev(asx_engine *e, const float *mix_dev, int64_t N, const HtPlan &p, uint32_t flags, const float *chunk_out, float *out_dev,
+                       hipStream_t s) {
+  HtNet &n = *e->ht;
+  const int S = n.cfg.n_sources;
+  const int64_t TL = n.L[0];
+  const int standardize = (flags & ASX_HT_STANDARDIZE) ? 1 : 0;
+  const int swap01 = (flags & ASX_HT_SWAP01) ? 1 : 0;
+  if (standardize) CHK(ht_ref_stats(e, mix_dev, N, s));
+  const int nsh = (int)p.shifts.size();
+  for (int si = 0; si < nsh; ++si) {
+    const HtShift &sh = p.shifts[si];
+    CHK(timed(e, ASX_PROF_FINALIZE, 0.0, 4.0 * ((double)sh.nk * S * 2 * TL + 2.0 * S * 2 * N), s, [&]() {
+      hipLaunchKernelGGL(ht_fold_kernel, dim3((unsigned)((N + 255) / 256), S * 2), dim3(256), 0, s, chunk_out + (size_t)sh.first * S * 2 * TL,
+                         sh.nk, S * 2, TL, p.stride, p.segment, sh.VL, p.max_shift - sh.offset, n.fold_w.f(), si == 0 ? 1 : 0,
+                         si == nsh - 1 ? 1 : 0, nsh, reinterpret_cast<const double *>(n.ref_acc.p), standardize, swap01, N, out_dev);
+    }));
+  }
+  return ASX_OK;
+}
+
 // mix_dev [2, N] -> out_dev [S, 2, N].  offsets: `shifts` draws of random.randint(0, samplerate/2) made by the host
 // (apply.py:209); shifts == 0 runs the plain split path.
 static int ht_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t shifts, const int64_t *offsets, double overlap,
                         uint32_t flags, float *out_dev, hipStream_t s) {
   HtNet &n = *e->ht;
-  const asx_ht_config &c = n.cfg;
-  const int S = c.n_sources;
-  const int64_t TL = n.L[0], segment = TL;
-  const int64_t stride = (int64_t)((1.0 - overlap) * (double)segment);   // int((1 - overlap) * segment), apply.py:220
-  REQUIRE(stride >= 1 && stride <= segment, "overlap %g gives a bad stride", overlap);
-  const int standardize = (flags & ASX_HT_STANDARDIZE) ? 1 : 0;
-  const int swap01 = (flags & ASX_HT_SWAP01) ? 1 : 0;
-  const int64_t max_shift = shifts > 0 ? c.samplerate / 2 : 0;
-  if (standardize) {   // ref = mix.mean(0); mean / unbiased std of ref (demucs_separator.py:171-173)
-    CHK(n.ref.ensure((size_t)N * 4));
-    CHK(n.ref_acc.ensure(16));
-    hipLaunchKernelGGL(ht_mono_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, mix_dev, N, n.ref.f());
-    HIPCHK(hipGetLastError());
-    CHK(ht_stats(e, n.ref.f(), 1, 1, N, N, 1, 1, 1, reinterpret_cast<double *>(n.ref_acc.p), s));
-  }
-  const int nsh = shifts > 0 ? shifts : 1;
-  const int maxB = c.max_batch > 0 ? c.max_batch : 16;   // 611 vs 536x real time against batches of 8 (4-min song)
-  for (int si = 0; si < nsh; ++si) {
-    const int64_t offset = shifts > 0 ? offsets[si] : 0;
-    REQUIRE(offset >= 0 && offset <= max_shift, "shift offset %lld outside [0, %lld]", (long long)offset, (long long)max_shift);
-    // view = padded_mix[offset : offset + N + max_shift - offset]; padded index p <-> song index p - max_shift
-    const int64_t VL = N + max_shift - offset;
-    std::vector<int64_t> starts;
-    for (int64_t off = 0; off < VL; off += stride) {
-      const int64_t clen = std::min(VL - off, segment);
-      const int64_t delta = TL - clen;
-      starts.push_back(offset + off - delta / 2 - max_shift);   // song index of model-input sample 0
-    }
-    const int nk = (int)starts.size();
-    CHK(n.chunk_out.ensure((size_t)nk * S * 2 * TL * 4));
-    CHK(n.d_starts.ensure((size_t)nk * 8));
-    HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const int nbatch = (nk + maxB - 1) / maxB;
-    const int per = (nk + nbatch - 1) / nbatch;
-    CHK(n.seg.ensure((size_t)per * 2 * TL * 4));
-    for (int k0 = 0; k0 < nk; k0 += per) {
-      const int B = std::min(per, nk - k0);
-      hipLaunchKernelGGL(ht_gather_kernel, dim3((unsigned)((TL + 255) / 256), 2, B), dim3(256), 0, s, mix_dev, N,
-                         reinterpret_cast<const int64_t *>(n.d_starts.p) + k0, TL,
-                         reinterpret_cast<const double *>(n.ref_acc.p), standardize, n.seg.f());
-      HIPCHK(hipGetLastError());
-      CHK(ht_forward_dev(e, n.seg.f(), B, n.chunk_out.f() + (size_t)k0 * S * 2 * TL, s));
-    }
-    CHK(timed(e, ASX_PROF_FINALIZE, 0.0, 4.0 * ((double)nk * S * 2 * TL + 2.0 * S * 2 * N), s, [&]() {
-      hipLaunchKernelGGL(ht_fold_kernel, dim3((unsigned)((N + 255) / 256), S * 2), dim3(256), 0, s, n.chunk_out.f(), nk,
-                         S * 2, TL, stride, segment, VL, max_shift - offset, n.fold_w.f(), si == 0 ? 1 : 0,
-                         si == nsh - 1 ? 1 : 0, nsh, reinterpret_cast<const double *>(n.ref_acc.p), standardize, swap01, N,
-                         out_dev);
-    }));
-  }
-  return ASX_OK;
+  HtPlan p;
+  CHK(ht_plan(e, N, shifts, offsets, overlap, p));
+  const int nseg = (int)p.starts.size();
+  CHK(n.chunk_out.ensure((size_t)nseg * n.cfg.n_sources * 2 * n.L[0] * 4));
+  CHK(ht_segments_dev(e, mix_dev, N, p, flags, 0, nseg, n.chunk_out.f(), s));
+  return ht_fold_dev(e, mix_dev, N, p, flags, n.chunk_out.f(), out_dev, s);
 }

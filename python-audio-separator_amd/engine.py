@@ -185,7 +185,9 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_set_option", "asx_rof_begin", "asx_rof_commit", "asx_rof_flops", "asx_rof_forward", "asx_rof_demix", "asx_rof_demix_dev",
            "asx_ht_begin", "asx_ht_commit", "asx_ht_flops", "asx_ht_forward", "asx_ht_demix", "asx_ht_demix_dev",
            "asx_vr_begin", "asx_vr_commit", "asx_vr_flops", "asx_vr_plan", "asx_vr_forward", "asx_vr_analysis",
-           "asx_vr_separate", "asx_vr_separate_dev", "asx_debug_fetch"]
+           "asx_vr_separate", "asx_vr_separate_dev", "asx_debug_fetch",
+           "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
+           "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev"]
 
 
 def load_library():
@@ -264,6 +266,14 @@ def load_library():
     lib.asx_vr_separate.argtypes = [vp, _FP, i64, C.POINTER(_VrParams), _FP, _FP]
     lib.asx_vr_separate_dev.argtypes = [vp, vp, i64, C.POINTER(_VrParams), vp, vp, vp]
     lib.asx_debug_fetch.argtypes = [vp, C.c_char_p, _FP, i64]
+    lib.asx_mdxc_chunks_dev.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
+    lib.asx_mdxc_finalize_dev.argtypes = [vp, vp, i64, i32, vp, vp]
+    lib.asx_rof_plan.argtypes = [vp, i64, i64, C.POINTER(i32), C.POINTER(i64)]
+    lib.asx_rof_chunks_dev.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp]
+    lib.asx_rof_finalize_dev.argtypes = [vp, vp, i64, i64, vp, vp]
+    lib.asx_ht_plan.argtypes = [vp, i64, i32, C.POINTER(C.c_int64), C.c_double, C.POINTER(i32), C.POINTER(i64)]
+    lib.asx_ht_segments_dev.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, i32, i32, vp, vp]
+    lib.asx_ht_fold_dev.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, vp, vp, vp]
     lib.asx_profile_enable.argtypes = [vp, i32]
     lib.asx_profile_read.argtypes = [vp, C.POINTER(_Profile)]
     for name in SYMBOLS:
@@ -587,6 +597,41 @@ class Engine:
                        int(bool(enable_post_process)), float(post_thres), 0)
         self._check(self._lib.asx_vr_separate_dev(self._h, wave_ptr, n_samples, C.byref(pr), primary_ptr or None,
                                                   secondary_ptr or None, stream or None))
+
+    # -- chunk-range halves of the sibling loops (multi-GPU sharding, sharding.py) ----------------------------
+    def mdxc_chunks_dev(self, mix_ptr, n, overlap, k0, k1, out_ptr, stream=0):
+        self._check(self._lib.asx_mdxc_chunks_dev(self._h, mix_ptr, n, int(overlap), k0, k1, out_ptr, stream or None))
+
+    def mdxc_finalize_dev(self, chunks_ptr, n, overlap, out_ptr, stream=0):
+        self._check(self._lib.asx_mdxc_finalize_dev(self._h, chunks_ptr, n, int(overlap), out_ptr, stream or None))
+
+    def rof_plan(self, n, step):
+        k, c = C.c_int32(), C.c_int64()
+        self._check(self._lib.asx_rof_plan(self._h, n, int(step), C.byref(k), C.byref(c)))
+        return {"n_chunks": k.value, "chunk_size": c.value}
+
+    def rof_chunks_dev(self, mix_ptr, n, step, k0, k1, out_ptr, stream=0):
+        self._check(self._lib.asx_rof_chunks_dev(self._h, mix_ptr, n, int(step), k0, k1, out_ptr, stream or None))
+
+    def rof_finalize_dev(self, chunks_ptr, n, step, out_ptr, stream=0):
+        self._check(self._lib.asx_rof_finalize_dev(self._h, chunks_ptr, n, int(step), out_ptr, stream or None))
+
+    @staticmethod
+    def _offs(shifts, offsets):
+        return (C.c_int64 * shifts)(*[int(o) for o in offsets]) if shifts else None
+
+    def ht_plan(self, n, shifts=0, offsets=None, overlap=0.25):
+        k, c = C.c_int32(), C.c_int64()
+        self._check(self._lib.asx_ht_plan(self._h, n, int(shifts), self._offs(shifts, offsets), float(overlap), C.byref(k), C.byref(c)))
+        return {"n_chunks": k.value, "chunk_size": c.value}
+
+    def ht_segments_dev(self, mix_ptr, n, k0, k1, out_ptr, shifts=0, offsets=None, overlap=0.25, flags=0, stream=0):
+        self._check(self._lib.asx_ht_segments_dev(self._h, mix_ptr, n, int(shifts), self._offs(shifts, offsets), float(overlap), flags,
+                                                  k0, k1, out_ptr, stream or None))
+
+    def ht_fold_dev(self, mix_ptr, n, chunks_ptr, out_ptr, shifts=0, offsets=None, overlap=0.25, flags=0, stream=0):
+        self._check(self._lib.asx_ht_fold_dev(self._h, mix_ptr, n, int(shifts), self._offs(shifts, offsets), float(overlap), flags,
+                                              chunks_ptr, out_ptr, stream or None))
 
     def debug_fetch(self, name: str, shape) -> np.ndarray:
         out = np.empty(shape, np.float32)

@@ -13,8 +13,14 @@ methods operating on torch tensors that live on the adapter's device,
     demix_chunks(mix, n, k0, k1, out)  windowed chunks [k1-k0, 2, C] -> out
     finalize(chunks, n, out)           all chunks [n_chunks, 2, C] -> out [2, n]
 
-``HipEngineAdapter`` binds those to libasx.so.  With backend "nccl" the gather
-is RCCL over xGMI; the CPU tests drive the same code over "gloo".
+and optionally ``stems`` (rows S of a chunk [S, 2, C]; default none) and
+``out_stems`` (rows of the result [S_out, 2, n]).
+
+``HipEngineAdapter`` binds those to libasx.so for the MDX loop; ``MdxcAdapter``,
+``RoformerAdapter`` and ``DemucsAdapter`` do the same for the sibling loops
+(MDXC unfold / uniform fold, Roformer Hamming fold, Demucs apply_model whose "chunks"
+are the segment-forwards of every shift) -- SURVEY.md 8e.  With backend "nccl" the
+gather is RCCL over xGMI; the CPU tests drive the same code over "gloo".
 """
 from __future__ import annotations
 
@@ -54,6 +60,76 @@ class HipEngineAdapter:
         self.engine.finalize_dev(chunks.data_ptr(), n_samples, out.data_ptr(), self.is_match_mix, self._stream())
 
 
+class _SiblingAdapter:
+    def __init__(self, engine):
+        self.engine = engine
+
+    def _stream(self):
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+
+
+class MdxcAdapter(_SiblingAdapter):
+    """MDXCSeparator.demix, TFC branch (mdxc_separator.py:345-404)."""
+
+    def __init__(self, engine, overlap: int):
+        super().__init__(engine)
+        self.overlap = int(overlap)
+        self.stems = self.out_stems = engine.v3_cfg.num_targets
+
+    def plan(self, n):
+        return self.engine.mdxc_plan(n, self.overlap)
+
+    def demix_chunks(self, mix, n, k0, k1, out):
+        self.engine.mdxc_chunks_dev(mix.data_ptr(), n, self.overlap, k0, k1, out.data_ptr(), self._stream())
+
+    def finalize(self, chunks, n, out):
+        self.engine.mdxc_finalize_dev(chunks.data_ptr(), n, self.overlap, out.data_ptr(), self._stream())
+
+
+class RoformerAdapter(_SiblingAdapter):
+    """MDXCSeparator.demix, Roformer branch (mdxc_separator.py:272-343); step in samples."""
+
+    def __init__(self, engine, step: int):
+        super().__init__(engine)
+        self.step = int(step)
+        self.stems = engine.rof_cfg.num_stems
+        self.out_stems = engine.rof_cfg.n_out
+
+    def plan(self, n):
+        return self.engine.rof_plan(n, self.step)
+
+    def demix_chunks(self, mix, n, k0, k1, out):
+        self.engine.rof_chunks_dev(mix.data_ptr(), n, self.step, k0, k1, out.data_ptr(), self._stream())
+
+    def finalize(self, chunks, n, out):
+        self.engine.rof_finalize_dev(chunks.data_ptr(), n, self.step, out.data_ptr(), self._stream())
+
+
+class DemucsAdapter(_SiblingAdapter):
+    """apply_model + demix_demucs (apply.py:124-260, demucs_separator.py:162-194); offsets = the shift draws, identical
+    on every rank."""
+
+    def __init__(self, engine, shifts=0, offsets=None, overlap=0.25, flags=3):
+        super().__init__(engine)
+        self.kw = dict(shifts=shifts, offsets=offsets, overlap=overlap)
+        self.flags = flags
+        self.stems = self.out_stems = len(engine.ht_cfg.sources)
+
+    def plan(self, n):
+        return self.engine.ht_plan(n, **self.kw)
+
+    def demix_chunks(self, mix, n, k0, k1, out):
+        self.engine.ht_segments_dev(mix.data_ptr(), n, k0, k1, out.data_ptr(), flags=self.flags, stream=self._stream(), **self.kw)
+
+    def finalize(self, chunks, n, out):
+        self.engine.ht_fold_dev(mix_ptr=self._mix.data_ptr(), n=n, chunks_ptr=chunks.data_ptr(), out_ptr=out.data_ptr(), flags=self.flags,
+                                stream=self._stream(), **self.kw)
+
+    def bind_mix(self, mix):          # the fold re-derives the standardisation statistics from the mix
+        self._mix = mix
+
+
 def sharded_demix(adapter, mix, group=None, dst: int = 0):
     """Demix one song across all ranks of ``group``.
 
@@ -71,11 +147,17 @@ def sharded_demix(adapter, mix, group=None, dst: int = 0):
     ranges = partition_chunks(nk, world)
     k0, k1 = ranges[rank]
     per = max(b - a for a, b in ranges)          # equal-size slabs keep it a single gather
-    local = torch.zeros((per, 2, C), dtype=torch.float32, device=mix.device)
+    stems = getattr(adapter, "stems", None)
+    out_stems = getattr(adapter, "out_stems", None)
+    cshape = (per, 2, C) if stems is None else (per, stems, 2, C)
+    oshape = tuple(mix.shape) if out_stems is None else (out_stems, 2, n)
+    if hasattr(adapter, "bind_mix"):
+        adapter.bind_mix(mix)
+    local = torch.zeros(cshape, dtype=torch.float32, device=mix.device)
     if k1 > k0:
         adapter.demix_chunks(mix, n, k0, k1, local[: k1 - k0])
     if world == 1:
-        out = torch.empty_like(mix)
+        out = torch.empty(oshape, dtype=torch.float32, device=mix.device)
         adapter.finalize(local[:nk], n, out)
         return out
     slabs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
@@ -83,6 +165,6 @@ def sharded_demix(adapter, mix, group=None, dst: int = 0):
     if rank != dst:
         return None
     allc = torch.cat([slabs[r][: b - a] for r, (a, b) in enumerate(ranges)], dim=0)
-    out = torch.empty_like(mix)
+    out = torch.empty(oshape, dtype=torch.float32, device=mix.device)
     adapter.finalize(allc, n, out)
     return out

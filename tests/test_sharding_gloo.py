@@ -101,3 +101,108 @@ def test_sharded_demix_gloo(world, n, match):
     run = None if match else O.make_model_run(O.make_convtdf_state(DIMS, seed=3), DIMS)
     ref = O.demix(mix, P, run, is_match_mix=match)
     assert np.array_equal(got, ref)
+
+
+# ---- sibling loops: Roformer chunks and Demucs segment-forwards through the same driver ------------------------------
+from fractions import Fraction  # noqa: E402
+
+from oracle import demucs_oracle as D  # noqa: E402
+from oracle import roformer_oracle as R  # noqa: E402
+
+RCFG = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64, stft_hop_length=16,
+                        stft_win_length=64, dim_t=21, sample_rate=100, mlp_expansion_factor=2)
+DCFG = D.HTConfig(channels=16, nfft=1024, depth=3, bottom_channels=128, t_layers=1, t_heads=2, samplerate=8000, segment=Fraction(1, 1))
+
+
+class RoformerOracleAdapter:
+    stems, out_stems = 1, 2
+
+    def __init__(self, overlap=2):
+        self.sd = R.make_roformer_state(RCFG, 7)
+        self.ov = overlap
+
+    def plan(self, n):
+        cs, step, starts = R.roformer_plan(n, RCFG, self.ov)
+        return {"chunk_size": cs, "n_chunks": len(starts)}
+
+    def demix_chunks(self, mix, n, k0, k1, out):
+        out.copy_(torch.from_numpy(R.roformer_chunks(mix.numpy(), self.sd, RCFG, self.ov, k0, k1)))
+
+    def finalize(self, chunks, n, out):
+        out.copy_(torch.from_numpy(np.ascontiguousarray(R.roformer_fold(chunks.numpy(), n, RCFG, self.ov))))
+
+
+class DemucsOracleAdapter:
+    stems = out_stems = 4
+
+    def __init__(self, shifts=1, offsets=(1234,), overlap=0.25):
+        self.sd = D.make_ht_state(DCFG, 11)
+        self.kw = dict(shifts=shifts, offsets=list(offsets), overlap=overlap)
+
+    def bind_mix(self, mix):
+        self.mix = mix.numpy()
+
+    def plan(self, n):
+        plan, _, _ = D.segment_plan(n, DCFG, **self.kw)
+        return {"chunk_size": DCFG.training_length, "n_chunks": len(plan)}
+
+    def demix_chunks(self, mix, n, k0, k1, out):
+        out.copy_(torch.from_numpy(D.demucs_segments(mix.numpy(), self.sd, DCFG, k0=k0, k1=k1, **self.kw)))
+
+    def finalize(self, chunks, n, out):
+        out.copy_(torch.from_numpy(np.ascontiguousarray(D.demucs_fold(self.mix, chunks.numpy(), DCFG, **self.kw))))
+
+
+def test_segment_form_equals_demix():
+    """the chunk-list restatements used by the adapters reproduce the oracle's monolithic loops"""
+    mix = (0.4 * np.random.default_rng(15).standard_normal((2, 1000))).astype(np.float32)
+    a = RoformerOracleAdapter()
+    nk = a.plan(1000)["n_chunks"]
+    got = R.roformer_fold(R.roformer_chunks(mix, a.sd, RCFG, 2, 0, nk), 1000, RCFG, 2)
+    assert np.array_equal(got, R.roformer_demix(mix, a.sd, RCFG, overlap=2))
+    mixd = (0.3 * np.random.default_rng(16).standard_normal((2, 13000)) + 0.02).astype(np.float32)
+    d = DemucsOracleAdapter(shifts=2, offsets=(1234, 77))
+    nseg = d.plan(13000)["n_chunks"]
+    got = D.demucs_fold(mixd, D.demucs_segments(mixd, d.sd, DCFG, k0=0, k1=nseg, **d.kw), DCFG, **d.kw)
+    want = D.demix_demucs(mixd, d.sd, DCFG, shifts=2, overlap=0.25, offsets=[1234, 77])
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-6
+
+
+def _sib_worker(rank, world, port, kind, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if kind == "roformer":
+        mix = torch.from_numpy((0.4 * np.random.default_rng(17).standard_normal((2, 1400))).astype(np.float32))
+        out = sharded_demix(RoformerOracleAdapter(), mix)
+    else:
+        mix = torch.from_numpy((0.3 * np.random.default_rng(18).standard_normal((2, 21000))).astype(np.float32))
+        out = sharded_demix(DemucsOracleAdapter(), mix)
+    if rank == 0:
+        q.put(out.numpy())
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["roformer", "demucs"])
+def test_sharded_siblings_gloo(kind):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sib_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if kind == "roformer":
+        mix = (0.4 * np.random.default_rng(17).standard_normal((2, 1400))).astype(np.float32)
+        assert np.array_equal(got, R.roformer_demix(mix, R.make_roformer_state(RCFG, 7), RCFG, overlap=2))
+    else:
+        mix = (0.3 * np.random.default_rng(18).standard_normal((2, 21000))).astype(np.float32)
+        want = D.demix_demucs(mix, D.make_ht_state(DCFG, 11), DCFG, shifts=1, overlap=0.25, offsets=[1234])
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-6
