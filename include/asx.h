@@ -340,6 +340,14 @@ int asx_vr_separate(asx_engine *e, const float *wave_host, int64_t n_samples, co
 int asx_vr_separate_dev(asx_engine *e, const float *wave_dev, int64_t n_samples, const asx_vr_params *params, float *primary_dev,
                         float *secondary_dev, void *stream);
 
+/* Writer edge: spec_utils.normalize + (stem * 32767).astype(np.int16) + channel interleave of
+ * CommonSeparator.write_audio_pydub (common_separator.py:309-337).  stem [2, N] planar -> pcm [N, 2]; bit-exact.
+ * *peak_after (optional) = max |stem| after normalisation: the reference skips the file when it is < 1e-6. */
+int asx_pcm16(asx_engine *e, const float *stem_host, int64_t n_samples, float max_peak, float min_peak, int32_t has_min,
+              int16_t *pcm_host, float *peak_after);
+int asx_pcm16_dev(asx_engine *e, const float *stem_dev, int64_t n_samples, float max_peak, float min_peak, int32_t has_min,
+                  int16_t *pcm_dev, float *peak_after, void *stream);
+
 /* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host. */
 int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel);
 

@@ -1250,6 +1250,49 @@ static int transpose_launch(const float *in, float *out, int planes, int rows, i
   return ASX_OK;
 }
 
+// write_audio_pydub's array work (common_separator.py:309-337): stem [2, N] planar float32 -> normalised int16 [N, 2];
+// *peak_after = max |stem| after normalisation (the caller skips near-silent stems: < 1e-6, :312-315)
+int asx_pcm16_dev(asx_engine *e, const float *stem_dev, int64_t N, float max_peak, float min_peak, int32_t has_min, int16_t *pcm_dev,
+                  float *peak_after, void *stream) {
+  REQUIRE(e && stem_dev && pcm_dev && N >= 1, "asx_pcm16_dev: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  CHK(e->d_peak.ensure(256));
+  unsigned int *pk = reinterpret_cast<unsigned int *>(e->d_peak.p);
+  HIPCHK(hipMemsetAsync(pk, 0, 4, s));
+  const int64_t n2 = 2 * N;
+  const unsigned nb = (unsigned)std::min<int64_t>((n2 + 255) / 256, 2048);
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 4.0 * n2, s, [&]() { hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, s, stem_dev, n2, pk); }));
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 6.0 * n2, s, [&]() {
+    hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, stem_dev, N, pk, max_peak, min_peak, has_min,
+                       reinterpret_cast<short *>(pcm_dev));
+  }));
+  if (peak_after) {
+    float maxv = 0.f;
+    HIPCHK(hipMemcpyAsync(&maxv, pk, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float scale = 1.0f;
+    if (maxv > max_peak) scale = max_peak / maxv;
+    else if (has_min && maxv < min_peak) scale = min_peak / maxv;
+    *peak_after = maxv * scale;
+  }
+  return ASX_OK;
+}
+
+int asx_pcm16(asx_engine *e, const float *stem_host, int64_t N, float max_peak, float min_peak, int32_t has_min, int16_t *pcm_host,
+              float *peak_after) {
+  REQUIRE(e && stem_host && pcm_host && N >= 1, "asx_pcm16: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  DevBuf ds, dp;
+  BufGuard g{{&ds, &dp}};
+  CHK(to_dev(ds, stem_host, (size_t)2 * N));
+  CHK(dp.ensure((size_t)2 * N * 2));
+  CHK(asx_pcm16_dev(e, ds.f(), N, max_peak, min_peak, has_min, reinterpret_cast<int16_t *>(dp.p), peak_after, nullptr));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(pcm_host, dp.p, (size_t)2 * N * 2, hipMemcpyDeviceToHost));
+  return ASX_OK;
+}
+
 int asx_stft(asx_engine *e, const float *wave_host, int32_t B, int64_t C, float *spec_host) {
   REQUIRE(e && wave_host && spec_host && B > 0, "asx_stft: bad argument");
   REQUIRE(C > e->cfg.n_fft / 2, "asx_stft: n_time %lld must exceed n_fft/2 (reflect padding)", (long long)C);

@@ -419,6 +419,35 @@ __global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ x, i
     x[i] = x[i] * scale;
 }
 
+// Writer edge (common_separator.py:309-337): spec_utils.normalize, then (stem * 32767).astype(np.int16) and channel
+// interleave.  stem [2, N] planar -> pcm [N, 2] int16.  float32 with one rounding per operation, C truncation.
+__global__ __launch_bounds__(256) void pcm16_kernel(const float *__restrict__ stem, int64_t N, const unsigned int *peak_bits,
+                                                    float max_peak, float min_peak, int has_min, short *__restrict__ pcm) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float maxv = __uint_as_float(*peak_bits);
+  float scale = 1.0f;
+  bool scaled = false;
+  if (maxv > max_peak) {
+    scale = __fdiv_rn(max_peak, maxv);
+    scaled = true;
+  } else if (has_min && maxv < min_peak) {
+    scale = __fdiv_rn(min_peak, maxv);
+    scaled = true;
+  }
+  float l = stem[i], r = stem[N + i];
+  if (scaled) {
+    l = l * scale;
+    r = r * scale;
+  }
+  const float lq = l * 32767.0f, rq = r * 32767.0f;
+  short2 o;
+  o.x = (short)(int)lq;
+  o.y = (short)(int)rq;
+  reinterpret_cast<short2 *>(pcm)[i] = o;
+}
+
 __global__ __launch_bounds__(256) void stems_kernel(const float *__restrict__ demixed, const float *__restrict__ mix,
                                                     int64_t N, const unsigned int *peak_bits, float compensate,
                                                     float *__restrict__ primary, float *__restrict__ secondary) {

@@ -187,7 +187,7 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_vr_begin", "asx_vr_commit", "asx_vr_flops", "asx_vr_plan", "asx_vr_forward", "asx_vr_analysis",
            "asx_vr_separate", "asx_vr_separate_dev", "asx_debug_fetch",
            "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
-           "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev"]
+           "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev", "asx_pcm16", "asx_pcm16_dev"]
 
 
 def load_library():
@@ -266,6 +266,8 @@ def load_library():
     lib.asx_vr_separate.argtypes = [vp, _FP, i64, C.POINTER(_VrParams), _FP, _FP]
     lib.asx_vr_separate_dev.argtypes = [vp, vp, i64, C.POINTER(_VrParams), vp, vp, vp]
     lib.asx_debug_fetch.argtypes = [vp, C.c_char_p, _FP, i64]
+    lib.asx_pcm16.argtypes = [vp, _FP, i64, C.c_float, C.c_float, i32, C.POINTER(C.c_int16), _FP]
+    lib.asx_pcm16_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp, _FP, vp]
     lib.asx_mdxc_chunks_dev.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     lib.asx_mdxc_finalize_dev.argtypes = [vp, vp, i64, i32, vp, vp]
     lib.asx_rof_plan.argtypes = [vp, i64, i64, C.POINTER(i32), C.POINTER(i64)]
@@ -632,6 +634,18 @@ class Engine:
     def ht_fold_dev(self, mix_ptr, n, chunks_ptr, out_ptr, shifts=0, offsets=None, overlap=0.25, flags=0, stream=0):
         self._check(self._lib.asx_ht_fold_dev(self._h, mix_ptr, n, int(shifts), self._offs(shifts, offsets), float(overlap), flags,
                                               chunks_ptr, out_ptr, stream or None))
+
+    def pcm16(self, stem: np.ndarray, max_peak: float = 1.0, min_peak=None):
+        """write_audio_pydub's array work: stem [N, 2] (or [2, N] planar with planar=True semantics when shape[0] == 2)
+        -> (int16 interleaved [N, 2], peak after normalisation)."""
+        stem = np.asarray(stem, np.float32)
+        planar = np.ascontiguousarray(stem.T if stem.shape[-1] == 2 and stem.shape[0] != 2 else stem)
+        n = planar.shape[1]
+        out = np.empty((n, 2), np.int16)
+        pk = C.c_float()
+        self._check(self._lib.asx_pcm16(self._h, _ptr(planar), n, float(max_peak), float(min_peak or 0.0), int(min_peak is not None),
+                                        out.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(pk)))
+        return out, pk.value
 
     def debug_fetch(self, name: str, shape) -> np.ndarray:
         out = np.empty(shape, np.float32)

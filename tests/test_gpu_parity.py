@@ -454,3 +454,25 @@ def test_winograd_hq3_excerpt_vs_oracle(A):
     e = rel_rms(got, ref)
     print("HQ_3 excerpt rel-RMS (winograd):", e)
     assert e < TOL_STEM, e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("peak,max_peak,min_peak", [(1.7, 0.9, None), (0.3, 0.9, 0.5), (0.5, 0.9, 0.0), (0.95, 1.0, None)])
+def test_pcm16_writer_edge_bit_exact(peak, max_peak, min_peak):
+    """spec_utils.normalize + (stem * 32767).astype(np.int16) + interleave (common_separator.py:309-337), bit for bit"""
+    import audio_separator_amd as A
+    eng = A.Engine(A.MDXConfig(n_fft=64, hop_length=16, dim_f=32, segment_size=8))
+    rng = np.random.default_rng(int(peak * 100))
+    stem = rng.standard_normal((50001, 2)).astype(np.float32)
+    stem *= np.float32(peak) / np.abs(stem).max()
+    w = stem.copy()
+    maxv = np.abs(w).max()                       # spec_utils.normalize (spec_utils.py:99-115)
+    if maxv > max_peak:
+        w *= max_peak / maxv
+    elif min_peak is not None and maxv < min_peak:
+        w *= min_peak / maxv
+    want = (w * 32767).astype(np.int16)
+    got, pk = eng.pcm16(stem, max_peak, min_peak)
+    assert got.dtype == np.int16 and got.shape == (50001, 2)
+    assert np.array_equal(got, want)
+    assert abs(pk - np.abs(w).max()) <= 1e-6 * max(1.0, pk)
