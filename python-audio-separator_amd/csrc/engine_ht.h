@@ -577,6 +577,8 @@ static int ht_mha(asx_engine *e, const float *q, int64_t ldq, const float *k, co
   a.nq = nq;
   a.nk = nk;
   a.scale = 1.0f / sqrtf((float)dh);
+  static const int attn_exact = getenv("ASX_ATTN_EXACT") != nullptr;
+  a.exact = attn_exact;
   const double flops = 4.0 * (double)B * heads * (double)nq * nk * dh;
   const double bytes = 4.0 * (double)B * heads * dh * (2.0 * nq + 2.0 * nk);
   const dim3 grid((unsigned)((nq + 63) / 64), (unsigned)heads, (unsigned)B);

@@ -230,6 +230,8 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
       aa.heads = H;
       aa.gate_ld = (H % 4 == 0) ? gl : H;
       aa.scale = 1.0f / sqrtf((float)c.dim_head);
+      static const int attn_exact = getenv("ASX_ATTN_EXACT") != nullptr;
+      aa.exact = attn_exact;
       int64_t nseq;
       if (time_axis) {
         aa.len = T;

@@ -417,6 +417,7 @@ struct MhaArgs {
   int64_t ldq, ldk, ldv, ldo;
   int nq, nk;
   float scale;
+  int exact;   // 1: libm expf in the softmax; 0: hardware exp
 };
 
 template <int DT>
@@ -449,31 +450,54 @@ __global__ __launch_bounds__(256) void mha_kernel(MhaArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
 
   const int nkt = (a.nk + 63) / 64;
+  // K / V tiles are prefetched into registers one tile ahead (the global latency hides behind the MFMAs of the current
+  // tile); the wave's Q fragments are loop invariant and live in registers
+  constexpr int NLD = (64 * C4 + 255) / 256;
+  float4 kreg[NLD], vreg[NLD];
+  auto fetch = [&](int kt) {
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + i * 256;
+      const int r = e / C4, c4 = e - r * C4;
+      kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      vreg[i] = kreg[i];
+      if (e < 64 * C4 && k0 + r < a.nk) {
+        kreg[i] = *reinterpret_cast<const float4 *>(kp + (int64_t)(k0 + r) * a.ldk + c4 * 4);
+        vreg[i] = *reinterpret_cast<const float4 *>(vp + (int64_t)(k0 + r) * a.ldv + c4 * 4);
+      }
+    }
+  };
+  fetch(0);
+  __syncthreads();   // Q staged
+  float bqr[DH / 4];
+#pragma unroll
+  for (int kk = 0; kk < DH / 4; ++kk) bqr[kk] = Qs[(wave * 16 + li) * QS + 4 * kk + lk];
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * 64;
-    __syncthreads();
-    for (int e = tid; e < 64 * C4; e += 256) {
-      const int r = e / C4, c4 = e - r * C4;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (k0 + r < a.nk) {
-        kv = *reinterpret_cast<const float4 *>(kp + (int64_t)(k0 + r) * a.ldk + c4 * 4);
-        vv = *reinterpret_cast<const float4 *>(vp + (int64_t)(k0 + r) * a.ldv + c4 * 4);
+    __syncthreads();   // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + i * 256;
+      if (e < 64 * C4) {
+        const int r = e / C4, c4 = e - r * C4;
+        float *dk = &Ks[r * QS + c4 * 4];
+        dk[0] = kreg[i].x;
+        dk[1] = kreg[i].y;
+        dk[2] = kreg[i].z;
+        dk[3] = kreg[i].w;
+        *reinterpret_cast<float4 *>(&Vs[r * VS + c4 * 4]) = vreg[i];
       }
-      float *dk = &Ks[r * QS + c4 * 4];
-      dk[0] = kv.x;
-      dk[1] = kv.y;
-      dk[2] = kv.z;
-      dk[3] = kv.w;
-      *reinterpret_cast<float4 *>(&Vs[r * VS + c4 * 4]) = vv;
     }
     __syncthreads();
+    if (kt + 1 < nkt) fetch(kt + 1);
 
     f32x4 st[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) st[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < DH / 4; ++kk) {
-      const float bq = Qs[(wave * 16 + li) * QS + 4 * kk + lk];
+      const float bq = bqr[kk];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const float av = Ks[(mt * 16 + li) * QS + 4 * kk + lk];
@@ -494,13 +518,13 @@ __global__ __launch_bounds__(256) void mha_kernel(MhaArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    const float corr = (m_run == -INFINITY) ? 0.f : (a.exact ? expf(m_run - m_new) : __expf(m_run - m_new));
     float psum = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = (st[mt][r] == -INFINITY) ? 0.f : expf(st[mt][r] - m_new);
+        const float p = (st[mt][r] == -INFINITY) ? 0.f : (a.exact ? expf(st[mt][r] - m_new) : __expf(st[mt][r] - m_new));
         st[mt][r] = p;
         psum += p;
       }

@@ -76,6 +76,7 @@ struct AttnArgs {
   int64_t inner_cnt;  // sequence s -> base row = (s / inner_cnt) * outer_stride + (s % inner_cnt) * inner_stride
   int64_t outer_stride, inner_stride;
   float scale;
+  int exact;          // 1: libm expf in the softmax; 0: the hardware exp unit (2 ulp, ASX_ATTN_EXACT unset)
 };
 
 constexpr int ATT_QS = 66;  // LDS row strides (floats): Q/K == 2 (mod 32), V == 4 (mod 8)
@@ -113,25 +114,44 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
 
   const int nkt = (a.len + 63) / 64;
-  for (int kt = 0; kt < nkt; ++kt) {
+  // K / V tiles are prefetched into registers one tile ahead; the wave's Q fragments stay in registers
+  float4 kreg[4], vreg[4];
+  auto fetch = [&](int kt) {
     const int k0 = kt * 64;
-    __syncthreads();  // previous tile fully consumed (and Q staged on the first pass)
-    for (int e = tid; e < 64 * 16; e += 256) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
       const int r = e >> 4, c4 = e & 15;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      vreg[i] = kreg[i];
       if (k0 + r < a.len) {
         const float *rowp = a.qkv + (base + (int64_t)(k0 + r) * a.row_stride) * ld + h * 64 + c4 * 4;
-        kv = *reinterpret_cast<const float4 *>(rowp + inner);
-        vv = *reinterpret_cast<const float4 *>(rowp + 2 * inner);
+        kreg[i] = *reinterpret_cast<const float4 *>(rowp + inner);
+        vreg[i] = *reinterpret_cast<const float4 *>(rowp + 2 * inner);
       }
+    }
+  };
+  fetch(0);
+  __syncthreads();   // Q staged
+  float bqr[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) bqr[kk] = Qs[(wave * 16 + li) * ATT_QS + 4 * kk + lk];
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int k0 = kt * 64;
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      const int r = e >> 4, c4 = e & 15;
       float *dk = &Ks[r * ATT_QS + c4 * 4];
-      dk[0] = kv.x;
-      dk[1] = kv.y;
-      dk[2] = kv.z;
-      dk[3] = kv.w;
-      *reinterpret_cast<float4 *>(&Vs[r * ATT_VS + c4 * 4]) = vv;
+      dk[0] = kreg[i].x;
+      dk[1] = kreg[i].y;
+      dk[2] = kreg[i].z;
+      dk[3] = kreg[i].w;
+      *reinterpret_cast<float4 *>(&Vs[r * ATT_VS + c4 * 4]) = vreg[i];
     }
     __syncthreads();
+    if (kt + 1 < nkt) fetch(kt + 1);
 
     // S^T[key, query] for this wave's 16 queries
     f32x4 st[4];
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     for (int i = 0; i < 4; ++i) st[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-      const float b = Qs[(wave * 16 + li) * ATT_QS + 4 * kk + lk];
+      const float b = bqr[kk];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const float av = Ks[(mt * 16 + li) * ATT_QS + 4 * kk + lk];
@@ -161,13 +181,13 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    const float corr = (m_run == -INFINITY) ? 0.f : (a.exact ? expf(m_run - m_new) : __expf(m_run - m_new));
     float psum = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = (st[mt][r] == -INFINITY) ? 0.f : expf(st[mt][r] - m_new);
+        const float p = (st[mt][r] == -INFINITY) ? 0.f : (a.exact ? expf(st[mt][r] - m_new) : __expf(st[mt][r] - m_new));
         st[mt][r] = p;
         psum += p;
       }
