@@ -496,8 +496,7 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
   const double bytes = 4.0 * ((double)rows_outer * q.I * q.Cin + out_elems + (double)g.n * g.k + (res ? out_elems : 0.0));
   const int cls = mode == GG_CONVT ? ASX_PROF_UP : (q.SI > 1 ? ASX_PROF_DOWN : ASX_PROF_CONV3X3);
   return timed(e, cls, flops, bytes, s, [&]() {
-    if (g.n > 64) ht_launch_gg<2, 8>(a, s);
-    else ht_launch_gg<1, 8>(a, s);
+    ht_gg_dispatch(a, s);
   });
 }
 
@@ -649,7 +648,7 @@ static int ht_ensure_workspace(asx_engine *e, int B) {
   {   // per-row GroupNorm partials of the DConv GEMMs: [N tiles][rows][2]
     size_t rsz = 0;
     for (int i = 0; i < D; ++i) {
-      const size_t tiles = (2 * (size_t)n.C[i] + 127) / 128;
+      const size_t tiles = (2 * (size_t)n.C[i] + 95) / 96;
       rsz = std::max(rsz, std::max(BT * n.F[i + 1], (size_t)B * n.L[i + 1]) * tiles * 2);
     }
     want(b.rowstat, rsz);
@@ -698,7 +697,7 @@ static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I
     const int64_t R = along_outer ? O : I;
     const int64_t M = (int64_t)B * O * I;
     auto fold = [&](int ncols, double count, double *acc, float2 *mr) {
-      const int ntile = (ncols + (ncols > 64 ? 128 : 64) - 1) / (ncols > 64 ? 128 : 64);   // N tiles of ht_gg's launch choice
+      const int ntile = (ncols + gg_tile_n(ncols) - 1) / gg_tile_n(ncols);   // N tiles of ht_gg's launch choice
       return timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)M * ntile, s, [&]() {
         hipLaunchKernelGGL(rowstat_reduce_kernel, dim3((unsigned)(G2 > 1 ? (G2 + 63) / 64 : 1), (unsigned)B), dim3(256), 0, s,
                            reinterpret_cast<const float2 *>(n.b.rowstat), M, ntile, (int64_t)O * I, G2, R, count, 1e-5f, acc, mr);

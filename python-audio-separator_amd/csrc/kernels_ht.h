@@ -44,10 +44,14 @@ struct GgArgs {
   const float *gamma, *beta, *ls;   // GG_GNGLU: GroupNorm affine (row order of w) and the LayerScale of the GLU outputs
 };
 
-template <int NREP, int MREP>
+// Wave layout: MS = false -- the four waves split the N tile (wave w owns columns [16*NREP*w, +16*NREP) of all BM = 16*MREP
+// rows): wide outputs.  MS = true -- the waves split the rows (wave w owns rows [16*MREP*w, +16*MREP) of all BN = 16*NREP
+// columns; BM = 64*MREP): narrow outputs (N = 8 .. 96) without padding N up to a multiple of 64.
+template <int NREP, int MREP, bool MS = false>
 __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
   constexpr int BK = 32, CPR = 8, RPI = 8;
-  constexpr int BM = 16 * MREP, BN = 64 * NREP, BUF = (BM + BN) * BK;
+  constexpr int BM = MS ? 64 * MREP : 16 * MREP, BN = MS ? 16 * NREP : 64 * NREP, BUF = (BM + BN) * BK;
+  constexpr int MG = MREP < 4 ? MREP : 4;   // activation fragments are loaded in groups of MG
   constexpr int NXI = BM / RPI, NWI = BN / RPI, NXL = (NXI + 3) / 4;
   extern __shared__ float lds_f[];
 
@@ -61,6 +65,9 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
   const int bn = lid % nbn;
   const int64_t m0 = (int64_t)(lid / nbn) * BM;
   const int n0 = bn * BN;
+
+  const int xrow0 = MS ? wave * 16 * MREP : 0;   // first tile row / column this wave owns
+  const int wcol0 = MS ? 0 : wave * 16 * NREP;
 
   const int lr = lane / CPR, lp = lane % CPR;
   // swizzle g(row) = (row >> 1) & 7 with row = q*8 + lr, q = wave + 4i: depends on (wave & 1, lr) only
@@ -161,18 +168,18 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
       f32x4 wa[NREP];
 #pragma unroll
       for (int n = 0; n < NREP; ++n)
-        wa[n] = *reinterpret_cast<const f32x4 *>(&ws[(wave * 16 * NREP + n * 16 + li) * BK + pc]);
+        wa[n] = *reinterpret_cast<const f32x4 *>(&ws[(wcol0 + n * 16 + li) * BK + pc]);
 #pragma unroll
-      for (int mg = 0; mg < MREP; mg += 4) {
-        f32x4 xf[4];
+      for (int mg = 0; mg < MREP; mg += MG) {
+        f32x4 xf[MG];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const f32x4 *>(&xs[((mg + m) * 16 + li) * BK + pc]);
+        for (int m = 0; m < MG; ++m) xf[m] = *reinterpret_cast<const f32x4 *>(&xs[(xrow0 + (mg + m) * 16 + li) * BK + pc]);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int n = 0; n < NREP; ++n)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[n][mg + m] = ASX_MFMA(wa[n][j], xf[m][j], acc[n][mg + m]);
+            for (int m = 0; m < MG; ++m) acc[n][mg + m] = ASX_MFMA(wa[n][j], xf[m][j], acc[n][mg + m]);
       }
     }
   }
@@ -183,12 +190,12 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
     // y[row, c] += ls[c] * glu(groupnorm(z))[c]; all read-modify-write loads are issued before the first store
     float2 old[MREP][NREP];
     float2 mr[MREP];
-    int64_t gb = (m0 + li) / a.g_outer;
-    int64_t gr = (m0 + li) - gb * a.g_outer;     // row inside the batch item
+    int64_t gb = (m0 + xrow0 + li) / a.g_outer;
+    int64_t gr = (m0 + xrow0 + li) - gb * a.g_outer;     // row inside the batch item
     int gm = (int)(gr % a.g_mod);
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
-      const int64_t row = m0 + m * 16 + li;
+      const int64_t row = m0 + xrow0 + m * 16 + li;
       mr[m] = make_float2(0.f, 1.f);
       if (row < a.M) mr[m] = a.stat_in[gb * a.g_mod + gm];
       gr += 16;
@@ -200,21 +207,21 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
       }
 #pragma unroll
       for (int n = 0; n < NREP; ++n) {
-        const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+        const int col = n0 + wcol0 + n * 16 + lk * 4;
         old[m][n] = make_float2(0.f, 0.f);
         if (row < a.M && col < a.N) old[m][n] = *reinterpret_cast<const float2 *>(a.y + row * a.ldy + (col >> 1));
       }
     }
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
-      const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+      const int col = n0 + wcol0 + n * 16 + lk * 4;
       if (col >= a.N) continue;
       const f32x4 bz = *reinterpret_cast<const f32x4 *>(a.bias + col);
       const f32x4 ga = *reinterpret_cast<const f32x4 *>(a.gamma + col), be = *reinterpret_cast<const f32x4 *>(a.beta + col);
       const float2 l2 = *reinterpret_cast<const float2 *>(a.ls + (col >> 1));
 #pragma unroll
       for (int m = 0; m < MREP; ++m) {
-        const int64_t row = m0 + m * 16 + li;
+        const int64_t row = m0 + xrow0 + m * 16 + li;
         if (row >= a.M) continue;
         const f32x4 v = acc[n][m] + bz;
         const float gm = mr[m].x, gr = mr[m].y;
@@ -231,13 +238,13 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
   float rs[MREP], rss[MREP];
   int64_t eb;
   int eoo, ej;
-  split(m0 + li, eb, eoo, ej);
-  int rmod = a.res_mod > 0 ? (int)((m0 + li) % a.res_mod) : 0;
+  split(m0 + xrow0 + li, eb, eoo, ej);
+  int rmod = a.res_mod > 0 ? (int)((m0 + xrow0 + li) % a.res_mod) : 0;
 #pragma unroll
   for (int m = 0; m < MREP; ++m) {
     rs[m] = 0.f;
     rss[m] = 0.f;
-    const int64_t row = m0 + m * 16 + li;
+    const int64_t row = m0 + xrow0 + m * 16 + li;
     const int64_t rrow = a.res_mod > 0 ? rmod : row;
     const int64_t bo = eb * a.OR + eoo;
     const int j = ej;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
     if (row >= a.M) continue;
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
-      const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+      const int col = n0 + wcol0 + n * 16 + lk * 4;
       if (col >= a.N) continue;
       f32x4 v = acc[n][m];
       if (a.bias != nullptr) v += *reinterpret_cast<const f32x4 *>(a.bias + col);
@@ -292,31 +299,44 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
     }
   }
   if (want_stats) {
-    // per-row sums: over the 4 column groups of a wave (lk), then over the 4 waves through LDS; one float2 per
-    // (N tile, row) goes to row_stat and rowstat_reduce_kernel folds rows into groups (no atomics, reproducible)
-    __syncthreads();   // the K loop's LDS tiles are dead
-    float *sh = lds_f;                 // [4 waves][BM][2]
+    // per-row sums: over the 4 column groups of a wave (lk), then (N-split layout) over the 4 waves through LDS; one
+    // float2 per (N tile, row) goes to row_stat and rowstat_reduce_kernel folds rows into groups (no atomics, reproducible)
+    if (MS) {
 #pragma unroll
-    for (int m = 0; m < MREP; ++m) {
-      float s1 = rs[m], s2 = rss[m];
-      s1 += __shfl_xor(s1, 16);
-      s2 += __shfl_xor(s2, 16);
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lk == 0) {
-        sh[(wave * BM + m * 16 + li) * 2] = s1;
-        sh[(wave * BM + m * 16 + li) * 2 + 1] = s2;
+      for (int m = 0; m < MREP; ++m) {
+        float s1 = rs[m], s2 = rss[m];
+        s1 += __shfl_xor(s1, 16);
+        s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        const int64_t row = m0 + xrow0 + m * 16 + li;
+        if (lk == 0 && row < a.M) a.row_stat[(int64_t)bn * a.M + row] = make_float2(s1, s2);
       }
-    }
-    __syncthreads();
-    if (tid < BM && m0 + tid < a.M) {
-      float s1 = 0.f, s2 = 0.f;
+    } else {
+      __syncthreads();   // the K loop's LDS tiles are dead
+      float *sh = lds_f;                 // [4 waves][BM][2]
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        s1 += sh[(w * BM + tid) * 2];
-        s2 += sh[(w * BM + tid) * 2 + 1];
+      for (int m = 0; m < MREP; ++m) {
+        float s1 = rs[m], s2 = rss[m];
+        s1 += __shfl_xor(s1, 16);
+        s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lk == 0) {
+          sh[(wave * BM + m * 16 + li) * 2] = s1;
+          sh[(wave * BM + m * 16 + li) * 2 + 1] = s2;
+        }
       }
-      a.row_stat[(int64_t)bn * a.M + m0 + tid] = make_float2(s1, s2);
+      __syncthreads();
+      if (tid < BM && m0 + tid < a.M) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s1 += sh[(w * BM + tid) * 2];
+          s2 += sh[(w * BM + tid) * 2 + 1];
+        }
+        a.row_stat[(int64_t)bn * a.M + m0 + tid] = make_float2(s1, s2);
+      }
     }
   }
 }
@@ -389,19 +409,42 @@ __global__ __launch_bounds__(256) void rowstat_reduce_kernel(const float2 *__res
   }
 }
 
-template <int NREP, int MREP>
+template <int NREP, int MREP, bool MS = false>
 static void ht_launch_gg(const GgArgs &a, hipStream_t s) {
-  constexpr int BM = 16 * MREP, BN = 64 * NREP;
+  constexpr int BM = MS ? 64 * MREP : 16 * MREP, BN = MS ? 16 * NREP : 64 * NREP;
   constexpr int lds = 2 * (BM + BN) * 32 * 4;
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gg_kernel<NREP, MREP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gg_kernel<NREP, MREP, MS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     once = true;
   }
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gg_kernel<NREP, MREP>), dim3((unsigned)(nbm * nbn)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((gg_kernel<NREP, MREP, MS>), dim3((unsigned)(nbm * nbn)), dim3(256), lds, s, a);
+}
+
+// N tile width ht_gg_dispatch will use for an output of n columns (rowstat_reduce_kernel needs the tile count)
+static inline int gg_tile_n(int n) {
+  static const bool legacy = getenv("ASX_GG_LEGACY") != nullptr;
+  if (legacy) return n > 64 ? 128 : 64;
+  if (n <= 16) return 16;
+  if (n <= 32) return 32;
+  if (n <= 48) return 48;
+  if (n <= 64) return 64;
+  const int p96 = (n + 95) / 96 * 96, p128 = (n + 127) / 128 * 128;
+  return p96 < p128 ? 96 : 128;
+}
+
+static void ht_gg_dispatch(const GgArgs &a, hipStream_t s) {
+  switch (gg_tile_n(a.N)) {
+    case 16: ht_launch_gg<1, 4, true>(a, s); break;
+    case 32: ht_launch_gg<2, 4, true>(a, s); break;
+    case 48: ht_launch_gg<3, 4, true>(a, s); break;
+    case 64: ht_launch_gg<1, 8>(a, s); break;
+    case 96: ht_launch_gg<6, 2, true>(a, s); break;
+    default: ht_launch_gg<2, 8>(a, s); break;
+  }
 }
 
 // ---------------------------------------------------------------------------
