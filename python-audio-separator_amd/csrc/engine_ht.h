@@ -542,6 +542,17 @@ static int ht_ln(asx_engine *e, const float *x, int C, const DevBuf &g, const De
 static int ht_stats(asx_engine *e, const float *x, int G1, int64_t R, int64_t P, int64_t gdiv, int ld, int Cn, int G2,
                     double *acc, hipStream_t s) {
   HIPCHK(hipMemsetAsync(acc, 0, (size_t)G1 * G2 * 16, s));
+  if (R == 1 && G2 == 1 && gdiv >= P && ld == 1 && P >= 65536) {
+    // one flat group per item: fold the plane into rows so that a thread sums a column instead of 256 threads
+    // hammering one LDS / global atomic each (0.5 ms -> tens of microseconds for a 688 k-sample segment)
+    for (int64_t d = 1024; d >= 2; --d)
+      if (P % d == 0 && P / d >= 256) {
+        R = d;
+        P /= d;
+        gdiv = P;
+        break;
+      }
+  }
   int64_t rsplit = R / 96;
   if (rsplit < 1) rsplit = 1;
   if (rsplit > 1024) rsplit = 1024;
