@@ -348,6 +348,18 @@ int asx_pcm16(asx_engine *e, const float *stem_host, int64_t n_samples, float ma
 int asx_pcm16_dev(asx_engine *e, const float *stem_dev, int64_t n_samples, float max_peak, float min_peak, int32_t has_min,
                   int16_t *pcm_dev, float *peak_after, void *stream);
 
+/* Spectral edges, librosa STFT(2048, 1024) semantics:
+ * asx_ensemble   = Ensembler.ensemble (audio_separator/separator/ensembler.py:12-160) over K equal-length stereo waves
+ *                  [K, 2, N]; algorithm: 0 avg_wave, 1 median_wave, 2 min_wave, 3 max_wave, 4 avg_fft, 5 median_fft,
+ *                  6 min_fft, 7 max_fft, 8 uvr_max_spec, 9 uvr_min_spec; weights [K] (avg_* only) or NULL; out [2, *n_out]
+ *                  (*n_out = N, or 1024 * (N / 1024) for the uvr_* algorithms, which do not pass a length to istft).
+ * asx_invert_stem = spec_utils.invert_stem(mixture, stem) (uvr_lib_v5/spec_utils.py:573-580), planar [2, *n_out]. */
+int asx_ensemble(asx_engine *e, const float *waves_host, int32_t k, int64_t n_samples, int32_t algorithm, const double *weights,
+                 float *out_host, int64_t *n_out);
+int asx_ensemble_dev(asx_engine *e, const float *waves_dev, int32_t k, int64_t n_samples, int32_t algorithm, const double *weights,
+                     float *out_dev, int64_t *n_out, void *stream);
+int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host, int64_t n_samples, float *out_host, int64_t *n_out);
+
 /* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host. */
 int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel);
 

@@ -47,6 +47,8 @@ def hann_periodic(n: int) -> np.ndarray:
 def lr_stft(y, n_fft=2048, hop_length=None, **_):
     """librosa.stft(y, n_fft, hop_length) with the 0.10+ defaults (center=True, pad_mode="constant", hann)."""
     y = np.asarray(y)
+    if y.ndim > 1:
+        return np.stack([lr_stft(c, n_fft, hop_length) for c in y])
     hop = hop_length if hop_length is not None else n_fft // 4
     w = hann_periodic(n_fft)
     yp = np.pad(y, (n_fft // 2, n_fft // 2), mode="constant")
@@ -58,24 +60,32 @@ def lr_stft(y, n_fft=2048, hop_length=None, **_):
     return out.astype(cdtype)
 
 
-def lr_istft(S, hop_length=None, n_fft=None, **_):
-    """librosa.istft(S, hop_length) (center=True, hann, length=None)."""
+def lr_istft(S, hop_length=None, n_fft=None, length=None, **_):
+    """librosa.istft(S, hop_length, length=length) (center=True, hann).  S may carry leading channel axes."""
     S = np.asarray(S)
+    if S.ndim > 2:
+        return np.stack([lr_istft(s_, hop_length, n_fft, length) for s_ in S])
     n_fft = n_fft or 2 * (S.shape[0] - 1)
     hop = hop_length if hop_length is not None else n_fft // 4
     T = S.shape[1]
+    if length is not None:
+        T = min(T, int(np.ceil((length + 2 * (n_fft // 2)) / hop)))      # frames that fit the padded target (librosa istft)
     w = hann_periodic(n_fft)
     rdtype = np.float32 if S.dtype == np.complex64 else np.float64
-    frames = np.fft.irfft(S, n=n_fft, axis=0) * w[:, None]
+    frames = np.fft.irfft(S[:, :T], n=n_fft, axis=0) * w[:, None]
     n = n_fft + hop * (T - 1)
-    y = np.zeros(n, dtype=rdtype)
-    ss = np.zeros(n, dtype=rdtype)
+    if length is not None:
+        n = length + 2 * (n_fft // 2)
+    y = np.zeros(max(n, n_fft + hop * (T - 1)), dtype=rdtype)
+    ss = np.zeros_like(y)
     wsq = (w ** 2).astype(rdtype)
     for t in range(T):
         y[t * hop: t * hop + n_fft] += frames[:, t].astype(rdtype)
         ss[t * hop: t * hop + n_fft] += wsq
     nz = ss > np.finfo(rdtype).tiny
     y[nz] /= ss[nz]
+    if length is not None:
+        return y[n_fft // 2: n_fft // 2 + length]
     return y[n_fft // 2: n_fft // 2 + hop * (T - 1)]
 
 

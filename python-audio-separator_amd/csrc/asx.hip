@@ -23,6 +23,7 @@
 #include "kernels_rof.h"
 #include "kernels_ht.h"
 #include "kernels_vr.h"
+#include "kernels_ens.h"
 
 using namespace asx;
 
@@ -117,6 +118,7 @@ struct V3Net;
 struct RofNet;
 struct HtNet;
 struct VrNet;
+struct EnsCtx;
 
 struct asx_engine {
   int device = 0;
@@ -124,6 +126,7 @@ struct asx_engine {
   RofNet *rof = nullptr;
   HtNet *ht = nullptr;
   VrNet *vr = nullptr;
+  EnsCtx *ens = nullptr;
   asx_mdx_config cfg{};
   FftPlan plan{};
   DevBuf d_window, d_tw, d_env;  // env for T = segment_size
@@ -815,6 +818,7 @@ static void v3_destroy(V3Net *n);
 static void rof_destroy(RofNet *n);
 static void ht_destroy(HtNet *n);
 static void vr_destroy(VrNet *n);
+static void ens_destroy(EnsCtx *c);
 static void free_conv(ConvLayer &L) {
   L.w.release();
   L.b.release();
@@ -865,6 +869,7 @@ void asx_engine_destroy(asx_engine *e) {
   if (e->rof) rof_destroy(e->rof);
   if (e->ht) ht_destroy(e->ht);
   if (e->vr) vr_destroy(e->vr);
+  if (e->ens) ens_destroy(e->ens);
   delete e;
 }
 
@@ -1025,6 +1030,7 @@ double asx_net_flops(const asx_engine *e, int32_t batch) {
 #include "engine_rof.h"
 #include "engine_ht.h"
 #include "engine_vr.h"
+#include "engine_ens.h"
 extern "C" {
 
 // ---- plan ------------------------------------------------------------------
@@ -2187,6 +2193,45 @@ int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel)
   }
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(host, src, (size_t)numel * 4, hipMemcpyDeviceToHost));
+  return ASX_OK;
+}
+
+// ---- spectral edges ------------------------------------------------------------------
+int asx_ensemble(asx_engine *e, const float *waves_host, int32_t K, int64_t N, int32_t algorithm, const double *weights,
+                 float *out_host, int64_t *n_out) {
+  REQUIRE(e && waves_host && out_host && n_out && N >= 1, "asx_ensemble: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  CHK(ens_ctx(e));
+  EnsCtx &c = *e->ens;
+  CHK(c.din.ensure((size_t)K * 2 * N * 4));
+  CHK(c.dout.ensure((size_t)2 * N * 4));
+  HIPCHK(hipMemcpy(c.din.p, waves_host, (size_t)K * 2 * N * 4, hipMemcpyHostToDevice));
+  CHK(ens_ensemble_dev(e, c.din.f(), K, N, algorithm, weights, c.dout.f(), n_out, nullptr));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out_host, c.dout.p, (size_t)2 * (*n_out) * 4, hipMemcpyDeviceToHost));
+  return ASX_OK;
+}
+
+int asx_ensemble_dev(asx_engine *e, const float *waves_dev, int32_t K, int64_t N, int32_t algorithm, const double *weights,
+                     float *out_dev, int64_t *n_out, void *stream) {
+  REQUIRE(e && waves_dev && out_dev && n_out && N >= 1, "asx_ensemble_dev: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  return ens_ensemble_dev(e, waves_dev, K, N, algorithm, weights, out_dev, n_out, reinterpret_cast<hipStream_t>(stream));
+}
+
+int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host, int64_t N, float *out_host, int64_t *n_out) {
+  REQUIRE(e && mix_host && stem_host && out_host && n_out && N >= 1, "asx_invert_stem: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  CHK(ens_ctx(e));
+  EnsCtx &c = *e->ens;
+  CHK(c.din.ensure((size_t)2 * N * 4));
+  CHK(c.din2.ensure((size_t)2 * N * 4));
+  CHK(c.dout.ensure((size_t)2 * N * 4));
+  HIPCHK(hipMemcpy(c.din.p, mix_host, (size_t)2 * N * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c.din2.p, stem_host, (size_t)2 * N * 4, hipMemcpyHostToDevice));
+  CHK(ens_invert_dev(e, c.din.f(), c.din2.f(), N, c.dout.f(), n_out, nullptr));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out_host, c.dout.p, (size_t)2 * (*n_out) * 4, hipMemcpyDeviceToHost));
   return ASX_OK;
 }
 

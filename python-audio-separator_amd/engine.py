@@ -187,7 +187,7 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_vr_begin", "asx_vr_commit", "asx_vr_flops", "asx_vr_plan", "asx_vr_forward", "asx_vr_analysis",
            "asx_vr_separate", "asx_vr_separate_dev", "asx_debug_fetch",
            "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
-           "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev", "asx_pcm16", "asx_pcm16_dev"]
+           "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem"]
 
 
 def load_library():
@@ -266,6 +266,9 @@ def load_library():
     lib.asx_vr_separate.argtypes = [vp, _FP, i64, C.POINTER(_VrParams), _FP, _FP]
     lib.asx_vr_separate_dev.argtypes = [vp, vp, i64, C.POINTER(_VrParams), vp, vp, vp]
     lib.asx_debug_fetch.argtypes = [vp, C.c_char_p, _FP, i64]
+    lib.asx_ensemble.argtypes = [vp, _FP, i32, i64, i32, C.POINTER(C.c_double), _FP, C.POINTER(i64)]
+    lib.asx_ensemble_dev.argtypes = [vp, vp, i32, i64, i32, C.POINTER(C.c_double), vp, C.POINTER(i64), vp]
+    lib.asx_invert_stem.argtypes = [vp, _FP, _FP, i64, _FP, C.POINTER(i64)]
     lib.asx_pcm16.argtypes = [vp, _FP, i64, C.c_float, C.c_float, i32, C.POINTER(C.c_int16), _FP]
     lib.asx_pcm16_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp, _FP, vp]
     lib.asx_mdxc_chunks_dev.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
@@ -646,6 +649,41 @@ class Engine:
         self._check(self._lib.asx_pcm16(self._h, _ptr(planar), n, float(max_peak), float(min_peak or 0.0), int(min_peak is not None),
                                         out.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(pk)))
         return out, pk.value
+
+    ENSEMBLE_ALGORITHMS = ("avg_wave", "median_wave", "min_wave", "max_wave", "avg_fft", "median_fft", "min_fft", "max_fft",
+                           "uvr_max_spec", "uvr_min_spec")
+
+    def ensemble(self, waveforms, algorithm: str = "avg_wave", weights=None) -> np.ndarray:
+        """Ensembler.ensemble (ensembler.py:12-74): list of [2, N] waves (zero-padded to the longest) -> [2, N']."""
+        if algorithm not in self.ENSEMBLE_ALGORITHMS:
+            raise ValueError(f"Unknown ensemble algorithm: {algorithm}")
+        ws = [_f32(w) for w in waveforms]
+        if len(ws) == 1:
+            return ws[0]
+        if any(w.ndim != 2 or w.shape[0] != 2 for w in ws):
+            raise ValueError("All waveforms must be stereo [2, N] for the accelerated ensemble")
+        n = max(w.shape[1] for w in ws)
+        stack = np.zeros((len(ws), 2, n), np.float32)
+        for k, w in enumerate(ws):
+            stack[k, :, : w.shape[1]] = w
+        wt = None
+        if weights is not None and len(weights) == len(ws) and np.all(np.isfinite(weights)) and np.sum(weights) != 0:
+            wt = (C.c_double * len(ws))(*[float(v) for v in weights])
+        out = np.empty((2, n), np.float32)
+        n_out = C.c_int64()
+        self._check(self._lib.asx_ensemble(self._h, _ptr(stack), len(ws), n, self.ENSEMBLE_ALGORITHMS.index(algorithm), wt, _ptr(out),
+                                           C.byref(n_out)))
+        return out.reshape(-1)[: 2 * n_out.value].reshape(2, n_out.value).copy()     # the engine writes planar [2, n_out]
+
+    def invert_stem(self, mixture: np.ndarray, stem: np.ndarray) -> np.ndarray:
+        """spec_utils.invert_stem(mixture [2, N], stem [2, N]) -> [N', 2]."""
+        m, st = _f32(mixture), _f32(stem)
+        n = min(m.shape[1], st.shape[1])
+        m, st = np.ascontiguousarray(m[:, :n]), np.ascontiguousarray(st[:, :n])
+        out = np.empty((2, n), np.float32)
+        n_out = C.c_int64()
+        self._check(self._lib.asx_invert_stem(self._h, _ptr(m), _ptr(st), n, _ptr(out), C.byref(n_out)))
+        return np.ascontiguousarray(out.reshape(-1)[: 2 * n_out.value].reshape(2, n_out.value).T)
 
     def debug_fetch(self, name: str, shape) -> np.ndarray:
         out = np.empty(shape, np.float32)
