@@ -1,0 +1,80 @@
+"""One unit of work at the PUBLIC model layouts (production tile shapes, FFT sizes, head dims -- the small golden
+configs cannot exercise them) against the CPU oracle: one htdemucs segment, one VR clip, one MDX23C chunk, one
+BS-Roformer chunk (transformer depth cut to 2 of 12 to keep the CPU side short; every layer has the same shape)."""
+import os
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel_rms(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(np.sqrt(np.mean(b ** 2)), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def A():
+    import torch
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    import audio_separator_amd as A
+    return A
+
+
+def test_htdemucs_segment(A):
+    from oracle import demucs_oracle as D
+    oc = D.HTConfig()
+    sd = D.make_ht_state(oc, 0)
+    eng = A.Engine(A.MDXConfig(n_fft=4096, hop_length=1024, dim_f=2048, segment_size=8))
+    eng.load_ht(A.HTConfig(segment=Fraction(39, 5)), sd)
+    x = (0.3 * np.random.default_rng(0).standard_normal((1, 2, oc.training_length))).astype(np.float32)
+    got = eng.ht_forward(x)
+    want = D.ht_forward(x, sd, oc)
+    assert rel_rms(got, want) < TOL, rel_rms(got, want)
+
+
+def test_vr_clip(A):
+    from oracle import vr_oracle as V
+    mp = {"bins": 768, "unstable_bins": 7, "reduction_bins": 668, "sr": 44100, "pre_filter_start": 740, "pre_filter_stop": 768,
+          "band": {1: {"sr": 11025, "hl": 128, "n_fft": 1024, "crop_start": 0, "crop_stop": 186, "lpf_start": 37, "lpf_stop": 73, "res_type": "polyphase"},
+                   2: {"sr": 11025, "hl": 128, "n_fft": 512, "crop_start": 4, "crop_stop": 185, "hpf_start": 36, "hpf_stop": 18, "lpf_start": 93, "lpf_stop": 185, "res_type": "polyphase"},
+                   3: {"sr": 22050, "hl": 256, "n_fft": 512, "crop_start": 46, "crop_stop": 186, "hpf_start": 93, "hpf_stop": 46, "lpf_start": 164, "lpf_stop": 186, "res_type": "polyphase"},
+                   4: {"sr": 44100, "hl": 512, "n_fft": 768, "crop_start": 121, "crop_stop": 382, "hpf_start": 138, "hpf_stop": 123, "res_type": "sinc_medium"}}}
+    arch = 123821
+    sd = V.make_vr_state(arch, 0)
+    dm = A.VRDemixer({"model_params": mp, "primary_stem_name": "Instrumental", "torch_device": 0},
+                     {"window_size": 512, "batch_size": 4, "aggression": 5}, state_dict=sd, nn_arch_size=arch)
+    wave = (0.3 * np.random.default_rng(1).standard_normal((2, 44100 * 5))).astype(np.float32)
+    gp, gs = dm.separate_stems(wave)
+    wp, ws = V.vr_separate(wave, sd, arch, V.ModelParams(mp), window_size=512, batch_size=2, aggression=5)
+    assert rel_rms(gp, wp) < TOL, rel_rms(gp, wp)
+    assert rel_rms(gs, ws) < TOL, rel_rms(gs, ws)
+
+
+def test_mdx23c_chunk(A):
+    from oracle import mdxc_oracle as M
+    cfg = M.V3Config()
+    sd = M.make_v3_state(cfg, 0)
+    dm = A.MDXCDemixer({"model_data": cfg.as_model_data(), "torch_device": 0}, {"overlap": 2}, state_dict=sd, max_batch=1)
+    Cn = cfg.hop_length * (cfg.dim_t - 1)
+    x = (0.3 * np.random.default_rng(2).standard_normal((1, 2, Cn))).astype(np.float32)
+    got = dm.engine.v3_forward(x)
+    want = M.v3_forward(x, sd, cfg)
+    assert rel_rms(got, want) < TOL, rel_rms(got, want)
+
+
+def test_bs_roformer_chunk(A):
+    from oracle import roformer_oracle as R
+    cfg = R.RoformerConfig(depth=2, freqs_per_bands=R.DEFAULT_FREQS_PER_BANDS)
+    sd = R.make_roformer_state(cfg, 0)
+    dm = A.MDXCDemixer({"model_data": cfg.as_model_data(), "torch_device": 0, "secondary_stem_name": "other"}, {"overlap": 8},
+                       state_dict=sd, max_batch=1)
+    C = cfg.stft_hop_length * (cfg.dim_t - 1)
+    x = (0.3 * np.random.default_rng(3).standard_normal((1, 2, C))).astype(np.float32)
+    got = dm.engine.rof_forward(x)
+    want = R.roformer_forward(x, sd, cfg)
+    assert rel_rms(got[:, 0] if got.ndim == 4 else got, want) < TOL
