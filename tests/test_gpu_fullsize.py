@@ -78,3 +78,52 @@ def test_bs_roformer_chunk(A):
     got = dm.engine.rof_forward(x)
     want = R.roformer_forward(x, sd, cfg)
     assert rel_rms(got[:, 0] if got.ndim == 4 else got, want) < TOL
+
+
+def test_mel_band_roformer_chunk(A):
+    from oracle import roformer_oracle as R
+    cfg = R.RoformerConfig.mel_config(dim=384, depth=2, heads=8, dim_head=64, num_bands=60, stft_n_fft=2048, stft_hop_length=441,
+                                      stft_win_length=2048, dim_t=256, sample_rate=44100)
+    sd = R.make_roformer_state(cfg, 1)
+    dm = A.MDXCDemixer({"model_data": cfg.as_model_data(), "torch_device": 0, "secondary_stem_name": "other"}, {"overlap": 8},
+                       state_dict=sd, max_batch=1)
+    C = cfg.stft_hop_length * (cfg.dim_t - 1)
+    x = (0.3 * np.random.default_rng(4).standard_normal((1, 2, C))).astype(np.float32)
+    got = dm.engine.rof_forward(x)
+    want = R.roformer_forward(x, sd, cfg)
+    assert rel_rms(got[:, 0] if got.ndim == 4 else got, want) < TOL
+
+
+def test_vr51_clip(A):
+    from oracle import vr_oracle as V
+    band = {1: {"sr": 11025, "hl": 128, "n_fft": 1024, "crop_start": 0, "crop_stop": 186, "lpf_start": 37, "lpf_stop": 73, "res_type": "polyphase",
+                "convert_channels": "mid_side_c"},
+            2: {"sr": 11025, "hl": 128, "n_fft": 512, "crop_start": 4, "crop_stop": 185, "hpf_start": 36, "hpf_stop": 18, "lpf_start": 93,
+                "lpf_stop": 185, "res_type": "polyphase", "convert_channels": "mid_side"},
+            3: {"sr": 22050, "hl": 256, "n_fft": 512, "crop_start": 46, "crop_stop": 186, "hpf_start": 93, "hpf_stop": 46, "lpf_start": 164,
+                "lpf_stop": 186, "res_type": "polyphase"},
+            4: {"sr": 44100, "hl": 512, "n_fft": 768, "crop_start": 121, "crop_stop": 382, "hpf_start": 138, "hpf_stop": 123, "res_type": "sinc_medium",
+                "convert_channels": "stereo_n"}}
+    mp = {"bins": 768, "unstable_bins": 7, "reduction_bins": 668, "sr": 44100, "pre_filter_start": 740, "pre_filter_stop": 768, "band": band}
+    sd = V.make_vr51_state(1536, 32, 128, 3)
+    dm = A.VRDemixer({"model_params": mp, "primary_stem_name": "Instrumental", "torch_device": 0, "model_data": {"nout": 32, "nout_lstm": 128}},
+                     {"window_size": 512, "batch_size": 2, "aggression": 5}, state_dict=sd, nn_arch_size=56817)
+    wave = (0.3 * np.random.default_rng(5).standard_normal((2, 44100 * 3))).astype(np.float32)
+    gp, gs = dm.separate_stems(wave)
+    wp, ws = V.vr_separate_v51(wave, sd, V.ModelParams(mp), window_size=512, batch_size=2, aggression=5)
+    assert rel_rms(gp, wp) < TOL, rel_rms(gp, wp)
+    assert rel_rms(gs, ws) < TOL, rel_rms(gs, ws)
+
+
+def test_htdemucs_6s_segment(A):
+    from oracle import demucs_oracle as D
+    src = ("drums", "bass", "other", "vocals", "guitar", "piano")
+    oc = D.HTConfig(sources=src, t_layers=2)
+    sd = D.make_ht_state(oc, 2)
+    eng = A.Engine(A.MDXConfig(n_fft=4096, hop_length=1024, dim_f=2048, segment_size=8))
+    eng.load_ht(A.HTConfig(sources=src, t_layers=2, segment=Fraction(39, 5)), sd)
+    x = (0.3 * np.random.default_rng(6).standard_normal((1, 2, oc.training_length - 1000))).astype(np.float32)
+    got = eng.ht_forward(x)
+    want = D.ht_forward(x, sd, oc)
+    assert got.shape == (1, 6, 2, oc.training_length - 1000)
+    assert rel_rms(got, want) < TOL, rel_rms(got, want)
