@@ -58,3 +58,27 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_header_is_plain_c_and_struct_layouts_match(tmp_path):
+    """include/asx.h compiles as C99 (the boundary is a C ABI, not C++), and every struct the ctypes binding mirrors has
+    the size the C compiler gives it."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    pairs = [("asx_mdx_config", E._MdxCfg), ("asx_net_config", E._NetCfg), ("asx_plan", E._Plan), ("asx_profile", E._Profile),
+             ("asx_v3_config", E._V3Cfg), ("asx_rof_config", E._RofCfg), ("asx_ht_config", E._HtCfg), ("asx_vr_band", E._VrBand),
+             ("asx_vr_config", E._VrCfg), ("asx_vr_params", E._VrParams)]
+    src = '#include <stdio.h>\n#include "asx.h"\nint main(void) {\n' + \
+          "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n, _ in pairs) + "  return 0;\n}\n"
+    c = tmp_path / "sizes.c"
+    c.write_text(src)
+    exe = tmp_path / "sizes"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)],
+                   check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, ct in pairs:
+        assert int(out[name]) == C.sizeof(ct), (name, out[name], C.sizeof(ct))
