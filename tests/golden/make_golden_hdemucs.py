@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Golden vectors for Demucs v3 (HDemucs) from the REFERENCE class (build container only).
+
+    python tests/golden/make_golden_hdemucs.py
+
+Same stubs as make_golden_demucs.py (`julius`, `diffq`: absent third-party deps that are not on the inference path).
+"""
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+_stub("julius")
+_stub("diffq", UniformQuantizer=object, DiffQuantizer=object, restore_quantized_state=lambda *a, **k: None)
+for pkg, path in (("audio_separator", f"{REF}/audio_separator"), ("audio_separator.separator", f"{REF}/audio_separator/separator"),
+                  ("audio_separator.separator.uvr_lib_v5", f"{REF}/audio_separator/separator/uvr_lib_v5")):
+    m = _stub(pkg)
+    m.__path__ = [path]
+
+from audio_separator.separator.uvr_lib_v5.demucs.hdemucs import HDemucs  # noqa: E402
+
+sys.path.insert(0, ROOT)
+from oracle.hdemucs_oracle import HDConfig, make_hd_state  # noqa: E402
+
+
+def small_cfg():
+    # nfft 1024 -> 512 -> 128 -> 32 -> 8 frequency rows, then the last_freq layer and one time-only layer; norm/LSTM/attention
+    # from layer 3 (the released hdemucs_mmi has the same structure one level deeper)
+    return HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, samplerate=8000, segment=4)
+
+
+def main():
+    cfg = small_cfg()
+    model = HDemucs(**cfg.ctor_kwargs())
+    sd = make_hd_state(cfg, 21)
+    ref = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    mine = {k: tuple(v.shape) for k, v in sd.items()}
+    assert ref == mine, (sorted(set(ref) - set(mine))[:8], sorted(set(mine) - set(ref))[:8],
+                         [(k, ref[k], mine[k]) for k in ref if k in mine and ref[k] != mine[k]][:8])
+    model.load_state_dict(sd)
+    model.eval()
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    # 12000 samples: 47 spectrogram frames (no BLSTM framing); 56000: 219 frames > 200 -> the overlapped-frame BLSTM path
+    for tag, n in (("a", 12000), ("b", 56000), ("c", 5001)):
+        x = torch.randn(1 if tag == "b" else 2, 2, n, generator=g) * 0.3
+        with torch.no_grad():
+            y = model(x)
+        out[f"x_{tag}"] = x.numpy()
+        out[f"y_{tag}"] = y.numpy().astype(np.float32)
+        print(tag, x.shape, y.shape, float(y.abs().mean()))
+    np.savez_compressed(os.path.join(HERE, "hdemucs_small.npz"), **out)
+    print("wrote hdemucs_small.npz", os.path.getsize(os.path.join(HERE, "hdemucs_small.npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
