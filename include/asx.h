@@ -289,6 +289,46 @@ int asx_ht_segments_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, 
 int asx_ht_fold_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t shifts, const int64_t *offsets, double overlap,
                     uint32_t flags, const float *chunk_out_dev, float *out_dev, void *stream);
 
+/* ---- Demucs v3 (HDemucs: the `hdemucs_mmi` entry of the reference's Demucs list) --------------------------
+ * Replaces HDemucs(**kwargs) + load_state_dict (uvr_lib_v5/demucs/hdemucs.py:362-571) and HDemucs.forward
+ * (:670-782) under the same apply_model / demix_demucs framing as Demucs v4 (apply.py:124-260,
+ * architectures/demucs_separator.py:162-194).  Structure built: the class defaults -- CaC, depth - 2 strided levels
+ * on both branches, the last-frequency level with the waveform branch injected, one time-only level; GroupNorm,
+ * BLSTM(max_steps 200) and LocalState on those two innermost levels.  HDemucs has no valid_length: every chunk
+ * of apply_model runs at its own length (apply.py:251-256), so asx_hd_forward takes any length >= nfft.
+ * Weights come in under the checkpoint's own state_dict keys (asx_net_set_tensor). */
+typedef struct asx_hd_config {
+  int32_t n_sources;
+  int32_t channels, growth, nfft, depth;     /* 48, 2, 4096, 6 */
+  int32_t kernel_size, stride, time_stride;  /* 8, 4, 2 */
+  int32_t norm_starts, norm_groups;          /* depth - 2, 4 */
+  int32_t dconv_depth, dconv_comp;           /* 2, 4 */
+  int32_t dconv_attn, dconv_lstm;            /* depth - 2 */
+  int32_t samplerate;
+  int32_t segment_samples;                   /* int(samplerate * segment): the split length of apply_model */
+  float freq_emb_scale;                      /* freq_emb (0.2); 0 = no embedding */
+  int32_t max_batch;                         /* equal-length chunks per forward batch (0 = 4) */
+} asx_hd_config;
+int asx_hd_begin(asx_engine *e, const asx_hd_config *cfg);
+int asx_hd_commit(asx_engine *e);
+double asx_hd_flops(const asx_engine *e, int64_t length);   /* 2*MAC of one chunk of `length` samples */
+/* HDemucs.forward: mix [B, 2, length] -> out [B, S, 2, length] */
+int asx_hd_forward(asx_engine *e, const float *mix_host, int32_t batch, int64_t length, float *out_host);
+/* apply_model(model, mix[None], shifts, split=True, overlap) + the demix_demucs framing in `flags` (ASX_HT_*):
+ * mix [2, N] -> out [S, 2, N]; offsets as for asx_ht_demix. */
+int asx_hd_demix(asx_engine *e, const float *mix_host, int64_t n_samples, int32_t shifts, const int64_t *offsets, double overlap,
+                 uint32_t flags, float *out_host);
+int asx_hd_demix_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t shifts, const int64_t *offsets, double overlap,
+                     uint32_t flags, float *out_dev, void *stream);
+/* sharded halves, as asx_ht_plan / asx_ht_segments_dev / asx_ht_fold_dev: chunk_out [n_segments, S, 2, segment_samples],
+ * row k holds the chunk's own length of valid samples from column 0 */
+int asx_hd_plan(const asx_engine *e, int64_t n_samples, int32_t shifts, const int64_t *offsets, double overlap, int32_t *n_segments,
+                int64_t *segment_samples);
+int asx_hd_segments_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t shifts, const int64_t *offsets, double overlap,
+                        uint32_t flags, int32_t k0, int32_t k1, float *chunk_out_dev, void *stream);
+int asx_hd_fold_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int32_t shifts, const int64_t *offsets, double overlap,
+                    uint32_t flags, const float *chunk_out_dev, float *out_dev, void *stream);
+
 /* ---- VR architecture -----------------------------------------------------------------
  * Replaces nets.determine_model_capacity(...) + load_state_dict (architectures/vr_separator.py:168-176,
  * uvr_lib_v5/vr_network/nets.py:65-93), VRSeparator.loading_mix (:255-291), inference_vr (:293-366) and spec_to_wav

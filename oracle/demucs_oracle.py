@@ -431,6 +431,12 @@ def _center_trim(t, ref):
     return t[..., delta // 2: t.shape[-1] - (delta - delta // 2)] if delta else t
 
 
+def _valid_length(cfg, length):
+    """apply.py:251-255: HTDemucs pads every leaf call to its training length; HDemucs (no valid_length) runs at `length`."""
+    tl = getattr(cfg, "training_length", None)
+    return tl if tl else length
+
+
 def apply_split(model_fn, tensor, base, length, cfg: HTConfig, overlap=0.25):
     """The `split` branch of apply_model (apply.py:215-250) + the leaf call (:251-260) on the view
     tensor[..., base:base+length] (a TensorChunk of a TensorChunk keeps the parent tensor, so the
@@ -445,7 +451,7 @@ def apply_split(model_fn, tensor, base, length, cfg: HTConfig, overlap=0.25):
     weight = (weight / weight.max()) ** 1.0
     for offset in range(0, length, stride):
         clen = min(length - offset, segment)
-        padded, _ = _padded(tensor, base + offset, clen, cfg.training_length)
+        padded, _ = _padded(tensor, base + offset, clen, _valid_length(cfg, clen))
         chunk_out = _center_trim(torch.as_tensor(model_fn(padded)), clen)
         out[..., offset:offset + segment] += weight[:clen] * chunk_out
         sum_weight[offset:offset + segment] += weight[:clen]
@@ -455,7 +461,7 @@ def apply_split(model_fn, tensor, base, length, cfg: HTConfig, overlap=0.25):
 def _apply_view(model_fn, tensor, base, length, cfg, split, overlap):
     if split:
         return apply_split(model_fn, tensor, base, length, cfg, overlap)
-    padded, _ = _padded(tensor, base, length, cfg.training_length)
+    padded, _ = _padded(tensor, base, length, _valid_length(cfg, length))
     return _center_trim(torch.as_tensor(model_fn(padded)), length)
 
 

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .demucs_oracle import _pad1d_reflect
+from .demucs_oracle import _pad1d_reflect, apply_model
 
 
 @dataclass
@@ -323,8 +323,8 @@ def _dec(x, skip, length, sd, p, L, cfg, freq, last, empty=False):
 
 
 @torch.no_grad()
-def hd_forward(mix, sd: dict, cfg: HDConfig):
-    """HDemucs.forward (hdemucs.py:670-782), eval: [B, 2, L] -> [B, S, 2, L]."""
+def hd_forward(mix, sd: dict, cfg: HDConfig, taps: dict | None = None):
+    """HDemucs.forward (hdemucs.py:670-782), eval: [B, 2, L] -> [B, S, 2, L].  taps: filled with intermediates (debugging)."""
     mix = torch.as_tensor(np.ascontiguousarray(mix), dtype=torch.float32)
     length = mix.shape[-1]
     hl = cfg.nfft // 4
@@ -354,14 +354,20 @@ def hd_forward(mix, sd: dict, cfg: HDConfig):
             xt = _enc(xt, sd, f"tencoder.{i}", L, cfg, freq=False, empty=L["last_freq"])
             if not L["last_freq"]:
                 saved_t.append(xt)
+                if taps is not None:
+                    taps[f"skt{i}"] = xt
             else:
                 inject = xt
+                if taps is not None:
+                    taps["inj"] = xt
         x = _enc(x, sd, f"encoder.{i}", L, cfg, freq=L["freq"], inject=inject)
         if i == 0 and cfg.freq_emb:
             frs = torch.arange(x.shape[-2])
             emb = (F.embedding(frs, sd["freq_emb.embedding.weight"]) * 10.0).t()[None, :, :, None].expand_as(x)
             x = x + cfg.freq_emb * emb
         saved.append(x)
+        if taps is not None:
+            taps[f"skf{i}"] = x
     x = torch.zeros_like(x)
     xt = torch.zeros_like(x)
     offset = cfg.depth - nt
@@ -369,6 +375,9 @@ def hd_forward(mix, sd: dict, cfg: HDConfig):
         L = Ls[cfg.depth - 1 - j]
         skip = saved.pop(-1)
         x, pre = _dec(x, skip, lengths.pop(-1), sd, f"decoder.{j}", L, cfg, freq=L["freq"], last=L["index"] == 0)
+        if taps is not None:
+            taps[f"dec{j}"] = x
+            taps[f"pre{j}"] = pre
         if j >= offset:
             jt = j - offset
             Lt = Ls[nt - 1 - jt]
@@ -377,6 +386,8 @@ def hd_forward(mix, sd: dict, cfg: HDConfig):
                 xt, _ = _dec(pre[:, :, 0], None, length_t, sd, f"tdecoder.{jt}", Lt, cfg, freq=False, last=Lt["index"] == 0, empty=True)
             else:
                 xt, _ = _dec(xt, saved_t.pop(-1), length_t, sd, f"tdecoder.{jt}", Lt, cfg, freq=False, last=Lt["index"] == 0)
+            if taps is not None:
+                taps[f"tdec{jt}"] = xt
     S = len(cfg.sources)
     x = x.view(B, S, -1, Fq, T) * std[:, None] + mean[:, None]
     zout = torch.view_as_complex(x.view(B, S, -1, 2, Fq, T).permute(0, 1, 2, 4, 5, 3).contiguous())
@@ -388,3 +399,16 @@ def hd_forward(mix, sd: dict, cfg: HDConfig):
     xo = xo.view(*shp[:-2], lei)[..., pad:pad + length]
     xt = xt.view(B, S, -1, length) * stdt[:, None] + meant[:, None]
     return (xt + xo).numpy()
+
+
+def demix_hdemucs(mix: np.ndarray, sd: dict, cfg: HDConfig, shifts=2, overlap=0.25, split=True, offsets=None) -> np.ndarray:
+    """DemucsSeparator.demix_demucs (demucs_separator.py:162-194) around HDemucs: [2, N] -> [S, 2, N] (stems 0/1 swapped).
+    apply_model's leaf call runs each chunk at its own length (HDemucs has no valid_length, apply.py:251-256)."""
+    m = torch.tensor(np.asarray(mix, np.float32))
+    ref = m.mean(0)
+    m = (m - ref.mean()) / ref.std()
+    fn = lambda x: hd_forward(x.numpy() if hasattr(x, "numpy") else x, sd, cfg)  # noqa: E731
+    src = apply_model(fn, m[None], cfg, shifts=shifts, split=split, overlap=overlap, offsets=offsets)[0]
+    src = (src * ref.std() + ref.mean()).numpy()
+    src[[0, 1]] = src[[1, 0]]
+    return src

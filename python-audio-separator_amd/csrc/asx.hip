@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -22,6 +23,7 @@
 #include "kernels_net.h"
 #include "kernels_rof.h"
 #include "kernels_ht.h"
+#include "kernels_hd.h"
 #include "kernels_vr.h"
 #include "kernels_ens.h"
 
@@ -117,6 +119,7 @@ struct ProfRec {
 struct V3Net;
 struct RofNet;
 struct HtNet;
+struct HdNet;
 struct VrNet;
 struct EnsCtx;
 
@@ -125,6 +128,7 @@ struct asx_engine {
   V3Net *v3 = nullptr;
   RofNet *rof = nullptr;
   HtNet *ht = nullptr;
+  HdNet *hd = nullptr;   // Demucs v3: owns the inner levels, e->ht the strided ones
   VrNet *vr = nullptr;
   EnsCtx *ens = nullptr;
   asx_mdx_config cfg{};
@@ -817,6 +821,7 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
 static void v3_destroy(V3Net *n);
 static void rof_destroy(RofNet *n);
 static void ht_destroy(HtNet *n);
+static void hd_destroy(HdNet *n);
 static void vr_destroy(VrNet *n);
 static void ens_destroy(EnsCtx *c);
 static void free_conv(ConvLayer &L) {
@@ -868,6 +873,7 @@ void asx_engine_destroy(asx_engine *e) {
   if (e->v3) v3_destroy(e->v3);
   if (e->rof) rof_destroy(e->rof);
   if (e->ht) ht_destroy(e->ht);
+  if (e->hd) hd_destroy(e->hd);
   if (e->vr) vr_destroy(e->vr);
   if (e->ens) ens_destroy(e->ens);
   delete e;
@@ -1029,6 +1035,7 @@ double asx_net_flops(const asx_engine *e, int32_t batch) {
 #include "engine_v3.h"
 #include "engine_rof.h"
 #include "engine_ht.h"
+#include "engine_hd.h"
 #include "engine_vr.h"
 #include "engine_ens.h"
 extern "C" {
@@ -2046,6 +2053,137 @@ int asx_ht_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t shifts
   return ASX_OK;
 }
 
+// ---- Demucs v3 (HDemucs) -------------------------------------------------------------
+int asx_hd_begin(asx_engine *e, const asx_hd_config *cfg) {
+  REQUIRE(e && cfg, "asx_hd_begin: null argument");
+  REQUIRE(cfg->n_sources >= 1 && cfg->channels >= 4 && cfg->growth >= 1 && cfg->depth >= 3 && cfg->depth <= 8, "bad HDemucs hyper-parameters");
+  REQUIRE(cfg->kernel_size == 8 && cfg->stride == 4 && cfg->time_stride == 2,
+          "only kernel_size 8 / stride 4 / time_stride 2 is built (got %d / %d / %d)", cfg->kernel_size, cfg->stride, cfg->time_stride);
+  REQUIRE(cfg->dconv_depth >= 1 && cfg->dconv_depth <= 4 && cfg->dconv_comp >= 1 && cfg->channels % cfg->dconv_comp == 0, "bad DConv hyper-parameters");
+  REQUIRE(cfg->norm_starts == cfg->depth - 2 && cfg->dconv_lstm == cfg->depth - 2 && cfg->dconv_attn == cfg->depth - 2,
+          "only the default structure (GroupNorm, BLSTM and LocalState on the two innermost levels: norm_starts = dconv_lstm = dconv_attn = depth - 2) "
+          "is built");
+  REQUIRE(cfg->norm_groups >= 1, "bad norm_groups");
+  REQUIRE(cfg->nfft >= 64 && cfg->nfft % 8 == 0, "bad nfft %d", cfg->nfft);
+  REQUIRE(cfg->samplerate > 0 && cfg->segment_samples >= cfg->nfft, "bad samplerate / segment");
+  if (!e->ht) e->ht = new HtNet();
+  ht_free(*e->ht);
+  if (!e->hd) e->hd = new HdNet();
+  hd_free(*e->hd);
+  e->hd->cfg = *cfg;
+  e->hd->begun = true;
+  asx_ht_config &h = e->ht->cfg;
+  h = asx_ht_config{};
+  h.n_sources = cfg->n_sources;
+  h.channels = cfg->channels;
+  h.growth = cfg->growth;
+  h.nfft = cfg->nfft;
+  h.depth = cfg->depth - 2;
+  h.kernel_size = cfg->kernel_size;
+  h.stride = cfg->stride;
+  h.dconv_depth = cfg->dconv_depth;
+  h.dconv_comp = cfg->dconv_comp;
+  h.samplerate = cfg->samplerate;
+  h.segment_samples = cfg->segment_samples;
+  h.freq_emb_scale = cfg->freq_emb_scale;
+  h.max_batch = cfg->max_batch;
+  e->host_tensors.clear();
+  e->net_begun = true;
+  return ASX_OK;
+}
+
+int asx_hd_commit(asx_engine *e) {
+  REQUIRE(e, "asx_hd_commit: null engine");
+  if (!e->hd || !e->hd->begun) {
+    set_err("asx_hd_commit before asx_hd_begin");
+    return ASX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  const int rc = hd_commit(e);
+  e->host_tensors.clear();
+  return rc;
+}
+
+#define HD_READY(fn)                                   \
+  do {                                                 \
+    if (!e->hd || !e->hd->ready) {                     \
+      set_err(fn ": weights not committed");           \
+      return ASX_ERR_STATE;                            \
+    }                                                  \
+  } while (0)
+
+double asx_hd_flops(const asx_engine *e, int64_t length) { return (e && e->hd && e->hd->ready && length > 0) ? hd_flops(e, length) : 0.0; }
+
+int asx_hd_forward(asx_engine *e, const float *mix_host, int32_t B, int64_t length, float *out_host) {
+  REQUIRE(e && mix_host && out_host && B > 0 && length > 0, "asx_hd_forward: bad argument");
+  HD_READY("asx_hd_forward");
+  HIPCHK(hipSetDevice(e->device));
+  const int S = e->hd->cfg.n_sources;
+  DevBuf din, dout;
+  BufGuard g{{&din, &dout}};
+  CHK(to_dev(din, mix_host, (size_t)B * 2 * length));
+  CHK(dout.ensure((size_t)B * S * 2 * length * 4));
+  CHK(hd_forward_dev(e, din.f(), B, length, dout.f(), nullptr));
+  HIPCHK(hipDeviceSynchronize());
+  return to_host(out_host, dout, (size_t)B * S * 2 * length);
+}
+
+int asx_hd_demix_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t shifts, const int64_t *offsets, double overlap, uint32_t flags,
+                     float *out_dev, void *stream) {
+  REQUIRE(e && mix_dev && out_dev && N >= 2, "asx_hd_demix_dev: bad argument");
+  REQUIRE(shifts >= 0 && (shifts == 0 || offsets), "shifts > 0 needs the offsets array");
+  REQUIRE(overlap >= 0.0 && overlap < 1.0, "overlap must be in [0, 1)");
+  HD_READY("asx_hd_demix_dev");
+  HIPCHK(hipSetDevice(e->device));
+  return hd_demix_dev(e, mix_dev, N, shifts, offsets, overlap, flags, out_dev, reinterpret_cast<hipStream_t>(stream));
+}
+
+int asx_hd_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t shifts, const int64_t *offsets, double overlap, uint32_t flags,
+                 float *out_host) {
+  REQUIRE(e && mix_host && out_host && N >= 2, "asx_hd_demix: bad argument");
+  HD_READY("asx_hd_demix");
+  HIPCHK(hipSetDevice(e->device));
+  const int S = e->hd->cfg.n_sources;
+  DevBuf dm, dout;
+  BufGuard g{{&dm, &dout}};
+  CHK(to_dev(dm, mix_host, (size_t)2 * N));
+  CHK(dout.ensure((size_t)S * 2 * N * 4));
+  CHK(asx_hd_demix_dev(e, dm.f(), N, shifts, offsets, overlap, flags, dout.f(), nullptr));
+  return to_host(out_host, dout, (size_t)S * 2 * N);
+}
+
+int asx_hd_plan(const asx_engine *e, int64_t N, int32_t shifts, const int64_t *offsets, double overlap, int32_t *n_segments,
+                int64_t *segment_samples) {
+  REQUIRE(e && n_segments && segment_samples && N >= 2 && shifts >= 0 && (shifts == 0 || offsets), "asx_hd_plan: bad argument");
+  HD_READY("asx_hd_plan");
+  HdPlan p;
+  CHK(hd_plan(e, N, shifts, offsets, overlap, p));
+  *n_segments = (int32_t)p.starts.size();
+  *segment_samples = p.segment;
+  return ASX_OK;
+}
+
+int asx_hd_segments_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t shifts, const int64_t *offsets, double overlap, uint32_t flags,
+                        int32_t k0, int32_t k1, float *chunk_out_dev, void *stream) {
+  REQUIRE(e && mix_dev && chunk_out_dev && N >= 2 && shifts >= 0 && (shifts == 0 || offsets), "asx_hd_segments_dev: bad argument");
+  HD_READY("asx_hd_segments_dev");
+  HIPCHK(hipSetDevice(e->device));
+  HdPlan p;
+  CHK(hd_plan(e, N, shifts, offsets, overlap, p));
+  REQUIRE(k0 >= 0 && k0 <= k1 && k1 <= (int)p.starts.size(), "segment range [%d, %d) outside [0, %d)", k0, k1, (int)p.starts.size());
+  return hd_segments_dev(e, mix_dev, N, p, flags, k0, k1, chunk_out_dev, reinterpret_cast<hipStream_t>(stream));
+}
+
+int asx_hd_fold_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t shifts, const int64_t *offsets, double overlap, uint32_t flags,
+                    const float *chunk_out_dev, float *out_dev, void *stream) {
+  REQUIRE(e && mix_dev && chunk_out_dev && out_dev && N >= 2 && shifts >= 0 && (shifts == 0 || offsets), "asx_hd_fold_dev: bad argument");
+  HD_READY("asx_hd_fold_dev");
+  HIPCHK(hipSetDevice(e->device));
+  HdPlan p;
+  CHK(hd_plan(e, N, shifts, offsets, overlap, p));
+  return hd_fold_dev(e, mix_dev, N, p, flags, chunk_out_dev, out_dev, reinterpret_cast<hipStream_t>(stream));
+}
+
 // ---- VR ------------------------------------------------------------------------------
 int asx_vr_begin(asx_engine *e, const asx_vr_config *cfg) {
   REQUIRE(e && cfg, "asx_vr_begin: null argument");
@@ -2186,6 +2324,23 @@ int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel)
       const int i = nm[4] - '0';
       src = nm[3] == 'D' ? b.D[i] : (nm[3] == 'E' ? b.E[i] : (nm[3] == 'O' ? b.O[i] : nullptr));
     }
+  }
+  if (e->hd && e->hd->ws_batch > 0 && e->ht && nm.compare(0, 3, "hd.") == 0) {
+    auto &w = e->hd->b;
+    auto &b = e->ht->b;
+    const int D = e->hd->D;
+    const int i = nm.size() == 7 ? nm[6] - '0' : -1;
+    if (nm == "hd.inj") src = w.inj;
+    else if (nm == "hd.ya") src = w.ya;
+    else if (nm == "hd.yz") src = w.yz;
+    else if (nm == "hd.skA") src = w.skA;
+    else if (nm == "hd.skZ") src = w.skZ;
+    else if (nm == "hd.dAin") src = w.dAin;
+    else if (nm == "hd.pre") src = w.pre;
+    else if (nm.compare(0, 6, "hd.skf") == 0 && i >= 0 && i < D) src = b.skf[i];
+    else if (nm.compare(0, 6, "hd.skt") == 0 && i >= 0 && i < D) src = b.skt[i];
+    else if (nm.compare(0, 6, "hd.df_") == 0 && i >= 0 && i <= D) src = b.df[i];
+    else if (nm.compare(0, 6, "hd.dt_") == 0 && i >= 0 && i <= D) src = b.dt[i];
   }
   if (!src) {
     set_err("asx_debug_fetch: unknown buffer '%s'", name);

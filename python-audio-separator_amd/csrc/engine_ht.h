@@ -197,12 +197,13 @@ static int ht_pack_linear(asx_engine *e, HtGemm &g, const std::string &wname, co
   return ASX_OK;
 }
 
-static int ht_load_dconv(asx_engine *e, HtDconv &d, const std::string &p, int ch, int comp, int idx) {
+// ins: modules inserted between the GELU and the 1x1 conv (Demucs v3's BLSTM / LocalState shift the Sequential's indices)
+static int ht_load_dconv(asx_engine *e, HtDconv &d, const std::string &p, int ch, int comp, int idx, int ins = 0) {
   d.hid = ch / comp;
   d.hp = (d.hid + 3) & ~3;
   const std::string q = p + ".layers." + std::to_string(idx);
   CHK(ht_pack_conv(e, d.c1, q + ".0", d.hid, ch, 3, 1, false, d.hp, 0));
-  CHK(ht_pack_conv(e, d.c2, q + ".3", 2 * ch, d.hid, 1, 1, true, 0, d.hp));   // GLU row order for the fused epilogue
+  CHK(ht_pack_conv(e, d.c2, q + "." + std::to_string(3 + ins), 2 * ch, d.hid, 1, 1, true, 0, d.hp));   // GLU row order for the fused epilogue
   const float *g, *b;
   CHK(get_tensor(e, q + ".1.weight", d.hid, &g));
   CHK(get_tensor(e, q + ".1.bias", d.hid, &b));
@@ -213,14 +214,14 @@ static int ht_load_dconv(asx_engine *e, HtDconv &d, const std::string &p, int ch
   CHK(ht_up(d.g1b, gb));
   {
     const float *g2, *b2;
-    CHK(get_tensor(e, q + ".4.weight", 2 * ch, &g2));
-    CHK(get_tensor(e, q + ".4.bias", 2 * ch, &b2));
+    CHK(get_tensor(e, q + "." + std::to_string(4 + ins) + ".weight", 2 * ch, &g2));
+    CHK(get_tensor(e, q + "." + std::to_string(4 + ins) + ".bias", 2 * ch, &b2));
     std::vector<float> pg(g2, g2 + 2 * ch), pb2(b2, b2 + 2 * ch);
     ht_glu_perm(pg, pb2, ch, 1);     // (weights, "bias") = (gamma, beta), one float per row
     CHK(ht_up(d.g2w, pg));
     CHK(ht_up(d.g2b, pb2));
   }
-  CHK(ht_up_named(e, d.ls, q + ".6.scale", ch));
+  CHK(ht_up_named(e, d.ls, q + "." + std::to_string(6 + ins) + ".scale", ch));
   return ASX_OK;
 }
 
@@ -283,6 +284,76 @@ static void ht_sin_2d(int C, int Fr, int T1, std::vector<float> &t) {   // rows 
   }
 }
 
+// STFT tables and the triangular transition window of apply_model (apply.py:226-231) for segments of TL samples
+static int ht_commit_tables(asx_engine *e, int64_t TL) {
+  HtNet &n = *e->ht;
+  const asx_ht_config &c = n.cfg;
+  const int hop = c.nfft / 4;
+  // tables
+  {
+    std::vector<float> w;
+    host_window(c.nfft, w);
+    CHK(ht_up(n.window, w));
+    std::vector<float> tw((size_t)c.nfft * 2);
+    for (int j = 0; j < c.nfft; ++j) {
+      const double ang = -2.0 * M_PI * (double)j / (double)c.nfft;
+      tw[2 * j] = (float)cos(ang);
+      tw[2 * j + 1] = (float)sin(ang);
+    }
+    CHK(ht_up(n.tw, tw));
+    std::vector<float> env((size_t)hop, 0.f);
+    for (int r = 0; r < hop; ++r)
+      for (int i = c.nfft / hop - 1; i >= 0; --i) env[r] += w[r + i * hop] * w[r + i * hop];   // frame order of torch's fold
+    CHK(ht_up(n.env_hop, env));
+    // triangular transition window (apply.py:226-231), float32 like torch
+    std::vector<float> fw((size_t)TL);
+    const int64_t h1 = TL / 2, h2 = TL - TL / 2;
+    const float mx = (float)std::max(h1, h2);
+    for (int64_t i = 0; i < h1; ++i) fw[i] = (float)(i + 1) / mx;
+    for (int64_t i = 0; i < h2; ++i) fw[h1 + i] = (float)(h2 - i) / mx;
+    CHK(ht_up(n.fold_w, fw));
+  }
+  return ASX_OK;
+}
+
+// weights of level i; the decoders are stored under `decoder.<dec_idx>` / `tdecoder.<tdec_idx>`
+static int ht_commit_level(asx_engine *e, int i, int dec_idx, int tdec_idx) {
+  HtNet &n = *e->ht;
+  const asx_ht_config &c = n.cfg;
+  const int S = c.n_sources, AC = 2;
+  {
+    const int cin_z = i == 0 ? 2 * AC : n.C[i - 1], cin_t = i == 0 ? AC : n.C[i - 1], co = n.C[i];
+    const std::string si = std::to_string(i), sj = std::to_string(dec_idx), sjt = std::to_string(tdec_idx);
+    HtEnc &E = n.enc[i], &Et = n.tenc[i];
+    E.cin = cin_z;
+    E.cout = co;
+    Et.cin = cin_t;
+    Et.cout = co;
+    CHK(ht_pack_conv(e, E.conv, "encoder." + si + ".conv", co, cin_z, c.kernel_size, 1, false));
+    CHK(ht_pack_conv(e, Et.conv, "tencoder." + si + ".conv", co, cin_t, c.kernel_size, 1, false));
+    CHK(ht_pack_conv(e, E.rewrite, "encoder." + si + ".rewrite", 2 * co, co, 1, 1, true));
+    CHK(ht_pack_conv(e, Et.rewrite, "tencoder." + si + ".rewrite", 2 * co, co, 1, 1, true));
+    E.dc.assign(c.dconv_depth, HtDconv());
+    Et.dc.assign(c.dconv_depth, HtDconv());
+    for (int d = 0; d < c.dconv_depth; ++d) {
+      CHK(ht_load_dconv(e, E.dc[d], "encoder." + si + ".dconv", co, c.dconv_comp, d));
+      CHK(ht_load_dconv(e, Et.dc[d], "tencoder." + si + ".dconv", co, c.dconv_comp, d));
+    }
+    const int out_z = i == 0 ? 2 * AC * S : n.C[i - 1], out_t = i == 0 ? AC * S : n.C[i - 1];
+    HtDec &Dz = n.dec[i], &Dt = n.tdec[i];
+    Dz.cin = co;
+    Dz.cout = out_z;
+    Dt.cin = co;
+    Dt.cout = out_t;
+    REQUIRE(out_z % 4 == 0 && out_t % 4 == 0, "decoder output channels must be multiples of 4");
+    CHK(ht_pack_conv(e, Dz.rewrite, "decoder." + sj + ".rewrite", 2 * co, co, 3, 3, true));
+    CHK(ht_pack_conv(e, Dt.rewrite, "tdecoder." + sjt + ".rewrite", 2 * co, co, 3, 1, true));
+    CHK(ht_pack_convtr(e, Dz.convtr, "decoder." + sj + ".conv_tr", co, out_z, c.kernel_size, c.stride));
+    CHK(ht_pack_convtr(e, Dt.convtr, "tdecoder." + sjt + ".conv_tr", co, out_t, c.kernel_size, c.stride));
+  }
+  return ASX_OK;
+}
+
 static int ht_commit(asx_engine *e) {
   HtNet &n = *e->ht;
   const asx_ht_config &c = n.cfg;
@@ -308,64 +379,12 @@ static int ht_commit(asx_engine *e) {
     REQUIRE(ch % 4 == 0, "channel counts must be multiples of 4 (layer %d has %d)", i, ch);
     ch *= c.growth;
   }
-  // tables
-  {
-    std::vector<float> w;
-    host_window(c.nfft, w);
-    CHK(ht_up(n.window, w));
-    std::vector<float> tw((size_t)c.nfft * 2);
-    for (int j = 0; j < c.nfft; ++j) {
-      const double ang = -2.0 * M_PI * (double)j / (double)c.nfft;
-      tw[2 * j] = (float)cos(ang);
-      tw[2 * j + 1] = (float)sin(ang);
-    }
-    CHK(ht_up(n.tw, tw));
-    std::vector<float> env((size_t)hop, 0.f);
-    for (int r = 0; r < hop; ++r)
-      for (int i = c.nfft / hop - 1; i >= 0; --i) env[r] += w[r + i * hop] * w[r + i * hop];   // frame order of torch's fold
-    CHK(ht_up(n.env_hop, env));
-    // triangular transition window (apply.py:226-231), float32 like torch
-    std::vector<float> fw((size_t)TL);
-    const int64_t h1 = TL / 2, h2 = TL - TL / 2;
-    const float mx = (float)std::max(h1, h2);
-    for (int64_t i = 0; i < h1; ++i) fw[i] = (float)(i + 1) / mx;
-    for (int64_t i = 0; i < h2; ++i) fw[h1 + i] = (float)(h2 - i) / mx;
-    CHK(ht_up(n.fold_w, fw));
-  }
+  CHK(ht_commit_tables(e, TL));
   n.enc.assign(D, HtEnc());
   n.tenc.assign(D, HtEnc());
   n.dec.assign(D, HtDec());
   n.tdec.assign(D, HtDec());
-  for (int i = 0; i < D; ++i) {
-    const int cin_z = i == 0 ? 2 * AC : n.C[i - 1], cin_t = i == 0 ? AC : n.C[i - 1], co = n.C[i];
-    const std::string si = std::to_string(i), sj = std::to_string(D - 1 - i);
-    HtEnc &E = n.enc[i], &Et = n.tenc[i];
-    E.cin = cin_z;
-    E.cout = co;
-    Et.cin = cin_t;
-    Et.cout = co;
-    CHK(ht_pack_conv(e, E.conv, "encoder." + si + ".conv", co, cin_z, c.kernel_size, 1, false));
-    CHK(ht_pack_conv(e, Et.conv, "tencoder." + si + ".conv", co, cin_t, c.kernel_size, 1, false));
-    CHK(ht_pack_conv(e, E.rewrite, "encoder." + si + ".rewrite", 2 * co, co, 1, 1, true));
-    CHK(ht_pack_conv(e, Et.rewrite, "tencoder." + si + ".rewrite", 2 * co, co, 1, 1, true));
-    E.dc.assign(c.dconv_depth, HtDconv());
-    Et.dc.assign(c.dconv_depth, HtDconv());
-    for (int d = 0; d < c.dconv_depth; ++d) {
-      CHK(ht_load_dconv(e, E.dc[d], "encoder." + si + ".dconv", co, c.dconv_comp, d));
-      CHK(ht_load_dconv(e, Et.dc[d], "tencoder." + si + ".dconv", co, c.dconv_comp, d));
-    }
-    const int out_z = i == 0 ? 2 * AC * S : n.C[i - 1], out_t = i == 0 ? AC * S : n.C[i - 1];
-    HtDec &Dz = n.dec[i], &Dt = n.tdec[i];
-    Dz.cin = co;
-    Dz.cout = out_z;
-    Dt.cin = co;
-    Dt.cout = out_t;
-    REQUIRE(out_z % 4 == 0 && out_t % 4 == 0, "decoder output channels must be multiples of 4");
-    CHK(ht_pack_conv(e, Dz.rewrite, "decoder." + sj + ".rewrite", 2 * co, co, 3, 3, true));
-    CHK(ht_pack_conv(e, Dt.rewrite, "tdecoder." + sj + ".rewrite", 2 * co, co, 3, 1, true));
-    CHK(ht_pack_convtr(e, Dz.convtr, "decoder." + sj + ".conv_tr", co, out_z, c.kernel_size, c.stride));
-    CHK(ht_pack_convtr(e, Dt.convtr, "tdecoder." + sj + ".conv_tr", co, out_t, c.kernel_size, c.stride));
-  }
+  for (int i = 0; i < D; ++i) CHK(ht_commit_level(e, i, D - 1 - i, D - 1 - i));
   if (c.freq_emb_scale != 0.f) {
     const float *w;
     CHK(get_tensor(e, "freq_emb.embedding.weight", (int64_t)n.F[1] * n.C[0], &w));
@@ -424,6 +443,7 @@ struct HtGeom {
   int IR = 1;
   int SO = 1, OR = 0;            // OR = 0: same as O
   int64_t x_bs = 0, y_bs = 0;    // 0: dense
+  int crop = 2, So = 4;          // GG_CONVT scatter: position So*j - crop + r
 };
 
 // GroupNorm fusion of the DConv GEMMs (kernels_ht.h: GgArgs::stat_acc ...)
@@ -470,8 +490,8 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
   a.act = act;
   a.Iout = Iout;
   a.Cout = Cout;
-  a.crop = 2;
-  a.So = 4;
+  a.crop = q.crop;
+  a.So = q.So;
   a.ldy = ldy;
   a.ldr = ldr;
   a.res_mod = res_mod;
@@ -615,7 +635,7 @@ static int ht_ensure_workspace(asx_engine *e, int B) {
   auto &b = n.b;
   const size_t BT = (size_t)B * T;
   want(b.xf0, BT * n.F[0] * 4);
-  want(b.xt0, (size_t)B * n.L[0] * 2);
+  want(b.xt0, (size_t)B * ((n.L[0] + 1) & ~(int64_t)1) * 2);
   size_t yf = 0, yt = 0, h = 0, rw = 0;
   for (int i = 0; i < D; ++i) {
     const int hp = (n.C[i] / c.dconv_comp + 3) & ~3;
@@ -679,7 +699,9 @@ static int ht_ensure_workspace(asx_engine *e, int B) {
 }
 
 // DConv residual branch (demucs.py:99-179) on y [B, O, I, C] in place; along_outer: the conv runs over the outer axis
-static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I, bool along_outer, hipStream_t s) {
+// mid: optional stage between the GELU and the 1x1 conv (Demucs v3's BLSTM / LocalState inserts) on h [B*O*I, hp]
+static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I, bool along_outer, hipStream_t s,
+                    const std::function<int(size_t, float *)> *mid = nullptr) {
   HtNet &n = *e->ht;
   const int C = E.cout;
   for (size_t d = 0; d < E.dc.size(); ++d) {
@@ -721,6 +743,7 @@ static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I
     CHK(ht_gg(e, dc.c1, y, g, (int64_t)B * O, n.b.h, dc.hp, GG_DENSE, 0, nullptr, 0, 0, 0, 0, s, &f1));
     CHK(fold(dc.hp, (double)R * dc.hid, n.b.acc_g, reinterpret_cast<float2 *>(n.b.mr_g)));
     CHK(ht_gn(e, n.b.h, B, R, G2, dc.hp, dc.hid, n.b.acc_g, dc.g1w.f(), dc.g1b.f(), 0, nullptr, 0, nullptr, s));
+    if (mid) CHK((*mid)(d, n.b.h));
     HtGeom g1;
     g1.O = O;
     g1.I = I;
@@ -778,30 +801,14 @@ static int ht_cross_attn(asx_engine *e, const HtTLayer &L, const float *q, int64
 }
 
 // ---- HTDemucs.forward on B full-length segments: seg [B, 2, TL] -> out [B, S, 2, TL] ----------------------------------
-static int ht_forward_dev(asx_engine *e, const float *seg, int B, float *out, hipStream_t s) {
+// encoder level i of both branches (hdemucs.py:139-170): skf[i-1] / skt[i-1] (or the network inputs) -> skf[i] / skt[i]
+static int ht_enc_level(asx_engine *e, int i, int B, hipStream_t s) {
   HtNet &n = *e->ht;
   const asx_ht_config &c = n.cfg;
-  CHK(ht_ensure_workspace(e, B));
   auto &b = n.b;
-  const int D = c.depth, S = c.n_sources, T = n.T, hop = c.nfft / 4;
+  const int T = n.T;
   const int64_t TL = n.L[0];
-  const int F0 = n.F[0];
-  // spectrogram + per-sample standardisation of both branches (htdemucs.py:505-519)
-  CHK(timed(e, ASX_PROF_STFT, 0.0, 4.0 * (double)B * (2.0 * TL + 4.0 * T * F0), s, [&]() {
-    hipLaunchKernelGGL(ht_stft_kernel, dim3(T, 2, B), dim3(256), stft_lds(n.plan), s, seg, TL, hop, T, b.xf0, n.window.f(),
-                       reinterpret_cast<const float2 *>(n.tw.p), n.plan);
-  }));
-  const int64_t nf = (int64_t)T * F0 * 4;
-  CHK(ht_stats(e, b.xf0, B, T, (int64_t)F0 * 4, (int64_t)F0 * 4, 4, 4, 1, b.acc_f, s));
-  CHK(timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)B * nf, s, [&]() {
-    hipLaunchKernelGGL(std_norm_kernel, dim3((unsigned)((nf + 255) / 256), B), dim3(256), 0, s, b.xf0, nf, b.acc_f);
-  }));
-  CHK(ht_stats(e, seg, B, 1, 2 * TL, 2 * TL, 1, 1, 1, b.acc_t, s));
-  CHK(timed(e, ASX_PROF_MISC, 0.0, 16.0 * (double)B * TL, s, [&]() {
-    hipLaunchKernelGGL(time_norm_kernel, dim3((unsigned)((TL + 255) / 256), B), dim3(256), 0, s, seg, TL, b.acc_t, b.xt0);
-  }));
-  // encoders
-  for (int i = 0; i < D; ++i) {
+  {
     const HtEnc &E = n.enc[i], &Et = n.tenc[i];
     const int C = n.C[i];
     {   // spectrogram branch (hdemucs.py:139-170, freq=True)
@@ -830,7 +837,8 @@ static int ht_forward_dev(asx_engine *e, const float *seg, int B, float *out, hi
       HtGeom g;
       g.O = 1;
       if (i == 0) {
-        g.I = (int)(TL / 2);
+        g.I = (int)((TL + 1) / 2);              // an odd length carries one zero sample (Demucs v3 chunks, engine_hd.h)
+        g.x_bs = (int64_t)g.I * 4;
         g.Cin = 4;
         g.ldc = 4;
         g.KI = c.kernel_size / 2;
@@ -855,6 +863,88 @@ static int ht_forward_dev(asx_engine *e, const float *seg, int B, float *out, hi
       CHK(ht_gg(e, Et.rewrite, b.yt, r, B, b.skt[i], C, GG_GLU, 0, nullptr, 0, 0, 0, 0, s));
     }
   }
+  return ASX_OK;
+}
+
+// decoder level i of both branches (hdemucs.py:303-330): df[i+1] / dt[i+1] (already x + skip) -> df[i] / dt[i]
+// (+ GELU + the next level's skip unless i == 0)
+static int ht_dec_level(asx_engine *e, int i, int B, hipStream_t s) {
+  HtNet &n = *e->ht;
+  auto &b = n.b;
+  const int T = n.T;
+  {
+    const HtDec &Dz = n.dec[i], &Dt = n.tdec[i];
+    const int C = n.C[i];
+    {
+      HtGeom g;
+      g.O = T;
+      g.I = n.F[i + 1];
+      g.Cin = C;
+      g.ldc = C;
+      g.KO = 3;
+      g.KI = 3;
+      g.PO = 1;
+      g.PI = 1;
+      g.IR = n.F[i + 1];
+      CHK(ht_gg(e, Dz.rewrite, b.df[i + 1], g, (int64_t)B * T, b.rw, C, GG_GLU, 0, nullptr, 0, 0, 0, 0, s));
+      HtGeom t;
+      t.O = T;
+      t.I = n.F[i + 1];
+      t.Cin = C;
+      t.ldc = C;
+      t.KI = 2;
+      t.PI = 1;
+      t.IR = n.F[i + 1] + 1;
+      CHK(ht_gg(e, Dz.convtr, b.rw, t, (int64_t)B * T, b.df[i], Dz.cout, GG_CONVT, i == 0 ? 0 : 2,
+                i == 0 ? nullptr : b.skf[i - 1], Dz.cout, 0, n.F[i], Dz.cout, s));
+    }
+    {
+      HtGeom g;
+      g.I = (int)n.L[i + 1];
+      g.Cin = C;
+      g.ldc = C;
+      g.KI = 3;
+      g.PI = 1;
+      g.IR = (int)n.L[i + 1];
+      CHK(ht_gg(e, Dt.rewrite, b.dt[i + 1], g, B, b.rw, C, GG_GLU, 0, nullptr, 0, 0, 0, 0, s));
+      HtGeom t;
+      t.I = (int)n.L[i + 1];
+      t.Cin = C;
+      t.ldc = C;
+      t.KI = 2;
+      t.PI = 1;
+      t.IR = (int)n.L[i + 1] + 1;
+      CHK(ht_gg(e, Dt.convtr, b.rw, t, B, b.dt[i], Dt.cout, GG_CONVT, i == 0 ? 0 : 2, i == 0 ? nullptr : b.skt[i - 1],
+                Dt.cout, 0, (int)n.L[i], Dt.cout, s));
+    }
+  }
+  return ASX_OK;
+}
+
+static int ht_forward_dev(asx_engine *e, const float *seg, int B, float *out, hipStream_t s) {
+  HtNet &n = *e->ht;
+  const asx_ht_config &c = n.cfg;
+  CHK(ht_ensure_workspace(e, B));
+  auto &b = n.b;
+  const int D = c.depth, S = c.n_sources, T = n.T, hop = c.nfft / 4;
+  const int64_t TL = n.L[0];
+  const int F0 = n.F[0];
+  // spectrogram + per-sample standardisation of both branches (htdemucs.py:505-519)
+  CHK(timed(e, ASX_PROF_STFT, 0.0, 4.0 * (double)B * (2.0 * TL + 4.0 * T * F0), s, [&]() {
+    hipLaunchKernelGGL(ht_stft_kernel, dim3(T, 2, B), dim3(256), stft_lds(n.plan), s, seg, TL, hop, T, b.xf0, n.window.f(),
+                       reinterpret_cast<const float2 *>(n.tw.p), n.plan);
+  }));
+  const int64_t nf = (int64_t)T * F0 * 4;
+  CHK(ht_stats(e, b.xf0, B, T, (int64_t)F0 * 4, (int64_t)F0 * 4, 4, 4, 1, b.acc_f, s));
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)B * nf, s, [&]() {
+    hipLaunchKernelGGL(std_norm_kernel, dim3((unsigned)((nf + 255) / 256), B), dim3(256), 0, s, b.xf0, nf, b.acc_f);
+  }));
+  CHK(ht_stats(e, seg, B, 1, 2 * TL, 2 * TL, 1, 1, 1, b.acc_t, s));
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 16.0 * (double)B * TL, s, [&]() {
+    hipLaunchKernelGGL(time_norm_kernel, dim3((unsigned)((TL + 255) / 256), B), dim3(256), 0, s, seg, TL, b.acc_t, b.xt0);
+  }));
+  // encoders
+  for (int i = 0; i < D; ++i) CHK(ht_enc_level(e, i, B, s));
   // cross transformer (transformer.py:520-548)
   const int Cb = n.C[D - 1];
   const int64_t NF = (int64_t)T * n.F[D], NT = n.L[D];
@@ -904,52 +994,7 @@ static int ht_forward_dev(asx_engine *e, const float *seg, int B, float *out, hi
     HIPCHK(hipGetLastError());
   }
   // decoders, deepest first (hdemucs.py:303-330); the input already holds x + skip
-  for (int i = D - 1; i >= 0; --i) {
-    const HtDec &Dz = n.dec[i], &Dt = n.tdec[i];
-    const int C = n.C[i];
-    {
-      HtGeom g;
-      g.O = T;
-      g.I = n.F[i + 1];
-      g.Cin = C;
-      g.ldc = C;
-      g.KO = 3;
-      g.KI = 3;
-      g.PO = 1;
-      g.PI = 1;
-      g.IR = n.F[i + 1];
-      CHK(ht_gg(e, Dz.rewrite, b.df[i + 1], g, (int64_t)B * T, b.rw, C, GG_GLU, 0, nullptr, 0, 0, 0, 0, s));
-      HtGeom t;
-      t.O = T;
-      t.I = n.F[i + 1];
-      t.Cin = C;
-      t.ldc = C;
-      t.KI = 2;
-      t.PI = 1;
-      t.IR = n.F[i + 1] + 1;
-      CHK(ht_gg(e, Dz.convtr, b.rw, t, (int64_t)B * T, b.df[i], Dz.cout, GG_CONVT, i == 0 ? 0 : 2,
-                i == 0 ? nullptr : b.skf[i - 1], Dz.cout, 0, n.F[i], Dz.cout, s));
-    }
-    {
-      HtGeom g;
-      g.I = (int)n.L[i + 1];
-      g.Cin = C;
-      g.ldc = C;
-      g.KI = 3;
-      g.PI = 1;
-      g.IR = (int)n.L[i + 1];
-      CHK(ht_gg(e, Dt.rewrite, b.dt[i + 1], g, B, b.rw, C, GG_GLU, 0, nullptr, 0, 0, 0, 0, s));
-      HtGeom t;
-      t.I = (int)n.L[i + 1];
-      t.Cin = C;
-      t.ldc = C;
-      t.KI = 2;
-      t.PI = 1;
-      t.IR = (int)n.L[i + 1] + 1;
-      CHK(ht_gg(e, Dt.convtr, b.rw, t, B, b.dt[i], Dt.cout, GG_CONVT, i == 0 ? 0 : 2, i == 0 ? nullptr : b.skt[i - 1],
-                Dt.cout, 0, (int)n.L[i], Dt.cout, s));
-    }
-  }
+  for (int i = D - 1; i >= 0; --i) CHK(ht_dec_level(e, i, B, s));
   // CaC -> iSTFT, + waveform branch (htdemucs.py:589-612)
   CHK(timed(e, ASX_PROF_ISTFT, 0.0, 4.0 * (double)B * S * 2 * T * (2.0 * F0 + c.nfft), s, [&]() {
     hipLaunchKernelGGL(ht_istft_kernel, dim3(T, S * 2, B), dim3(256), istft_lds(n.plan), s, b.df[0], T, 4 * S, b.acc_f,
@@ -1083,7 +1128,7 @@ static int ht_fold_dev(asx_engine *e, const float *mix_dev, int64_t N, const HtP
     CHK(timed(e, ASX_PROF_FINALIZE, 0.0, 4.0 * ((double)sh.nk * S * 2 * TL + 2.0 * S * 2 * N), s, [&]() {
       hipLaunchKernelGGL(ht_fold_kernel, dim3((unsigned)((N + 255) / 256), S * 2), dim3(256), 0, s, chunk_out + (size_t)sh.first * S * 2 * TL,
                          sh.nk, S * 2, TL, p.stride, p.segment, sh.VL, p.max_shift - sh.offset, n.fold_w.f(), si == 0 ? 1 : 0,
-                         si == nsh - 1 ? 1 : 0, nsh, reinterpret_cast<const double *>(n.ref_acc.p), standardize, swap01, N, out_dev);
+                         si == nsh - 1 ? 1 : 0, nsh, reinterpret_cast<const double *>(n.ref_acc.p), standardize, swap01, 1, N, out_dev);
     }));
   }
   return ASX_OK;

@@ -1,0 +1,236 @@
+// Demucs v3 (HDemucs) kernels that the v4 set (kernels_ht.h) does not have: channel-group GroupNorm of the two
+// innermost layers, the BLSTM and LocalState inserts of their DConv branches (uvr_lib_v5/demucs/demucs.py:19-66,
+// 152-221) and the odd-length waveform input.  All fp32, channels-last.
+#pragma once
+
+namespace asx {
+
+// waveform branch input (hdemucs.py:700-704): seg [B, 2, L] -> xt [B, Lp, 2] = (seg - mean) / (1e-5 + std), Lp = L
+// rounded up to even; the pad sample is zero (the first encoder zero-pads to a multiple of its stride, hdemucs.py:147-149)
+__global__ __launch_bounds__(256) void hd_time_norm_kernel(const float *__restrict__ seg, int64_t L, int64_t Lp,
+                                                           const double *__restrict__ acc, float *__restrict__ xt) {
+  const int64_t b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Lp) return;
+  float2 o = make_float2(0.f, 0.f);
+  if (i < L) {
+    float mean, stdv;
+    sample_mean_std(acc, b, (double)(2 * L), mean, stdv);
+    const float d = 1e-5f + stdv;
+    o = make_float2((seg[(b * 2) * L + i] - mean) / d, (seg[(b * 2 + 1) * L + i] - mean) / d);
+  }
+  reinterpret_cast<float2 *>(xt)[b * Lp + i] = o;
+}
+
+// GroupNorm(G, C) over x [B, R, C] (R = every non-channel position), statistics from gstats_kernel
+// (acc[(b*G + g)*2 + {sum, sum of squares}]).
+//   mode 0: dst = gelu(norm(x)) (+ skip)        HEncLayer.norm1 / HDecLayer.norm2 (hdemucs.py:161, 322-329)
+//   mode 1: dst[.., c] = norm(x)[c] * sigmoid(norm(x)[c + C/2])   GLU after norm2 / norm1 (hdemucs.py:169, 315)
+//   mode 2: dst = norm(x) (+ skip)              the last decoder has no GELU
+__global__ __launch_bounds__(256) void hd_gn_kernel(const float *__restrict__ x, int64_t R, int C, int G,
+                                                    const double *__restrict__ acc, const float *__restrict__ gam,
+                                                    const float *__restrict__ bet, int mode, float *__restrict__ dst,
+                                                    const float *__restrict__ skip, int64_t total) {
+  const int Ce = mode == 1 ? C / 2 : C;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;            // total = B*R*Ce
+  const int c = (int)(idx % Ce);
+  const int64_t row = idx / Ce;        // (b, r)
+  const int64_t b = row / R;
+  const int cg = C / G;
+  const double cnt = (double)R * cg;
+  float mean, rstd;
+  group_mean_rstd(acc, b * G + c / cg, cnt, 1e-5f, mean, rstd);
+  const float *xp = x + row * C;
+  float v = (xp[c] - mean) * rstd * gam[c] + bet[c];
+  if (mode == 1) {
+    float m2, r2;
+    group_mean_rstd(acc, b * G + (c + Ce) / cg, cnt, 1e-5f, m2, r2);
+    const float g = (xp[c + Ce] - m2) * r2 * gam[c + Ce] + bet[c + Ce];
+    v = v * (1.0f / (1.0f + expf(-g)));
+  } else if (mode == 0) {
+    v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  }
+  if (skip != nullptr) v += skip[idx];
+  dst[idx] = v;
+}
+
+// ---------------------------------------------------------------------------
+// BLSTM (demucs.py:19-66): sequences longer than max_steps = 200 are cut into frames of 200 with stride 100
+// (utils.unfold, zero padded), every frame is an independent sequence; the output keeps the middle of each frame.
+// Sequence-major rows: row = step * N + n with n = b * nfr + k.
+// ---------------------------------------------------------------------------
+// h [B, T, H] -> xs [steps * N, H]
+__global__ __launch_bounds__(256) void hd_lstm_frame_kernel(const float *__restrict__ h, int B, int T, int H, int nfr,
+                                                            int steps, int fstride, float *__restrict__ xs, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over steps * N * H
+  if (idx >= total) return;
+  const int c = (int)(idx % H);
+  int64_t p = idx / H;
+  const int N = B * nfr;
+  const int n = (int)(p % N);
+  const int s = (int)(p / N);
+  const int b = n / nfr, k = n - b * nfr;
+  const int t = k * fstride + s;
+  xs[idx] = t < T ? h[((int64_t)b * T + t) * H + c] : 0.f;
+}
+
+// h [B, T, H] += lin rows picked as BLSTM.forward stitches them (demucs.py:50-64): frame 0 gives steps [0, 150),
+// the last frame [50, 200), the others [50, 150); unframed (nfr == 1): row t.
+__global__ __launch_bounds__(256) void hd_lstm_unframe_kernel(const float *__restrict__ lin, int B, int T, int H, int nfr,
+                                                              int fstride, float *__restrict__ h, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * T * H
+  if (idx >= total) return;
+  const int c = (int)(idx % H);
+  int64_t p = idx / H;
+  const int t = (int)(p % T);
+  const int b = (int)(p / T);
+  int k = 0;
+  if (nfr > 1 && t >= fstride + fstride / 2) {
+    k = (t - fstride / 2) / fstride;
+    if (k > nfr - 1) k = nfr - 1;
+  }
+  const int s = t - k * fstride;
+  const int N = B * nfr;
+  h[idx] += lin[((int64_t)s * N + b * nfr + k) * H + c];
+}
+
+// One time step of a bidirectional nn.LSTM layer for N sequences (gate order i, f, g, o):
+//   gates = xp[t_dir][n][dir] + W_hh[dir] h_prev[dir][n];  c = f*c + i*g;  h = o * tanh(c)
+// xp [steps*N, 2, 4H] (input projection + b_ih + b_hh, one GEMM for all steps), whh [2, 4H, H], hprev / hnext / cst
+// [2, N, H], out [steps*N, 2H].  Direction 0 handles step s, direction 1 step steps-1-s.
+// grid = (H / 16, 2, ceil(N / 64)): a workgroup owns 16 hidden units (64 gate rows) x 64 sequences.
+__global__ __launch_bounds__(256) void hd_lstm_step_kernel(const float *__restrict__ xp, const float *__restrict__ whh,
+                                                           const float *__restrict__ hprev, float *__restrict__ hnext,
+                                                           float *__restrict__ cst, float *__restrict__ out, int N, int H,
+                                                           int s, int steps) {
+  __shared__ float Wt[64][65];
+  __shared__ float Ht[64][65];
+  const int u0 = blockIdx.x * 16, dir = blockIdx.y, n0 = blockIdx.z * 64;
+  const int tid = threadIdx.x;
+  const int r = tid & 63, sg = tid >> 6;
+  const int t = dir ? steps - 1 - s : s;
+  const float *W = whh + (int64_t)dir * 4 * H * H;
+  const float *hp = hprev + (int64_t)dir * N * H;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int k0 = 0; k0 < H; k0 += 64) {
+    // tiles: Wt[row][kk] = W[(row/16)*H + u0 + row%16][k0 + kk], Ht[nn][kk] = hprev[n0 + nn][k0 + kk]
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int row = i >> 6, kk = i & 63;
+      const int k = k0 + kk;
+      Wt[row][kk] = k < H ? W[((int64_t)(row >> 4) * H + u0 + (row & 15)) * H + k] : 0.f;
+      const int n = n0 + row;
+      Ht[row][kk] = (k < H && n < N) ? hp[(int64_t)n * H + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 64; ++kk) {
+      const float w = Wt[r][kk];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] += w * Ht[sg * 16 + j][kk];
+    }
+    __syncthreads();
+  }
+  // gate pre-activations of (sequence, gate row) through LDS, then the cell update per (sequence, unit)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) Ht[sg * 16 + j][r] = acc[j];
+  __syncthreads();
+  for (int i = tid; i < 64 * 16; i += 256) {
+    const int nn = i >> 4, u = i & 15;
+    const int n = n0 + nn;
+    if (n >= N) continue;
+    const float *xr = xp + (((int64_t)t * N + n) * 2 + dir) * 4 * H + u0 + u;
+    const float gi = Ht[nn][u] + xr[0], gf = Ht[nn][16 + u] + xr[H], gg = Ht[nn][32 + u] + xr[2 * H],
+                go = Ht[nn][48 + u] + xr[3 * H];
+    const float ig = 1.0f / (1.0f + expf(-gi)), fg = 1.0f / (1.0f + expf(-gf)), og = 1.0f / (1.0f + expf(-go));
+    const int64_t si = ((int64_t)dir * N + n) * H + u0 + u;
+    const float c = fg * cst[si] + ig * tanhf(gg);
+    cst[si] = c;
+    const float hv = og * tanhf(c);
+    hnext[si] = hv;
+    out[((int64_t)t * N + n) * 2 * H + dir * H + u0 + u] = hv;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LocalState (demucs.py:152-221, heads = 4, ndecay = 4, nfreqs = 0): for every query s
+//   score[t] = k_t . q_s / sqrt(dh) - |t - s| * D_s,   D_s = 1/4 * sum_f (f + 1) * sigmoid(decay_f[s]),   score[s] = -100
+//   out[s] = sum_t softmax_t(score)[t] * content_t
+// qkvd [B*T, ld]: query | key | content (H channels each, head h owns [h*DH, (h+1)*DH)) | decay logits [heads*4].
+// One thread per query, keys staged through LDS in tiles of 32; grid = (ceil(T / 128), heads, B), block 128.
+// ---------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(128) void hd_local_attn_kernel(const float *__restrict__ qkvd, int ld, int T, int H,
+                                                            float *__restrict__ out) {
+  __shared__ float Ks[32][DH];
+  __shared__ float Cs[32][DH];
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int s = blockIdx.x * 128 + threadIdx.x;
+  const bool live = s < T;
+  const float *base = qkvd + (int64_t)b * T * ld;
+  float q[DH], acc[DH];
+  float D = 0.f;
+  const float scale = 1.0f / sqrtf((float)DH);
+  if (live) {
+    const float *qr = base + (int64_t)s * ld + head * DH;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) q[c] = qr[c] * scale;
+    const float *dr = base + (int64_t)s * ld + 3 * H + head * 4;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) D += (float)(f + 1) * (1.0f / (1.0f + expf(-dr[f])));
+    D *= 0.25f;
+  } else {
+#pragma unroll
+    for (int c = 0; c < DH; ++c) q[c] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < DH; ++c) acc[c] = 0.f;
+  float m = -3.0e38f, l = 0.f;
+  for (int t0 = 0; t0 < T; t0 += 32) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * DH; i += 128) {
+      const int tt = i / DH, c = i - tt * DH;
+      const int t = t0 + tt;
+      float kv = 0.f, cv = 0.f;
+      if (t < T) {
+        const float *row = base + (int64_t)t * ld + head * DH + c;
+        kv = row[H];
+        cv = row[2 * H];
+      }
+      Ks[tt][c] = kv;
+      Cs[tt][c] = cv;
+    }
+    __syncthreads();
+    const int tn = T - t0 < 32 ? T - t0 : 32;
+    for (int tt = 0; tt < tn; ++tt) {
+      const int t = t0 + tt;
+      float sc = 0.f;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) sc += q[c] * Ks[tt][c];
+      const int d = t > s ? t - s : s - t;
+      sc -= (float)d * D;
+      if (t == s) sc = -100.0f;
+      if (sc > m) {
+        const float r = expf(m - sc);
+        l *= r;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) acc[c] *= r;
+        m = sc;
+      }
+      const float p = expf(sc - m);
+      l += p;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) acc[c] += p * Cs[tt][c];
+    }
+  }
+  if (live) {
+    const float inv = 1.0f / l;
+    float *o = out + ((int64_t)b * T + s) * H + head * DH;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) o[c] = acc[c] * inv;
+  }
+}
+
+}  // namespace asx

@@ -914,7 +914,8 @@ __global__ __launch_bounds__(256) void ht_fold_kernel(const float *__restrict__ 
                                                       int64_t TL, int64_t stride, int64_t segment, int64_t VL,
                                                       int64_t lead, const float *__restrict__ weight, int first,
                                                       int last, int shifts, const double *__restrict__ ref_acc,
-                                                      int standardize, int swap01, int64_t N, float *__restrict__ out) {
+                                                      int standardize, int swap01, int center, int64_t N,
+                                                      float *__restrict__ out) {
   const int sc_ = blockIdx.y;
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(256) void ht_fold_kernel(const float *__restrict__ 
     const int64_t clen = (VL - off < segment) ? VL - off : segment;
     const int64_t j = u - off;
     if (j < 0 || j >= clen) continue;
-    const int64_t trim = (TL - clen) / 2;
+    const int64_t trim = center ? (TL - clen) / 2 : 0;   // Demucs v3 chunks run unpadded (engine_hd.h)
     const float w = weight[j];
     num += w * chunk_out[((int64_t)k * SC + sc_) * TL + trim + j];
     den += w;

@@ -8,8 +8,9 @@ work -- standardisation, shift trick, segment split, HTDemucs forward, triangula
 ``random`` (uvr_lib_v5/demucs/apply.py:209).
 
 A bag of models (BagOfModels, apply.py:26-66,169-196: htdemucs_ft, htdemucs_6s ...) is a list of
-(HTConfig, state_dict, per-source weights); the per-model results are combined on the host with the reference's
-weighted average.  Only HTDemucs (Demucs v4) checkpoints are accelerated; v1-v3 raise NotImplementedError.
+(HTConfig | HDConfig, state_dict, per-source weights); the per-model results are combined on the host with the
+reference's weighted average.  HTDemucs (Demucs v4) and HDemucs (Demucs v3: `hdemucs_mmi`, asx_hd_demix) checkpoints
+are accelerated; the waveform-only Demucs v1 / v2 raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ import random
 
 import numpy as np
 
-from .engine import Engine, HTConfig, MDXConfig
+from .engine import Engine, HDConfig, HTConfig, MDXConfig
 
 
 def htconfig_from_kwargs(kwargs: dict, max_batch: int = 0) -> HTConfig:
@@ -41,6 +42,26 @@ def htconfig_from_kwargs(kwargs: dict, max_batch: int = 0) -> HTConfig:
                     bottom_channels=k.get("bottom_channels", 0), t_layers=k.get("t_layers", 5), t_heads=k.get("t_heads", 8),
                     t_hidden_scale=k.get("t_hidden_scale", 4.0), samplerate=k.get("samplerate", 44100),
                     segment=k.get("segment", 10), max_batch=max_batch)
+
+
+def hdconfig_from_kwargs(kwargs: dict, max_batch: int = 0) -> HDConfig:
+    """HDConfig from the `kwargs` of a Demucs v3 (HDemucs) checkpoint package; NotImplementedError outside the class defaults."""
+    k = dict(kwargs)
+    fixed = {"cac": True, "wiener_iters": 0, "end_iters": 0, "multi_freqs": None, "dconv_mode": 1, "context": 1, "context_enc": 0,
+             "rewrite": True, "hybrid": True, "hybrid_old": False, "audio_channels": 2, "channels_time": None, "norm_groups": 4,
+             "emb_scale": 10, "emb_smooth": True, "dconv_init": 1e-4}
+    for name, want in fixed.items():
+        if name in k and k[name] != want and not (want is None and not k[name]):
+            raise NotImplementedError(f"HDemucs option {name}={k[name]!r} is not built (only {want!r})")
+    depth = k.get("depth", 6)
+    for name in ("norm_starts", "dconv_attn", "dconv_lstm"):
+        if k.get(name, 4) != depth - 2:
+            raise NotImplementedError(f"HDemucs {name}={k.get(name, 4)} with depth {depth}: only depth - 2 is built")
+    return HDConfig(sources=tuple(k["sources"]), channels=k.get("channels", 48), growth=k.get("growth", 2), nfft=k.get("nfft", 4096),
+                    depth=depth, kernel_size=k.get("kernel_size", 8), stride=k.get("stride", 4), time_stride=k.get("time_stride", 2),
+                    norm_starts=depth - 2, norm_groups=4, dconv_depth=k.get("dconv_depth", 2), dconv_comp=k.get("dconv_comp", 4),
+                    dconv_attn=depth - 2, dconv_lstm=depth - 2, freq_emb=k.get("freq_emb", 0.2), samplerate=k.get("samplerate", 44100),
+                    segment=k.get("segment", 40), max_batch=max_batch)
 
 
 class DemucsDemixer:
@@ -76,7 +97,12 @@ class DemucsDemixer:
             # the MDX geometry of the engine is unused on this path; any valid one will do
             self.engine = Engine(MDXConfig(n_fft=hc.nfft, hop_length=hc.nfft // 4, dim_f=hc.nfft // 2, segment_size=8),
                                  device=self.device)
-        self.engine.load_ht(hc, sd)
+        if isinstance(hc, HDConfig):
+            self.engine.load_hd(hc, sd)
+            self._demix = self.engine.hd_demix
+        else:
+            self.engine.load_ht(hc, sd)
+            self._demix = self.engine.ht_demix
         self._loaded = idx
 
     def demix(self, mix: np.ndarray, offsets=None) -> np.ndarray:
@@ -95,8 +121,8 @@ class DemucsDemixer:
                 offs = offsets[i] if offsets is not None else [random.randint(0, int(0.5 * hc.samplerate))
                                                                for _ in range(self.shifts)]
             # a single model is de-standardised and swapped inside the engine; a bag is combined first (apply.py:186-196)
-            out = self.engine.ht_demix(mix, shifts=self.shifts, offsets=offs, overlap=self.overlap, standardize=single,
-                                       swap01=single) if single else self._bag_member(mix, offs)
+            out = self._demix(mix, shifts=self.shifts, offsets=offs, overlap=self.overlap, standardize=single,
+                              swap01=single) if single else self._bag_member(mix, offs)
             if single:
                 return out
             w = np.asarray(self.weights[i], np.float32)
@@ -116,4 +142,4 @@ class DemucsDemixer:
         t = torch.from_numpy(mix)
         ref = t.mean(0)
         std_mix = ((t - ref.mean()) / ref.std()).numpy()
-        return self.engine.ht_demix(std_mix, shifts=self.shifts, offsets=offs, overlap=self.overlap)
+        return self._demix(std_mix, shifts=self.shifts, offsets=offs, overlap=self.overlap)

@@ -55,6 +55,13 @@ class _HtCfg(C.Structure):
                [("freq_emb_scale", C.c_float), ("max_batch", C.c_int32)]
 
 
+class _HdCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_sources", "channels", "growth", "nfft", "depth", "kernel_size", "stride", "time_stride",
+                                         "norm_starts", "norm_groups", "dconv_depth", "dconv_comp", "dconv_attn", "dconv_lstm",
+                                         "samplerate", "segment_samples")] + \
+               [("freq_emb_scale", C.c_float), ("max_batch", C.c_int32)]
+
+
 class _VrBand(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("sr", "hl", "n_fft", "crop_start", "crop_stop", "hpf_start", "hpf_stop", "lpf_start",
                                          "lpf_stop", "convert")]
@@ -173,6 +180,33 @@ class HTConfig:
         return self.bottom_channels or self.channels * self.growth ** (self.depth - 1)
 
 
+@dataclass
+class HDConfig:
+    """HDemucs constructor arguments (uvr_lib_v5/demucs/hdemucs.py:362-420) the engine builds (Demucs v3: `hdemucs_mmi`)."""
+    sources: tuple = ("drums", "bass", "other", "vocals")
+    channels: int = 48
+    growth: int = 2
+    nfft: int = 4096
+    depth: int = 6
+    kernel_size: int = 8
+    stride: int = 4
+    time_stride: int = 2
+    norm_starts: int = 4
+    norm_groups: int = 4
+    dconv_depth: int = 2
+    dconv_comp: int = 4
+    dconv_attn: int = 4
+    dconv_lstm: int = 4
+    freq_emb: float = 0.2
+    samplerate: int = 44100
+    segment: object = 40           # seconds
+    max_batch: int = 0
+
+    @property
+    def segment_samples(self) -> int:
+        return int(self.samplerate * self.segment)
+
+
 _FP = C.POINTER(C.c_float)
 _lib = None
 
@@ -187,7 +221,9 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_vr_begin", "asx_vr_commit", "asx_vr_flops", "asx_vr_plan", "asx_vr_forward", "asx_vr_analysis",
            "asx_vr_separate", "asx_vr_separate_dev", "asx_debug_fetch",
            "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
-           "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem"]
+           "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev",
+           "asx_hd_begin", "asx_hd_commit", "asx_hd_flops", "asx_hd_forward", "asx_hd_demix", "asx_hd_demix_dev", "asx_hd_plan",
+           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem"]
 
 
 def load_library():
@@ -279,6 +315,16 @@ def load_library():
     lib.asx_ht_plan.argtypes = [vp, i64, i32, C.POINTER(C.c_int64), C.c_double, C.POINTER(i32), C.POINTER(i64)]
     lib.asx_ht_segments_dev.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, i32, i32, vp, vp]
     lib.asx_ht_fold_dev.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, vp, vp, vp]
+    lib.asx_hd_begin.argtypes = [vp, C.POINTER(_HdCfg)]
+    lib.asx_hd_commit.argtypes = [vp]
+    lib.asx_hd_flops.argtypes = [vp, i64]
+    lib.asx_hd_flops.restype = C.c_double
+    lib.asx_hd_forward.argtypes = [vp, _FP, i32, i64, _FP]
+    lib.asx_hd_demix.argtypes = [vp, _FP, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, _FP]
+    lib.asx_hd_demix_dev.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, vp, vp]
+    lib.asx_hd_plan.argtypes = [vp, i64, i32, C.POINTER(C.c_int64), C.c_double, C.POINTER(i32), C.POINTER(i64)]
+    lib.asx_hd_segments_dev.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, i32, i32, vp, vp]
+    lib.asx_hd_fold_dev.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_int64), C.c_double, u32, vp, vp, vp]
     lib.asx_profile_enable.argtypes = [vp, i32]
     lib.asx_profile_read.argtypes = [vp, C.POINTER(_Profile)]
     for name in SYMBOLS:
@@ -522,6 +568,65 @@ class Engine:
         offs = (C.c_int64 * shifts)(*[int(o) for o in offsets]) if shifts else None
         self._check(self._lib.asx_ht_demix_dev(self._h, mix_ptr, n_samples, int(shifts), offs, float(overlap), flags,
                                                out_ptr, stream or None))
+
+    # -- Demucs v3 ----------------------------------------------------------------
+    def load_hd(self, hc: HDConfig, state_dict: dict):
+        """HDemucs(**kwargs) + load_state_dict (uvr_lib_v5/demucs/hdemucs.py:362-571)."""
+        c = _HdCfg(len(hc.sources), hc.channels, hc.growth, hc.nfft, hc.depth, hc.kernel_size, hc.stride, hc.time_stride,
+                   hc.norm_starts, hc.norm_groups, hc.dconv_depth, hc.dconv_comp, hc.dconv_attn, hc.dconv_lstm, hc.samplerate,
+                   hc.segment_samples, float(hc.freq_emb), hc.max_batch)
+        self._check(self._lib.asx_hd_begin(self._h, C.byref(c)))
+        for name, t in state_dict.items():
+            if hasattr(t, "detach"):
+                t = t.detach().cpu().numpy()
+            a = _f32(t).reshape(-1)
+            self._check(self._lib.asx_net_set_tensor(self._h, name.encode(), _ptr(a), a.size))
+        self._check(self._lib.asx_hd_commit(self._h))
+        self.hd_cfg = hc
+
+    def hd_flops(self, length: int) -> float:
+        return float(self._lib.asx_hd_flops(self._h, int(length)))
+
+    def hd_forward(self, mix: np.ndarray) -> np.ndarray:
+        """HDemucs.forward: [B, 2, L] -> [B, S, 2, L], any L >= nfft."""
+        mix = _f32(mix)
+        B, ch, L = mix.shape
+        if ch != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got {ch} channels")
+        out = np.empty((B, len(self.hd_cfg.sources), 2, L), np.float32)
+        self._check(self._lib.asx_hd_forward(self._h, _ptr(mix), B, L, _ptr(out)))
+        return out
+
+    def hd_demix(self, mix: np.ndarray, shifts: int = 0, offsets=None, overlap: float = 0.25, standardize: bool = False,
+                 swap01: bool = False) -> np.ndarray:
+        mix = _f32(mix)
+        if mix.ndim != 2 or mix.shape[0] != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got shape {mix.shape}")
+        out = np.empty((len(self.hd_cfg.sources), 2, mix.shape[1]), np.float32)
+        if shifts and (offsets is None or len(offsets) != shifts):
+            raise ValueError("shifts > 0 needs one offset per shift")
+        flags = (1 if standardize else 0) | (2 if swap01 else 0)
+        self._check(self._lib.asx_hd_demix(self._h, _ptr(mix), mix.shape[1], int(shifts), self._offs(shifts, offsets), float(overlap),
+                                           flags, _ptr(out)))
+        return out
+
+    def hd_demix_dev(self, mix_ptr: int, n_samples: int, out_ptr: int, shifts: int = 0, offsets=None, overlap: float = 0.25,
+                     flags: int = 0, stream: int = 0):
+        self._check(self._lib.asx_hd_demix_dev(self._h, mix_ptr, n_samples, int(shifts), self._offs(shifts, offsets), float(overlap),
+                                               flags, out_ptr, stream or None))
+
+    def hd_plan(self, n, shifts=0, offsets=None, overlap=0.25):
+        k, c = C.c_int32(), C.c_int64()
+        self._check(self._lib.asx_hd_plan(self._h, n, int(shifts), self._offs(shifts, offsets), float(overlap), C.byref(k), C.byref(c)))
+        return {"n_chunks": k.value, "chunk_size": c.value}
+
+    def hd_segments_dev(self, mix_ptr, n, k0, k1, out_ptr, shifts=0, offsets=None, overlap=0.25, flags=0, stream=0):
+        self._check(self._lib.asx_hd_segments_dev(self._h, mix_ptr, n, int(shifts), self._offs(shifts, offsets), float(overlap), flags,
+                                                  k0, k1, out_ptr, stream or None))
+
+    def hd_fold_dev(self, mix_ptr, n, chunks_ptr, out_ptr, shifts=0, offsets=None, overlap=0.25, flags=0, stream=0):
+        self._check(self._lib.asx_hd_fold_dev(self._h, mix_ptr, n, int(shifts), self._offs(shifts, offsets), float(overlap), flags,
+                                              chunks_ptr, out_ptr, stream or None))
 
     # -- VR -----------------------------------------------------------------------
     def load_vr(self, model_params: dict, arch: int, capacity, state_dict: dict, window_size: int = 512, offset: int = 128,

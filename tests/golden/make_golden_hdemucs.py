@@ -34,6 +34,9 @@ for pkg, path in (("audio_separator", f"{REF}/audio_separator"), ("audio_separat
     m = _stub(pkg)
     m.__path__ = [path]
 
+import random  # noqa: E402
+
+from audio_separator.separator.uvr_lib_v5.demucs.apply import apply_model  # noqa: E402
 from audio_separator.separator.uvr_lib_v5.demucs.hdemucs import HDemucs  # noqa: E402
 
 sys.path.insert(0, ROOT)
@@ -43,7 +46,7 @@ from oracle.hdemucs_oracle import HDConfig, make_hd_state  # noqa: E402
 def small_cfg():
     # nfft 1024 -> 512 -> 128 -> 32 -> 8 frequency rows, then the last_freq layer and one time-only layer; norm/LSTM/attention
     # from layer 3 (the released hdemucs_mmi has the same structure one level deeper)
-    return HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, samplerate=8000, segment=4)
+    return HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, samplerate=8000, segment=2)
 
 
 def main():
@@ -66,6 +69,24 @@ def main():
         out[f"x_{tag}"] = x.numpy()
         out[f"y_{tag}"] = y.numpy().astype(np.float32)
         print(tag, x.shape, y.shape, float(y.abs().mean()))
+    # apply_model on 2.3 segments: every chunk runs at its own length (no valid_length), the shift draws are recorded
+    mix = torch.randn(1, 2, int(2.3 * cfg.segment * cfg.samplerate) + 77, generator=g) * 0.3
+    out["mix"] = mix.numpy()
+    with torch.no_grad():
+        out["split"] = apply_model(model, mix, shifts=0, split=True, overlap=0.25, progress=False).numpy()
+    random.seed(4321)
+    offs = []
+    real_randint = random.randint
+
+    def rec(a, b):
+        offs.append(real_randint(a, b))
+        return offs[-1]
+    random.randint = rec
+    with torch.no_grad():
+        out["shift"] = apply_model(model, mix, shifts=2, split=True, overlap=0.25, progress=False).numpy()
+    random.randint = real_randint
+    out["offsets"] = np.array(offs, np.int64)
+    print("apply_model", mix.shape, out["offsets"])
     np.savez_compressed(os.path.join(HERE, "hdemucs_small.npz"), **out)
     print("wrote hdemucs_small.npz", os.path.getsize(os.path.join(HERE, "hdemucs_small.npz")) // 1024, "KiB")
 

@@ -9,13 +9,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
+from oracle.demucs_oracle import apply_model  # noqa: E402
 from oracle.hdemucs_oracle import HDConfig, hd_forward, make_hd_state  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden", "hdemucs_small.npz")
 
 
 def small_cfg():
-    return HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, samplerate=8000, segment=4)
+    return HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, samplerate=8000, segment=2)
 
 
 def test_layer_plan_released_model():
@@ -37,4 +38,20 @@ def test_forward_matches_reference(tag):
     ref = g[f"y_{tag}"]
     assert y.shape == ref.shape
     err = np.abs(y - ref).max() / np.abs(ref).max()
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("mode", ["split", "shift"])
+def test_apply_model_matches_reference(mode):
+    # chunks run unpadded at their own length (HDemucs has no valid_length, apply.py:251-256)
+    g = np.load(GOLD)
+    cfg = small_cfg()
+    sd = make_hd_state(cfg, 21)
+    fn = lambda x: hd_forward(x.numpy() if hasattr(x, "numpy") else x, sd, cfg)  # noqa: E731
+    if mode == "split":
+        y = apply_model(fn, g["mix"], cfg, shifts=0, split=True, overlap=0.25)
+    else:
+        y = apply_model(fn, g["mix"], cfg, shifts=2, split=True, overlap=0.25, offsets=[int(o) for o in g["offsets"]])
+    ref = g[mode]
+    err = np.abs(np.asarray(y) - ref).max() / np.abs(ref).max()
     assert err < 2e-5, err
