@@ -295,7 +295,8 @@ int asx_ht_fold_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int3
  * architectures/demucs_separator.py:162-194).  Structure built: the class defaults -- CaC, depth - 2 strided levels
  * on both branches, the last-frequency level with the waveform branch injected, one time-only level; GroupNorm,
  * BLSTM(max_steps 200) and LocalState on those two innermost levels.  HDemucs has no valid_length: every chunk
- * of apply_model runs at its own length (apply.py:251-256), so asx_hd_forward takes any length >= nfft.
+ * of apply_model runs at its own length (apply.py:251-256), so asx_hd_forward takes any length >= 1 (short inputs get
+ * pad1d's zero extension before the reflection, hdemucs.py:21-34).
  * Weights come in under the checkpoint's own state_dict keys (asx_net_set_tensor). */
 typedef struct asx_hd_config {
   int32_t n_sources;

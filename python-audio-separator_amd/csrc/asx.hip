@@ -2065,7 +2065,7 @@ int asx_hd_begin(asx_engine *e, const asx_hd_config *cfg) {
           "is built");
   REQUIRE(cfg->norm_groups >= 1, "bad norm_groups");
   REQUIRE(cfg->nfft >= 64 && cfg->nfft % 8 == 0, "bad nfft %d", cfg->nfft);
-  REQUIRE(cfg->samplerate > 0 && cfg->segment_samples >= cfg->nfft, "bad samplerate / segment");
+  REQUIRE(cfg->samplerate > 0 && cfg->segment_samples >= 1, "bad samplerate / segment");
   if (!e->ht) e->ht = new HtNet();
   ht_free(*e->ht);
   if (!e->hd) e->hd = new HdNet();

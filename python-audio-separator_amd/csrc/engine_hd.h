@@ -303,7 +303,7 @@ static int hd_ensure_workspace(asx_engine *e, int B, int64_t L) {
   want(b.rwZ, BT2 * 2 * CZ);
   want(b.skZ, BT2 * CZ);
   want(b.g, std::max(BT2 * CZ, BT * CA));
-  want(b.tr, std::max(std::max(BT * CA, BT * n.F[D] * h.CD), (size_t)B * n.L[D] * h.CD));
+  want(b.tr, std::max(std::max((size_t)B * (d.T2 + 1) * c.time_stride * CA, BT * n.F[D] * h.CD), (size_t)B * (d.T + 1) * c.stride * h.CD));
   want(b.dAin, BT * CA);
   want(b.pre, BT * CA);
   const size_t rowsA = (size_t)d.stepsA * B * d.nfrA, rowsZ = (size_t)d.stepsZ * B * d.nfrZ;
@@ -322,16 +322,17 @@ static int hd_ensure_workspace(asx_engine *e, int B, int64_t L) {
 }
 
 // ---- stages -----------------------------------------------------------------------------------------------------
-// GroupNorm(G, C) over x [B, R, C] -> dst (hd_gn_kernel modes)
+// GroupNorm(G, C) over x [B, Rin, C] -> dst [B, R, C] = rows [r0, r0 + R) (hd_gn_kernel modes); Rin = 0: Rin = R
 static int hd_group_norm(asx_engine *e, const float *x, int B, int64_t R, int C, const HdNorm &g, int mode, float *dst, const float *skip,
-                         hipStream_t s) {
+                         hipStream_t s, int64_t Rin = 0, int64_t r0 = 0) {
   HtNet &n = *e->ht;
   const int G = e->hd->cfg.norm_groups;
-  CHK(ht_stats(e, x, B, R, C, C / G, C, C, G, n.b.acc_g, s));
+  if (!Rin) Rin = R;
+  CHK(ht_stats(e, x, B, Rin, C, C / G, C, C, G, n.b.acc_g, s));
   const int64_t total = (int64_t)B * R * (mode == 1 ? C / 2 : C);
   return timed(e, ASX_PROF_MISC, 0.0, 4.0 * (double)B * R * C * 2, s, [&]() {
-    hipLaunchKernelGGL(hd_gn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, R, C, G, n.b.acc_g, g.w.f(), g.b.f(), mode,
-                       dst, skip, total);
+    hipLaunchKernelGGL(hd_gn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, Rin, r0, R, C, G, n.b.acc_g, g.w.f(), g.b.f(),
+                       mode, dst, skip, total);
   });
 }
 
@@ -403,7 +404,7 @@ static int hd_forward_dev(asx_engine *e, const float *seg, int B, int64_t L, flo
   HdNet &h = *e->hd;
   HtNet &n = *e->ht;
   const asx_hd_config &c = h.cfg;
-  REQUIRE(L >= c.nfft, "segment of %lld samples is shorter than nfft = %d", (long long)L, c.nfft);
+  REQUIRE(L >= 1, "empty segment");
   CHK(hd_ensure_workspace(e, B, L));
   auto &b = n.b;
   auto &w = h.b;
@@ -411,9 +412,18 @@ static int hd_forward_dev(asx_engine *e, const float *seg, int B, int64_t L, flo
   const int D = h.D, S = c.n_sources, T = dm.T, T2 = dm.T2, hop = c.nfft / 4;
   const int F0 = n.F[0], CA = h.CA, CZ = h.CZ, CD = h.CD;
   const int64_t Lp = (L + 1) & ~(int64_t)1;
-  // spectrogram + standardisation of both branches (hdemucs.py:680-704)
+  // spectrogram + standardisation of both branches (hdemucs.py:680-704); pad1d's zero extension of short inputs (:21-34)
+  int64_t el = 0, Lv = L;
+  {
+    const int64_t left = hop / 2 * 3, right = left + (int64_t)T * hop - L, mx = std::max(left, right);
+    if (L <= mx) {
+      const int64_t extra = mx - L + 1, er = std::min(right, extra);
+      el = extra - er;
+      Lv = L + extra;
+    }
+  }
   CHK(timed(e, ASX_PROF_STFT, 0.0, 4.0 * (double)B * (2.0 * L + 4.0 * T * F0), s, [&]() {
-    hipLaunchKernelGGL(ht_stft_kernel, dim3(T, 2, B), dim3(256), stft_lds(n.plan), s, seg, L, hop, T, b.xf0, n.window.f(),
+    hipLaunchKernelGGL(ht_stft_kernel, dim3(T, 2, B), dim3(256), stft_lds(n.plan), s, seg, L, el, Lv, hop, T, b.xf0, n.window.f(),
                        reinterpret_cast<const float2 *>(n.tw.p), n.plan);
   }));
   const int64_t nf = (int64_t)T * F0 * 4;
@@ -496,9 +506,10 @@ static int hd_forward_dev(asx_engine *e, const float *seg, int B, int64_t L, flo
     t.PI = 1;
     t.IR = T2 + 1;
     t.So = c.time_stride;
-    t.crop = c.time_stride / 2;
-    CHK(ht_gg(e, h.decZ_tr, w.g, t, B, w.tr, CA, GG_CONVT, 0, nullptr, CA, 0, T, CA, s));
-    CHK(hd_group_norm(e, w.tr, B, T, CA, h.dZn2, 0, w.dAin, w.skA, s));   // gelu(norm2) + the skip of level A
+    t.crop = 0;   // norm2 sees the uncropped output (hdemucs.py:321-327)
+    const int full = (T2 + 1) * c.time_stride;
+    CHK(ht_gg(e, h.decZ_tr, w.g, t, B, w.tr, CA, GG_CONVT, 0, nullptr, CA, 0, full, CA, s));
+    CHK(hd_group_norm(e, w.tr, B, T, CA, h.dZn2, 0, w.dAin, w.skA, s, full, c.time_stride / 2));   // gelu(norm2)[crop] + the skip of level A
   }
   // ---- decoder of level A: spectrogram half and the waveform half fed by `pre` ----
   {
@@ -530,8 +541,10 @@ static int hd_forward_dev(asx_engine *e, const float *seg, int B, int64_t L, flo
     u.KI = 2;
     u.PI = 1;
     u.IR = T + 1;
-    CHK(ht_gg(e, h.tdecA_tr, w.pre, u, B, w.tr, CD, GG_CONVT, 0, nullptr, CD, 0, (int)n.L[D], CD, s));
-    CHK(hd_group_norm(e, w.tr, B, n.L[D], CD, h.tdAn2, 0, b.dt[D], b.skt[D - 1], s));
+    u.crop = 0;
+    const int full = (T + 1) * c.stride;
+    CHK(ht_gg(e, h.tdecA_tr, w.pre, u, B, w.tr, CD, GG_CONVT, 0, nullptr, CD, 0, full, CD, s));
+    CHK(hd_group_norm(e, w.tr, B, n.L[D], CD, h.tdAn2, 0, b.dt[D], b.skt[D - 1], s, full, c.kernel_size / 4));
   }
   for (int i = D - 1; i >= 0; --i) CHK(ht_dec_level(e, i, B, s));
   // CaC -> iSTFT, + waveform branch (hdemucs.py:760-781)
@@ -639,7 +652,6 @@ static int hd_segments_dev(asx_engine *e, const float *mix_dev, int64_t N, const
     std::vector<int64_t> st;
     while (j < order.size() && p.clen[order[j]] == L && (int)st.size() < maxB) st.push_back(p.starts[order[j++]]);
     const int B = (int)st.size();
-    REQUIRE(L >= h.cfg.nfft, "a chunk of %lld samples is shorter than nfft = %d (not supported)", (long long)L, h.cfg.nfft);
     HIPCHK(hipMemcpyAsync(h.starts.p, st.data(), (size_t)B * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     CHK(n.seg.ensure((size_t)maxB * 2 * p.segment * 4));

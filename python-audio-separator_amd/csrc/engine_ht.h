@@ -931,7 +931,7 @@ static int ht_forward_dev(asx_engine *e, const float *seg, int B, float *out, hi
   const int F0 = n.F[0];
   // spectrogram + per-sample standardisation of both branches (htdemucs.py:505-519)
   CHK(timed(e, ASX_PROF_STFT, 0.0, 4.0 * (double)B * (2.0 * TL + 4.0 * T * F0), s, [&]() {
-    hipLaunchKernelGGL(ht_stft_kernel, dim3(T, 2, B), dim3(256), stft_lds(n.plan), s, seg, TL, hop, T, b.xf0, n.window.f(),
+    hipLaunchKernelGGL(ht_stft_kernel, dim3(T, 2, B), dim3(256), stft_lds(n.plan), s, seg, TL, (int64_t)0, TL, hop, T, b.xf0, n.window.f(),
                        reinterpret_cast<const float2 *>(n.tw.p), n.plan);
   }));
   const int64_t nf = (int64_t)T * F0 * 4;

@@ -22,12 +22,13 @@ __global__ __launch_bounds__(256) void hd_time_norm_kernel(const float *__restri
   reinterpret_cast<float2 *>(xt)[b * Lp + i] = o;
 }
 
-// GroupNorm(G, C) over x [B, R, C] (R = every non-channel position), statistics from gstats_kernel
-// (acc[(b*G + g)*2 + {sum, sum of squares}]).
+// GroupNorm(G, C) over x [B, Rin, C] (Rin = every non-channel position), statistics from gstats_kernel
+// (acc[(b*G + g)*2 + {sum, sum of squares}]); dst [B, R, C] keeps rows [r0, r0 + R) -- HDecLayer normalises the whole
+// transposed-conv output and crops afterwards (hdemucs.py:321-327), so the cropped rows still count in the statistics.
 //   mode 0: dst = gelu(norm(x)) (+ skip)        HEncLayer.norm1 / HDecLayer.norm2 (hdemucs.py:161, 322-329)
 //   mode 1: dst[.., c] = norm(x)[c] * sigmoid(norm(x)[c + C/2])   GLU after norm2 / norm1 (hdemucs.py:169, 315)
 //   mode 2: dst = norm(x) (+ skip)              the last decoder has no GELU
-__global__ __launch_bounds__(256) void hd_gn_kernel(const float *__restrict__ x, int64_t R, int C, int G,
+__global__ __launch_bounds__(256) void hd_gn_kernel(const float *__restrict__ x, int64_t Rin, int64_t r0, int64_t R, int C, int G,
                                                     const double *__restrict__ acc, const float *__restrict__ gam,
                                                     const float *__restrict__ bet, int mode, float *__restrict__ dst,
                                                     const float *__restrict__ skip, int64_t total) {
@@ -38,10 +39,10 @@ __global__ __launch_bounds__(256) void hd_gn_kernel(const float *__restrict__ x,
   const int64_t row = idx / Ce;        // (b, r)
   const int64_t b = row / R;
   const int cg = C / G;
-  const double cnt = (double)R * cg;
+  const double cnt = (double)Rin * cg;
   float mean, rstd;
   group_mean_rstd(acc, b * G + c / cg, cnt, 1e-5f, mean, rstd);
-  const float *xp = x + row * C;
+  const float *xp = x + (b * Rin + (row - b * R) + r0) * C;
   float v = (xp[c] - mean) * rstd * gam[c] + bet[c];
   if (mode == 1) {
     float m2, r2;

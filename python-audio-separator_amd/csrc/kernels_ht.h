@@ -773,7 +773,9 @@ __global__ __launch_bounds__(256) void add_kernel(float *__restrict__ y, const f
 // then the centre padding of torch.stft, which frames 2 .. 2+le never touch), window = periodic Hann,
 // normalized=True (x n_fft^-0.5); the Nyquist bin is dropped.  grid = (T, 2, B).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ht_stft_kernel(const float *__restrict__ seg, int64_t L, int hop, int T,
+// Inputs no longer than the right pad are first zero-extended by pad1d (hdemucs.py:21-34: el zeros on the left, up to
+// Lv samples in all) and the reflection runs on that; el = 0, Lv = L otherwise.
+__global__ __launch_bounds__(256) void ht_stft_kernel(const float *__restrict__ seg, int64_t L, int64_t el, int64_t Lv, int hop, int T,
                                                       float *__restrict__ spec, const float *__restrict__ window,
                                                       const float2 *__restrict__ tw, FftPlan p) {
   extern __shared__ float2 lds[];
@@ -784,10 +786,11 @@ __global__ __launch_bounds__(256) void ht_stft_kernel(const float *__restrict__ 
   const int pad = hop / 2 * 3;
   float *fa = reinterpret_cast<float *>(bufA);
   for (int e = threadIdx.x; e < p.n_fft; e += blockDim.x) {
-    int64_t q = (int64_t)t * hop + e - pad;
+    int64_t q = (int64_t)t * hop + e - pad + el;
     if (q < 0) q = -q;
-    if (q >= L) q = 2 * (L - 1) - q;
-    fa[e] = src[q] * window[e];
+    if (q >= Lv) q = 2 * (Lv - 1) - q;
+    q -= el;
+    fa[e] = (q >= 0 && q < L) ? src[q] * window[e] : 0.f;
   }
   float2 *Z = fft_lds<-1>(bufA, bufB, p, tw);
   const int nh = p.nh;

@@ -61,8 +61,9 @@ def main():
     model.eval()
     g = torch.Generator().manual_seed(77)
     out = {}
+    # d, e, f: shorter than nfft / than the reflect pad (pad1d's zero extension, hdemucs.py:21-34), down to one frame;
     # 12000 samples: 47 spectrogram frames (no BLSTM framing); 56000: 219 frames > 200 -> the overlapped-frame BLSTM path
-    for tag, n in (("a", 12000), ("b", 56000), ("c", 5001)):
+    for tag, n in (("a", 12000), ("b", 56000), ("c", 5001), ("d", 877), ("e", 100), ("f", 3)):
         x = torch.randn(1 if tag == "b" else 2, 2, n, generator=g) * 0.3
         with torch.no_grad():
             y = model(x)

@@ -50,9 +50,10 @@ def dm(A):
     return d
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
 def test_forward_golden(dm, g, tag):
-    # a: 47 frames (plain BLSTM); b: 219 frames (overlapped BLSTM frames, demucs.py:41-64); c: odd length, batch 2
+    # a: 47 frames (plain BLSTM); b: 219 frames (overlapped BLSTM frames, demucs.py:41-64); c: odd length, batch 2;
+    # d, e, f: 877 / 100 / 3 samples -- shorter than nfft and than the reflect pad (pad1d's zero extension), 4 / 1 / 1 frames
     y = dm.engine.hd_forward(g[f"x_{tag}"])
     assert y.shape == g[f"y_{tag}"].shape
     assert rel_rms(y, g[f"y_{tag}"]) < TOL, rel_rms(y, g[f"y_{tag}"])
@@ -108,11 +109,6 @@ def test_sharded_halves_match_single_call(dm, g):
     e.hd_fold_dev(mix.data_ptr(), n, chunks.data_ptr(), out.data_ptr(), shifts=2, offsets=offs)
     torch.cuda.synchronize()
     assert rel_rms(out.cpu().numpy(), g["shift"][0]) < TOL
-
-
-def test_short_chunk_is_rejected(dm):
-    with pytest.raises(RuntimeError, match="shorter than nfft"):
-        dm.engine.hd_forward(np.zeros((1, 2, 500), np.float32))
 
 
 def test_unsupported_structure_is_rejected(A):

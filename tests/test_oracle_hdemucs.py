@@ -29,7 +29,7 @@ def test_layer_plan_released_model():
     assert [L["lstm"] for L in Ls] == [False] * 4 + [True] * 2
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
 def test_forward_matches_reference(tag):
     g = np.load(GOLD)
     cfg = small_cfg()
