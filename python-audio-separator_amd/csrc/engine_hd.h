@@ -353,7 +353,7 @@ static int hd_blstm(asx_engine *e, const HdLstm &L, float *hbuf, int B, int T, i
     CHK(ht_linear(e, ih, in, din, rows, b.xp, 8 * H, 0, nullptr, 0, s));
     HIPCHK(hipMemsetAsync(b.hb, 0, (size_t)4 * N * H * 4, s));
     HIPCHK(hipMemsetAsync(b.cst, 0, (size_t)2 * N * H * 4, s));
-    const dim3 grid((unsigned)(H / 16), 2, (unsigned)((N + 63) / 64));
+    const dim3 grid((unsigned)(H / 4), 2, (unsigned)((N + 127) / 128));
     CHK(timed(e, ASX_PROF_CONV1X1, 2.0 * steps * 2.0 * N * 4.0 * H * H, 4.0 * steps * 2.0 * (4.0 * H * H + 10.0 * N * H), s, [&]() {
       for (int st = 0; st < steps; ++st) {
         float *hp = b.hb + (size_t)(st & 1) * 2 * N * H, *hn = b.hb + (size_t)((st + 1) & 1) * 2 * N * H;

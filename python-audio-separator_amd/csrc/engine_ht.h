@@ -57,6 +57,7 @@ struct HtNet {
     std::vector<float *> skf, skt, df, dt;
     double *acc_f, *acc_t, *acc_g, *acc_g2;
     float *rowstat, *mr_g;
+    unsigned *ticket;   // rowstat_reduce_kernel's arrival counters (zero between launches)
   } b;
 };
 
@@ -689,11 +690,13 @@ static int ht_ensure_workspace(asx_engine *e, int B) {
   for (auto &pr : plan) *pr.first = reinterpret_cast<float *>(reinterpret_cast<char *>(n.ws.p) + pr.second);
   // float64 accumulators: per-sample (freq, time) + group-norm groups (max B * F[1])
   const size_t ng = (size_t)B * std::max(n.F[1], 1);
-  CHK(n.acc.ensure((2 * (size_t)B + 2 * ng) * 16));
+  CHK(n.acc.ensure((2 * (size_t)B + 2 * ng) * 16 + (size_t)B * 4));
   b.acc_f = reinterpret_cast<double *>(n.acc.p);
   b.acc_t = b.acc_f + 2 * (size_t)B;
   b.acc_g = b.acc_t + 2 * (size_t)B;
   b.acc_g2 = b.acc_g + 2 * ng;
+  b.ticket = reinterpret_cast<unsigned *>(b.acc_g2 + 2 * ng);
+  HIPCHK(hipMemset(b.ticket, 0, (size_t)B * 4));
   n.ws_batch = B;
   return ASX_OK;
 }
@@ -731,9 +734,14 @@ static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I
     const int64_t M = (int64_t)B * O * I;
     auto fold = [&](int ncols, double count, double *acc, float2 *mr) {
       const int ntile = (ncols + gg_tile_n(ncols) - 1) / gg_tile_n(ncols);   // N tiles of ht_gg's launch choice
+      unsigned gx = (unsigned)((G2 + 15) / 16);
+      if (G2 == 1) {
+        gx = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, R / 4096));
+        if (gx > 1) HIPCHK(hipMemsetAsync(acc, 0, (size_t)B * 16, s));
+      }
       return timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)M * ntile, s, [&]() {
-        hipLaunchKernelGGL(rowstat_reduce_kernel, dim3((unsigned)(G2 > 1 ? (G2 + 63) / 64 : 1), (unsigned)B), dim3(256), 0, s,
-                           reinterpret_cast<const float2 *>(n.b.rowstat), M, ntile, (int64_t)O * I, G2, R, count, 1e-5f, acc, mr);
+        hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, reinterpret_cast<const float2 *>(n.b.rowstat), M,
+                           ntile, (int64_t)O * I, G2, R, count, 1e-5f, acc, mr, n.b.ticket);
       });
     };
     HtFuse f1;

@@ -100,58 +100,61 @@ __global__ __launch_bounds__(256) void hd_lstm_unframe_kernel(const float *__res
 //   gates = xp[t_dir][n][dir] + W_hh[dir] h_prev[dir][n];  c = f*c + i*g;  h = o * tanh(c)
 // xp [steps*N, 2, 4H] (input projection + b_ih + b_hh, one GEMM for all steps), whh [2, 4H, H], hprev / hnext / cst
 // [2, N, H], out [steps*N, 2H].  Direction 0 handles step s, direction 1 step steps-1-s.
-// grid = (H / 16, 2, ceil(N / 64)): a workgroup owns 16 hidden units (64 gate rows) x 64 sequences.
+// grid = (H / 4, 2, ceil(N / 128)): a workgroup owns 4 hidden units -- 16 gate rows, the M side of v_mfma_f32_16x16x4_f32
+// with row = unit*4 + gate, so that a lane's four accumulators are the four gates of one (unit, sequence) -- for up to
+// 8 tiles of 16 sequences; its 4 waves split K, fragments come straight from L2 as 16-byte rows (the k order inside a
+// 16-wide chunk is permuted identically for both operands), partial sums meet in LDS.  The recurrence is a chain of
+// tiny GEMMs (N x 4H x H per direction); the kernel is latency-bound, so it keeps every load of a wave independent.
 __global__ __launch_bounds__(256) void hd_lstm_step_kernel(const float *__restrict__ xp, const float *__restrict__ whh,
                                                            const float *__restrict__ hprev, float *__restrict__ hnext,
                                                            float *__restrict__ cst, float *__restrict__ out, int N, int H,
                                                            int s, int steps) {
-  __shared__ float Wt[64][65];
-  __shared__ float Ht[64][65];
-  const int u0 = blockIdx.x * 16, dir = blockIdx.y, n0 = blockIdx.z * 64;
-  const int tid = threadIdx.x;
-  const int r = tid & 63, sg = tid >> 6;
+  __shared__ f32x4 red[4][8][64];
+  const int u0 = blockIdx.x * 4, dir = blockIdx.y, nb = blockIdx.z * 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kq = lane >> 4;
   const int t = dir ? steps - 1 - s : s;
-  const float *W = whh + (int64_t)dir * 4 * H * H;
-  const float *hp = hprev + (int64_t)dir * N * H;
-  float acc[16];
+  const int ntile = (N - nb + 15) / 16 < 8 ? (N - nb + 15) / 16 : 8;
+  const int kc = ((H / 16 + 3) / 4) * 16;
+  const int k_lo = wave * kc, k_hi = (k_lo + kc < H) ? k_lo + kc : H;
+  const float *wrow = whh + ((int64_t)dir * 4 * H + (int64_t)(m & 3) * H + u0 + (m >> 2)) * H + kq * 4;
+  const float *hbase = hprev + (int64_t)dir * N * H + kq * 4;
+  f32x4 acc[8];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-  for (int k0 = 0; k0 < H; k0 += 64) {
-    // tiles: Wt[row][kk] = W[(row/16)*H + u0 + row%16][k0 + kk], Ht[nn][kk] = hprev[n0 + nn][k0 + kk]
-    for (int i = tid; i < 64 * 64; i += 256) {
-      const int row = i >> 6, kk = i & 63;
-      const int k = k0 + kk;
-      Wt[row][kk] = k < H ? W[((int64_t)(row >> 4) * H + u0 + (row & 15)) * H + k] : 0.f;
-      const int n = n0 + row;
-      Ht[row][kk] = (k < H && n < N) ? hp[(int64_t)n * H + k] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < 64; ++kk) {
-      const float w = Wt[r][kk];
+  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = k_lo; k < k_hi; k += 16) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + k);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] += w * Ht[sg * 16 + j][kk];
+    for (int j = 0; j < 8; ++j) {
+      if (j < ntile) {
+        int n = nb + j * 16 + m;
+        if (n >= N) n = N - 1;   // padding columns: computed, never stored
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(hbase + (int64_t)n * H + k);
+        acc[j] = ASX_MFMA(a.x, b.x, acc[j]);
+        acc[j] = ASX_MFMA(a.y, b.y, acc[j]);
+        acc[j] = ASX_MFMA(a.z, b.z, acc[j]);
+        acc[j] = ASX_MFMA(a.w, b.w, acc[j]);
+      }
     }
-    __syncthreads();
   }
-  // gate pre-activations of (sequence, gate row) through LDS, then the cell update per (sequence, unit)
 #pragma unroll
-  for (int j = 0; j < 16; ++j) Ht[sg * 16 + j][r] = acc[j];
+  for (int j = 0; j < 8; ++j)
+    if (j < ntile) red[wave][j][lane] = acc[j];
   __syncthreads();
-  for (int i = tid; i < 64 * 16; i += 256) {
-    const int nn = i >> 4, u = i & 15;
-    const int n = n0 + nn;
+  for (int i = threadIdx.x; i < ntile * 64; i += 256) {
+    const int j = i >> 6, l = i & 63;
+    const int n = nb + j * 16 + (l & 15), u = u0 + (l >> 4);
     if (n >= N) continue;
-    const float *xr = xp + (((int64_t)t * N + n) * 2 + dir) * 4 * H + u0 + u;
-    const float gi = Ht[nn][u] + xr[0], gf = Ht[nn][16 + u] + xr[H], gg = Ht[nn][32 + u] + xr[2 * H],
-                go = Ht[nn][48 + u] + xr[3 * H];
+    const f32x4 g = (red[0][j][l] + red[1][j][l]) + (red[2][j][l] + red[3][j][l]);
+    const float *xr = xp + (((int64_t)t * N + n) * 2 + dir) * 4 * H + u;
+    const float gi = g.x + xr[0], gf = g.y + xr[H], gg = g.z + xr[2 * H], go = g.w + xr[3 * H];
     const float ig = 1.0f / (1.0f + expf(-gi)), fg = 1.0f / (1.0f + expf(-gf)), og = 1.0f / (1.0f + expf(-go));
-    const int64_t si = ((int64_t)dir * N + n) * H + u0 + u;
+    const int64_t si = ((int64_t)dir * N + n) * H + u;
     const float c = fg * cst[si] + ig * tanhf(gg);
     cst[si] = c;
     const float hv = og * tanhf(c);
     hnext[si] = hv;
-    out[((int64_t)t * N + n) * 2 * H + dir * H + u0 + u] = hv;
+    out[((int64_t)t * N + n) * 2 * H + dir * H + u] = hv;
   }
 }
 
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(256) void hd_lstm_step_kernel(const float *__restri
 template <int DH>
 __global__ __launch_bounds__(128) void hd_local_attn_kernel(const float *__restrict__ qkvd, int ld, int T, int H,
                                                             float *__restrict__ out) {
-  __shared__ float Ks[32][DH];
-  __shared__ float Cs[32][DH];
+  __shared__ __attribute__((aligned(16))) float Ks[32][DH];
+  __shared__ __attribute__((aligned(16))) float Cs[32][DH];
   const int head = blockIdx.y, b = blockIdx.z;
   const int s = blockIdx.x * 128 + threadIdx.x;
   const bool live = s < T;
@@ -209,7 +212,10 @@ __global__ __launch_bounds__(128) void hd_local_attn_kernel(const float *__restr
       const int t = t0 + tt;
       float sc = 0.f;
 #pragma unroll
-      for (int c = 0; c < DH; ++c) sc += q[c] * Ks[tt][c];
+      for (int c = 0; c < DH; c += 4) {
+        const float4 kv = *reinterpret_cast<const float4 *>(&Ks[tt][c]);
+        sc += (q[c] * kv.x + q[c + 1] * kv.y) + (q[c + 2] * kv.z + q[c + 3] * kv.w);
+      }
       const int d = t > s ? t - s : s - t;
       sc -= (float)d * D;
       if (t == s) sc = -100.0f;
@@ -223,7 +229,13 @@ __global__ __launch_bounds__(128) void hd_local_attn_kernel(const float *__restr
       const float p = expf(sc - m);
       l += p;
 #pragma unroll
-      for (int c = 0; c < DH; ++c) acc[c] += p * Cs[tt][c];
+      for (int c = 0; c < DH; c += 4) {
+        const float4 cv = *reinterpret_cast<const float4 *>(&Cs[tt][c]);
+        acc[c] += p * cv.x;
+        acc[c + 1] += p * cv.y;
+        acc[c + 2] += p * cv.z;
+        acc[c + 3] += p * cv.w;
+      }
     }
   }
   if (live) {
