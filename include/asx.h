@@ -308,7 +308,7 @@ typedef struct asx_hd_config {
   int32_t samplerate;
   int32_t segment_samples;                   /* int(samplerate * segment): the split length of apply_model */
   float freq_emb_scale;                      /* freq_emb (0.2); 0 = no embedding */
-  int32_t max_batch;                         /* equal-length chunks per forward batch (0 = 4) */
+  int32_t max_batch;                         /* equal-length chunks per forward batch (0 = 16) */
 } asx_hd_config;
 int asx_hd_begin(asx_engine *e, const asx_hd_config *cfg);
 int asx_hd_commit(asx_engine *e);

@@ -372,7 +372,7 @@ static int hd_blstm(asx_engine *e, const HdLstm &L, float *hbuf, int B, int T, i
 
 template <int DH>
 static void hd_launch_attn(const float *qkvd, int ld, int T, int H, float *out, int B, hipStream_t s) {
-  hipLaunchKernelGGL((hd_local_attn_kernel<DH>), dim3((unsigned)((T + 127) / 128), 4, (unsigned)B), dim3(128), 0, s, qkvd, ld, T, H, out);
+  hipLaunchKernelGGL((hd_local_attn_kernel<DH>), dim3((unsigned)((T + 63) / 64), 4, (unsigned)B), dim3(64), 0, s, qkvd, ld, T, H, out);
 }
 
 // LocalState in place on hbuf [B, T, H] (demucs.py:197-221)
@@ -383,19 +383,40 @@ static int hd_local_state(asx_engine *e, const HdAttn &A, float *hbuf, int B, in
   CHK(ht_linear(e, A.qkvd, hbuf, H, M, b.qkvd, ld, 0, nullptr, 0, s));
   int bad = 0;
   CHK(timed(e, ASX_PROF_CONV1X1, 4.0 * B * 4.0 * (double)T * T * dh, 4.0 * (double)M * (ld + H), s, [&]() {
-    switch (dh) {
+    if (dh % 16 == 0 && (dh <= 64 || dh == 96)) {
+      // the flash attention of the v4 transformer (kernels_ht.h) with the per-query decay slope and the -100 diagonal
+      MhaArgs a{};
+      a.q = b.qkvd;
+      a.k = b.qkvd + H;
+      a.v = b.qkvd + 2 * H;
+      a.out = b.att;
+      a.ldq = a.ldk = a.ldv = ld;
+      a.ldo = H;
+      a.nq = a.nk = T;
+      a.scale = 1.0f / sqrtf((float)dh);
+      static const int attn_exact = getenv("ASX_ATTN_EXACT") != nullptr;
+      a.exact = attn_exact;
+      a.decay = b.qkvd + 3 * H;
+      a.ldd = ld;
+      const dim3 grid((unsigned)((T + 63) / 64), 4, (unsigned)B);
+      switch (dh / 16) {
+        case 1: hipLaunchKernelGGL((mha_kernel<1, true>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((mha_kernel<2, true>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((mha_kernel<3, true>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((mha_kernel<4, true>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((mha_kernel<6, true>), grid, dim3(256), 0, s, a); break;
+      }
+      return;
+    }
+    switch (dh) {   // narrow heads: one thread per query
       case 4: hd_launch_attn<4>(b.qkvd, ld, T, H, b.att, B, s); break;
       case 8: hd_launch_attn<8>(b.qkvd, ld, T, H, b.att, B, s); break;
-      case 16: hd_launch_attn<16>(b.qkvd, ld, T, H, b.att, B, s); break;
+      case 12: hd_launch_attn<12>(b.qkvd, ld, T, H, b.att, B, s); break;
       case 24: hd_launch_attn<24>(b.qkvd, ld, T, H, b.att, B, s); break;
-      case 32: hd_launch_attn<32>(b.qkvd, ld, T, H, b.att, B, s); break;
-      case 48: hd_launch_attn<48>(b.qkvd, ld, T, H, b.att, B, s); break;
-      case 64: hd_launch_attn<64>(b.qkvd, ld, T, H, b.att, B, s); break;
-      case 96: hd_launch_attn<96>(b.qkvd, ld, T, H, b.att, B, s); break;
       default: bad = 1;
     }
   }));
-  REQUIRE(!bad, "LocalState head dim %d is not built (4, 8, 16, 24, 32, 48, 64, 96)", dh);
+  REQUIRE(!bad, "LocalState head dim %d is not built (4, 8, 12, 24 and multiples of 16 up to 64, 96)", dh);
   return ht_linear(e, A.proj, b.att, H, M, hbuf, H, 0, hbuf, H, s);
 }
 
@@ -643,7 +664,9 @@ static int hd_segments_dev(asx_engine *e, const float *mix_dev, int64_t N, const
   std::vector<int> order;
   for (int k = k0; k < k1; ++k) order.push_back(k);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p.clen[a] > p.clen[b]; });
-  const int maxB = h.cfg.max_batch > 0 ? h.cfg.max_batch : 4;
+  // 16: the BLSTM recurrences cost the same 200 steps whatever the batch, so the equal-length chunks of a song go together
+  // (4-min song, 44-s chunks: 730 -> 789x real time against batches of 4; ~2.2 GB of workspace per 44-s chunk)
+  const int maxB = h.cfg.max_batch > 0 ? h.cfg.max_batch : 16;
   CHK(h.starts.ensure((size_t)maxB * 8));
   size_t i = 0;
   while (i < order.size()) {

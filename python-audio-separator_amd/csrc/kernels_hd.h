@@ -119,6 +119,20 @@ __global__ __launch_bounds__(256) void hd_lstm_step_kernel(const float *__restri
   const int k_lo = wave * kc, k_hi = (k_lo + kc < H) ? k_lo + kc : H;
   const float *wrow = whh + ((int64_t)dir * 4 * H + (int64_t)(m & 3) * H + u0 + (m >> 2)) * H + kq * 4;
   const float *hbase = hprev + (int64_t)dir * N * H + kq * 4;
+  // epilogue operands of this thread's (sequence, unit) items: issued before the GEMM so that their HBM latency (xp is
+  // streamed once) hides behind it
+  float xin[2][4], cprev[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = threadIdx.x + q * 256;
+    const int j = i >> 6, l = i & 63;
+    const int n = nb + j * 16 + (l & 15), u = u0 + (l >> 4);
+    const bool ok = j < ntile && n < N;
+    const float *xr = xp + (((int64_t)t * N + (ok ? n : 0)) * 2 + dir) * 4 * H + u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xin[q][g] = ok ? xr[g * H] : 0.f;
+    cprev[q] = ok ? cst[((int64_t)dir * N + n) * H + u] : 0.f;
+  }
   f32x4 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -141,16 +155,17 @@ __global__ __launch_bounds__(256) void hd_lstm_step_kernel(const float *__restri
   for (int j = 0; j < 8; ++j)
     if (j < ntile) red[wave][j][lane] = acc[j];
   __syncthreads();
-  for (int i = threadIdx.x; i < ntile * 64; i += 256) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = threadIdx.x + q * 256;
     const int j = i >> 6, l = i & 63;
     const int n = nb + j * 16 + (l & 15), u = u0 + (l >> 4);
-    if (n >= N) continue;
+    if (j >= ntile || n >= N) continue;
     const f32x4 g = (red[0][j][l] + red[1][j][l]) + (red[2][j][l] + red[3][j][l]);
-    const float *xr = xp + (((int64_t)t * N + n) * 2 + dir) * 4 * H + u;
-    const float gi = g.x + xr[0], gf = g.y + xr[H], gg = g.z + xr[2 * H], go = g.w + xr[3 * H];
+    const float gi = g.x + xin[q][0], gf = g.y + xin[q][1], gg = g.z + xin[q][2], go = g.w + xin[q][3];
     const float ig = 1.0f / (1.0f + expf(-gi)), fg = 1.0f / (1.0f + expf(-gf)), og = 1.0f / (1.0f + expf(-go));
     const int64_t si = ((int64_t)dir * N + n) * H + u;
-    const float c = fg * cst[si] + ig * tanhf(gg);
+    const float c = fg * cprev[q] + ig * tanhf(gg);
     cst[si] = c;
     const float hv = og * tanhf(c);
     hnext[si] = hv;
@@ -163,15 +178,16 @@ __global__ __launch_bounds__(256) void hd_lstm_step_kernel(const float *__restri
 //   score[t] = k_t . q_s / sqrt(dh) - |t - s| * D_s,   D_s = 1/4 * sum_f (f + 1) * sigmoid(decay_f[s]),   score[s] = -100
 //   out[s] = sum_t softmax_t(score)[t] * content_t
 // qkvd [B*T, ld]: query | key | content (H channels each, head h owns [h*DH, (h+1)*DH)) | decay logits [heads*4].
-// One thread per query, keys staged through LDS in tiles of 32; grid = (ceil(T / 128), heads, B), block 128.
+// One thread per query, keys staged through LDS in tiles of 32; grid = (ceil(T / 64), heads, B), block 64: one wave per
+// workgroup puts two or more workgroups on every CU at the chunk sizes of apply_model (T = 1895: 480 workgroups).
 // ---------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(128) void hd_local_attn_kernel(const float *__restrict__ qkvd, int ld, int T, int H,
+__global__ __launch_bounds__(64) void hd_local_attn_kernel(const float *__restrict__ qkvd, int ld, int T, int H,
                                                             float *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) float Ks[32][DH];
   __shared__ __attribute__((aligned(16))) float Cs[32][DH];
   const int head = blockIdx.y, b = blockIdx.z;
-  const int s = blockIdx.x * 128 + threadIdx.x;
+  const int s = blockIdx.x * 64 + threadIdx.x;
   const bool live = s < T;
   const float *base = qkvd + (int64_t)b * T * ld;
   float q[DH], acc[DH];
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(128) void hd_local_attn_kernel(const float *__restr
   float m = -3.0e38f, l = 0.f;
   for (int t0 = 0; t0 < T; t0 += 32) {
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * DH; i += 128) {
+    for (int i = threadIdx.x; i < 32 * DH; i += 64) {
       const int tt = i / DH, c = i - tt * DH;
       const int t = t0 + tt;
       float kv = 0.f, cv = 0.f;

@@ -484,13 +484,19 @@ struct MhaArgs {
   int nq, nk;
   float scale;
   int exact;   // 1: libm expf in the softmax; 0: hardware exp
+  // LocalState of Demucs v3 (demucs.py:197-221; nq == nk): decay logits [B*nq, ldd] (4 per head) give every query a
+  // slope D = 1/4 * sum_f (f + 1) * sigmoid(logit_f); score -= |key - query| * D, and the diagonal is set to -100
+  const float *decay;
+  int64_t ldd;
 };
 
-template <int DT>
+template <int DT, bool DECAY = false>
 __global__ __launch_bounds__(256) void mha_kernel(MhaArgs a) {
   constexpr int DH = 16 * DT, QS = DH + 2, VS = DH + 4, C4 = DH / 4;
-  __shared__ float lds[64 * QS * 2 + 64 * VS];
-  float *Qs = lds, *Ks = lds + 64 * QS, *Vs = lds + 128 * QS;
+  // Q is staged through the K tile's space (its fragments move to registers before the first K tile is written):
+  // head dim 96 fits the 64 KB of static LDS
+  __shared__ float lds[64 * QS + 64 * VS];
+  float *Qs = lds, *Ks = lds, *Vs = lds + 64 * QS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -539,6 +545,14 @@ __global__ __launch_bounds__(256) void mha_kernel(MhaArgs a) {
   float bqr[DH / 4];
 #pragma unroll
   for (int kk = 0; kk < DH / 4; ++kk) bqr[kk] = Qs[(wave * 16 + li) * QS + 4 * kk + lk];
+  const int qi = q0 + wave * 16 + li;
+  float slope = 0.f;
+  if (DECAY && qi < a.nq) {
+    const float *dr = a.decay + ((int64_t)b * a.nq + qi) * a.ldd + h * 4;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) slope += (float)(f + 1) * (1.0f / (1.0f + expf(-dr[f])));
+    slope *= 0.25f;
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * 64;
     __syncthreads();   // previous tile fully consumed
@@ -576,7 +590,11 @@ __global__ __launch_bounds__(256) void mha_kernel(MhaArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = k0 + mt * 16 + 4 * lk + r;
-        const float s = (key < a.nk) ? st[mt][r] * a.scale : -INFINITY;
+        float s = (key < a.nk) ? st[mt][r] * a.scale : -INFINITY;
+        if (DECAY && key < a.nk) {
+          const int d = key > qi ? key - qi : qi - key;
+          s = d == 0 ? -100.0f : s - (float)d * slope;
+        }
         st[mt][r] = s;
         mx = fmaxf(mx, s);
       }

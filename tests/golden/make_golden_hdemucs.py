@@ -49,6 +49,11 @@ def small_cfg():
     return HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, samplerate=8000, segment=2)
 
 
+def wide_cfg():
+    # dconv_comp 1: DConv hidden sizes 64 / 128 on the two inner levels -> LocalState head dims 16 / 32 (the MFMA attention path)
+    return HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, dconv_comp=1, samplerate=8000, segment=2)
+
+
 def main():
     cfg = small_cfg()
     model = HDemucs(**cfg.ctor_kwargs())
@@ -70,6 +75,16 @@ def main():
         out[f"x_{tag}"] = x.numpy()
         out[f"y_{tag}"] = y.numpy().astype(np.float32)
         print(tag, x.shape, y.shape, float(y.abs().mean()))
+    wc = wide_cfg()
+    wm = HDemucs(**wc.ctor_kwargs())
+    wsd = make_hd_state(wc, 22)
+    assert {k: tuple(v.shape) for k, v in wm.state_dict().items()} == {k: tuple(v.shape) for k, v in wsd.items()}
+    wm.load_state_dict(wsd)
+    wm.eval()
+    xw = torch.randn(1, 2, 20000, generator=g) * 0.3
+    with torch.no_grad():
+        out["x_w"], out["y_w"] = xw.numpy(), wm(xw).numpy().astype(np.float32)
+    print("w", xw.shape, float(np.abs(out["y_w"]).mean()))
     # apply_model on 2.3 segments: every chunk runs at its own length (no valid_length), the shift draws are recorded
     mix = torch.randn(1, 2, int(2.3 * cfg.segment * cfg.samplerate) + 77, generator=g) * 0.3
     out["mix"] = mix.numpy()

@@ -59,6 +59,17 @@ def test_forward_golden(dm, g, tag):
     assert rel_rms(y, g[f"y_{tag}"]) < TOL, rel_rms(y, g[f"y_{tag}"])
 
 
+def test_forward_wide_hidden_golden(A, g):
+    # DConv hidden 64 / 128 -> LocalState head dims 16 / 32: the MFMA flash-attention path with the decay slope, 79 frames
+    oc = H.HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, dconv_comp=1, samplerate=8000, segment=2)
+    hc = A.HDConfig(sources=tuple(oc.sources), channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, dconv_comp=1,
+                    samplerate=8000, segment=2)
+    d = A.DemucsDemixer({"torch_device": 0}, {}, models=[(hc, H.make_hd_state(oc, 22))])
+    d._load(0)
+    y = d.engine.hd_forward(g["x_w"])
+    assert rel_rms(y, g["y_w"]) < TOL, rel_rms(y, g["y_w"])
+
+
 def test_forward_lengths_share_one_engine(dm, g):
     # the workspace is re-planned per length; going back to an earlier length gives the same numbers (float64 atomics in
     # the statistics make the last bits order-dependent)

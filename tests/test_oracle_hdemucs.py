@@ -55,3 +55,11 @@ def test_apply_model_matches_reference(mode):
     ref = g[mode]
     err = np.abs(np.asarray(y) - ref).max() / np.abs(ref).max()
     assert err < 2e-5, err
+
+
+def test_forward_wide_hidden_matches_reference():
+    g = np.load(GOLD)
+    cfg = HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, dconv_comp=1, samplerate=8000, segment=2)
+    y = hd_forward(g["x_w"], make_hd_state(cfg, 22), cfg)
+    err = np.abs(y - g["y_w"]).max() / np.abs(g["y_w"]).max()
+    assert err < 2e-5, err

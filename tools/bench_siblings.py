@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the sibling segment loops (BASELINE.json configs 0, 2, 3 and MDX23C) in bench.py's JSON schema.
 
-    python tools/bench_siblings.py [--workloads vr,htdemucs,roformer,mdx23c] [--seconds 240] [--steps 3] [--cpu 1]
+    python tools/bench_siblings.py [--workloads vr,htdemucs,hdemucs,roformer,mdx23c] [--seconds 240] [--steps 3] [--cpu 1]
 
 One JSON line per workload: whole-song RTF with the input resident in HBM, the roofline fraction of the kernel class
 that dominates the step (in-engine hipEvent profile), and the CPU oracle timed on a bounded sample beside it.
@@ -210,6 +210,47 @@ def run_mdx23c(args):
                  "net_tflops_per_s": round(eng.v3_flops(plan["n_chunks"]) / dt / 1e12, 1)})
 
 
+def run_hdemucs(args):
+    from oracle import hdemucs_oracle as H
+    oc = H.HDConfig(segment=44)
+    sd = H.make_hd_state(oc, 0)
+    hc = A.HDConfig(segment=44)
+    eng = A.Engine(A.MDXConfig(n_fft=4096, hop_length=1024, dim_f=2048, segment_size=8))
+    eng.load_hd(hc, sd)
+    n = int(SR * args.seconds)
+    mixh = synth(n)
+    mix = torch.from_numpy(mixh).cuda()
+    out = torch.empty((4, 2, n), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    offs = [11025, 3000]
+    step = lambda: eng.hd_demix_dev(mix.data_ptr(), n, out.data_ptr(), shifts=2, offsets=offs, flags=3, stream=st)  # noqa: E731
+    dt = timed(step, args.steps, args.warmup)
+    roof, kms = dominant(eng, step, {"conv3x3": "gg_kernel (rewrite 3x3 / DConv / 1x1)", "tdf": "tdf_dma_kernel (LSTM input / LocalState projections)",
+                                     "conv1x1": "hd_lstm_step_kernel + hd_local_attn_kernel", "down": "gg_kernel (k8/s4 convs)",
+                                     "up": "gg_kernel (transposed convs)"})
+    TL = hc.segment_samples
+    lens = []
+    for o in offs:
+        vl = n + 22050 - o
+        lens += [min(vl - k, TL) for k in range(0, vl, int(0.75 * TL))]
+    flops = sum(eng.hd_flops(l) for l in lens)
+    cpu = None
+    if args.cpu:
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        cs = 12.0
+        m = mixh[:, : int(SR * cs)]
+        t0 = time.perf_counter()
+        want = H.demix_hdemucs(m, sd, oc, shifts=1, overlap=0.25, offsets=[11025])
+        cdt = time.perf_counter() - t0
+        got = eng.hd_demix(m, shifts=1, offsets=[11025], overlap=0.25, standardize=True, swap01=True)
+        cpu = {"value": round(cs / cdt / 2, 3), "unit": "audio-s/wall-s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{cs:g} s with shifts=1 ({cdt:.1f} s wall), halved to the shifts=2 rate of the GPU line; torch-CPU oracle",
+               "parity_rel_rms": rel_rms(got, want)}
+    return line("hdemucs_mmi layout (Demucs v3: 83.6 M params, 4 sources, nfft 4096, depth 6, BLSTM + LocalState on the two inner levels, 44-s chunks), "
+                "shifts=2, overlap 0.25, synthetic weights", args.seconds, dt, args.steps, args.warmup, roof, kms, cpu,
+                {"chunk_forwards": len(lens), "gflop_per_song": round(flops / 1e9, 1), "net_tflops_per_s": round(flops / dt / 1e12, 1)})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="vr,htdemucs,roformer,mdx23c")
@@ -219,7 +260,7 @@ def main():
     ap.add_argument("--cpu", type=int, default=1)
     args = ap.parse_args()
     torch.cuda.set_device(0)
-    fns = {"vr": run_vr, "htdemucs": run_htdemucs, "roformer": run_roformer, "mdx23c": run_mdx23c}
+    fns = {"vr": run_vr, "htdemucs": run_htdemucs, "hdemucs": run_hdemucs, "roformer": run_roformer, "mdx23c": run_mdx23c}
     for w in args.workloads.split(","):
         print(json.dumps(fns[w](args)), flush=True)
 
