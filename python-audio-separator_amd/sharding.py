@@ -110,21 +110,25 @@ class DemucsAdapter(_SiblingAdapter):
     """apply_model + demix_demucs (apply.py:124-260, demucs_separator.py:162-194); offsets = the shift draws, identical
     on every rank."""
 
-    def __init__(self, engine, shifts=0, offsets=None, overlap=0.25, flags=3):
+    def __init__(self, engine, shifts=0, offsets=None, overlap=0.25, flags=3, v3=False):
+        """v3: the engine holds a Demucs v3 HDemucs (load_hd) instead of an HTDemucs; same list-of-chunk-forwards split,
+        rows of the chunk slab hold each chunk's own length."""
         super().__init__(engine)
         self.kw = dict(shifts=shifts, offsets=offsets, overlap=overlap)
         self.flags = flags
-        self.stems = self.out_stems = len(engine.ht_cfg.sources)
+        self.stems = self.out_stems = len((engine.hd_cfg if v3 else engine.ht_cfg).sources)
+        self._plan, self._segments, self._fold = ((engine.hd_plan, engine.hd_segments_dev, engine.hd_fold_dev) if v3 else
+                                                  (engine.ht_plan, engine.ht_segments_dev, engine.ht_fold_dev))
 
     def plan(self, n):
-        return self.engine.ht_plan(n, **self.kw)
+        return self._plan(n, **self.kw)
 
     def demix_chunks(self, mix, n, k0, k1, out):
-        self.engine.ht_segments_dev(mix.data_ptr(), n, k0, k1, out.data_ptr(), flags=self.flags, stream=self._stream(), **self.kw)
+        self._segments(mix.data_ptr(), n, k0, k1, out.data_ptr(), flags=self.flags, stream=self._stream(), **self.kw)
 
     def finalize(self, chunks, n, out):
-        self.engine.ht_fold_dev(mix_ptr=self._mix.data_ptr(), n=n, chunks_ptr=chunks.data_ptr(), out_ptr=out.data_ptr(), flags=self.flags,
-                                stream=self._stream(), **self.kw)
+        self._fold(mix_ptr=self._mix.data_ptr(), n=n, chunks_ptr=chunks.data_ptr(), out_ptr=out.data_ptr(), flags=self.flags,
+                   stream=self._stream(), **self.kw)
 
     def bind_mix(self, mix):          # the fold re-derives the standardisation statistics from the mix
         self._mix = mix

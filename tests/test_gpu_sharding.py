@@ -82,3 +82,25 @@ def test_demucs_halves(A):
     ad = DemucsAdapter(eng, shifts=2, offsets=offs, overlap=0.25, flags=3)
     assert np.array_equal(sharded_demix(ad, mix).cpu().numpy(), want)
     assert np.array_equal(_split_run(ad, mix, torch, 5), want)
+
+
+def test_hdemucs_halves(A):
+    # Demucs v3: the chunk forwards of a call (each at its own length) split across ranks exactly like the v4 segments
+    import torch
+    from oracle import hdemucs_oracle as H
+    from audio_separator_amd.sharding import DemucsAdapter, sharded_demix
+    oc = H.HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, samplerate=8000, segment=2)
+    hc = A.HDConfig(sources=tuple(oc.sources), channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, samplerate=8000,
+                    segment=2, max_batch=2)
+    eng = A.Engine(A.MDXConfig(n_fft=1024, hop_length=256, dim_f=512, segment_size=8))
+    eng.load_hd(hc, H.make_hd_state(oc, 21))
+    mixh = (0.3 * np.random.default_rng(6).standard_normal((2, 50011)) + 0.01).astype(np.float32)
+    offs = [1234, 77]
+    want = eng.hd_demix(mixh, shifts=2, offsets=offs, overlap=0.25, standardize=True, swap01=True)
+    mix = torch.from_numpy(mixh).cuda()
+    ad = DemucsAdapter(eng, shifts=2, offsets=offs, overlap=0.25, flags=3, v3=True)
+
+    def close(a, b):   # float64 atomics in the statistics: the last bit may depend on the batch composition
+        return np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)) < 1e-6 * np.sqrt(np.mean(b.astype(np.float64) ** 2))
+    assert close(sharded_demix(ad, mix).cpu().numpy(), want)
+    assert close(_split_run(ad, mix, torch, 3), want)
