@@ -74,9 +74,6 @@ class DemucsDemixer:
         if self.segment_size not in ("Default", None):
             # demucs_segments (apply.py:263-300) never changes the model's segment (`segment` stays None on every path)
             pass
-        if not self.segments_enabled:
-            raise NotImplementedError("segments_enabled=False (split=False) is only defined for inputs up to one segment; "
-                                      "use the engine's ht_forward for that")
         dev = common_config.get("torch_device", 0)
         self.device = getattr(dev, "index", dev) or 0
         self.models = list(models)
@@ -112,7 +109,7 @@ class DemucsDemixer:
             raise ValueError(f"Expected a 2-channel audio signal, but got shape {mix.shape}")
         est = None
         totals = np.zeros(len(self.models[0][0].sources), np.float64)
-        single = len(self.models) == 1
+        single = len(self.models) == 1 and self.segments_enabled   # split=False combines on the host like a bag
         for i in range(len(self.models)):
             self._load(i)
             hc = self.models[i][0]
@@ -137,9 +134,38 @@ class DemucsDemixer:
         est[[0, 1]] = est[[1, 0]]
         return est
 
+    def _apply_whole(self, std_mix: np.ndarray, hc, offs) -> np.ndarray:
+        """apply_model(..., split=False) (apply.py:198-214, 251-260): one forward per shift over the whole (shifted) track.
+        HDemucs runs it at its own length; HTDemucs centres it in a training-length window (valid_length) and trims."""
+        n = std_mix.shape[1]
+        max_shift = int(0.5 * hc.samplerate) if self.shifts else 0
+        padded = np.pad(std_mix, ((0, 0), (max_shift, max_shift)))
+        out = None
+        for off in (offs if self.shifts else [0]):
+            length = n + max_shift - off
+            view = padded[:, off:off + length]
+            if isinstance(hc, HDConfig):
+                y = self.engine.hd_forward(view[None])[0]
+            else:
+                tl = hc.segment_samples
+                if length > tl:
+                    raise ValueError(f"segments_enabled=False: {length} samples exceed the model's training length {tl} "
+                                     "(the reference fails inside HTDemucs for such inputs)")
+                delta = tl - length
+                start = off - delta // 2                      # TensorChunk.padded: real context from the padded mix
+                lo, hi = max(0, start), min(padded.shape[1], start + tl)
+                win = np.zeros((2, tl), np.float32)
+                win[:, lo - start:hi - start] = padded[:, lo:hi]
+                y = self.engine.ht_forward(win[None])[0][..., delta // 2: delta // 2 + length]
+            y = y[..., max_shift - off:]
+            out = y if out is None else out + y
+        return out / max(self.shifts, 1)
+
     def _bag_member(self, mix, offs):
         import torch
         t = torch.from_numpy(mix)
         ref = t.mean(0)
         std_mix = ((t - ref.mean()) / ref.std()).numpy()
+        if not self.segments_enabled:
+            return self._apply_whole(std_mix, self.models[self._loaded][0], offs)
         return self._demix(std_mix, shifts=self.shifts, offsets=offs, overlap=self.overlap)

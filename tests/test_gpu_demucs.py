@@ -132,3 +132,18 @@ def test_error_paths(A):
                      segment=Fraction(1, 1))   # head dim 12
     with pytest.raises(A.AsxError):
         demixer(A, bad, 1)._load(0)
+
+
+def test_segments_disabled_matches_oracle(A):
+    # apply_model(split=False): the shifted track is centred in a training-length window (valid_length) and trimmed; longer
+    # inputs fail like the reference (HTDemucs.valid_length raises)
+    oc = ocfg_a()
+    rng = np.random.default_rng(9)
+    mix = (rng.standard_normal((2, 3300)) * 0.2 + 0.01).astype(np.float32)
+    offs = [[2100, 40]]
+    dm = demixer(A, oc, 11, shifts=2, segments_enabled=False)
+    out = dm.demix(mix, offsets=offs)
+    ref = D.demix_demucs(mix, D.make_ht_state(oc, 11), oc, shifts=2, split=False, offsets=offs[0])
+    assert rel_rms(out, ref) < TOL, rel_rms(out, ref)
+    with pytest.raises(ValueError, match="training length"):
+        dm.demix(np.zeros((2, 9000), np.float32) + mix[:, :1], offsets=offs)

@@ -128,3 +128,15 @@ def test_unsupported_structure_is_rejected(A):
         A.hdconfig_from_kwargs(dict(sources=list(oc.sources), depth=6, dconv_lstm=5))
     with pytest.raises(NotImplementedError):
         A.hdconfig_from_kwargs(dict(sources=list(oc.sources), hybrid_old=True))
+
+
+def test_segments_disabled_matches_oracle(A):
+    # segments_enabled=False -> apply_model(split=False): one forward per shift over the whole shifted track (apply.py:251-260)
+    oc = ocfg()
+    rng = np.random.default_rng(8)
+    mix = (rng.standard_normal((2, 23011)) * 0.2 - 0.02).astype(np.float32)
+    offs = [[3999, 5]]
+    d = demixer(A, shifts=2, overlap=0.25, segments_enabled=False)
+    out = d.demix(mix, offsets=offs)
+    ref = H.demix_hdemucs(mix, H.make_hd_state(oc, 21), oc, shifts=2, split=False, offsets=offs[0])
+    assert rel_rms(out, ref) < TOL, rel_rms(out, ref)
