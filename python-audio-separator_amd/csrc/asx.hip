@@ -129,6 +129,10 @@ struct asx_engine {
   RofNet *rof = nullptr;
   HtNet *ht = nullptr;
   HdNet *hd = nullptr;   // Demucs v3: owns the inner levels, e->ht the strided ones
+  // workspaces of further chunk groups over the same weights (engine_hd.h) and the shared BLSTM scratch
+  std::vector<HtNet *> ht_cl;
+  std::vector<HdNet *> hd_cl;
+  DevBuf hd_lstm_ws;
   VrNet *vr = nullptr;
   EnsCtx *ens = nullptr;
   asx_mdx_config cfg{};
@@ -822,6 +826,7 @@ static void v3_destroy(V3Net *n);
 static void rof_destroy(RofNet *n);
 static void ht_destroy(HtNet *n);
 static void hd_destroy(HdNet *n);
+static void hd_drop_clones(asx_engine *e);
 static void vr_destroy(VrNet *n);
 static void ens_destroy(EnsCtx *c);
 static void free_conv(ConvLayer &L) {
@@ -872,6 +877,7 @@ void asx_engine_destroy(asx_engine *e) {
   for (auto &sk : e->skip) sk.release();
   if (e->v3) v3_destroy(e->v3);
   if (e->rof) rof_destroy(e->rof);
+  hd_drop_clones(e);
   if (e->ht) ht_destroy(e->ht);
   if (e->hd) hd_destroy(e->hd);
   if (e->vr) vr_destroy(e->vr);
@@ -1935,6 +1941,7 @@ int asx_ht_begin(asx_engine *e, const asx_ht_config *cfg) {
   REQUIRE(cfg->t_layers >= 0 && (cfg->t_layers == 0 || (cfg->t_heads >= 1 && cfg->t_hidden >= 4 && cfg->t_hidden % 4 == 0)),
           "bad transformer hyper-parameters");
   REQUIRE(cfg->samplerate > 0 && cfg->segment_samples > 0, "bad samplerate / segment");
+  hd_drop_clones(e);
   if (!e->ht) e->ht = new HtNet();
   ht_free(*e->ht);
   e->ht->cfg = *cfg;
@@ -2066,6 +2073,7 @@ int asx_hd_begin(asx_engine *e, const asx_hd_config *cfg) {
   REQUIRE(cfg->norm_groups >= 1, "bad norm_groups");
   REQUIRE(cfg->nfft >= 64 && cfg->nfft % 8 == 0, "bad nfft %d", cfg->nfft);
   REQUIRE(cfg->samplerate > 0 && cfg->segment_samples >= 1, "bad samplerate / segment");
+  hd_drop_clones(e);
   if (!e->ht) e->ht = new HtNet();
   ht_free(*e->ht);
   if (!e->hd) e->hd = new HdNet();

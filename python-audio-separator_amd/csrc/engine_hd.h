@@ -40,7 +40,7 @@ struct HdNet {
   int64_t ws_len = 0;
   int ws_batch = 0;
   struct {
-    float *inj, *ya, *rwA, *skA, *yz, *rwZ, *skZ, *g, *tr, *dAin, *pre, *xs, *xp, *out, *hb, *cst, *qkvd, *att;
+    float *inj, *ya, *rwA, *skA, *yz, *rwZ, *skZ, *g, *tr, *dAin, *pre, *qkvd, *att;
   } b;
 };
 
@@ -306,13 +306,6 @@ static int hd_ensure_workspace(asx_engine *e, int B, int64_t L) {
   want(b.tr, std::max(std::max((size_t)B * (d.T2 + 1) * c.time_stride * CA, BT * n.F[D] * h.CD), (size_t)B * (d.T + 1) * c.stride * h.CD));
   want(b.dAin, BT * CA);
   want(b.pre, BT * CA);
-  const size_t rowsA = (size_t)d.stepsA * B * d.nfrA, rowsZ = (size_t)d.stepsZ * B * d.nfrZ;
-  const size_t NA = (size_t)B * d.nfrA, NZ = (size_t)B * d.nfrZ;
-  want(b.xs, std::max(rowsA * HA, rowsZ * HZ));
-  want(b.xp, std::max(rowsA * 8 * HA, rowsZ * 8 * HZ));
-  want(b.out, std::max(rowsA * 2 * HA, rowsZ * 2 * HZ));
-  want(b.hb, std::max(NA * HA, NZ * HZ) * 4);
-  want(b.cst, std::max(NA * HA, NZ * HZ) * 2);
   want(b.qkvd, std::max(BT * (3 * HA + 16), BT2 * (3 * HZ + 16)));
   want(b.att, std::max(BT * HA, BT2 * HZ));
   CHK(h.ws.ensure(off));
@@ -336,38 +329,114 @@ static int hd_group_norm(asx_engine *e, const float *x, int B, int64_t R, int C,
   });
 }
 
-// BLSTM(dim, layers=2, max_steps=200, skip=True) in place on hbuf [B, T, H] (demucs.py:33-66)
-static int hd_blstm(asx_engine *e, const HdLstm &L, float *hbuf, int B, int T, int H, hipStream_t s) {
-  auto &b = e->hd->b;
-  const int steps = T > 200 ? 200 : T, nfr = T > 200 ? (T + 99) / 100 : 1, N = B * nfr;
-  const int64_t rows = (int64_t)steps * N;
-  CHK(timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)rows * H, s, [&]() {
-    hipLaunchKernelGGL(hd_lstm_frame_kernel, dim3((unsigned)((rows * H + 255) / 256)), dim3(256), 0, s, hbuf, B, T, H, nfr, steps, 100, b.xs,
-                       rows * H);
-  }));
-  const float *in = b.xs;
-  int din = H;
-  for (int layer = 0; layer < 2; ++layer) {
-    const HtGemm &ih = layer ? L.ih1 : L.ih0;
-    const float *whh = layer ? L.whh1.f() : L.whh0.f();
-    CHK(ht_linear(e, ih, in, din, rows, b.xp, 8 * H, 0, nullptr, 0, s));
-    HIPCHK(hipMemsetAsync(b.hb, 0, (size_t)4 * N * H * 4, s));
-    HIPCHK(hipMemsetAsync(b.cst, 0, (size_t)2 * N * H * 4, s));
-    const dim3 grid((unsigned)(H / 4), 2, (unsigned)((N + 127) / 128));
-    CHK(timed(e, ASX_PROF_CONV1X1, 2.0 * steps * 2.0 * N * 4.0 * H * H, 4.0 * steps * 2.0 * (4.0 * H * H + 10.0 * N * H), s, [&]() {
-      for (int st = 0; st < steps; ++st) {
-        float *hp = b.hb + (size_t)(st & 1) * 2 * N * H, *hn = b.hb + (size_t)((st + 1) & 1) * 2 * N * H;
-        hipLaunchKernelGGL(hd_lstm_step_kernel, grid, dim3(256), 0, s, b.xp, whh, hp, hn, b.cst, b.out, N, H, st, steps);
-      }
-    }));
-    in = b.out;
-    din = 2 * H;
+// ---- chunk groups ---------------------------------------------------------------------------------------------------
+// A forward call works on one or more groups of chunks, one length each.  Every group has its own activations: the
+// first lives in e->ht / e->hd, the others in clones of the two nets that alias the weights and own a workspace
+// (e->ht_cl / e->hd_cl).  The groups advance phase by phase and meet at every BLSTM, where the sequences of all groups
+// with the same step count (200 for anything longer than 200 frames, demucs.py:41-48) share the 2 x 200 recurrence
+// launches: the step chain is latency-bound and costs the same for 4 sequences as for 400, and a song's chunks come in
+// only a few lengths (the split length plus a tail or two per shift).
+struct HdGroup {
+  HtNet *ht;
+  HdNet *hd;
+  int B;
+  int64_t L;
+  const float *seg;   // [B, 2, L]
+  float *out;         // [B, S, 2, L]
+  HdDims dm;
+};
+
+static void hd_drop_clones(asx_engine *e) {
+  for (HtNet *n : e->ht_cl) {
+    for (DevBuf *p : {&n->ws, &n->acc, &n->chunk_out, &n->d_starts, &n->seg, &n->ref}) p->release();   // ref_acc is never the clone's own
+    delete n;
   }
-  CHK(ht_linear(e, L.lin, b.out, 2 * H, rows, b.xs, H, 0, nullptr, 0, s));
-  const int64_t total = (int64_t)B * T * H;
-  return timed(e, ASX_PROF_MISC, 0.0, 12.0 * (double)total, s, [&]() {
-    hipLaunchKernelGGL(hd_lstm_unframe_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, b.xs, B, T, H, nfr, 100, hbuf, total);
-  });
+  for (HdNet *h : e->hd_cl) {
+    for (DevBuf *p : {&h->ws, &h->tmp_out, &h->starts}) p->release();
+    delete h;
+  }
+  e->ht_cl.clear();
+  e->hd_cl.clear();
+  e->hd_lstm_ws.release();
+}
+
+static int hd_clone(asx_engine *e, size_t idx) {
+  while (e->hd_cl.size() <= idx) {
+    HtNet *n = new HtNet(*e->ht);
+    for (DevBuf *p : {&n->ws, &n->acc, &n->chunk_out, &n->d_starts, &n->seg, &n->ref, &n->ref_acc}) *p = DevBuf();
+    n->ws_batch = 0;
+    HdNet *h = new HdNet(*e->hd);
+    for (DevBuf *p : {&h->ws, &h->tmp_out, &h->starts}) *p = DevBuf();
+    h->ws_batch = 0;
+    h->ws_len = 0;
+    e->ht_cl.push_back(n);
+    e->hd_cl.push_back(h);
+  }
+  return ASX_OK;
+}
+
+// BLSTM(dim, layers=2, max_steps=200, skip=True) (demucs.py:33-66) in place on the DConv hidden buffers b.h [B, T, H] of
+// every group, level A (T frames) or Z (T2)
+static int hd_blstm_joint(asx_engine *e, std::vector<HdGroup> &G, bool levelZ, size_t d, hipStream_t s) {
+  HdNet &h0 = *G[0].hd;
+  const HdLstm &L = (levelZ ? h0.insZ : h0.insA)[d].lstm;
+  const int H = (levelZ ? h0.CZ : h0.CA) / h0.cfg.dconv_comp;
+  std::map<int, std::vector<size_t>> by_steps;
+  for (size_t gi = 0; gi < G.size(); ++gi) by_steps[levelZ ? G[gi].dm.stepsZ : G[gi].dm.stepsA].push_back(gi);
+  for (auto &kv : by_steps) {
+    const int steps = kv.first;
+    int N = 0;
+    for (size_t gi : kv.second) N += G[gi].B * (levelZ ? G[gi].dm.nfrZ : G[gi].dm.nfrA);
+    const int64_t rows = (int64_t)steps * N;
+    auto pad = [](size_t f) { return (f + 63) & ~(size_t)63; };
+    const size_t o_xs = 0, o_xp = o_xs + pad((size_t)rows * H), o_out = o_xp + pad((size_t)rows * 8 * H), o_hb = o_out + pad((size_t)rows * 2 * H),
+                 o_cst = o_hb + pad((size_t)4 * N * H), total = o_cst + pad((size_t)2 * N * H);
+    CHK(e->hd_lstm_ws.ensure(total * 4));
+    float *xs = e->hd_lstm_ws.f() + o_xs, *xp = e->hd_lstm_ws.f() + o_xp, *out = e->hd_lstm_ws.f() + o_out, *hb = e->hd_lstm_ws.f() + o_hb,
+          *cst = e->hd_lstm_ws.f() + o_cst;
+    int n_off = 0;
+    for (size_t gi : kv.second) {
+      const HdGroup &g = G[gi];
+      const int T = levelZ ? g.dm.T2 : g.dm.T, nfr = levelZ ? g.dm.nfrZ : g.dm.nfrA;
+      const int64_t tot = (int64_t)steps * g.B * nfr * H;
+      CHK(timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)tot, s, [&]() {
+        hipLaunchKernelGGL(hd_lstm_frame_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, g.ht->b.h, g.B, T, H, nfr, steps, 100, N,
+                           n_off, xs, tot);
+      }));
+      n_off += g.B * nfr;
+    }
+    const float *in = xs;
+    int din = H;
+    for (int layer = 0; layer < 2; ++layer) {
+      const HtGemm &ih = layer ? L.ih1 : L.ih0;
+      const float *whh = layer ? L.whh1.f() : L.whh0.f();
+      CHK(ht_linear(e, ih, in, din, rows, xp, 8 * H, 0, nullptr, 0, s));
+      HIPCHK(hipMemsetAsync(hb, 0, (size_t)4 * N * H * 4, s));
+      HIPCHK(hipMemsetAsync(cst, 0, (size_t)2 * N * H * 4, s));
+      const dim3 grid((unsigned)(H / 4), 2, (unsigned)((N + 127) / 128));
+      CHK(timed(e, ASX_PROF_CONV1X1, 2.0 * steps * 2.0 * N * 4.0 * H * H, 4.0 * steps * 2.0 * (4.0 * H * H + 10.0 * N * H), s, [&]() {
+        for (int st = 0; st < steps; ++st) {
+          float *hp = hb + (size_t)(st & 1) * 2 * N * H, *hn = hb + (size_t)((st + 1) & 1) * 2 * N * H;
+          hipLaunchKernelGGL(hd_lstm_step_kernel, grid, dim3(256), 0, s, xp, whh, hp, hn, cst, out, N, H, st, steps);
+        }
+      }));
+      in = out;
+      din = 2 * H;
+    }
+    CHK(ht_linear(e, L.lin, out, 2 * H, rows, xs, H, 0, nullptr, 0, s));
+    n_off = 0;
+    for (size_t gi : kv.second) {
+      const HdGroup &g = G[gi];
+      const int T = levelZ ? g.dm.T2 : g.dm.T, nfr = levelZ ? g.dm.nfrZ : g.dm.nfrA;
+      const int64_t tot = (int64_t)g.B * T * H;
+      CHK(timed(e, ASX_PROF_MISC, 0.0, 12.0 * (double)tot, s, [&]() {
+        hipLaunchKernelGGL(hd_lstm_unframe_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, xs, g.B, T, H, nfr, 100, N, n_off,
+                           g.ht->b.h, tot);
+      }));
+      n_off += g.B * nfr;
+    }
+  }
+  return ASX_OK;
 }
 
 template <int DH>
@@ -420,18 +489,21 @@ static int hd_local_state(asx_engine *e, const HdAttn &A, float *hbuf, int B, in
   return ht_linear(e, A.proj, b.att, H, M, hbuf, H, 0, hbuf, H, s);
 }
 
-// HDemucs.forward (hdemucs.py:670-782) for B segments of L samples: seg [B, 2, L] -> out [B, S, 2, L]
-static int hd_forward_dev(asx_engine *e, const float *seg, int B, int64_t L, float *out, hipStream_t s) {
+// HDemucs.forward (hdemucs.py:670-782) of the group in e->ht / e->hd, first phase: spectrogram, standardisation, the
+// strided encoder levels, level A up to the GELU of its first DConv layer
+static int hd_phase_front(asx_engine *e, const HdGroup &gr, hipStream_t s) {
   HdNet &h = *e->hd;
   HtNet &n = *e->ht;
   const asx_hd_config &c = h.cfg;
-  REQUIRE(L >= 1, "empty segment");
+  const int B = gr.B;
+  const int64_t L = gr.L;
+  const float *seg = gr.seg;
   CHK(hd_ensure_workspace(e, B, L));
   auto &b = n.b;
   auto &w = h.b;
-  const HdDims dm = hd_dims(h, L);
-  const int D = h.D, S = c.n_sources, T = dm.T, T2 = dm.T2, hop = c.nfft / 4;
-  const int F0 = n.F[0], CA = h.CA, CZ = h.CZ, CD = h.CD;
+  const HdDims &dm = gr.dm;
+  const int D = h.D, T = dm.T, hop = c.nfft / 4;
+  const int F0 = n.F[0], CA = h.CA, CD = h.CD;
   const int64_t Lp = (L + 1) & ~(int64_t)1;
   // spectrogram + standardisation of both branches (hdemucs.py:680-704); pad1d's zero extension of short inputs (:21-34)
   int64_t el = 0, Lv = L;
@@ -458,37 +530,49 @@ static int hd_forward_dev(asx_engine *e, const float *seg, int B, int64_t L, flo
   }));
   for (int i = 0; i < D; ++i) CHK(ht_enc_level(e, i, B, s));
   // ---- level A (hdemucs.py:715-733 with HEncLayer.forward :139-170) ----
-  {
-    HtGeom g;   // tencoder: bare conv, its output is injected into the spectrogram branch
-    g.I = (int)n.L[D];
-    g.Cin = CD;
-    g.ldc = CD;
-    g.KI = c.kernel_size;
-    g.PI = c.kernel_size / 4;
-    g.SI = c.stride;
-    g.IR = T;
-    CHK(ht_gg(e, h.tencA, b.skt[D - 1], g, B, w.inj, CA, GG_DENSE, 0, nullptr, 0, 0, 0, 0, s));
-    HtGeom f;   // all remaining frequency rows -> one
-    f.O = T;
-    f.I = n.F[D];
-    f.Cin = CD;
-    f.ldc = CD;
-    f.KI = n.F[D];
-    f.SI = c.stride;
-    f.IR = 1;
-    CHK(ht_gg(e, h.encA.conv, b.skf[D - 1], f, (int64_t)B * T, w.ya, CA, GG_DENSE, 0, w.inj, CA, 0, 0, 0, s));
-    CHK(hd_group_norm(e, w.ya, B, T, CA, h.n1A, 0, w.ya, nullptr, s));
+  HtGeom g;   // tencoder: bare conv, its output is injected into the spectrogram branch
+  g.I = (int)n.L[D];
+  g.Cin = CD;
+  g.ldc = CD;
+  g.KI = c.kernel_size;
+  g.PI = c.kernel_size / 4;
+  g.SI = c.stride;
+  g.IR = T;
+  CHK(ht_gg(e, h.tencA, b.skt[D - 1], g, B, w.inj, CA, GG_DENSE, 0, nullptr, 0, 0, 0, 0, s));
+  HtGeom f;   // all remaining frequency rows -> one
+  f.O = T;
+  f.I = n.F[D];
+  f.Cin = CD;
+  f.ldc = CD;
+  f.KI = n.F[D];
+  f.SI = c.stride;
+  f.IR = 1;
+  CHK(ht_gg(e, h.encA.conv, b.skf[D - 1], f, (int64_t)B * T, w.ya, CA, GG_DENSE, 0, w.inj, CA, 0, 0, 0, s));
+  CHK(hd_group_norm(e, w.ya, B, T, CA, h.n1A, 0, w.ya, nullptr, s));
+  return ht_dconv_layer(e, h.encA, 0, 1, w.ya, B, T, 1, true, s);
+}
+
+// the phase after the BLSTM of DConv layer d of level A / Z: LocalState, the rest of the layer, then everything up to the
+// next BLSTM (or the end of the network)
+static int hd_phase_after(asx_engine *e, const HdGroup &gr, bool levelZ, size_t d, hipStream_t s) {
+  HdNet &h = *e->hd;
+  HtNet &n = *e->ht;
+  const asx_hd_config &c = h.cfg;
+  auto &b = n.b;
+  auto &w = h.b;
+  const HdDims &dm = gr.dm;
+  const int B = gr.B, D = h.D, S = c.n_sources, T = dm.T, T2 = dm.T2, hop = c.nfft / 4;
+  const int64_t L = gr.L;
+  const int F0 = n.F[0], CA = h.CA, CZ = h.CZ, CD = h.CD;
+  const size_t K = h.encA.dc.size();
+  if (!levelZ) {
     const int HA = CA / c.dconv_comp;
-    const std::function<int(size_t, float *)> mid = [&](size_t d, float *hb) {
-      CHK(hd_blstm(e, h.insA[d].lstm, hb, B, T, HA, s));
-      return hd_local_state(e, h.insA[d].attn, hb, B, T, HA, s);
-    };
-    CHK(ht_dconv(e, h.encA, w.ya, B, T, 1, true, s, &mid));
+    CHK(hd_local_state(e, h.insA[d].attn, b.h, B, T, HA, s));
+    CHK(ht_dconv_layer(e, h.encA, d, 2, w.ya, B, T, 1, true, s));
+    if (d + 1 < K) return ht_dconv_layer(e, h.encA, d + 1, 1, w.ya, B, T, 1, true, s);
     CHK(ht_linear(e, h.encA.rewrite, w.ya, CA, (int64_t)B * T, w.rwA, 2 * CA, 0, nullptr, 0, s));
     CHK(hd_group_norm(e, w.rwA, B, T, 2 * CA, h.n2A, 1, w.skA, nullptr, s));
-  }
-  // ---- level Z: time-only layer on the merged branch ----
-  {
+    // ---- level Z: time-only layer on the merged branch ----
     HtGeom g;
     g.I = T;
     g.Cin = CA;
@@ -499,15 +583,14 @@ static int hd_forward_dev(asx_engine *e, const float *seg, int B, int64_t L, flo
     g.IR = T2;
     CHK(ht_gg(e, h.encZ.conv, w.skA, g, B, w.yz, CZ, GG_DENSE, 0, nullptr, 0, 0, 0, 0, s));
     CHK(hd_group_norm(e, w.yz, B, T2, CZ, h.n1Z, 0, w.yz, nullptr, s));
-    const int HZ = CZ / c.dconv_comp;
-    const std::function<int(size_t, float *)> mid = [&](size_t d, float *hb) {
-      CHK(hd_blstm(e, h.insZ[d].lstm, hb, B, T2, HZ, s));
-      return hd_local_state(e, h.insZ[d].attn, hb, B, T2, HZ, s);
-    };
-    CHK(ht_dconv(e, h.encZ, w.yz, B, 1, T2, false, s, &mid));
-    CHK(ht_linear(e, h.encZ.rewrite, w.yz, CZ, (int64_t)B * T2, w.rwZ, 2 * CZ, 0, nullptr, 0, s));
-    CHK(hd_group_norm(e, w.rwZ, B, T2, 2 * CZ, h.n2Z, 1, w.skZ, nullptr, s));
+    return ht_dconv_layer(e, h.encZ, 0, 1, w.yz, B, 1, T2, false, s);
   }
+  const int HZ = CZ / c.dconv_comp;
+  CHK(hd_local_state(e, h.insZ[d].attn, b.h, B, T2, HZ, s));
+  CHK(ht_dconv_layer(e, h.encZ, d, 2, w.yz, B, 1, T2, false, s));
+  if (d + 1 < K) return ht_dconv_layer(e, h.encZ, d + 1, 1, w.yz, B, 1, T2, false, s);
+  CHK(ht_linear(e, h.encZ.rewrite, w.yz, CZ, (int64_t)B * T2, w.rwZ, 2 * CZ, 0, nullptr, 0, s));
+  CHK(hd_group_norm(e, w.rwZ, B, T2, 2 * CZ, h.n2Z, 1, w.skZ, nullptr, s));
   // ---- decoder of level Z (x = 0 + skip; hdemucs.py:303-330) ----
   {
     HtGeom g;
@@ -569,14 +652,51 @@ static int hd_forward_dev(asx_engine *e, const float *seg, int B, int64_t L, flo
   }
   for (int i = D - 1; i >= 0; --i) CHK(ht_dec_level(e, i, B, s));
   // CaC -> iSTFT, + waveform branch (hdemucs.py:760-781)
+  const int64_t nf = (int64_t)T * F0 * 4;
   CHK(timed(e, ASX_PROF_ISTFT, 0.0, 4.0 * (double)B * S * 2 * T * (2.0 * F0 + c.nfft), s, [&]() {
     hipLaunchKernelGGL(ht_istft_kernel, dim3(T, S * 2, B), dim3(256), istft_lds(n.plan), s, b.df[0], T, 4 * S, b.acc_f, (double)nf, b.frames,
                        n.window.f(), reinterpret_cast<const float2 *>(n.tw.p), n.plan);
   }));
   return timed(e, ASX_PROF_OLA, 0.0, 4.0 * (double)B * S * 2 * (T * (double)c.nfft + 2.0 * L), s, [&]() {
     hipLaunchKernelGGL(ht_ola_kernel, dim3((unsigned)((L + 255) / 256), S * 2, B), dim3(256), 0, s, b.frames, n.env_hop.f(), c.nfft, hop, T, L,
-                       b.dt[0], 2 * S, b.acc_t, out);
+                       b.dt[0], 2 * S, b.acc_t, gr.out);
   });
+}
+
+// all groups, phase by phase (G[0] must be the engine's own nets)
+static int hd_forward_groups(asx_engine *e, std::vector<HdGroup> &G, hipStream_t s) {
+  HtNet *const ht0 = e->ht;
+  HdNet *const hd0 = e->hd;
+  int rc = ASX_OK;
+  auto each = [&](const std::function<int(const HdGroup &)> &fn) {
+    for (HdGroup &g : G) {
+      e->ht = g.ht;
+      e->hd = g.hd;
+      rc = fn(g);
+      e->ht = ht0;
+      e->hd = hd0;
+      if (rc != ASX_OK) return rc;
+    }
+    return rc;
+  };
+  for (HdGroup &g : G) {
+    REQUIRE(g.L >= 1 && g.B >= 1, "empty segment");
+    g.dm = hd_dims(*hd0, g.L);
+  }
+  CHK(each([&](const HdGroup &g) { return hd_phase_front(e, g, s); }));
+  const size_t K = hd0->encA.dc.size();
+  for (int lvl = 0; lvl < 2; ++lvl)
+    for (size_t d = 0; d < K; ++d) {
+      CHK(hd_blstm_joint(e, G, lvl == 1, d, s));
+      CHK(each([&](const HdGroup &g) { return hd_phase_after(e, g, lvl == 1, d, s); }));
+    }
+  return ASX_OK;
+}
+
+// HDemucs.forward for B segments of L samples: seg [B, 2, L] -> out [B, S, 2, L]
+static int hd_forward_dev(asx_engine *e, const float *seg, int B, int64_t L, float *out, hipStream_t s) {
+  std::vector<HdGroup> G{HdGroup{e->ht, e->hd, B, L, seg, out, HdDims{}}};
+  return hd_forward_groups(e, G, s);
 }
 
 // 2*MAC of the GEMM-shaped work of one segment of L samples
@@ -651,8 +771,12 @@ static int hd_plan(const asx_engine *e, int64_t N, int32_t shifts, const int64_t
   return ASX_OK;
 }
 
-// chunk forwards [k0, k1) -> chunk_out [k1-k0, S, 2, segment] (each row holds clen valid samples); chunks of equal
-// length run as one batch
+// chunk forwards [k0, k1) -> chunk_out [k1-k0, S, 2, segment] (each row holds clen valid samples).  Chunks of equal
+// length form one group (up to max_batch of them); up to HD_MAX_GROUPS groups advance together and share their BLSTM
+// launches (hd_forward_groups).  (Running the tail groups on a second stream instead was measured and gave nothing: the
+// two HSA queues never had kernels in flight together)
+constexpr int HD_MAX_GROUPS = 6;
+
 static int hd_segments_dev(asx_engine *e, const float *mix_dev, int64_t N, const HdPlan &p, uint32_t flags, int k0, int k1, float *chunk_out,
                            hipStream_t s) {
   HdNet &h = *e->hd;
@@ -667,26 +791,45 @@ static int hd_segments_dev(asx_engine *e, const float *mix_dev, int64_t N, const
   // 16: the BLSTM recurrences cost the same 200 steps whatever the batch, so the equal-length chunks of a song go together
   // (4-min song, 44-s chunks: 730 -> 789x real time against batches of 4; ~2.2 GB of workspace per 44-s chunk)
   const int maxB = h.cfg.max_batch > 0 ? h.cfg.max_batch : 16;
-  CHK(h.starts.ensure((size_t)maxB * 8));
-  size_t i = 0;
-  while (i < order.size()) {
-    const int64_t L = p.clen[order[i]];
-    size_t j = i;
-    std::vector<int64_t> st;
-    while (j < order.size() && p.clen[order[j]] == L && (int)st.size() < maxB) st.push_back(p.starts[order[j++]]);
-    const int B = (int)st.size();
-    HIPCHK(hipMemcpyAsync(h.starts.p, st.data(), (size_t)B * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
-    CHK(n.seg.ensure((size_t)maxB * 2 * p.segment * 4));
-    CHK(h.tmp_out.ensure((size_t)maxB * S * 2 * p.segment * 4));
-    hipLaunchKernelGGL(ht_gather_kernel, dim3((unsigned)((L + 255) / 256), 2, B), dim3(256), 0, s, mix_dev, N,
-                       reinterpret_cast<const int64_t *>(h.starts.p), L, reinterpret_cast<const double *>(n.ref_acc.p), standardize, n.seg.f());
-    HIPCHK(hipGetLastError());
-    CHK(hd_forward_dev(e, n.seg.f(), B, L, h.tmp_out.f(), s));
-    for (int bi = 0; bi < B; ++bi)
-      HIPCHK(hipMemcpy2DAsync(chunk_out + (size_t)(order[i + bi] - k0) * S * 2 * p.segment, (size_t)p.segment * 4,
-                              h.tmp_out.f() + (size_t)bi * S * 2 * L, (size_t)L * 4, (size_t)L * 4, (size_t)S * 2, hipMemcpyDeviceToDevice, s));
-    i = j;
+  const int nk = (int)order.size();
+  std::vector<int64_t> st(nk);
+  for (int i = 0; i < nk; ++i) st[i] = p.starts[order[i]];
+  CHK(h.starts.ensure((size_t)nk * 8));
+  HIPCHK(hipMemcpyAsync(h.starts.p, st.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));   // st is a local
+  static const int max_groups = getenv("ASX_HD_GROUPS") ? std::max(1, std::min(HD_MAX_GROUPS, atoi(getenv("ASX_HD_GROUPS")))) : HD_MAX_GROUPS;
+  int i = 0;
+  while (i < nk) {
+    std::vector<HdGroup> G;
+    std::vector<int> first;
+    while (i < nk && (int)G.size() < max_groups) {
+      const int64_t L = p.clen[order[i]];
+      int j = i;
+      while (j < nk && p.clen[order[j]] == L && j - i < maxB) ++j;
+      HtNet *gn = &n;
+      HdNet *gh = &h;
+      if (!G.empty()) {
+        CHK(hd_clone(e, G.size() - 1));
+        gn = e->ht_cl[G.size() - 1];
+        gh = e->hd_cl[G.size() - 1];
+      }
+      const int B = j - i;
+      CHK(gn->seg.ensure((size_t)B * 2 * L * 4));
+      CHK(gh->tmp_out.ensure((size_t)B * S * 2 * L * 4));
+      hipLaunchKernelGGL(ht_gather_kernel, dim3((unsigned)((L + 255) / 256), 2, B), dim3(256), 0, s, mix_dev, N,
+                         reinterpret_cast<const int64_t *>(h.starts.p) + i, L, reinterpret_cast<const double *>(n.ref_acc.p), standardize,
+                         gn->seg.f());
+      HIPCHK(hipGetLastError());
+      G.push_back(HdGroup{gn, gh, B, L, gn->seg.f(), gh->tmp_out.f(), HdDims{}});
+      first.push_back(i);
+      i = j;
+    }
+    CHK(hd_forward_groups(e, G, s));
+    for (size_t gi = 0; gi < G.size(); ++gi)
+      for (int bi = 0; bi < G[gi].B; ++bi)
+        HIPCHK(hipMemcpy2DAsync(chunk_out + (size_t)(order[first[gi] + bi] - k0) * S * 2 * p.segment, (size_t)p.segment * 4,
+                                G[gi].out + (size_t)bi * S * 2 * G[gi].L, (size_t)G[gi].L * 4, (size_t)G[gi].L * 4, (size_t)S * 2,
+                                hipMemcpyDeviceToDevice, s));
   }
   return ASX_OK;
 }

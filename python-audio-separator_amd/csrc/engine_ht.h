@@ -701,15 +701,40 @@ static int ht_ensure_workspace(asx_engine *e, int B) {
   return ASX_OK;
 }
 
-// DConv residual branch (demucs.py:99-179) on y [B, O, I, C] in place; along_outer: the conv runs over the outer axis
-// mid: optional stage between the GELU and the 1x1 conv (Demucs v3's BLSTM / LocalState inserts) on h [B*O*I, hp]
-static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I, bool along_outer, hipStream_t s,
-                    const std::function<int(size_t, float *)> *mid = nullptr) {
+// One layer d of the DConv residual branch (demucs.py:99-179) on y [B, O, I, C] in place; along_outer: the conv runs over
+// the outer axis.  part 1 (head): dilated conv + GroupNorm + GELU -> h [B*O*I, hp] (the workspace's b.h); part 2 (tail):
+// 1x1 conv + GroupNorm + GLU + LayerScale + residual add into y; 3: both.  Demucs v3 runs its BLSTM / LocalState inserts on
+// h between the two parts (engine_hd.h).
+static int ht_dconv_layer(asx_engine *e, const HtEnc &E, size_t d, int part, float *y, int B, int O, int I, bool along_outer,
+                          hipStream_t s) {
   HtNet &n = *e->ht;
   const int C = E.cout;
-  for (size_t d = 0; d < E.dc.size(); ++d) {
-    const HtDconv &dc = E.dc[d];
-    const int dil = 1 << d;
+  const HtDconv &dc = E.dc[d];
+  const int dil = 1 << d;
+  // GroupNorm(1, .) per conv batch item: (b, f) over (t, c) on the spectrogram branch, b over (l, c) on the waveform.
+  // Statistics are accumulated by the producing GEMM's epilogue; the 1x1 conv runs twice (K = C/8 is tiny) --
+  // once for the statistics, once to normalise + GLU + LayerScale + add into y -- so its 2C-wide output never
+  // reaches HBM.
+  const int G2 = along_outer ? I : 1;
+  const int64_t R = along_outer ? O : I;
+  const int64_t M = (int64_t)B * O * I;
+  auto fold = [&](int ncols, double count, double *acc, float2 *mr) {
+    const int ntile = (ncols + gg_tile_n(ncols) - 1) / gg_tile_n(ncols);   // N tiles of ht_gg's launch choice
+    unsigned gx = (unsigned)((G2 + 15) / 16);
+    if (G2 == 1) {
+      gx = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, R / 4096));
+      if (gx > 1) HIPCHK(hipMemsetAsync(acc, 0, (size_t)B * 16, s));
+    }
+    return timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)M * ntile, s, [&]() {
+      hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, reinterpret_cast<const float2 *>(n.b.rowstat), M,
+                         ntile, (int64_t)O * I, G2, R, count, 1e-5f, acc, mr, n.b.ticket);
+    });
+  };
+  HtFuse f1;
+  f1.row_stat = reinterpret_cast<float2 *>(n.b.rowstat);
+  f1.g_outer = (int64_t)O * I;
+  f1.g_mod = G2;
+  if (part & 1) {
     HtGeom g;
     g.O = O;
     g.I = I;
@@ -725,33 +750,11 @@ static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I
       g.DI = dil;
       g.PI = dil;
     }
-    // GroupNorm(1, .) per conv batch item: (b, f) over (t, c) on the spectrogram branch, b over (l, c) on the waveform.
-    // Statistics are accumulated by the producing GEMM's epilogue; the 1x1 conv runs twice (K = C/8 is tiny) --
-    // once for the statistics, once to normalise + GLU + LayerScale + add into y -- so its 2C-wide output never
-    // reaches HBM.
-    const int G2 = along_outer ? I : 1;
-    const int64_t R = along_outer ? O : I;
-    const int64_t M = (int64_t)B * O * I;
-    auto fold = [&](int ncols, double count, double *acc, float2 *mr) {
-      const int ntile = (ncols + gg_tile_n(ncols) - 1) / gg_tile_n(ncols);   // N tiles of ht_gg's launch choice
-      unsigned gx = (unsigned)((G2 + 15) / 16);
-      if (G2 == 1) {
-        gx = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, R / 4096));
-        if (gx > 1) HIPCHK(hipMemsetAsync(acc, 0, (size_t)B * 16, s));
-      }
-      return timed(e, ASX_PROF_MISC, 0.0, 8.0 * (double)M * ntile, s, [&]() {
-        hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, reinterpret_cast<const float2 *>(n.b.rowstat), M,
-                           ntile, (int64_t)O * I, G2, R, count, 1e-5f, acc, mr, n.b.ticket);
-      });
-    };
-    HtFuse f1;
-    f1.row_stat = reinterpret_cast<float2 *>(n.b.rowstat);
-    f1.g_outer = (int64_t)O * I;
-    f1.g_mod = G2;
     CHK(ht_gg(e, dc.c1, y, g, (int64_t)B * O, n.b.h, dc.hp, GG_DENSE, 0, nullptr, 0, 0, 0, 0, s, &f1));
     CHK(fold(dc.hp, (double)R * dc.hid, n.b.acc_g, reinterpret_cast<float2 *>(n.b.mr_g)));
     CHK(ht_gn(e, n.b.h, B, R, G2, dc.hp, dc.hid, n.b.acc_g, dc.g1w.f(), dc.g1b.f(), 0, nullptr, 0, nullptr, s));
-    if (mid) CHK((*mid)(d, n.b.h));
+  }
+  if (part & 2) {
     HtGeom g1;
     g1.O = O;
     g1.I = I;
@@ -768,6 +771,11 @@ static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I
     f3.ls = dc.ls.f();
     CHK(ht_gg(e, dc.c2, n.b.h, g1, (int64_t)B * O, y, C, GG_GNGLU, 0, nullptr, 0, 0, 0, 0, s, &f3));
   }
+  return ASX_OK;
+}
+
+static int ht_dconv(asx_engine *e, const HtEnc &E, float *y, int B, int O, int I, bool along_outer, hipStream_t s) {
+  for (size_t d = 0; d < E.dc.size(); ++d) CHK(ht_dconv_layer(e, E, d, 3, y, B, O, I, along_outer, s));
   return ASX_OK;
 }
 

@@ -59,11 +59,13 @@ __global__ __launch_bounds__(256) void hd_gn_kernel(const float *__restrict__ x,
 // ---------------------------------------------------------------------------
 // BLSTM (demucs.py:19-66): sequences longer than max_steps = 200 are cut into frames of 200 with stride 100
 // (utils.unfold, zero padded), every frame is an independent sequence; the output keeps the middle of each frame.
-// Sequence-major rows: row = step * N + n with n = b * nfr + k.
+// Sequence-major rows: row = step * Ntot + n_off + n with n = b * nfr + k; Ntot counts the sequences of every chunk group
+// that shares the recurrence launches (engine_hd.h), n_off is this group's first sequence.
 // ---------------------------------------------------------------------------
-// h [B, T, H] -> xs [steps * N, H]
+// h [B, T, H] -> xs [steps * Ntot, H]
 __global__ __launch_bounds__(256) void hd_lstm_frame_kernel(const float *__restrict__ h, int B, int T, int H, int nfr,
-                                                            int steps, int fstride, float *__restrict__ xs, int64_t total) {
+                                                            int steps, int fstride, int Ntot, int n_off,
+                                                            float *__restrict__ xs, int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over steps * N * H
   if (idx >= total) return;
   const int c = (int)(idx % H);
@@ -73,13 +75,14 @@ __global__ __launch_bounds__(256) void hd_lstm_frame_kernel(const float *__restr
   const int s = (int)(p / N);
   const int b = n / nfr, k = n - b * nfr;
   const int t = k * fstride + s;
-  xs[idx] = t < T ? h[((int64_t)b * T + t) * H + c] : 0.f;
+  xs[((int64_t)s * Ntot + n_off + n) * H + c] = t < T ? h[((int64_t)b * T + t) * H + c] : 0.f;
 }
 
 // h [B, T, H] += lin rows picked as BLSTM.forward stitches them (demucs.py:50-64): frame 0 gives steps [0, 150),
 // the last frame [50, 200), the others [50, 150); unframed (nfr == 1): row t.
 __global__ __launch_bounds__(256) void hd_lstm_unframe_kernel(const float *__restrict__ lin, int B, int T, int H, int nfr,
-                                                              int fstride, float *__restrict__ h, int64_t total) {
+                                                              int fstride, int Ntot, int n_off, float *__restrict__ h,
+                                                              int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * T * H
   if (idx >= total) return;
   const int c = (int)(idx % H);
@@ -92,8 +95,7 @@ __global__ __launch_bounds__(256) void hd_lstm_unframe_kernel(const float *__res
     if (k > nfr - 1) k = nfr - 1;
   }
   const int s = t - k * fstride;
-  const int N = B * nfr;
-  h[idx] += lin[((int64_t)s * N + b * nfr + k) * H + c];
+  h[idx] += lin[((int64_t)s * Ntot + n_off + b * nfr + k) * H + c];
 }
 
 // One time step of a bidirectional nn.LSTM layer for N sequences (gate order i, f, g, o):
