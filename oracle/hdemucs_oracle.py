@@ -412,3 +412,56 @@ def demix_hdemucs(mix: np.ndarray, sd: dict, cfg: HDConfig, shifts=2, overlap=0.
     src = (src * ref.std() + ref.mean()).numpy()
     src[[0, 1]] = src[[1, 0]]
     return src
+
+
+# --------------------------------------------------------------------------
+# chunk-list form of demix_hdemucs (test double of asx_hd_plan / asx_hd_segments_dev / asx_hd_fold_dev): every chunk runs at
+# its own length; row k of the slab holds it from column 0
+# --------------------------------------------------------------------------
+def hd_segment_plan(n: int, cfg: HDConfig, shifts, offsets, overlap=0.25):
+    seg = int(cfg.samplerate * cfg.segment)
+    stride = int((1 - overlap) * seg)
+    max_shift = int(0.5 * cfg.samplerate) if shifts else 0
+    plan = []
+    for si in range(max(shifts, 1)):
+        off = offsets[si] if shifts else 0
+        vl = n + max_shift - off
+        plan += [(si, off, vl, o, min(vl - o, seg)) for o in range(0, vl, stride)]
+    return plan, stride, max_shift, seg
+
+
+def _std(mix):
+    m = torch.tensor(np.asarray(mix, np.float32))
+    ref = m.mean(0)
+    return (m - ref.mean()) / ref.std(), ref
+
+
+def hd_segments(mix, sd, cfg: HDConfig, shifts, offsets, overlap, k0, k1):
+    m, _ = _std(mix)
+    plan, _, max_shift, seg = hd_segment_plan(m.shape[1], cfg, shifts, offsets, overlap)
+    padded = F.pad(m, (max_shift, max_shift))
+    out = np.zeros((k1 - k0, len(cfg.sources), 2, seg), np.float32)
+    for i, (si, off, vl, o, clen) in enumerate(plan[k0:k1]):
+        out[i, :, :, :clen] = hd_forward(padded[None, :, off + o: off + o + clen].numpy(), sd, cfg)[0]
+    return out
+
+
+def hd_fold(mix, chunks, cfg: HDConfig, shifts, offsets, overlap):
+    m, ref = _std(mix)
+    plan, stride, max_shift, seg = hd_segment_plan(m.shape[1], cfg, shifts, offsets, overlap)
+    weight = torch.cat([torch.arange(1, seg // 2 + 1), torch.arange(seg - seg // 2, 0, -1)])
+    weight = weight / weight.max()
+    total = 0
+    for si in range(max(shifts, 1)):
+        items = [(k, p) for k, p in enumerate(plan) if p[0] == si]
+        off, vl = items[0][1][1], items[0][1][2]
+        out = torch.zeros(len(cfg.sources), 2, vl)
+        sw = torch.zeros(vl)
+        for k, (_, _, _, o, clen) in items:
+            out[..., o:o + seg] += weight[:clen] * torch.tensor(chunks[k][..., :clen])
+            sw[o:o + seg] += weight[:clen]
+        total = total + (out / sw)[..., max_shift - off:]
+    src = total / max(shifts, 1)
+    src = (src * ref.std() + ref.mean()).numpy()
+    src[[0, 1]] = src[[1, 0]]
+    return src

@@ -70,7 +70,7 @@ def test_header_is_plain_c_and_struct_layouts_match(tmp_path):
     if not gcc:
         pytest.skip("gcc not available")
     pairs = [("asx_mdx_config", E._MdxCfg), ("asx_net_config", E._NetCfg), ("asx_plan", E._Plan), ("asx_profile", E._Profile),
-             ("asx_v3_config", E._V3Cfg), ("asx_rof_config", E._RofCfg), ("asx_ht_config", E._HtCfg), ("asx_vr_band", E._VrBand),
+             ("asx_v3_config", E._V3Cfg), ("asx_rof_config", E._RofCfg), ("asx_ht_config", E._HtCfg), ("asx_hd_config", E._HdCfg), ("asx_vr_band", E._VrBand),
              ("asx_vr_config", E._VrCfg), ("asx_vr_params", E._VrParams)]
     src = '#include <stdio.h>\n#include "asx.h"\nint main(void) {\n' + \
           "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n, _ in pairs) + "  return 0;\n}\n"

@@ -107,10 +107,12 @@ def test_sharded_demix_gloo(world, n, match):
 from fractions import Fraction  # noqa: E402
 
 from oracle import demucs_oracle as D  # noqa: E402
+from oracle import hdemucs_oracle as H  # noqa: E402
 from oracle import roformer_oracle as R  # noqa: E402
 
 RCFG = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64, stft_hop_length=16,
                         stft_win_length=64, dim_t=21, sample_rate=100, mlp_expansion_factor=2)
+HCFG = H.HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, samplerate=8000, segment=2)
 DCFG = D.HTConfig(channels=16, nfft=1024, depth=3, bottom_channels=128, t_layers=1, t_heads=2, samplerate=8000, segment=Fraction(1, 1))
 
 
@@ -153,6 +155,24 @@ class DemucsOracleAdapter:
         out.copy_(torch.from_numpy(np.ascontiguousarray(D.demucs_fold(self.mix, chunks.numpy(), DCFG, **self.kw))))
 
 
+class HDemucsOracleAdapter(DemucsOracleAdapter):
+    """Demucs v3: chunks at their own length (rows of the slab hold them from column 0)"""
+
+    def __init__(self, shifts=1, offsets=(1234,), overlap=0.25):
+        self.sd = H.make_hd_state(HCFG, 21)
+        self.kw = dict(shifts=shifts, offsets=list(offsets), overlap=overlap)
+
+    def plan(self, n):
+        plan, _, _, seg = H.hd_segment_plan(n, HCFG, **self.kw)
+        return {"chunk_size": seg, "n_chunks": len(plan)}
+
+    def demix_chunks(self, mix, n, k0, k1, out):
+        out.copy_(torch.from_numpy(H.hd_segments(mix.numpy(), self.sd, HCFG, k0=k0, k1=k1, **self.kw)))
+
+    def finalize(self, chunks, n, out):
+        out.copy_(torch.from_numpy(np.ascontiguousarray(H.hd_fold(self.mix, chunks.numpy(), HCFG, **self.kw))))
+
+
 def test_segment_form_equals_demix():
     """the chunk-list restatements used by the adapters reproduce the oracle's monolithic loops"""
     mix = (0.4 * np.random.default_rng(15).standard_normal((2, 1000))).astype(np.float32)
@@ -166,6 +186,12 @@ def test_segment_form_equals_demix():
     got = D.demucs_fold(mixd, D.demucs_segments(mixd, d.sd, DCFG, k0=0, k1=nseg, **d.kw), DCFG, **d.kw)
     want = D.demix_demucs(mixd, d.sd, DCFG, shifts=2, overlap=0.25, offsets=[1234, 77])
     assert np.abs(got - want).max() / np.abs(want).max() < 1e-6
+    mixh = (0.3 * np.random.default_rng(19).standard_normal((2, 40011)) - 0.01).astype(np.float32)
+    hd = HDemucsOracleAdapter(shifts=2, offsets=(1234, 77))
+    nseg = hd.plan(40011)["n_chunks"]
+    got = H.hd_fold(mixh, H.hd_segments(mixh, hd.sd, HCFG, k0=0, k1=nseg, **hd.kw), HCFG, **hd.kw)
+    want = H.demix_hdemucs(mixh, hd.sd, HCFG, shifts=2, overlap=0.25, offsets=[1234, 77])
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-6
 
 
 def _sib_worker(rank, world, port, kind, q):
@@ -176,6 +202,9 @@ def _sib_worker(rank, world, port, kind, q):
     if kind == "roformer":
         mix = torch.from_numpy((0.4 * np.random.default_rng(17).standard_normal((2, 1400))).astype(np.float32))
         out = sharded_demix(RoformerOracleAdapter(), mix)
+    elif kind == "hdemucs":
+        mix = torch.from_numpy((0.3 * np.random.default_rng(20).standard_normal((2, 50000))).astype(np.float32))
+        out = sharded_demix(HDemucsOracleAdapter(), mix)
     else:
         mix = torch.from_numpy((0.3 * np.random.default_rng(18).standard_normal((2, 21000))).astype(np.float32))
         out = sharded_demix(DemucsOracleAdapter(), mix)
@@ -187,7 +216,7 @@ def _sib_worker(rank, world, port, kind, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["roformer", "demucs"])
+@pytest.mark.parametrize("kind", ["roformer", "demucs", "hdemucs"])
 def test_sharded_siblings_gloo(kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -202,6 +231,10 @@ def test_sharded_siblings_gloo(kind):
     if kind == "roformer":
         mix = (0.4 * np.random.default_rng(17).standard_normal((2, 1400))).astype(np.float32)
         assert np.array_equal(got, R.roformer_demix(mix, R.make_roformer_state(RCFG, 7), RCFG, overlap=2))
+    elif kind == "hdemucs":
+        mix = (0.3 * np.random.default_rng(20).standard_normal((2, 50000))).astype(np.float32)
+        want = H.demix_hdemucs(mix, H.make_hd_state(HCFG, 21), HCFG, shifts=1, overlap=0.25, offsets=[1234])
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-6
     else:
         mix = (0.3 * np.random.default_rng(18).standard_normal((2, 21000))).astype(np.float32)
         want = D.demix_demucs(mix, D.make_ht_state(DCFG, 11), DCFG, shifts=1, overlap=0.25, offsets=[1234])
