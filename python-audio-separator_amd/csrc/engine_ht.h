@@ -358,7 +358,7 @@ static int ht_commit_level(asx_engine *e, int i, int dec_idx, int tdec_idx) {
 static int ht_commit(asx_engine *e) {
   HtNet &n = *e->ht;
   const asx_ht_config &c = n.cfg;
-  const int D = c.depth, S = c.n_sources, AC = 2;
+  const int D = c.depth;
   REQUIRE(make_plan(c.nfft, &n.plan), "nfft/2 = %d must factor into {2,3,5}", c.nfft / 2);
   const int hop = c.nfft / 4;
   const int64_t TL = c.segment_samples;

@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   float *in_s = lds_f;
   float *w_s = lds_f + CFG::IN_ELEMS;
   constexpr int KH = CFG::KH, KW = CFG::KW, S = CFG::S, PAD = CFG::PAD, NREP = CFG::NREP, KC = CFG::KC;
-  constexpr int RPW = CFG::RPW, MREP = CFG::MREP, IW = CFG::IW, IH = CFG::IH, PS = CFG::PS, PS0 = CFG::PS0;
-  constexpr int NW = CFG::NW, NWP = CFG::NWP, NIN = CFG::NIN, NWV = CFG::NWV, TH = CFG::TH, TW = CFG::TW;
+  constexpr int RPW = CFG::RPW, MREP = CFG::MREP, IW = CFG::IW, PS = CFG::PS, PS0 = CFG::PS0;
+  constexpr int NWP = CFG::NWP, NIN = CFG::NIN, NWV = CFG::NWV, TH = CFG::TH, TW = CFG::TW;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
   extern __shared__ float lds_f[];
   constexpr int KH = CFG::KH, KW = CFG::KW, S = CFG::S, PAD = CFG::PAD, NREP = CFG::NREP, KC = CFG::KC;
   constexpr int RPW = CFG::RPW, MREP = CFG::MREP, IWA = CFG::IWA, C4 = CFG::C4, PS = CFG::PS, LP = CFG::LP;
-  constexpr int NW = CFG::NW, NWP = CFG::NWP, TH = CFG::TH, TW = CFG::TW, NI = CFG::NI, SLOTS = CFG::SLOTS;
+  constexpr int NWP = CFG::NWP, TH = CFG::TH, TW = CFG::TW, NI = CFG::NI, SLOTS = CFG::SLOTS;
   constexpr int BUF = CFG::BUF, WSTAGE = CFG::WSTAGE, NWI = CFG::NWI;
 
   const int tid = threadIdx.x;
