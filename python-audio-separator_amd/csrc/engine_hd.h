@@ -413,11 +413,13 @@ static int hd_blstm_joint(asx_engine *e, std::vector<HdGroup> &G, bool levelZ, s
       CHK(ht_linear(e, ih, in, din, rows, xp, 8 * H, 0, nullptr, 0, s));
       HIPCHK(hipMemsetAsync(hb, 0, (size_t)4 * N * H * 4, s));
       HIPCHK(hipMemsetAsync(cst, 0, (size_t)2 * N * H * 4, s));
-      const dim3 grid((unsigned)(H / 4), 2, (unsigned)((N + 127) / 128));
+      // sequence tiles of 16 are spread evenly over the z blocks (<= 8 tiles each): 18 tiles run as 6 + 6 + 6, not 8 + 8 + 2
+      const int tiles = (N + 15) / 16, nz = (tiles + 7) / 8, tpz = (tiles + nz - 1) / nz;
+      const dim3 grid((unsigned)(H / 4), 2, (unsigned)nz);
       CHK(timed(e, ASX_PROF_CONV1X1, 2.0 * steps * 2.0 * N * 4.0 * H * H, 4.0 * steps * 2.0 * (4.0 * H * H + 10.0 * N * H), s, [&]() {
         for (int st = 0; st < steps; ++st) {
           float *hp = hb + (size_t)(st & 1) * 2 * N * H, *hn = hb + (size_t)((st + 1) & 1) * 2 * N * H;
-          hipLaunchKernelGGL(hd_lstm_step_kernel, grid, dim3(256), 0, s, xp, whh, hp, hn, cst, out, N, H, st, steps);
+          hipLaunchKernelGGL(hd_lstm_step_kernel, grid, dim3(256), 0, s, xp, whh, hp, hn, cst, out, N, H, st, steps, tpz);
         }
       }));
       in = out;

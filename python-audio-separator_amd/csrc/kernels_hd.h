@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void hd_lstm_unframe_kernel(const float *__res
 //   gates = xp[t_dir][n][dir] + W_hh[dir] h_prev[dir][n];  c = f*c + i*g;  h = o * tanh(c)
 // xp [steps*N, 2, 4H] (input projection + b_ih + b_hh, one GEMM for all steps), whh [2, 4H, H], hprev / hnext / cst
 // [2, N, H], out [steps*N, 2H].  Direction 0 handles step s, direction 1 step steps-1-s.
-// grid = (H / 4, 2, ceil(N / 128)): a workgroup owns 4 hidden units -- 16 gate rows, the M side of v_mfma_f32_16x16x4_f32
+// grid = (H / 4, 2, nz), tpz <= 8 sequence tiles per z block: a workgroup owns 4 hidden units -- 16 gate rows, the M side of v_mfma_f32_16x16x4_f32
 // with row = unit*4 + gate, so that a lane's four accumulators are the four gates of one (unit, sequence) -- for up to
 // 8 tiles of 16 sequences; its 4 waves split K, fragments come straight from L2 as 16-byte rows (the k order inside a
 // 16-wide chunk is permuted identically for both operands), partial sums meet in LDS.  The recurrence is a chain of
@@ -110,13 +110,13 @@ __global__ __launch_bounds__(256) void hd_lstm_unframe_kernel(const float *__res
 __global__ __launch_bounds__(256) void hd_lstm_step_kernel(const float *__restrict__ xp, const float *__restrict__ whh,
                                                            const float *__restrict__ hprev, float *__restrict__ hnext,
                                                            float *__restrict__ cst, float *__restrict__ out, int N, int H,
-                                                           int s, int steps) {
+                                                           int s, int steps, int tpz) {
   __shared__ f32x4 red[4][8][64];
-  const int u0 = blockIdx.x * 4, dir = blockIdx.y, nb = blockIdx.z * 128;
+  const int u0 = blockIdx.x * 4, dir = blockIdx.y, nb = blockIdx.z * tpz * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kq = lane >> 4;
   const int t = dir ? steps - 1 - s : s;
-  const int ntile = (N - nb + 15) / 16 < 8 ? (N - nb + 15) / 16 : 8;
+  const int ntile = (N - nb + 15) / 16 < tpz ? (N - nb + 15) / 16 : tpz;
   const int kc = ((H / 16 + 3) / 4) * 16;
   const int k_lo = wave * kc, k_hi = (k_lo + kc < H) ? k_lo + kc : H;
   const float *wrow = whh + ((int64_t)dir * 4 * H + (int64_t)(m & 3) * H + u0 + (m >> 2)) * H + kq * 4;
