@@ -1942,6 +1942,7 @@ int asx_ht_begin(asx_engine *e, const asx_ht_config *cfg) {
           "bad transformer hyper-parameters");
   REQUIRE(cfg->samplerate > 0 && cfg->segment_samples > 0, "bad samplerate / segment");
   hd_drop_clones(e);
+  if (e->hd) hd_free(*e->hd);   // a Demucs v3 net shares e->ht: it is gone with these weights
   if (!e->ht) e->ht = new HtNet();
   ht_free(*e->ht);
   e->ht->cfg = *cfg;

@@ -74,6 +74,7 @@ static void hd_free(HdNet &n) {
   }
   for (DevBuf *p : {&n.ws, &n.tmp_out, &n.starts}) p->release();
   n.ready = false;
+  n.begun = false;
   n.ws_batch = 0;
   n.ws_len = 0;
 }

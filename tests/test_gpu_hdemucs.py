@@ -140,3 +140,23 @@ def test_segments_disabled_matches_oracle(A):
     out = d.demix(mix, offsets=offs)
     ref = H.demix_hdemucs(mix, H.make_hd_state(oc, 21), oc, shifts=2, split=False, offsets=offs[0])
     assert rel_rms(out, ref) < TOL, rel_rms(out, ref)
+
+
+def test_v3_then_v4_on_one_engine(A, g):
+    # loading a v4 net replaces the strided levels the v3 net was using: the v3 entry points must refuse, not run on them
+    from fractions import Fraction
+    from oracle import demucs_oracle as D
+    d = demixer(A)
+    d._load(0)
+    e = d.engine
+    y = e.hd_forward(g["x_c"])
+    assert rel_rms(y, g["y_c"]) < TOL
+    oc = D.HTConfig(channels=16, nfft=1024, depth=3, bottom_channels=128, t_layers=1, t_heads=2, samplerate=8000, segment=Fraction(1, 1))
+    e.load_ht(A.HTConfig(sources=tuple(oc.sources), channels=16, nfft=1024, depth=3, bottom_channels=128, t_layers=1, t_heads=2,
+                         samplerate=8000, segment=Fraction(1, 1)), D.make_ht_state(oc, 11))
+    with pytest.raises(RuntimeError, match="not committed"):
+        e.hd_forward(g["x_c"])
+    e.load_hd(hcfg(A, ocfg()), H.make_hd_state(ocfg(), 21))
+    with pytest.raises(RuntimeError, match="not committed"):
+        e.ht_forward(np.zeros((1, 2, 8000), np.float32))
+    assert rel_rms(e.hd_forward(g["x_c"]), g["y_c"]) < TOL
