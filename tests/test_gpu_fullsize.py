@@ -1,5 +1,5 @@
 """One unit of work at the PUBLIC model layouts (production tile shapes, FFT sizes, head dims -- the small golden
-configs cannot exercise them) against the CPU oracle: one htdemucs segment, one VR clip, one MDX23C chunk, one
+configs cannot exercise them) against the CPU oracle: one htdemucs segment, one hdemucs_mmi chunk, one VR clip, one MDX23C chunk, one
 BS-Roformer chunk (transformer depth cut to 2 of 12 to keep the CPU side short; every layer has the same shape)."""
 import os
 from fractions import Fraction
@@ -34,6 +34,20 @@ def test_htdemucs_segment(A):
     x = (0.3 * np.random.default_rng(0).standard_normal((1, 2, oc.training_length))).astype(np.float32)
     got = eng.ht_forward(x)
     want = D.ht_forward(x, sd, oc)
+    assert rel_rms(got, want) < TOL, rel_rms(got, want)
+
+
+def test_hdemucs_chunk(A):
+    # Demucs v3 at the hdemucs_mmi layout: BLSTM hidden 192 / 384 on overlapped frames (517 and 259 frames), LocalState head dims
+    # 48 / 96 on the flash kernel, odd length, batch 2 (two 16-sequence tiles share the recurrence launches)
+    from oracle import hdemucs_oracle as H
+    oc = H.HDConfig(segment=44)
+    sd = H.make_hd_state(oc, 0)
+    eng = A.Engine(A.MDXConfig(n_fft=4096, hop_length=1024, dim_f=2048, segment_size=8))
+    eng.load_hd(A.HDConfig(segment=44), sd)
+    x = (0.3 * np.random.default_rng(3).standard_normal((2, 2, 529201))).astype(np.float32)
+    got = eng.hd_forward(x)
+    want = H.hd_forward(x, sd, oc)
     assert rel_rms(got, want) < TOL, rel_rms(got, want)
 
 
