@@ -48,7 +48,7 @@ def model_capacity(nn_architecture: int):
         return [(2, 32), (2, 32), (34, 16, 1, 1, 0), (16, 32), (66, 32, 1, 1, 0), (32, 64), (64, 2, 1), (32, 2, 1), (32, 2, 1)]
     if nn_architecture in (537238, 537227):
         return [(2, 64), (2, 64), (66, 32, 1, 1, 0), (32, 64), (130, 64, 1, 1, 0), (64, 128), (128, 2, 1), (64, 2, 1), (64, 2, 1)]
-    raise NotImplementedError(f"VR architecture size {nn_architecture} is not a CascadedASPPNet (VR 5.1 models are not built)")
+    raise NotImplementedError(f"VR architecture size {nn_architecture} is not a CascadedASPPNet capacity table entry (VR 5.1 sizes take nout / nout_lstm instead)")
 
 
 def nn_arch_size_from_file(model_path: str) -> int:
