@@ -160,3 +160,20 @@ def test_v3_then_v4_on_one_engine(A, g):
     with pytest.raises(RuntimeError, match="not committed"):
         e.ht_forward(np.zeros((1, 2, 8000), np.float32))
     assert rel_rms(e.hd_forward(g["x_c"]), g["y_c"]) < TOL
+
+
+def test_joint_recurrences_across_lengths(A):
+    # 8-s chunks at 8 kHz are 250 frames: the two full chunks and the second chunk of each shift (235 / 231 frames) are framed BLSTM
+    # sequences of 200 steps in three groups of different length that share the recurrence launches at level A
+    # (hd_forward_groups); the short tails (47 / 43 frames) and everything at level Z (125 / 118 / 116 ... frames) run their own
+    # unframed recurrences -- five groups advance together
+    oc = H.HDConfig(channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, samplerate=8000, segment=8)
+    hc = A.HDConfig(sources=tuple(oc.sources), channels=8, nfft=1024, depth=5, norm_starts=3, dconv_attn=3, dconv_lstm=3, samplerate=8000,
+                    segment=8)
+    sd = H.make_hd_state(oc, 21)
+    d = A.DemucsDemixer({"torch_device": 0}, {"shifts": 2, "overlap": 0.25}, models=[(hc, sd)])
+    mix = (0.25 * np.random.default_rng(12).standard_normal((2, 105000)) + 0.01).astype(np.float32)
+    offs = [[1000, 2000]]
+    out = d.demix(mix, offsets=offs)
+    ref = H.demix_hdemucs(mix, sd, oc, shifts=2, overlap=0.25, offsets=offs[0])
+    assert rel_rms(out, ref) < TOL, rel_rms(out, ref)
