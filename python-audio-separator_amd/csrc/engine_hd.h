@@ -384,15 +384,26 @@ static int hd_blstm_joint(asx_engine *e, std::vector<HdGroup> &G, bool levelZ, s
   const int H = (levelZ ? h0.CZ : h0.CA) / h0.cfg.dconv_comp;
   std::map<int, std::vector<size_t>> by_steps;
   for (size_t gi = 0; gi < G.size(); ++gi) by_steps[levelZ ? G[gi].dm.stepsZ : G[gi].dm.stepsA].push_back(gi);
+  auto pad = [](size_t f) { return (f + 63) & ~(size_t)63; };
+  auto count = [&](const std::vector<size_t> &members) {
+    int N = 0;
+    for (size_t gi : members) N += G[gi].B * (levelZ ? G[gi].dm.nfrZ : G[gi].dm.nfrA);
+    return N;
+  };
+  {   // one allocation for the largest set, before anything of this call is in flight
+    size_t need = 0;
+    for (auto &kv : by_steps) {
+      const size_t N = (size_t)count(kv.second), rows = (size_t)kv.first * N;
+      need = std::max(need, pad(rows * H) + pad(rows * 8 * H) + pad(rows * 2 * H) + pad(4 * N * H) + pad(2 * N * H));
+    }
+    CHK(e->hd_lstm_ws.ensure(need * 4));
+  }
   for (auto &kv : by_steps) {
     const int steps = kv.first;
-    int N = 0;
-    for (size_t gi : kv.second) N += G[gi].B * (levelZ ? G[gi].dm.nfrZ : G[gi].dm.nfrA);
+    const int N = count(kv.second);
     const int64_t rows = (int64_t)steps * N;
-    auto pad = [](size_t f) { return (f + 63) & ~(size_t)63; };
     const size_t o_xs = 0, o_xp = o_xs + pad((size_t)rows * H), o_out = o_xp + pad((size_t)rows * 8 * H), o_hb = o_out + pad((size_t)rows * 2 * H),
-                 o_cst = o_hb + pad((size_t)4 * N * H), total = o_cst + pad((size_t)2 * N * H);
-    CHK(e->hd_lstm_ws.ensure(total * 4));
+                 o_cst = o_hb + pad((size_t)4 * N * H);
     float *xs = e->hd_lstm_ws.f() + o_xs, *xp = e->hd_lstm_ws.f() + o_xp, *out = e->hd_lstm_ws.f() + o_out, *hb = e->hd_lstm_ws.f() + o_hb,
           *cst = e->hd_lstm_ws.f() + o_cst;
     int n_off = 0;
