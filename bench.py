@@ -173,6 +173,19 @@ def main():
             res["parity_rel_rms_vs_cpu"] = float(f"{parity:.3e}")
         if prof is not None:
             res["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
+            # achieved roofline fraction of every stage: MFMA-shaped classes against the fp32 MFMA peak, the
+            # FFT / fold stages against HBM (algorithmic bytes / kernel time; spec 8 TB/s)
+            stages = {}
+            for k, v in prof.items():
+                if not v["launches"] or v["ms"] <= 0:
+                    continue
+                tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+                gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                if tf / PEAK_FP32_MFMA_TFLOPS >= gb / 8000.0:   # the roof the class sits closer to is the one that binds it
+                    stages[k] = {"bound": "mfma", "achieved": round(tf, 2), "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+                else:
+                    stages[k] = {"bound": "hbm", "achieved": round(gb, 1), "unit": "GB/s", "frac": round(gb / 8000.0, 4)}
+            res["stage_roofline"] = stages
         print(json.dumps(res))
     if use_dist:
         dist.barrier()
