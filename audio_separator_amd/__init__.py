@@ -13,3 +13,5 @@ from .onnx_reader import convtdf_from_onnx, OnnxFormatError  # noqa: E402,F401
 from .mdxc import MDXCDemixer  # noqa: E402,F401
 from .demucs import DemucsDemixer, hdconfig_from_kwargs, htconfig_from_kwargs  # noqa: E402,F401
 from .vr import VRDemixer, load_model_params, model_capacity  # noqa: E402,F401
+from .plugin import install, uninstall  # noqa: E402,F401
+from .common_separator import CommonSeparator  # noqa: E402,F401

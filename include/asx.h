@@ -36,7 +36,7 @@ extern "C" {
 #define ASX_ERR_HIP 2     /* a HIP runtime call failed (no GPU, OOM, launch) */
 #define ASX_ERR_STATE 3   /* call order violated (e.g. demix before commit)  */
 
-#define ASX_ABI_VERSION 1
+#define ASX_ABI_VERSION 2
 
 /* flags of asx_demix*(): */
 #define ASX_FLAG_MATCH_MIX 1u /* demix(mix, is_match_mix=True): overlap 0.02, no net (mdx_separator.py:308-313, :429-432) */
@@ -59,7 +59,7 @@ typedef struct asx_mdx_config {
   int32_t hop_length;
   int32_t dim_f;
   int32_t segment_size;
-  float overlap;
+  double overlap;       /* a Python float: step = int((1 - overlap) * chunk_size) is evaluated in double, mdx_separator.py:335 */
   int32_t enable_denoise;
   int32_t max_batch;
 } asx_mdx_config;
@@ -388,6 +388,11 @@ int asx_pcm16(asx_engine *e, const float *stem_host, int64_t n_samples, float ma
               int16_t *pcm_host, float *peak_after);
 int asx_pcm16_dev(asx_engine *e, const float *stem_dev, int64_t n_samples, float max_peak, float min_peak, int32_t has_min,
                   int16_t *pcm_dev, float *peak_after, void *stream);
+
+/* spec_utils.normalize(wave, max_peak, min_peak) (uvr_lib_v5/spec_utils.py:99-115) in place on any float32 array of
+ * `numel` values (MDXCSeparator.separate applies it to the mix and to every stem, mdxc_separator.py:147,170-190);
+ * *peak_before (optional) = max |wave| before scaling.  has_min_peak = 0 mirrors min_peak=None. */
+int asx_normalize(asx_engine *e, float *wave_host, int64_t numel, float max_peak, float min_peak, int32_t has_min, float *peak_before);
 
 /* Spectral edges, librosa STFT(2048, 1024) semantics:
  * asx_ensemble   = Ensembler.ensemble (audio_separator/separator/ensembler.py:12-160) over K equal-length stereo waves

@@ -2,3 +2,4 @@
 
 Imported through the ``audio_separator_amd`` shim at the repo root (this
 directory's name is not a valid Python identifier)."""
+

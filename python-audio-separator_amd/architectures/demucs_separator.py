@@ -1,0 +1,81 @@
+"""DemucsSeparator on the HIP engine: drop-in for audio_separator/separator/architectures/demucs_separator.py.
+
+Same constructor, ``separate`` / ``demix_demucs`` contract, source maps and output naming.  The model package
+(``.th`` + bag ``.yaml``, read without importing or executing any Demucs code -- model_files.py) is loaded once and
+kept resident instead of being re-read for every file (:119-124); ``apply_model`` with its shift trick, segment split
+and triangular fold, the HTDemucs / HDemucs forward and the standardise / de-standardise / stem swap of ``demix_demucs``
+(:162-194) are ``asx_ht_demix`` / ``asx_hd_demix``.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ..common_separator import CommonSeparator
+from ..demucs import DemucsDemixer
+
+DEMUCS_4_SOURCE = ["drums", "bass", "other", "vocals"]
+DEMUCS_2_SOURCE_MAPPER = {CommonSeparator.INST_STEM: 0, CommonSeparator.VOCAL_STEM: 1}
+DEMUCS_4_SOURCE_MAPPER = {CommonSeparator.BASS_STEM: 0, CommonSeparator.DRUM_STEM: 1, CommonSeparator.OTHER_STEM: 2,
+                          CommonSeparator.VOCAL_STEM: 3}
+DEMUCS_6_SOURCE_MAPPER = {CommonSeparator.BASS_STEM: 0, CommonSeparator.DRUM_STEM: 1, CommonSeparator.OTHER_STEM: 2,
+                          CommonSeparator.VOCAL_STEM: 3, CommonSeparator.GUITAR_STEM: 4, CommonSeparator.PIANO_STEM: 5}
+
+
+class DemucsSeparator(CommonSeparator):
+    def __init__(self, common_config, arch_config):
+        super().__init__(config=common_config)
+        self.segment_size = arch_config.get("segment_size", "Default")
+        self.shifts = arch_config.get("shifts", 2)
+        self.overlap = arch_config.get("overlap", 0.25)
+        self.segments_enabled = arch_config.get("segments_enabled", True)
+        self.logger.debug(f"Demucs arch params: segment_size={self.segment_size}, segments_enabled={self.segments_enabled}, "
+                          f"shifts={self.shifts}, overlap={self.overlap}")
+        self.demucs_source_map = DEMUCS_4_SOURCE_MAPPER
+        self.audio_file_path = None
+        self.audio_file_base = None
+        self.demucs_model_instance = None
+        self._common, self._arch = dict(common_config), dict(arch_config)
+        self._max_batch = int(arch_config.get("asx_max_batch", 0))
+        self.logger.info("Demucs Separator initialisation complete")
+
+    def load_model(self):
+        """demucs_separator.py:119-124 (get_demucs_model + demucs_segments + .to(device).eval()), done once."""
+        if self.demucs_model_instance is None:
+            common = dict(self._common)
+            common["logger"] = self.logger
+            self.demucs_model_instance = DemucsDemixer(common, self._arch, models=common.get("asx_models"),
+                                                       weights=common.get("asx_weights"), max_batch=self._max_batch)
+            self.demucs_model_instance._load(0)
+            self.engine = self.demucs_model_instance.engine
+        return self.demucs_model_instance
+
+    def demix_demucs(self, mix):
+        """demucs_separator.py:162-194: [2, N] -> [S, 2, N] with sources 0 / 1 swapped."""
+        dm = self.load_model()
+        dm.shifts, dm.overlap, dm.segments_enabled = self.shifts, self.overlap, self.segments_enabled
+        out = dm.demix(np.ascontiguousarray(mix, np.float32))
+        self.engine = dm.engine
+        return out
+
+    def separate(self, audio_file_path, custom_output_names=None):
+        """demucs_separator.py:83-160."""
+        self.audio_file_path = audio_file_path
+        self.audio_file_base = os.path.splitext(os.path.basename(audio_file_path))[0]
+        mix = self.prepare_mix(self.audio_file_path)
+        self.load_model()
+        source = self.demix_demucs(mix)
+        self.clear_gpu_cache()
+
+        n = len(source)
+        self.demucs_source_map = {2: DEMUCS_2_SOURCE_MAPPER, 6: DEMUCS_6_SOURCE_MAPPER}.get(n, DEMUCS_4_SOURCE_MAPPER)
+        output_files = []
+        for stem_name, stem_value in self.demucs_source_map.items():
+            if self.output_single_stem is not None and stem_name.lower() != self.output_single_stem.lower():
+                self.logger.debug(f"Skipping writing stem {stem_name} as output_single_stem is set to {self.output_single_stem}...")
+                continue
+            stem_path = self.get_stem_output_path(stem_name, custom_output_names)
+            self.final_process(stem_path, source[stem_value].T, stem_name)
+            output_files.append(stem_path)
+        return output_files

@@ -1,0 +1,129 @@
+"""MDXSeparator on the HIP engine: drop-in for audio_separator/separator/architectures/mdx_separator.py.
+
+Same constructor (``common_config``, ``arch_config``), attributes, ``load_model`` / ``separate`` / ``demix`` /
+``run_model`` / ``initialize_model_settings`` / ``initialize_mix`` contract, output naming and ``ValueError``s.
+``ort.InferenceSession(model_path)`` (:108-133) is replaced by the ONNX reader + ``asx_net_*``; the array work of
+``separate`` (:155-182) -- peak, in-place normalise, demix, ``* peak``, ``mix.T - compensate * primary`` -- is one C call
+(``asx_separate``) and the writer's normalise / int16 / interleave another (``asx_pcm16``).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ..common_separator import CommonSeparator
+from ..mdx import MDXDemixer
+
+
+class MDXSeparator(CommonSeparator):
+    def __init__(self, common_config, arch_config):
+        super().__init__(config=common_config)
+        self.segment_size = arch_config.get("segment_size")
+        self.overlap = arch_config.get("overlap")
+        self.batch_size = arch_config.get("batch_size", 1)
+        self.hop_length = arch_config.get("hop_length")
+        self.enable_denoise = arch_config.get("enable_denoise")
+        self.logger.debug(f"MDX arch params: batch_size={self.batch_size}, segment_size={self.segment_size}, overlap={self.overlap}, "
+                          f"hop_length={self.hop_length}, enable_denoise={self.enable_denoise}")
+        self.compensate = self.model_data["compensate"]
+        self.dim_f = self.model_data["mdx_dim_f_set"]
+        self.dim_t = 2 ** self.model_data["mdx_dim_t_set"]
+        self.n_fft = self.model_data["mdx_n_fft_scale_set"]
+        self.config_yaml = self.model_data.get("config_yaml", None)
+        # engine knob, not a reference option: chunks per device batch (results do not depend on it)
+        self._max_batch = int(arch_config.get("asx_max_batch", 0))
+        self._common, self._arch = dict(common_config), dict(arch_config)
+
+        self.load_model()
+
+        self.n_bins = 0
+        self.trim = 0
+        self.chunk_size = 0
+        self.gen_size = 0
+        self.stft = None
+        self.primary_source = None
+        self.secondary_source = None
+        self.audio_file_path = None
+        self.audio_file_base = None
+
+    def load_model(self):
+        """mdx_separator.py:108-133.  ``common_config["asx_state_dict"]`` (a ConvTDFNet state_dict, optional, with
+        ``asx_net_config``) bypasses the file for callers that hold the weights in memory."""
+        common = dict(self._common)
+        common["logger"] = self.logger
+        self._dm = MDXDemixer(common, self._arch, state_dict=common.get("asx_state_dict"),
+                              net_config=common.get("asx_net_config"), max_batch=self._max_batch)
+        self.engine = self._dm.engine
+        self.model_run = self._dm.engine.net_forward     # spek [B, 4, dim_f, dim_t] -> same (mdx_separator.py:123)
+
+    def initialize_model_settings(self):
+        """mdx_separator.py:205-228."""
+        self._dm.initialize_model_settings()
+        self.n_bins, self.trim = self._dm.n_bins, self._dm.trim
+        self.chunk_size, self.gen_size, self.stft = self._dm.chunk_size, self._dm.gen_size, self._dm.stft
+
+    def initialize_mix(self, mix, is_ckpt=False):
+        """mdx_separator.py:230-291 (unused by demix in the reference as well): chunk tensor + pad, as numpy."""
+        if mix.shape[0] != 2:
+            raise ValueError(f"Expected a 2-channel audio signal, but got {mix.shape[0]} channels")
+        self.initialize_model_settings()
+        n = mix.shape[-1]
+        if is_ckpt:
+            pad = self.gen_size + self.trim - (n % self.gen_size)
+            mixture = np.concatenate((np.zeros((2, self.trim), "float32"), mix, np.zeros((2, pad), "float32"),
+                                      np.zeros((2, self.trim), "float32")), 1)
+            waves = [mixture[:, i * self.gen_size: i * self.gen_size + self.chunk_size]
+                     for i in range(mixture.shape[-1] // self.gen_size)]
+        else:
+            pad = self.gen_size - n % self.gen_size
+            mix_p = np.concatenate((np.zeros((2, self.trim)), mix, np.zeros((2, pad)), np.zeros((2, self.trim))), 1)
+            waves, i = [], 0
+            while i < n + pad:
+                waves.append(np.array(mix_p[:, i: i + self.chunk_size]))
+                i += self.gen_size
+        return np.asarray(waves, dtype=np.float32), pad
+
+    def demix(self, mix, is_match_mix=False):
+        """mdx_separator.py:293-412: float32 [2, N] -> [2, N]."""
+        out = self._dm.demix(mix, is_match_mix=is_match_mix)
+        self.n_bins, self.trim = self._dm.n_bins, self._dm.trim
+        self.chunk_size, self.gen_size, self.stft = self._dm.chunk_size, self._dm.gen_size, self._dm.stft
+        return out
+
+    def run_model(self, mix, is_match_mix=False):
+        """mdx_separator.py:414-450."""
+        return self._dm.run_model(mix, is_match_mix=is_match_mix)
+
+    def separate(self, audio_file_path, custom_output_names=None):
+        """mdx_separator.py:135-203."""
+        self.audio_file_path = audio_file_path
+        self.audio_file_base = os.path.splitext(os.path.basename(audio_file_path))[0]
+        mix = self.prepare_mix(self.audio_file_path)
+        if mix.shape[0] != 2:
+            msg = f"Expected a 2-channel audio signal, but got {mix.shape[0]} channels"
+            self.logger.error(msg)
+            raise ValueError(msg)
+        mix = np.ascontiguousarray(mix, np.float32)
+        self.initialize_model_settings()
+        need_primary = not isinstance(self.primary_source, np.ndarray)
+        need_secondary = not isinstance(self.secondary_source, np.ndarray)
+        # peak / normalise(mix) in place / demix * peak / mix.T - compensate * primary (or invert_stem): MDXDemixer.separate_stems
+        primary, secondary = self._dm.separate_stems(mix)
+        if need_primary:
+            self.primary_source = primary
+        if need_secondary:
+            self.secondary_source = secondary
+
+        output_files = []
+        if not self.output_single_stem or self.output_single_stem.lower() == self.secondary_stem_name.lower():
+            self.secondary_stem_output_path = self.get_stem_output_path(self.secondary_stem_name, custom_output_names)
+            self.logger.info(f"Saving {self.secondary_stem_name} stem to {self.secondary_stem_output_path}...")
+            self.final_process(self.secondary_stem_output_path, self.secondary_source, self.secondary_stem_name)
+            output_files.append(self.secondary_stem_output_path)
+        if not self.output_single_stem or self.output_single_stem.lower() == self.primary_stem_name.lower():
+            self.primary_stem_output_path = self.get_stem_output_path(self.primary_stem_name, custom_output_names)
+            self.logger.info(f"Saving {self.primary_stem_name} stem to {self.primary_stem_output_path}...")
+            self.final_process(self.primary_stem_output_path, self.primary_source, self.primary_stem_name)
+            output_files.append(self.primary_stem_output_path)
+        return output_files

@@ -1,0 +1,137 @@
+"""MDXCSeparator on the HIP engine: drop-in for audio_separator/separator/architectures/mdxc_separator.py.
+
+TFC-TDF v3 (MDX23C) checkpoints and BS / Mel-Band Roformer checkpoints; same constructor, ``load_model`` / ``separate`` /
+``demix`` contract, stem dictionary, file naming and the "shorter than 10 s -> override_model_segment_size" rule
+(:131-138).  ``torch.load`` + ``load_state_dict`` (:76-116) become ``asx_v3_*`` / ``asx_rof_*``; ``spec_utils.normalize`` of
+the mix and of every stem (:147, :170-190) is ``asx_normalize``; the chunk loops are ``asx_mdxc_demix`` / ``asx_rof_demix``.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ..common_separator import CommonSeparator
+from ..mdxc import MDXCDemixer
+
+
+class MDXCSeparator(CommonSeparator):
+    def __init__(self, common_config, arch_config):
+        super().__init__(config=common_config)
+        self.segment_size = arch_config.get("segment_size", 256)
+        self.override_model_segment_size = arch_config.get("override_model_segment_size", False)
+        self.overlap = arch_config.get("overlap", 8)
+        self.batch_size = arch_config.get("batch_size", 1)
+        self.pitch_shift = arch_config.get("pitch_shift", 0)
+        self.process_all_stems = arch_config.get("process_all_stems", True)
+        self.logger.debug(f"MDXC arch params: batch_size={self.batch_size}, segment_size={self.segment_size}, overlap={self.overlap}, "
+                          f"override_model_segment_size={self.override_model_segment_size}, pitch_shift={self.pitch_shift}")
+        self.is_roformer = getattr(self, "is_roformer_model", False)
+        self._common, self._arch = dict(common_config), dict(arch_config)
+        self._max_batch = int(arch_config.get("asx_max_batch", 0))
+        self._demixers = {}                 # one engine per chunk geometry (override_model_segment_size may flip per file)
+
+        self.load_model()
+
+        self.primary_source = None
+        self.secondary_source = None
+        self.audio_file_path = None
+        self.audio_file_base = None
+        training = self.model_data.get("training", {}) or {}
+        self.is_primary_stem_main_target = bool(training.get("target_instrument"))
+        self.logger.info("MDXC Separator initialisation complete")
+
+    # ---- weights ---------------------------------------------------------------
+    def _demixer(self) -> MDXCDemixer:
+        key = bool(self.override_model_segment_size)
+        dm = self._demixers.get(key)
+        if dm is None:
+            common = dict(self._common)
+            common["logger"] = self.logger
+            common["primary_stem_name"], common["secondary_stem_name"] = self.primary_stem_name, self.secondary_stem_name
+            arch = dict(self._arch)
+            arch["override_model_segment_size"] = key
+            dm = MDXCDemixer(common, arch, state_dict=self._state_dict, max_batch=self._max_batch)
+            if self.roformer_loader is not None and getattr(dm, "roformer_loader", None) is not None:
+                self.roformer_loader._loading_stats = dm.roformer_loader.get_loading_stats()
+            self._demixers[key] = dm
+        dm.overlap = self.overlap
+        self.engine = dm.engine
+        return dm
+
+    def load_model(self):
+        """mdxc_separator.py:76-116: the checkpoint is read once; a failing / corrupt file exits like the reference."""
+        import sys
+        from ..model_files import read_state_dict
+        from ..roformer_config import read_checkpoint
+        self._state_dict = self._common.get("asx_state_dict")
+        try:
+            if self._state_dict is None:
+                self._state_dict = read_checkpoint(self.model_path) if self.is_roformer else read_state_dict(self.model_path)
+            self._demixer()
+        except RuntimeError as e:
+            self.logger.error(f"Error: {e}")
+            self.logger.error("An error occurred while loading the model file. This often occurs when the model file is corrupt or incomplete.")
+            self.logger.error(f"Please try deleting the model file from {self.model_path} and run audio-separator again to re-download it.")
+            sys.exit(1)
+
+    # ---- the path ----------------------------------------------------------------
+    def demix(self, mix: np.ndarray):
+        """mdxc_separator.py:257-468: dict of stems, or the primary array for a single-target model without residual."""
+        return self._demixer().demix(mix)
+
+    def separate(self, audio_file_path, custom_output_names=None):
+        """mdxc_separator.py:118-227."""
+        self.primary_source = None
+        self.secondary_source = None
+        self.audio_file_path = audio_file_path
+        self.audio_file_base = os.path.splitext(os.path.basename(audio_file_path))[0]
+        mix = self.prepare_mix(self.audio_file_path)
+
+        seconds = mix.shape[1] / self.sample_rate
+        if seconds < 10.0 and not self.override_model_segment_size:
+            self.override_model_segment_size = True
+            self.logger.warning(f"Audio duration ({seconds:.2f}s) is less than 10 seconds.")
+            self.logger.warning("Automatically enabling override_model_segment_size for better processing of short audio.")
+
+        dm = self._demixer()
+        eng = dm.engine
+        norm = lambda w: eng.normalize(w, self.normalization_threshold, self.amplification_threshold)   # noqa: E731
+        mix = norm(np.ascontiguousarray(mix, np.float32))
+        source = dm.demix(mix)
+
+        output_files = []
+        training = self.model_data.get("training", {}) or {}
+        if isinstance(source, dict):
+            stem_list = [training["target_instrument"]] if training.get("target_instrument") else list(training.get("instruments") or [])
+            if self.process_all_stems and len(stem_list) > 2:
+                for stem_name in stem_list:
+                    stem_output_path = self.get_stem_output_path(stem_name, custom_output_names)
+                    stem_source = norm(source[stem_name]).T
+                    self.logger.info(f"Saving {stem_name} stem to {stem_output_path}...")
+                    self.final_process(stem_output_path, stem_source, stem_name)
+                    output_files.append(stem_output_path)
+            else:
+                if not isinstance(self.primary_source, np.ndarray):
+                    self.primary_source = norm(source[self.primary_stem_name]).T
+                if not isinstance(self.secondary_source, np.ndarray):
+                    self.secondary_source = norm(source[self.secondary_stem_name]).T
+                if not self.output_single_stem or self.output_single_stem.lower() == self.secondary_stem_name.lower():
+                    self.secondary_stem_output_path = self.get_stem_output_path(self.secondary_stem_name, custom_output_names)
+                    self.logger.info(f"Saving {self.secondary_stem_name} stem to {self.secondary_stem_output_path}...")
+                    self.final_process(self.secondary_stem_output_path, self.secondary_source, self.secondary_stem_name)
+                    output_files.append(self.secondary_stem_output_path)
+                if not self.output_single_stem or self.output_single_stem.lower() == self.primary_stem_name.lower():
+                    self.primary_stem_output_path = self.get_stem_output_path(self.primary_stem_name, custom_output_names)
+                    self.logger.info(f"Saving {self.primary_stem_name} stem to {self.primary_stem_output_path}...")
+                    self.final_process(self.primary_stem_output_path, self.primary_source, self.primary_stem_name)
+                    output_files.append(self.primary_stem_output_path)
+        else:
+            if not self.output_single_stem or self.output_single_stem.lower() == self.primary_stem_name.lower():
+                self.primary_stem_output_path = self.get_stem_output_path(self.primary_stem_name, custom_output_names)
+                if not isinstance(self.primary_source, np.ndarray):
+                    self.primary_source = source.T
+                self.logger.info(f"Saving {self.primary_stem_name} stem to {self.primary_stem_output_path}...")
+                self.final_process(self.primary_stem_output_path, self.primary_source, self.primary_stem_name)
+                output_files.append(self.primary_stem_output_path)
+        return output_files

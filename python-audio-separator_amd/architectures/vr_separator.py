@@ -1,0 +1,166 @@
+"""VRSeparator on the HIP engine: drop-in for audio_separator/separator/architectures/vr_separator.py.
+
+Same constructor, attributes and ``separate`` contract (:115-253).  ``loading_mix`` / ``inference_vr`` / ``spec_to_wav``
+and the spec_utils functions under them are one C call (``asx_vr_separate``, vr.py:VRDemixer); the network is built and
+the ``.pth`` read once, at the first file, instead of at every ``separate`` (:158-178).
+
+Resampler: the reference's *synthesis* chain uses libsamplerate's ``sinc_fastest`` off macOS-ARM
+(uvr_lib_v5/spec_utils.py:33-38), and band entries may ask for ``sinc_*`` / ``kaiser_*`` on analysis; the engine has the
+``polyphase`` chain (the reference's ARM / MPS behaviour) and a windowed-sinc converter built from libsamplerate's
+published algorithm with a regenerated Kaiser table (``arch_config["asx_res_type"]``: "polyphase" | "sinc").  Neither
+is bit-comparable with libsamplerate's shipped coefficient table: see INTEGRATION.md "VR resampler" for the measured
+deviation.  A warning is logged once whenever the model parameters or the platform would have selected a libsamplerate
+converter in the reference.
+"""
+from __future__ import annotations
+
+import math
+import os
+import platform
+
+import numpy as np
+
+from .. import audio_io
+from ..common_separator import CommonSeparator
+from ..model_files import read_state_dict
+from ..vr import NN_ARCH_SIZES, VR_5_1, VRDemixer, load_model_params, reference_params_dir
+
+
+def reference_wav_resolution() -> str:
+    """spec_utils.py:33-38: the synthesis res_type the reference picks on this platform."""
+    if platform.system() == "Darwin":
+        arm = "arm" in platform.processor().lower() or "arm" in platform.platform().lower()
+        return "polyphase" if arm else "sinc_fastest"
+    return "sinc_fastest"
+
+
+class VRSeparator(CommonSeparator):
+    def __init__(self, common_config, arch_config: dict):
+        super().__init__(config=common_config)
+        self.model_capacity = 32, 128
+        self.is_vr_51_model = False
+        if "nout" in self.model_data.keys() and "nout_lstm" in self.model_data.keys():
+            self.model_capacity = self.model_data["nout"], self.model_data["nout_lstm"]
+            self.is_vr_51_model = True
+        params_dir = common_config.get("vr_params_dir") or reference_params_dir()
+        self.model_params_path = os.path.join(params_dir or "", f"{self.model_data['vr_model_param']}.json")
+        self.model_params = load_model_params(self.model_params_path)
+
+        self.enable_tta = arch_config.get("enable_tta", False)
+        self.enable_post_process = arch_config.get("enable_post_process", False)
+        self.post_process_threshold = arch_config.get("post_process_threshold", 0.2)
+        self.batch_size = arch_config.get("batch_size", 1)
+        self.window_size = arch_config.get("window_size", 512)
+        self.high_end_process = arch_config.get("high_end_process", False)
+        self.input_high_end_h = None
+        self.input_high_end = None
+        self.aggression = float(int(arch_config.get("aggression", 5)) / 100)
+        self.aggressiveness = {"value": self.aggression, "split_bin": self.model_params["band"][1]["crop_stop"],
+                               "aggr_correction": self.model_params.get("aggr_correction")}
+        self.model_samplerate = self.model_params["sr"]
+        self.res_type = arch_config.get("asx_res_type", "polyphase")
+        self._common, self._arch = dict(common_config), dict(arch_config)
+        self._dm = None
+        self.model_run = None
+        self.logger.debug(f"VR arch params: enable_tta={self.enable_tta}, enable_post_process={self.enable_post_process}, "
+                          f"post_process_threshold={self.post_process_threshold}, batch_size={self.batch_size}, "
+                          f"window_size={self.window_size}, high_end_process={self.high_end_process}, aggression={self.aggression}")
+        self.logger.info("VR Separator initialisation complete")
+
+    def _warn_resampler(self):
+        wanted = {reference_wav_resolution()} | {str(b.get("res_type")) for b in self.model_params["band"].values()}
+        foreign = sorted(w for w in wanted if w not in ("polyphase", "None"))
+        if foreign:
+            self.logger.warning(f"VR resampling: the reference would use {foreign} (libsamplerate / resampy) here; this engine runs "
+                                f"its '{self.res_type}' converter for every band.  Stems differ from the reference's by the "
+                                "converter's pass-band ripple (INTEGRATION.md, 'VR resampler').")
+
+    def load_model(self):
+        """vr_separator.py:158-178: architecture size from the file size, CascadedASPPNet / CascadedNet, load_state_dict."""
+        if self._dm is not None:
+            return self._dm
+        state_dict = self._common.get("asx_state_dict")
+        if state_dict is None:
+            model_size = math.ceil(os.stat(self.model_path).st_size / 1024)
+            nn_arch_size = min(NN_ARCH_SIZES, key=lambda x: abs(x - model_size))
+            state_dict = read_state_dict(self.model_path)
+        else:
+            nn_arch_size = self._common["asx_nn_arch_size"]
+        nn_arch_size = self._common.get("asx_nn_arch_size", nn_arch_size)
+        if nn_arch_size in VR_5_1 or self.is_vr_51_model:
+            self.is_vr_51_model = True
+        common = dict(self._common)
+        common.update(model_params=self.model_params, primary_stem_name=self.primary_stem_name, logger=self.logger)
+        self._dm = VRDemixer(common, self._arch, state_dict, nn_arch_size, capacity=self._common.get("asx_capacity"),
+                             max_batch=int(self._arch.get("asx_max_batch", 0)))
+        self.engine = self._dm.engine
+        self.model_run = self._dm.engine.vr_forward
+        self._warn_resampler()
+        return self._dm
+
+    def separate(self, audio_file_path, custom_output_names=None):
+        """vr_separator.py:115-253."""
+        self.primary_source = None
+        self.secondary_source = None
+        self.audio_file_path = audio_file_path
+        self.audio_file_base = os.path.splitext(os.path.basename(audio_file_path))[0]
+        try:
+            self.input_audio_subtype = audio_io.info(audio_file_path)["subtype"]
+            if "24" in self.input_audio_subtype:
+                self.wav_subtype, self.input_bit_depth = "PCM_24", 24
+            elif "32" in self.input_audio_subtype:
+                self.wav_subtype, self.input_bit_depth = "PCM_32", 32
+            else:
+                self.wav_subtype, self.input_bit_depth = "PCM_16", 16
+        except Exception as e:
+            self.logger.warning(f"Could not detect input audio bit depth: {e}. Defaulting to PCM_16")
+            self.wav_subtype, self.input_audio_subtype, self.input_bit_depth = "PCM_16", None, 16
+        self.input_subtype = self.input_audio_subtype
+
+        dm = self.load_model()
+        bands = self.model_params["band"]
+        top = bands[len(bands)]
+        # loading_mix (:255-291): the top band is the file decoded at the band's rate; everything below happens on the device
+        wave, _ = audio_io.load(audio_file_path, sr=top["sr"], mono=False)
+        if wave.ndim == 1:
+            wave = np.asarray([wave, wave])
+        wave = np.ascontiguousarray(wave, np.float32)
+
+        if self.output_single_stem and self.output_single_stem.lower() not in (self.primary_stem_name.lower(),
+                                                                               self.secondary_stem_name.lower()):
+            self.logger.warning(f"The output_single_stem setting '{self.output_single_stem}' does not match any of the output files: "
+                                f"'{self.primary_stem_name}' and '{self.secondary_stem_name}'. For this model '{self.model_name}', "
+                                "the output_single_stem setting will be ignored and all output files will be saved.")
+            self.output_single_stem = None
+
+        want_p = not self.output_single_stem or self.output_single_stem.lower() == self.primary_stem_name.lower()
+        want_s = not self.output_single_stem or self.output_single_stem.lower() == self.secondary_stem_name.lower()
+        primary, secondary = dm.separate_stems(wave, want_primary=want_p, want_secondary=want_s)
+
+        output_files = []
+        if want_p:
+            if not isinstance(self.primary_source, np.ndarray):
+                self.primary_source = self._to_44100(primary)
+            self.primary_stem_output_path = self.get_stem_output_path(self.primary_stem_name, custom_output_names)
+            self.logger.info(f"Saving {self.primary_stem_name} stem to {self.primary_stem_output_path}...")
+            self.final_process(self.primary_stem_output_path, self.primary_source, self.primary_stem_name)
+            output_files.append(self.primary_stem_output_path)
+        if want_s:
+            if not isinstance(self.secondary_source, np.ndarray):
+                self.secondary_source = self._to_44100(secondary)
+            self.secondary_stem_output_path = self.get_stem_output_path(self.secondary_stem_name, custom_output_names)
+            self.logger.info(f"Saving {self.secondary_stem_name} stem to {self.secondary_stem_output_path}...")
+            self.final_process(self.secondary_stem_output_path, self.secondary_source, self.secondary_stem_name)
+            output_files.append(self.secondary_stem_output_path)
+        return output_files
+
+    def _to_44100(self, stem):
+        """vr_separator.py:218-220, :238-240: models trained at another rate are brought back with librosa.resample's
+        default converter (soxr_hq) -- a host library the reference depends on; it is used when present."""
+        if self.model_samplerate == 44100:
+            return stem
+        librosa = audio_io._optional("librosa")
+        if librosa is None or not hasattr(librosa, "resample"):
+            raise NotImplementedError(f"model sample rate {self.model_samplerate} != 44100: the final librosa.resample "
+                                      "(soxr_hq) needs librosa, which is not installed")
+        return librosa.resample(stem.T, orig_sr=self.model_samplerate, target_sr=44100).T

@@ -1,0 +1,349 @@
+"""The plugin-surface base class: what ``Separator.load_model`` / ``_separate_file`` expect of a model instance.
+
+Mirror of audio_separator/separator/common_separator.py:CommonSeparator (reference file:line cited per member):
+same constructor key set (``common_config`` built at separator.py:867-886), same public attributes the orchestrator
+reads and writes (``output_dir`` separator.py:1087-1088, ``is_roformer_model`` / ``get_roformer_loading_stats`` :926-929,
+``write_audio`` :1379), same stem naming, same file naming and the same per-file state reset.  The sample
+arithmetic of the edges (``spec_utils.normalize``, int16 quantisation, channel interleave) runs in libasx.so through
+``self.engine``; decode / encode containers stay on the host (audio_io.py).  There is no CPU path for the arithmetic:
+a subclass without an engine cannot write audio.
+"""
+from __future__ import annotations
+
+import gc
+import logging
+import os
+import re
+
+import numpy as np
+
+from . import audio_io
+
+
+class CommonSeparator:
+    # stem vocabulary (common_separator.py:19-53): part of the naming contract of the output files
+    ALL_STEMS = "All Stems"
+    VOCAL_STEM = "Vocals"
+    INST_STEM = "Instrumental"
+    OTHER_STEM = "Other"
+    BASS_STEM = "Bass"
+    DRUM_STEM = "Drums"
+    GUITAR_STEM = "Guitar"
+    PIANO_STEM = "Piano"
+    SYNTH_STEM = "Synthesizer"
+    STRINGS_STEM = "Strings"
+    WOODWINDS_STEM = "Woodwinds"
+    BRASS_STEM = "Brass"
+    WIND_INST_STEM = "Wind Inst"
+    NO_STEM = "No "
+    NO_OTHER_STEM = "No Other"
+    NO_BASS_STEM = "No Bass"
+    NO_DRUM_STEM = "No Drums"
+    NO_GUITAR_STEM = "No Guitar"
+    NO_PIANO_STEM = "No Piano"
+    NO_SYNTH_STEM = "No Synthesizer"
+    NO_STRINGS_STEM = "No Strings"
+    NO_WOODWINDS_STEM = "No Woodwinds"
+    NO_WIND_INST_STEM = "No Wind Inst"
+    NO_BRASS_STEM = "No Brass"
+    PRIMARY_STEM = "Primary Stem"
+    SECONDARY_STEM = "Secondary Stem"
+    LEAD_VOCAL_STEM = "lead_only"
+    BV_VOCAL_STEM = "backing_only"
+    LEAD_VOCAL_STEM_I = "with_lead_vocals"
+    BV_VOCAL_STEM_I = "with_backing_vocals"
+    LEAD_VOCAL_STEM_LABEL = "Lead Vocals"
+    BV_VOCAL_STEM_LABEL = "Backing Vocals"
+
+    STEM_PAIR_MAPPER = {VOCAL_STEM: INST_STEM, INST_STEM: VOCAL_STEM, LEAD_VOCAL_STEM: BV_VOCAL_STEM,
+                        BV_VOCAL_STEM: LEAD_VOCAL_STEM, PRIMARY_STEM: SECONDARY_STEM}
+    NON_ACCOM_STEMS = (VOCAL_STEM, OTHER_STEM, BASS_STEM, DRUM_STEM, GUITAR_STEM, PIANO_STEM, SYNTH_STEM, STRINGS_STEM,
+                       WOODWINDS_STEM, BRASS_STEM, WIND_INST_STEM)
+
+    _CONFIG_KEYS = ("log_level", "torch_device", "torch_device_cpu", "torch_device_mps", "onnx_execution_provider",
+                    "model_name", "model_path", "model_data", "output_dir", "output_format", "output_bitrate",
+                    "normalization_threshold", "amplification_threshold", "enable_denoise", "output_single_stem",
+                    "invert_using_spec", "sample_rate", "use_soundfile")
+
+    def __init__(self, config: dict):
+        """common_separator.py:55-148."""
+        self.logger = config.get("logger") or logging.getLogger("audio_separator_amd")
+        for key in self._CONFIG_KEYS:
+            setattr(self, key, config.get(key))
+        if self.model_data is None:
+            self.model_data = {}
+        self.engine = None                       # the libasx.so handle; set by the architecture subclass
+
+        self.roformer_loader = None
+        self.is_roformer_model = self._detect_roformer_model()
+        if self.is_roformer_model:
+            self._initialize_roformer_loader()
+
+        self.primary_stem_name = None
+        self.secondary_stem_name = None
+        self.input_bit_depth = None
+        self.input_subtype = None
+
+        training = self.model_data.get("training") if isinstance(self.model_data, dict) else None
+        instruments = (training or {}).get("instruments") if isinstance(training, dict) else None
+        if instruments:
+            target = training.get("target_instrument")
+            # a target that is listed second names the model's actual output (common_separator.py:112-122)
+            if target and len(instruments) >= 2 and instruments[0] != target and instruments[1] == target:
+                self.primary_stem_name, self.secondary_stem_name = instruments[1], instruments[0]
+            else:
+                self.primary_stem_name = instruments[0]
+                self.secondary_stem_name = instruments[1] if len(instruments) > 1 else self.secondary_stem(instruments[0])
+        if self.primary_stem_name is None:
+            self.primary_stem_name = self.model_data.get("primary_stem", "Vocals")
+            self.secondary_stem_name = self.secondary_stem(self.primary_stem_name)
+
+        self.is_karaoke = self.model_data.get("is_karaoke", False)
+        self.is_bv_model = self.model_data.get("is_bv_model", False)
+        self.bv_model_rebalance = self.model_data.get("is_bv_model_rebalanced", 0)
+
+        self.logger.debug(f"Common params: model_name={self.model_name}, model_path={self.model_path}, "
+                          f"output_dir={self.output_dir}, output_format={self.output_format}")
+        self.logger.debug(f"Common params: primary_stem_name={self.primary_stem_name}, "
+                          f"secondary_stem_name={self.secondary_stem_name}")
+
+        self.audio_file_path = None
+        self.audio_file_base = None
+        self.primary_source = None
+        self.secondary_source = None
+        self.primary_stem_output_path = None
+        self.secondary_stem_output_path = None
+        self.cached_sources_map = {}
+
+    # ---- stem naming -------------------------------------------------------
+    def secondary_stem(self, primary_stem: str):
+        """common_separator.py:150-159."""
+        primary_stem = primary_stem if primary_stem else self.NO_STEM
+        if primary_stem in self.STEM_PAIR_MAPPER:
+            return self.STEM_PAIR_MAPPER[primary_stem]
+        if self.NO_STEM in primary_stem:
+            return primary_stem.replace(self.NO_STEM, "")
+        return f"{self.NO_STEM}{primary_stem}"
+
+    def separate(self, audio_file_path, custom_output_names=None):
+        raise NotImplementedError("This method should be overridden by subclasses.")
+
+    def final_process(self, stem_path, source, stem_name):
+        """common_separator.py:167-174."""
+        self.logger.debug(f"Finalizing {stem_name} stem processing and writing audio...")
+        self.write_audio(stem_path, source)
+        return {stem_name: source}
+
+    # ---- source cache (common_separator.py:176-215) -----------------------
+    def cached_sources_clear(self):
+        self.cached_sources_map = {}
+
+    def cached_source_callback(self, model_architecture, model_name=None):
+        model, sources = None, None
+        for key, value in self.cached_sources_map[model_architecture].items():
+            if model_name in key:
+                model, sources = key, value
+        return model, sources
+
+    def cached_model_source_holder(self, model_architecture, sources, model_name=None):
+        self.cached_sources_map[model_architecture] = {**self.cached_sources_map.get(model_architecture, {}),
+                                                       **{model_name: sources}}
+
+    # ---- decode edge -------------------------------------------------------
+    def _probe_bit_depth(self, path):
+        """common_separator.py:231-250: remember the input's sample format so the writer can keep it."""
+        try:
+            self.input_subtype = audio_io.info(path)["subtype"]
+            st = self.input_subtype
+            if "PCM_16" in st or st == "PCM_S8":
+                self.input_bit_depth = 16
+            elif "PCM_24" in st:
+                self.input_bit_depth = 24
+            elif "PCM_32" in st or "FLOAT" in st or "DOUBLE" in st:
+                self.input_bit_depth = 32
+            else:
+                self.input_bit_depth = 16
+                self.logger.warning(f"Unknown audio subtype {st}, defaulting to 16-bit output")
+            self.logger.info(f"Input audio subtype: {st}, bit depth: {self.input_bit_depth}")
+        except Exception as e:   # the reference swallows every failure here too
+            self.logger.warning(f"Could not read audio file info, defaulting to 16-bit output: {e}")
+            self.input_bit_depth, self.input_subtype = 16, "PCM_16"
+
+    def prepare_mix(self, mix):
+        """common_separator.py:217-282: path -> float32 [2, N] at ``sample_rate``; an ndarray [N, ch] is transposed;
+        mono is duplicated; an all-zero file raises ValueError."""
+        audio_path = mix
+        if not isinstance(mix, np.ndarray):
+            self._probe_bit_depth(mix)
+            mix, sr = audio_io.load(mix, mono=False, sr=self.sample_rate)
+            self.logger.debug(f"Audio loaded. Sample rate: {sr}, Audio shape: {mix.shape}")
+        else:
+            if self.input_bit_depth is None:
+                self.input_bit_depth, self.input_subtype = 16, "PCM_16"
+            mix = mix.T
+        if isinstance(audio_path, str) and not np.any(mix):
+            msg = f"Audio file {audio_path} is empty or not valid"
+            self.logger.error(msg)
+            raise ValueError(msg)
+        if mix.ndim == 1:
+            mix = np.asfortranarray([mix, mix])
+        return mix
+
+    # ---- encode edge -------------------------------------------------------
+    def _require_engine(self):
+        if self.engine is None:
+            raise RuntimeError("no libasx.so engine bound to this separator: the writer's normalise / quantise runs on the "
+                               "GPU and has no CPU path")
+        return self.engine
+
+    def write_audio(self, stem_path: str, stem_source):
+        """common_separator.py:284-303."""
+        if self.audio_file_path:
+            secs = audio_io.duration(self.audio_file_path)
+            self.logger.info(f"Audio duration is {secs / 3600:.2f} hours ({secs:.2f} seconds).")
+        if self.use_soundfile:
+            self.write_audio_soundfile(stem_path, stem_source)
+        else:
+            self.write_audio_pydub(stem_path, stem_source)
+
+    def _stereo_rows(self, stem_source):
+        a = np.asarray(stem_source)
+        if a.ndim != 2 or a.shape[1] != 2:
+            raise ValueError(f"write_audio expects a [N, 2] stem, got {a.shape}")
+        return a
+
+    def write_audio_pydub(self, stem_path: str, stem_source):
+        """common_separator.py:305-397.  normalize -> silence check -> (x * 32767).astype(int16) -> interleave is one
+        device pass (asx_pcm16, bit-exact); the container is written by pydub when it is installed, else by the
+        built-in WAV writer (int16 widened exactly like ffmpeg's s16 -> s32 / pcm_s24le conversion)."""
+        eng = self._require_engine()
+        a = self._stereo_rows(stem_source)
+        if a.dtype == np.int16:
+            pcm, peak = np.ascontiguousarray(a), float(np.abs(a).max()) if a.size else 0.0
+        else:
+            if a.shape[0] == 0:
+                self.logger.warning("Warning: stem_source array is near-silent or empty.")
+                return
+            pcm, peak = eng.pcm16(a, self.normalization_threshold, self.amplification_threshold)
+        if peak < 1e-6:
+            self.logger.warning("Warning: stem_source array is near-silent or empty.")
+            return
+        if self.output_dir:
+            os.makedirs(self.output_dir, exist_ok=True)
+            stem_path = os.path.join(self.output_dir, stem_path)
+        depth = self.input_bit_depth if self.input_bit_depth is not None else 16
+        self.logger.info(f"Writing output with {depth}-bit depth")
+        file_format = stem_path.lower().split(".")[-1]
+        pydub = audio_io._optional("pydub")
+        if pydub is not None and hasattr(pydub, "AudioSegment") and hasattr(pydub.AudioSegment, "export"):
+            seg = pydub.AudioSegment(pcm.reshape(-1).tobytes(), frame_rate=self.sample_rate, sample_width=2, channels=2)
+            fmt = {"m4a": "mp4", "mka": "matroska"}.get(file_format, file_format)
+            params = {"format": fmt}
+            bitrate = "320k" if fmt == "mp3" and self.output_bitrate is None else self.output_bitrate
+            if bitrate:
+                params["bitrate"] = bitrate
+            if fmt in ("wav", "flac"):
+                if depth == 16:
+                    params["parameters"] = ["-sample_fmt", "s16"]
+                else:
+                    params["parameters"] = ["-sample_fmt", "s32"]
+                    if fmt == "wav":
+                        params["codec"] = "pcm_s24le" if depth == 24 else "pcm_s32le"
+            try:
+                seg.export(stem_path, **params)
+            except (IOError, ValueError) as e:
+                self.logger.error(f"Error exporting audio file: {e}")
+            return
+        if file_format != "wav":
+            raise audio_io.AudioIOError(f"writing .{file_format} needs pydub + ffmpeg (not installed); WAV is built in")
+        audio_io.write_wav(stem_path, pcm, self.sample_rate, {16: "PCM_16", 24: "PCM_24", 32: "PCM_32"}.get(depth, "PCM_16"))
+
+    def write_audio_soundfile(self, stem_path: str, stem_source):
+        """common_separator.py:399-461: normalise (device), keep the input's subtype, hand floats to the container."""
+        eng = self._require_engine()
+        a = self._stereo_rows(stem_source)
+        if a.shape[0] == 0:
+            self.logger.warning("Warning: stem_source array is near-silent or empty.")
+            return
+        buf = eng.normalize(np.ascontiguousarray(a, np.float32), self.normalization_threshold, self.amplification_threshold)
+        if np.max(np.abs(buf)) < 1e-6:
+            self.logger.warning("Warning: stem_source array is near-silent or empty.")
+            return
+        if self.output_dir:
+            os.makedirs(self.output_dir, exist_ok=True)
+            stem_path = os.path.join(self.output_dir, stem_path)
+        if self.input_subtype:
+            subtype = self.input_subtype
+        elif self.input_bit_depth:
+            subtype = {16: "PCM_16", 24: "PCM_24", 32: "PCM_32"}.get(self.input_bit_depth, "PCM_16")
+        else:
+            subtype = "PCM_16"
+        sf = audio_io._optional("soundfile")
+        try:
+            if sf is not None and hasattr(sf, "write"):
+                sf.write(stem_path, buf, self.sample_rate, subtype=subtype)
+            else:
+                audio_io.write_wav(stem_path, buf, self.sample_rate, subtype)
+        except Exception as e:
+            self.logger.error(f"Error exporting audio file: {e}")
+
+    # ---- per-file state ------------------------------------------------------
+    def clear_gpu_cache(self):
+        """common_separator.py:463-474.  The engine's workspaces are sized once and reused across files (they are the
+        point of keeping 288 GB resident); only Python garbage and torch's caching allocator are trimmed."""
+        gc.collect()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.empty_cache()
+        except Exception:
+            pass
+
+    def clear_file_specific_paths(self):
+        """common_separator.py:476-489."""
+        self.logger.info("Clearing input audio file paths, sources and stems...")
+        self.audio_file_path = None
+        self.audio_file_base = None
+        self.primary_source = None
+        self.secondary_source = None
+        self.primary_stem_output_path = None
+        self.secondary_stem_output_path = None
+
+    # ---- file naming -------------------------------------------------------
+    def sanitize_filename(self, filename):
+        """common_separator.py:491-498."""
+        s = re.sub(r'[<>:"/\\|?*]', "_", filename)
+        s = re.sub(r"_+", "_", s)
+        return s.strip("_. ")
+
+    def get_stem_output_path(self, stem_name, custom_output_names):
+        """common_separator.py:500-519: names are relative to ``output_dir``."""
+        ext = self.output_format.lower()
+        if custom_output_names:
+            lowered = {k.lower(): v for k, v in custom_output_names.items()}
+            if stem_name.lower() in lowered:
+                return os.path.join(f"{self.sanitize_filename(lowered[stem_name.lower()])}.{ext}")
+        return os.path.join(f"{self.sanitize_filename(self.audio_file_base)}_({self.sanitize_filename(stem_name)})_"
+                            f"{self.sanitize_filename(self.model_name)}.{ext}")
+
+    # ---- Roformer hooks the orchestrator probes (separator.py:926-929) -------
+    def _detect_roformer_model(self):
+        """common_separator.py:521-543."""
+        if not self.model_data:
+            return False
+        if self.model_data.get("is_roformer", False):
+            return True
+        for text in (self.model_path, self.model_name):
+            if text and "roformer" in text.lower():
+                return True
+        return False
+
+    def _initialize_roformer_loader(self):
+        from .roformer_config import RoformerLoader
+        self.roformer_loader = RoformerLoader()
+
+    def get_roformer_loading_stats(self):
+        return self.roformer_loader.get_loading_stats() if self.roformer_loader else {}
+
+    def validate_roformer_config(self, config, model_type):
+        return self.roformer_loader.validate_configuration(config, model_type) if self.roformer_loader else True

@@ -769,7 +769,7 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
   REQUIRE(cfg->hop_length > 0 && cfg->segment_size >= 2, "bad hop_length/segment_size");
   REQUIRE(cfg->dim_f > 0 && cfg->dim_f <= cfg->n_fft / 2 + 1, "dim_f %d out of range for n_fft %d", cfg->dim_f,
           cfg->n_fft);
-  REQUIRE(cfg->overlap >= 0.f && cfg->overlap < 1.f, "overlap must be in [0,1)");
+  REQUIRE(cfg->overlap >= 0.0 && cfg->overlap < 1.0, "overlap must be in [0,1)");
   const int64_t C = (int64_t)cfg->hop_length * (cfg->segment_size - 1);
   REQUIRE(C > cfg->n_fft / 2, "chunk_size %lld must exceed n_fft/2 (reflect padding)", (long long)C);
   REQUIRE(C - cfg->n_fft > 0, "chunk_size %lld must exceed n_fft (gen_size > 0)", (long long)C);
@@ -1052,7 +1052,7 @@ int asx_plan_query(const asx_engine *e, int64_t N, uint32_t flags, asx_plan *out
   REQUIRE(N >= 1, "n_samples must be >= 1 (an empty mix raises in the reference, common_separator.py:267)");
   const bool match = (flags & ASX_FLAG_MATCH_MIX) != 0;
   // python: overlap is a float (double); 0.02 for the match-mix pass (mdx_separator.py:311)
-  const double overlap = match ? 0.02 : (double)e->cfg.overlap;
+  const double overlap = match ? 0.02 : e->cfg.overlap;
   asx_plan p{};
   p.n_samples = N;
   p.trim = e->cfg.n_fft / 2;
@@ -1070,7 +1070,7 @@ int asx_plan_query(const asx_engine *e, int64_t N, uint32_t flags, asx_plan *out
 
 // ---- chunk batches -----------------------------------------------------------
 static bool windowed_mode(const asx_engine *e, uint32_t flags) {
-  return (flags & ASX_FLAG_MATCH_MIX) ? true : (e->cfg.overlap != 0.f);
+  return (flags & ASX_FLAG_MATCH_MIX) ? true : (e->cfg.overlap != 0.0);
 }
 
 int asx_demix_chunks_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t k0, int32_t k1,
@@ -1241,6 +1241,36 @@ int asx_separate(asx_engine *e, float *mix_host, int64_t N, float max_peak, floa
   dmix.release();
   dp.release();
   ds.release();
+  return rc;
+}
+
+// spec_utils.normalize(wave, max_peak, min_peak) (uvr_lib_v5/spec_utils.py:99-115) on any float32 array, in place:
+// maxv = |wave|.max(); > max_peak: *= max_peak / maxv; else (min_peak given and maxv < min_peak): *= min_peak / maxv.
+int asx_normalize(asx_engine *e, float *wave_host, int64_t numel, float max_peak, float min_peak, int32_t has_min, float *peak_before) {
+  REQUIRE(e && wave_host && numel >= 1, "asx_normalize: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  CHK(e->d_peak.ensure(256));
+  DevBuf d;
+  int rc = d.ensure((size_t)numel * 4);
+  unsigned int *pk = reinterpret_cast<unsigned int *>(e->d_peak.p);
+  float maxv = 0.f;
+  const unsigned nb = (unsigned)std::min<int64_t>((numel + 255) / 256, 2048);
+  if (rc == ASX_OK && (hipMemcpy(d.p, wave_host, (size_t)numel * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                       hipMemsetAsync(pk, 0, 4, nullptr) != hipSuccess)) {
+    set_err("asx_normalize: H2D copy failed");
+    rc = ASX_ERR_HIP;
+  }
+  if (rc == ASX_OK) {
+    hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, nullptr, d.f(), numel, pk);
+    hipLaunchKernelGGL(normalize_kernel, dim3(nb), dim3(256), 0, nullptr, d.f(), numel, pk, max_peak, min_peak, has_min);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(&maxv, pk, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(wave_host, d.p, (size_t)numel * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      set_err("asx_normalize: device execution failed");
+      rc = ASX_ERR_HIP;
+    }
+  }
+  if (peak_before) *peak_before = maxv;
+  d.release();
   return rc;
 }
 

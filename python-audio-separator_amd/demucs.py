@@ -19,6 +19,7 @@ import random
 import numpy as np
 
 from .engine import Engine, HDConfig, HTConfig, MDXConfig
+from .mdx import _device_index
 
 
 def htconfig_from_kwargs(kwargs: dict, max_batch: int = 0) -> HTConfig:
@@ -64,18 +65,46 @@ def hdconfig_from_kwargs(kwargs: dict, max_batch: int = 0) -> HDConfig:
                     segment=k.get("segment", 40), max_batch=max_batch)
 
 
+def models_from_files(model_path: str, segment_size="Default", max_batch: int = 0):
+    """What DemucsSeparator.separate builds before demixing (architectures/demucs_separator.py:119-124):
+    ``get_demucs_model(name=<file stem>, repo=<file dir>)`` + ``demucs_segments(segment_size, model)``, as
+    ([(HTConfig | HDConfig, state_dict)], weights).
+
+    Segment rules kept from the reference: a bag's YAML ``segment`` overrides every member's (apply.py:52-53); an integer
+    ``segment_size`` then overrides every member of a *bag* (apply.py:274-279) -- for a single non-bag ``.th`` the
+    reference's branch raises NameError inside its bare ``try`` and leaves the model untouched (:280-292), as here."""
+    import os
+    from .model_files import get_demucs_model
+    name = os.path.splitext(os.path.basename(model_path))[0]
+    bag = get_demucs_model(name, os.path.dirname(os.path.abspath(model_path)))
+    segment = bag["segment"]
+    if bag["is_bag"] and segment_size not in ("Default", None):
+        try:
+            segment = int(segment_size)
+        except (TypeError, ValueError):
+            pass
+    models = []
+    for pkg in bag["models"]:
+        kw = dict(pkg["kwargs"])
+        if segment is not None:
+            kw["segment"] = segment
+        cfg = (htconfig_from_kwargs if pkg["kind"] == "HTDemucs" else hdconfig_from_kwargs)(kw, max_batch=max_batch)
+        models.append((cfg, pkg["state"]))
+    return models, bag["weights"]
+
+
 class DemucsDemixer:
-    def __init__(self, common_config: dict, arch_config: dict, models, weights=None):
-        """models: list of (HTConfig, state_dict); weights: per-model list of per-source weights (BagOfModels.weights)."""
+    def __init__(self, common_config: dict, arch_config: dict, models=None, weights=None, max_batch: int = 0):
+        """models: list of (HTConfig | HDConfig, state_dict); weights: per-model list of per-source weights
+        (BagOfModels.weights).  Without ``models`` they are read from ``common_config["model_path"]`` (a bag ``.yaml`` or a
+        ``.th`` package next to its siblings, models_from_files)."""
+        if models is None:
+            models, weights = models_from_files(common_config["model_path"], arch_config.get("segment_size", "Default"), max_batch)
         self.shifts = arch_config.get("shifts", 2)
         self.overlap = arch_config.get("overlap", 0.25)
         self.segments_enabled = arch_config.get("segments_enabled", True)
         self.segment_size = arch_config.get("segment_size", "Default")
-        if self.segment_size not in ("Default", None):
-            # demucs_segments (apply.py:263-300) never changes the model's segment (`segment` stays None on every path)
-            pass
-        dev = common_config.get("torch_device", 0)
-        self.device = getattr(dev, "index", dev) or 0
+        self.device = _device_index(common_config.get("torch_device", 0))
         self.models = list(models)
         if not self.models:
             raise ValueError("at least one (HTConfig, state_dict) model is required")

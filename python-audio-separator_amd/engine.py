@@ -29,7 +29,7 @@ def lib_path() -> str:
 
 class _MdxCfg(C.Structure):
     _fields_ = [("n_fft", C.c_int32), ("hop_length", C.c_int32), ("dim_f", C.c_int32), ("segment_size", C.c_int32),
-                ("overlap", C.c_float), ("enable_denoise", C.c_int32), ("max_batch", C.c_int32)]
+                ("overlap", C.c_double), ("enable_denoise", C.c_int32), ("max_batch", C.c_int32)]
 
 
 class _NetCfg(C.Structure):
@@ -223,7 +223,7 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
            "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev",
            "asx_hd_begin", "asx_hd_commit", "asx_hd_flops", "asx_hd_forward", "asx_hd_demix", "asx_hd_demix_dev", "asx_hd_plan",
-           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem"]
+           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize"]
 
 
 def load_library():
@@ -306,6 +306,7 @@ def load_library():
     lib.asx_ensemble_dev.argtypes = [vp, vp, i32, i64, i32, C.POINTER(C.c_double), vp, C.POINTER(i64), vp]
     lib.asx_invert_stem.argtypes = [vp, _FP, _FP, i64, _FP, C.POINTER(i64)]
     lib.asx_pcm16.argtypes = [vp, _FP, i64, C.c_float, C.c_float, i32, C.POINTER(C.c_int16), _FP]
+    lib.asx_normalize.argtypes = [vp, _FP, i64, C.c_float, C.c_float, i32, _FP]
     lib.asx_pcm16_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp, _FP, vp]
     lib.asx_mdxc_chunks_dev.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     lib.asx_mdxc_finalize_dev.argtypes = [vp, vp, i64, i32, vp, vp]
@@ -754,6 +755,20 @@ class Engine:
         self._check(self._lib.asx_pcm16(self._h, _ptr(planar), n, float(max_peak), float(min_peak or 0.0), int(min_peak is not None),
                                         out.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(pk)))
         return out, pk.value
+
+    def normalize(self, wave: np.ndarray, max_peak: float = 1.0, min_peak=None) -> np.ndarray:
+        """spec_utils.normalize (uvr_lib_v5/spec_utils.py:99-115): scales ``wave`` IN PLACE when it is a C-contiguous float32
+        array (like the reference, whose ``wave *= ...`` mutates the caller's array) and returns it."""
+        a = wave if (isinstance(wave, np.ndarray) and wave.dtype == np.float32 and wave.flags.c_contiguous) else None
+        buf = a if a is not None else np.ascontiguousarray(wave, np.float32)
+        if buf.size:
+            pk = C.c_float()
+            self._check(self._lib.asx_normalize(self._h, _ptr(buf), buf.size, float(max_peak), float(min_peak or 0.0),
+                                                int(min_peak is not None), C.byref(pk)))
+        if a is None and isinstance(wave, np.ndarray) and wave.dtype == np.float32:
+            wave[...] = buf                      # non-contiguous view (e.g. a transposed stem): write the result back
+            return wave
+        return buf
 
     ENSEMBLE_ALGORITHMS = ("avg_wave", "median_wave", "min_wave", "max_wave", "avg_fft", "median_fft", "min_fft", "max_fft",
                            "uvr_max_spec", "uvr_min_spec")

@@ -74,12 +74,16 @@ class STFT:
 
 
 def _device_index(device) -> int:
-    idx = getattr(device, "index", None)
-    if idx is not None:
-        return int(idx)
+    """GPU ordinal of ``common_config["torch_device"]``: a torch.device, "cuda" / "cuda:N", an int, or None (-> 0)."""
+    if isinstance(device, bool) or device is None:
+        return 0
     if isinstance(device, int):
         return device
-    return 0
+    if isinstance(device, str):
+        tail = device.rsplit(":", 1)[1] if ":" in device else ""
+        return int(tail) if tail.isdigit() else 0
+    idx = getattr(device, "index", None)
+    return int(idx) if isinstance(idx, int) else 0
 
 
 class MDXDemixer:
@@ -87,8 +91,9 @@ class MDXDemixer:
 
     ``common_config`` / ``arch_config`` carry the keys the reference's
     ``Separator.load_model`` builds (separator.py:867-886, :125).  The weights
-    come in as a ConvTDFNet state_dict (torch as the weight container) instead of
-    an ONNX path, because no ONNX reader ships yet.
+    come from the ``.onnx`` file at ``common_config["model_path"]`` (onnx_reader.py)
+    or, when given, from a ConvTDFNet ``state_dict`` (torch as the weight container).
+    The file-level plugin class on top of this is architectures/mdx_separator.py.
     """
 
     def __init__(self, common_config: dict, arch_config: dict, state_dict: dict | None = None,
@@ -177,8 +182,6 @@ class MDXDemixer:
         ``mix`` [2, N] is normalised in place like the reference's
         spec_utils.normalize call; returns (primary [N,2], secondary [N,2]).
         """
-        if self.invert_using_spec:
-            raise NotImplementedError("invert_using_spec (spec_utils.invert_stem) is outside the accelerated path")
         self.initialize_model_settings()
         if mix.ndim != 2 or mix.shape[0] != 2:
             raise ValueError(f"Expected a 2-channel audio signal, but got {mix.shape[0] if mix.ndim else 0} channels")
@@ -186,4 +189,9 @@ class MDXDemixer:
             raise ValueError("Audio file is empty or not valid")
         self.primary_source, self.secondary_source = self.engine.separate(
             mix, self.normalization_threshold, self.amplification_threshold, self.compensate)
+        if self.invert_using_spec:
+            # The reference hands primary to spec_utils.invert_stem as [N, 2] (mdx_separator.py:177-179), which cannot run
+            # (librosa.stft over a 2-sample axis, then a shape mismatch); the intended call -- stem as [2, N] -- runs here.
+            raw_mix = self.engine.demix(mix, is_match_mix=True)
+            self.secondary_source = self.engine.invert_stem(raw_mix, (self.primary_source * self.compensate).T)
         return self.primary_source, self.secondary_source

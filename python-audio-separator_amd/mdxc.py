@@ -1,8 +1,9 @@
-"""Host-side mirror of the MDXC plugin's TFC-TDF (MDX23C) demix path.
+"""Host-side mirror of the MDXC plugin's demix path: TFC-TDF v3 (MDX23C), BS-Roformer and Mel-Band Roformer models.
 
-Reference: architectures/mdxc_separator.py (MDXCSeparator.__init__ :22, load_model :76, demix
-:257 -- TFC branch :345-404 and the stem dictionary :406-468) and uvr_lib_v5/tfc_tdf_v3.py.
-The Roformer branch of the same class is not part of this mirror yet.  No CPU path.
+Reference: architectures/mdxc_separator.py (MDXCSeparator.__init__ :22, load_model :76, demix :257 -- Roformer branch
+:272-343, TFC branch :345-404, the stem dictionary :406-468), uvr_lib_v5/tfc_tdf_v3.py, uvr_lib_v5/roformer/*.py and the
+loader stack under roformer/ (roformer_config.py here).  Array level only; the file-level plugin class on top of this is
+architectures/mdxc_separator.py.  No CPU path.
 """
 from __future__ import annotations
 
@@ -80,7 +81,9 @@ class MDXCDemixer:
         if self.pitch_shift != 0:
             raise NotImplementedError("pitch_shift is outside the accelerated path")
         audio, model, training = (self.model_data.get(k, {}) for k in ("audio", "model", "training"))
-        self.is_roformer = bool(self.model_data.get("is_roformer"))
+        # CommonSeparator._detect_roformer_model (common_separator.py:521-543): the flag, or "roformer" in the path / name
+        self.is_roformer = bool(self.model_data.get("is_roformer")) or any(
+            t and "roformer" in str(t).lower() for t in (self.model_path, common_config.get("model_name")))
         self.instruments = list(training.get("instruments") or [])
         self.target_instrument = training.get("target_instrument")
         self.is_primary_stem_main_target = bool(self.target_instrument)
@@ -108,43 +111,48 @@ class MDXCDemixer:
             self.load_model(state_dict)
 
     def _init_roformer(self, audio, model, state_dict, max_batch):
-        """BS-Roformer (freqs_per_bands) and Mel-Band Roformer (num_bands) models (roformer_loader.py:123-195)."""
-        n_fft = model.get("stft_n_fft", 2048)
-        if model.get("stft_win_length", n_fft) != n_fft:
+        """BS-Roformer (freqs_per_bands) and Mel-Band Roformer (num_bands) models.  The constructor arguments are the ones
+        the reference's loader would pass (roformer_loader.py:123-195 after configuration_normalizer.py), quirks included."""
+        from .roformer_config import RoformerLoader
+        self.roformer_loader = getattr(self, "roformer_loader", None) or RoformerLoader()
+        res = self.roformer_loader.load_model(self.model_path or "", self.model_data, state_dict=state_dict)
+        if not res.success:
+            raise RuntimeError(res.error_message)
+        a = res.args
+        self._rof_state = res.state_dict
+        n_fft = a["stft_n_fft"]
+        if a["stft_win_length"] != n_fft:
             raise NotImplementedError("stft_win_length != stft_n_fft")
-        hop = model.get("stft_hop_length") or audio["hop_length"]           # mdxc_separator.py:289-296
-        mel = "freqs_per_bands" not in model
+        if a["stft_normalized"]:
+            raise NotImplementedError("stft_normalized=True")
+        # the chunk loop derives its hop from the raw YAML (mdxc_separator.py:289-296), the network from the normalised one
+        hop = model.get("stft_hop_length") or audio["hop_length"]
+        if int(hop) != int(a["stft_hop_length"]):
+            raise NotImplementedError(f"chunk hop {hop} differs from the model's stft_hop_length {a['stft_hop_length']}")
+        mel = res.model_type == "mel_band_roformer"
         if mel:
-            if "num_bands" not in model:
-                raise ValueError("Roformer model config has neither freqs_per_bands nor num_bands")
-            starts, counts = mel_band_layout(model.get("sample_rate", 44100), n_fft, model["num_bands"])
+            starts, counts = mel_band_layout(a["sample_rate"], n_fft, a["num_bands"])
         else:
-            starts, counts = (), tuple(model["freqs_per_bands"])
-        self.rof = RofConfig(dim=model["dim"], depth=model["depth"], heads=model.get("heads", 8),
-                             dim_head=model.get("dim_head", 64), num_stems=model.get("num_stems", 1 if mel else 2),
-                             time_transformer_depth=model.get("time_transformer_depth", 2),
-                             freq_transformer_depth=model.get("freq_transformer_depth", 2),
-                             mlp_expansion_factor=model.get("mlp_expansion_factor", 4),
-                             mask_estimator_depth=model.get("mask_estimator_depth", 1 if mel else 2),
+            starts, counts = (), tuple(a["freqs_per_bands"])
+        self.rof = RofConfig(dim=a["dim"], depth=a["depth"], heads=a["heads"], dim_head=a["dim_head"], num_stems=a["num_stems"],
+                             time_transformer_depth=a["time_transformer_depth"], freq_transformer_depth=a["freq_transformer_depth"],
+                             mlp_expansion_factor=a["mlp_expansion_factor"], mask_estimator_depth=a["mask_estimator_depth"],
                              freqs_per_bands=tuple(counts), n_out=max(1, len(self.instruments)), mel=mel,
                              band_starts=tuple(starts))
-        if not model.get("stereo", False):
+        if not a["stereo"]:
             raise NotImplementedError("mono Roformer models")
-        self.engine = Engine(MDXConfig(n_fft=n_fft, hop_length=hop, dim_f=n_fft // 2 + 1,
+        self.engine = Engine(MDXConfig(n_fft=n_fft, hop_length=int(hop), dim_f=n_fft // 2 + 1,
                                        segment_size=self.mdx_segment_size, overlap=0.0, max_batch=max_batch),
                              device=_device_index(self.torch_device))
-        if state_dict is not None or self.model_path:
-            self.load_model(state_dict)
+        if self._rof_state is not None:
+            self.load_model(self._rof_state)
 
     def load_model(self, state_dict: dict | None = None):
         """torch.load(model_path) + load_state_dict (mdxc_separator.py:107-110, roformer_loader.py:97-104)."""
         if state_dict is None:
-            import torch
-            state_dict = torch.load(self.model_path, map_location="cpu")
-            if isinstance(state_dict, dict) and "state_dict" in state_dict:
-                state_dict = state_dict["state_dict"]
-            elif isinstance(state_dict, dict) and "model" in state_dict:
-                state_dict = state_dict["model"]
+            from .model_files import read_state_dict
+            from .roformer_config import read_checkpoint
+            state_dict = read_checkpoint(self.model_path) if self.is_roformer else read_state_dict(self.model_path)
         if self.is_roformer:
             self.engine.load_rof(self.rof, state_dict)
         else:

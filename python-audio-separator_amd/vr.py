@@ -19,6 +19,7 @@ import os
 import numpy as np
 
 from .engine import Engine, MDXConfig
+from .mdx import _device_index
 
 NON_ACCOM_STEMS = ("Vocals", "Other", "Bass", "Drums", "Guitar", "Piano", "Synthesizer", "Strings", "Woodwinds", "Brass",
                    "Wind Inst")   # common_separator.py:46
@@ -51,6 +52,22 @@ def model_capacity(nn_architecture: int):
     raise NotImplementedError(f"VR architecture size {nn_architecture} is not a CascadedASPPNet capacity table entry (VR 5.1 sizes take nout / nout_lstm instead)")
 
 
+def reference_params_dir():
+    """Directory of the reference's VR model-parameter JSON files (uvr_lib_v5/vr_network/modelparams, the path
+    VRSeparator.__init__ builds at vr_separator.py:46-50).  The files are data of the installed ``audio_separator``
+    package this plugin is loaded into; they are looked up there, not copied.  None when the package is absent."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("audio_separator")
+    except (ImportError, ValueError):
+        spec = None
+    for root in (list(spec.submodule_search_locations) if spec and spec.submodule_search_locations else []):
+        d = os.path.join(root, "separator", "uvr_lib_v5", "vr_network", "modelparams")
+        if os.path.isdir(d):
+            return d
+    return os.environ.get("ASX_VR_PARAMS_DIR")
+
+
 def nn_arch_size_from_file(model_path: str) -> int:
     """vr_separator.py:161-164: nearest known size to ceil(file bytes / 1024)."""
     import math
@@ -74,7 +91,7 @@ class VRDemixer:
             offset = 64 if self.is_vr_51_model else 128        # nets_new.py:101 / nets.py:130
         mp = common_config.get("model_params")
         if mp is None:
-            here = common_config["vr_params_dir"]
+            here = common_config.get("vr_params_dir") or reference_params_dir() or ""
             mp = os.path.join(here, f"{md['vr_model_param']}.json")
         self.model_params = load_model_params(mp)
         self.primary_stem_name = common_config.get("primary_stem_name", md.get("primary_stem", "Instrumental"))
@@ -88,20 +105,22 @@ class VRDemixer:
         self.aggressiveness = {"value": self.aggression, "split_bin": self.model_params["band"][1]["crop_stop"],
                                "aggr_correction": self.model_params.get("aggr_correction")}
         self.model_samplerate = self.model_params["sr"]
-        dev = common_config.get("torch_device", 0)
         bins = self.model_params["bins"]
         self.engine = Engine(MDXConfig(n_fft=2 * bins, hop_length=bins // 2, dim_f=bins, segment_size=8),
-                             device=getattr(dev, "index", dev) or 0)
+                             device=_device_index(common_config.get("torch_device", 0)))
         self.engine.load_vr(self.model_params, nn_arch_size,
                             None if self.is_vr_51_model else (capacity or model_capacity(nn_arch_size)), state_dict,
                             window_size=self.window_size, offset=offset, max_batch=max_batch or max(self.batch_size, 4),
                             v51=self.model_capacity if self.is_vr_51_model else None)
 
-    def separate_stems(self, wave: np.ndarray):
-        """(primary_source, secondary_source) as [n', 2] arrays (vr_separator.py:211-236, before final_process)."""
+    def separate_stems(self, wave: np.ndarray, want_primary: bool = True, want_secondary: bool = True):
+        """(primary_source, secondary_source) as [n', 2] arrays (vr_separator.py:211-236, before final_process), at the
+        MODEL's sample rate ``self.model_samplerate``: for parameter sets with sr != 44100 the reference then calls
+        librosa.resample(..., target_sr=44100) (:218-220, :238-240), which the file-level VRSeparator does on the host.
+        A stem that is not wanted (output_single_stem) comes back as None."""
         p, s = self.engine.vr_separate(wave, self.aggressiveness["value"], self.aggressiveness["split_bin"],
                                        is_non_accom=self.primary_stem_name in NON_ACCOM_STEMS,
                                        aggr_correction=self.aggressiveness["aggr_correction"], enable_tta=self.enable_tta,
                                        enable_post_process=self.enable_post_process, post_thres=self.post_process_threshold,
                                        high_end_process=self.high_end_process)
-        return p.T, s.T
+        return (p.T if want_primary else None), (s.T if want_secondary else None)

@@ -267,6 +267,28 @@ def test_plan_matches_reference_arithmetic(A):
             (ref[0], ref[1], ref[2], ref[3], ref[4], len(ref[5]))
 
 
+@pytest.mark.parametrize("overlap", [0.1, 0.9, 0.05, 0.15, 0.2, 0.3, 0.4, 0.6, 0.001, 0.999])
+def test_plan_non_dyadic_overlap(A, overlap):
+    """step = int((1 - overlap) * chunk_size) in Python doubles (mdx_separator.py:335); float32 overlap would be off by one
+    (ADVICE r1): hop 1024 / seg 256 at overlap 0.1 is 235008, not 235007."""
+    eng = A.Engine(A.MDXConfig(overlap=overlap))
+    for N in (1000, 44100 * 30, 10_584_000):
+        ref = O.chunk_plan(N, O.MDXParams(overlap=overlap), False)
+        q = eng.plan(N)
+        assert (q["step"], q["n_chunks"], q["padded_len"]) == (ref[4], len(ref[5]), ref[3]), (overlap, N, q, ref[4])
+    if overlap == 0.1:
+        assert eng.plan(1000)["step"] == 235008
+
+
+@pytest.mark.parametrize("overlap", [0.1, 0.9])
+def test_demix_non_dyadic_overlap_vs_oracle(A, overlap):
+    eng, sd, d = small_engine(A, overlap=overlap)
+    mix = (0.4 * np.random.default_rng(77).standard_normal((2, 3000))).astype(np.float32)
+    ref = O.demix(mix, O.MDXParams(n_fft=96, hop_length=16, dim_f=32, segment_size=16, overlap=overlap), O.make_model_run(sd, d))
+    out = eng.demix(mix)
+    assert rel_rms(out, ref) < TOL_STEM, rel_rms(out, ref)
+
+
 def test_errors(A):
     eng, _, _ = small_engine(A)
     with pytest.raises(ValueError):
