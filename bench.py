@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the demix hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode files|chunks] [--songs-per-rank S]
 
-A "step" = one pass of the hot path (asx_demix_dev: chunking -> STFT -> ConvTDFNet
--> iSTFT -> Hann fold -> result/divider) over ONE 4-minute 44.1 kHz stereo song
-that is already resident in HBM, on the UVR-MDX-NET-Inst_HQ_3 geometry
-(n_fft 6144, hop 1024, dim_f 3072, segment 256, overlap 0.25; ConvTDFNet g=48,
-l=3, 11 blocks, bn=8) with seeded synthetic weights and input (no network for
-checkpoints or datasets).  All arithmetic is fp32 (fp32-input MFMA).
+A "step" = one pass of the hot path (asx_demix_dev: chunking -> STFT -> ConvTDFNet -> iSTFT -> Hann fold ->
+result/divider) over 4-minute 44.1 kHz stereo songs that are already resident in HBM, on the UVR-MDX-NET-Inst_HQ_3
+geometry (n_fft 6144, hop 1024, dim_f 3072, segment 256, overlap 0.25; ConvTDFNet g=48, l=3, 11 blocks, bn=8) with
+seeded synthetic weights and input (no network for checkpoints or datasets).  All arithmetic is fp32 (fp32-input MFMA).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank
-demixes its own song (weak scaling: config 5 shards files across GPUs) and the
-separated stems are gathered to rank 0 over xGMI inside the timed region.
+Ranks.  ``--gpus N`` with N > 1 launches N ranks itself (``python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ...``) unless it already runs under such a launcher (WORLD_SIZE set), in
+which case WORLD_SIZE must equal N -- anything else is an error, never a silent 1-rank run.  One rank per GPU, RCCL.
 
-Prints ONE JSON line on rank 0 (see the field notes in DESIGN.md).
+  --mode files  (default; BASELINE config 5; weak scaling) every rank demixes its own ``--songs-per-rank`` songs
+                (default 1; config 5 is 8 per rank on 8 GPUs = 64 songs) and the rank's stems go to rank 0 in ONE
+                gather per step over xGMI, inside the timed region; the gather of step k overlaps the compute of step
+                k + 1 (asynchronous collective on RCCL's stream, double-buffered stems).
+  --mode chunks (strong scaling) ONE song, its chunk list split across the ranks (sharding.sharded_demix): contiguous
+                chunk ranges, one gather of windowed chunks, fold on rank 0.
+
+``--dry-gloo`` replaces the GPU work by a copy and RCCL by gloo so that the launcher / rendezvous / collective plumbing
+can be exercised on a CPU-only box (tests/test_bench_launcher.py); its line says ``"dry": true`` and carries no rate.
+
+Prints ONE JSON line on rank 0 (field notes in DESIGN.md 4).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +41,7 @@ SR = 44100
 SONG_SECONDS = 240
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 METRIC = "audio-sec separated / wall-sec (RTF), UVR-MDX-NET 44.1kHz stereo, 1/2/4/8 GPU"
+PMC_FILES = ("r02_pmc_conv3x3.json", "r01_pmc_conv3x3.json")
 
 
 def cpu_baseline(seconds: float, seed: int):
@@ -54,33 +65,74 @@ def cpu_baseline(seconds: float, seed: int):
                                 f"{dt:.1f} s wall"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=("files", "chunks"), default="files")
+    ap.add_argument("--songs-per-rank", type=int, default=1)
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--seconds", type=float, default=SONG_SECONDS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the CPU-baseline sample (0 = skip)")
-    args = ap.parse_args()
+    ap.add_argument("--siblings", type=int, default=1, help="1: append short htdemucs / BS-Roformer / VR / hdemucs lines (N = 1 only)")
+    ap.add_argument("--no-overlap", action="store_true", help="blocking gather (A/B of the gather / compute overlap)")
+    ap.add_argument("--dry-gloo", action="store_true")
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """Re-exec under torch.distributed.run with one rank per GPU."""
+    port = args.master_port or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["ASX_BENCH_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(self_launch(args))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}; refusing to report a mislabelled run")
 
     import torch
     import torch.distributed as dist
+    if args.dry_gloo:
+        return dry_run(args, world, rank)
+
     from oracle import mdx_oracle as O           # synthetic weights/input generator + cpu_baseline leg only
     import audio_separator_amd as A
+    from audio_separator_amd.sharding import HipEngineAdapter, sharded_demix
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} visible")
     # BENCH_FORCE_DIST=1 exercises the RCCL code path (init, gather, all_reduce, barrier) with a single rank
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    torch.cuda.set_device(local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+        assert dist.get_world_size() == args.gpus
     dev = torch.device("cuda", local_rank)
 
     # ---- engine + synthetic model --------------------------------------------------------
@@ -89,28 +141,60 @@ def main():
     eng = A.Engine(A.MDXConfig(max_batch=args.max_batch), device=local_rank)
     eng.load_net(A.NetConfig(), A.fold_convtdf_state(sd, d.num_blocks, d.l))
     N = int(SR * args.seconds)
-    mix = torch.from_numpy(O.synth_mix(N, seed=rank)).to(dev)       # resident in HBM before timing
-    out = torch.empty_like(mix)
-    gathered = [torch.empty_like(out) for _ in range(world)] if (use_dist and rank == 0) else None
+    S = args.songs_per_rank if args.mode == "files" else 1
     stream = torch.cuda.current_stream().cuda_stream
     plan = eng.plan(N)
+    if args.mode == "files":
+        # resident in HBM before timing: S songs per rank, seeds rank * S + s (64 distinct songs at 8 x 8)
+        mixes = [torch.from_numpy(O.synth_mix(N, seed=rank * S + s)).to(dev) for s in range(S)]
+        outs = [torch.empty((S, 2, N), dtype=torch.float32, device=dev) for _ in range(2)]
+        gathered = [[torch.empty_like(outs[0]) for _ in range(world)] for _ in range(2)] if (use_dist and rank == 0) else [None, None]
+        pending = [None, None]
 
-    def step():
-        eng.demix_dev(mix.data_ptr(), N, out.data_ptr(), stream=stream)
-        if use_dist:
-            dist.gather(out, gathered, dst=0)
+        def step(k):
+            b = k & 1
+            if pending[b] is not None:
+                pending[b].wait()                 # the stems buffer is free again once its gather has drained
+                pending[b] = None
+            for s in range(S):
+                eng.demix_dev(mixes[s].data_ptr(), N, outs[b][s].data_ptr(), stream=stream)
+            if use_dist:
+                if args.no_overlap:
+                    dist.gather(outs[b], gathered[b], dst=0)
+                else:
+                    pending[b] = dist.gather(outs[b], gathered[b], dst=0, async_op=True)
+
+        def drain():
+            for b in (0, 1):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
+        songs_per_step = world * S
+        scaling = "weak"
+    else:
+        mix = torch.from_numpy(O.synth_mix(N, seed=0)).to(dev)           # the same song on every rank
+        adapter = HipEngineAdapter(eng)
+
+        def step(k):
+            sharded_demix(adapter, mix)
+
+        def drain():
+            pass
+        songs_per_step = 1
+        scaling = "strong"
 
     def fence():
+        drain()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -118,28 +202,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * args.seconds * args.steps / dt
+    value = songs_per_step * args.seconds * args.steps / dt
 
     # ---- roofline of the dominant kernel (3x3 TFC conv, MFMA bound), HIP events on the launch stream ----
     roofline = None
     prof = None
     if rank == 0:
+        m0 = mixes[0] if args.mode == "files" else mix
+        o0 = torch.empty_like(m0)
         eng.profile_enable(True)
-        eng.demix_dev(mix.data_ptr(), N, out.data_ptr(), stream=stream)
+        eng.demix_dev(m0.data_ptr(), N, o0.data_ptr(), stream=stream)
         prof = eng.profile_read()
         eng.profile_enable(False)
         c = prof["conv3x3"]
         ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
-        # HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the gfx950
-        # correction + WRITE_SIZE), scaled by this run's algorithmic bytes per launch
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_conv3x3.json")
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as fh:
-                traffic = round(json.load(fh)["traffic_over_algorithmic"] * c["bytes"] / max(1, c["launches"]), 1)
+        # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 around the process).  The ratio
+        # traffic / algorithmic bytes comes from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the gfx950
+        # correction + WRITE_SIZE) and is applied to this run's algorithmic bytes per launch; traffic_source says so.
+        traffic, source = None, None
+        for name in PMC_FILES:
+            pmc_path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc_path):
+                with open(pmc_path) as fh:
+                    traffic = round(json.load(fh)["traffic_over_algorithmic"] * c["bytes"] / max(1, c["launches"]), 1)
+                source = f"stored: profiles/{name} (rocprofv3 --pmc passes), ratio applied to this run's algorithmic bytes"
+                break
         roofline = {"kernel": "conv_dma_kernel<3,3,1,1,3,8,2,0> (TFC 3x3 convs)", "bound": "mfma", "achieved": round(ach, 2),
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": c["bytes"] / max(1, c["launches"]),
+                    "traffic": traffic, "traffic_source": source,
+                    "algorithmic_bytes_per_launch": c["bytes"] / max(1, c["launches"]),
                     "launches": c["launches"],
                     "avg_launch_ms": round(c["ms"] / max(1, c["launches"]), 4),
                     "flops_per_launch": c["flops"] / max(1, c["launches"]),
@@ -155,18 +246,22 @@ def main():
         cpu["value"] = round(cpu["value"], 3)
 
     if rank == 0:
+        par = (f"files sharded over {world} GPU(s), {S} song(s) per rank" + (", stems gathered to rank 0 (one RCCL gather per step"
+               + (", blocking" if args.no_overlap else ", overlapped with the next step's compute") + ")" if world > 1 else "")) \
+            if args.mode == "files" else f"chunks of one song sharded over {world} GPU(s), one RCCL gather of windowed chunks, fold on rank 0"
         res = {
             "metric": METRIC, "value": round(value, 2), "unit": "audio-s/wall-s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "UVR-MDX-NET-Inst_HQ_3 geometry (n_fft 6144, hop 1024, dim_f 3072, segment 256, "
                                    "overlap 0.25; ConvTDFNet g48 l3 11 blocks bn8, synthetic weights), "
-                                   f"{args.seconds:g}-s 44.1 kHz stereo song per GPU, input resident in HBM",
-                       "samples_per_song": N, "chunks_per_song": plan["n_chunks"],
-                       "songs_per_step": world, "parallelism": f"files sharded over {world} GPU(s)"
-                       + (", stems gathered to rank 0 (RCCL)" if world > 1 else ""),
+                                   f"{args.seconds:g}-s 44.1 kHz stereo song(s), input resident in HBM",
+                       "mode": args.mode, "samples_per_song": N, "chunks_per_song": plan["n_chunks"],
+                       "songs_per_step": songs_per_step, "parallelism": par,
                        "samples_per_s": round(value * SR * 2, 1),
-                       "net_tflops_per_s": round(eng.net_flops(plan["n_chunks"]) * world * args.steps / dt / 1e12, 2)},
+                       "net_tflops_per_s": round(eng.net_flops(plan["n_chunks"]) * songs_per_step * args.steps / dt / 1e12, 2)},
+            "rccl": {"world_size": dist.get_world_size() if use_dist else 1, "backend": dist.get_backend() if use_dist else None,
+                     "launcher": "self" if os.environ.get("ASX_BENCH_LAUNCHED") == "1" else ("external" if "WORLD_SIZE" in os.environ else None)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if parity is not None:
@@ -186,9 +281,66 @@ def main():
                 else:
                     stages[k] = {"bound": "hbm", "achieved": round(gb, 1), "unit": "GB/s", "frac": round(gb / 8000.0, 4)}
             res["stage_roofline"] = stages
+        if world == 1 and args.siblings:
+            eng.close()
+            res["siblings"] = sibling_lines(args)
         print(json.dumps(res))
     if use_dist:
         dist.barrier()
+        dist.destroy_process_group()
+
+
+def sibling_lines(args):
+    """Short runs of the sibling segment loops (BASELINE configs 0, 2, 3 + hdemucs_mmi) after the timed region, so that
+    their rates are observed by whoever runs bench.py and not only claimed: 1 warm-up + 2 steps of a 4-minute song each,
+    roofline fraction of the dominant kernel class from the in-engine hipEvent profile.  Not part of `value`."""
+    import types
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_siblings as BS
+    out = {}
+    a = types.SimpleNamespace(seconds=float(SONG_SECONDS), steps=2, warmup=1, cpu=0)
+    for name, fn in (("htdemucs", BS.run_htdemucs), ("bs_roformer", BS.run_roformer), ("vr", BS.run_vr), ("hdemucs_mmi", BS.run_hdemucs)):
+        try:
+            r = fn(a)
+            out[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
+                         "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "unit", "frac", "share_of_step_ms")},
+                         "net_tflops_per_s": r["config"].get("net_tflops_per_s")}
+        except Exception as e:                      # a sibling must never take the headline line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    return out
+
+
+def dry_run(args, world, rank):
+    """Launcher / rendezvous / collective plumbing on CPU (gloo); no GPU, no engine, no rate."""
+    import torch
+    import torch.distributed as dist
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 4096
+    S = args.songs_per_rank
+    mixes = torch.full((S, 2, n), float(rank))
+    gathered = [torch.empty_like(mixes) for _ in range(world)] if rank == 0 else None
+    for _ in range(args.warmup + args.steps):
+        out = mixes.clone()
+        if use_dist:
+            dist.gather(out, gathered, dst=0)
+    ok = True
+    if use_dist:
+        dist.barrier()
+        if rank == 0:
+            ok = all(float(g[0, 0, 0]) == float(r) for r, g in enumerate(gathered))
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry": True, "mode": args.mode, "gather_ok": ok,
+                          "rccl": {"world_size": dist.get_world_size() if use_dist else 1, "backend": "gloo" if use_dist else None,
+                                   "launcher": "self" if os.environ.get("ASX_BENCH_LAUNCHED") == "1" else
+                                   ("external" if "WORLD_SIZE" in os.environ else None)}}))
+    if use_dist:
         dist.destroy_process_group()
 
 

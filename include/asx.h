@@ -2,11 +2,15 @@
  * asx.h -- C ABI of the MI355X-native demix engine (libasx.so).
  *
  * Drop-in boundary for ONE hot path of nomadkaraoke/python-audio-separator: the
- * chunked-spectrogram demix loop of the MDX architecture plugin
- * (audio_separator/separator/architectures/mdx_separator.py, MDXSeparator.demix
- * :293-412 and run_model :414-450, with uvr_lib_v5/stft.py:20-126 and the
- * ConvTDFNet graph of uvr_lib_v5/mdxnet.py:30-120 that the reference executes
- * through onnxruntime at mdx_separator.py:122-123).
+ * chunked-spectrogram demix loop behind its architecture plugins.  Primary: the MDX
+ * plugin (audio_separator/separator/architectures/mdx_separator.py, MDXSeparator.demix
+ * :293-412 and run_model :414-450, with uvr_lib_v5/stft.py:20-126 and the ConvTDFNet
+ * graph of uvr_lib_v5/mdxnet.py:30-120 that the reference executes through onnxruntime
+ * at mdx_separator.py:122-123).  Sibling loops behind the same handle: MDXC (TFC-TDF v3,
+ * BS / Mel-Band Roformer: mdxc_separator.py:257-468), Demucs v4 / v3
+ * (demucs_separator.py:162-194, uvr_lib_v5/demucs/apply.py:124-260), VR
+ * (vr_separator.py:255-375), and the normalise / quantise / ensemble / invert edges
+ * (common_separator.py:309-337, ensembler.py, uvr_lib_v5/spec_utils.py:99,573).
  *
  * Plain C: pointers and sizes only, no torch/STL types.  Every function returns
  * ASX_OK (0) or a positive error code and never throws; the message of the last
@@ -18,7 +22,11 @@
  * reference object is not re-entrant either).  "host" pointers are
  * pageable or pinned host memory, "dev" pointers are HIP device pointers on the
  * engine's GPU.  `stream` is a hipStream_t passed as void* (NULL = the null
- * stream); *_dev entry points are asynchronous with respect to the host.
+ * stream).  asx_demix_dev / asx_demix_chunks_dev / asx_finalize_dev / asx_separate_dev and the
+ * asx_mdxc_*_dev calls only enqueue work on `stream` once the engine's workspace has reached its
+ * size (first call): no host copy, no host synchronisation -- they can be captured into a hipGraph and a
+ * collective on step k can overlap the compute of step k + 1.  The Roformer / Demucs / VR *_dev calls
+ * upload small index tables from the host and synchronise `stream` once per call.
  *
  * All audio is float32.  Layouts are C-order.
  */

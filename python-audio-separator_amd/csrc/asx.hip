@@ -1069,6 +1069,16 @@ int asx_plan_query(const asx_engine *e, int64_t N, uint32_t flags, asx_plan *out
 }
 
 // ---- chunk batches -----------------------------------------------------------
+__global__ void chunk_table_kernel(int k0, int nk, int64_t step, int64_t chunk, int64_t padded_len, int win,
+                                   int64_t *__restrict__ starts, int64_t *__restrict__ nact) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nk) return;
+  const int64_t st = (int64_t)(k0 + i) * step;
+  const int64_t na = chunk < padded_len - st ? chunk : padded_len - st;
+  starts[i] = st;
+  nact[i] = win ? na : -1;
+}
+
 static bool windowed_mode(const asx_engine *e, uint32_t flags) {
   return (flags & ASX_FLAG_MATCH_MIX) ? true : (e->cfg.overlap != 0.0);
 }
@@ -1093,20 +1103,15 @@ int asx_demix_chunks_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t
   const int nbatch = (nk + maxB - 1) / maxB;
   const int per = (nk + nbatch - 1) / nbatch;
   CHK(ensure_workspace(e, per, need_net));
-  // chunk tables
-  std::vector<int64_t> starts(nk), nact(nk);
+  // chunk tables, built on the device: start of chunk k = k * step, active length = min(chunk, L - start), or negative
+  // for "no chunk window" (overlap == 0, mdx_separator.py:389-390).  No host copy, no host synchronisation: the call
+  // only enqueues work on `stream` (hipGraph-capturable, and a gather of step k can overlap the compute of step k + 1).
   const bool win = windowed_mode(e, flags);
-  for (int i = 0; i < nk; ++i) {
-    const int64_t st = (int64_t)(k0 + i) * p.step;
-    starts[i] = st;
-    const int64_t na = std::min<int64_t>(p.chunk_size, p.padded_len - st);
-    nact[i] = win ? na : -1;  // negative: no chunk window (overlap == 0, mdx_separator.py:389-390)
-  }
   CHK(e->d_starts.ensure((size_t)nk * 8));
   CHK(e->d_nact.ensure((size_t)nk * 8));
-  HIPCHK(hipMemcpyAsync(e->d_starts.p, starts.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(e->d_nact.p, nact.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));  // host vectors go out of scope
+  hipLaunchKernelGGL(chunk_table_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, k0, nk, p.step, p.chunk_size,
+                     p.padded_len, win ? 1 : 0, reinterpret_cast<int64_t *>(e->d_starts.p), reinterpret_cast<int64_t *>(e->d_nact.p));
+  HIPCHK(hipGetLastError());
   const int T = e->cfg.segment_size;
   const int64_t C = p.chunk_size;
   const size_t spec_elems = (size_t)4 * T * e->cfg.dim_f;
@@ -1623,11 +1628,10 @@ int asx_mdxc_chunks_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t 
   const int S = n.cfg.num_targets;
   const int64_t C = p.chunk_size;
   const int nk = k1 - k0;
-  std::vector<int64_t> starts(nk);
-  for (int k = 0; k < nk; ++k) starts[k] = (int64_t)(k0 + k) * p.step;
-  CHK(n.d_starts.ensure((size_t)nk * 8));
-  HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));
+  CHK(n.d_starts.ensure((size_t)nk * 16));   // starts | (unused) active lengths, built on the device: no host sync
+  hipLaunchKernelGGL(chunk_table_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, k0, nk, p.step, p.chunk_size,
+                     p.padded_len, 0, reinterpret_cast<int64_t *>(n.d_starts.p), reinterpret_cast<int64_t *>(n.d_starts.p) + nk);
+  HIPCHK(hipGetLastError());
   const int maxB = e->cfg.max_batch > 0 ? e->cfg.max_batch : 8;
   const int nbatch = (nk + maxB - 1) / maxB;
   const int per = (nk + nbatch - 1) / nbatch;

@@ -144,7 +144,8 @@ def sharded_demix(adapter, mix, group=None, dst: int = 0):
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    rank = dist.get_rank(group) if dist.is_initialized() else 0          # position inside the group: picks the chunk range
+    is_dst = (dist.get_rank() == dst) if dist.is_initialized() else True  # `dst` is a GLOBAL rank, like dist.gather's
     n = mix.shape[-1]
     plan = adapter.plan(n)
     nk, C = plan["n_chunks"], plan["chunk_size"]
@@ -164,9 +165,9 @@ def sharded_demix(adapter, mix, group=None, dst: int = 0):
         out = torch.empty(oshape, dtype=torch.float32, device=mix.device)
         adapter.finalize(local[:nk], n, out)
         return out
-    slabs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    slabs = [torch.empty_like(local) for _ in range(world)] if is_dst else None
     dist.gather(local, slabs, dst=dst, group=group)
-    if rank != dst:
+    if not is_dst:
         return None
     allc = torch.cat([slabs[r][: b - a] for r, (a, b) in enumerate(ranges)], dim=0)
     out = torch.empty(oshape, dtype=torch.float32, device=mix.device)
