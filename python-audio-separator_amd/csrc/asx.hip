@@ -21,6 +21,10 @@
 #include "../../include/asx.h"
 #include "kernels_fft.h"
 #include "kernels_net.h"
+#include "kernels_gemm2.h"
+#ifndef ASX_TDF2_DEFAULT
+#define ASX_TDF2_DEFAULT 0
+#endif
 #include "kernels_rof.h"
 #include "kernels_ht.h"
 #include "kernels_hd.h"
@@ -528,8 +532,59 @@ static void launch_tdf_dma_t(const TdfDmaArgs &a, hipStream_t s) {
 // bytes per flop, charged as 4 %.  Measured: N = 512 out-proj / FF2 of BS-Roformer 103 -> 111 TFLOP/s (a third 192-wide tile
 // would be 1/3 empty); HTDemucs transformer linears (43 k rows, N = 384 .. 1536) 73 -> 92 TFLOP/s.
 // ASX_GEMM_T128=0 forces 128 x 192, =2 forces 128 x 128 (tuning aid).
+// second-generation row GEMM (kernels_gemm2.h).  ASX_TDF2: 0 = tdf_dma_kernel only, 1 = tdf2 one tile per workgroup,
+// 2 = + persistent over the column tiles of a row tile on short-K layers, 3 = + start stagger (ASX_TDF2_SBIT: block-id bit).
+static int tdf2_mode() {
+  static const int m = getenv("ASX_TDF2") ? atoi(getenv("ASX_TDF2")) : ASX_TDF2_DEFAULT;
+  return m;
+}
+static bool tdf2_ok(const TdfDmaArgs &d) {
+  auto a16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int64_t lda = d.lda ? d.lda : d.K, ldy = d.ldy ? d.ldy : d.N, ldr = d.ldr ? d.ldr : d.N;
+  return tdf2_mode() > 0 && d.K % 32 == 0 && d.K >= 32 && d.M % 8 == 0 && d.M >= 8 && d.M < (1ll << 31) && d.T > 0 && d.C > 0 && d.N % 8 == 0 && d.N >= 8 && lda % 4 == 0 &&
+         ldy % 4 == 0 && ldr % 4 == 0 && a16(d.x) && a16(d.w) && a16(d.y) && (!d.res || a16(d.res)) && (!d.bias || a16(d.bias)) &&
+         (uint64_t)8 * (uint64_t)lda * 4 < (1ull << 31) && (uint64_t)8 * (uint64_t)d.K * 4 < (1ull << 31);
+}
+template <int NREP, int MREP, int ABL>
+static void launch_tdf2_abl(const TdfDmaArgs &a, hipStream_t s) {
+  using CFG = TdfDmaCfg<NREP, MREP, 32>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tdf2_kernel<NREP, MREP, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              CFG::LDS_BYTES);
+    attr_done = true;
+  }
+  static const int sbit = getenv("ASX_TDF2_SBIT") ? atoi(getenv("ASX_TDF2_SBIT")) : 8;
+  const int64_t nbm = (a.M + CFG::BM - 1) / CFG::BM;
+  const int nbn = (a.N + CFG::BN - 1) / CFG::BN;
+  const int mode = tdf2_mode();
+  // persistent over the column tiles when the K loop is short (prologue / epilogue are a visible share of a tile) and the
+  // row tiles alone fill the 512 workgroup slots several times over
+  const bool persist = mode >= 2 && nbn >= 2 && a.K <= 768 && nbm >= 2048;
+  const int tiles = persist ? nbn : 1;
+  hipLaunchKernelGGL((tdf2_kernel<NREP, MREP, ABL>), dim3((unsigned)(nbm * (nbn / tiles))), dim3(256), CFG::LDS_BYTES, s, a, tiles,
+                     (mode >= 3 && persist) ? sbit : -1);
+}
+template <int NREP, int MREP>
+static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
+  static const int abl = getenv("ASX_TDF2_ABL") ? atoi(getenv("ASX_TDF2_ABL")) : 0;   // ablation builds exist for the 128 x 192 tile only
+  if constexpr (NREP == 3 && MREP == 8) {
+    switch (abl) {
+      case 1: return launch_tdf2_abl<3, 8, 1>(a, s);
+      case 2: return launch_tdf2_abl<3, 8, 2>(a, s);
+      case 3: return launch_tdf2_abl<3, 8, 3>(a, s);
+      case 4: return launch_tdf2_abl<3, 8, 4>(a, s);
+      case 5: return launch_tdf2_abl<3, 8, 5>(a, s);
+      case 7: return launch_tdf2_abl<3, 8, 7>(a, s);
+      default: break;
+    }
+  }
+  launch_tdf2_abl<NREP, MREP, 0>(a, s);
+}
+
 static void launch_tdf_dma_auto(const TdfDmaArgs &d, hipStream_t s) {
   static const int t128 = getenv("ASX_GEMM_T128") ? atoi(getenv("ASX_GEMM_T128")) : 1;
+  const bool v2 = tdf2_ok(d);
   if (d.N > 128) {
     const double rows = (double)((d.M + 127) / 128);
     auto cost = [&](int bn, double eff) {
@@ -537,10 +592,10 @@ static void launch_tdf_dma_auto(const TdfDmaArgs &d, hipStream_t s) {
       return ceil(blocks / 512.0) * bn / eff;
     };
     const bool narrow = t128 == 2 || (t128 == 1 && cost(128, 0.96) < cost(192, 1.0));
-    if (narrow) launch_tdf_dma_t<2, 8>(d, s);
-    else launch_tdf_dma_t<3, 8>(d, s);
+    if (narrow) v2 ? launch_tdf2<2, 8>(d, s) : launch_tdf_dma_t<2, 8>(d, s);
+    else v2 ? launch_tdf2<3, 8>(d, s) : launch_tdf_dma_t<3, 8>(d, s);
   } else if (d.N > 64) {
-    launch_tdf_dma_t<2, 4>(d, s);
+    v2 ? launch_tdf2<2, 4>(d, s) : launch_tdf_dma_t<2, 4>(d, s);
   } else {
     launch_tdf_dma_t<1, 4>(d, s);
   }

@@ -1,0 +1,254 @@
+// Row GEMM  y[M,N] = act(scale * (x[M,K] . W[N,K]^T + bias) + shift) (+ res), second generation of tdf_dma_kernel
+// (kernels_net.h) for the TDF blocks of ConvTDFNet (uvr_lib_v5/modules.py:57-74) and every other nn.Linear on the path.
+//
+// Same tile (128 x 64*NREP x 32), same unpadded XOR-swizzled LDS image, same fp32 MFMA fragment maps and the same
+// accumulation order per output element as tdf_dma_kernel -- results are bit-identical -- but the stage loop is
+// rebuilt around what the round-1 counters showed (72 % MFMA-busy on K = 384, 82 % on K = 3072):
+//   * fragment reads are software-pipelined by hand: the ds_read_b128 of group g+1 are issued before the 48 MFMAs of
+//     group g (hipcc had placed them 2-4 MFMAs before their s_waitcnt, exposing the LDS latency four times a stage);
+//   * the global->LDS DMA of the next stage is addressed as SGPR base + one constant 32-bit lane offset
+//     (`global_load_lds_dwordx4 v, s[..]`): no per-lane 64-bit pointer arithmetic, no predicates, no branches in the
+//     stage loop -- row groups past M / N are clamped to the last valid group and masked in the epilogue;
+//   * optionally PERSISTENT over the column tiles of one row tile (short-K layers, e.g. Linear(F/8 -> F)): the first
+//     stage of column tile j+1 is in flight while tile j runs its epilogue, and the x tile stays hot in L2;
+//   * optional start stagger of half a tile for every second workgroup, so that the two co-resident workgroups of a
+//     CU do not reach their (MFMA-idle) epilogues together.
+// Preconditions (else the launcher falls back to tdf_dma_kernel): K % 32 == 0, M % 8 == 0, N % 8 == 0, 16-byte aligned rows.
+#pragma once
+#include "kernels_net.h"
+
+namespace asx {
+
+// ABL (ASX_TDF2_ABL, measurement-only instantiations, results are garbage): 1 = no DMA after the first stage, 2 = no MFMA,
+// 4 = no epilogue traffic
+template <int NREP, int MREP, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_per_wg, int stagger_bit) {
+  constexpr int abl = ABL;
+  using CFG = TdfDmaCfg<NREP, MREP, 32>;
+  constexpr int BK = 32, BM = CFG::BM, BN = CFG::BN, BUF = CFG::BUF;
+  constexpr int XPW = BM / 32, WPW = BN / 32;        // 1-KiB DMA pieces (8 rows x 32 floats) per wave and stage
+  constexpr int MG = MREP / 4, NG = 2 * MG;          // MFMA groups per stage: (kk = 0, 1) x (row quads)
+  static_assert(BM % 32 == 0 && BN % 32 == 0 && MREP % 4 == 0, "tile shape");
+  extern __shared__ float lds_f[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+
+  const int nbn = (a.N + BN - 1) / BN;
+  const int groups = nbn / tiles_per_wg;             // launcher: tiles_per_wg divides nbn
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bg = lid % groups;
+  const int64_t m0 = (int64_t)(lid / groups) * BM;
+  const int64_t lda = a.lda ? a.lda : a.K, ldy = a.ldy ? a.ldy : a.N, ldr = a.ldr ? a.ldr : a.N;
+  const int nk = a.K / BK;
+  const int total = nk * tiles_per_wg;
+
+  if (stagger_bit >= 0 && ((blockIdx.x >> stagger_bit) & 1)) {
+    // half a tile of MFMA time: nk stages x 192 MFMAs x 32 cycles / 2, in s_sleep units of 64 cycles
+    const int naps = (nk * NREP * MREP * 8 * 32 / 2) / (64 * 100);
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(100);
+  }
+
+  // ---- DMA addressing: piece q = wave + 4 i covers tile rows 8 q .. 8 q + 7; lane (lr, lp) fetches the 16-byte chunk that
+  // lands in physical slot lp of row lr, i.e. logical chunk lp ^ g(row) with g(row) = (row >> 1) & 7 = (4 (wave & 1) + (lr >> 1)) & 7
+  const int lr = lane >> 3, lp = lane & 7;
+  const int gsw = (((wave & 1) << 2) + (lr >> 1)) & 7;
+  const uint32_t voff_x = (uint32_t)((lr * lda + ((lp ^ gsw) << 2)) * 4);
+  const uint32_t voff_w = (uint32_t)(((int64_t)lr * a.K + ((lp ^ gsw) << 2)) * 4);
+  const char *xrow[XPW];
+#pragma unroll
+  for (int i = 0; i < XPW; ++i) {
+    int64_t r = m0 + 8 * (wave + 4 * i);
+    r = r < a.M - 8 ? r : a.M - 8;                    // clamp whole row groups; masked at the store
+    xrow[i] = reinterpret_cast<const char *>(a.x) + r * lda * 4;
+  }
+
+  const char *wrow[WPW];
+  auto set_wrows = [&](int n0) {                      // once per column tile
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+      int r = n0 + 8 * (wave + 4 * i);
+      r = r < a.N - 8 ? r : a.N - 8;
+      wrow[i] = reinterpret_cast<const char *>(a.w) + ((int64_t)r * a.K) * 4;
+    }
+  };
+  auto issue = [&](int ks, int buf) {
+    float *xs = lds_f + buf * BUF;
+    float *ws = xs + BM * BK;
+    const int kb = ks * (BK * 4);
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) ASX_GLDS16(xrow[i] + kb + voff_x, xs + (wave + 4 * i) * 256);
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) ASX_GLDS16(wrow[i] + kb + voff_w, ws + (wave + 4 * i) * 256);
+  };
+
+  f32x4 acc[NREP][MREP];
+#pragma unroll
+  for (int n = 0; n < NREP; ++n)
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int sw = (li >> 1) & 7;                       // g(row) of fragment rows 16 t + li
+  const int pc0 = ((lk ^ sw) << 2), pc1 = (((4 + lk) ^ sw) << 2);
+  const int wrow_f = (wave * 16 * NREP + li) * BK;
+  const int xrw = li * BK;
+
+  int it_ks = 0, it_tile = 0;                         // cursor of the stage being issued (runs one ahead)
+  set_wrows((bg * tiles_per_wg) * BN);
+  issue(0, 0);
+  it_ks = 1;
+  if (it_ks == nk) {
+    it_ks = 0;
+    it_tile = 1;
+    if (tiles_per_wg > 1) set_wrows((bg * tiles_per_wg + 1) * BN);
+  }
+
+  int ks = 0, tile = 0;
+  for (int it = 0; it < total; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const float *xs = lds_f + (it & 1) * BUF;
+    const float *ws = xs + BM * BK;
+    f32x4 wa[2][NREP], xb[2][4];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) wa[0][n] = *reinterpret_cast<const f32x4 *>(&ws[wrow_f + n * 16 * BK + pc0]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) xb[0][m] = *reinterpret_cast<const f32x4 *>(&xs[xrw + m * 16 * BK + pc0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 1 < total) {
+      if constexpr (!(abl & 1)) issue(it_ks, (it + 1) & 1);
+      if (++it_ks == nk) {
+        it_ks = 0;
+        ++it_tile;
+        if (it_tile < tiles_per_wg) set_wrows((bg * tiles_per_wg + it_tile) * BN);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int kk = g / MG, mg = (g % MG) * 4;
+      // the group's first MFMA carries the (free) wait for operands that were requested a whole group ago; the requests
+      // for group g + 1 follow it, so their latency hides under the group's remaining MFMAs
+      // (it reads the LAST registers of the group's request batch: LDS returns in order, so one wait covers the batch)
+      if constexpr ((abl & 2) != 0) {
+        acc[NREP - 1][mg + 3] += wa[kk & 1][NREP - 1] + xb[g & 1][3];
+      } else {
+        acc[NREP - 1][mg + 3] = ASX_MFMA(wa[kk & 1][NREP - 1][0], xb[g & 1][3][0], acc[NREP - 1][mg + 3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < NG) {
+        const int kk1 = (g + 1) / MG, mg1 = ((g + 1) % MG) * 4;
+        const int pc = kk1 ? pc1 : pc0;
+        if (kk1 != kk) {
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) wa[kk1 & 1][n] = *reinterpret_cast<const f32x4 *>(&ws[wrow_f + n * 16 * BK + pc]);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xb[(g + 1) & 1][m] = *reinterpret_cast<const f32x4 *>(&xs[xrw + (mg1 + m) * 16 * BK + pc]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((abl & 2) != 0) {
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[n][mg + m] += wa[kk & 1][n] * xb[g & 1][m];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              if (j || n != NREP - 1 || m != 3) acc[n][mg + m] = ASX_MFMA(wa[kk & 1][n][j], xb[g & 1][m][j], acc[n][mg + m]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++ks < nk) continue;
+    ks = 0;
+
+    // ---- epilogue of column tile `tile` (the next tile's first stage is already in flight) -------------------------------
+    const int n0 = (bg * tiles_per_wg + tile) * BN;
+    ++tile;
+    const bool full = (m0 + BM <= a.M) && (n0 + BN <= a.N);
+    if constexpr ((abl & 4) != 0) {
+      float chk = 0.f;
+#pragma unroll
+      for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          chk += acc[n][m].x + acc[n][m].y + acc[n][m].z + acc[n][m].w;
+          acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      if (chk == 1.2345e-30f) a.y[0] = chk;
+    } else
+    if (full) {
+      f32x4 bz[NREP];
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) {
+        const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+        bz[n] = (a.bias != nullptr) ? *reinterpret_cast<const f32x4 *>(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int mg = 0; mg < MREP; mg += 2) {            // two 16-row groups at a time: 2 x NREP residual vectors in flight
+        float sc[2], sh[2];
+        f32x4 rs[2][NREP];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int64_t row = m0 + (mg + m) * 16 + li;
+          const int c = (int)(((uint32_t)row / (uint32_t)a.T) % (uint32_t)a.C);   // launcher: M < 2^31 on this kernel
+          sc[m] = a.scale ? a.scale[c] : 1.f;
+          sh[m] = a.shift ? a.shift[c] : 0.f;
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) {
+            const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+            rs[m][n] = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(a.res + row * ldr + col)
+                                          : (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int64_t row = m0 + (mg + m) * 16 + li;
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) {
+            const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+            const f32x4 v = acc[n][mg + m];
+            f32x4 o;
+            o.x = tdf_act(sc[m] * (v.x + bz[n].x) + sh[m], a.relu) + rs[m][n].x;
+            o.y = tdf_act(sc[m] * (v.y + bz[n].y) + sh[m], a.relu) + rs[m][n].y;
+            o.z = tdf_act(sc[m] * (v.z + bz[n].z) + sh[m], a.relu) + rs[m][n].z;
+            o.w = tdf_act(sc[m] * (v.w + bz[n].w) + sh[m], a.relu) + rs[m][n].w;
+            *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = o;
+            acc[n][mg + m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) {
+        const int64_t row = m0 + m * 16 + li;
+        const bool rok = row < a.M;
+        const int c = rok ? (int)(((uint32_t)row / (uint32_t)a.T) % (uint32_t)a.C) : 0;
+        const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+          const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+          const f32x4 v = acc[n][m];
+          acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (!rok || col >= a.N) continue;          // N % 8 == 0 and col % 4 == 0: a float4 is inside or outside as a whole
+          const f32x4 b4 = (a.bias != nullptr) ? *reinterpret_cast<const f32x4 *>(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          const f32x4 r4 = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(a.res + row * ldr + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          f32x4 o;
+          o.x = tdf_act(sc * (v.x + b4.x) + sh, a.relu) + r4.x;
+          o.y = tdf_act(sc * (v.y + b4.y) + sh, a.relu) + r4.y;
+          o.z = tdf_act(sc * (v.z + b4.z) + sh, a.relu) + r4.z;
+          o.w = tdf_act(sc * (v.w + b4.w) + sh, a.relu) + r4.w;
+          *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = o;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace asx

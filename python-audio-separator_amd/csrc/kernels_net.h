@@ -23,6 +23,7 @@
 namespace asx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define ASX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -578,7 +579,10 @@ struct ConvDmaCfg {
   static constexpr int SLOTS = IH * C4;                                  // float4 per plane
   static constexpr int NI = (SLOTS + 63) / 64;                           // wave-issues per plane
   static constexpr int PS0 = IH * IWA;
-  static constexpr int PS = (S == 1) ? (PS0 + ((16 - PS0 % 32) + 32) % 32) : PS0 + 4;
+  // plane stride: stride-1 kernels fetch fragments with ds_read_b32 (32 banks: planes lk, lk+1 must sit 16 banks apart);
+  // the stride-2 kernel fetches both dx taps of a pixel with one ds_read_b64 (64 banks per 32-lane group: the 16 pixels
+  // of a fragment row cover banks 0..31, so the second plane of the group must start 32 banks further)
+  static constexpr int PS = (S == 1) ? (PS0 + ((16 - PS0 % 32) + 32) % 32) : (PS0 + ((32 - PS0 % 64) + 64) % 64);
   static constexpr int NW = 16 * NREP;
   static constexpr int NWP = (NREP % 2 == 0) ? NW + 16 : NW;
   static constexpr int NTAP = KH * KW;
@@ -667,24 +671,49 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
     if (ci + 1 < a.NCI) issue(ci + 1, (ci + 1) & 1);
     const float *in_s = lds_f + (ci & 1) * BUF;
     const float *w_s = in_s + KC * PS;
+    if constexpr (S == 2 && KW == 2 && KC == 4 && LP == 0) {
+      // 2x2 / stride-2 conv: the two dx taps of an output pixel are adjacent floats -> one conflict-free ds_read_b64 per
+      // (row tap, pixel) instead of two 2-way conflicting ds_read_b32 (SQ_LDS_BANK_CONFLICT was 42 % of the LDS cycles);
+      // tap order (dy, dx) and therefore the accumulation order are unchanged
 #pragma unroll
-    for (int tap = 0; tap < KH * KW; ++tap) {
-      const int dy = tap / KW, dx = tap % KW;
-#pragma unroll
-      for (int kq = 0; kq < KC / 4; ++kq) {
-        float bf[NREP];
-#pragma unroll
-        for (int n = 0; n < NREP; ++n) bf[n] = w_s[(tap * KC + kq * 4 + lk) * NWP + n * 16 + li];
-        float af[MREP];
+      for (int dy = 0; dy < KH; ++dy) {
+        f32x2 a2[MREP];
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
           const int rr = m >> 2, cc = m & 3;
-          af[m] = in_s[(kq * 4 + lk) * PS + ((wave * RPW + rr) * S + dy) * IWA + LP + (cc * 16 + li) * S + dx];
+          a2[m] = *reinterpret_cast<const f32x2 *>(&in_s[lk * PS + ((wave * RPW + rr) * S + dy) * IWA + (cc * 16 + li) * S]);   // ds_read_b64
         }
 #pragma unroll
-        for (int m = 0; m < MREP; ++m)
+        for (int dx = 0; dx < 2; ++dx) {
+          float bf[NREP];
 #pragma unroll
-          for (int n = 0; n < NREP; ++n) acc[m][n] = ASX_MFMA(af[m], bf[n], acc[m][n]);
+          for (int n = 0; n < NREP; ++n) bf[n] = w_s[((dy * KW + dx) * KC + lk) * NWP + n * 16 + li];
+#pragma unroll
+          for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) acc[m][n] = ASX_MFMA(dx ? a2[m].y : a2[m].x, bf[n], acc[m][n]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < KH * KW; ++tap) {
+        const int dy = tap / KW, dx = tap % KW;
+#pragma unroll
+        for (int kq = 0; kq < KC / 4; ++kq) {
+          float bf[NREP];
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) bf[n] = w_s[(tap * KC + kq * 4 + lk) * NWP + n * 16 + li];
+          float af[MREP];
+#pragma unroll
+          for (int m = 0; m < MREP; ++m) {
+            const int rr = m >> 2, cc = m & 3;
+            af[m] = in_s[(kq * 4 + lk) * PS + ((wave * RPW + rr) * S + dy) * IWA + LP + (cc * 16 + li) * S + dx];
+          }
+#pragma unroll
+          for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) acc[m][n] = ASX_MFMA(af[m], bf[n], acc[m][n]);
+        }
       }
     }
   }

@@ -8,9 +8,12 @@ and maps the ConvTDFNet pattern (uvr_lib_v5/mdxnet.py:54-120) onto the engine's
 canonical tensors (include/asx.h), folding BatchNormalization nodes in float64.
 
 Only the ONNX features such exports use are understood: Conv, ConvTranspose,
-MatMul (+ optional bias Add), BatchNormalization, Relu, Add, Mul, Transpose; fp32
-initialisers stored as ``raw_data`` or ``float_data``.  Anything else raises
-``OnnxFormatError`` rather than guessing.
+MatMul (+ optional bias Add), BatchNormalization (fused into the Conv by the
+exporter or left as its own node), Relu, Add, Mul, Transpose; weights as fp32
+initialisers (``raw_data`` or ``float_data``) or derived from them through
+Constant / Identity / Transpose / Reshape / Squeeze / Unsqueeze / Cast nodes (exports
+made without constant folding).  Anything else raises ``OnnxFormatError`` rather
+than guessing.
 
 Field numbers follow onnx.proto3 (ModelProto.graph = 7; GraphProto.node = 1,
 initializer = 5, input = 11; NodeProto.input = 1, output = 2, op_type = 4,
@@ -133,6 +136,8 @@ def _parse_attr(b):
             val = _sint64(v)
         elif fno == 4:
             val = bytes(v)
+        elif fno == 5:                                   # AttributeProto.t: the tensor of a Constant node
+            val = _parse_tensor(v)[1]
         elif fno == 8:
             ints += [_sint64(x) for x in _packed_varints(v)] if wt == 2 else [_sint64(v)]
     return name, (ints if ints else val)
@@ -202,6 +207,47 @@ def parse_onnx(path_or_bytes):
 # ---------------------------------------------------------------------------
 # ConvTDFNet pattern -> engine tensors
 # ---------------------------------------------------------------------------
+def fold_constants(nodes, inits) -> dict:
+    """Initialisers plus everything a chain of Constant / Identity / Transpose / Reshape / Squeeze / Unsqueeze / Cast nodes
+    derives from them.  Exports made with ``do_constant_folding=False`` (or TrainingMode.PRESERVE) keep such nodes in
+    the graph -- e.g. ``Transpose(linear.weight) -> MatMul`` -- where a folded export stores the result."""
+    vals = dict(inits)
+    for n in nodes:                                       # graph order is topological
+        if not n.outputs:
+            continue
+        if n.op == "Constant":
+            v = n.attrs.get("value")
+            if isinstance(v, np.ndarray):
+                vals[n.outputs[0]] = v
+            continue
+        if n.op not in ("Identity", "Transpose", "Reshape", "Squeeze", "Unsqueeze", "Cast") or not n.inputs or n.inputs[0] not in vals:
+            continue
+        x = vals[n.inputs[0]]
+        if n.op in ("Identity", "Cast"):
+            y = x
+        elif n.op == "Transpose":
+            perm = n.attrs.get("perm")
+            y = np.transpose(x, perm if perm else None)
+        elif n.op == "Reshape":
+            if len(n.inputs) < 2 or n.inputs[1] not in vals:
+                continue
+            shape = [int(d) for d in np.asarray(vals[n.inputs[1]]).reshape(-1)]
+            shape = [x.shape[i] if d == 0 else d for i, d in enumerate(shape)]
+            y = x.reshape(shape)
+        else:
+            axes = n.attrs.get("axes")
+            if axes is None and len(n.inputs) > 1 and n.inputs[1] in vals:
+                axes = [int(a) for a in np.asarray(vals[n.inputs[1]]).reshape(-1)]
+            if axes is None:
+                continue
+            axes = [axes] if isinstance(axes, int) else list(axes)
+            y = x
+            for ax in sorted(axes, reverse=(n.op == "Squeeze")):
+                y = np.squeeze(y, ax) if n.op == "Squeeze" else np.expand_dims(y, ax)
+        vals[n.outputs[0]] = y
+    return vals
+
+
 def _bn_affine(node: Node, inits):
     g, b, m, v = (np.asarray(inits[n], np.float64) for n in node.inputs[1:5])
     eps = float(node.attrs.get("epsilon", 1e-5))
@@ -215,7 +261,8 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
     ``dim_t`` overrides the time size found in the graph input (the net is
     convolutional in time; the reference re-exports through onnx2torch when
     segment_size != dim_t, mdx_separator.py:126-132)."""
-    nodes, inits, ginputs = parse_onnx(path_or_bytes)
+    nodes, raw_inits, ginputs = parse_onnx(path_or_bytes)
+    inits = fold_constants(nodes, raw_inits)
     consumers: dict = {}
     for idx, n in enumerate(nodes):
         for i in n.inputs:
@@ -328,7 +375,7 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
 
     if dim_t is None:
         for name, dims in ginputs.items():
-            if name not in inits and dims and len(dims) == 4 and dims[3]:
+            if name not in raw_inits and dims and len(dims) == 4 and dims[3]:
                 dim_t = int(dims[3])
         if dim_t is None:
             raise OnnxFormatError("time size not recorded in the graph input; pass dim_t")

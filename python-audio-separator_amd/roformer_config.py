@@ -178,6 +178,26 @@ def constructor_args(cfg: dict, model_type: str) -> dict:
     return a
 
 
+def legacy_constructor_args(model_cfg: dict, model_type: str) -> dict:
+    """``BSRoformer(**model_cfg)`` / ``MelBandRoformer(**model_cfg)`` of the legacy path (roformer_loader.py:209-217): every
+    key of the YAML's model section reaches the class, the rest are the class defaults."""
+    a = {"stereo": False, "num_stems": 1, "time_transformer_depth": 2, "freq_transformer_depth": 2, "dim_head": 64, "heads": 8,
+         "mlp_expansion_factor": 4, "stft_n_fft": 2048, "stft_hop_length": 512, "stft_win_length": 2048, "stft_normalized": False,
+         "linear_transformer_depth": 0, "mask_estimator_depth": 2 if model_type == "bs_roformer" else 1}
+    if model_type == "bs_roformer":
+        a["freqs_per_bands"] = DEFAULT_FREQS_PER_BANDS
+    else:
+        a.update(num_bands=60, sample_rate=44100)
+    for k, v in model_cfg.items():
+        if k in a or k in ("dim", "depth"):
+            a[k] = tuple(v) if k == "freqs_per_bands" else v
+    if model_cfg.get("stft_window_fn") is not None:
+        raise NotImplementedError("stft_window_fn other than the Hann default")
+    if a["linear_transformer_depth"]:
+        raise NotImplementedError("linear_transformer_depth > 0")
+    return a
+
+
 def read_checkpoint(model_path: str) -> dict:
     """torch.load + the 'state_dict' / 'model' unwrapping of roformer_loader.py:97-104 (torch is the weight container)."""
     import torch
@@ -220,7 +240,18 @@ class RoformerLoader:
         except ParameterValidationError as e:
             return LoadResult(False, error_message=f"Config validation: {e}")
         try:
-            args = constructor_args(cfg, model_type)
+            # A Mel-Band YAML whose file name does not say so is typed "bs_roformer" by the normaliser (the nested `model`
+            # section is invisible to its detection and the BS defaults bring a freqs_per_bands along); the reference then
+            # fails to build the BS model and its legacy path constructs the class straight from the raw `model` section
+            # (roformer_loader.py:197-236).  That outcome is taken directly.
+            raw_model = config.get("model", config) if isinstance(config, dict) else {}
+            legacy = isinstance(raw_model, dict) and ("num_bands" in raw_model) != ("freqs_per_bands" in raw_model) and \
+                (("num_bands" in raw_model) != (model_type == "mel_band_roformer"))
+            if legacy:
+                model_type = "mel_band_roformer" if "num_bands" in raw_model else "bs_roformer"
+                args = legacy_constructor_args(raw_model, model_type)
+            else:
+                args = constructor_args(cfg, model_type)
             if state_dict is None and os.path.exists(model_path):
                 state_dict = read_checkpoint(model_path)
             self._loading_stats["new_implementation_success"] += 1

@@ -50,6 +50,17 @@ def main():
         torch.onnx.export(net, (torch.randn(1, 4, 32, 16),), out, input_names=["input"], output_names=["output"],
                           dynamo=False, opset_version=13)
         print(out, os.path.getsize(out))
+        if bias:
+            # the same net through other exporter settings real MDX-Net files were written with: an older opset, and no
+            # constant folding (BatchNormalization left unfused after every Conv, Linear weights behind Transpose nodes,
+            # dynamic batch / time axes so that the time size is NOT recorded in the graph input)
+            for tag, kw in (("op11", dict(opset_version=11)),
+                            ("op17_nofold", dict(opset_version=17, do_constant_folding=False,
+                                                 dynamic_axes={"input": {0: "b", 3: "t"}, "output": {0: "b", 3: "t"}}))):
+                out2 = os.path.join(HERE, fname.replace(".onnx", f"_{tag}.onnx"))
+                torch.onnx.export(net, (torch.randn(1, 4, 32, 16),), out2, input_names=["input"], output_names=["output"],
+                                  dynamo=False, **kw)
+                print(out2, os.path.getsize(out2))
 
 
 if __name__ == "__main__":

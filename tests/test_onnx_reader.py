@@ -25,6 +25,26 @@ def test_reader_recovers_config_and_weights(golden_dir, fname, bias, seed):
         assert np.allclose(tensors[k], want[k], rtol=2e-6, atol=2e-7), k
 
 
+@pytest.mark.parametrize("fname", ["net_small_bias_op11.onnx", "net_small_bias_op17_nofold.onnx"])
+def test_reader_other_exporter_settings(golden_dir, fname):
+    """opset 11 with fused Conv+BN, and opset 17 exported WITHOUT constant folding: 25 BatchNormalization nodes (one after every
+    Conv / ConvTranspose / MatMul), every Linear weight behind a Transpose node, dynamic batch / time axes."""
+    path = os.path.join(golden_dir, fname)
+    nodes, inits, inputs = parse_onnx(path)
+    ops = [n.op for n in nodes]
+    if "nofold" in fname:
+        assert ops.count("BatchNormalization") == 25 and ops.count("Transpose") == 12 and inputs["input"] == [None, 4, 32, None]
+        with pytest.raises(OnnxFormatError, match="time size"):
+            convtdf_from_onnx(path)                      # dynamic axis: the caller supplies dim_t (= segment_size)
+    cfg, tensors = convtdf_from_onnx(path, dim_t=16)
+    assert (cfg.dim_c, cfg.dim_f, cfg.dim_t, cfg.g, cfg.l, cfg.num_blocks, cfg.k, cfg.bn, cfg.tdf_bias) == (4, 32, 16, 8, 2, 5, 3, 4, True)
+    d = O.NetDims(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=4, bias=True)
+    want = fold_convtdf_state(O.make_convtdf_state(d, seed=4), d.num_blocks, d.l, tdf_bias=True)
+    assert sorted(tensors) == sorted(want)
+    for k in want:
+        assert np.allclose(tensors[k], want[k], rtol=2e-6, atol=2e-7), k
+
+
 def test_graph_structure(golden_dir):
     nodes, inits, inputs = parse_onnx(os.path.join(golden_dir, "net_small.onnx"))
     ops = [n.op for n in nodes]

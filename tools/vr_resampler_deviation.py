@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""How far is the VR synthesis chain on the `polyphase` resampler (what this engine and the oracle implement; the reference's
+macOS-ARM / MPS behaviour) from the chain on libsamplerate's `sinc_fastest` (what the reference uses on Linux / Windows / Intel
+macOS, uvr_lib_v5/spec_utils.py:33-38, :374,:390)?
+
+libsamplerate and its coefficient table are not available here, so `sinc_fastest` is bracketed by two stand-ins:
+  * `kaiser`: libsamplerate's published algorithm shape (src_sinc.c: a windowed-sinc table sampled `increment` = 128 times
+    per zero crossing, ~19 zero crossings per side like fastest_coeffs.h's 2464 entries, linear interpolation between
+    entries, double accumulation) with a REGENERATED Kaiser table sized for its documented 97 dB / 80 % bandwidth;
+  * `ideal`: band-limited (FFT zero-padding) interpolation, the limit every high-quality sinc converter approaches in-band.
+CPU only (numpy / scipy + the oracle's synthesis code); prints one JSON line and is quoted in DESIGN.md / INTEGRATION.md.
+
+    python tools/vr_resampler_deviation.py [--seconds 10]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import scipy.signal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import vr_oracle as V  # noqa: E402
+from tools.bench_siblings import VR_MP  # noqa: E402  (the 4band_44100 layout)
+
+
+def kaiser_sinc_table(zero_crossings=19.25, increment=128, atten_db=97.0, bandwidth=0.80):
+    """Half of a symmetric windowed-sinc, `increment` samples per zero crossing; cutoff midway between the pass-band edge
+    (bandwidth x Nyquist) and Nyquist."""
+    half = int(zero_crossings * increment)
+    t = np.arange(half + 1) / increment
+    fc = 0.5 * (bandwidth + 1.0)
+    beta = 0.1102 * (atten_db - 8.7)
+    win = np.i0(beta * np.sqrt(np.clip(1 - (t / zero_crossings) ** 2, 0, None))) / np.i0(beta)
+    return fc * np.sinc(fc * t) * win, increment
+
+
+def src_sinc(x, ratio, table, increment):
+    """src_sinc.c's variable-ratio loop for ratio >= 1 (up-sampling: the table is walked at `increment` per input sample)."""
+    n_in = x.shape[-1]
+    n_out = int(np.ceil(n_in * ratio))
+    pos = np.arange(n_out) / ratio                       # input_index of every output sample
+    base = np.floor(pos).astype(np.int64)
+    frac = pos - base
+    half = (len(table) - 1) // increment
+    out = np.zeros(x.shape[:-1] + (n_out,), np.float64)
+    xp = np.pad(np.asarray(x, np.float64), [(0, 0)] * (x.ndim - 1) + [(half + 1, half + 2)])
+    for k in range(-half, half + 2):                     # taps at input samples base + k
+        d = np.abs(frac - k) * increment                 # distance to the tap, in table steps
+        i0 = np.floor(d).astype(np.int64)
+        w = d - i0
+        ok = i0 + 1 < len(table)
+        c = np.where(ok, table[np.minimum(i0, len(table) - 2)] * (1 - w) + table[np.minimum(i0 + 1, len(table) - 1)] * w, 0.0)
+        out += c * xp[..., base + k + half + 1]
+    return out
+
+
+_POLY = V.lr_resample
+
+
+def resample(y, orig_sr, target_sr, kind):
+    if orig_sr == target_sr:
+        return y
+    if kind == "polyphase":
+        return _POLY(y, orig_sr=orig_sr, target_sr=target_sr, res_type="polyphase")
+    ratio = target_sr / orig_sr
+    n_out = int(np.ceil(y.shape[-1] * ratio))
+    if kind == "ideal":
+        return scipy.signal.resample(np.asarray(y, np.float64), n_out, axis=-1)
+    table, inc = kaiser_sinc_table()
+    return src_sinc(y, ratio, table, inc)[..., :n_out]
+
+
+def synth(spec, mp, kind):
+    orig = V.lr_resample
+    V.lr_resample = lambda y, orig_sr=None, target_sr=None, res_type=None, **kw: resample(y, orig_sr, target_sr, kind)
+    try:
+        return V.cmb_spectrogram_to_wave(spec, mp)
+    finally:
+        V.lr_resample = orig
+
+
+def rel_rms(a, b):
+    n = min(a.shape[-1], b.shape[-1])
+    a, b = np.asarray(a[..., :n], np.float64), np.asarray(b[..., :n], np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=10.0)
+    args = ap.parse_args()
+    mp = V.ModelParams(VR_MP)
+    n = int(44100 * args.seconds)
+    rng = np.random.default_rng(0)                        # band-limited pink-ish noise, peak 0.5
+    spec = np.fft.rfft(rng.standard_normal((2, n)))
+    spec /= np.sqrt(np.maximum(np.arange(spec.shape[-1]), 1.0))
+    wave = np.fft.irfft(spec, n)
+    wave = (0.5 * wave / np.abs(wave).max()).astype(np.float32)
+    X = V.loading_mix(wave, mp)
+    mask = 0.5 + 0.4 * np.sin(np.arange(X.shape[1])[None, :, None] / 37.0) * np.cos(np.arange(X.shape[2])[None, None, :] / 11.0)
+    y_spec = mask * X                                     # a smooth synthetic mask: the deviation is a property of the synthesis chain
+    waves = {k: synth(y_spec, mp, k) for k in ("polyphase", "kaiser", "ideal")}
+    res = {"clip_seconds": args.seconds, "layout": "4band_44100",
+           "polyphase_vs_kaiser_sinc": rel_rms(waves["polyphase"], waves["kaiser"]),
+           "polyphase_vs_ideal": rel_rms(waves["polyphase"], waves["ideal"]),
+           "kaiser_sinc_vs_ideal": rel_rms(waves["kaiser"], waves["ideal"])}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
