@@ -65,6 +65,15 @@ def cpu_baseline(seconds: float, seed: int):
                                 f"{dt:.1f} s wall"}
 
 
+_JSON_FD = None
+
+
+def emit(obj):
+    """The result line, on the process's original stdout."""
+    line = (json.dumps(obj) + "\n").encode()
+    os.write(_JSON_FD if _JSON_FD is not None else 1, line)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +122,12 @@ def main():
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if world != args.gpus:
             sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}; refusing to report a mislabelled run")
+
+    # exactly ONE line on stdout: RCCL prints a version banner to fd 1 at init, so everything else goes to stderr
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -284,7 +299,7 @@ def main():
         if world == 1 and args.siblings:
             eng.close()
             res["siblings"] = sibling_lines(args)
-        print(json.dumps(res))
+        emit(res)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -335,11 +350,11 @@ def dry_run(args, world, rank):
         if rank == 0:
             ok = all(float(g[0, 0, 0]) == float(r) for r, g in enumerate(gathered))
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "value": None, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps,
+        emit({"metric": METRIC, "value": None, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "dry": True, "mode": args.mode, "gather_ok": ok,
                           "rccl": {"world_size": dist.get_world_size() if use_dist else 1, "backend": "gloo" if use_dist else None,
                                    "launcher": "self" if os.environ.get("ASX_BENCH_LAUNCHED") == "1" else
-                                   ("external" if "WORLD_SIZE" in os.environ else None)}}))
+                                   ("external" if "WORLD_SIZE" in os.environ else None)}})
     if use_dist:
         dist.destroy_process_group()
 

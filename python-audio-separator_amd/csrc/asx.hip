@@ -20,10 +20,11 @@
 
 #include "../../include/asx.h"
 #include "kernels_fft.h"
+#include "kernels_fft3.h"
 #include "kernels_net.h"
 #include "kernels_gemm2.h"
 #ifndef ASX_TDF2_DEFAULT
-#define ASX_TDF2_DEFAULT 0
+#define ASX_TDF2_DEFAULT 1
 #endif
 #include "kernels_rof.h"
 #include "kernels_ht.h"
@@ -142,6 +143,8 @@ struct asx_engine {
   asx_mdx_config cfg{};
   FftPlan plan{};
   DevBuf d_window, d_tw, d_env;  // env for T = segment_size
+  DevBuf d_tw3, seam3;           // fast FFT path (kernels_fft3.h): twiddles [16][12] + [16][192]; seam partial sums
+  bool fft3 = false;             // n_fft == 6144 && hop == 1024 (and ASX_FFT3 != 0)
   DevBuf d_zeros;                // zero page: source of out-of-range DMA slots
   // net
   bool net_begun = false, net_ready = false;
@@ -576,6 +579,7 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
       case 4: return launch_tdf2_abl<3, 8, 4>(a, s);
       case 5: return launch_tdf2_abl<3, 8, 5>(a, s);
       case 7: return launch_tdf2_abl<3, 8, 7>(a, s);
+      case 8: return launch_tdf2_abl<3, 8, 8>(a, s);
       default: break;
     }
   }
@@ -690,6 +694,27 @@ static int stft_launch(asx_engine *e, const float *wave, const int64_t *d_starts
   a.sign = sign;
   const double bytes = 4.0 * ((double)B * 2 * C + (double)B * 4 * T * e->cfg.dim_f);
   FftPlan p = e->plan;
+  if (e->fft3 && tf_layout == 1 && e->cfg.dim_f <= f3::NH) {
+    // n_fft 6144 / hop 1024, engine-internal [B, 4, T, F] layout: three-pass register FFT (kernels_fft3.h)
+    f3::Stft3Args f{};
+    f.wave = wave;
+    f.chunk_start = d_starts;
+    f.n_song = n_song;
+    f.trim = a.trim;
+    f.C = C;
+    f.T = T;
+    f.dim_f = a.dim_f;
+    f.zero_low = zero_low;
+    f.spec = spec;
+    f.window = a.window;
+    f.tw = a.tw;
+    f.twB = reinterpret_cast<const float2 *>(e->d_tw3.p);
+    f.twC = f.twB + 16 * 12;
+    f.sign = sign;
+    return timed(e, ASX_PROF_STFT, 0.0, bytes, s, [&]() {
+      hipLaunchKernelGGL(f3::stft3_kernel, dim3(T, 2, B), dim3(256), f3::STFT3_LDS_BYTES, s, f);
+    });
+  }
   return timed(e, ASX_PROF_STFT, 0.0, bytes, s, [&]() {
     hipLaunchKernelGGL(stft_kernel, dim3(T, 2, B), dim3(256), stft_lds(p), s, a, p);
   });
@@ -720,6 +745,40 @@ static int ola_launch(asx_engine *e, const float *frames, const float *env, cons
   return timed(e, ASX_PROF_OLA, 0.0, bytes, s, [&]() {
     hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((C + 255) / 256), 2, B), dim3(256), 0, s, frames, env, d_nact,
                        n_fft, hop, T, C, out);
+  });
+}
+
+// STFT.inverse + the chunk's Hann window: the fast path (n_fft 6144 / hop 1024) inverse-transforms, overlap-adds in an LDS
+// ring and writes the chunk directly (kernels_fft3.h); every other geometry runs istft_kernel -> frames -> ola_kernel.
+static int istft_ola_launch(asx_engine *e, const float *spec, int B, int T, int combine, const int64_t *d_nact, int64_t C,
+                            float *out, hipStream_t s) {
+  if (!(e->fft3 && e->cfg.dim_f <= f3::NH && C == (int64_t)f3::HOP * (T - 1))) {
+    CHK(istft_launch(e, spec, B, T, 1, combine, e->frames.f(), s));
+    return ola_launch(e, e->frames.f(), e->d_env.f(), d_nact, B, T, C, out, s);
+  }
+  const int G = 32, ng = std::max(1, T / G);
+  CHK(e->seam3.ensure((size_t)B * 2 * ng * 2 * 5 * f3::HOP * 4));
+  f3::Istft3Args f{};
+  f.spec = spec;
+  f.T = T;
+  f.dim_f = e->cfg.dim_f;
+  f.combine = combine;
+  f.window = e->d_window.f();
+  f.tw = reinterpret_cast<const float2 *>(e->d_tw.p);
+  f.twB = reinterpret_cast<const float2 *>(e->d_tw3.p);
+  f.twC = f.twB + 16 * 12;
+  f.env = e->d_env.f();
+  f.n_act = d_nact;
+  f.C = C;
+  f.out = out;
+  f.seam = e->seam3.f();
+  f.G = G;
+  f.n_groups = ng;
+  const double seam_bytes = ng > 1 ? 4.0 * (double)B * 2 * (ng - 1) * 2 * 5 * f3::HOP * 2 : 0.0;
+  const double bytes = 4.0 * ((double)B * 4 * T * e->cfg.dim_f * (combine ? 2 : 1) + (double)B * 2 * C) + seam_bytes;
+  return timed(e, ASX_PROF_ISTFT, 0.0, bytes, s, [&]() {
+    hipLaunchKernelGGL(f3::istft3_kernel, dim3(ng, 2, B), dim3(256), f3::ISTFT3_LDS_BYTES, s, f);
+    if (ng > 1) hipLaunchKernelGGL(f3::seam3_kernel, dim3(5, ng - 1, B * 2), dim3(256), 0, s, f);
   });
 }
 
@@ -858,6 +917,33 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
       rc = ASX_ERR_HIP;
     }
   }
+  if (rc == ASX_OK && cfg->n_fft == f3::NFFT && cfg->hop_length == f3::HOP && !(getenv("ASX_FFT3") && atoi(getenv("ASX_FFT3")) == 0)) {
+    std::vector<float> t3((size_t)(16 * 12 + 16 * f3::NB) * 2);
+    for (int r = 0; r < 16; ++r)
+      for (int k = 0; k < 12; ++k) {
+        const double ang = -2.0 * M_PI * (double)(k * r) / 192.0;
+        t3[(size_t)(r * 12 + k) * 2] = (float)cos(ang);
+        t3[(size_t)(r * 12 + k) * 2 + 1] = (float)sin(ang);
+      }
+    for (int r = 0; r < 16; ++r)
+      for (int j = 0; j < f3::NB; ++j) {
+        const double ang = -2.0 * M_PI * (double)(j * r) / (double)f3::NH;
+        t3[(size_t)(16 * 12 + r * f3::NB + j) * 2] = (float)cos(ang);
+        t3[(size_t)(16 * 12 + r * f3::NB + j) * 2 + 1] = (float)sin(ang);
+      }
+    if ((rc = e->d_tw3.ensure(t3.size() * 4)) == ASX_OK) {
+      if (hipMemcpy(e->d_tw3.p, t3.data(), t3.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        set_err("table upload failed");
+        rc = ASX_ERR_HIP;
+      } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f3::stft3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  f3::STFT3_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f3::istft3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  f3::ISTFT3_LDS_BYTES);
+        e->fft3 = true;
+      }
+    }
+  }
   if (rc == ASX_OK) rc = e->d_zeros.ensure(256);
   if (rc == ASX_OK && hipMemset(e->d_zeros.p, 0, 256) != hipSuccess) {
     set_err("zero page init failed");
@@ -911,6 +997,8 @@ void asx_engine_destroy(asx_engine *e) {
   e->d_window.release();
   e->d_tw.release();
   e->d_env.release();
+  e->d_tw3.release();
+  e->seam3.release();
   e->d_zeros.release();
   free_conv(e->first);
   free_conv(e->final_);
@@ -1188,8 +1276,7 @@ int asx_demix_chunks_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t
       CHK(net_forward_dev(e, e->spec_in.f(), e->spec_out.f(), Bn, s));
       spec_final = e->spec_out.f();
     }
-    CHK(istft_launch(e, spec_final, B, T, 1, combine, e->frames.f(), s));
-    CHK(ola_launch(e, e->frames.f(), e->d_env.f(), dn, B, T, C, chunk_out_dev + (size_t)b0 * 2 * C, s));
+    CHK(istft_ola_launch(e, spec_final, B, T, combine, dn, C, chunk_out_dev + (size_t)b0 * 2 * C, s));
   }
   return ASX_OK;
 }
@@ -1494,8 +1581,7 @@ int asx_run_model(asx_engine *e, const float *wave_host, int32_t B, float *out_h
     CHK(net_forward_dev(e, e->spec_in.f(), e->spec_out.f(), Bn, nullptr));
     spec_final = e->spec_out.f();
   }
-  CHK(istft_launch(e, spec_final, B, T, 1, combine, e->frames.f(), nullptr));
-  CHK(ola_launch(e, e->frames.f(), e->d_env.f(), nullptr, B, T, C, dout.f(), nullptr));
+  CHK(istft_ola_launch(e, spec_final, B, T, combine, nullptr, C, dout.f(), nullptr));
   CHK(to_host(out_host, dout, (size_t)B * 2 * C));
   return ASX_OK;
 }

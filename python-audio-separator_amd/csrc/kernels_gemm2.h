@@ -183,6 +183,49 @@ __global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_pe
         }
       if (chk == 1.2345e-30f) a.y[0] = chk;
     } else
+    if (((abl & 8) != 0) && full) {
+      // ABL bit 3: row-coalesced epilogue.  The accumulators of three 16-row groups at a time go through the stage buffer
+      // that was just consumed ([48][BN + 4] floats, conflict-free for the 8-lane groups of ds_write_b128), and come back
+      // one full output row per 48 consecutive lanes, so residual loads and stores are 768-byte row segments instead of
+      // sixteen 64-byte pieces per instruction.  Same arithmetic per element, bit-identical results.
+      float *st = lds_f + (it & 1) * BUF;
+      constexpr int SW = BN + 4, PM = 3, C4 = BN / 4;
+#pragma unroll
+      for (int p0 = 0; p0 < MREP; p0 += PM) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int pm = (MREP - p0) < PM ? (MREP - p0) : PM;
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PM; ++m) {
+          if (m < pm) {
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) {
+              *reinterpret_cast<f32x4 *>(&st[(m * 16 + li) * SW + wave * 16 * NREP + n * 16 + lk * 4]) = acc[n][p0 + m];
+              acc[n][p0 + m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+          }
+        }
+        __syncthreads();
+        const int nvec = pm * 16 * C4;
+        for (int idx = tid; idx < nvec; idx += 256) {
+          const int row_l = idx / C4, c4 = idx - row_l * C4;
+          const int64_t row = m0 + p0 * 16 + row_l;
+          const int col = n0 + c4 * 4;
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(&st[row_l * SW + c4 * 4]);
+          const f32x4 b4 = (a.bias != nullptr) ? *reinterpret_cast<const f32x4 *>(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          const f32x4 r4 = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(a.res + row * ldr + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          const int c = (int)(((uint32_t)row / (uint32_t)a.T) % (uint32_t)a.C);
+          const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
+          f32x4 o;
+          o.x = tdf_act(sc * (v.x + b4.x) + sh, a.relu) + r4.x;
+          o.y = tdf_act(sc * (v.y + b4.y) + sh, a.relu) + r4.y;
+          o.z = tdf_act(sc * (v.z + b4.z) + sh, a.relu) + r4.z;
+          o.w = tdf_act(sc * (v.w + b4.w) + sh, a.relu) + r4.w;
+          *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = o;
+        }
+      }
+    } else
     if (full) {
       f32x4 bz[NREP];
 #pragma unroll

@@ -35,6 +35,7 @@ def _stub(name, **attrs):
 _stub("librosa", stft=V.lr_stft, istft=V.lr_istft, resample=V.lr_resample)
 _stub("soundfile")
 _stub("audioread")
+_stub("pydub", AudioSegment=object)
 try:
     import six  # noqa: F401
 except ImportError:
@@ -43,6 +44,7 @@ for pkg, path in (("audio_separator", f"{REF}/audio_separator"), ("audio_separat
                   ("audio_separator.separator.uvr_lib_v5", f"{REF}/audio_separator/separator/uvr_lib_v5")):
     m = _stub(pkg)
     m.__path__ = [path]
+    m.__spec__ = importlib.machinery.ModuleSpec(pkg, None, is_package=True)
 
 from audio_separator.separator.uvr_lib_v5 import spec_utils  # noqa: E402
 from audio_separator.separator.uvr_lib_v5.vr_network import nets  # noqa: E402
@@ -73,46 +75,21 @@ def ref_loading_mix(wave, mp):
 
 
 def ref_inference(X_spec, model, window_size, batch_size, aggressiveness, tta, post, thres, non_accom=False):
-    """VRSeparator.inference_vr (vr_separator.py:293-366), verbatim control flow."""
-    def _execute(X_mag_pad, roi_size):
-        X_dataset = []
-        patches = (X_mag_pad.shape[2] - 2 * model.offset) // roi_size
-        for i in range(patches):
-            start = i * roi_size
-            X_dataset.append(X_mag_pad[:, :, start:start + window_size])
-        X_dataset = np.asarray(X_dataset)
-        model.eval()
-        with torch.no_grad():
-            mask = []
-            for i in range(0, patches, batch_size):
-                pred = model.predict_mask(torch.from_numpy(X_dataset[i:i + batch_size]))
-                pred = pred.detach().cpu().numpy()
-                mask.append(np.concatenate(pred, axis=2))
-            mask = np.concatenate(mask, axis=2)
-        return mask
-
-    X_mag, X_phase = spec_utils.preprocess(X_spec)
-    n_frame = X_mag.shape[2]
-    pad_l, pad_r, roi_size = spec_utils.make_padding(n_frame, window_size, model.offset)
-    X_mag_pad = np.pad(X_mag, ((0, 0), (0, 0), (pad_l, pad_r)), mode="constant")
-    X_mag_pad /= X_mag_pad.max()
-    mask = _execute(X_mag_pad, roi_size)
-    if tta:
-        pad_l += roi_size // 2
-        pad_r += roi_size // 2
-        X_mag_pad = np.pad(X_mag, ((0, 0), (0, 0), (pad_l, pad_r)), mode="constant")
-        X_mag_pad /= X_mag_pad.max()
-        mask_tta = _execute(X_mag_pad, roi_size)
-        mask_tta = mask_tta[:, :, roi_size // 2:]
-        mask = (mask[:, :, :n_frame] + mask_tta[:, :, :n_frame]) * 0.5
-    else:
-        mask = mask[:, :, :n_frame]
-    mask = spec_utils.adjust_aggr(mask, non_accom, aggressiveness)
-    if post:
-        mask = spec_utils.merge_artifacts(mask, thres=thres)
-    y_spec = mask * X_mag * np.exp(1.0j * X_phase)
-    v_spec = (1 - mask) * X_mag * np.exp(1.0j * X_phase)
-    return y_spec, v_spec, mask
+    """The reference's own VRSeparator.inference_vr (vr_separator.py:293-366), bound to a bare instance that carries exactly
+    the attributes the method reads."""
+    import logging
+    from audio_separator.separator.architectures.vr_separator import VRSeparator
+    inst = VRSeparator.__new__(VRSeparator)
+    inst.logger = logging.getLogger("golden")
+    inst.model_run = model
+    inst.window_size = window_size
+    inst.batch_size = batch_size
+    inst.enable_tta = tta
+    inst.enable_post_process = post
+    inst.post_process_threshold = thres
+    inst.primary_stem_name = "Vocals" if non_accom else "Instrumental"
+    y_spec, v_spec = inst.inference_vr(X_spec, torch.device("cpu"), aggressiveness)
+    return y_spec, v_spec, None
 
 
 def main():
@@ -145,7 +122,6 @@ def main():
                 y, v, mask = ref_inference(X_spec, model, 64, 2, aggr, tta, post, 0.2)
                 out[f"inf_{name}_y"] = y.astype(np.complex64)
                 out[f"inf_{name}_v"] = v.astype(np.complex64)
-                out[f"inf_{name}_mask"] = mask.astype(np.float32)
                 if name == "plain":
                     out["wav_y"] = spec_utils.cmb_spectrogram_to_wave(y, mp, is_v51_model=False)
                     out["wav_v"] = spec_utils.cmb_spectrogram_to_wave(v, mp, is_v51_model=False)
@@ -200,7 +176,6 @@ def main_v51(wave):
         out["net_out"] = model.forward(torch.from_numpy(x)).numpy()
     aggr = {"value": 0.05, "split_bin": mp.param["band"][1]["crop_stop"], "aggr_correction": None}
     y, v, mask = ref_inference(X_spec, model, 64, 2, aggr, False, False, 0.2)
-    out["inf_mask"] = mask.astype(np.float32)
     out["wav_y"] = spec_utils.cmb_spectrogram_to_wave(y, mp, is_v51_model=True)
     out["wav_v"] = spec_utils.cmb_spectrogram_to_wave(v, mp, is_v51_model=True)
     np.savez_compressed(os.path.join(HERE, "vr51_small.npz"), **out)

@@ -330,6 +330,25 @@ def test_run_model_vs_oracle(A):
     assert rel_rms(got, ref) < TOL_STEM
 
 
+def test_fft3_fast_path_vs_generic_and_oracle(A, monkeypatch):
+    """n_fft 6144 / hop 1024 runs the three-pass register FFT with the frame overlap-add fused into the inverse
+    (csrc/kernels_fft3.h); ASX_FFT3=0 keeps the generic six-pass kernels + frame buffer + ola_kernel.  Both against the oracle
+    (STFT -> bins [0, 3) zeroed -> iSTFT, the match-mix pass of run_model) on a 3-chunk batch, at a short segment too (T = 40:
+    one frame group, no seams) and at T = 70 (two groups, the second longer than G)."""
+    for seg in (256, 40, 70):
+        C = 1024 * (seg - 1)
+        w = (0.3 * np.random.default_rng(seg).standard_normal((3, 2, C))).astype(np.float32)
+        ref = O.run_model(w, O.MDXParams(segment_size=seg), None, is_match_mix=True)
+        monkeypatch.setenv("ASX_FFT3", "1")
+        fast = A.Engine(A.MDXConfig(segment_size=seg)).run_model(w, is_match_mix=True)
+        monkeypatch.setenv("ASX_FFT3", "0")
+        slow = A.Engine(A.MDXConfig(segment_size=seg)).run_model(w, is_match_mix=True)
+        assert rel_rms(fast, ref) < 5e-6, (seg, rel_rms(fast, ref))
+        assert rel_rms(slow, ref) < 5e-6, (seg, rel_rms(slow, ref))
+        assert rel_rms(fast, slow) < 5e-6 and max_abs(fast, slow) < 2e-5, (seg, max_abs(fast, slow))
+    monkeypatch.delenv("ASX_FFT3")
+
+
 def test_batching_is_invisible(A):
     # results must not depend on how many chunks share a device batch (reference: batch_size has no effect)
     mix = (0.4 * np.random.default_rng(77).standard_normal((2, 5000))).astype(np.float32)
