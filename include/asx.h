@@ -416,6 +416,8 @@ int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host
 
 /* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host. */
 int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel);
+/* measurement hook: the s_memtime timeline the ASX_TDF2_ABL=16 build of the row GEMM records (8 x uint64 per workgroup). */
+int asx_debug_trace(uint64_t *host, int64_t n_u64);
 
 /* ---- stage hooks (host buffers; mirror the reference's own test surface) ---- */
 /* STFT.__call__ (stft.py:20): wave [B,2,C] -> spec [B,4,dim_f,C/hop+1]. */

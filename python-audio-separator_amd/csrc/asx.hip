@@ -143,6 +143,7 @@ struct asx_engine {
   asx_mdx_config cfg{};
   FftPlan plan{};
   DevBuf d_window, d_tw, d_env;  // env for T = segment_size
+  DevBuf d_hann3;                // np.hanning(chunk_size) in float64 for the fused inverse's chunk window
   DevBuf d_tw3, seam3;           // fast FFT path (kernels_fft3.h): twiddles [16][12] + [16][192]; seam partial sums
   bool fft3 = false;             // n_fft == 6144 && hop == 1024 (and ASX_FFT3 != 0)
   DevBuf d_zeros;                // zero page: source of out-of-range DMA slots
@@ -546,7 +547,8 @@ static bool tdf2_ok(const TdfDmaArgs &d) {
   const int64_t lda = d.lda ? d.lda : d.K, ldy = d.ldy ? d.ldy : d.N, ldr = d.ldr ? d.ldr : d.N;
   return tdf2_mode() > 0 && d.K % 32 == 0 && d.K >= 32 && d.M % 8 == 0 && d.M >= 8 && d.M < (1ll << 31) && d.T > 0 && d.C > 0 && d.N % 8 == 0 && d.N >= 8 && lda % 4 == 0 &&
          ldy % 4 == 0 && ldr % 4 == 0 && a16(d.x) && a16(d.w) && a16(d.y) && (!d.res || a16(d.res)) && (!d.bias || a16(d.bias)) &&
-         (uint64_t)8 * (uint64_t)lda * 4 < (1ull << 31) && (uint64_t)8 * (uint64_t)d.K * 4 < (1ull << 31);
+         (uint64_t)8 * (uint64_t)lda * 4 < (1ull << 31) && (uint64_t)8 * (uint64_t)d.K * 4 < (1ull << 31) &&
+         (uint64_t)16 * (uint64_t)ldy * 4 < (1ull << 31) && (uint64_t)16 * (uint64_t)ldr * 4 < (1ull << 31);
 }
 template <int NREP, int MREP, int ABL>
 static void launch_tdf2_abl(const TdfDmaArgs &a, hipStream_t s) {
@@ -580,6 +582,7 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
       case 5: return launch_tdf2_abl<3, 8, 5>(a, s);
       case 7: return launch_tdf2_abl<3, 8, 7>(a, s);
       case 8: return launch_tdf2_abl<3, 8, 8>(a, s);
+      case 16: return launch_tdf2_abl<3, 8, 16>(a, s);
       default: break;
     }
   }
@@ -589,6 +592,8 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
 static void launch_tdf_dma_auto(const TdfDmaArgs &d, hipStream_t s) {
   static const int t128 = getenv("ASX_GEMM_T128") ? atoi(getenv("ASX_GEMM_T128")) : 1;
   const bool v2 = tdf2_ok(d);
+  static const int small = getenv("ASX_TDF2_SMALL") ? atoi(getenv("ASX_TDF2_SMALL")) : 0;   // A/B: 64 x 128 tiles (3+ workgroups per CU) on short-K layers
+  if (v2 && small && d.K <= small && d.N > 128) return launch_tdf2<2, 4>(d, s);
   if (d.N > 128) {
     const double rows = (double)((d.M + 127) / 128);
     auto cost = [&](int bn, double eff) {
@@ -756,7 +761,8 @@ static int istft_ola_launch(asx_engine *e, const float *spec, int B, int T, int 
     CHK(istft_launch(e, spec, B, T, 1, combine, e->frames.f(), s));
     return ola_launch(e, e->frames.f(), e->d_env.f(), d_nact, B, T, C, out, s);
   }
-  const int G = 32, ng = std::max(1, T / G);
+  static const int G = getenv("ASX_FFT3_G") ? std::max(5, atoi(getenv("ASX_FFT3_G"))) : 16;   // frames per workgroup
+  const int ng = std::max(1, T / G);
   CHK(e->seam3.ensure((size_t)B * 2 * ng * 2 * 5 * f3::HOP * 4));
   f3::Istft3Args f{};
   f.spec = spec;
@@ -774,6 +780,7 @@ static int istft_ola_launch(asx_engine *e, const float *spec, int B, int T, int 
   f.seam = e->seam3.f();
   f.G = G;
   f.n_groups = ng;
+  f.hann = (C == (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1) && e->d_hann3.p) ? reinterpret_cast<const double *>(e->d_hann3.p) : nullptr;
   const double seam_bytes = ng > 1 ? 4.0 * (double)B * 2 * (ng - 1) * 2 * 5 * f3::HOP * 2 : 0.0;
   const double bytes = 4.0 * ((double)B * 4 * T * e->cfg.dim_f * (combine ? 2 : 1) + (double)B * 2 * C) + seam_bytes;
   return timed(e, ASX_PROF_ISTFT, 0.0, bytes, s, [&]() {
@@ -941,6 +948,14 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f3::istft3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   f3::ISTFT3_LDS_BYTES);
         e->fft3 = true;
+        if ((rc = e->d_hann3.ensure((size_t)C * 8)) == ASX_OK) {
+          hipLaunchKernelGGL(f3::hann3_table_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, nullptr, C,
+                             reinterpret_cast<double *>(e->d_hann3.p));
+          if (hipDeviceSynchronize() != hipSuccess) {
+            set_err("hann table kernel failed");
+            rc = ASX_ERR_HIP;
+          }
+        }
       }
     }
   }
@@ -998,6 +1013,7 @@ void asx_engine_destroy(asx_engine *e) {
   e->d_tw.release();
   e->d_env.release();
   e->d_tw3.release();
+  e->d_hann3.release();
   e->seam3.release();
   e->d_zeros.release();
   free_conv(e->first);
@@ -2487,6 +2503,13 @@ int asx_vr_separate(asx_engine *e, const float *wave_host, int64_t n_samples, co
 }
 
 // debug hook: copy `numel` floats of a named engine workspace buffer to the host (tests / bring-up only)
+int asx_debug_trace(uint64_t *host, int64_t n_u64) {
+  REQUIRE(host && n_u64 > 0 && n_u64 <= 4096 * 8, "asx_debug_trace: bad argument");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(host, HIP_SYMBOL(asx_dbg_trace), (size_t)n_u64 * 8));
+  return ASX_OK;
+}
+
 int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel) {
   REQUIRE(e && name && host && numel > 0, "asx_debug_fetch: bad argument");
   HIPCHK(hipSetDevice(e->device));

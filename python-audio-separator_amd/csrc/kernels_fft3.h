@@ -44,7 +44,7 @@ namespace f3 {
 constexpr int NFFT = 6144, NH = 3072, HOP = 1024, HPF = NFFT / HOP;   // hops per frame
 constexpr int NB = 192;          // butterflies (= active threads) of passes B and C
 constexpr int BSTRIDE = 204;     // padded block stride (complex) of the pass-B output
-constexpr int LDS_A = NH, LDS_B = 16 * BSTRIDE;                       // float2 elements
+constexpr int LDS_X = 16 * BSTRIDE;                                   // float2 elements of the one exchange buffer (>= NH)
 
 ASX_HD float2 cm(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 ASX_HD float2 ca(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -141,13 +141,15 @@ ASX_HD void pass_a(int j, float2 *a, float2 *bufA) {
   for (int s = 0; s < 6; ++s) p[s] = make_float4(a[2 * s].x, a[2 * s].y, a[2 * s + 1].x, a[2 * s + 1].y);
 }
 // pass B: thread j < 192; radix 16, ns = 12: k = j % 12, q = j / 12; twiddle exp(SIGN 2 pi i k r / 192) = twB[r * 12 + k]
-// (table holds the forward sign; the inverse conjugates); out[q * 192 + k + 12 r] in blocks of BSTRIDE
-template <int SIGN>
-ASX_HD void pass_b(int j, const float2 *bufA, float2 *bufB, const float2 *twB) {
-  const int k = j % 12, q = j / 12;
-  float2 c[16];
+// (table holds the forward sign; the inverse conjugates); out[q * 192 + k + 12 r] in blocks of BSTRIDE.  Load and store are
+// separate calls: with a barrier between them one LDS buffer of LDS_X elements serves every exchange.
+ASX_HD void pass_b_load(int j, const float2 *buf, float2 *c) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) c[r] = bufA[j + NB * r];
+  for (int r = 0; r < 16; ++r) c[r] = buf[j + NB * r];
+}
+template <int SIGN>
+ASX_HD void pass_b_store(int j, float2 *c, float2 *buf, const float2 *twB) {
+  const int k = j % 12, q = j / 12;
 #pragma unroll
   for (int r = 1; r < 16; ++r) {
     float2 w = twB[r * 12 + k];
@@ -156,14 +158,16 @@ ASX_HD void pass_b(int j, const float2 *bufA, float2 *bufB, const float2 *twB) {
   }
   dft16<SIGN>(c);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) bufB[q * BSTRIDE + k + 12 * r] = c[r];
+  for (int r = 0; r < 16; ++r) buf[q * BSTRIDE + k + 12 * r] = c[r];
 }
 // pass C: thread j < 192; radix 16, ns = 192 (q = 0, k = j); twiddle exp(SIGN 2 pi i j r / 3072) = twC[r * 192 + j]; result
 // c[r] = Z[j + 192 r] stays in registers
-template <int SIGN>
-ASX_HD void pass_c(int j, const float2 *bufB, const float2 *twC, float2 *c) {
+ASX_HD void pass_c_load(int j, const float2 *buf, float2 *c) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) c[r] = bufB[r * BSTRIDE + j];
+  for (int r = 0; r < 16; ++r) c[r] = buf[r * BSTRIDE + j];
+}
+template <int SIGN>
+ASX_HD void pass_c_compute(int j, float2 *c, const float2 *twC) {
 #pragma unroll
   for (int r = 1; r < 16; ++r) {
     float2 w = twC[r * NB + j];
@@ -210,13 +214,12 @@ struct Stft3Args {
   int64_t out_bstride;         // floats between batch items (0 = dense)
 };
 
-constexpr int STFT3_LDS_BYTES = (LDS_A + LDS_B) * 8;
-constexpr int ISTFT3_LDS_BYTES = (LDS_A + LDS_B) * 8 + NFFT * 4;
+constexpr int STFT3_LDS_BYTES = LDS_X * 8;
+constexpr int ISTFT3_LDS_BYTES = LDS_X * 8 + NFFT * 4;
 
 __global__ __launch_bounds__(256) void stft3_kernel(Stft3Args a) {
   extern __shared__ float2 lds3[];
-  float2 *bufA = lds3;
-  float2 *bufB = lds3 + LDS_A;
+  float2 *buf = lds3;
   const int t = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
   const int j = threadIdx.x;
   const int64_t C = a.C;
@@ -263,17 +266,22 @@ __global__ __launch_bounds__(256) void stft3_kernel(Stft3Args a) {
       v[r] = make_float2(xe[0] * w.x, xe[1] * w.y);
     }
   }
-  pass_a<-1>(j, v, bufA);
-  __syncthreads();
-  if (j < NB) pass_b<-1>(j, bufA, bufB, a.twB);
-  __syncthreads();
   float2 c[16];
+  pass_a<-1>(j, v, buf);
+  __syncthreads();
+  if (j < NB) pass_b_load(j, buf, c);
+  __syncthreads();
+  if (j < NB) pass_b_store<-1>(j, c, buf, a.twB);
+  __syncthreads();
+  if (j < NB) pass_c_load(j, buf, c);
+  __syncthreads();
   if (j < NB) {
-    pass_c<-1>(j, bufB, a.twC, c);
+    pass_c_compute<-1>(j, c, a.twC);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bufA[j + NB * r] = c[r];
+    for (int r = 0; r < 16; ++r) buf[j + NB * r] = c[r];
   }
   __syncthreads();
+  const float2 *bufA = buf;
   const int64_t bst = a.out_bstride ? a.out_bstride : (int64_t)4 * a.T * a.dim_f;
   float *re = a.spec + (int64_t)b * bst + ((int64_t)(ch * 2) * a.T + t) * a.dim_f;
   float *im = re + (int64_t)a.T * a.dim_f;
@@ -306,11 +314,18 @@ struct Istft3Args {
   float *out;              // [B, 2, C]
   float *seam;             // [B, 2, n_groups, 2, 5 * hop] partial hops (head, tail) of every frame group
   int G, n_groups;         // frames per workgroup (>= 5), groups per (chunk, channel) = max(1, T / G)
+  const double *hann;      // np.hanning(C) in float64 (the chunk window of a full-length chunk), or nullptr
 };
 
 __device__ __forceinline__ double hanning3_f64(int64_t j, int64_t M) {
   if (M == 1) return 1.0;
   return 0.5 + 0.5 * cos(3.14159265358979323846 * (double)(2 * j + 1 - M) / (double)(M - 1));
+}
+
+// np.hanning(M) in float64, element by element the same expression emit_hop evaluates for a chunk of any other length
+__global__ void hann3_table_kernel(int64_t M, double *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) out[i] = hanning3_f64(i, M);
 }
 
 // finish one complete hop: acc / env, chunk window, write (positions outside [0, C) belong to the stripped centre padding)
@@ -323,16 +338,15 @@ __device__ __noinline__ void emit_hop(const Istft3Args &a, int b, int ch, int64_
     const int64_t m = m0 + i, jo = m - NH;
     if (jo < 0 || jo >= a.C) continue;
     float y = vv[i] / a.env[m];
-    if (na >= 0) y = jo < na ? (float)((double)y * hanning3_f64(jo, na)) : 0.f;
+    if (na >= 0) y = jo < na ? (float)((double)y * ((na == a.C && a.hann) ? a.hann[jo] : hanning3_f64(jo, na))) : 0.f;
     a.out[((int64_t)b * 2 + ch) * a.C + jo] = y;
   }
 }
 
 __global__ __launch_bounds__(256, 2) void istft3_kernel(Istft3Args a) {
   extern __shared__ float2 lds3[];
-  float2 *bufA = lds3;
-  float2 *bufB = lds3 + LDS_A;
-  float *ring = reinterpret_cast<float *>(lds3 + LDS_A + LDS_B);
+  float2 *buf = lds3;
+  float *ring = reinterpret_cast<float *>(lds3 + LDS_X);
   const int g = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
   const int j = threadIdx.x;
   const int t0 = g * a.G;
@@ -362,13 +376,16 @@ __global__ __launch_bounds__(256, 2) void istft3_kernel(Istft3Args a) {
       const int k = j + 256 * r;
       v[r] = merge_bin(bin(k), bin(NH - k), a.tw[k]);           // k = 0 pairs with the (zero) Nyquist bin NH
     }
-    pass_a<+1>(j, v, bufA);
+    pass_a<+1>(j, v, buf);
     __syncthreads();
-    if (j < NB) pass_b<+1>(j, bufA, bufB, a.twB);
+    float2 c[16];
+    if (j < NB) pass_b_load(j, buf, c);
+    __syncthreads();
+    if (j < NB) pass_b_store<+1>(j, c, buf, a.twB);
     __syncthreads();
     if (j < NB) {
-      float2 c[16];
-      pass_c<+1>(j, bufB, a.twC, c);
+      pass_c_load(j, buf, c);
+      pass_c_compute<+1>(j, c, a.twC);
       const float scale = 1.0f / (float)NH;
       float2 *ring2 = reinterpret_cast<float2 *>(ring);
 #pragma unroll
@@ -392,7 +409,8 @@ __global__ __launch_bounds__(256, 2) void istft3_kernel(Istft3Args a) {
       if (t - t0 >= HPF - 1 || t0 == 0) emit_hop(a, b, ch, t, v4, j);
       else reinterpret_cast<float4 *>(seam_head + (t - t0) * HOP)[j] = v4;
     }
-    // the ring slot is re-used by frame t + 1 only after two more barriers (passes A and B)
+    // the ring slot is re-used by frame t + 1 only after three more barriers; the exchange buffer is rewritten by frame
+    // t + 1's pass A only after the barrier above, when every pass-C read of frame t has completed
   }
   __syncthreads();
   // hops t1 + 1 .. t1 + 5 still miss the frames of the next group (or are final when this group ends the chunk)

@@ -21,9 +21,23 @@ namespace asx {
 
 // ABL (ASX_TDF2_ABL, measurement-only instantiations, results are garbage): 1 = no DMA after the first stage, 2 = no MFMA,
 // 4 = no epilogue traffic
+// ABL bit 4 (16): timeline probe -- workgroups < 4096 of a launch with K == 384 record s_memtime at start / first data /
+// end of the K loop / end of the epilogue plus HW_ID and XCC_ID into asx_dbg_trace (read back by asx_debug_trace)
+__device__ unsigned long long asx_dbg_trace[4096 * 8];
+
 template <int NREP, int MREP, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_per_wg, int stagger_bit) {
   constexpr int abl = ABL;
+  const bool probe = ((abl & 16) != 0) && a.K == 384 && blockIdx.x < 4096 && threadIdx.x == 0;
+  if (probe) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asx_dbg_trace[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
+    asx_dbg_trace[blockIdx.x * 8 + 4] = hw;
+    asx_dbg_trace[blockIdx.x * 8 + 5] = xcc;
+    asx_dbg_trace[blockIdx.x * 8 + 6] = (unsigned long long)gridDim.x;
+  }
   using CFG = TdfDmaCfg<NREP, MREP, 32>;
   constexpr int BK = 32, BM = CFG::BM, BN = CFG::BN, BUF = CFG::BUF;
   constexpr int XPW = BM / 32, WPW = BN / 32;        // 1-KiB DMA pieces (8 rows x 32 floats) per wave and stage
@@ -38,9 +52,33 @@ __global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_pe
 
   const int nbn = (a.N + BN - 1) / BN;
   const int groups = nbn / tiles_per_wg;             // launcher: tiles_per_wg divides nbn
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bg = lid % groups;
-  const int64_t m0 = (int64_t)(lid / groups) * BM;
+  // Tile -> workgroup map.  The dispatcher places block b on XCD b % 8, each XCD has its own 4 MiB L2, and the level-0 TDF
+  // weights are 4.7 MB: with every XCD sweeping all column tiles the W tiles thrash L2 and each workgroup re-streams its
+  // 295 KB from MALL / HBM (timeline probe: ~690 KB of L2-miss traffic per workgroup against 196 KB algorithmic, the launch
+  // ran at the memory system's ~4.6 TB/s).  Column tiles are therefore PARTITIONED over the XCDs whenever the shapes allow:
+  //   groups % 8 == 0 : XCD x owns column groups [x * groups / 8, (x + 1) * groups / 8) for every row tile;
+  //   8 % groups == 0 : 8 / groups XCDs share one column group and split the row tiles between them;
+  // so an XCD keeps only its slice of W hot, and the x tile of a row is read by the XCDs through MALL.
+  int bg;
+  int64_t bm_i;
+  {
+    const int nbm_i = (int)((a.M + BM - 1) / BM);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if ((gridDim.x & 7) == 0 && groups >= 8 && (groups & 7) == 0) {
+      const int cx = groups >> 3;
+      bg = xcd * cx + slot % cx;
+      bm_i = slot / cx;
+    } else if ((gridDim.x & 7) == 0 && groups < 8 && (8 % groups) == 0 && nbm_i % (8 / groups) == 0) {
+      const int r = 8 / groups;
+      bg = xcd / r;
+      bm_i = (int64_t)slot * r + (xcd % r);
+    } else {
+      const int lid = xcd_remap(blockIdx.x, gridDim.x);
+      bg = lid % groups;
+      bm_i = lid / groups;
+    }
+  }
+  const int64_t m0 = bm_i * BM;
   const int64_t lda = a.lda ? a.lda : a.K, ldy = a.ldy ? a.ldy : a.N, ldr = a.ldr ? a.ldr : a.N;
   const int nk = a.K / BK;
   const int total = nk * tiles_per_wg;
@@ -109,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_pe
   for (int it = 0; it < total; ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (probe && it == 0) asx_dbg_trace[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
     const float *xs = lds_f + (it & 1) * BUF;
     const float *ws = xs + BM * BK;
     f32x4 wa[2][NREP], xb[2][4];
@@ -167,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_pe
     }
     if (++ks < nk) continue;
     ks = 0;
+    if (probe && tile == 0) asx_dbg_trace[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue of column tile `tile` (the next tile's first stage is already in flight) -------------------------------
     const int n0 = (bg * tiles_per_wg + tile) * BN;
@@ -233,37 +273,75 @@ __global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_pe
         const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
         bz[n] = (a.bias != nullptr) ? *reinterpret_cast<const f32x4 *>(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
+      // The timeline probe (ASX_TDF2_ABL=16) showed this epilogue to be LATENCY-bound: with the residual fetched in dependent
+      // load -> compute -> store rounds of 6 float4 per wave it took as long as the whole 12-stage K loop (~100 k cycles on
+      // K = 384, i.e. ~2 B/clk per workgroup).  On the ReLU path (every TDF layer of ConvTDFNet) the residual of FOUR 16-row
+      // groups is kept in flight (a register ring refilled as soon as a group has been stored; the fragment registers of the
+      // K loop are dead here), addressed as scalar base + one 32-bit lane offset to keep address pairs out of the budget.  Other activations (erf /
+      // tanh / exp bodies) keep rounds of two 16-row groups.
+      const uint32_t voff_r = (uint32_t)((li * ldr + wave * 16 * NREP + lk * 4) * 4);
+      const uint32_t voff_y = (uint32_t)((li * ldy + wave * 16 * NREP + lk * 4) * 4);
+      if (a.relu == 1) {
+        constexpr int RING = MREP < 4 ? MREP : 4;        // 16-row groups whose residual is in flight at any time
+        f32x4 rs[RING][NREP];
+        auto fetch = [&](int m) {
+          const char *rb = reinterpret_cast<const char *>(a.res) + ((m0 + m * 16) * ldr + n0) * 4;
 #pragma unroll
-      for (int mg = 0; mg < MREP; mg += 2) {            // two 16-row groups at a time: 2 x NREP residual vectors in flight
-        float sc[2], sh[2];
-        f32x4 rs[2][NREP];
+          for (int n = 0; n < NREP; ++n)
+            rs[m % RING][n] = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(rb + voff_r + n * 64) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const int64_t row = m0 + (mg + m) * 16 + li;
-          const int c = (int)(((uint32_t)row / (uint32_t)a.T) % (uint32_t)a.C);   // launcher: M < 2^31 on this kernel
-          sc[m] = a.scale ? a.scale[c] : 1.f;
-          sh[m] = a.shift ? a.shift[c] : 0.f;
+        for (int m = 0; m < RING; ++m) fetch(m);
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const uint32_t row = (uint32_t)(m0 + m * 16 + li);                      // launcher: M < 2^31 on this kernel
+          const int c = (int)((row / (uint32_t)a.T) % (uint32_t)a.C);
+          const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
+          char *yb = reinterpret_cast<char *>(a.y) + ((m0 + m * 16) * ldy + n0) * 4;
 #pragma unroll
           for (int n = 0; n < NREP; ++n) {
-            const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
-            rs[m][n] = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(a.res + row * ldr + col)
-                                          : (f32x4){0.f, 0.f, 0.f, 0.f};
-          }
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const int64_t row = m0 + (mg + m) * 16 + li;
-#pragma unroll
-          for (int n = 0; n < NREP; ++n) {
-            const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
-            const f32x4 v = acc[n][mg + m];
+            const f32x4 v = acc[n][m];
+            const f32x4 r = rs[m % RING][n];
             f32x4 o;
-            o.x = tdf_act(sc[m] * (v.x + bz[n].x) + sh[m], a.relu) + rs[m][n].x;
-            o.y = tdf_act(sc[m] * (v.y + bz[n].y) + sh[m], a.relu) + rs[m][n].y;
-            o.z = tdf_act(sc[m] * (v.z + bz[n].z) + sh[m], a.relu) + rs[m][n].z;
-            o.w = tdf_act(sc[m] * (v.w + bz[n].w) + sh[m], a.relu) + rs[m][n].w;
-            *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = o;
-            acc[n][mg + m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            o.x = fmaxf(sc * (v.x + bz[n].x) + sh, 0.f) + r.x;
+            o.y = fmaxf(sc * (v.y + bz[n].y) + sh, 0.f) + r.y;
+            o.z = fmaxf(sc * (v.z + bz[n].z) + sh, 0.f) + r.z;
+            o.w = fmaxf(sc * (v.w + bz[n].w) + sh, 0.f) + r.w;
+            *reinterpret_cast<f32x4 *>(yb + voff_y + n * 64) = o;
+            acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+          if (m + RING < MREP) fetch(m + RING);        // refill the slot just consumed: RING groups stay in flight
+        }
+      } else {
+#pragma unroll
+        for (int mg = 0; mg < MREP; mg += 2) {
+          float sc[2], sh[2];
+          f32x4 rs[2][NREP];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const uint32_t row = (uint32_t)(m0 + (mg + m) * 16 + li);
+            const int c = (int)((row / (uint32_t)a.T) % (uint32_t)a.C);
+            sc[m] = a.scale ? a.scale[c] : 1.f;
+            sh[m] = a.shift ? a.shift[c] : 0.f;
+            const char *rb = reinterpret_cast<const char *>(a.res) + ((m0 + (mg + m) * 16) * ldr + n0) * 4;
+#pragma unroll
+            for (int n = 0; n < NREP; ++n)
+              rs[m][n] = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(rb + voff_r + n * 64) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            char *yb = reinterpret_cast<char *>(a.y) + ((m0 + (mg + m) * 16) * ldy + n0) * 4;
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) {
+              const f32x4 v = acc[n][mg + m];
+              f32x4 o;
+              o.x = tdf_act(sc[m] * (v.x + bz[n].x) + sh[m], a.relu) + rs[m][n].x;
+              o.y = tdf_act(sc[m] * (v.y + bz[n].y) + sh[m], a.relu) + rs[m][n].y;
+              o.z = tdf_act(sc[m] * (v.z + bz[n].z) + sh[m], a.relu) + rs[m][n].z;
+              o.w = tdf_act(sc[m] * (v.w + bz[n].w) + sh[m], a.relu) + rs[m][n].w;
+              *reinterpret_cast<f32x4 *>(yb + voff_y + n * 64) = o;
+              acc[n][mg + m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
           }
         }
       }
@@ -290,6 +368,10 @@ __global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_pe
           *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = o;
         }
       }
+    }
+    if (probe && tile == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asx_dbg_trace[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memtime();
     }
   }
 }

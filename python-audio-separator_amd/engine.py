@@ -223,7 +223,7 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
            "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev",
            "asx_hd_begin", "asx_hd_commit", "asx_hd_flops", "asx_hd_forward", "asx_hd_demix", "asx_hd_demix_dev", "asx_hd_plan",
-           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize"]
+           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_debug_trace"]
 
 
 def load_library():

@@ -23,20 +23,22 @@ int main(int argc, char **argv) {
     for (int k = 0; k < 12; ++k) twB[r * 12 + k] = make_float2((float)cos(2 * PI * k * r / 192.0), (float)-sin(2 * PI * k * r / 192.0));
   for (int r = 0; r < 16; ++r)
     for (int j = 0; j < NB; ++j) twC[r * NB + j] = make_float2((float)cos(2 * PI * j * r / 3072.0), (float)-sin(2 * PI * j * r / 3072.0));
-  std::vector<float2> bufA(LDS_A), bufB(LDS_B);
+  std::vector<float2> buf(LDS_X);
+  std::vector<float2> regs(NB * 16);   // the registers a thread keeps across a barrier
   std::vector<float> out(2 * NH + NFFT);
   // ---- forward ----
   for (int j = 0; j < 256; ++j) {
     float2 v[12];
     for (int r = 0; r < 12; ++r) v[r] = make_float2(x[2 * (j + 256 * r)], x[2 * (j + 256 * r) + 1]);
-    pass_a<-1>(j, v, bufA.data());
+    pass_a<-1>(j, v, buf.data());
   }
-  for (int j = 0; j < NB; ++j) pass_b<-1>(j, bufA.data(), bufB.data(), twB.data());
+  for (int j = 0; j < NB; ++j) pass_b_load(j, buf.data(), &regs[j * 16]);                       // barrier
+  for (int j = 0; j < NB; ++j) pass_b_store<-1>(j, &regs[j * 16], buf.data(), twB.data());       // barrier
+  for (int j = 0; j < NB; ++j) pass_c_load(j, buf.data(), &regs[j * 16]);                       // barrier
   std::vector<float2> Z(NH);
   for (int j = 0; j < NB; ++j) {
-    float2 c[16];
-    pass_c<-1>(j, bufB.data(), twC.data(), c);
-    for (int r = 0; r < 16; ++r) Z[j + NB * r] = c[r];
+    pass_c_compute<-1>(j, &regs[j * 16], twC.data());
+    for (int r = 0; r < 16; ++r) Z[j + NB * r] = regs[j * 16 + r];
   }
   for (int k = 0; k < NH; ++k) {
     const float2 v = split_bin(k, Z.data(), tw[k]);
@@ -51,12 +53,14 @@ int main(int argc, char **argv) {
       const int k = j + 256 * r;
       v[r] = merge_bin(bin(k), bin(NH - k), tw[k]);
     }
-    pass_a<+1>(j, v, bufA.data());
+    pass_a<+1>(j, v, buf.data());
   }
-  for (int j = 0; j < NB; ++j) pass_b<+1>(j, bufA.data(), bufB.data(), twB.data());
+  for (int j = 0; j < NB; ++j) pass_b_load(j, buf.data(), &regs[j * 16]);
+  for (int j = 0; j < NB; ++j) pass_b_store<+1>(j, &regs[j * 16], buf.data(), twB.data());
   for (int j = 0; j < NB; ++j) {
-    float2 c[16];
-    pass_c<+1>(j, bufB.data(), twC.data(), c);
+    float2 *c = &regs[j * 16];
+    pass_c_load(j, buf.data(), c);
+    pass_c_compute<+1>(j, c, twC.data());
     for (int r = 0; r < 16; ++r) {
       const int m = j + NB * r;
       out[2 * NH + 2 * m] = c[r].x / (float)NH;
