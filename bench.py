@@ -242,7 +242,7 @@ def main():
                     traffic = round(json.load(fh)["traffic_over_algorithmic"] * c["bytes"] / max(1, c["launches"]), 1)
                 source = f"stored: profiles/{name} (rocprofv3 --pmc passes), ratio applied to this run's algorithmic bytes"
                 break
-        roofline = {"kernel": "conv_dma_kernel<3,3,1,1,3,8,2,0> (TFC 3x3 convs)", "bound": "mfma", "achieved": round(ach, 2),
+        roofline = {"kernel": "conv_dma_kernel<3,3,1,1,3,4,2,0> (TFC 3x3 convs)", "bound": "mfma", "achieved": round(ach, 2),
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": source,
                     "algorithmic_bytes_per_launch": c["bytes"] / max(1, c["launches"]),

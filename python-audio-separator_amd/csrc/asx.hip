@@ -281,6 +281,12 @@ static int conv_setup(ConvLayer &L, int kind, int cin, int cout, int relu) {
   } else {
     L.nrep = pick_nrep_conv(cout);
     L.kc = (kind == CK_3X3) ? 8 : (kind == CK_DOWN ? 4 : (cin >= 16 ? 16 : 4));
+    // 3x3 convs stage FOUR channels at a time (37 KB of LDS instead of 75 KB at eight): a third co-resident workgroup
+    // per CU covers the prologue / epilogue / barrier gaps of the other two.  Measured on the bench configuration: 3x3 class
+    // 234.9 -> 224.0 ms (85.1 -> 89.4 % of the fp32-MFMA peak), every level gains.  ASX_CONV_KC4=<cin threshold> for the
+    // A/B (0 = eight channels everywhere).
+    static const int kc4 = getenv("ASX_CONV_KC4") ? atoi(getenv("ASX_CONV_KC4")) : (1 << 30);
+    if (kind == CK_3X3 && cin <= kc4 && cin % 4 == 0 && pick_nrep_conv(cout) == 3) L.kc = 4;
     L.cg = ((cout + 15) / 16 + L.nrep - 1) / L.nrep;
   }
   L.nci = (cin + L.kc - 1) / L.kc;
@@ -455,7 +461,8 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
   CHK(timed(e, cls, flops, bytes, s, [&]() {
     switch (L.kind) {
       case CK_3X3:
-        if (L.nrep == 3) ASX_CONV_CASE(3, 3, 1, 1, 3, 8, 2, EPI_BIAS_ACT);
+        if (L.nrep == 3 && L.kc == 4) ASX_CONV_CASE(3, 3, 1, 1, 3, 4, 2, EPI_BIAS_ACT);
+        else if (L.nrep == 3) ASX_CONV_CASE(3, 3, 1, 1, 3, 8, 2, EPI_BIAS_ACT);
         else if (L.nrep == 2) ASX_CONV_CASE(3, 3, 1, 1, 2, 8, 2, EPI_BIAS_ACT);
         else ASX_CONV_CASE(3, 3, 1, 1, 1, 8, 2, EPI_BIAS_ACT);
         break;
@@ -550,24 +557,24 @@ static bool tdf2_ok(const TdfDmaArgs &d) {
          (uint64_t)8 * (uint64_t)lda * 4 < (1ull << 31) && (uint64_t)8 * (uint64_t)d.K * 4 < (1ull << 31) &&
          (uint64_t)16 * (uint64_t)ldy * 4 < (1ull << 31) && (uint64_t)16 * (uint64_t)ldr * 4 < (1ull << 31);
 }
-template <int NREP, int MREP, int ABL>
+template <int NREP, int MREP, int ABL, int BK = 32>
 static void launch_tdf2_abl(const TdfDmaArgs &a, hipStream_t s) {
-  using CFG = TdfDmaCfg<NREP, MREP, 32>;
+  constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = 2 * (BM + BN) * BK * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tdf2_kernel<NREP, MREP, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              CFG::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tdf2_kernel<NREP, MREP, ABL, BK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_done = true;
   }
   static const int sbit = getenv("ASX_TDF2_SBIT") ? atoi(getenv("ASX_TDF2_SBIT")) : 8;
-  const int64_t nbm = (a.M + CFG::BM - 1) / CFG::BM;
-  const int nbn = (a.N + CFG::BN - 1) / CFG::BN;
+  const int64_t nbm = (a.M + BM - 1) / BM;
+  const int nbn = (a.N + BN - 1) / BN;
   const int mode = tdf2_mode();
   // persistent over the column tiles when the K loop is short (prologue / epilogue are a visible share of a tile) and the
   // row tiles alone fill the 512 workgroup slots several times over
   const bool persist = mode >= 2 && nbn >= 2 && a.K <= 768 && nbm >= 2048;
   const int tiles = persist ? nbn : 1;
-  hipLaunchKernelGGL((tdf2_kernel<NREP, MREP, ABL>), dim3((unsigned)(nbm * (nbn / tiles))), dim3(256), CFG::LDS_BYTES, s, a, tiles,
+  hipLaunchKernelGGL((tdf2_kernel<NREP, MREP, ABL, BK>), dim3((unsigned)(nbm * (nbn / tiles))), dim3(256), LDS_BYTES, s, a, tiles,
                      (mode >= 3 && persist) ? sbit : -1);
 }
 template <int NREP, int MREP>
@@ -584,6 +591,14 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
       case 8: return launch_tdf2_abl<3, 8, 8>(a, s);
       case 16: return launch_tdf2_abl<3, 8, 16>(a, s);
       default: break;
+    }
+  }
+  // ASX_TDF2_BK16: 16-float stages (40 KB of LDS, launch bound 3) -- 1: on the 128 x 192 tile, 2: on a 64 x 192 tile
+  static const int bk16 = getenv("ASX_TDF2_BK16") ? atoi(getenv("ASX_TDF2_BK16")) : 0;
+  if constexpr (NREP == 3 && MREP == 8) {
+    if (a.M % 16 == 0 && a.N % 16 == 0) {
+      if (bk16 == 1) return launch_tdf2_abl<3, 8, 0, 16>(a, s);
+      if (bk16 == 2) return launch_tdf2_abl<3, 4, 0, 16>(a, s);
     }
   }
   launch_tdf2_abl<NREP, MREP, 0>(a, s);

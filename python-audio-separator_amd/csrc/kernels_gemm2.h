@@ -25,8 +25,11 @@ namespace asx {
 // end of the K loop / end of the epilogue plus HW_ID and XCC_ID into asx_dbg_trace (read back by asx_debug_trace)
 __device__ unsigned long long asx_dbg_trace[4096 * 8];
 
-template <int NREP, int MREP, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_per_wg, int stagger_bit) {
+// BK_ = 32: 80 KB of LDS, two workgroups per CU.  BK_ = 16: 40 KB and half-length stages -- a THIRD co-resident workgroup when
+// the registers allow it (launch bound 3: <= 168 VGPRs); rows are then 64 bytes (4 chunks) and the chunk swizzle is
+// chunk ^ h((row >> 2) & 3), h = {0, 2, 3, 1}, which keeps every 16-lane group of ds_read_b128 on four distinct chunk slots.
+template <int NREP, int MREP, int ABL = 0, int BK_ = 32>
+__global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaArgs a, int tiles_per_wg, int stagger_bit) {
   constexpr int abl = ABL;
   const bool probe = ((abl & 16) != 0) && a.K == 384 && blockIdx.x < 4096 && threadIdx.x == 0;
   if (probe) {
@@ -38,11 +41,13 @@ __global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_pe
     asx_dbg_trace[blockIdx.x * 8 + 5] = xcc;
     asx_dbg_trace[blockIdx.x * 8 + 6] = (unsigned long long)gridDim.x;
   }
-  using CFG = TdfDmaCfg<NREP, MREP, 32>;
-  constexpr int BK = 32, BM = CFG::BM, BN = CFG::BN, BUF = CFG::BUF;
-  constexpr int XPW = BM / 32, WPW = BN / 32;        // 1-KiB DMA pieces (8 rows x 32 floats) per wave and stage
-  constexpr int MG = MREP / 4, NG = 2 * MG;          // MFMA groups per stage: (kk = 0, 1) x (row quads)
-  static_assert(BM % 32 == 0 && BN % 32 == 0 && MREP % 4 == 0, "tile shape");
+  constexpr int BK = BK_, BM = 16 * MREP, BN = 64 * NREP, BUF = (BM + BN) * BK;
+  constexpr int CPR = BK / 4, RP = 64 / CPR;         // 16-byte chunks per row; rows per 1-KiB DMA piece (8 or 16)
+  constexpr int XPW = BM / RP / 4, WPW = BN / RP / 4;  // pieces per wave and stage
+  constexpr int NKK = BK / 16, MG = MREP / 4, NG = NKK * MG;   // MFMA groups per stage: (kk) x (row quads)
+  static_assert(BK == 32 || BK == 16, "BK");
+  static_assert((abl & 8) == 0 || BK == 32, "the staged epilogue needs a 40 KB stage buffer");
+  static_assert(BM % (4 * RP) == 0 && BN % (4 * RP) == 0 && MREP % 4 == 0, "tile shape");
   extern __shared__ float lds_f[];
 
   const int tid = threadIdx.x;
@@ -85,21 +90,23 @@ __global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_pe
 
   if (stagger_bit >= 0 && ((blockIdx.x >> stagger_bit) & 1)) {
     // half a tile of MFMA time: nk stages x 192 MFMAs x 32 cycles / 2, in s_sleep units of 64 cycles
-    const int naps = (nk * NREP * MREP * 8 * 32 / 2) / (64 * 100);
+    const int naps = (nk * NREP * MREP * (BK / 4) * 32 / 2) / (64 * 100);
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(100);
   }
 
-  // ---- DMA addressing: piece q = wave + 4 i covers tile rows 8 q .. 8 q + 7; lane (lr, lp) fetches the 16-byte chunk that
-  // lands in physical slot lp of row lr, i.e. logical chunk lp ^ g(row) with g(row) = (row >> 1) & 7 = (4 (wave & 1) + (lr >> 1)) & 7
-  const int lr = lane >> 3, lp = lane & 7;
-  const int gsw = (((wave & 1) << 2) + (lr >> 1)) & 7;
+  // ---- DMA addressing: piece q = wave + 4 i covers tile rows RP q .. RP q + RP - 1; lane (lr, lp) fetches the 16-byte chunk
+  // that lands in physical slot lp of row lr, i.e. logical chunk lp ^ g(row):
+  //   BK 32: g(row) = (row >> 1) & 7 = (4 (wave & 1) + (lr >> 1)) & 7      BK 16: g(row) = h((row >> 2) & 3) = h((lr >> 2) & 3)
+  auto hsw = [](int g) { return g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 3 : 1)); };
+  const int lr = lane / CPR, lp = lane % CPR;
+  const int gsw = BK == 32 ? ((((wave & 1) << 2) + (lr >> 1)) & 7) : hsw((lr >> 2) & 3);
   const uint32_t voff_x = (uint32_t)((lr * lda + ((lp ^ gsw) << 2)) * 4);
   const uint32_t voff_w = (uint32_t)(((int64_t)lr * a.K + ((lp ^ gsw) << 2)) * 4);
   const char *xrow[XPW];
 #pragma unroll
   for (int i = 0; i < XPW; ++i) {
-    int64_t r = m0 + 8 * (wave + 4 * i);
-    r = r < a.M - 8 ? r : a.M - 8;                    // clamp whole row groups; masked at the store
+    int64_t r = m0 + RP * (wave + 4 * i);
+    r = r < a.M - RP ? r : a.M - RP;                  // clamp whole row groups (launcher: M % RP == 0); masked at the store
     xrow[i] = reinterpret_cast<const char *>(a.x) + r * lda * 4;
   }
 
@@ -107,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_pe
   auto set_wrows = [&](int n0) {                      // once per column tile
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-      int r = n0 + 8 * (wave + 4 * i);
-      r = r < a.N - 8 ? r : a.N - 8;
+      int r = n0 + RP * (wave + 4 * i);
+      r = r < a.N - RP ? r : a.N - RP;
       wrow[i] = reinterpret_cast<const char *>(a.w) + ((int64_t)r * a.K) * 4;
     }
   };
@@ -128,8 +135,8 @@ __global__ __launch_bounds__(256, 2) void tdf2_kernel(TdfDmaArgs a, int tiles_pe
 #pragma unroll
     for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int sw = (li >> 1) & 7;                       // g(row) of fragment rows 16 t + li
-  const int pc0 = ((lk ^ sw) << 2), pc1 = (((4 + lk) ^ sw) << 2);
+  const int sw = BK == 32 ? ((li >> 1) & 7) : hsw((li >> 2) & 3);   // g(row) of fragment rows 16 t + li
+  const int pc0 = ((lk ^ sw) << 2), pc1 = (((4 + lk) ^ sw) << 2);     // pc1 (second 16-float half of a stage) only when BK = 32
   const int wrow_f = (wave * 16 * NREP + li) * BK;
   const int xrw = li * BK;
 

@@ -75,3 +75,43 @@ def test_mdx_invert_using_spec(tmp_path, monkeypatch):
     want = EO.invert_stem(raw, (primary * inst.compensate).T)
     assert secondary.shape == want.shape
     assert SC.rel_rms(secondary, want) < 1e-4
+
+
+def test_normalize_bit_exact_and_inplace():
+    """asx_normalize = spec_utils.normalize (uvr_lib_v5/spec_utils.py:99-115): float32 numpy semantics, in place."""
+    import audio_separator_amd as A
+    eng = A.Engine(A.MDXConfig(n_fft=96, hop_length=16, dim_f=32, segment_size=16))
+    rng = np.random.default_rng(3)
+    for amp, thr, amp_thr in ((2.0, 0.9, None), (0.2, 0.9, 0.5), (0.5, 0.9, 0.0), (0.95, 1.0, None)):
+        x = (amp * rng.uniform(-1, 1, (2, 5001))).astype(np.float32)
+        want = x.copy()
+        maxv = np.abs(want).max()
+        if maxv > thr:
+            want *= thr / maxv
+        elif amp_thr is not None and maxv < amp_thr:
+            want *= amp_thr / maxv
+        got = eng.normalize(x, thr, amp_thr)
+        assert got is x and np.array_equal(x, want)
+    v = np.asfortranarray((3.0 * rng.uniform(-1, 1, (700, 2))).astype(np.float32)).T      # non-contiguous view: written back
+    ref = v.copy()
+    ref *= np.float32(0.9) / np.abs(ref).max()
+    out = eng.normalize(v, 0.9, 0.0)
+    assert np.array_equal(np.asarray(out), ref)
+
+
+def test_soundfile_writer_path_keeps_input_subtype(tmp_path, monkeypatch):
+    """use_soundfile=True (common_separator.py:399-461): normalise on the device, keep the input's subtype (24-bit in -> PCM_24 out)."""
+    from audio_separator_amd import audio_io
+    case = SC.cases("mdx", str(tmp_path))[0]
+    tag, cls, common, arch, wav, custom = case
+    x, sr = audio_io.read_wav(wav)
+    wav24 = str(tmp_path / "in24.wav")
+    audio_io.write_wav(wav24, x.T, sr, "PCM_24")
+    inst = SC.plugin_class(cls)(common_config=dict(common, use_soundfile=True), arch_config=arch)
+    names = inst.separate(wav24, None)
+    assert inst.input_bit_depth == 24 and inst.input_subtype == "PCM_24"
+    for n in names:
+        info = audio_io.info(os.path.join(common["output_dir"], n))
+        assert info["subtype"] == "PCM_24" and info["channels"] == 2 and info["frames"] == x.shape[1]
+        y, _ = audio_io.read_wav(os.path.join(common["output_dir"], n))
+        assert 0.1 < np.abs(y).max() <= 0.9 + 1e-6
