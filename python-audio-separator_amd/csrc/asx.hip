@@ -146,6 +146,7 @@ struct asx_engine {
   DevBuf d_hann3;                // np.hanning(chunk_size) in float64 for the fused inverse's chunk window
   DevBuf d_tw3, seam3;           // fast FFT path (kernels_fft3.h): twiddles [16][12] + [16][192]; seam partial sums
   bool fft3 = false;             // n_fft == 6144 && hop == 1024 (and ASX_FFT3 != 0)
+  bool fft3p = false;            // inverse with the LDS-DMA spectrum prefetch (ASX_FFT3P != 0)
   DevBuf d_zeros;                // zero page: source of out-of-range DMA slots
   // net
   bool net_begun = false, net_ready = false;
@@ -727,12 +728,19 @@ static int stft_launch(asx_engine *e, const float *wave, const int64_t *d_starts
     f.zero_low = zero_low;
     f.spec = spec;
     f.window = a.window;
-    f.tw = a.tw;
-    f.twB = reinterpret_cast<const float2 *>(e->d_tw3.p);
+    f.tw = reinterpret_cast<const f3::cplx *>(a.tw);
+    f.twB = reinterpret_cast<const f3::cplx *>(e->d_tw3.p);
     f.twC = f.twB + 16 * 12;
     f.sign = sign;
+    // ~16 frames per workgroup, in even shares: many short workgroups balance better over the CUs than two or three rounds
+    // of long ones (measured: 8 / 16 frames 0.257 / 0.253 ms, 20 frames in exactly two rounds 0.368 ms)
+    static const int GS = getenv("ASX_FFT3_GS") ? std::max(1, atoi(getenv("ASX_FFT3_GS"))) : 16;
+    f.n_groups = std::max(1, T / GS);
     return timed(e, ASX_PROF_STFT, 0.0, bytes, s, [&]() {
-      hipLaunchKernelGGL(f3::stft3_kernel, dim3(T, 2, B), dim3(256), f3::STFT3_LDS_BYTES, s, f);
+      if (e->fft3p)
+        hipLaunchKernelGGL(f3::stft3p_kernel, dim3(f.n_groups, 2, B), dim3(256), f3::STFT3P_LDS_BYTES, s, f);
+      else
+        hipLaunchKernelGGL(f3::stft3_kernel, dim3(T, 2, B), dim3(256), f3::STFT3_LDS_BYTES, s, f);
     });
   }
   return timed(e, ASX_PROF_STFT, 0.0, bytes, s, [&]() {
@@ -776,7 +784,9 @@ static int istft_ola_launch(asx_engine *e, const float *spec, int B, int T, int 
     CHK(istft_launch(e, spec, B, T, 1, combine, e->frames.f(), s));
     return ola_launch(e, e->frames.f(), e->d_env.f(), d_nact, B, T, C, out, s);
   }
-  static const int G = getenv("ASX_FFT3_G") ? std::max(5, atoi(getenv("ASX_FFT3_G"))) : 16;   // frames per workgroup
+  // >= 16 frames per workgroup, in even shares.  The grouping depends on T only: a hop on a seam is summed as
+  // (tail partial) + (head partial), so results stay bit-identical whatever the batch size.
+  static const int G = getenv("ASX_FFT3_G") ? std::max(5, atoi(getenv("ASX_FFT3_G"))) : 16;
   const int ng = std::max(1, T / G);
   CHK(e->seam3.ensure((size_t)B * 2 * ng * 2 * 5 * f3::HOP * 4));
   f3::Istft3Args f{};
@@ -785,21 +795,30 @@ static int istft_ola_launch(asx_engine *e, const float *spec, int B, int T, int 
   f.dim_f = e->cfg.dim_f;
   f.combine = combine;
   f.window = e->d_window.f();
-  f.tw = reinterpret_cast<const float2 *>(e->d_tw.p);
-  f.twB = reinterpret_cast<const float2 *>(e->d_tw3.p);
+  f.tw = reinterpret_cast<const f3::cplx *>(e->d_tw.p);
+  f.twB = reinterpret_cast<const f3::cplx *>(e->d_tw3.p);
   f.twC = f.twB + 16 * 12;
   f.env = e->d_env.f();
   f.n_act = d_nact;
   f.C = C;
   f.out = out;
   f.seam = e->seam3.f();
-  f.G = G;
   f.n_groups = ng;
   f.hann = (C == (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1) && e->d_hann3.p) ? reinterpret_cast<const double *>(e->d_hann3.p) : nullptr;
-  const double seam_bytes = ng > 1 ? 4.0 * (double)B * 2 * (ng - 1) * 2 * 5 * f3::HOP * 2 : 0.0;
-  const double bytes = 4.0 * ((double)B * 4 * T * e->cfg.dim_f * (combine ? 2 : 1) + (double)B * 2 * C) + seam_bytes;
+  // algorithmic bytes: the spectrogram read once, the chunk written once (the seam buffer's round trip is overhead, not counted)
+  const double bytes = 4.0 * ((double)B * 4 * T * e->cfg.dim_f * (combine ? 2 : 1) + (double)B * 2 * C);
   return timed(e, ASX_PROF_ISTFT, 0.0, bytes, s, [&]() {
-    hipLaunchKernelGGL(f3::istft3_kernel, dim3(ng, 2, B), dim3(256), f3::ISTFT3_LDS_BYTES, s, f);
+    const bool aligned = e->cfg.dim_f % 4 == 0 && (reinterpret_cast<uintptr_t>(spec) & 15) == 0 && f.in_bstride % 4 == 0;
+    if (e->fft3p && combine == 0 && aligned)
+    {
+      static const int abl = getenv("ASX_ISTFT_ABL") ? atoi(getenv("ASX_ISTFT_ABL")) : 0;   // timing probes (results invalid)
+      if (abl == 1) hipLaunchKernelGGL(f3::istft3p_kernel<1>, dim3(ng, 2, B), dim3(256), f3::ISTFT3P_LDS_BYTES, s, f);
+      else if (abl == 2) hipLaunchKernelGGL(f3::istft3p_kernel<2>, dim3(ng, 2, B), dim3(256), f3::ISTFT3P_LDS_BYTES, s, f);
+      else if (abl == 3) hipLaunchKernelGGL(f3::istft3p_kernel<3>, dim3(ng, 2, B), dim3(256), f3::ISTFT3P_LDS_BYTES, s, f);
+      else hipLaunchKernelGGL(f3::istft3p_kernel<0>, dim3(ng, 2, B), dim3(256), f3::ISTFT3P_LDS_BYTES, s, f);
+    }
+    else
+      hipLaunchKernelGGL(f3::istft3_kernel, dim3(ng, 2, B), dim3(256), f3::ISTFT3_LDS_BYTES, s, f);
     if (ng > 1) hipLaunchKernelGGL(f3::seam3_kernel, dim3(5, ng - 1, B * 2), dim3(256), 0, s, f);
   });
 }
@@ -962,7 +981,18 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
                                   f3::STFT3_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f3::istft3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   f3::ISTFT3_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f3::istft3p_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  f3::ISTFT3P_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f3::istft3p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  f3::ISTFT3P_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f3::istft3p_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  f3::ISTFT3P_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f3::istft3p_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  f3::ISTFT3P_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f3::stft3p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  f3::STFT3P_LDS_BYTES);
         e->fft3 = true;
+        e->fft3p = !(getenv("ASX_FFT3P") && atoi(getenv("ASX_FFT3P")) == 0);
         if ((rc = e->d_hann3.ensure((size_t)C * 8)) == ASX_OK) {
           hipLaunchKernelGGL(f3::hann3_table_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, nullptr, C,
                              reinterpret_cast<double *>(e->d_hann3.p));

@@ -335,17 +335,23 @@ def test_fft3_fast_path_vs_generic_and_oracle(A, monkeypatch):
     (csrc/kernels_fft3.h); ASX_FFT3=0 keeps the generic six-pass kernels + frame buffer + ola_kernel.  Both against the oracle
     (STFT -> bins [0, 3) zeroed -> iSTFT, the match-mix pass of run_model) on a 3-chunk batch, at a short segment too (T = 40:
     one frame group, no seams) and at T = 70 (two groups, the second longer than G)."""
-    for seg in (256, 40, 70):
+    for seg, dim_f in ((256, 3072), (40, 3072), (70, 3072), (70, 2048)):
         C = 1024 * (seg - 1)
         w = (0.3 * np.random.default_rng(seg).standard_normal((3, 2, C))).astype(np.float32)
-        ref = O.run_model(w, O.MDXParams(segment_size=seg), None, is_match_mix=True)
+        ref = O.run_model(w, O.MDXParams(segment_size=seg, dim_f=dim_f), None, is_match_mix=True)
         monkeypatch.setenv("ASX_FFT3", "1")
-        fast = A.Engine(A.MDXConfig(segment_size=seg)).run_model(w, is_match_mix=True)
+        monkeypatch.setenv("ASX_FFT3P", "1")
+        fast = A.Engine(A.MDXConfig(segment_size=seg, dim_f=dim_f)).run_model(w, is_match_mix=True)
+        monkeypatch.setenv("ASX_FFT3P", "0")      # the inverse without the LDS-DMA spectrum prefetch (the denoise path's kernel)
+        fast0 = A.Engine(A.MDXConfig(segment_size=seg, dim_f=dim_f)).run_model(w, is_match_mix=True)
         monkeypatch.setenv("ASX_FFT3", "0")
-        slow = A.Engine(A.MDXConfig(segment_size=seg)).run_model(w, is_match_mix=True)
+        slow = A.Engine(A.MDXConfig(segment_size=seg, dim_f=dim_f)).run_model(w, is_match_mix=True)
         assert rel_rms(fast, ref) < 5e-6, (seg, rel_rms(fast, ref))
+        assert rel_rms(fast0, ref) < 5e-6, (seg, rel_rms(fast0, ref))
         assert rel_rms(slow, ref) < 5e-6, (seg, rel_rms(slow, ref))
         assert rel_rms(fast, slow) < 5e-6 and max_abs(fast, slow) < 2e-5, (seg, max_abs(fast, slow))
+        assert rel_rms(fast, fast0) < 1e-6, (seg, rel_rms(fast, fast0))
+    monkeypatch.delenv("ASX_FFT3P")
     monkeypatch.delenv("ASX_FFT3")
 
 

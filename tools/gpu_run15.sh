@@ -1,0 +1,15 @@
+#!/bin/bash
+# multi-frame STFT (stft3p) + istft3p with register window / emit prefetch: parity + timing
+set -u
+O=gpurun_out/r2o
+mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_separate.py tests/test_gpu_fullsize.py -q -x 2>&1 | tail -5
+for cfg in "16 8" "16 4" "16 16" "8 8" "32 8" "16 6"; do
+  set -- $cfg
+  ASX_FFT3_G=$1 ASX_FFT3_GS=$2 timeout 300 python bench.py --steps 5 --warmup 2 --cpu-seconds 0 --siblings 0 > $O/b_$1_$2.json 2>$O/b_$1_$2.err
+  python - <<PY
+import json
+r=json.loads(open('$O/b_$1_$2.json').read().strip().splitlines()[-1])
+k=r['kernel_ms']; print('G=$1 GS=$2', r['value'], {x:k[x] for x in k if 'stft' in x}, r['stage_roofline']['stft']['frac'], r['stage_roofline']['istft']['frac'], r.get('parity_rel_rms_vs_cpu'))
+PY
+done
