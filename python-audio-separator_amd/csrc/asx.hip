@@ -288,6 +288,9 @@ static int conv_setup(ConvLayer &L, int kind, int cin, int cout, int relu) {
     // A/B (0 = eight channels everywhere).
     static const int kc4 = getenv("ASX_CONV_KC4") ? atoi(getenv("ASX_CONV_KC4")) : (1 << 30);
     if (kind == CK_3X3 && cin <= kc4 && cin % 4 == 0 && pick_nrep_conv(cout) == 3) L.kc = 4;
+    // 2x2 / stride-2 conv: two-channel stages (four workgroups per CU); ASX_DOWN_KC2=0 keeps the four-channel stages
+    static const int down_kc2 = getenv("ASX_DOWN_KC2") ? atoi(getenv("ASX_DOWN_KC2")) : 1;
+    if (kind == CK_DOWN && down_kc2 && cin % 2 == 0 && pick_nrep_conv(cout) == 3) L.kc = 2;
     L.cg = ((cout + 15) / 16 + L.nrep - 1) / L.nrep;
   }
   L.nci = (cin + L.kc - 1) / L.kc;
@@ -468,7 +471,8 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
         else ASX_CONV_CASE(3, 3, 1, 1, 1, 8, 2, EPI_BIAS_ACT);
         break;
       case CK_DOWN:
-        if (L.nrep == 3) ASX_CONV_CASE(2, 2, 2, 0, 3, 4, 2, EPI_BIAS_ACT);
+        if (L.nrep == 3 && L.kc == 2) ASX_CONV_CASE(2, 2, 2, 0, 3, 2, 2, EPI_BIAS_ACT);
+        else if (L.nrep == 3) ASX_CONV_CASE(2, 2, 2, 0, 3, 4, 2, EPI_BIAS_ACT);
         else if (L.nrep == 2) ASX_CONV_CASE(2, 2, 2, 0, 2, 4, 2, EPI_BIAS_ACT);
         else ASX_CONV_CASE(2, 2, 2, 0, 1, 4, 2, EPI_BIAS_ACT);
         break;

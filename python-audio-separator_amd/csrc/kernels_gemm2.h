@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaAr
       const uint32_t voff_r = (uint32_t)((li * ldr + wave * 16 * NREP + lk * 4) * 4);
       const uint32_t voff_y = (uint32_t)((li * ldy + wave * 16 * NREP + lk * 4) * 4);
       if (a.relu == 1) {
-        constexpr int RING = MREP < 4 ? MREP : 4;        // 16-row groups whose residual is in flight at any time
+        constexpr int RING = BK_ == 16 ? 1 : (MREP < 4 ? MREP : 4);   // 16-row groups whose residual is in flight at any time (16-float stages: 168-register budget)
         f32x4 rs[RING][NREP];
         auto fetch = [&](int m) {
           const char *rb = reinterpret_cast<const char *>(a.res) + ((m0 + m * 16) * ldr + n0) * 4;

@@ -293,6 +293,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     commit(ci);
     __syncthreads();
     if (ci + 1 < a.NCI) fetch(ci + 1);
+    if constexpr (KC == 2) {
+      // two-channel stages of the 2x2 / stride-2 conv (same k-step layout as conv_dma_kernel: channel lk >> 1, tap dx = lk & 1)
+      static_assert(KC != 2 || (S == 2 && KW == 2), "two-channel stages: only the 2x2 / stride-2 conv");
+      const int c2 = lk >> 1, dx2 = lk & 1;
+#pragma unroll
+      for (int dy = 0; dy < KH; ++dy) {
+        float bf[NREP];
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) bf[n] = w_s[((dy * KW + dx2) * KC + c2) * NWP + n * 16 + li];
+        float af[MREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int rr = m >> 2, cc = m & 3;
+          af[m] = in_s[c2 * PS + ((wave * RPW + rr) * S + dy) * IW + (cc * 16 + li) * S + dx2];
+        }
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) acc[m][n] = ASX_MFMA(af[m], bf[n], acc[m][n]);
+      }
+    } else {
 #pragma unroll
     for (int tap = 0; tap < KH * KW; ++tap) {
       const int dy = tap / KW, dx = tap % KW;
@@ -312,6 +333,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
           for (int n = 0; n < NREP; ++n) acc[m][n] = ASX_MFMA(af[m], bf[n], acc[m][n]);
       }
+    }
     }
   }
 
@@ -592,7 +614,7 @@ struct ConvDmaCfg {
   static constexpr int BUF = KC * PS + WSTAGE;                           // floats per LDS buffer
   static constexpr int LDS_BYTES = 2 * BUF * 4;
   static constexpr int MREP = RPW * 4;
-  static_assert(KC % 4 == 0, "KC must be a multiple of 4");
+  static_assert(KC % 4 == 0 || (KC == 2 && S == 2 && KW == 2 && PAD == 0), "KC must be a multiple of 4 (2: only the 2x2 / stride-2 conv)");
   static_assert(PS % 4 == 0, "plane stride must keep 16-B alignment");
 };
 
@@ -639,8 +661,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
     float *in_s = lds_f + buf * BUF;
     float *w_s = in_s + KC * PS;
 #pragma unroll
-    for (int p = 0; p < KC / 4; ++p) {
+    for (int p = 0; p < (KC + 3) / 4; ++p) {
       const int pl = wave + 4 * p;
+      if (KC % 4 != 0 && pl >= KC) continue;                 // two-channel stages: waves 0 and 1 carry the planes
       const int c = ci * KC + pl;
       const float *xc = xb + (int64_t)c * plane_sz;
       const bool cok = c < a.Cin;
@@ -671,7 +694,29 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
     if (ci + 1 < a.NCI) issue(ci + 1, (ci + 1) & 1);
     const float *in_s = lds_f + (ci & 1) * BUF;
     const float *w_s = in_s + KC * PS;
-    if constexpr (S == 2 && KW == 2 && KC == 4 && LP == 0) {
+    if constexpr (S == 2 && KW == 2 && KC == 2 && LP == 0) {
+      // 2x2 / stride-2 conv, TWO-channel stages (18.7 KB per LDS buffer: four workgroups per CU instead of two -- the kernel
+      // reads its input exactly once, so it needs HBM latency hidden, not LDS reuse).  One MFMA k-step = (2 channels) x
+      // (2 dx taps): lane group lk reads channel lk >> 1, tap dx = lk & 1.  The 16 pixels x 2 taps of a channel are 32
+      // consecutive floats and the second plane starts 32 banks further: conflict-free ds_read_b32.
+      const int c2 = lk >> 1, dx2 = lk & 1;
+#pragma unroll
+      for (int dy = 0; dy < KH; ++dy) {
+        float bf[NREP];
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) bf[n] = w_s[((dy * KW + dx2) * KC + c2) * NWP + n * 16 + li];
+        float af[MREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int rr = m >> 2, cc = m & 3;
+          af[m] = in_s[c2 * PS + ((wave * RPW + rr) * S + dy) * IWA + (cc * 16 + li) * S + dx2];
+        }
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) acc[m][n] = ASX_MFMA(af[m], bf[n], acc[m][n]);
+      }
+    } else if constexpr (S == 2 && KW == 2 && KC == 4 && LP == 0) {
       // 2x2 / stride-2 conv: the two dx taps of an output pixel are adjacent floats -> one conflict-free ds_read_b64 per
       // (row tap, pixel) instead of two 2-way conflicting ds_read_b32 (SQ_LDS_BANK_CONFLICT was 42 % of the LDS cycles);
       // tap order (dy, dx) and therefore the accumulation order are unchanged

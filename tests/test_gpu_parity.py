@@ -141,6 +141,7 @@ CONV_CASES = [
     ("conv3x3", 2, 8, 8, 16, 32), ("conv3x3", 1, 24, 24, 4, 8), ("conv3x3", 1, 16, 16, 5, 7),
     ("conv3x3", 1, 144, 144, 8, 96), ("conv3x3", 1, 80, 80, 8, 64),
     ("down", 1, 48, 96, 16, 128), ("down", 2, 8, 16, 16, 32), ("down", 1, 96, 144, 8, 256), ("down", 1, 16, 24, 8, 16),
+    ("down", 1, 48, 96, 8, 30), ("down", 1, 50, 144, 6, 72),   # two-channel stages: register-staged loader (F % 4 != 0), cin % 4 != 0
     ("up", 1, 96, 48, 8, 64), ("up", 2, 16, 8, 8, 16), ("up", 1, 144, 96, 4, 96), ("up", 1, 24, 16, 4, 8),
     ("up", 1, 64, 32, 6, 40),
     ("conv1x1", 2, 4, 48, 16, 128), ("conv1x1", 1, 48, 4, 16, 128), ("conv1x1", 2, 4, 8, 16, 32),
