@@ -1357,7 +1357,8 @@ int asx_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t N, float
   const double bytes = 4.0 * ((double)p.n_chunks * 2 * p.chunk_size + 2.0 * N);
   return timed(e, ASX_PROF_FINALIZE, 0.0, bytes, s, [&]() {
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, s, chunk_out_dev,
-                       p.n_chunks, p.chunk_size, p.step, p.padded_len, p.trim, N, win, out_dev);
+                       p.n_chunks, p.chunk_size, p.step, p.padded_len, p.trim, N, win, out_dev,
+                       (e->fft3 && e->d_hann3.p) ? reinterpret_cast<const double *>(e->d_hann3.p) : nullptr);
   });
 }
 

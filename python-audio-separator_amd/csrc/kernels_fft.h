@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void ola_kernel(const float *__restrict__ fram
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__ chunk_out, int n_chunks, int64_t C,
                                                        int64_t step, int64_t L, int trim, int64_t N, int windowed,
-                                                       float *__restrict__ out) {
+                                                       float *__restrict__ out, const double *__restrict__ hann) {
   const int ch = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__
     if (j >= na) continue;
     acc += chunk_out[(k * 2 + ch) * C + j];
     if (windowed)
-      div = (float)((double)div + hanning_f64(j, na));
+      div = (float)((double)div + ((hann && na == C) ? hann[j] : hanning_f64(j, na)));   // hann = np.hanning(C) in float64, the same expression
     else
       div += 1.0f;
   }
