@@ -601,7 +601,7 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
   // ASX_TDF2_BK16: 16-float stages (40 KB of LDS, launch bound 3) -- 1: on the 128 x 192 tile, 2: on a 64 x 192 tile
   static const int bk16 = getenv("ASX_TDF2_BK16") ? atoi(getenv("ASX_TDF2_BK16")) : 0;
   if constexpr (NREP == 3 && MREP == 8) {
-    if (a.M % 16 == 0 && a.N % 16 == 0) {
+    if (a.M % 16 == 0 && a.N % 16 == 0 && a.relu == 1 && a.K % 16 == 0) {
       if (bk16 == 1) return launch_tdf2_abl<3, 8, 0, 16>(a, s);
       if (bk16 == 2) return launch_tdf2_abl<3, 4, 0, 16>(a, s);
     }

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaAr
           }
           if (m + RING < MREP) fetch(m + RING);        // refill the slot just consumed: RING groups stay in flight
         }
-      } else {
+      } else if constexpr (BK_ != 16) {               // (the 16-float-stage build is launched for ReLU layers only: 168 registers)
 #pragma unroll
         for (int mg = 0; mg < MREP; mg += 2) {
           float sc[2], sh[2];
