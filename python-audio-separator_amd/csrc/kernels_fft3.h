@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) void stft3_kernel(Stft3Args a) {
   const int64_t q0 = (int64_t)t * HOP - NH;
   const bool inside_chunk = q0 >= 0 && q0 + NFFT <= C;
   const int64_t s0 = a.n_song >= 0 ? cstart + q0 - a.trim : q0;
-  const bool fast = inside_chunk && (a.n_song < 0 || (s0 >= 0 && s0 + NFFT <= a.n_song)) && ((s0 & 1) == 0);
+  const bool fast = inside_chunk && (a.n_song < 0 || (s0 >= 0 && s0 + NFFT <= a.n_song)) &&
+                    ((reinterpret_cast<uintptr_t>(src + s0) & 7) == 0);
   cplx v[12];
   const cplx *w2 = reinterpret_cast<const cplx *>(a.window);
   if (fast) {
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256, 3) void stft3p_kernel(Stft3Args a) {
     const int64_t q0 = h * HOP - NH + 4 * j;
     const int64_t s0 = a.n_song >= 0 ? cstart + q0 - a.trim : q0;
     const bool inside = q0 >= 0 && q0 + 4 <= C && (a.n_song < 0 || (s0 >= 0 && s0 + 4 <= a.n_song));
-    if (inside && (s0 & 3) == 0) return *reinterpret_cast<const float4 *>(src + s0);
+    if (inside && (reinterpret_cast<uintptr_t>(src + s0) & 15) == 0) return *reinterpret_cast<const float4 *>(src + s0);
     float x[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

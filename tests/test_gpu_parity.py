@@ -356,6 +356,23 @@ def test_fft3_fast_path_vs_generic_and_oracle(A, monkeypatch):
     monkeypatch.delenv("ASX_FFT3")
 
 
+def test_fft3_song_mode_edges_vs_oracle(A, monkeypatch):
+    """The multi-frame forward kernel maps every hop through the song position (zero outside the song, reflection at the chunk
+    ends, unaligned starts); the inverse groups frames by T alone.  Match-mix demix (STFT -> zero bins -> iSTFT -> Hann fold, no
+    net) of mixes shorter than a chunk, of odd length, and at a short segment, against the oracle and the generic kernels."""
+    for seg, N in ((256, 100_000), (256, 300_001), (256, 523_457), (8, 30_011), (20, 44_100)):
+        mix = O.synth_mix(N, seed=N % 97)
+        ref = O.demix(mix, O.MDXParams(segment_size=seg), None, is_match_mix=True)
+        monkeypatch.setenv("ASX_FFT3", "1")
+        fast = A.Engine(A.MDXConfig(segment_size=seg)).demix(mix, is_match_mix=True)
+        monkeypatch.setenv("ASX_FFT3", "0")
+        slow = A.Engine(A.MDXConfig(segment_size=seg)).demix(mix, is_match_mix=True)
+        assert fast.shape == ref.shape
+        assert rel_rms(fast, ref) < 1e-5, (seg, N, rel_rms(fast, ref))
+        assert rel_rms(fast, slow) < 5e-6 and max_abs(fast, slow) < 2e-5, (seg, N, max_abs(fast, slow))
+    monkeypatch.delenv("ASX_FFT3")
+
+
 def test_batching_is_invisible(A):
     # results must not depend on how many chunks share a device batch (reference: batch_size has no effect)
     mix = (0.4 * np.random.default_rng(77).standard_normal((2, 5000))).astype(np.float32)
