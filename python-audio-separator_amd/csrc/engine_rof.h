@@ -131,8 +131,15 @@ static int rof_load_layer(asx_engine *e, RofLayer &L, const std::string &p, int 
 }
 
 // y[M, n] (row stride ldy) = act(x[M, k] (row stride lda) @ w^T + b) (+ res)
+// rotary epilogue of a qkv projection (kernels_net.h: TdfDmaArgs::rot_*); tab == nullptr: none
+struct RofRot {
+  const float2 *tab = nullptr;
+  int cols = 0, half = 0, pos_mod = 1;
+  int64_t pos_div = 1;
+};
+
 static int rof_gemm(asx_engine *e, const RofLin &L, const float *x, int64_t lda, int64_t M, float *y, int64_t ldy,
-                    int act, const float *res, int64_t ldr, hipStream_t s) {
+                    int act, const float *res, int64_t ldr, hipStream_t s, const RofRot *rot = nullptr) {
   if (M <= 0) return ASX_OK;
   if ((L.k & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) {
     set_err("rof_gemm: K and the row stride must be multiples of 4 floats (K=%d lda=%lld)", L.k, (long long)lda);
@@ -154,6 +161,13 @@ static int rof_gemm(asx_engine *e, const RofLin &L, const float *x, int64_t lda,
   d.T = 1;
   d.relu = act;
   d.lda = lda;
+  if (rot && rot->tab) {
+    d.rot_tab = rot->tab;
+    d.rot_cols = rot->cols;
+    d.rot_half = rot->half;
+    d.rot_pos_mod = rot->pos_mod;
+    d.rot_pos_div = rot->pos_div;
+  }
   // the float4 epilogue needs 16-byte aligned rows; otherwise force the scalar epilogue by an odd N check inside
   d.ldy = ldy;
   d.ldr = ldr;
@@ -188,8 +202,18 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
   for (auto &L : layers) {
     // attention: x = attn(x) + x
     CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.attn.norm_g.f(), n.XN.f(), D, M, s));
-    CHK(rof_gemm(e, L.attn.qkv, n.XN.f(), D, M, n.QKV.f(), 3 * inner, 0, nullptr, 0, s));
-    {
+    // rotary on q and k: in the projection's epilogue (default), or as a separate in-place pass (ASX_ROF_FUSE=0)
+    static const bool fuse_rot = !(getenv("ASX_ROF_FUSE") && atoi(getenv("ASX_ROF_FUSE")) == 0);
+    RofRot rr;
+    if (fuse_rot && c.dim_head % 4 == 0 && M < (1ll << 31)) {
+      rr.tab = reinterpret_cast<const float2 *>(L.attn.rot_tab.p);
+      rr.cols = 2 * inner;
+      rr.half = c.dim_head / 2;
+      rr.pos_div = time_axis ? Fb : 1;
+      rr.pos_mod = time_axis ? T : Fb;
+    }
+    CHK(rof_gemm(e, L.attn.qkv, n.XN.f(), D, M, n.QKV.f(), 3 * inner, 0, nullptr, 0, s, &rr));
+    if (!rr.tab) {
       const int64_t tot = M * 2 * H * (c.dim_head / 2);
       const int64_t pos_div = time_axis ? Fb : 1;
       const int pos_mod = time_axis ? T : Fb;

@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaAr
               o.y = tdf_act(sc[m] * (v.y + bz[n].y) + sh[m], a.relu) + rs[m][n].y;
               o.z = tdf_act(sc[m] * (v.z + bz[n].z) + sh[m], a.relu) + rs[m][n].z;
               o.w = tdf_act(sc[m] * (v.w + bz[n].w) + sh[m], a.relu) + rs[m][n].w;
-              *reinterpret_cast<f32x4 *>(yb + voff_y + n * 64) = o;
+              *reinterpret_cast<f32x4 *>(yb + voff_y + n * 64) =
+                  tdf_rot4(a, o, m0 + (mg + m) * 16 + li, n0 + wave * 16 * NREP + n * 16 + lk * 4);
               acc[n][mg + m] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
           }
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaAr
           o.y = tdf_act(sc * (v.y + b4.y) + sh, a.relu) + r4.y;
           o.z = tdf_act(sc * (v.z + b4.z) + sh, a.relu) + r4.z;
           o.w = tdf_act(sc * (v.w + b4.w) + sh, a.relu) + r4.w;
-          *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = o;
+          *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = tdf_rot4(a, o, row, col);
         }
       }
     }

@@ -779,7 +779,30 @@ struct TdfDmaArgs {
   int N, K, C, T;
   int relu;                 // activation enum of tdf_act()
   int64_t lda, ldy, ldr;    // row strides (floats) of x, y, res; 0 = dense (K, N, N)
+  // optional rotary embedding on output columns [0, rot_cols) (the q | k thirds of a Roformer qkv projection, applied in the
+  // epilogue instead of a separate in-place pass): interleaved pairs (2i, 2i + 1) of every rot_half * 2 wide head are rotated
+  // by rot_tab[pos(row)][i] = (cos, sin), pos(row) = (row / rot_pos_div) % rot_pos_mod.  rot_tab == nullptr: none.
+  const float2 *rot_tab;
+  int rot_cols, rot_half, rot_pos_mod;
+  int64_t rot_pos_div;
 };
+
+// rotary step of the row-GEMM epilogues on the float4 (row, col .. col + 3), col % 4 == 0.  Every product and sum is rounded
+// explicitly (no compiler-chosen fma contraction), so the full-tile and the ragged-tile epilogues of every row-GEMM kernel
+// agree bit for bit and results stay independent of the batch size.
+__device__ __forceinline__ f32x4 tdf_rot4(const TdfDmaArgs &a, f32x4 o, int64_t row, int col) {
+  if (a.rot_tab == nullptr || col >= a.rot_cols) return o;
+  const uint32_t pos = ((uint32_t)row / (uint32_t)a.rot_pos_div) % (uint32_t)a.rot_pos_mod;   // launchers: M < 2^31 with a rotary epilogue
+  const int i = (col % (2 * a.rot_half)) >> 1;
+  const float2 *t = a.rot_tab + (int64_t)pos * a.rot_half + i;
+  const float2 c0 = t[0], c1 = t[1];
+  f32x4 r;
+  r.x = __fmaf_rn(o.x, c0.x, -__fmul_rn(o.y, c0.y));
+  r.y = __fmaf_rn(o.y, c0.x, __fmul_rn(o.x, c0.y));
+  r.z = __fmaf_rn(o.z, c1.x, -__fmul_rn(o.w, c1.y));
+  r.w = __fmaf_rn(o.w, c1.x, __fmul_rn(o.z, c1.y));
+  return r;
+}
 
 template <int NREP, int MREP, int BK_ = 32>
 struct TdfDmaCfg {
@@ -922,7 +945,7 @@ __global__ __launch_bounds__(256, (BK_ == 32 ? 2 : 1)) void tdf_dma_kernel(TdfDm
           o.y = tdf_act(sc[m] * (v.y + bz[n].y) + sh[m], a.relu) + rs[m][n].y;
           o.z = tdf_act(sc[m] * (v.z + bz[n].z) + sh[m], a.relu) + rs[m][n].z;
           o.w = tdf_act(sc[m] * (v.w + bz[n].w) + sh[m], a.relu) + rs[m][n].w;
-          *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = o;
+          *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = tdf_rot4(a, o, row, col);
         }
       }
     }
@@ -946,6 +969,13 @@ __global__ __launch_bounds__(256, (BK_ == 32 ? 2 : 1)) void tdf_dma_kernel(TdfDm
         o[r] = tdf_act(sc * (o[r] + bzz) + sh, a.relu);
       }
       float *dst = a.y + row * ldy + col;
+      if (a.rot_tab != nullptr) {                     // launcher: N % 4 == 0 and no residual with a rotary epilogue
+        const f32x4 q = tdf_rot4(a, (f32x4){o[0], o[1], o[2], o[3]}, row, col);
+        o[0] = q.x;
+        o[1] = q.y;
+        o[2] = q.z;
+        o[3] = q.w;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (col + r < a.N) dst[r] = o[r] + (a.res != nullptr ? a.res[row * ldr + col + r] : 0.f);
