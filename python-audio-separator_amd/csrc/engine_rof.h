@@ -9,12 +9,14 @@ struct RofLin {
 };
 
 struct RofAttn {
+  bool norm_folded = false;   // gamma of `norm` is folded into qkv / gates (rows are scaled in their epilogues)
   DevBuf norm_g;
   RofLin qkv, gates, out;
   DevBuf rot_tab;   // [n_pos, dh/2] (cos, sin)
 };
 
 struct RofFF {
+  bool norm_folded = false;   // gamma of the feed-forward RMSNorm is folded into l1
   DevBuf norm_g;
   RofLin l1, l2;
 };
@@ -40,7 +42,7 @@ struct RofNet {
   std::vector<std::vector<std::vector<RofLin>>> mask;  // [stem][band][mlp layer]
   // workspace
   int ws_batch = 0;
-  DevBuf X0, XB, TOK, XN, QKV, ATT, GATE, FFH, HID, GLU, MASK, frames, chunk_out, d_starts, d_window;
+  DevBuf X0, XB, TOK, XN, RS, QKV, ATT, GATE, FFH, HID, GLU, MASK, frames, chunk_out, d_starts, d_window;
 };
 
 static void rof_free_lin(RofLin &l) {
@@ -71,7 +73,7 @@ static void rof_free(RofNet &n) {
   for (auto &s : n.mask)
     for (auto &b : s)
       for (auto &l : b) rof_free_lin(l);
-  DevBuf *bufs[] = {&n.X0, &n.XB, &n.TOK, &n.XN, &n.QKV, &n.ATT, &n.GATE, &n.FFH, &n.HID, &n.GLU,
+  DevBuf *bufs[] = {&n.X0, &n.XB, &n.TOK, &n.XN, &n.RS, &n.QKV, &n.ATT, &n.GATE, &n.FFH, &n.HID, &n.GLU,
                     &n.MASK, &n.frames, &n.chunk_out, &n.d_starts, &n.d_window};
   for (auto *b : bufs) b->release();
   n.ready = false;
@@ -99,6 +101,30 @@ static int rof_load_lin(asx_engine *e, RofLin &l, const std::string &name, int n
   return ASX_OK;
 }
 
+// nn.Linear weight [n, k] with the gamma [k] of the RMSNorm in front of it folded in: w'[i][j] = w[i][j] * gamma[j]
+static int rof_load_lin_folded(asx_engine *e, RofLin &l, const std::string &name, int n, int k, bool bias,
+                               const std::string &gamma_name) {
+  l.n = n;
+  l.k = k;
+  l.has_bias = bias;
+  const float *w, *g;
+  CHK(get_tensor(e, name + ".weight", (int64_t)n * k, &w));
+  CHK(get_tensor(e, gamma_name, k, &g));
+  std::vector<float> f((size_t)n * k);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < k; ++j) f[(size_t)i * k + j] = w[(size_t)i * k + j] * g[j];
+  CHK(l.w.ensure(f.size() * 4));
+  HIPCHK(hipMemcpy(l.w.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+  if (bias) CHK(rof_upload(e, l.b, name + ".bias", n));
+  return ASX_OK;
+}
+
+// RMSNorms folded into the projections behind them (default; ASX_ROF_NORMFUSE=0 keeps the separate normalisation pass)
+static bool rof_norm_fuse() {
+  static const bool on = !(getenv("ASX_ROF_NORMFUSE") && atoi(getenv("ASX_ROF_NORMFUSE")) == 0);
+  return on;
+}
+
 // cos/sin table exactly as torch builds it: angle = float32(pos) * float32(freq) (one float32
 // rounding), then cos/sin of that float32 angle.
 static int rof_rot_table(asx_engine *e, DevBuf &tab, const std::string &name, int n_pos, int half) {
@@ -120,12 +146,21 @@ static int rof_load_layer(asx_engine *e, RofLayer &L, const std::string &p, int 
   const asx_rof_config &c = e->rof->cfg;
   const int d = c.dim, inner = c.heads * c.dim_head;
   CHK(rof_upload(e, L.attn.norm_g, p + ".0.norm.gamma", d));
-  CHK(rof_load_lin(e, L.attn.qkv, p + ".0.to_qkv", 3 * inner, d, false));
-  CHK(rof_load_lin(e, L.attn.gates, p + ".0.to_gates", c.heads, d, true));
+  // (the gates projection has a scalar-epilogue fallback for head counts that are not a multiple of 4: no folding there)
+  L.attn.norm_folded = rof_norm_fuse() && c.heads % 4 == 0;
+  if (L.attn.norm_folded) {
+    CHK(rof_load_lin_folded(e, L.attn.qkv, p + ".0.to_qkv", 3 * inner, d, false, p + ".0.norm.gamma"));
+    CHK(rof_load_lin_folded(e, L.attn.gates, p + ".0.to_gates", c.heads, d, true, p + ".0.norm.gamma"));
+  } else {
+    CHK(rof_load_lin(e, L.attn.qkv, p + ".0.to_qkv", 3 * inner, d, false));
+    CHK(rof_load_lin(e, L.attn.gates, p + ".0.to_gates", c.heads, d, true));
+  }
   CHK(rof_load_lin(e, L.attn.out, p + ".0.to_out.0", d, inner, false));
   CHK(rof_rot_table(e, L.attn.rot_tab, p + ".0.rotary_embed.freqs", n_pos, c.dim_head / 2));
   CHK(rof_upload(e, L.ff.norm_g, p + ".1.net.0.gamma", d));
-  CHK(rof_load_lin(e, L.ff.l1, p + ".1.net.1", 4 * d, d, true));
+  L.ff.norm_folded = rof_norm_fuse();
+  if (L.ff.norm_folded) CHK(rof_load_lin_folded(e, L.ff.l1, p + ".1.net.1", 4 * d, d, true, p + ".1.net.0.gamma"));
+  else CHK(rof_load_lin(e, L.ff.l1, p + ".1.net.1", 4 * d, d, true));
   CHK(rof_load_lin(e, L.ff.l2, p + ".1.net.4", d, 4 * d, true));
   return ASX_OK;
 }
@@ -139,7 +174,8 @@ struct RofRot {
 };
 
 static int rof_gemm(asx_engine *e, const RofLin &L, const float *x, int64_t lda, int64_t M, float *y, int64_t ldy,
-                    int act, const float *res, int64_t ldr, hipStream_t s, const RofRot *rot = nullptr) {
+                    int act, const float *res, int64_t ldr, hipStream_t s, const RofRot *rot = nullptr,
+                    const float *rscale = nullptr) {
   if (M <= 0) return ASX_OK;
   if ((L.k & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) {
     set_err("rof_gemm: K and the row stride must be multiples of 4 floats (K=%d lda=%lld)", L.k, (long long)lda);
@@ -161,6 +197,7 @@ static int rof_gemm(asx_engine *e, const RofLin &L, const float *x, int64_t lda,
   d.T = 1;
   d.relu = act;
   d.lda = lda;
+  d.rscale = rscale;
   if (rot && rot->tab) {
     d.rot_tab = rot->tab;
     d.rot_cols = rot->cols;
@@ -192,6 +229,12 @@ static int rof_rmsnorm(asx_engine *e, const float *x, int64_t lda, int d, const 
   });
 }
 
+static int rof_rownorm(asx_engine *e, const float *x, int64_t lda, int d, float *r, int64_t M, hipStream_t s) {
+  return timed(e, ASX_PROF_MISC, 0.0, 4.0 * M * d, s, [&]() {
+    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, lda, d, r, M);
+  });
+}
+
 // one Transformer (bs_roformer.py:136-160, norm_output = False) over the token matrix TOK [M, D]
 static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool time_axis, int B, hipStream_t s,
                            const DevBuf *out_norm = nullptr) {
@@ -201,7 +244,15 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
   const int64_t M = (int64_t)B * T * Fb;
   for (auto &L : layers) {
     // attention: x = attn(x) + x
-    CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.attn.norm_g.f(), n.XN.f(), D, M, s));
+    // RMSNorm in front of qkv / gates: folded (TOK is the operand, 1 / |x| scales the rows in the epilogue) or explicit
+    const float *ain = n.TOK.f(), *ars = nullptr;
+    if (L.attn.norm_folded) {
+      CHK(rof_rownorm(e, n.TOK.f(), D, D, n.RS.f(), M, s));
+      ars = n.RS.f();
+    } else {
+      CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.attn.norm_g.f(), n.XN.f(), D, M, s));
+      ain = n.XN.f();
+    }
     // rotary on q and k: in the projection's epilogue (default), or as a separate in-place pass (ASX_ROF_FUSE=0)
     static const bool fuse_rot = !(getenv("ASX_ROF_FUSE") && atoi(getenv("ASX_ROF_FUSE")) == 0);
     RofRot rr;
@@ -212,7 +263,7 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
       rr.pos_div = time_axis ? Fb : 1;
       rr.pos_mod = time_axis ? T : Fb;
     }
-    CHK(rof_gemm(e, L.attn.qkv, n.XN.f(), D, M, n.QKV.f(), 3 * inner, 0, nullptr, 0, s, &rr));
+    CHK(rof_gemm(e, L.attn.qkv, ain, D, M, n.QKV.f(), 3 * inner, 0, nullptr, 0, s, &rr, ars));
     if (!rr.tab) {
       const int64_t tot = M * 2 * H * (c.dim_head / 2);
       const int64_t pos_div = time_axis ? Fb : 1;
@@ -228,7 +279,7 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
       const int gl = (H + 3) / 4 * 4;
       RofLin &G = L.attn.gates;
       if (H % 4 == 0) {
-        CHK(rof_gemm(e, G, n.XN.f(), D, M, n.GATE.f(), gl, 0, nullptr, 0, s));
+        CHK(rof_gemm(e, G, ain, D, M, n.GATE.f(), gl, 0, nullptr, 0, s, nullptr, ars));
       } else {
         // tiny head counts (tests): scalar epilogue through the generic register-staged kernel
         TdfArgs a{};
@@ -281,8 +332,13 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
     CHK(rof_gemm(e, L.attn.out, n.ATT.f(), inner, M, n.TOK.f(), D, 0, n.TOK.f(), D, s));   // + x (in place: each
     // output element depends only on ATT and on the same TOK element it overwrites)
     // feed-forward: x = ff(x) + x
-    CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.ff.norm_g.f(), n.XN.f(), D, M, s));
-    CHK(rof_gemm(e, L.ff.l1, n.XN.f(), D, M, n.FFH.f(), 4 * D, 2, nullptr, 0, s));          // GELU
+    if (L.ff.norm_folded) {
+      CHK(rof_rownorm(e, n.TOK.f(), D, D, n.RS.f(), M, s));
+      CHK(rof_gemm(e, L.ff.l1, n.TOK.f(), D, M, n.FFH.f(), 4 * D, 2, nullptr, 0, s, nullptr, n.RS.f()));   // GELU
+    } else {
+      CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.ff.norm_g.f(), n.XN.f(), D, M, s));
+      CHK(rof_gemm(e, L.ff.l1, n.XN.f(), D, M, n.FFH.f(), 4 * D, 2, nullptr, 0, s));          // GELU
+    }
     CHK(rof_gemm(e, L.ff.l2, n.FFH.f(), 4 * D, M, n.TOK.f(), D, 0, n.TOK.f(), D, s));
   }
   // MelBandRoformer: Transformer(norm_output=True) (mel_band_roformer.py:111,120); in place (a row is read, then written)
@@ -303,6 +359,7 @@ static int rof_ensure_workspace(asx_engine *e, int B) {
   CHK(n.XB.ensure(BT * maxd * 4 + 256));
   CHK(n.TOK.ensure(M * D * 4));
   CHK(n.XN.ensure(M * D * 4));
+  CHK(n.RS.ensure(M * 4));
   CHK(n.QKV.ensure(M * 3 * inner * 4));
   CHK(n.ATT.ensure(M * inner * 4));
   CHK(n.GATE.ensure(M * ((c.heads + 3) / 4 * 4) * 4));

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaAr
       } else if constexpr (BK_ != 16) {               // (the 16-float-stage build is launched for ReLU layers only: 168 registers)
 #pragma unroll
         for (int mg = 0; mg < MREP; mg += 2) {
-          float sc[2], sh[2];
+          float sc[2], sh[2], rw[2];
           f32x4 rs[2][NREP];
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaAr
             const int c = (int)((row / (uint32_t)a.T) % (uint32_t)a.C);
             sc[m] = a.scale ? a.scale[c] : 1.f;
             sh[m] = a.shift ? a.shift[c] : 0.f;
+            rw[m] = a.rscale ? a.rscale[row] : 1.f;
             const char *rb = reinterpret_cast<const char *>(a.res) + ((m0 + (mg + m) * 16) * ldr + n0) * 4;
 #pragma unroll
             for (int n = 0; n < NREP; ++n)
@@ -342,10 +343,10 @@ __global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaAr
             for (int n = 0; n < NREP; ++n) {
               const f32x4 v = acc[n][mg + m];
               f32x4 o;
-              o.x = tdf_act(sc[m] * (v.x + bz[n].x) + sh[m], a.relu) + rs[m][n].x;
-              o.y = tdf_act(sc[m] * (v.y + bz[n].y) + sh[m], a.relu) + rs[m][n].y;
-              o.z = tdf_act(sc[m] * (v.z + bz[n].z) + sh[m], a.relu) + rs[m][n].z;
-              o.w = tdf_act(sc[m] * (v.w + bz[n].w) + sh[m], a.relu) + rs[m][n].w;
+              o.x = tdf_act(sc[m] * __fmaf_rn(v.x, rw[m], bz[n].x) + sh[m], a.relu) + rs[m][n].x;
+              o.y = tdf_act(sc[m] * __fmaf_rn(v.y, rw[m], bz[n].y) + sh[m], a.relu) + rs[m][n].y;
+              o.z = tdf_act(sc[m] * __fmaf_rn(v.z, rw[m], bz[n].z) + sh[m], a.relu) + rs[m][n].z;
+              o.w = tdf_act(sc[m] * __fmaf_rn(v.w, rw[m], bz[n].w) + sh[m], a.relu) + rs[m][n].w;
               *reinterpret_cast<f32x4 *>(yb + voff_y + n * 64) =
                   tdf_rot4(a, o, m0 + (mg + m) * 16 + li, n0 + wave * 16 * NREP + n * 16 + lk * 4);
               acc[n][mg + m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -360,6 +361,7 @@ __global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaAr
         const bool rok = row < a.M;
         const int c = rok ? (int)(((uint32_t)row / (uint32_t)a.T) % (uint32_t)a.C) : 0;
         const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
+        const float rw = (rok && a.rscale) ? a.rscale[row] : 1.f;
 #pragma unroll
         for (int n = 0; n < NREP; ++n) {
           const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
@@ -369,10 +371,10 @@ __global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaAr
           const f32x4 b4 = (a.bias != nullptr) ? *reinterpret_cast<const f32x4 *>(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
           const f32x4 r4 = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(a.res + row * ldr + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
           f32x4 o;
-          o.x = tdf_act(sc * (v.x + b4.x) + sh, a.relu) + r4.x;
-          o.y = tdf_act(sc * (v.y + b4.y) + sh, a.relu) + r4.y;
-          o.z = tdf_act(sc * (v.z + b4.z) + sh, a.relu) + r4.z;
-          o.w = tdf_act(sc * (v.w + b4.w) + sh, a.relu) + r4.w;
+          o.x = tdf_act(sc * __fmaf_rn(v.x, rw, b4.x) + sh, a.relu) + r4.x;
+          o.y = tdf_act(sc * __fmaf_rn(v.y, rw, b4.y) + sh, a.relu) + r4.y;
+          o.z = tdf_act(sc * __fmaf_rn(v.z, rw, b4.z) + sh, a.relu) + r4.z;
+          o.w = tdf_act(sc * __fmaf_rn(v.w, rw, b4.w) + sh, a.relu) + r4.w;
           *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = tdf_rot4(a, o, row, col);
         }
       }

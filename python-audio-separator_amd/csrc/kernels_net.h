@@ -785,6 +785,10 @@ struct TdfDmaArgs {
   const float2 *rot_tab;
   int rot_cols, rot_half, rot_pos_mod;
   int64_t rot_pos_div;
+  // optional per-ROW factor applied to the accumulator before the bias: y = act(acc * rscale[row] + bias) -- an RMSNorm in
+  // front of the projection folded into it (gamma is folded into W by the loader, rscale = sqrt(d) / max(|x_row|, eps)).
+  // Honoured by the generic-activation epilogues (not by the ReLU + residual path of the TDF layers).
+  const float *rscale;
 };
 
 // rotary step of the row-GEMM epilogues on the float4 (row, col .. col + 3), col % 4 == 0.  Every product and sum is rounded
@@ -918,7 +922,7 @@ __global__ __launch_bounds__(256, (BK_ == 32 ? 2 : 1)) void tdf_dma_kernel(TdfDm
     }
 #pragma unroll
     for (int mg = 0; mg < MREP; mg += 4) {
-      float sc[4], sh[4];
+      float sc[4], sh[4], rw[4];
       f32x4 rs[4][NREP];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -926,6 +930,7 @@ __global__ __launch_bounds__(256, (BK_ == 32 ? 2 : 1)) void tdf_dma_kernel(TdfDm
         const int c = (int)((row / a.T) % a.C);
         sc[m] = a.scale ? a.scale[c] : 1.f;
         sh[m] = a.shift ? a.shift[c] : 0.f;
+        rw[m] = a.rscale ? a.rscale[row] : 1.f;
 #pragma unroll
         for (int n = 0; n < NREP; ++n) {
           const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
@@ -941,10 +946,11 @@ __global__ __launch_bounds__(256, (BK_ == 32 ? 2 : 1)) void tdf_dma_kernel(TdfDm
           const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
           const f32x4 v = acc[n][mg + m];
           f32x4 o;
-          o.x = tdf_act(sc[m] * (v.x + bz[n].x) + sh[m], a.relu) + rs[m][n].x;
-          o.y = tdf_act(sc[m] * (v.y + bz[n].y) + sh[m], a.relu) + rs[m][n].y;
-          o.z = tdf_act(sc[m] * (v.z + bz[n].z) + sh[m], a.relu) + rs[m][n].z;
-          o.w = tdf_act(sc[m] * (v.w + bz[n].w) + sh[m], a.relu) + rs[m][n].w;
+          // acc * rw + bias as ONE explicitly rounded fma in every epilogue variant (rw = 1: exactly acc + bias)
+          o.x = tdf_act(sc[m] * __fmaf_rn(v.x, rw[m], bz[n].x) + sh[m], a.relu) + rs[m][n].x;
+          o.y = tdf_act(sc[m] * __fmaf_rn(v.y, rw[m], bz[n].y) + sh[m], a.relu) + rs[m][n].y;
+          o.z = tdf_act(sc[m] * __fmaf_rn(v.z, rw[m], bz[n].z) + sh[m], a.relu) + rs[m][n].z;
+          o.w = tdf_act(sc[m] * __fmaf_rn(v.w, rw[m], bz[n].w) + sh[m], a.relu) + rs[m][n].w;
           *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = tdf_rot4(a, o, row, col);
         }
       }
@@ -957,6 +963,7 @@ __global__ __launch_bounds__(256, (BK_ == 32 ? 2 : 1)) void tdf_dma_kernel(TdfDm
     if (row >= a.M) continue;
     const int c = (int)((row / a.T) % a.C);
     const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
+    const float rw = a.rscale ? a.rscale[row] : 1.f;
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
       const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
@@ -966,7 +973,7 @@ __global__ __launch_bounds__(256, (BK_ == 32 ? 2 : 1)) void tdf_dma_kernel(TdfDm
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float bzz = (a.bias != nullptr && col + r < a.N) ? a.bias[col + r] : 0.f;
-        o[r] = tdf_act(sc * (o[r] + bzz) + sh, a.relu);
+        o[r] = tdf_act(sc * __fmaf_rn(o[r], rw, bzz) + sh, a.relu);
       }
       float *dst = a.y + row * ldy + col;
       if (a.rot_tab != nullptr) {                     // launcher: N % 4 == 0 and no residual with a rotary epilogue

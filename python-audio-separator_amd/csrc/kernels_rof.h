@@ -34,6 +34,27 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// The row factor of an RMSNorm folded into the projections that consume it (TdfDmaArgs::rscale):
+// r[row] = sqrt(d) / max(||x_row||_2, 1e-12); the sum of squares is accumulated exactly as in rmsnorm_kernel.  One wave per
+// row: the row is read once and nothing but one float is written.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ x, int64_t lda, int d, float *__restrict__ r,
+                                                      int64_t M) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float *xp = x + row * lda;
+  float ss = 0.f;
+  for (int i = lane; i < d; i += 64) {
+    const float v = xp[i];
+    ss += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  if (lane == 0) r[row] = sqrtf((float)d) / fmaxf(sqrtf(ss), 1e-12f);
+}
+
+// ---------------------------------------------------------------------------
 // Rotary embedding on the q and k thirds of the qkv matrix, in place
 // (rotary_embedding_torch.apply_rotary_emb: t*cos + rotate_half(t)*sin, interleaved pairs).
 // tab[pos][i] = (cos, sin) of float32(pos) * freqs[i];  pos(row) = (row / pos_div) % pos_mod.
