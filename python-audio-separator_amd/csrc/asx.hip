@@ -400,6 +400,8 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
   a.act = v.act >= 0 ? v.act : (L.relu ? ACT_RELU : ACT_NONE);
   a.CG = L.cg;
   a.NCI = L.nci;
+  static const int nt_mode = getenv("ASX_NT") ? atoi(getenv("ASX_NT")) : 0;   // bit 0: conv stores, bit 1: TDF stores, bit 2: TDF residual loads
+  a.nt = nt_mode & 1;
   int cls = ASX_PROF_CONV3X3;
   double taps = 9;
   int64_t out_plane;
@@ -665,6 +667,8 @@ static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const fl
   d.C = a.C;
   d.T = a.T;
   d.relu = a.relu;
+  static const int nt_mode = getenv("ASX_NT") ? atoi(getenv("ASX_NT")) : 0;
+  d.nt = ((nt_mode >> 1) & 1) | ((nt_mode >> 2) & 1) << 1;
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
     if (dma) {
       launch_tdf_dma_auto(d, s);

@@ -295,7 +295,9 @@ __global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaAr
           const char *rb = reinterpret_cast<const char *>(a.res) + ((m0 + m * 16) * ldr + n0) * 4;
 #pragma unroll
           for (int n = 0; n < NREP; ++n)
-            rs[m % RING][n] = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(rb + voff_r + n * 64) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            rs[m % RING][n] = (a.res == nullptr) ? (f32x4){0.f, 0.f, 0.f, 0.f}
+                              : ((a.nt & 2) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rb + voff_r + n * 64))
+                                            : *reinterpret_cast<const f32x4 *>(rb + voff_r + n * 64));
         };
 #pragma unroll
         for (int m = 0; m < RING; ++m) fetch(m);
@@ -314,7 +316,8 @@ __global__ __launch_bounds__(256, (BK_ == 16 ? 3 : 2)) void tdf2_kernel(TdfDmaAr
             o.y = fmaxf(sc * (v.y + bz[n].y) + sh, 0.f) + r.y;
             o.z = fmaxf(sc * (v.z + bz[n].z) + sh, 0.f) + r.z;
             o.w = fmaxf(sc * (v.w + bz[n].w) + sh, 0.f) + r.w;
-            *reinterpret_cast<f32x4 *>(yb + voff_y + n * 64) = o;
+            if (a.nt & 1) __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(yb + voff_y + n * 64));
+            else *reinterpret_cast<f32x4 *>(yb + voff_y + n * 64) = o;
             acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
           if (m + RING < MREP) fetch(m + RING);        // refill the slot just consumed: RING groups stay in flight

@@ -83,6 +83,7 @@ struct ConvArgs {
   int To, Fo;                // output spatial size handled by tiles (= T,F; T/2,F/2 for stride 2)
   int tilesT, tilesF, CG, NCI;
   int act;
+  int nt;              // 1: non-temporal output stores of the full-tile epilogue (A/B switch ASX_NT)
   int64_t x_bstride, y_bstride, aux_bstride;
 };
 
@@ -118,7 +119,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x4 (&acc)[CF
           v.z = act_fn(v.z + bv, a.act);
           v.w = act_fn(v.w + bv, a.act);
           if (rb != nullptr) v += rs[m];
-          *reinterpret_cast<f32x4 *>(yb + ((int64_t)co * a.To + t) * a.Fo + f) = v;
+          if (a.nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(yb + ((int64_t)co * a.To + t) * a.Fo + f));
+          else *reinterpret_cast<f32x4 *>(yb + ((int64_t)co * a.To + t) * a.Fo + f) = v;
         }
       } else {
 #pragma unroll
@@ -789,6 +791,7 @@ struct TdfDmaArgs {
   // front of the projection folded into it (gamma is folded into W by the loader, rscale = sqrt(d) / max(|x_row|, eps)).
   // Honoured by the generic-activation epilogues (not by the ReLU + residual path of the TDF layers).
   const float *rscale;
+  int nt;                   // bit 0: non-temporal output stores, bit 1: non-temporal residual loads (ReLU path; A/B switch ASX_NT)
 };
 
 // rotary step of the row-GEMM epilogues on the float4 (row, col .. col + 3), col % 4 == 0.  Every product and sum is rounded
