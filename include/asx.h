@@ -405,7 +405,8 @@ int asx_normalize(asx_engine *e, float *wave_host, int64_t numel, float max_peak
 /* Spectral edges, librosa STFT(2048, 1024) semantics:
  * asx_ensemble   = Ensembler.ensemble (audio_separator/separator/ensembler.py:12-160) over K equal-length stereo waves
  *                  [K, 2, N]; algorithm: 0 avg_wave, 1 median_wave, 2 min_wave, 3 max_wave, 4 avg_fft, 5 median_fft,
- *                  6 min_fft, 7 max_fft, 8 uvr_max_spec, 9 uvr_min_spec; weights [K] (avg_* only) or NULL; out [2, *n_out]
+ *                  6 min_fft, 7 max_fft, 8 uvr_max_spec, 9 uvr_min_spec, 10 ensemble_wav (spec_utils.py:1245-1266: each
+ *                  channel from the input with the smallest mean |x|); weights [K] (avg_* only) or NULL; out [2, *n_out]
  *                  (*n_out = N, or 1024 * (N / 1024) for the uvr_* algorithms, which do not pass a length to istft).
  * asx_invert_stem = spec_utils.invert_stem(mixture, stem) (uvr_lib_v5/spec_utils.py:573-580), planar [2, *n_out]. */
 int asx_ensemble(asx_engine *e, const float *waves_host, int32_t k, int64_t n_samples, int32_t algorithm, const double *weights,

@@ -12,7 +12,7 @@ import numpy as np
 from .vr_oracle import lr_istft, lr_stft
 
 ALGORITHMS = ("avg_wave", "median_wave", "min_wave", "max_wave", "avg_fft", "median_fft", "min_fft", "max_fft", "uvr_max_spec",
-              "uvr_min_spec")
+              "uvr_min_spec", "ensemble_wav")
 
 
 def _take(arr, idx):
@@ -30,6 +30,15 @@ def ensemble(waveforms, algorithm="avg_wave", weights=None):
         for w, wt in zip(waveforms, weights):
             out += w * wt
         return out / np.sum(weights)
+    if algorithm == "ensemble_wav":
+        # spec_utils.ensemble_wav (uvr_lib_v5/spec_utils.py:1245-1266) as Ensembler.ensemble calls it (ensembler.py:71-72): the
+        # [channels, N] arrays are split along axis 0 into 240 sections, so section c < channels is channel c (the other 238
+        # sections are empty), and each channel is taken whole from the input whose mean |x| over that channel is smallest.
+        rows = []
+        for c in range(waveforms[0].shape[0]):
+            means = [np.abs(w[c]).mean() for w in waveforms]
+            rows.append(waveforms[int(np.argmin(means))][c])
+        return np.stack(rows)
     if algorithm == "median_wave":
         return np.median(waveforms, axis=0)
     if algorithm == "min_wave":

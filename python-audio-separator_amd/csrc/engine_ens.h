@@ -3,12 +3,12 @@
 
 struct EnsCtx {
   FftPlan plan{};
-  DevBuf window, tw, frames, wss, dweights, din, din2, dout;
+  DevBuf window, tw, frames, wss, dweights, din, din2, dout, partial, sel;
   bool ready = false;
 };
 
 static void ens_destroy(EnsCtx *c) {
-  for (DevBuf *b : {&c->window, &c->tw, &c->frames, &c->wss, &c->dweights, &c->din, &c->din2, &c->dout}) b->release();
+  for (DevBuf *b : {&c->window, &c->tw, &c->frames, &c->wss, &c->dweights, &c->din, &c->din2, &c->dout, &c->partial, &c->sel}) b->release();
   delete c;
 }
 
@@ -60,7 +60,19 @@ static int ens_ensemble_dev(asx_engine *e, const float *waves, int K, int64_t N,
   CHK(ens_ctx(e));
   EnsCtx &c = *e->ens;
   REQUIRE(K >= 2 && K <= ENS_MAX_K, "ensemble of %d inputs (2 .. %d are built)", K, ENS_MAX_K);
-  REQUIRE(alg >= ENS_AVG_WAVE && alg <= ENS_UVR_MIN_SPEC, "unknown ensemble algorithm %d", alg);
+  REQUIRE(alg >= ENS_AVG_WAVE && alg <= ENS_ENSEMBLE_WAV, "unknown ensemble algorithm %d", alg);
+  if (alg == ENS_ENSEMBLE_WAV) {
+    CHK(c.partial.ensure((size_t)K * 2 * ENS_ABS_BLOCKS * 8));
+    CHK(c.sel.ensure(16));
+    *n_out = N;
+    return timed(e, ASX_PROF_MISC, 0.0, 4.0 * (K + 2) * 2 * N, s, [&]() {
+      hipLaunchKernelGGL(ens_abssum_kernel, dim3(ENS_ABS_BLOCKS, K * 2), dim3(256), 0, s, waves, N, reinterpret_cast<double *>(c.partial.p));
+      hipLaunchKernelGGL(ens_pick_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const double *>(c.partial.p), K, ENS_ABS_BLOCKS,
+                         reinterpret_cast<int *>(c.sel.p));
+      hipLaunchKernelGGL(ens_take_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, s, waves, N,
+                         reinterpret_cast<const int *>(c.sel.p), out);
+    });
+  }
   std::vector<double> w(K, 1.0);
   if (weights_host) w.assign(weights_host, weights_host + K);
   double wsum = 0.0;

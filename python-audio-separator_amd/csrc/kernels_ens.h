@@ -9,7 +9,8 @@
 namespace asx {
 
 enum { ENS_AVG_WAVE = 0, ENS_MEDIAN_WAVE = 1, ENS_MIN_WAVE = 2, ENS_MAX_WAVE = 3, ENS_AVG_FFT = 4, ENS_MEDIAN_FFT = 5,
-       ENS_MIN_FFT = 6, ENS_MAX_FFT = 7, ENS_UVR_MAX_SPEC = 8, ENS_UVR_MIN_SPEC = 9 };
+       ENS_MIN_FFT = 6, ENS_MAX_FFT = 7, ENS_UVR_MAX_SPEC = 8, ENS_UVR_MIN_SPEC = 9, ENS_ENSEMBLE_WAV = 10 };
+constexpr int ENS_ABS_BLOCKS = 256;   // partial sums per (input, channel) of ensemble_wav
 constexpr int ENS_MAX_K = 8;
 
 __device__ __forceinline__ float median_small(float *v, int K) {
@@ -49,6 +50,48 @@ __global__ __launch_bounds__(256) void ens_wave_kernel(const float *__restrict__
     }
     out[i] = best;
   }
+}
+
+// spec_utils.ensemble_wav as Ensembler.ensemble calls it (uvr_lib_v5/spec_utils.py:1245-1266, ensembler.py:71-72): every channel
+// is taken whole from the input whose mean |x| over that channel is smallest (np.array_split along axis 0 of a [2, N] array:
+// section c < 2 is channel c, the other 238 sections are empty).  Three deterministic steps: partial sums of |x| in float64
+// (fixed strided order per block), the argmin per channel (first minimum; a NaN sum wins like in np.argmin), the row copy.
+__global__ __launch_bounds__(256) void ens_abssum_kernel(const float *__restrict__ waves, int64_t N, double *__restrict__ partial) {
+  const int kc = blockIdx.y;                        // input * 2 + channel
+  const float *x = waves + (int64_t)kc * N;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) acc += (double)fabsf(x[i]);
+  __shared__ double sh[256];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(int64_t)kc * gridDim.x + blockIdx.x] = sh[0];
+}
+__global__ void ens_pick_kernel(const double *__restrict__ partial, int K, int P, int *__restrict__ sel) {
+  const int ch = threadIdx.x;
+  if (ch >= 2) return;
+  int best = 0;
+  double bt = 0.0;
+  for (int k = 0; k < K; ++k) {
+    double t = 0.0;
+    for (int b = 0; b < P; ++b) t += partial[(int64_t)(k * 2 + ch) * P + b];
+    if (k == 0) {
+      bt = t;
+    } else if (!(bt != bt) && ((t != t) || t < bt)) {   // np.argmin: the first NaN, else the first minimum
+      best = k;
+      bt = t;
+    }
+  }
+  sel[ch] = best;
+}
+__global__ __launch_bounds__(256) void ens_take_kernel(const float *__restrict__ waves, int64_t N, const int *__restrict__ sel,
+                                                       float *__restrict__ out) {
+  const int ch = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) out[(int64_t)ch * N + i] = waves[((int64_t)sel[ch] * 2 + ch) * N + i];
 }
 
 // librosa.stft frame t of channel ch of wave [2, n] (centre, zero padding) -> X[0 .. nh] in LDS

@@ -771,7 +771,7 @@ class Engine:
         return buf
 
     ENSEMBLE_ALGORITHMS = ("avg_wave", "median_wave", "min_wave", "max_wave", "avg_fft", "median_fft", "min_fft", "max_fft",
-                           "uvr_max_spec", "uvr_min_spec")
+                           "uvr_max_spec", "uvr_min_spec", "ensemble_wav")
 
     def ensemble(self, waveforms, algorithm: str = "avg_wave", weights=None) -> np.ndarray:
         """Ensembler.ensemble (ensembler.py:12-74): list of [2, N] waves (zero-padded to the longest) -> [2, N']."""
