@@ -44,7 +44,7 @@ extern "C" {
 #define ASX_ERR_HIP 2     /* a HIP runtime call failed (no GPU, OOM, launch) */
 #define ASX_ERR_STATE 3   /* call order violated (e.g. demix before commit)  */
 
-#define ASX_ABI_VERSION 2
+#define ASX_ABI_VERSION 3
 
 /* flags of asx_demix*(): */
 #define ASX_FLAG_MATCH_MIX 1u /* demix(mix, is_match_mix=True): overlap 0.02, no net (mdx_separator.py:308-313, :429-432) */
@@ -70,6 +70,9 @@ typedef struct asx_mdx_config {
   double overlap;       /* a Python float: step = int((1 - overlap) * chunk_size) is evaluated in double, mdx_separator.py:335 */
   int32_t enable_denoise;
   int32_t max_batch;
+  int32_t win_length;   /* torch.stft / istft win_length: a periodic Hann window of this length, zero padded to n_fft at both
+                         * ends (BSRoformer stft_win_length, bs_roformer.py:376-377); 0 = n_fft */
+  int32_t reserved;     /* 0 */
 } asx_mdx_config;
 
 /* ConvTDFNet hyper-parameters (uvr_lib_v5/mdxnet.py:31-52); dim_t must equal

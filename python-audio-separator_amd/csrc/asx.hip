@@ -217,15 +217,18 @@ static bool make_plan(int n_fft, FftPlan *p) {
   return n == 1;
 }
 
-static void host_window(int n, std::vector<float> &w) {
-  w.resize(n);
-  for (int k = 0; k < n; ++k) w[k] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)k / (double)n));
+// torch.hann_window(win_length) (periodic), zero padded to n at both ends like torch.stft does for win_length < n_fft
+static void host_window(int n, std::vector<float> &w, int win_length = 0) {
+  const int wl = (win_length > 0 && win_length < n) ? win_length : n;
+  const int off = (n - wl) / 2;
+  w.assign(n, 0.f);
+  for (int k = 0; k < wl; ++k) w[off + k] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)k / (double)wl));
 }
 
 // sum of squared windows, accumulated in f32 in increasing frame order like torch.istft
-static void host_env(int n, int hop, int T, std::vector<float> &env) {
+static void host_env(int n, int hop, int T, std::vector<float> &env, int win_length = 0) {
   std::vector<float> w;
-  host_window(n, w);
+  host_window(n, w, win_length);
   env.assign((size_t)n + (size_t)hop * (T - 1), 0.f);
   for (int t = 0; t < T; ++t)
     for (int k = 0; k < n; ++k) env[(size_t)t * hop + k] += w[k] * w[k];
@@ -933,6 +936,7 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
   REQUIRE(cfg->dim_f > 0 && cfg->dim_f <= cfg->n_fft / 2 + 1, "dim_f %d out of range for n_fft %d", cfg->dim_f,
           cfg->n_fft);
   REQUIRE(cfg->overlap >= 0.0 && cfg->overlap < 1.0, "overlap must be in [0,1)");
+  REQUIRE(cfg->win_length >= 0 && cfg->win_length <= cfg->n_fft, "win_length %d out of range for n_fft %d", cfg->win_length, cfg->n_fft);
   const int64_t C = (int64_t)cfg->hop_length * (cfg->segment_size - 1);
   REQUIRE(C > cfg->n_fft / 2, "chunk_size %lld must exceed n_fft/2 (reflect padding)", (long long)C);
   REQUIRE(C - cfg->n_fft > 0, "chunk_size %lld must exceed n_fft (gen_size > 0)", (long long)C);
@@ -947,7 +951,7 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
   e->cfg = *cfg;
   e->plan = plan;
   std::vector<float> w;
-  host_window(cfg->n_fft, w);
+  host_window(cfg->n_fft, w, cfg->win_length);
   std::vector<float> tw((size_t)cfg->n_fft * 2);
   for (int j = 0; j < cfg->n_fft; ++j) {
     const double ang = -2.0 * M_PI * (double)j / (double)cfg->n_fft;
@@ -955,7 +959,7 @@ int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out) {
     tw[2 * j + 1] = (float)sin(ang);
   }
   std::vector<float> env;
-  host_env(cfg->n_fft, cfg->hop_length, cfg->segment_size, env);
+  host_env(cfg->n_fft, cfg->hop_length, cfg->segment_size, env, cfg->win_length);
   int rc = ASX_OK;
   if ((rc = e->d_window.ensure(w.size() * 4)) == ASX_OK && (rc = e->d_tw.ensure(tw.size() * 4)) == ASX_OK &&
       (rc = e->d_env.ensure(env.size() * 4)) == ASX_OK) {
@@ -1587,7 +1591,7 @@ int asx_istft(asx_engine *e, const float *spec_host, int32_t B, int32_t T, float
   CHK(dfr.ensure((size_t)B * 2 * T * n * 4));
   CHK(dout.ensure((size_t)B * 2 * C * 4));
   std::vector<float> env;
-  host_env(n, hop, T, env);
+  host_env(n, hop, T, env, e->cfg.win_length);
   CHK(to_dev(denv, env.data(), env.size()));
   CHK(istft_launch(e, dsp.f(), B, T, 0, 0, dfr.f(), nullptr));
   CHK(ola_launch(e, dfr.f(), denv.f(), nullptr, B, T, C, dout.f(), nullptr));

@@ -29,7 +29,8 @@ def lib_path() -> str:
 
 class _MdxCfg(C.Structure):
     _fields_ = [("n_fft", C.c_int32), ("hop_length", C.c_int32), ("dim_f", C.c_int32), ("segment_size", C.c_int32),
-                ("overlap", C.c_double), ("enable_denoise", C.c_int32), ("max_batch", C.c_int32)]
+                ("overlap", C.c_double), ("enable_denoise", C.c_int32), ("max_batch", C.c_int32), ("win_length", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class _NetCfg(C.Structure):
@@ -100,6 +101,7 @@ class MDXConfig:
     overlap: float = 0.25
     enable_denoise: bool = False
     max_batch: int = 0
+    win_length: int = 0       # torch.stft win_length (Roformer stft_win_length); 0 = n_fft
 
 
 @dataclass
@@ -210,6 +212,8 @@ class HDConfig:
 _FP = C.POINTER(C.c_float)
 _lib = None
 
+ABI_VERSION = 3   # ASX_ABI_VERSION of include/asx.h the structures below mirror
+
 # every symbol include/asx.h declares
 SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_create", "asx_engine_destroy",
            "asx_net_begin", "asx_net_set_tensor", "asx_net_commit", "asx_net_flops", "asx_plan_query", "asx_demix",
@@ -245,6 +249,8 @@ def load_library():
     lib = C.CDLL(path)
     vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
     lib.asx_abi_version.restype = C.c_int
+    if lib.asx_abi_version() != ABI_VERSION:
+        raise AsxError(f"{path} speaks ABI {lib.asx_abi_version()}, this binding ABI {ABI_VERSION}: rebuild (python build.py)")
     lib.asx_last_error.restype = C.c_char_p
     lib.asx_device_count.restype = C.c_int
     lib.asx_engine_create.argtypes = [C.c_int, C.POINTER(_MdxCfg), C.POINTER(vp)]
@@ -389,7 +395,7 @@ class Engine:
         if self._lib.asx_device_count() <= 0:
             raise AsxError("no HIP device visible: the demix path runs on MI355X only (no CPU fallback)")
         c = _MdxCfg(cfg.n_fft, cfg.hop_length, cfg.dim_f, cfg.segment_size, float(cfg.overlap),
-                    int(bool(cfg.enable_denoise)), int(cfg.max_batch))
+                    int(bool(cfg.enable_denoise)), int(cfg.max_batch), int(getattr(cfg, "win_length", 0) or 0), 0)
         self._check(self._lib.asx_engine_create(device, C.byref(c), C.byref(self._h)))
 
     # -- plumbing ---------------------------------------------------------

@@ -121,8 +121,9 @@ class MDXCDemixer:
         a = res.args
         self._rof_state = res.state_dict
         n_fft = a["stft_n_fft"]
-        if a["stft_win_length"] != n_fft:
-            raise NotImplementedError("stft_win_length != stft_n_fft")
+        win_length = int(a["stft_win_length"])
+        if not 0 < win_length <= n_fft:
+            raise ValueError(f"stft_win_length {win_length} must be in (0, stft_n_fft = {n_fft}]")
         if a["stft_normalized"]:
             raise NotImplementedError("stft_normalized=True")
         # the chunk loop derives its hop from the raw YAML (mdxc_separator.py:289-296), the network from the normalised one
@@ -142,7 +143,8 @@ class MDXCDemixer:
         if not a["stereo"]:
             raise NotImplementedError("mono Roformer models")
         self.engine = Engine(MDXConfig(n_fft=n_fft, hop_length=int(hop), dim_f=n_fft // 2 + 1,
-                                       segment_size=self.mdx_segment_size, overlap=0.0, max_batch=max_batch),
+                                       segment_size=self.mdx_segment_size, overlap=0.0, max_batch=max_batch,
+                                       win_length=0 if win_length == n_fft else win_length),
                              device=_device_index(self.torch_device))
         if self._rof_state is not None:
             self.load_model(self._rof_state)

@@ -90,6 +90,16 @@ def main():
     with torch.no_grad():
         out["fwd2"] = net2(torch.tensor(w)).numpy()
 
+    # stft_win_length < stft_n_fft: torch.stft / istft zero-pad the Hann window to n_fft at both ends (bs_roformer.py:376-377)
+    cfg3 = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
+                            stft_hop_length=16, stft_win_length=48, dim_t=21, sample_rate=100, mlp_expansion_factor=2)
+    sd3 = R.make_roformer_state(cfg3, 9)
+    net3 = BSRoformer(**cfg3.model_kwargs(), flash_attn=False)
+    net3.load_state_dict(sd3, strict=True)
+    net3.eval()
+    with torch.no_grad():
+        out["fwd3_win48"] = net3(torch.tensor(w)).numpy()
+
     def ref_demix(model, c, mix, overlap):
         s = MDXCSeparator.__new__(MDXCSeparator)
         s.logger = logging.getLogger("golden")

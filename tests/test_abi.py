@@ -30,13 +30,13 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.asx_abi_version() == 2
+    assert lib.asx_abi_version() == 3
 
 
 def test_struct_sizes_match_header():
     # 7 x 4 bytes, 9 x 4 bytes, 6 x 8 + 4 x 4 bytes, 10 x (8 + 8 + 8 + 8)
     import ctypes as C
-    assert C.sizeof(E._MdxCfg) == 32
+    assert C.sizeof(E._MdxCfg) == 40
     assert C.sizeof(E._NetCfg) == 36
     assert C.sizeof(E._Plan) == 64
     assert C.sizeof(E._Profile) == 320

@@ -15,6 +15,8 @@ CFG = R.RoformerConfig(dim=32, depth=2, heads=2, dim_head=64, freqs_per_bands=(2
 CFG2 = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
                         stft_hop_length=16, stft_win_length=64, dim_t=21, sample_rate=100, num_stems=2,
                         time_transformer_depth=2, freq_transformer_depth=2, target_instrument=None)
+CFG3 = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64,
+                        stft_hop_length=16, stft_win_length=48, dim_t=21, sample_rate=100, mlp_expansion_factor=2)
 
 
 def rel_rms(a, b):
@@ -47,6 +49,14 @@ def test_forward_golden(A, g):
     assert rel_rms(y[:, 0], g["fwd1"]) < TOL, rel_rms(y[:, 0], g["fwd1"])
     y2 = demixer(A, CFG2, 8, 8).engine.rof_forward(w)
     assert rel_rms(y2, g["fwd2"]) < TOL, rel_rms(y2, g["fwd2"])
+
+
+def test_forward_win_length_golden(A, g):
+    """stft_win_length < stft_n_fft: the Hann window is zero padded to n_fft at both ends (torch.stft / istft), vector written by
+    the reference BSRoformer (asx_mdx_config.win_length, ABI 3)."""
+    w = (0.4 * np.random.default_rng(81).standard_normal((2, 2, 320))).astype(np.float32)
+    y = demixer(A, CFG3, 9, 8).engine.rof_forward(w)
+    assert rel_rms(y[:, 0], g["fwd3_win48"]) < TOL, rel_rms(y[:, 0], g["fwd3_win48"])
 
 
 @pytest.mark.parametrize("name,n,ov", [("n1000_ov8", 1000, 8), ("n1000_ov2", 1000, 2), ("n320_ov1", 320, 1),
