@@ -141,6 +141,8 @@ class MDXCDemixer:
                              freqs_per_bands=tuple(counts), n_out=max(1, len(self.instruments)), mel=mel,
                              band_starts=tuple(starts))
         if not a["stereo"]:
+            # (the reference cannot run them either: prepare_mix always yields [2, N] and BSRoformer.forward asserts one channel
+            # for a mono model, bs_roformer.py:443-445)
             raise NotImplementedError("mono Roformer models")
         self.engine = Engine(MDXConfig(n_fft=n_fft, hop_length=int(hop), dim_f=n_fft // 2 + 1,
                                        segment_size=self.mdx_segment_size, overlap=0.0, max_batch=max_batch,
