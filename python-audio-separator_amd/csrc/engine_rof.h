@@ -326,7 +326,12 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
       const int qtiles = (aa.len + 63) / 64;
       const double fl = 4.0 * (double)nseq * H * (double)aa.len * aa.len * c.dim_head;
       CHK(timed(e, ASX_PROF_CONV1X1, fl, 4.0 * M * 4 * inner, s, [&]() {
-        hipLaunchKernelGGL(attention_kernel, dim3(qtiles, H, (unsigned)nseq), dim3(256), 0, s, aa);
+        static const bool v1 = getenv("ASX_ATTN_V1") && atoi(getenv("ASX_ATTN_V1")) != 0;   // the 4-byte-fragment kernel (A/B)
+        static const int qw = getenv("ASX_ATTN_QW") ? atoi(getenv("ASX_ATTN_QW")) : 1;   // 2: 128 queries per workgroup (measured slower: 357 vs 328 ms)
+        if (v1) hipLaunchKernelGGL(attention_kernel, dim3(qtiles, H, (unsigned)nseq), dim3(256), 0, s, aa);
+        else if (qw >= 2 && aa.len > 64)
+          hipLaunchKernelGGL(attention2_kernel<2>, dim3((aa.len + 127) / 128, H, (unsigned)nseq), dim3(256), 0, s, aa);
+        else hipLaunchKernelGGL(attention2_kernel<1>, dim3(qtiles, H, (unsigned)nseq), dim3(256), 0, s, aa);
       }));
     }
     CHK(rof_gemm(e, L.attn.out, n.ATT.f(), inner, M, n.TOK.f(), D, 0, n.TOK.f(), D, s));   // + x (in place: each

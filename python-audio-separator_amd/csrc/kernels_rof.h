@@ -250,6 +250,189 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// attention2_kernel: the same flash-style algorithm with 16-byte LDS fragment reads.  The MFMA k-steps are re-assigned so
+// that a lane's operands are contiguous in LDS:
+//   S^T = K Q^T : k-step kk of lane group lk multiplies head dim lk * 16 + kk (attention_kernel: 4 kk + lk), so the sixteen
+//                 values a lane needs from a K row (or its Q row) are four ds_read_b128 instead of sixteen ds_read_b32;
+//   O^T += V^T P^T : V is stored TRANSPOSED (Vt[d][key]), so the four keys 4 lk .. 4 lk + 3 of k-steps r = 0..3 are one
+//                 ds_read_b128; the key index is XOR-swizzled by 4 * (d >> 4) so that the transposing ds_write_b32 of a
+//                 32-lane group hit 32 different banks (the 16-byte read stays contiguous: 4 (lk ^ dt) .. + 3).
+// 128 fragment reads per 64-key tile and wave become 32; every row stride is 68 floats (16-byte aligned rows, conflict-free
+// for the 8-lane groups of a b128 access).  The sum over the head dimension runs in a different order than in
+// attention_kernel (same terms, fp32 MFMA accumulation).
+// ---------------------------------------------------------------------------
+constexpr int ATT2_S = 68;
+
+// QW = 16-query groups per wave: a workgroup owns 64 * QW queries of one (sequence, head).  Every K / V tile that is
+// streamed in (32 KB per 64 keys) serves QW times the MFMA work: with QW = 1 the kernel needs ~8 B/clk per CU at the full
+// MFMA rate; QW = 2 halves that (and halves the LDS fragment reads per MFMA, the K / V fragments being shared by both query
+// groups of a wave) at the price of the third co-resident workgroup (69 KB LDS, 212 registers).  Measured on the ep_317
+// layout: QW = 2 357 ms, QW = 1 328 ms (the 4-byte-fragment attention_kernel: 335 ms) -- neither the fragment reads nor the
+// K / V stream bind this kernel; the two workgroup barriers per key tile between three co-resident workgroups do.  QW = 1 is
+// the default.
+template <int QW>
+__global__ __launch_bounds__(256, QW == 1 ? 3 : 2) void attention2_kernel(AttnArgs a) {
+  constexpr int NQ = 64 * QW;                               // queries per workgroup
+  __shared__ float lds[(NQ + 128) * ATT2_S];
+  float *Qs = lds, *Ks = lds + NQ * ATT2_S, *Vt = Ks + 64 * ATT2_S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int qt = blockIdx.x, h = blockIdx.y;
+  const int64_t sq = blockIdx.z;
+  const int64_t base = (sq / a.inner_cnt) * a.outer_stride + (sq % a.inner_cnt) * a.inner_stride;
+  const int inner = a.heads * 64;
+  const int64_t ld = 3 * (int64_t)inner;
+  const int q0 = qt * NQ;
+
+  for (int e = tid; e < NQ * 16; e += 256) {
+    const int r = e >> 4, c4 = e & 15;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (q0 + r < a.len)
+      v = *reinterpret_cast<const f32x4 *>(a.qkv + (base + (int64_t)(q0 + r) * a.row_stride) * ld + h * 64 + c4 * 4);
+    *reinterpret_cast<f32x4 *>(&Qs[r * ATT2_S + c4 * 4]) = v;
+  }
+
+  f32x4 acc_o[QW][4];
+  float m_run[QW], l_run[QW];
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_o[g][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m_run[g] = -INFINITY;
+    l_run[g] = 0.f;
+  }
+
+  const int nkt = (a.len + 63) / 64;
+  f32x4 kreg[4], vreg[4];
+  auto fetch = [&](int kt) {
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      const int r = e >> 4, c4 = e & 15;
+      kreg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      vreg[i] = kreg[i];
+      if (k0 + r < a.len) {
+        const float *rowp = a.qkv + (base + (int64_t)(k0 + r) * a.row_stride) * ld + h * 64 + c4 * 4;
+        kreg[i] = *reinterpret_cast<const f32x4 *>(rowp + inner);
+        vreg[i] = *reinterpret_cast<const f32x4 *>(rowp + 2 * inner);
+      }
+    }
+  };
+  fetch(0);
+  __syncthreads();   // Q staged
+  f32x4 bq[QW][4];   // head dims lk * 16 .. + 15 of query (wave * QW + g) * 16 + li
+#pragma unroll
+  for (int g = 0; g < QW; ++g)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bq[g][q] = *reinterpret_cast<const f32x4 *>(&Qs[((wave * QW + g) * 16 + li) * ATT2_S + lk * 16 + 4 * q]);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int k0 = kt * 64;
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      const int r = e >> 4, c4 = e & 15;
+      *reinterpret_cast<f32x4 *>(&Ks[r * ATT2_S + c4 * 4]) = kreg[i];
+      const int rs = r ^ (4 * (c4 >> 2));                 // key swizzle of the transposed V: 4 * (d >> 4), d = 4 c4 + j
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Vt[(c4 * 4 + j) * ATT2_S + rs] = vreg[i][j];
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) fetch(kt + 1);
+
+    f32x4 st[QW][4];
+#pragma unroll
+    for (int g = 0; g < QW; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st[g][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f32x4 kf[2][4];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          kf[m][q] = *reinterpret_cast<const f32x4 *>(&Ks[((2 * p + m) * 16 + li) * ATT2_S + lk * 16 + 4 * q]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < QW; ++g) st[g][2 * p + m] = ASX_MFMA(kf[m][q][j], bq[g][q][j], st[g][2 * p + m]);
+    }
+#pragma unroll
+    for (int g = 0; g < QW; ++g) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + mt * 16 + 4 * lk + r;
+          const float sv = (key < a.len) ? st[g][mt][r] * a.scale : -INFINITY;
+          st[g][mt][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[g], mx);
+      const float corr = (m_run[g] == -INFINITY) ? 0.f : (a.exact ? expf(m_run[g] - m_new) : __expf(m_run[g] - m_new));
+      float psum = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = (st[g][mt][r] == -INFINITY) ? 0.f : (a.exact ? expf(st[g][mt][r] - m_new) : __expf(st[g][mt][r] - m_new));
+          st[g][mt][r] = p;
+          psum += p;
+        }
+      }
+      psum += __shfl_xor(psum, 16);
+      psum += __shfl_xor(psum, 32);
+      l_run[g] = l_run[g] * corr + psum;
+      m_run[g] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) acc_o[g][dt] *= corr;
+    }
+    // O^T[d, query] += V^T[d, key] P^T[key, query]
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4 vf[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        vf[dt] = *reinterpret_cast<const f32x4 *>(&Vt[(dt * 16 + li) * ATT2_S + mt * 16 + 4 * (lk ^ dt)]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int g = 0; g < QW; ++g) acc_o[g][dt] = ASX_MFMA(vf[dt][r], st[g][mt][r], acc_o[g][dt]);
+    }
+  }
+
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+    const int q = q0 + (wave * QW + g) * 16 + li;
+    if (q < a.len) {
+      const int64_t row = base + (int64_t)q * a.row_stride;
+      const float gt = a.gate[row * a.gate_ld + h];
+      const float gs = 1.0f / (1.0f + expf(-gt));
+      const float inv = gs / l_run[g];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        f32x4 o = acc_o[g][dt];
+        o *= inv;
+        *reinterpret_cast<f32x4 *>(a.out + row * inner + h * 64 + dt * 16 + 4 * lk) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // GLU of the mask MLP output (bs_roformer.py:216) scattered into the mask tensor [B, S, T, W]:
 //   mask[b, st, t, off + j] = a[m, j] * sigmoid(a[m, din + j]),   m = b*T + t
 // ---------------------------------------------------------------------------
