@@ -1006,16 +1006,14 @@ static int vr_synthesis_dev(asx_engine *e, int which, const float *M, int T, flo
       return ASX_ERR_INVALID;
     }
     CHK(n.frames.ensure((size_t)2 * T * nf * 4));
-    // squared-window sum over the T frames (librosa.filters.window_sumsquare)
-    std::vector<float> w;
-    host_window(nf, w);
-    std::vector<double> ss((size_t)nf + (size_t)hop * (T - 1), 0.0);
-    for (int t = 0; t < T; ++t)
-      for (int k = 0; k < nf; ++k) ss[(size_t)t * hop + k] += (double)w[k] * (double)w[k];
-    std::vector<float> ssf(ss.begin(), ss.end());
-    CHK(n.wss.ensure(ssf.size() * 4));
-    HIPCHK(hipMemcpyAsync(n.wss.p, ssf.data(), ssf.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
+    // squared-window sum over the T frames (librosa.filters.window_sumsquare), on the device: the host loop it replaces cost
+    // T * n_fft double adds per band and stem (~100 ms per 4-minute song) and a stream synchronisation
+    {
+      const int64_t nw = (int64_t)nf + (int64_t)hop * (T - 1);
+      CHK(n.wss.ensure((size_t)nw * 4));
+      hipLaunchKernelGGL(vr_wss_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, B.window.f(), nf, hop, T, nw, n.wss.f());
+      HIPCHK(hipGetLastError());
+    }
     CHK(timed(e, ASX_PROF_ISTFT, 0.0, 4.0 * 2 * T * (3.0 * (B.b.crop_stop - B.b.crop_start) + nf), s, [&]() {
       hipLaunchKernelGGL(vr_istft_kernel, dim3(T, 2), dim3(256), istft_lds(B.plan), s, reinterpret_cast<const float2 *>(n.X.p), M, which,
                          n.nb1, B.b.crop_start, B.b.crop_stop, row_off, B.gain_syn.f(), n.frames.f(), B.window.f(),

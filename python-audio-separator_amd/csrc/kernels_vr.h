@@ -12,6 +12,24 @@
 
 namespace asx {
 
+// librosa.filters.window_sumsquare over T frames: out[i] = sum_t w[i - t * hop]^2, accumulated in float64 in increasing t like
+// the host loop it replaces (bit-identical), rounded to float32.  One thread per output sample; at most n_fft / hop terms.
+__global__ __launch_bounds__(256) void vr_wss_kernel(const float *__restrict__ window, int n_fft, int hop, int T, int64_t n,
+                                                     float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t t_lo = (i - n_fft + hop) / hop;          // ceil((i - n_fft + 1) / hop) for i - n_fft + 1 > 0
+  if (i - n_fft + 1 <= 0) t_lo = 0;
+  int64_t t_hi = i / hop;
+  if (t_hi > T - 1) t_hi = T - 1;
+  double acc = 0.0;
+  for (int64_t t = t_lo; t <= t_hi; ++t) {
+    const double w = (double)window[i - t * hop];
+    acc += w * w;
+  }
+  out[i] = (float)acc;
+}
+
 // F.interpolate(scale_factor=2, mode="bilinear", align_corners=True) (layers.py:154): x [B, h, w, C] (row stride ldx)
 // -> y [B, 2h, 2w, (ldy)] channel slice [0, C).  src = dst * (in - 1) / (out - 1).
 __global__ __launch_bounds__(256) void vr_upsample2x_kernel(const float *__restrict__ x, int h, int w, int C, int ldx,
