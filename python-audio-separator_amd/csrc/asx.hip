@@ -290,7 +290,9 @@ static int conv_setup(ConvLayer &L, int kind, int cin, int cout, int relu) {
     // 234.9 -> 224.0 ms (85.1 -> 89.4 % of the fp32-MFMA peak), every level gains.  ASX_CONV_KC4=<cin threshold> for the
     // A/B (0 = eight channels everywhere).
     static const int kc4 = getenv("ASX_CONV_KC4") ? atoi(getenv("ASX_CONV_KC4")) : (1 << 30);
-    if (kind == CK_3X3 && cin <= kc4 && cin % 4 == 0 && pick_nrep_conv(cout) == 3) L.kc = 4;
+    // (also for the two-tile channel groups of the MDX23C widths: ASX_CONV_KC4_N2=0 keeps their eight-channel stages)
+    static const int kc4_n2 = getenv("ASX_CONV_KC4_N2") ? atoi(getenv("ASX_CONV_KC4_N2")) : 1;
+    if (kind == CK_3X3 && cin <= kc4 && cin % 4 == 0 && (pick_nrep_conv(cout) == 3 || (kc4_n2 && pick_nrep_conv(cout) == 2))) L.kc = 4;
     // 2x2 / stride-2 conv: two-channel stages (four workgroups per CU); ASX_DOWN_KC2=0 keeps the four-channel stages
     static const int down_kc2 = getenv("ASX_DOWN_KC2") ? atoi(getenv("ASX_DOWN_KC2")) : 1;
     if (kind == CK_DOWN && down_kc2 && cin % 2 == 0 && pick_nrep_conv(cout) == 3) L.kc = 2;
@@ -472,6 +474,7 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
       case CK_3X3:
         if (L.nrep == 3 && L.kc == 4) ASX_CONV_CASE(3, 3, 1, 1, 3, 4, 2, EPI_BIAS_ACT);
         else if (L.nrep == 3) ASX_CONV_CASE(3, 3, 1, 1, 3, 8, 2, EPI_BIAS_ACT);
+        else if (L.nrep == 2 && L.kc == 4) ASX_CONV_CASE(3, 3, 1, 1, 2, 4, 2, EPI_BIAS_ACT);
         else if (L.nrep == 2) ASX_CONV_CASE(3, 3, 1, 1, 2, 8, 2, EPI_BIAS_ACT);
         else ASX_CONV_CASE(3, 3, 1, 1, 1, 8, 2, EPI_BIAS_ACT);
         break;
