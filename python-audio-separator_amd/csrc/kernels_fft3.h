@@ -1,25 +1,29 @@
 // Fast STFT / iSTFT path for n_fft = 6144, hop = 1024 (the UVR-MDX-NET HQ geometry): a real FFT of 6144 points as one
-// complex FFT of 3072 = 12 x 16 x 16 points in THREE register-resident Stockham passes (radix 12, 16, 16) with two LDS
+// complex FFT of 3072 = 12 x 16 x 16 points in THREE register-resident Stockham passes (radix 12, 16, 16) with LDS
 // exchanges, instead of the generic six-pass radix-{4,3} loop of kernels_fft.h.  Replaces, on that geometry,
 // torch.stft / torch.istft as used by uvr_lib_v5/stft.py:41,117 and the frame overlap-add inside torch.istft.
 //
-// Forward (stft3_kernel), one workgroup of 256 threads per (frame, channel, chunk):
-//   load + periodic-Hann window straight into registers: thread j holds z[j + 256 r], r < 12 (z[m] = x[2m] + i x[2m+1]);
-//   pass A: 12-point DFT in registers (3 x radix-4, W12 twiddles, 4 x radix-3), written as six 16-byte stores per thread
-//           (row stride 96 B: conflict-free for ds_write_b128's 8-lane groups);
+// The transform, per 256-thread workgroup and frame:
+//   pass A: thread j holds z[j + 256 r], r < 12 (z[m] = x[2m] + i x[2m+1]); 12-point DFT in registers (3 x radix-4, W12
+//           twiddles, 4 x radix-3), written as six 16-byte stores per thread (row stride 96 B: conflict-free for
+//           ds_write_b128's 8-lane groups);
 //   pass B: threads j < 192 read in[j + 192 r] (consecutive lanes, conflict-free ds_read_b64), twiddle by W192^(k r),
 //           16-point DFT (radix-4 x radix-4), write out[q*192 + k + 12 r] into blocks padded to 204 so that a 16-lane
 //           ds_write_b64 group never wraps onto its own banks;
-//   pass C: same read pattern, twiddle W3072^(j r) (coalesced table [r][j]), 16-point DFT -> Z[j + 192 r];
-//   split : Z goes to LDS once more so that X[k] = E + W6144^k O can pair Z[k] with conj Z[3072 - k]; the two planes of a
-//           [T, F] row are written coalesced.
-// Inverse (istft3_kernel): a workgroup owns G consecutive frames of one (chunk, channel).  Per frame: X[k] and X[3072-k]
-//   are read straight from the spectrogram (coalesced, ascending / descending), merged to Z, the same three passes run
-//   with conjugate twiddles, and the windowed frame is ACCUMULATED INTO AN LDS RING of n_fft floats (a frame covers six
-//   hops; after frame t hop t is complete, is divided by the window envelope, multiplied by the chunk's Hann window and
-//   written out).  The [B, 2, T, n_fft] frame buffer of the generic path (12.6 MB per chunk written and re-read) never
-//   exists; only the five partial hops at either end of a workgroup's frame range travel through a small seam buffer,
-//   which seam3_kernel folds (tail of group g + head of group g + 1) in a fixed order -- deterministic, no atomics.
+//   pass C: same read pattern, twiddle W3072^(j r), 16-point DFT -> Z[j + 192 r];
+//   split (forward) / merge (inverse): X[k] = E + W6144^k O pairs Z[k] with conj Z[3072 - k].
+// Complex arithmetic is packed fp32 (one or two v_pk_* instructions per operation, see below).
+//
+// Kernels:
+//   stft3p_kernel   forward, ~16 consecutive frames of one (chunk, channel) per workgroup, samples in an LDS ring
+//   istft3p_kernel  inverse, ~16 frames per workgroup: spectrum rows prefetched global -> LDS by DMA, frames ACCUMULATED INTO AN
+//                   LDS RING of n_fft floats (a frame covers six hops; after frame t hop t is complete, is divided by the
+//                   window envelope, multiplied by the chunk's Hann window and written).  The [B, 2, T, n_fft] frame buffer of
+//                   the generic path never exists; only the five partial hops at either end of a workgroup's frame range
+//                   travel through a small seam buffer,
+//   seam3_kernel    which folds them (tail of group g + head of group g + 1) in a fixed order -- deterministic, no atomics;
+//   stft3_kernel / istft3_kernel   the first generation (one frame per workgroup forward; inverse without prefetch, also the
+//                   denoise-combine path), kept behind ASX_FFT3P=0.
 //
 // The per-thread stage bodies are plain inline functions of (thread id, "LDS" pointers) so that tests/host/fft3_host.cpp
 // can run them on the CPU, thread by thread, against a reference DFT (ASX_HOST_TEST).
