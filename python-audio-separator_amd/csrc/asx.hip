@@ -854,7 +854,10 @@ static int block_forward(asx_engine *e, const Block &blk, float *&cur, float *de
   }
   const int64_t M = (int64_t)B * blk.c * blk.t;
   CHK(tdf_launch(e, blk.tdf0, cur, nullptr, e->H.f(), M, blk.t, s));
-  float *out = dest ? dest : next_free(cur, nullptr);
+  // (A/B ASX_TDF_INPLACE=1: x + tdf(x) written over x where no skip copy is needed -- every output element depends on the
+  // same element of x only)
+  static const bool inplace = getenv("ASX_TDF_INPLACE") && atoi(getenv("ASX_TDF_INPLACE")) != 0;
+  float *out = dest ? dest : (inplace ? cur : next_free(cur, nullptr));
   CHK(tdf_launch(e, blk.tdf1, e->H.f(), cur, out, M, blk.t, s));
   cur = out;
   return ASX_OK;
