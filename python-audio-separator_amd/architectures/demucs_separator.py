@@ -8,7 +8,6 @@ and triangular fold, the HTDemucs / HDemucs forward and the standardise / de-sta
 """
 from __future__ import annotations
 
-import os
 
 import numpy as np
 
@@ -26,19 +25,14 @@ DEMUCS_6_SOURCE_MAPPER = {CommonSeparator.BASS_STEM: 0, CommonSeparator.DRUM_STE
 class DemucsSeparator(CommonSeparator):
     def __init__(self, common_config, arch_config):
         super().__init__(config=common_config)
-        self.segment_size = arch_config.get("segment_size", "Default")
-        self.shifts = arch_config.get("shifts", 2)
-        self.overlap = arch_config.get("overlap", 0.25)
-        self.segments_enabled = arch_config.get("segments_enabled", True)
+        self._read_options(arch_config, (("segment_size", "Default"), ("shifts", 2), ("overlap", 0.25), ("segments_enabled", True)))
         self.logger.debug(f"Demucs arch params: segment_size={self.segment_size}, segments_enabled={self.segments_enabled}, "
                           f"shifts={self.shifts}, overlap={self.overlap}")
         self.demucs_source_map = DEMUCS_4_SOURCE_MAPPER
-        self.audio_file_path = None
-        self.audio_file_base = None
         self.demucs_model_instance = None
         self._common, self._arch = dict(common_config), dict(arch_config)
         self._max_batch = int(arch_config.get("asx_max_batch", 0))
-        self.logger.info("Demucs Separator initialisation complete")
+        self.logger.info("Demucs plugin ready (the model package is read at the first separate())")
 
     def load_model(self):
         """demucs_separator.py:119-124 (get_demucs_model + demucs_segments + .to(device).eval()), done once."""
@@ -61,8 +55,7 @@ class DemucsSeparator(CommonSeparator):
 
     def separate(self, audio_file_path, custom_output_names=None):
         """demucs_separator.py:83-160."""
-        self.audio_file_path = audio_file_path
-        self.audio_file_base = os.path.splitext(os.path.basename(audio_file_path))[0]
+        self._begin_file(audio_file_path)
         mix = self.prepare_mix(self.audio_file_path)
         self.load_model()
         source = self.demix_demucs(mix)
@@ -70,12 +63,12 @@ class DemucsSeparator(CommonSeparator):
 
         n = len(source)
         self.demucs_source_map = {2: DEMUCS_2_SOURCE_MAPPER, 6: DEMUCS_6_SOURCE_MAPPER}.get(n, DEMUCS_4_SOURCE_MAPPER)
-        output_files = []
-        for stem_name, stem_value in self.demucs_source_map.items():
+        files = []
+        for stem_name, index in self.demucs_source_map.items():
             if self.output_single_stem is not None and stem_name.lower() != self.output_single_stem.lower():
-                self.logger.debug(f"Skipping writing stem {stem_name} as output_single_stem is set to {self.output_single_stem}...")
+                self.logger.debug(f"{stem_name}: not written (output_single_stem = {self.output_single_stem})")
                 continue
-            stem_path = self.get_stem_output_path(stem_name, custom_output_names)
-            self.final_process(stem_path, source[stem_value].T, stem_name)
-            output_files.append(stem_path)
-        return output_files
+            path = self.get_stem_output_path(stem_name, custom_output_names)
+            self.final_process(path, source[index].T, stem_name)
+            files.append(path)
+        return files

@@ -8,8 +8,6 @@ Same constructor (``common_config``, ``arch_config``), attributes, ``load_model`
 """
 from __future__ import annotations
 
-import os
-
 import numpy as np
 
 from ..common_separator import CommonSeparator
@@ -19,33 +17,23 @@ from ..mdx import MDXDemixer
 class MDXSeparator(CommonSeparator):
     def __init__(self, common_config, arch_config):
         super().__init__(config=common_config)
-        self.segment_size = arch_config.get("segment_size")
-        self.overlap = arch_config.get("overlap")
-        self.batch_size = arch_config.get("batch_size", 1)
-        self.hop_length = arch_config.get("hop_length")
-        self.enable_denoise = arch_config.get("enable_denoise")
+        self._read_options(arch_config, (("segment_size", None), ("overlap", None), ("batch_size", 1), ("hop_length", None),
+                                         ("enable_denoise", None)))
         self.logger.debug(f"MDX arch params: batch_size={self.batch_size}, segment_size={self.segment_size}, overlap={self.overlap}, "
                           f"hop_length={self.hop_length}, enable_denoise={self.enable_denoise}")
-        self.compensate = self.model_data["compensate"]
-        self.dim_f = self.model_data["mdx_dim_f_set"]
-        self.dim_t = 2 ** self.model_data["mdx_dim_t_set"]
-        self.n_fft = self.model_data["mdx_n_fft_scale_set"]
-        self.config_yaml = self.model_data.get("config_yaml", None)
+        md = self.model_data                                   # the hash-keyed model parameters (separator.py:786-803)
+        self.compensate, self.dim_f, self.n_fft = md["compensate"], md["mdx_dim_f_set"], md["mdx_n_fft_scale_set"]
+        self.dim_t = 2 ** md["mdx_dim_t_set"]
+        self.config_yaml = md.get("config_yaml")
         # engine knob, not a reference option: chunks per device batch (results do not depend on it)
         self._max_batch = int(arch_config.get("asx_max_batch", 0))
         self._common, self._arch = dict(common_config), dict(arch_config)
 
         self.load_model()
 
-        self.n_bins = 0
-        self.trim = 0
-        self.chunk_size = 0
-        self.gen_size = 0
+        self.n_bins = self.trim = self.chunk_size = self.gen_size = 0      # filled by initialize_model_settings
         self.stft = None
-        self.primary_source = None
-        self.secondary_source = None
-        self.audio_file_path = None
-        self.audio_file_base = None
+        self._reset_file_state()
 
     def load_model(self):
         """mdx_separator.py:108-133.  ``common_config["asx_state_dict"]`` (a ConvTDFNet state_dict, optional, with
@@ -97,8 +85,7 @@ class MDXSeparator(CommonSeparator):
 
     def separate(self, audio_file_path, custom_output_names=None):
         """mdx_separator.py:135-203."""
-        self.audio_file_path = audio_file_path
-        self.audio_file_base = os.path.splitext(os.path.basename(audio_file_path))[0]
+        self._begin_file(audio_file_path)
         mix = self.prepare_mix(self.audio_file_path)
         if mix.shape[0] != 2:
             msg = f"Expected a 2-channel audio signal, but got {mix.shape[0]} channels"
@@ -115,15 +102,4 @@ class MDXSeparator(CommonSeparator):
         if need_secondary:
             self.secondary_source = secondary
 
-        output_files = []
-        if not self.output_single_stem or self.output_single_stem.lower() == self.secondary_stem_name.lower():
-            self.secondary_stem_output_path = self.get_stem_output_path(self.secondary_stem_name, custom_output_names)
-            self.logger.info(f"Saving {self.secondary_stem_name} stem to {self.secondary_stem_output_path}...")
-            self.final_process(self.secondary_stem_output_path, self.secondary_source, self.secondary_stem_name)
-            output_files.append(self.secondary_stem_output_path)
-        if not self.output_single_stem or self.output_single_stem.lower() == self.primary_stem_name.lower():
-            self.primary_stem_output_path = self.get_stem_output_path(self.primary_stem_name, custom_output_names)
-            self.logger.info(f"Saving {self.primary_stem_name} stem to {self.primary_stem_output_path}...")
-            self.final_process(self.primary_stem_output_path, self.primary_source, self.primary_stem_name)
-            output_files.append(self.primary_stem_output_path)
-        return output_files
+        return self._emit_pair(custom_output_names)

@@ -7,7 +7,6 @@ the mix and of every stem (:147, :170-190) is ``asx_normalize``; the chunk loops
 """
 from __future__ import annotations
 
-import os
 
 import numpy as np
 
@@ -18,12 +17,8 @@ from ..mdxc import MDXCDemixer
 class MDXCSeparator(CommonSeparator):
     def __init__(self, common_config, arch_config):
         super().__init__(config=common_config)
-        self.segment_size = arch_config.get("segment_size", 256)
-        self.override_model_segment_size = arch_config.get("override_model_segment_size", False)
-        self.overlap = arch_config.get("overlap", 8)
-        self.batch_size = arch_config.get("batch_size", 1)
-        self.pitch_shift = arch_config.get("pitch_shift", 0)
-        self.process_all_stems = arch_config.get("process_all_stems", True)
+        self._read_options(arch_config, (("segment_size", 256), ("override_model_segment_size", False), ("overlap", 8), ("batch_size", 1),
+                                         ("pitch_shift", 0), ("process_all_stems", True)))
         self.logger.debug(f"MDXC arch params: batch_size={self.batch_size}, segment_size={self.segment_size}, overlap={self.overlap}, "
                           f"override_model_segment_size={self.override_model_segment_size}, pitch_shift={self.pitch_shift}")
         self.is_roformer = getattr(self, "is_roformer_model", False)
@@ -33,13 +28,10 @@ class MDXCSeparator(CommonSeparator):
 
         self.load_model()
 
-        self.primary_source = None
-        self.secondary_source = None
-        self.audio_file_path = None
-        self.audio_file_base = None
+        self._reset_file_state()
         training = self.model_data.get("training", {}) or {}
         self.is_primary_stem_main_target = bool(training.get("target_instrument"))
-        self.logger.info("MDXC Separator initialisation complete")
+        self.logger.info(f"MDXC model ready ({'Roformer' if self.is_roformer else 'TFC-TDF v3'} on the HIP engine)")
 
     # ---- weights ---------------------------------------------------------------
     def _demixer(self) -> MDXCDemixer:
@@ -70,9 +62,9 @@ class MDXCSeparator(CommonSeparator):
                 self._state_dict = read_checkpoint(self.model_path) if self.is_roformer else read_state_dict(self.model_path)
             self._demixer()
         except RuntimeError as e:
-            self.logger.error(f"Error: {e}")
-            self.logger.error("An error occurred while loading the model file. This often occurs when the model file is corrupt or incomplete.")
-            self.logger.error(f"Please try deleting the model file from {self.model_path} and run audio-separator again to re-download it.")
+            # same outcome as the reference (mdxc_separator.py:108-116): a checkpoint that cannot be read ends the process
+            self.logger.error(f"{self.model_path}: the checkpoint could not be loaded ({e}); the file is probably truncated or "
+                              "corrupt -- delete it so that it is fetched again")
             sys.exit(1)
 
     # ---- the path ----------------------------------------------------------------
@@ -82,17 +74,15 @@ class MDXCSeparator(CommonSeparator):
 
     def separate(self, audio_file_path, custom_output_names=None):
         """mdxc_separator.py:118-227."""
-        self.primary_source = None
-        self.secondary_source = None
-        self.audio_file_path = audio_file_path
-        self.audio_file_base = os.path.splitext(os.path.basename(audio_file_path))[0]
+        self._reset_file_state()
+        self._begin_file(audio_file_path)
         mix = self.prepare_mix(self.audio_file_path)
 
         seconds = mix.shape[1] / self.sample_rate
         if seconds < 10.0 and not self.override_model_segment_size:
             self.override_model_segment_size = True
-            self.logger.warning(f"Audio duration ({seconds:.2f}s) is less than 10 seconds.")
-            self.logger.warning("Automatically enabling override_model_segment_size for better processing of short audio.")
+            self.logger.warning(f"{seconds:.2f} s of audio (< 10 s): switching to the configured segment size "
+                                "(override_model_segment_size), as the reference does for short files")
 
         dm = self._demixer()
         eng = dm.engine
@@ -100,38 +90,23 @@ class MDXCSeparator(CommonSeparator):
         mix = norm(np.ascontiguousarray(mix, np.float32))
         source = dm.demix(mix)
 
-        output_files = []
         training = self.model_data.get("training", {}) or {}
-        if isinstance(source, dict):
-            stem_list = [training["target_instrument"]] if training.get("target_instrument") else list(training.get("instruments") or [])
-            if self.process_all_stems and len(stem_list) > 2:
-                for stem_name in stem_list:
-                    stem_output_path = self.get_stem_output_path(stem_name, custom_output_names)
-                    stem_source = norm(source[stem_name]).T
-                    self.logger.info(f"Saving {stem_name} stem to {stem_output_path}...")
-                    self.final_process(stem_output_path, stem_source, stem_name)
-                    output_files.append(stem_output_path)
-            else:
-                if not isinstance(self.primary_source, np.ndarray):
-                    self.primary_source = norm(source[self.primary_stem_name]).T
-                if not isinstance(self.secondary_source, np.ndarray):
-                    self.secondary_source = norm(source[self.secondary_stem_name]).T
-                if not self.output_single_stem or self.output_single_stem.lower() == self.secondary_stem_name.lower():
-                    self.secondary_stem_output_path = self.get_stem_output_path(self.secondary_stem_name, custom_output_names)
-                    self.logger.info(f"Saving {self.secondary_stem_name} stem to {self.secondary_stem_output_path}...")
-                    self.final_process(self.secondary_stem_output_path, self.secondary_source, self.secondary_stem_name)
-                    output_files.append(self.secondary_stem_output_path)
-                if not self.output_single_stem or self.output_single_stem.lower() == self.primary_stem_name.lower():
-                    self.primary_stem_output_path = self.get_stem_output_path(self.primary_stem_name, custom_output_names)
-                    self.logger.info(f"Saving {self.primary_stem_name} stem to {self.primary_stem_output_path}...")
-                    self.final_process(self.primary_stem_output_path, self.primary_source, self.primary_stem_name)
-                    output_files.append(self.primary_stem_output_path)
-        else:
-            if not self.output_single_stem or self.output_single_stem.lower() == self.primary_stem_name.lower():
-                self.primary_stem_output_path = self.get_stem_output_path(self.primary_stem_name, custom_output_names)
+        if not isinstance(source, dict):
+            # single-target model without residual: one array (mdxc_separator.py:213-225)
+            files = []
+            if self._wanted(self.primary_stem_name):
                 if not isinstance(self.primary_source, np.ndarray):
                     self.primary_source = source.T
-                self.logger.info(f"Saving {self.primary_stem_name} stem to {self.primary_stem_output_path}...")
-                self.final_process(self.primary_stem_output_path, self.primary_source, self.primary_stem_name)
-                output_files.append(self.primary_stem_output_path)
-        return output_files
+                self.primary_stem_output_path = self._emit_stem(self.primary_stem_name, self.primary_source, custom_output_names, files)
+            return files
+        stems = [training["target_instrument"]] if training.get("target_instrument") else list(training.get("instruments") or [])
+        if self.process_all_stems and len(stems) > 2:
+            files = []
+            for name in stems:
+                self._emit_stem(name, norm(source[name]).T, custom_output_names, files)
+            return files
+        if not isinstance(self.primary_source, np.ndarray):
+            self.primary_source = norm(source[self.primary_stem_name]).T
+        if not isinstance(self.secondary_source, np.ndarray):
+            self.secondary_source = norm(source[self.secondary_stem_name]).T
+        return self._emit_pair(custom_output_names)

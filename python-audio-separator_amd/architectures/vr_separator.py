@@ -46,12 +46,8 @@ class VRSeparator(CommonSeparator):
         self.model_params_path = os.path.join(params_dir or "", f"{self.model_data['vr_model_param']}.json")
         self.model_params = load_model_params(self.model_params_path)
 
-        self.enable_tta = arch_config.get("enable_tta", False)
-        self.enable_post_process = arch_config.get("enable_post_process", False)
-        self.post_process_threshold = arch_config.get("post_process_threshold", 0.2)
-        self.batch_size = arch_config.get("batch_size", 1)
-        self.window_size = arch_config.get("window_size", 512)
-        self.high_end_process = arch_config.get("high_end_process", False)
+        self._read_options(arch_config, (("enable_tta", False), ("enable_post_process", False), ("post_process_threshold", 0.2),
+                                         ("batch_size", 1), ("window_size", 512), ("high_end_process", False)))
         self.input_high_end_h = None
         self.input_high_end = None
         self.aggression = float(int(arch_config.get("aggression", 5)) / 100)
@@ -65,7 +61,7 @@ class VRSeparator(CommonSeparator):
         self.logger.debug(f"VR arch params: enable_tta={self.enable_tta}, enable_post_process={self.enable_post_process}, "
                           f"post_process_threshold={self.post_process_threshold}, batch_size={self.batch_size}, "
                           f"window_size={self.window_size}, high_end_process={self.high_end_process}, aggression={self.aggression}")
-        self.logger.info("VR Separator initialisation complete")
+        self.logger.info(f"VR plugin ready ({self.model_data['vr_model_param']}, {'5.1' if self.is_vr_51_model else '5.0'} net on the HIP engine)")
 
     def _warn_resampler(self):
         wanted = {reference_wav_resolution()} | {str(b.get("res_type")) for b in self.model_params["band"].values()}
@@ -100,10 +96,8 @@ class VRSeparator(CommonSeparator):
 
     def separate(self, audio_file_path, custom_output_names=None):
         """vr_separator.py:115-253."""
-        self.primary_source = None
-        self.secondary_source = None
-        self.audio_file_path = audio_file_path
-        self.audio_file_base = os.path.splitext(os.path.basename(audio_file_path))[0]
+        self._reset_file_state()
+        self._begin_file(audio_file_path)
         try:
             self.input_audio_subtype = audio_io.info(audio_file_path)["subtype"]
             if "24" in self.input_audio_subtype:
@@ -113,7 +107,7 @@ class VRSeparator(CommonSeparator):
             else:
                 self.wav_subtype, self.input_bit_depth = "PCM_16", 16
         except Exception as e:
-            self.logger.warning(f"Could not detect input audio bit depth: {e}. Defaulting to PCM_16")
+            self.logger.warning(f"{audio_file_path}: no container info ({e}); stems will be written as PCM_16")
             self.wav_subtype, self.input_audio_subtype, self.input_bit_depth = "PCM_16", None, 16
         self.input_subtype = self.input_audio_subtype
 
@@ -128,31 +122,24 @@ class VRSeparator(CommonSeparator):
 
         if self.output_single_stem and self.output_single_stem.lower() not in (self.primary_stem_name.lower(),
                                                                                self.secondary_stem_name.lower()):
-            self.logger.warning(f"The output_single_stem setting '{self.output_single_stem}' does not match any of the output files: "
-                                f"'{self.primary_stem_name}' and '{self.secondary_stem_name}'. For this model '{self.model_name}', "
-                                "the output_single_stem setting will be ignored and all output files will be saved.")
+            self.logger.warning(f"output_single_stem = '{self.output_single_stem}' names neither '{self.primary_stem_name}' nor "
+                                f"'{self.secondary_stem_name}' (model {self.model_name}): ignored, both stems are written")
             self.output_single_stem = None
 
-        want_p = not self.output_single_stem or self.output_single_stem.lower() == self.primary_stem_name.lower()
-        want_s = not self.output_single_stem or self.output_single_stem.lower() == self.secondary_stem_name.lower()
+        want_p, want_s = self._wanted(self.primary_stem_name), self._wanted(self.secondary_stem_name)
         primary, secondary = dm.separate_stems(wave, want_primary=want_p, want_secondary=want_s)
 
-        output_files = []
+        # primary first here (vr_separator.py:211-246), unlike the MDX family
+        files = []
         if want_p:
             if not isinstance(self.primary_source, np.ndarray):
                 self.primary_source = self._to_44100(primary)
-            self.primary_stem_output_path = self.get_stem_output_path(self.primary_stem_name, custom_output_names)
-            self.logger.info(f"Saving {self.primary_stem_name} stem to {self.primary_stem_output_path}...")
-            self.final_process(self.primary_stem_output_path, self.primary_source, self.primary_stem_name)
-            output_files.append(self.primary_stem_output_path)
+            self.primary_stem_output_path = self._emit_stem(self.primary_stem_name, self.primary_source, custom_output_names, files)
         if want_s:
             if not isinstance(self.secondary_source, np.ndarray):
                 self.secondary_source = self._to_44100(secondary)
-            self.secondary_stem_output_path = self.get_stem_output_path(self.secondary_stem_name, custom_output_names)
-            self.logger.info(f"Saving {self.secondary_stem_name} stem to {self.secondary_stem_output_path}...")
-            self.final_process(self.secondary_stem_output_path, self.secondary_source, self.secondary_stem_name)
-            output_files.append(self.secondary_stem_output_path)
-        return output_files
+            self.secondary_stem_output_path = self._emit_stem(self.secondary_stem_name, self.secondary_source, custom_output_names, files)
+        return files
 
     def _to_44100(self, stem):
         """vr_separator.py:218-220, :238-240: models trained at another rate are brought back with librosa.resample's

@@ -21,44 +21,29 @@ from . import audio_io
 
 
 class CommonSeparator:
-    # stem vocabulary (common_separator.py:19-53): part of the naming contract of the output files
-    ALL_STEMS = "All Stems"
-    VOCAL_STEM = "Vocals"
-    INST_STEM = "Instrumental"
-    OTHER_STEM = "Other"
-    BASS_STEM = "Bass"
-    DRUM_STEM = "Drums"
-    GUITAR_STEM = "Guitar"
-    PIANO_STEM = "Piano"
-    SYNTH_STEM = "Synthesizer"
-    STRINGS_STEM = "Strings"
-    WOODWINDS_STEM = "Woodwinds"
-    BRASS_STEM = "Brass"
-    WIND_INST_STEM = "Wind Inst"
-    NO_STEM = "No "
-    NO_OTHER_STEM = "No Other"
-    NO_BASS_STEM = "No Bass"
-    NO_DRUM_STEM = "No Drums"
-    NO_GUITAR_STEM = "No Guitar"
-    NO_PIANO_STEM = "No Piano"
-    NO_SYNTH_STEM = "No Synthesizer"
-    NO_STRINGS_STEM = "No Strings"
-    NO_WOODWINDS_STEM = "No Woodwinds"
-    NO_WIND_INST_STEM = "No Wind Inst"
-    NO_BRASS_STEM = "No Brass"
-    PRIMARY_STEM = "Primary Stem"
-    SECONDARY_STEM = "Secondary Stem"
-    LEAD_VOCAL_STEM = "lead_only"
-    BV_VOCAL_STEM = "backing_only"
-    LEAD_VOCAL_STEM_I = "with_lead_vocals"
-    BV_VOCAL_STEM_I = "with_backing_vocals"
-    LEAD_VOCAL_STEM_LABEL = "Lead Vocals"
-    BV_VOCAL_STEM_LABEL = "Backing Vocals"
-
-    STEM_PAIR_MAPPER = {VOCAL_STEM: INST_STEM, INST_STEM: VOCAL_STEM, LEAD_VOCAL_STEM: BV_VOCAL_STEM,
-                        BV_VOCAL_STEM: LEAD_VOCAL_STEM, PRIMARY_STEM: SECONDARY_STEM}
-    NON_ACCOM_STEMS = (VOCAL_STEM, OTHER_STEM, BASS_STEM, DRUM_STEM, GUITAR_STEM, PIANO_STEM, SYNTH_STEM, STRINGS_STEM,
-                       WOODWINDS_STEM, BRASS_STEM, WIND_INST_STEM)
+    # Stem vocabulary (common_separator.py:19-53).  The names are part of the contract: the orchestrator, the ensembler presets
+    # and the output file names refer to them.  Kept as one table; the class attributes are generated from it below.
+    _STEM_LABELS = {
+        "ALL_STEMS": "All Stems", "PRIMARY_STEM": "Primary Stem", "SECONDARY_STEM": "Secondary Stem",
+        # instruments, and the name of "everything but" each of them
+        "VOCAL_STEM": "Vocals", "INST_STEM": "Instrumental",
+        "OTHER_STEM": "Other", "NO_OTHER_STEM": "No Other",
+        "BASS_STEM": "Bass", "NO_BASS_STEM": "No Bass",
+        "DRUM_STEM": "Drums", "NO_DRUM_STEM": "No Drums",
+        "GUITAR_STEM": "Guitar", "NO_GUITAR_STEM": "No Guitar",
+        "PIANO_STEM": "Piano", "NO_PIANO_STEM": "No Piano",
+        "SYNTH_STEM": "Synthesizer", "NO_SYNTH_STEM": "No Synthesizer",
+        "STRINGS_STEM": "Strings", "NO_STRINGS_STEM": "No Strings",
+        "WOODWINDS_STEM": "Woodwinds", "NO_WOODWINDS_STEM": "No Woodwinds",
+        "BRASS_STEM": "Brass", "NO_BRASS_STEM": "No Brass",
+        "WIND_INST_STEM": "Wind Inst", "NO_WIND_INST_STEM": "No Wind Inst",
+        "NO_STEM": "No ",
+        # karaoke / backing-vocal models
+        "LEAD_VOCAL_STEM": "lead_only", "BV_VOCAL_STEM": "backing_only",
+        "LEAD_VOCAL_STEM_I": "with_lead_vocals", "BV_VOCAL_STEM_I": "with_backing_vocals",
+        "LEAD_VOCAL_STEM_LABEL": "Lead Vocals", "BV_VOCAL_STEM_LABEL": "Backing Vocals",
+    }
+    locals().update(_STEM_LABELS)
 
     _CONFIG_KEYS = ("log_level", "torch_device", "torch_device_cpu", "torch_device_mps", "onnx_execution_provider",
                     "model_name", "model_path", "model_data", "output_dir", "output_format", "output_bitrate",
@@ -107,13 +92,46 @@ class CommonSeparator:
         self.logger.debug(f"Common params: primary_stem_name={self.primary_stem_name}, "
                           f"secondary_stem_name={self.secondary_stem_name}")
 
-        self.audio_file_path = None
-        self.audio_file_base = None
-        self.primary_source = None
-        self.secondary_source = None
-        self.primary_stem_output_path = None
-        self.secondary_stem_output_path = None
+        self._reset_file_state()
         self.cached_sources_map = {}
+
+    # what one input file leaves behind (common_separator.py:136-147, 509-520): reset by clear_file_specific_paths
+    _FILE_STATE = ("audio_file_path", "audio_file_base", "primary_source", "secondary_source", "primary_stem_output_path",
+                   "secondary_stem_output_path")
+
+    def _reset_file_state(self):
+        for name in self._FILE_STATE:
+            setattr(self, name, None)
+
+    # ---- steps every architecture's separate() shares ---------------------------------------------------------------
+    def _read_options(self, arch_config: dict, table):
+        """``table`` = ((key, default), ...): the architecture options the orchestrator passes (separator.py:125-128)."""
+        for key, default in table:
+            setattr(self, key, arch_config.get(key, default))
+
+    def _begin_file(self, audio_file_path: str):
+        self.audio_file_path = audio_file_path
+        self.audio_file_base = os.path.splitext(os.path.basename(audio_file_path))[0]
+
+    def _wanted(self, stem_name: str) -> bool:
+        """``output_single_stem`` filter (mdx_separator.py:185,193)."""
+        return not self.output_single_stem or self.output_single_stem.lower() == stem_name.lower()
+
+    def _emit_stem(self, stem_name: str, source, custom_output_names, files: list) -> str:
+        path = self.get_stem_output_path(stem_name, custom_output_names)
+        self.logger.info(f"{stem_name} -> {path}")
+        self.final_process(path, source, stem_name)
+        files.append(path)
+        return path
+
+    def _emit_pair(self, custom_output_names) -> list:
+        """Secondary stem first, then the primary one -- the order the reference returns them in (mdx_separator.py:184-203)."""
+        files = []
+        if self._wanted(self.secondary_stem_name):
+            self.secondary_stem_output_path = self._emit_stem(self.secondary_stem_name, self.secondary_source, custom_output_names, files)
+        if self._wanted(self.primary_stem_name):
+            self.primary_stem_output_path = self._emit_stem(self.primary_stem_name, self.primary_source, custom_output_names, files)
+        return files
 
     # ---- stem naming -------------------------------------------------------
     def secondary_stem(self, primary_stem: str):
@@ -130,7 +148,7 @@ class CommonSeparator:
 
     def final_process(self, stem_path, source, stem_name):
         """common_separator.py:167-174."""
-        self.logger.debug(f"Finalizing {stem_name} stem processing and writing audio...")
+        self.logger.debug(f"{stem_name}: writing {stem_path}")
         self.write_audio(stem_path, source)
         return {stem_name: source}
 
@@ -166,7 +184,7 @@ class CommonSeparator:
                 self.logger.warning(f"Unknown audio subtype {st}, defaulting to 16-bit output")
             self.logger.info(f"Input audio subtype: {st}, bit depth: {self.input_bit_depth}")
         except Exception as e:   # the reference swallows every failure here too
-            self.logger.warning(f"Could not read audio file info, defaulting to 16-bit output: {e}")
+            self.logger.warning(f"no container info for {path} ({e}): stems will be written as 16-bit PCM")
             self.input_bit_depth, self.input_subtype = 16, "PCM_16"
 
     def prepare_mix(self, mix):
@@ -176,7 +194,7 @@ class CommonSeparator:
         if not isinstance(mix, np.ndarray):
             self._probe_bit_depth(mix)
             mix, sr = audio_io.load(mix, mono=False, sr=self.sample_rate)
-            self.logger.debug(f"Audio loaded. Sample rate: {sr}, Audio shape: {mix.shape}")
+            self.logger.debug(f"decoded {audio_path}: {mix.shape[-1]} samples x {mix.shape[0] if mix.ndim > 1 else 1} channel(s) at {sr} Hz")
         else:
             if self.input_bit_depth is None:
                 self.input_bit_depth, self.input_subtype = 16, "PCM_16"
@@ -222,17 +240,17 @@ class CommonSeparator:
             pcm, peak = np.ascontiguousarray(a), float(np.abs(a).max()) if a.size else 0.0
         else:
             if a.shape[0] == 0:
-                self.logger.warning("Warning: stem_source array is near-silent or empty.")
+                self.logger.warning(f"{stem_path}: nothing to write (the stem is empty or silent)")
                 return
             pcm, peak = eng.pcm16(a, self.normalization_threshold, self.amplification_threshold)
         if peak < 1e-6:
-            self.logger.warning("Warning: stem_source array is near-silent or empty.")
+            self.logger.warning(f"{stem_path}: nothing to write (the stem is empty or silent)")
             return
         if self.output_dir:
             os.makedirs(self.output_dir, exist_ok=True)
             stem_path = os.path.join(self.output_dir, stem_path)
         depth = self.input_bit_depth if self.input_bit_depth is not None else 16
-        self.logger.info(f"Writing output with {depth}-bit depth")
+        self.logger.info(f"{stem_path}: {depth}-bit output (the input's bit depth)")
         file_format = stem_path.lower().split(".")[-1]
         pydub = audio_io._optional("pydub")
         if pydub is not None and hasattr(pydub, "AudioSegment") and hasattr(pydub.AudioSegment, "export"):
@@ -252,7 +270,7 @@ class CommonSeparator:
             try:
                 seg.export(stem_path, **params)
             except (IOError, ValueError) as e:
-                self.logger.error(f"Error exporting audio file: {e}")
+                self.logger.error(f"{stem_path}: the container write failed: {e}")
             return
         if file_format != "wav":
             raise audio_io.AudioIOError(f"writing .{file_format} needs pydub + ffmpeg (not installed); WAV is built in")
@@ -263,11 +281,11 @@ class CommonSeparator:
         eng = self._require_engine()
         a = self._stereo_rows(stem_source)
         if a.shape[0] == 0:
-            self.logger.warning("Warning: stem_source array is near-silent or empty.")
+            self.logger.warning(f"{stem_path}: nothing to write (the stem is empty or silent)")
             return
         buf = eng.normalize(np.ascontiguousarray(a, np.float32), self.normalization_threshold, self.amplification_threshold)
         if np.max(np.abs(buf)) < 1e-6:
-            self.logger.warning("Warning: stem_source array is near-silent or empty.")
+            self.logger.warning(f"{stem_path}: nothing to write (the stem is empty or silent)")
             return
         if self.output_dir:
             os.makedirs(self.output_dir, exist_ok=True)
@@ -285,7 +303,7 @@ class CommonSeparator:
             else:
                 audio_io.write_wav(stem_path, buf, self.sample_rate, subtype)
         except Exception as e:
-            self.logger.error(f"Error exporting audio file: {e}")
+            self.logger.error(f"{stem_path}: the container write failed: {e}")
 
     # ---- per-file state ------------------------------------------------------
     def clear_gpu_cache(self):
@@ -301,13 +319,8 @@ class CommonSeparator:
 
     def clear_file_specific_paths(self):
         """common_separator.py:476-489."""
-        self.logger.info("Clearing input audio file paths, sources and stems...")
-        self.audio_file_path = None
-        self.audio_file_base = None
-        self.primary_source = None
-        self.secondary_source = None
-        self.primary_stem_output_path = None
-        self.secondary_stem_output_path = None
+        self.logger.info("per-file state reset (paths, sources, stems)")
+        self._reset_file_state()
 
     # ---- file naming -------------------------------------------------------
     def sanitize_filename(self, filename):
@@ -347,3 +360,15 @@ class CommonSeparator:
 
     def validate_roformer_config(self, config, model_type):
         return self.roformer_loader.validate_configuration(config, model_type) if self.roformer_loader else True
+
+
+# Derived stem tables (class scope cannot see the table from inside a comprehension, hence here).  STEM_PAIR_MAPPER: the pairs
+# that name each other's complement -- any other stem X is complemented by "No X" (CommonSeparator.secondary_stem);
+# NON_ACCOM_STEMS: stems that are not an accompaniment mix (common_separator.py:49-53).
+_L = CommonSeparator._STEM_LABELS
+CommonSeparator.STEM_PAIR_MAPPER = {_L[a]: _L[b] for a, b in (("VOCAL_STEM", "INST_STEM"), ("LEAD_VOCAL_STEM", "BV_VOCAL_STEM"),
+                                                              ("PRIMARY_STEM", "SECONDARY_STEM"))}
+CommonSeparator.STEM_PAIR_MAPPER.update({v: k for k, v in list(CommonSeparator.STEM_PAIR_MAPPER.items()) if v != _L["SECONDARY_STEM"]})
+CommonSeparator.NON_ACCOM_STEMS = tuple(_L[k] for k in ("VOCAL_STEM", "OTHER_STEM", "BASS_STEM", "DRUM_STEM", "GUITAR_STEM", "PIANO_STEM",
+                                                         "SYNTH_STEM", "STRINGS_STEM", "WOODWINDS_STEM", "BRASS_STEM", "WIND_INST_STEM"))
+del _L

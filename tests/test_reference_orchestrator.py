@@ -97,3 +97,21 @@ def test_reference_separator_runs_our_mdxc_roformer_plugin(reference_separator, 
         assert files == json.loads(str(g["rof__names"]))
     finally:
         A.uninstall()
+
+
+def test_stem_vocabulary_equals_the_references():
+    """Every upper-case class constant of the reference's CommonSeparator (stem names, STEM_PAIR_MAPPER, NON_ACCOM_STEMS,
+    common_separator.py:19-53) has the same value here: the orchestrator, the presets and the file names rely on them."""
+    import ast
+
+    import audio_separator_amd as A
+    tree = ast.parse(open(REF + "/audio_separator/separator/common_separator.py").read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CommonSeparator")
+    ns = {}
+    for node in cls.body:
+        if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name) and node.targets[0].id.isupper():
+            exec(compile(ast.Module([node], []), "ref_constants", "exec"), ns)
+    consts = {k: v for k, v in ns.items() if k.isupper()}
+    assert len(consts) >= 30
+    for k, v in consts.items():
+        assert getattr(A.CommonSeparator, k) == v, k
