@@ -404,6 +404,40 @@ def test_sharded_chunks_equal_single_pass(A):
     assert torch.equal(out1, out2)
 
 
+def test_demix_dev_is_capturable_into_a_hip_graph(A):
+    """include/asx.h: once the workspace has its size, asx_demix_dev only enqueues kernels on the caller's stream -- no host copy,
+    no synchronisation -- so a whole demix can be captured into a hipGraph and replayed.  Generic FFT path (small net) and the
+    6144 / 1024 fast path (match-mix pass, no net); the replayed result equals the directly launched one bit for bit."""
+    import torch
+    cases = []
+    eng, _, _ = small_engine(A)
+    cases.append((eng, 5000, 0))
+    cases.append((A.Engine(A.MDXConfig(segment_size=40)), 90_000, 1))       # n_fft 6144 / hop 1024, ASX_FLAG_MATCH_MIX
+    for eng, N, flags in cases:
+        mix = torch.tensor((0.4 * np.random.default_rng(N).standard_normal((2, N))).astype(np.float32)).cuda()
+        direct = torch.empty_like(mix)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            eng.demix_dev(mix.data_ptr(), N, direct.data_ptr(), is_match_mix=bool(flags), stream=side.cuda_stream)   # sizes the workspace
+        torch.cuda.synchronize()
+        replayed = torch.zeros_like(mix)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            eng.demix_dev(mix.data_ptr(), N, replayed.data_ptr(), is_match_mix=bool(flags),
+                          stream=torch.cuda.current_stream().cuda_stream)
+        assert float(replayed.abs().sum()) == 0.0          # nothing ran during capture
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(direct, replayed)
+        mix.mul_(0.5)                                      # same buffers, new content: the graph is reusable
+        graph.replay()
+        torch.cuda.synchronize()
+        again = torch.empty_like(mix)
+        eng.demix_dev(mix.data_ptr(), N, again.data_ptr(), is_match_mix=bool(flags), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(again, replayed)
+
+
 # ---------------------------------------------------------------------------
 # HQ_3 geometry (the metric configuration), bounded so the CPU oracle finishes
 # ---------------------------------------------------------------------------
