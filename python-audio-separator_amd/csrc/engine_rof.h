@@ -242,15 +242,20 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
   const asx_rof_config &c = n.cfg;
   const int T = e->cfg.segment_size, Fb = c.n_bands, D = c.dim, H = c.heads, inner = H * c.dim_head;
   const int64_t M = (int64_t)B * T * Fb;
+  // The row-wise launches run over M rounded up to a multiple of 8 (the workspace holds the pad rows): the second-generation
+  // row GEMM needs M % 8 == 0, and M = B * T * bands is odd * 2 for the public layouts unless B is a multiple of 4.  Pad rows
+  // hold garbage, feed only themselves (every one of these kernels is row-independent) and are never read by the attention,
+  // the band split or the mask estimator.
+  const int64_t Mg = (M + 7) & ~(int64_t)7;
   for (auto &L : layers) {
     // attention: x = attn(x) + x
     // RMSNorm in front of qkv / gates: folded (TOK is the operand, 1 / |x| scales the rows in the epilogue) or explicit
     const float *ain = n.TOK.f(), *ars = nullptr;
     if (L.attn.norm_folded) {
-      CHK(rof_rownorm(e, n.TOK.f(), D, D, n.RS.f(), M, s));
+      CHK(rof_rownorm(e, n.TOK.f(), D, D, n.RS.f(), Mg, s));
       ars = n.RS.f();
     } else {
-      CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.attn.norm_g.f(), n.XN.f(), D, M, s));
+      CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.attn.norm_g.f(), n.XN.f(), D, Mg, s));
       ain = n.XN.f();
     }
     // rotary on q and k: in the projection's epilogue (default), or as a separate in-place pass (ASX_ROF_FUSE=0)
@@ -263,7 +268,7 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
       rr.pos_div = time_axis ? Fb : 1;
       rr.pos_mod = time_axis ? T : Fb;
     }
-    CHK(rof_gemm(e, L.attn.qkv, ain, D, M, n.QKV.f(), 3 * inner, 0, nullptr, 0, s, &rr, ars));
+    CHK(rof_gemm(e, L.attn.qkv, ain, D, Mg, n.QKV.f(), 3 * inner, 0, nullptr, 0, s, &rr, ars));
     if (!rr.tab) {
       const int64_t tot = M * 2 * H * (c.dim_head / 2);
       const int64_t pos_div = time_axis ? Fb : 1;
@@ -279,7 +284,7 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
       const int gl = (H + 3) / 4 * 4;
       RofLin &G = L.attn.gates;
       if (H % 4 == 0) {
-        CHK(rof_gemm(e, G, ain, D, M, n.GATE.f(), gl, 0, nullptr, 0, s, nullptr, ars));
+        CHK(rof_gemm(e, G, ain, D, Mg, n.GATE.f(), gl, 0, nullptr, 0, s, nullptr, ars));
       } else {
         // tiny head counts (tests): scalar epilogue through the generic register-staged kernel
         TdfArgs a{};
@@ -334,20 +339,20 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
         else hipLaunchKernelGGL(attention2_kernel<1>, dim3(qtiles, H, (unsigned)nseq), dim3(256), 0, s, aa);
       }));
     }
-    CHK(rof_gemm(e, L.attn.out, n.ATT.f(), inner, M, n.TOK.f(), D, 0, n.TOK.f(), D, s));   // + x (in place: each
+    CHK(rof_gemm(e, L.attn.out, n.ATT.f(), inner, Mg, n.TOK.f(), D, 0, n.TOK.f(), D, s));   // + x (in place: each
     // output element depends only on ATT and on the same TOK element it overwrites)
     // feed-forward: x = ff(x) + x
     if (L.ff.norm_folded) {
-      CHK(rof_rownorm(e, n.TOK.f(), D, D, n.RS.f(), M, s));
-      CHK(rof_gemm(e, L.ff.l1, n.TOK.f(), D, M, n.FFH.f(), 4 * D, 2, nullptr, 0, s, nullptr, n.RS.f()));   // GELU
+      CHK(rof_rownorm(e, n.TOK.f(), D, D, n.RS.f(), Mg, s));
+      CHK(rof_gemm(e, L.ff.l1, n.TOK.f(), D, Mg, n.FFH.f(), 4 * D, 2, nullptr, 0, s, nullptr, n.RS.f()));   // GELU
     } else {
-      CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.ff.norm_g.f(), n.XN.f(), D, M, s));
-      CHK(rof_gemm(e, L.ff.l1, n.XN.f(), D, M, n.FFH.f(), 4 * D, 2, nullptr, 0, s));          // GELU
+      CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.ff.norm_g.f(), n.XN.f(), D, Mg, s));
+      CHK(rof_gemm(e, L.ff.l1, n.XN.f(), D, Mg, n.FFH.f(), 4 * D, 2, nullptr, 0, s));          // GELU
     }
-    CHK(rof_gemm(e, L.ff.l2, n.FFH.f(), 4 * D, M, n.TOK.f(), D, 0, n.TOK.f(), D, s));
+    CHK(rof_gemm(e, L.ff.l2, n.FFH.f(), 4 * D, Mg, n.TOK.f(), D, 0, n.TOK.f(), D, s));
   }
   // MelBandRoformer: Transformer(norm_output=True) (mel_band_roformer.py:111,120); in place (a row is read, then written)
-  if (out_norm) CHK(rof_rmsnorm(e, n.TOK.f(), D, D, out_norm->f(), n.TOK.f(), D, M, s));
+  if (out_norm) CHK(rof_rmsnorm(e, n.TOK.f(), D, D, out_norm->f(), n.TOK.f(), D, Mg, s));
   return ASX_OK;
 }
 
@@ -356,7 +361,7 @@ static int rof_ensure_workspace(asx_engine *e, int B) {
   if (B <= n.ws_batch) return ASX_OK;
   const asx_rof_config &c = n.cfg;
   const int T = e->cfg.segment_size, Fb = c.n_bands, D = c.dim, inner = c.heads * c.dim_head;
-  const size_t M = (size_t)B * T * Fb, BT = (size_t)B * T;
+  const size_t M = (((size_t)B * T * Fb) + 7) & ~(size_t)7, BT = (size_t)B * T;   // token rows, padded to a multiple of 8 (rof_transformer)
   const int hid = D * (c.mel ? 4 : c.mlp_expansion_factor);
   int maxd = 0;
   for (int d : n.band_dim) maxd = std::max(maxd, d);
