@@ -33,8 +33,18 @@ def test_abi_version(lib):
     assert lib.asx_abi_version() == 3
 
 
+def test_binding_refuses_a_library_of_another_abi(monkeypatch):
+    """A stale libasx.so (other struct layouts) must not be driven silently: the loader compares asx_abi_version() with the
+    version its ctypes structures mirror."""
+    monkeypatch.setattr(E, "_lib", None)
+    monkeypatch.setattr(E, "ABI_VERSION", E.ABI_VERSION + 1)
+    with pytest.raises(E.AsxError, match="ABI"):
+        E.load_library()
+    monkeypatch.setattr(E, "_lib", None)          # the next user reloads with the real version
+
+
 def test_struct_sizes_match_header():
-    # 7 x 4 bytes, 9 x 4 bytes, 6 x 8 + 4 x 4 bytes, 10 x (8 + 8 + 8 + 8)
+    # 8 x 4 bytes + one double, 9 x 4 bytes, 6 x 8 + 4 x 4 bytes, 10 x (8 + 8 + 8 + 8)
     import ctypes as C
     assert C.sizeof(E._MdxCfg) == 40
     assert C.sizeof(E._NetCfg) == 36
