@@ -250,7 +250,7 @@ def load_library():
     vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
     lib.asx_abi_version.restype = C.c_int
     if lib.asx_abi_version() != ABI_VERSION:
-        raise AsxError(f"{path} speaks ABI {lib.asx_abi_version()}, this binding ABI {ABI_VERSION}: rebuild (python build.py)")
+        raise AsxError(f"{path} speaks ABI {lib.asx_abi_version()}, this binding ABI {ABI_VERSION}: rebuild (python __graft_entry__.py)")
     lib.asx_last_error.restype = C.c_char_p
     lib.asx_device_count.restype = C.c_int
     lib.asx_engine_create.argtypes = [C.c_int, C.POINTER(_MdxCfg), C.POINTER(vp)]
