@@ -85,10 +85,15 @@ def parse_args(argv=None):
     ap.add_argument("--seconds", type=float, default=SONG_SECONDS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--siblings", type=int, default=1, help="1: append short htdemucs / BS-Roformer / VR / hdemucs lines (N = 1 only)")
+    ap.add_argument("--file-level", type=int, default=1, help="1: time Separator-level separate(wav) -> stem files after the timed region (N = 1 only)")
     ap.add_argument("--no-overlap", action="store_true", help="blocking gather (A/B of the gather / compute overlap)")
+    ap.add_argument("--config5", action="store_true", help="BASELINE config 5 preset: --mode files --songs-per-rank 8 (64 songs on 8 GPUs)")
     ap.add_argument("--dry-gloo", action="store_true")
     ap.add_argument("--master-port", type=int, default=0)
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.config5:
+        args.mode, args.songs_per_rank = "files", 8
+    return args
 
 
 def free_port():
@@ -161,37 +166,21 @@ def main():
     plan = eng.plan(N)
     if args.mode == "files":
         # resident in HBM before timing: S songs per rank, seeds rank * S + s (64 distinct songs at 8 x 8)
+        from audio_separator_amd.sharding import FilesPipeline
         mixes = [torch.from_numpy(O.synth_mix(N, seed=rank * S + s)).to(dev) for s in range(S)]
-        outs = [torch.empty((S, 2, N), dtype=torch.float32, device=dev) for _ in range(2)]
-        gathered = [[torch.empty_like(outs[0]) for _ in range(world)] for _ in range(2)] if (use_dist and rank == 0) else [None, None]
-        pending = [None, None]
-
-        def step(k):
-            b = k & 1
-            if pending[b] is not None:
-                pending[b].wait()                 # the stems buffer is free again once its gather has drained
-                pending[b] = None
-            for s in range(S):
-                eng.demix_dev(mixes[s].data_ptr(), N, outs[b][s].data_ptr(), stream=stream)
-            if use_dist:
-                if args.no_overlap:
-                    dist.gather(outs[b], gathered[b], dst=0)
-                else:
-                    pending[b] = dist.gather(outs[b], gathered[b], dst=0, async_op=True)
-
-        def drain():
-            for b in (0, 1):
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
+        pipe = FilesPipeline(lambda m, o: eng.demix_dev(m.data_ptr(), N, o.data_ptr(), stream=stream), mixes, world, rank, use_dist,
+                             overlap=not args.no_overlap)
+        step, drain = pipe.step, pipe.drain
         songs_per_step = world * S
         scaling = "weak"
     else:
+        from audio_separator_amd.sharding import ShardWorkspace
         mix = torch.from_numpy(O.synth_mix(N, seed=0)).to(dev)           # the same song on every rank
         adapter = HipEngineAdapter(eng)
+        shard_ws = ShardWorkspace()          # local / slab / out allocated once: the loop times compute + gather + fold
 
         def step(k):
-            sharded_demix(adapter, mix)
+            sharded_demix(adapter, mix, workspace=shard_ws)
 
         def drain():
             pass
@@ -218,6 +207,35 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = songs_per_step * args.seconds * args.steps / dt
+
+    # ---- what the exchange costs, outside the timed region (so that a sub-linear N > 1 result can be attributed) ----
+    comm = {"gather_bytes_per_step": 0, "gather_ms": None, "fold_ms": None}
+    if args.mode == "files":
+        comm["gather_bytes_per_step"] = pipe.gather_bytes_per_step
+        if use_dist:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            dist.barrier()
+            torch.cuda.synchronize()
+            ev[0].record()
+            for _ in range(3):
+                dist.gather(pipe.outs[0], pipe.gathered[0], dst=0)          # blocking: ordered with the current stream
+            ev[1].record()
+            torch.cuda.synchronize()
+            comm["gather_ms"] = round(ev[0].elapsed_time(ev[1]) / 3, 3)
+            comm["gather_ms_note"] = "one blocking dist.gather of a step's stems, hipEvents on the current stream, mean of 3; in the timed loop it overlaps the next step"
+    else:
+        shard_ws.timed = True
+        sharded_demix(adapter, mix, workspace=shard_ws)
+        shard_ws.timed = False
+        if shard_ws.timings:
+            comm["gather_ms"] = round(shard_ws.timings["gather_ms"], 3)
+            comm["fold_ms"] = round(shard_ws.timings["fold_ms"], 3)
+            comm["compute_ms"] = round(shard_ws.timings["compute_ms"], 3)
+        cs = plan["chunk_size"]
+        per = -(-plan["n_chunks"] // world)
+        comm["gather_bytes_per_step"] = per * 2 * cs * 4 * (world - 1)
+        if use_dist:
+            dist.barrier()
 
     # ---- roofline of the dominant kernel (3x3 TFC conv, MFMA bound), HIP events on the launch stream ----
     roofline = None
@@ -270,13 +288,16 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "UVR-MDX-NET-Inst_HQ_3 geometry (n_fft 6144, hop 1024, dim_f 3072, segment 256, "
                                    "overlap 0.25; ConvTDFNet g48 l3 11 blocks bn8, synthetic weights), "
-                                   f"{args.seconds:g}-s 44.1 kHz stereo song(s), input resident in HBM",
+                                   f"{args.seconds:g}-s 44.1 kHz stereo song(s), input resident in HBM"
+                                   + (f"; BASELINE config 5 preset: batch of {songs_per_step} songs sharded across {world} GPU(s) with one RCCL gather per step"
+                                      if args.config5 else ""),
                        "mode": args.mode, "samples_per_song": N, "chunks_per_song": plan["n_chunks"],
                        "songs_per_step": songs_per_step, "parallelism": par,
                        "samples_per_s": round(value * SR * 2, 1),
                        "net_tflops_per_s": round(eng.net_flops(plan["n_chunks"]) * songs_per_step * args.steps / dt / 1e12, 2)},
-            "rccl": {"world_size": dist.get_world_size() if use_dist else 1, "backend": dist.get_backend() if use_dist else None,
-                     "launcher": "self" if os.environ.get("ASX_BENCH_LAUNCHED") == "1" else ("external" if "WORLD_SIZE" in os.environ else None)},
+            "rccl": dict({"world_size": dist.get_world_size() if use_dist else 1, "backend": dist.get_backend() if use_dist else None,
+                          "launcher": "self" if os.environ.get("ASX_BENCH_LAUNCHED") == "1" else ("external" if "WORLD_SIZE" in os.environ else None)},
+                         **comm),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if parity is not None:
@@ -298,13 +319,89 @@ def main():
                     stages[k] = {"bound": "hbm", "achieved": round(gb, 1), "unit": "GB/s", "frac": round(gb / 8000.0, 4),
                                  "frac_vs_copy": round(gb / 6290.0, 4)}
             res["stage_roofline"] = stages
-        if world == 1 and args.siblings:
+        if world == 1 and (args.siblings or args.file_level):
             eng.close()
+        if world == 1 and args.file_level:
+            try:
+                res["file_level"] = file_level_line(args, sd)
+            except Exception as e:                  # never take the headline line down
+                res["file_level"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and args.siblings:
             res["siblings"] = sibling_lines(args)
         emit(res)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def file_level_line(args, sd):
+    """File-to-files rate of the plugin surface (SURVEY.md 8d "separately reported"; the reference logs it at separator.py:1016,
+    1043): ``MDXSeparator.separate(song.wav)`` -> two PCM16 stem files, through ``install()``'s class, on a 4-minute PCM16 WAV
+    in tmpfs.  Wall clock of whole calls (after one warm-up call), with the per-phase breakdown the class records when
+    ``asx_profile_file`` is set (each phase fenced by a stream synchronise, so the phases sum to the wall time), and the same
+    call with the device-resident path switched off (ASX_FILE_FASTPATH=0: host decode, host stems, re-upload for int16) as
+    the A/B.  Not part of `value`."""
+    import logging
+    import shutil
+    import tempfile
+    import audio_separator_amd as A
+    from audio_separator_amd import audio_io
+    from audio_separator_amd.architectures.mdx_separator import MDXSeparator
+    from oracle import mdx_oracle as O
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="asx_file_level_", dir=base)
+    try:
+        n = int(SR * args.seconds)
+        mix = O.synth_mix(n, seed=0)
+        wav = os.path.join(tmp, "song.wav")
+        audio_io.write_wav(wav, np.ascontiguousarray(mix.T), SR, "PCM_16")
+        log = logging.getLogger("bench.file_level")
+        log.setLevel(logging.ERROR)
+        common = {"logger": log, "log_level": logging.ERROR, "torch_device": "cuda:0", "torch_device_cpu": "cpu", "torch_device_mps": None,
+                  "onnx_execution_provider": ["ROCMExecutionProvider"], "model_name": "UVR-MDX-NET-Inst_HQ_3", "model_path": None,
+                  "model_data": {"compensate": 1.022, "mdx_dim_f_set": 3072, "mdx_dim_t_set": 8, "mdx_n_fft_scale_set": 6144,
+                                 "primary_stem": "Instrumental"},
+                  "output_format": "WAV", "output_bitrate": None, "output_dir": os.path.join(tmp, "out"),
+                  "normalization_threshold": 0.9, "amplification_threshold": 0.0, "output_single_stem": None, "invert_using_spec": False,
+                  "sample_rate": SR, "use_soundfile": False, "asx_state_dict": sd, "asx_net_config": A.NetConfig(), "asx_profile_file": True}
+        arch = {"hop_length": 1024, "segment_size": 256, "overlap": 0.25, "batch_size": 1, "enable_denoise": False}
+        sep = MDXSeparator(common, arch)
+
+        def run(calls):
+            walls, phases = [], {}
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                files = sep.separate(wav)
+                walls.append(time.perf_counter() - t0)
+                for k, v in sep.file_timings.items():
+                    phases[k] = phases.get(k, 0.0) + v
+                sep.clear_gpu_cache()
+                sep.clear_file_specific_paths()
+            return files, walls, {k: v / calls for k, v in phases.items()}
+
+        run(1)                                              # warm-up: workspaces, pinned staging, page cache
+        files, walls, phases = run(3)
+        wall = sum(walls) / len(walls)
+        sizes = [os.path.getsize(os.path.join(common["output_dir"], f)) for f in files]
+        os.environ["ASX_FILE_FASTPATH"] = "0"
+        try:
+            run(1)
+            _, walls_h, _ = run(2)
+        finally:
+            os.environ.pop("ASX_FILE_FASTPATH", None)
+        wall_h = sum(walls_h) / len(walls_h)
+        sep.engine.close()
+        ph = {k: round(v * 1e3, 2) for k, v in phases.items()}
+        return {"what": "MDXSeparator.separate(4-min PCM16 WAV on tmpfs) -> 2 PCM16 stem files (Instrumental, Vocals), plugin class of install()",
+                "rtf": round(args.seconds / wall, 1), "wall_ms": round(wall * 1e3, 2), "calls": len(walls),
+                "phases_ms": ph, "phases_sum_ms": round(sum(ph.values()), 2),
+                "unaccounted_ms": round(wall * 1e3 - sum(ph.values()), 2),
+                "files": files, "file_bytes": sizes,
+                "host_path": {"what": "same call with ASX_FILE_FASTPATH=0 (round-2 path: host decode, float stems to the host, "
+                                      "re-upload per stem for the int16 pass)",
+                              "rtf": round(args.seconds / wall_h, 1), "wall_ms": round(wall_h * 1e3, 2)}}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def sibling_lines(args):
@@ -330,9 +427,12 @@ def sibling_lines(args):
 
 
 def dry_run(args, world, rank):
-    """Launcher / rendezvous / collective plumbing on CPU (gloo); no GPU, no engine, no rate."""
+    """Launcher / rendezvous / collective plumbing on CPU (gloo), through the SAME FilesPipeline (double-buffered stems, one
+    asynchronous gather per step, buffer reuse only after its gather completed) as the GPU run; the engine is a stand-in
+    whose output encodes (rank, song, step), and rank 0 checks that every gathered buffer holds exactly its step's data."""
     import torch
     import torch.distributed as dist
+    from audio_separator_amd.sharding import FilesPipeline
     use_dist = world > 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -340,23 +440,42 @@ def dry_run(args, world, rank):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     n = 4096
     S = args.songs_per_rank
-    mixes = torch.full((S, 2, n), float(rank))
-    gathered = [torch.empty_like(mixes) for _ in range(world)] if rank == 0 else None
-    for _ in range(args.warmup + args.steps):
-        out = mixes.clone()
-        if use_dist:
-            dist.gather(out, gathered, dst=0)
+    mixes = [torch.full((2, n), float(100 * rank + s)) for s in range(S)]
+    calls = [0]
+
+    def demix(mix, out):                      # stand-in hot path: out = mix + 10000 * (step + 1); S calls per step
+        step = calls[0] // S
+        calls[0] += 1
+        out.copy_(mix).add_(10000.0 * (step + 1))
+
+    seen, bad = [], []
+
+    def on_gathered(step, slabs):
+        seen.append(step)
+        for r, slab in enumerate(slabs):
+            for s in range(S):
+                want = 100.0 * r + s + 10000.0 * (step + 1)
+                if not bool((slab[s] == want).all()):
+                    bad.append((step, r, s, float(slab[s].flatten()[0]), want))
+
+    pipe = FilesPipeline(demix, mixes, world, rank, use_dist, overlap=not args.no_overlap, on_gathered=on_gathered)
+    total = args.warmup + args.steps
+    for k in range(total):
+        pipe.step(k)
+    pipe.drain()
     ok = True
     if use_dist:
         dist.barrier()
         if rank == 0:
-            ok = all(float(g[0, 0, 0]) == float(r) for r, g in enumerate(gathered))
+            ok = not bad and seen == list(range(total))
     if rank == 0:
         emit({"metric": METRIC, "value": None, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "dry": True, "mode": args.mode, "gather_ok": ok,
+                          "gathers_checked": len(seen), "gather_mismatches": bad[:4],
                           "rccl": {"world_size": dist.get_world_size() if use_dist else 1, "backend": "gloo" if use_dist else None,
                                    "launcher": "self" if os.environ.get("ASX_BENCH_LAUNCHED") == "1" else
-                                   ("external" if "WORLD_SIZE" in os.environ else None)}})
+                                   ("external" if "WORLD_SIZE" in os.environ else None),
+                                   "gather_bytes_per_step": pipe.gather_bytes_per_step}})
     if use_dist:
         dist.destroy_process_group()
 

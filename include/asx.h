@@ -44,7 +44,7 @@ extern "C" {
 #define ASX_ERR_HIP 2     /* a HIP runtime call failed (no GPU, OOM, launch) */
 #define ASX_ERR_STATE 3   /* call order violated (e.g. demix before commit)  */
 
-#define ASX_ABI_VERSION 3
+#define ASX_ABI_VERSION 4
 
 /* flags of asx_demix*(): */
 #define ASX_FLAG_MATCH_MIX 1u /* demix(mix, is_match_mix=True): overlap 0.02, no net (mdx_separator.py:308-313, :429-432) */
@@ -399,6 +399,20 @@ int asx_pcm16(asx_engine *e, const float *stem_host, int64_t n_samples, float ma
               int16_t *pcm_host, float *peak_after);
 int asx_pcm16_dev(asx_engine *e, const float *stem_dev, int64_t n_samples, float max_peak, float min_peak, int32_t has_min,
                   int16_t *pcm_dev, float *peak_after, void *stream);
+
+/* The same edge for a stem that is ALREADY [N, 2] interleaved on the device -- the layout asx_separate_dev writes and
+ * write_audio receives (common_separator.py:330-337) -- so that a file-level caller never brings the float stem to the host:
+ * stem_rows [N, 2] -> pcm [N, 2]; bit-identical to asx_pcm16 on the transposed array.  (ABI 4) */
+int asx_pcm16_rows_dev(asx_engine *e, const float *stem_rows_dev, int64_t n_samples, float max_peak, float min_peak, int32_t has_min,
+                       int16_t *pcm_dev, float *peak_after, void *stream);
+
+/* Decode edge (common_separator.py:217-282 prepare_mix -> librosa.load -> libsndfile): the `data` chunk of a RIFF/WAVE file,
+ * [frames, channels] interleaved little-endian samples already copied to the device, -> float32 planar mix [2, frames]
+ * (a mono file feeds both rows, :278-280; channels beyond the second are ignored).  sample_format: 16 / 24 / 32 = integer
+ * PCM bits (x / 2^(bits-1), PCM_32 through double like libsndfile), 0x120 = IEEE float32.  *peak (optional, synchronises)
+ * = max |mix|: prepare_mix raises on a silent file (:268-271).  (ABI 4) */
+int asx_pcm_decode_dev(asx_engine *e, const void *raw_dev, int64_t frames, int32_t channels, int32_t sample_format, float *mix_dev,
+                       float *peak, void *stream);
 
 /* spec_utils.normalize(wave, max_peak, min_peak) (uvr_lib_v5/spec_utils.py:99-115) in place on any float32 array of
  * `numel` values (MDXCSeparator.separate applies it to the mix and to every stem, mdxc_separator.py:147,170-190);

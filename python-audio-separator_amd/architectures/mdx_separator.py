@@ -83,9 +83,38 @@ class MDXSeparator(CommonSeparator):
         """mdx_separator.py:414-450."""
         return self._dm.run_model(mix, is_match_mix=is_match_mix)
 
+    def _separate_on_device(self, custom_output_names):
+        """The same steps with every array in HBM (RIFF/WAVE input at the model's rate): data chunk -> pinned -> device ->
+        asx_pcm_decode_dev -> asx_separate_dev -> [host mirrors of the float stems, pinned, for ``primary_source`` /
+        ``secondary_source``] -> asx_pcm16_rows_dev per written stem -> int16 back -> container.  The float stems are never
+        uploaded again.  Returns None when the file needs the host decoder (the caller continues on the generic path)."""
+        mix = self._device_mix(self.audio_file_path)
+        if mix is None:
+            return None
+        import torch
+        t0 = self._now()
+        self.initialize_model_settings()
+        n = mix.shape[1]
+        primary = torch.empty((n, 2), dtype=torch.float32, device=mix.device)
+        secondary = torch.empty((n, 2), dtype=torch.float32, device=mix.device)
+        self.engine.separate_dev(mix.data_ptr(), n, self.normalization_threshold, self.amplification_threshold, self.compensate,
+                                 primary.data_ptr(), secondary.data_ptr(), stream=self._stream())
+        t0 = self._tick("demix", t0)
+        if not isinstance(self.primary_source, np.ndarray):
+            self.primary_source = self._host_stem(primary)
+        if not isinstance(self.secondary_source, np.ndarray):
+            self.secondary_source = self._host_stem(secondary)
+        self._sync()                     # the host mirrors are complete before anyone can read primary_source / secondary_source
+        self._tick("stems_d2h", t0)
+        return self._emit_pair(custom_output_names)
+
     def separate(self, audio_file_path, custom_output_names=None):
         """mdx_separator.py:135-203."""
         self._begin_file(audio_file_path)
+        if not self.invert_using_spec:
+            files = self._separate_on_device(custom_output_names)
+            if files is not None:
+                return files
         mix = self.prepare_mix(self.audio_file_path)
         if mix.shape[0] != 2:
             msg = f"Expected a 2-channel audio signal, but got {mix.shape[0]} channels"

@@ -109,7 +109,9 @@ class VRSeparator(CommonSeparator):
         except Exception as e:
             self.logger.warning(f"{audio_file_path}: no container info ({e}); stems will be written as PCM_16")
             self.wav_subtype, self.input_audio_subtype, self.input_bit_depth = "PCM_16", None, 16
-        self.input_subtype = self.input_audio_subtype
+        # the reference's VR path never goes through prepare_mix, so input_subtype stays None and the soundfile writer picks
+        # PCM_16 / 24 / 32 from input_bit_depth (common_separator.py:390-402); keep that
+        self.input_subtype = None
 
         dm = self.load_model()
         bands = self.model_params["band"]

@@ -110,12 +110,16 @@ def write_wav(path: str, data: np.ndarray, samplerate: int, subtype: str = "PCM_
         bits = {"PCM_16": 16, "PCM_24": 24, "PCM_32": 32}.get(subtype)
         if bits is None:
             raise AudioIOError(f"unsupported WAV subtype {subtype}")
-        if a.dtype == np.int16:
-            v = a.astype(np.int64) << (bits - 16)
+        if a.dtype == np.int16 and bits == 16:
+            v = None                                   # already the file's sample format: no widening pass
+        elif a.dtype == np.int16:
+            v = a.astype(np.int32) << (bits - 16)
         else:
             full = float(2 ** (bits - 1) - 1)
             v = np.clip(np.rint(a.astype(np.float64) * full), -full - 1, full).astype(np.int64)
-        if bits == 16:
+        if v is None:
+            body = memoryview(np.ascontiguousarray(a.astype("<i2", copy=False))).cast("B")
+        elif bits == 16:
             body = v.astype("<i2").tobytes()
         elif bits == 32:
             body = v.astype("<i4").tobytes()

@@ -58,6 +58,8 @@ class CommonSeparator:
         if self.model_data is None:
             self.model_data = {}
         self.engine = None                       # the libasx.so handle; set by the architecture subclass
+        self.asx_profile_file = bool(config.get("asx_profile_file"))   # per-phase wall times of separate() in file_timings
+        self.file_timings = {}
 
         self.roformer_loader = None
         self.is_roformer_model = self._detect_roformer_model()
@@ -102,6 +104,8 @@ class CommonSeparator:
     def _reset_file_state(self):
         for name in self._FILE_STATE:
             setattr(self, name, None)
+        self._dev_stems = {}          # id(host array) -> (host array, device tensor [N, 2]): stems that never left HBM
+        self._file_seconds = None     # duration of the current input, probed once per file
 
     # ---- steps every architecture's separate() shares ---------------------------------------------------------------
     def _read_options(self, arch_config: dict, table):
@@ -112,6 +116,101 @@ class CommonSeparator:
     def _begin_file(self, audio_file_path: str):
         self.audio_file_path = audio_file_path
         self.audio_file_base = os.path.splitext(os.path.basename(audio_file_path))[0]
+        self._dev_stems = {}
+        self._file_seconds = None
+        self.file_timings = {}        # seconds per phase of this file when ``asx_profile_file`` is set (bench.py file_level)
+
+    # ---- device-resident file path (load / normalise / write edges without host round trips) -----------------
+    def _tick(self, phase: str, t0: float) -> float:
+        """Accumulate wall time of ``phase`` since ``t0`` (device drained first) when per-file profiling is on."""
+        if not getattr(self, "asx_profile_file", False):
+            return t0
+        import time
+        self._sync()
+        t1 = time.perf_counter()
+        self.file_timings[phase] = self.file_timings.get(phase, 0.0) + (t1 - t0)
+        return t1
+
+    def _now(self) -> float:
+        import time
+        return time.perf_counter()
+
+    def _torch_device(self):
+        import torch
+        return torch.device("cuda", self.engine.device)
+
+    def _stream(self) -> int:
+        import torch
+        return torch.cuda.current_stream(self._torch_device()).cuda_stream
+
+    def _sync(self):
+        import torch
+        if self.engine is not None and torch.cuda.is_available():
+            torch.cuda.current_stream(self._torch_device()).synchronize()
+
+    def _fast_file_path_enabled(self) -> bool:
+        if self.engine is None or os.environ.get("ASX_FILE_FASTPATH", "1") == "0" or not hasattr(self.engine, "pcm_decode_dev"):
+            return False
+        try:
+            import torch
+            return torch.cuda.is_available()      # torch is the allocator of the pinned / device staging buffers
+        except Exception:
+            return False
+
+    def _device_mix(self, path):
+        """prepare_mix for a RIFF/WAVE file at the model's rate WITHOUT a host float array: the data chunk is read into pinned
+        memory, copied to HBM once and converted to the planar float32 mix [2, N] on the device (asx_pcm_decode_dev: the same
+        x / 2^(bits-1) conversion libsndfile applies under librosa.load, common_separator.py:252).  Returns a CUDA tensor, or
+        None when the file needs the host decoder (other container, other rate, exotic subtype) -- the caller then takes
+        prepare_mix.  Raises the reference's ValueError for a silent file (:268-271)."""
+        if not self._fast_file_path_enabled() or not isinstance(path, str):
+            return None
+        import torch
+        try:
+            info = audio_io.wav_info(path)
+        except (audio_io.AudioIOError, OSError):
+            return None
+        if info["samplerate"] != self.sample_rate or info["subtype"] not in self.engine.PCM_FORMATS or info["frames"] < 1 or info["channels"] > 2:
+            return None                # (more than two channels: prepare_mix + the reference's "Expected a 2-channel" error)
+        t0 = self._now()
+        # what _probe_bit_depth records for the writer (common_separator.py:231-250)
+        self.input_subtype = st = info["subtype"]
+        self.input_bit_depth = 16 if st == "PCM_16" else (24 if st == "PCM_24" else 32)
+        self._file_seconds = info["frames"] / float(info["samplerate"])
+        frames, ch = info["frames"], info["channels"]
+        nbytes = frames * ch * info["bits"] // 8
+        staged = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        with open(path, "rb") as f:
+            f.seek(info["data_offset"])
+            got = f.readinto(memoryview(staged.numpy()))
+        if got != nbytes:
+            return None
+        t0 = self._tick("read", t0)
+        dev = self._torch_device()
+        raw = staged.to(dev, non_blocking=True)
+        mix = torch.empty((2, frames), dtype=torch.float32, device=dev)
+        peak = self.engine.pcm_decode_dev(raw.data_ptr(), frames, ch, st, mix.data_ptr(), stream=self._stream())
+        self._tick("h2d_decode", t0)
+        if not peak > 0.0:
+            msg = f"Audio file {path} is empty or not valid"
+            self.logger.error(msg)
+            raise ValueError(msg)
+        return mix
+
+    def _host_stem(self, dev_stem):
+        """A device stem [N, 2] as the numpy array the reference leaves in ``primary_source`` / ``secondary_source`` (pinned
+        staging, one asynchronous copy) and remember which device tensor it mirrors, so write_audio can quantise on the device
+        instead of uploading the array again."""
+        import torch
+        host = torch.empty(dev_stem.shape, dtype=dev_stem.dtype, pin_memory=True)
+        host.copy_(dev_stem, non_blocking=True)
+        arr = host.numpy()
+        self._dev_stems[id(arr)] = (arr, dev_stem, host)
+        return arr
+
+    def _device_stem_for(self, stem_source):
+        hit = self._dev_stems.get(id(stem_source))
+        return hit[1] if hit is not None and hit[0] is stem_source else None
 
     def _wanted(self, stem_name: str) -> bool:
         """``output_single_stem`` filter (mdx_separator.py:185,193)."""
@@ -217,7 +316,9 @@ class CommonSeparator:
     def write_audio(self, stem_path: str, stem_source):
         """common_separator.py:284-303."""
         if self.audio_file_path:
-            secs = audio_io.duration(self.audio_file_path)
+            if self._file_seconds is None:           # probed once per input, not once per stem
+                self._file_seconds = audio_io.duration(self.audio_file_path)
+            secs = self._file_seconds
             self.logger.info(f"Audio duration is {secs / 3600:.2f} hours ({secs:.2f} seconds).")
         if self.use_soundfile:
             self.write_audio_soundfile(stem_path, stem_source)
@@ -236,13 +337,27 @@ class CommonSeparator:
         built-in WAV writer (int16 widened exactly like ffmpeg's s16 -> s32 / pcm_s24le conversion)."""
         eng = self._require_engine()
         a = self._stereo_rows(stem_source)
-        if a.dtype == np.int16:
+        t0 = self._now()
+        dev_stem = self._device_stem_for(stem_source)
+        if dev_stem is not None:
+            # the stem is still in HBM (same array object separate() produced): normalise + quantise there, bring back int16 only
+            import torch
+            n = dev_stem.shape[0]
+            pcm_dev = torch.empty((n, 2), dtype=torch.int16, device=dev_stem.device)
+            peak = eng.pcm16_rows_dev(dev_stem.data_ptr(), n, self.normalization_threshold, self.amplification_threshold,
+                                      pcm_dev.data_ptr(), stream=self._stream())
+            pcm_host = torch.empty((n, 2), dtype=torch.int16, pin_memory=True)
+            pcm_host.copy_(pcm_dev, non_blocking=True)
+            self._sync()
+            pcm = pcm_host.numpy()
+        elif a.dtype == np.int16:
             pcm, peak = np.ascontiguousarray(a), float(np.abs(a).max()) if a.size else 0.0
         else:
             if a.shape[0] == 0:
                 self.logger.warning(f"{stem_path}: nothing to write (the stem is empty or silent)")
                 return
             pcm, peak = eng.pcm16(a, self.normalization_threshold, self.amplification_threshold)
+        t0 = self._tick("pcm16_d2h", t0)
         if peak < 1e-6:
             self.logger.warning(f"{stem_path}: nothing to write (the stem is empty or silent)")
             return
@@ -275,6 +390,7 @@ class CommonSeparator:
         if file_format != "wav":
             raise audio_io.AudioIOError(f"writing .{file_format} needs pydub + ffmpeg (not installed); WAV is built in")
         audio_io.write_wav(stem_path, pcm, self.sample_rate, {16: "PCM_16", 24: "PCM_24", 32: "PCM_32"}.get(depth, "PCM_16"))
+        self._tick("container_write", t0)
 
     def write_audio_soundfile(self, stem_path: str, stem_source):
         """common_separator.py:399-461: normalise (device), keep the input's subtype, hand floats to the container."""
@@ -309,6 +425,7 @@ class CommonSeparator:
     def clear_gpu_cache(self):
         """common_separator.py:463-474.  The engine's workspaces are sized once and reused across files (they are the
         point of keeping 288 GB resident); only Python garbage and torch's caching allocator are trimmed."""
+        self._dev_stems = {}
         gc.collect()
         try:
             import torch

@@ -28,6 +28,7 @@
 #endif
 #include "kernels_rof.h"
 #include "kernels_ht.h"
+#include "kernels_halo.h"
 #include "kernels_hd.h"
 #include "kernels_vr.h"
 #include "kernels_ens.h"
@@ -1551,6 +1552,57 @@ int asx_pcm16_dev(asx_engine *e, const float *stem_dev, int64_t N, float max_pea
     if (maxv > max_peak) scale = max_peak / maxv;
     else if (has_min && maxv < min_peak) scale = min_peak / maxv;
     *peak_after = maxv * scale;
+  }
+  return ASX_OK;
+}
+
+int asx_pcm16_rows_dev(asx_engine *e, const float *stem_rows_dev, int64_t N, float max_peak, float min_peak, int32_t has_min,
+                       int16_t *pcm_dev, float *peak_after, void *stream) {
+  REQUIRE(e && stem_rows_dev && pcm_dev && N >= 1, "asx_pcm16_rows_dev: bad argument");
+  REQUIRE((((uintptr_t)stem_rows_dev) & 15) == 0 && (((uintptr_t)pcm_dev) & 7) == 0, "asx_pcm16_rows_dev: stem must be 16-byte and pcm 8-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  CHK(e->d_peak.ensure(256));
+  unsigned int *pk = reinterpret_cast<unsigned int *>(e->d_peak.p);
+  HIPCHK(hipMemsetAsync(pk, 0, 4, s));
+  const int64_t n2 = 2 * N;
+  const unsigned nb = (unsigned)std::min<int64_t>((n2 + 255) / 256, 2048);
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 4.0 * n2, s, [&]() { hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, s, stem_rows_dev, n2, pk); }));
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 6.0 * n2, s, [&]() {
+    hipLaunchKernelGGL(pcm16_rows_kernel, dim3((unsigned)((n2 / 4 + 256) / 256)), dim3(256), 0, s, stem_rows_dev, n2, pk, max_peak, min_peak,
+                       has_min, reinterpret_cast<short *>(pcm_dev));
+  }));
+  if (peak_after) {
+    float maxv = 0.f;
+    HIPCHK(hipMemcpyAsync(&maxv, pk, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float scale = 1.0f;
+    if (maxv > max_peak) scale = max_peak / maxv;
+    else if (has_min && maxv < min_peak) scale = min_peak / maxv;
+    *peak_after = maxv * scale;
+  }
+  return ASX_OK;
+}
+
+int asx_pcm_decode_dev(asx_engine *e, const void *raw_dev, int64_t frames, int32_t channels, int32_t sample_format, float *mix_dev,
+                       float *peak, void *stream) {
+  REQUIRE(e && raw_dev && mix_dev && frames >= 1, "asx_pcm_decode_dev: bad argument");
+  REQUIRE(channels >= 1 && channels <= 64, "asx_pcm_decode_dev: %d channels", channels);
+  REQUIRE(sample_format == 16 || sample_format == 24 || sample_format == 32 || sample_format == 0x120,
+          "asx_pcm_decode_dev: sample format %d (16, 24, 32 = integer PCM bits, 0x120 = IEEE float32)", sample_format);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  CHK(e->d_peak.ensure(256));
+  unsigned int *pk = reinterpret_cast<unsigned int *>(e->d_peak.p) + 1;   // its own word: asx_separate_dev uses word 0
+  HIPCHK(hipMemsetAsync(pk, 0, 4, s));
+  const unsigned nb = (unsigned)std::min<int64_t>((frames + 255) / 256, 4096);
+  CHK(timed(e, ASX_PROF_MISC, 0.0, (double)frames * (channels * (sample_format & 0xff) / 8 + 8.0), s, [&]() {
+    hipLaunchKernelGGL(pcm_decode_kernel, dim3(nb), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(raw_dev), frames, (int)channels,
+                       (int)sample_format, mix_dev, pk);
+  }));
+  if (peak) {
+    HIPCHK(hipMemcpyAsync(peak, pk, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
   }
   return ASX_OK;
 }

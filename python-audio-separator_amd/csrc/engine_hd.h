@@ -48,6 +48,7 @@ static void hd_free(HdNet &n) {
   auto fg = [](HtGemm &g) {
     g.w.release();
     g.b.release();
+    g.wh.release();
   };
   for (HtEnc *E : {&n.encA, &n.encZ}) {
     fg(E->conv);
@@ -223,7 +224,7 @@ static int hd_commit(asx_engine *e) {
     CHK(hd_load_ins(e, h.insZ[d], "encoder." + sZ + ".dconv.layers." + std::to_string(d), CZ / c.dconv_comp));
   }
   // decoders: decoder.0 undoes level Z, decoder.1 level A, tdecoder.0 the waveform half of level A
-  CHK(ht_pack_conv(e, h.decZ_rw, "decoder.0.rewrite", 2 * CZ, CZ, 3, 1, false));
+  CHK(ht_pack_conv(e, h.decZ_rw, "decoder.0.rewrite", 2 * CZ, CZ, 3, 1, false, 0, 0, true));
   CHK(hd_norm_load(e, h.dZn1, "decoder.0.norm1", 2 * CZ));
   CHK(ht_pack_convtr(e, h.decZ_tr, "decoder.0.conv_tr", CZ, CA, 2 * c.time_stride, c.time_stride));
   CHK(hd_norm_load(e, h.dZn2, "decoder.0.norm2", CA));

@@ -14,6 +14,8 @@
 struct HtGemm {
   DevBuf w, b;
   int n = 0, k = 0;
+  DevBuf wh;                    // halo-tile packing of a k3 / 3x3 conv (kernels_halo.h); empty: not eligible
+  int wh_nt = 0, wh_taps = 0;   // its N tile and tap count
 };
 struct HtDconv {
   HtGemm c1, c2;
@@ -65,6 +67,7 @@ static void ht_free(HtNet &n) {
   auto fg = [](HtGemm &g) {
     g.w.release();
     g.b.release();
+    g.wh.release();
   };
   for (auto *v : {&n.enc, &n.tenc})
     for (auto &e : *v) {
@@ -117,6 +120,17 @@ static int ht_up_named(asx_engine *e, DevBuf &d, const std::string &name, int64_
   return ASX_OK;
 }
 
+// second packing of a stride-1 k3 / 3x3 conv for the halo-tile kernel (pw = [N, taps*cinp] as uploaded to g.w)
+static int ht_halo_pack(HtGemm &g, const std::vector<float> &pw, int taps, int cinp) {
+  static const bool off = getenv("ASX_HALO") != nullptr && atoi(getenv("ASX_HALO")) == 0;
+  if (off || (taps != 3 && taps != 9) || (cinp % HG_KC) != 0 || (g.n & 3)) return ASX_OK;
+  std::vector<float> ph;
+  g.wh_nt = hg_tile_n(g.n);
+  g.wh_taps = taps;
+  hg_pack_weights(pw, g.n, taps, cinp, g.wh_nt, ph);
+  return ht_up(g.wh, ph);
+}
+
 // rows (a_2q, a_2q+1, g_2q, g_2q+1): a lane of the GEMM epilogue holds both halves of two GLU outputs
 static void ht_glu_perm(std::vector<float> &w, std::vector<float> &b, int c, int k) {
   std::vector<float> w2(w.size()), b2(b.size());
@@ -134,7 +148,7 @@ static void ht_glu_perm(std::vector<float> &w, std::vector<float> &b, int c, int
 // torch conv weight [Cout, Cin, KA, KB] (KB = 1 for 1-D) -> [Npad, (to*KI + ti)*CinP + ci];
 // inner_first: the first kernel axis (KA) is the inner (frequency) tap, the second the outer (time) tap
 static int ht_pack_conv(asx_engine *e, HtGemm &g, const std::string &name, int cout, int cin, int ka, int kb,
-                        bool glu, int npad = 0, int cinp = 0) {
+                        bool glu, int npad = 0, int cinp = 0, bool halo = false) {
   const float *w, *b;
   CHK(get_tensor(e, name + ".weight", (int64_t)cout * cin * ka * kb, &w));
   CHK(get_tensor(e, name + ".bias", cout, &b));
@@ -154,6 +168,7 @@ static int ht_pack_conv(asx_engine *e, HtGemm &g, const std::string &name, int c
   g.k = K;
   CHK(ht_up(g.w, pw));
   CHK(ht_up(g.b, pb));
+  if (halo) CHK(ht_halo_pack(g, pw, ka * kb, cinp));
   return ASX_OK;
 }
 
@@ -347,8 +362,8 @@ static int ht_commit_level(asx_engine *e, int i, int dec_idx, int tdec_idx) {
     Dt.cin = co;
     Dt.cout = out_t;
     REQUIRE(out_z % 4 == 0 && out_t % 4 == 0, "decoder output channels must be multiples of 4");
-    CHK(ht_pack_conv(e, Dz.rewrite, "decoder." + sj + ".rewrite", 2 * co, co, 3, 3, true));
-    CHK(ht_pack_conv(e, Dt.rewrite, "tdecoder." + sjt + ".rewrite", 2 * co, co, 3, 1, true));
+    CHK(ht_pack_conv(e, Dz.rewrite, "decoder." + sj + ".rewrite", 2 * co, co, 3, 3, true, 0, 0, true));
+    CHK(ht_pack_conv(e, Dt.rewrite, "tdecoder." + sjt + ".rewrite", 2 * co, co, 3, 1, true, 0, 0, true));
     CHK(ht_pack_convtr(e, Dz.convtr, "decoder." + sj + ".conv_tr", co, out_z, c.kernel_size, c.stride));
     CHK(ht_pack_convtr(e, Dt.convtr, "tdecoder." + sjt + ".conv_tr", co, out_t, c.kernel_size, c.stride));
   }
@@ -516,6 +531,43 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
   const double out_elems = mode == GG_STATS ? 0.0 : (mode == GG_GNGLU ? (double)a.M * g.n : (double)a.M * g.n / (mode == GG_GLU ? 2 : 1));
   const double bytes = 4.0 * ((double)rows_outer * q.I * q.Cin + out_elems + (double)g.n * g.k + (res ? out_elems : 0.0));
   const int cls = mode == GG_CONVT ? ASX_PROF_UP : (q.SI > 1 ? ASX_PROF_DOWN : ASX_PROF_CONV3X3);
+  // stride-1 k3 / 3x3 convs with a halo packing run on the halo-tile kernel (the input block enters LDS once for all taps)
+  HgGeom hgm;
+  if (g.wh.p != nullptr && q.SI == 1 && q.SO == 1 && q.KI == 3 && (q.KO == 1 || q.KO == 3) && q.KO * q.KI == g.wh_taps &&
+      (mode == GG_DENSE || mode == GG_GLU) && res == nullptr && a.row_stat == nullptr && q.IR == q.I && a.OR == q.O &&
+      (q.KO == 3 || q.O == 1) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && hg_geometry(q.O, q.I, q.KO, q.DO, q.DI, &hgm)) {
+    HgArgs h{};
+    h.x = x;
+    h.wp = g.wh.f();
+    h.bias = g.b.f();
+    h.zeros = e->d_zeros.f();
+    h.y = y;
+    h.O = q.O;
+    h.I = q.I;
+    h.ldc = q.ldc;
+    h.NCH = q.Cin / HG_KC;
+    h.N = g.n;
+    h.nbn = (g.n + g.wh_nt - 1) / g.wh_nt;
+    h.x_bs = a.x_bs;
+    h.y_bs = a.y_bs;
+    h.ldy = ldy;
+    h.DO = q.KO == 3 ? q.DO : 0;
+    h.DI = q.DI;
+    h.PO = q.KO == 3 ? q.PO : 0;
+    h.PI = q.PI;
+    h.til2 = hgm.til2;
+    h.tilesO = hgm.tilesO;
+    h.tilesI = hgm.tilesI;
+    h.IWt = hgm.IWt;
+    h.NPIX = hgm.NPIX;
+    h.inb = hgm.inb;
+    h.mode = mode;
+    h.act = act;
+    const int Bn = (int)(rows_outer / q.O);
+    return timed(e, cls, flops, bytes, s, [&]() {
+      hg_dispatch(h, g.wh_nt, q.KO, Bn, s);
+    });
+  }
   return timed(e, cls, flops, bytes, s, [&]() {
     ht_gg_dispatch(a, s);
   });

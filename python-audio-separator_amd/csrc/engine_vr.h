@@ -72,6 +72,7 @@ static void vr_free(VrNet &n) {
   auto fc = [](VrConv &c) {
     c.g.w.release();
     c.g.b.release();
+    c.g.wh.release();
   };
   for (VrBase *bs : {&n.s1l, &n.s1h, &n.s2, &n.s3}) {
     for (auto *v : {&bs->enc1, &bs->enc2, &bs->dec})
@@ -162,6 +163,7 @@ static int vr_pack_conv(asx_engine *e, VrConv &c, const std::string &wname, cons
   c.g.k = K;
   CHK(ht_up(c.g.w, pw));
   CHK(ht_up(c.g.b, pb));
+  if (k == 3) CHK(ht_halo_pack(c.g, pw, 9, cin_p));   // stride-1 launches of this layer take the halo-tile kernel
   return ASX_OK;
 }
 

@@ -448,6 +448,99 @@ __global__ __launch_bounds__(256) void pcm16_kernel(const float *__restrict__ st
   reinterpret_cast<short2 *>(pcm)[i] = o;
 }
 
+// The same writer edge for a stem that is already [N, 2] interleaved (what asx_separate_dev produces and write_audio consumes):
+// purely elementwise over the 2 N values, four per thread.  Bit-identical to pcm16_kernel on the transposed input.
+__global__ __launch_bounds__(256) void pcm16_rows_kernel(const float *__restrict__ stem, int64_t n2, const unsigned int *peak_bits,
+                                                         float max_peak, float min_peak, int has_min, short *__restrict__ pcm) {
+#pragma clang fp contract(off)
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n2) return;
+  const float maxv = __uint_as_float(*peak_bits);
+  float scale = 1.0f;
+  bool scaled = false;
+  if (maxv > max_peak) {
+    scale = __fdiv_rn(max_peak, maxv);
+    scaled = true;
+  } else if (has_min && maxv < min_peak) {
+    scale = __fdiv_rn(min_peak, maxv);
+    scaled = true;
+  }
+  float v[4];
+  const bool full = i + 4 <= n2;
+  if (full) {
+    const float4 q = *reinterpret_cast<const float4 *>(stem + i);
+    v[0] = q.x;
+    v[1] = q.y;
+    v[2] = q.z;
+    v[3] = q.w;
+  } else {
+    for (int j = 0; j < 4; ++j) v[j] = i + j < n2 ? stem[i + j] : 0.f;
+  }
+  short o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x = v[j];
+    if (scaled) x = x * scale;
+    const float xq = x * 32767.0f;
+    o[j] = (short)(int)xq;
+  }
+  if (full) {
+    short4 w;
+    w.x = o[0];
+    w.y = o[1];
+    w.z = o[2];
+    w.w = o[3];
+    *reinterpret_cast<short4 *>(pcm + i) = w;
+  } else {
+    for (int j = 0; j < 4 && i + j < n2; ++j) pcm[i + j] = o[j];
+  }
+}
+
+// Decode edge: the data chunk of a RIFF/WAVE file, [frames, channels] interleaved little-endian samples, -> float32 planar
+// [2, frames] (a mono file feeds both rows: common_separator.py:278-280), with the conversions libsndfile / audio_io.read_wav
+// apply: PCM_16 x / 2^15, PCM_24 x / 2^23, PCM_32 (double)x / 2^31 rounded to float, IEEE float copied.  fmt = bits per sample
+// (16, 24, 32) or 0x20 | 0x100 for float32.  Also folds max |x| into peak_bits (the "file is silent" check of prepare_mix).
+__global__ __launch_bounds__(256) void pcm_decode_kernel(const unsigned char *__restrict__ raw, int64_t frames, int channels, int fmt,
+                                                         float *__restrict__ out, unsigned int *peak_bits) {
+  float m = 0.f;
+  const int bps = (fmt & 0xff) / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < frames; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int cc = c < channels ? c : channels - 1;
+      const unsigned char *p = raw + (i * channels + cc) * bps;
+      float x;
+      if (fmt == 16) {
+        const short q = (short)((unsigned)p[0] | ((unsigned)p[1] << 8));
+        x = (float)q * (1.0f / 32768.0f);
+      } else if (fmt == 24) {
+        int q = (int)((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16));
+        if (q >= (1 << 23)) q -= (1 << 24);
+        x = (float)q * (1.0f / 8388608.0f);
+      } else if (fmt == 32) {
+        const int q = (int)((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24));
+        x = (float)((double)q * (1.0 / 2147483648.0));
+      } else {
+        x = __uint_as_float((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24));
+      }
+      v[c] = x;
+    }
+    out[i] = v[0];
+    out[frames + i] = v[1];
+    m = fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1])));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    atomicMax(peak_bits, __float_as_uint(m));
+  }
+}
+
 __global__ __launch_bounds__(256) void stems_kernel(const float *__restrict__ demixed, const float *__restrict__ mix,
                                                     int64_t N, const unsigned int *peak_bits, float compensate,
                                                     float *__restrict__ primary, float *__restrict__ secondary) {

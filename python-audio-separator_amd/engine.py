@@ -212,7 +212,7 @@ class HDConfig:
 _FP = C.POINTER(C.c_float)
 _lib = None
 
-ABI_VERSION = 3   # ASX_ABI_VERSION of include/asx.h the structures below mirror
+ABI_VERSION = 4   # ASX_ABI_VERSION of include/asx.h the structures below mirror
 
 # every symbol include/asx.h declares
 SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_create", "asx_engine_destroy",
@@ -227,7 +227,7 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
            "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev",
            "asx_hd_begin", "asx_hd_commit", "asx_hd_flops", "asx_hd_forward", "asx_hd_demix", "asx_hd_demix_dev", "asx_hd_plan",
-           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_debug_trace"]
+           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_debug_trace"]
 
 
 def load_library():
@@ -314,6 +314,8 @@ def load_library():
     lib.asx_pcm16.argtypes = [vp, _FP, i64, C.c_float, C.c_float, i32, C.POINTER(C.c_int16), _FP]
     lib.asx_normalize.argtypes = [vp, _FP, i64, C.c_float, C.c_float, i32, _FP]
     lib.asx_pcm16_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp, _FP, vp]
+    lib.asx_pcm16_rows_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp, _FP, vp]
+    lib.asx_pcm_decode_dev.argtypes = [vp, vp, i64, i32, i32, vp, _FP, vp]
     lib.asx_mdxc_chunks_dev.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     lib.asx_mdxc_finalize_dev.argtypes = [vp, vp, i64, i32, vp, vp]
     lib.asx_rof_plan.argtypes = [vp, i64, i64, C.POINTER(i32), C.POINTER(i64)]
@@ -761,6 +763,27 @@ class Engine:
         self._check(self._lib.asx_pcm16(self._h, _ptr(planar), n, float(max_peak), float(min_peak or 0.0), int(min_peak is not None),
                                         out.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(pk)))
         return out, pk.value
+
+    def pcm16_rows_dev(self, stem_ptr: int, n_samples: int, max_peak: float, min_peak, pcm_ptr: int, stream: int = 0,
+                       want_peak: bool = True):
+        """asx_pcm16_rows_dev: a device-resident [N, 2] stem -> int16 [N, 2] on the device; returns the peak after
+        normalisation (synchronises the stream) or None."""
+        pk = C.c_float()
+        self._check(self._lib.asx_pcm16_rows_dev(self._h, stem_ptr, n_samples, float(max_peak), float(min_peak or 0.0),
+                                                 int(min_peak is not None), pcm_ptr, C.byref(pk) if want_peak else None, stream or None))
+        return pk.value if want_peak else None
+
+    PCM_FORMATS = {"PCM_16": 16, "PCM_24": 24, "PCM_32": 32, "FLOAT": 0x120}
+
+    def pcm_decode_dev(self, raw_ptr: int, frames: int, channels: int, subtype: str, mix_ptr: int, stream: int = 0,
+                       want_peak: bool = True):
+        """asx_pcm_decode_dev: a WAVE data chunk on the device -> float32 planar [2, frames]; returns max |mix| or None."""
+        if subtype not in self.PCM_FORMATS:
+            raise ValueError(f"no device decoder for subtype {subtype}")
+        pk = C.c_float()
+        self._check(self._lib.asx_pcm_decode_dev(self._h, raw_ptr, frames, channels, self.PCM_FORMATS[subtype], mix_ptr,
+                                                 C.byref(pk) if want_peak else None, stream or None))
+        return pk.value if want_peak else None
 
     def normalize(self, wave: np.ndarray, max_peak: float = 1.0, min_peak=None) -> np.ndarray:
         """spec_utils.normalize (uvr_lib_v5/spec_utils.py:99-115): scales ``wave`` IN PLACE when it is a C-contiguous float32

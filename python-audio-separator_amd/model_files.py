@@ -143,11 +143,27 @@ def get_demucs_model(name: str, repo: str) -> dict:
 
 def read_state_dict(path: str) -> dict:
     """torch.load(model_path, map_location="cpu") of a bare state_dict (vr_separator.py:176, mdxc_separator.py:109)."""
-    import torch
-    try:
-        sd = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
-        sd = torch.load(path, map_location="cpu", weights_only=False)
+    sd = safe_torch_load(path)
     if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
         sd = sd["state_dict"]
     return sd
+
+
+UNSAFE_ENV = "ASX_ALLOW_UNSAFE_PICKLE"
+
+
+def safe_torch_load(path: str):
+    """torch.load restricted to tensors and plain containers (weights_only=True -- what the reference's plain torch.load does
+    on torch >= 2.6).  A file that needs arbitrary pickle globals is REFUSED: un-pickling it would run code from a downloaded
+    model.  Setting ASX_ALLOW_UNSAFE_PICKLE=1 opts into the unrestricted loader for a file the user trusts (logged)."""
+    import logging
+    import torch
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:
+        if os.environ.get(UNSAFE_ENV, "") != "1":
+            raise ModelLoadingError(
+                f"{path}: refused by the restricted (weights_only) loader: {e}.  If you trust this file, set {UNSAFE_ENV}=1 "
+                "to un-pickle it without restrictions.") from e
+        logging.getLogger(__name__).warning("%s: loading with UNRESTRICTED pickle (%s=1) -- the file can execute code", path, UNSAFE_ENV)
+        return torch.load(path, map_location="cpu", weights_only=False)

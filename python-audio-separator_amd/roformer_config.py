@@ -200,11 +200,8 @@ def legacy_constructor_args(model_cfg: dict, model_type: str) -> dict:
 
 def read_checkpoint(model_path: str) -> dict:
     """torch.load + the 'state_dict' / 'model' unwrapping of roformer_loader.py:97-104 (torch is the weight container)."""
-    import torch
-    try:
-        sd = torch.load(model_path, map_location="cpu", weights_only=True)
-    except Exception:
-        sd = torch.load(model_path, map_location="cpu", weights_only=False)
+    from .model_files import safe_torch_load
+    sd = safe_torch_load(model_path)
     if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
         sd = sd["state_dict"]
     elif isinstance(sd, dict) and "model" in sd and isinstance(sd["model"], dict):

@@ -134,11 +134,81 @@ class DemucsAdapter(_SiblingAdapter):
         self._mix = mix
 
 
-def sharded_demix(adapter, mix, group=None, dst: int = 0):
+class FilesPipeline:
+    """BASELINE config 5 (files sharded over the ranks, stems gathered to rank ``dst``): every rank demixes its own songs
+    into one of TWO stem buffers and hands the buffer to ONE asynchronous ``dist.gather``; the gather of step k drains while
+    step k + 1 computes into the other buffer, and a buffer is reused only after its gather has completed.
+
+    ``demix(mix, out)`` is the per-song hot path (libasx.so's ``demix_dev`` on the GPU; any callable in the CPU tests).
+    ``on_gathered(step, slabs)`` (rank ``dst`` only) is called when the gather of ``step`` has completed, before its buffers
+    are reused: ``slabs[r]`` is rank r's [S, 2, N] stems of that step.  With ``overlap=False`` the gather blocks."""
+
+    def __init__(self, demix, mixes, world: int, rank: int, use_dist: bool, dst: int = 0, overlap: bool = True, on_gathered=None):
+        import torch
+        self.demix, self.mixes, self.world, self.rank, self.dst = demix, mixes, world, rank, dst
+        self.use_dist, self.overlap, self.on_gathered = use_dist, overlap, on_gathered
+        S, shape = len(mixes), tuple(mixes[0].shape)
+        mk = lambda: torch.empty((S,) + shape, dtype=mixes[0].dtype, device=mixes[0].device)  # noqa: E731
+        self.outs = [mk(), mk()]
+        self.gathered = [[mk() for _ in range(world)] for _ in range(2)] if (use_dist and rank == dst) else [None, None]
+        self.pending = [None, None]       # (work, step) per buffer
+        self.gather_bytes_per_step = (self.outs[0].numel() * self.outs[0].element_size() * (world - 1)) if use_dist else 0
+
+    def _complete(self, b):
+        if self.pending[b] is None:
+            return
+        work, step = self.pending[b]
+        if work is not None:
+            work.wait()
+        self.pending[b] = None
+        if self.on_gathered is not None and self.gathered[b] is not None:
+            self.on_gathered(step, self.gathered[b])
+
+    def step(self, k: int):
+        import torch.distributed as dist
+        b = k & 1
+        self._complete(b)                 # the stems buffer is free again once its gather has drained
+        for s, mix in enumerate(self.mixes):
+            self.demix(mix, self.outs[b][s])
+        if self.use_dist:
+            if self.overlap:
+                self.pending[b] = (dist.gather(self.outs[b], self.gathered[b], dst=self.dst, async_op=True), k)
+            else:
+                dist.gather(self.outs[b], self.gathered[b], dst=self.dst)
+                self.pending[b] = (None, k)
+                self._complete(b)
+
+    def drain(self):
+        # oldest first, so on_gathered sees the steps in order
+        order = sorted((b for b in (0, 1) if self.pending[b] is not None), key=lambda b: self.pending[b][1])
+        for b in order:
+            self._complete(b)
+
+
+class ShardWorkspace:
+    """Buffers of sharded_demix, allocated once per (shape, world) and reused: the strong-scaling loop then times compute +
+    gather + fold, not the caching allocator.  ``timings`` (when ``timed``) holds event-measured milliseconds of the last
+    call: local compute, gather, fold."""
+
+    def __init__(self, timed: bool = False):
+        self.key = None
+        self.timed = timed
+        self.timings = {}
+
+    def get(self, key, make):
+        if self.key != key:
+            self.key = key
+            self.bufs = make()
+        return self.bufs
+
+
+def sharded_demix(adapter, mix, group=None, dst: int = 0, workspace: ShardWorkspace | None = None):
     """Demix one song across all ranks of ``group``.
 
     ``mix``: float32 tensor [2, N] on the adapter's device, identical on every
     rank.  Returns the separated [2, N] tensor on rank ``dst`` and None elsewhere.
+    With a ``workspace`` no tensor is allocated after the first call and the returned tensor is the workspace's (it is
+    overwritten by the next call).
     """
     import torch
     import torch.distributed as dist
@@ -158,18 +228,54 @@ def sharded_demix(adapter, mix, group=None, dst: int = 0):
     oshape = tuple(mix.shape) if out_stems is None else (out_stems, 2, n)
     if hasattr(adapter, "bind_mix"):
         adapter.bind_mix(mix)
-    local = torch.zeros(cshape, dtype=torch.float32, device=mix.device)
+    even = all(b - a == per for a, b in ranges)     # equal ranges: the gathered slabs ARE the chunk list, no compaction copy
+
+    def make():
+        bufs = {"local": torch.zeros(cshape, dtype=torch.float32, device=mix.device)}
+        if is_dst:
+            bufs["out"] = torch.empty(oshape, dtype=torch.float32, device=mix.device)
+            if world > 1:
+                bufs["slab"] = torch.empty((world * per,) + cshape[1:], dtype=torch.float32, device=mix.device)
+                if not even:
+                    bufs["allc"] = torch.empty((nk,) + cshape[1:], dtype=torch.float32, device=mix.device)
+        return bufs
+    bufs = workspace.get((cshape, oshape, world, str(mix.device), is_dst), make) if workspace is not None else make()
+    timed = workspace is not None and workspace.timed and mix.is_cuda
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+    local = bufs["local"]
+    if timed:
+        ev[0].record()
     if k1 > k0:
         adapter.demix_chunks(mix, n, k0, k1, local[: k1 - k0])
+    if timed:
+        ev[1].record()
     if world == 1:
-        out = torch.empty(oshape, dtype=torch.float32, device=mix.device)
+        out = bufs["out"]
         adapter.finalize(local[:nk], n, out)
+        if timed:
+            ev[2].record()
+            ev[3].record()
+            torch.cuda.synchronize()
+            workspace.timings = {"compute_ms": ev[0].elapsed_time(ev[1]), "gather_ms": 0.0, "fold_ms": ev[1].elapsed_time(ev[2])}
         return out
-    slabs = [torch.empty_like(local) for _ in range(world)] if is_dst else None
+    slabs = [bufs["slab"][r * per:(r + 1) * per] for r in range(world)] if is_dst else None
     dist.gather(local, slabs, dst=dst, group=group)
-    if not is_dst:
-        return None
-    allc = torch.cat([slabs[r][: b - a] for r, (a, b) in enumerate(ranges)], dim=0)
-    out = torch.empty(oshape, dtype=torch.float32, device=mix.device)
-    adapter.finalize(allc, n, out)
+    if timed:
+        ev[2].record()
+    out = None
+    if is_dst:
+        if even:
+            allc = bufs["slab"]
+        else:
+            allc = bufs["allc"]
+            for r, (a, b) in enumerate(ranges):
+                if b > a:
+                    allc[a:b].copy_(slabs[r][: b - a])
+        out = bufs["out"]
+        adapter.finalize(allc, n, out)
+    if timed:
+        ev[3].record()
+        torch.cuda.synchronize()
+        workspace.timings = {"compute_ms": ev[0].elapsed_time(ev[1]), "gather_ms": ev[1].elapsed_time(ev[2]),
+                             "fold_ms": ev[2].elapsed_time(ev[3])}
     return out

@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.asx_abi_version() == 3
+    assert lib.asx_abi_version() == 4
 
 
 def test_binding_refuses_a_library_of_another_abi(monkeypatch):

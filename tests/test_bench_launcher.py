@@ -27,7 +27,20 @@ def test_self_launch_two_ranks():
     r = _run([sys.executable, BENCH, "--gpus", "2", "--dry-gloo", "--steps", "2", "--warmup", "1", "--songs-per-rank", "3"])
     assert r.returncode == 0, r.stderr[-2000:]
     row = _line(r.stdout)
-    assert row["n_gpus"] == 2 and row["rccl"] == {"world_size": 2, "backend": "gloo", "launcher": "self"} and row["gather_ok"] and row["dry"]
+    assert row["n_gpus"] == 2 and row["gather_ok"] and row["dry"]
+    assert {k: row["rccl"][k] for k in ("world_size", "backend", "launcher")} == {"world_size": 2, "backend": "gloo", "launcher": "self"}
+    assert row["rccl"]["gather_bytes_per_step"] == 3 * 2 * 4096 * 4
+
+
+def test_double_buffered_gather_holds_the_right_step(tmp_path):
+    """the REAL step() / drain() logic of the files mode (FilesPipeline: two stem buffers, one asynchronous
+    gather per step, a buffer reused only after its gather drained) with a CPU stand-in engine over gloo, world 2, 6 steps:
+    every gathered buffer must hold exactly the data of its own step, in order -- overlapped and blocking."""
+    for extra in ([], ["--no-overlap"]):
+        r = _run([sys.executable, BENCH, "--gpus", "2", "--dry-gloo", "--steps", "4", "--warmup", "2", "--songs-per-rank", "2"] + extra)
+        assert r.returncode == 0, r.stderr[-2000:]
+        row = _line(r.stdout)
+        assert row["gather_ok"] and row["gathers_checked"] == 6 and row["gather_mismatches"] == [], row
 
 
 def test_external_launcher_must_match_gpus():

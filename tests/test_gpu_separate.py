@@ -115,3 +115,70 @@ def test_soundfile_writer_path_keeps_input_subtype(tmp_path, monkeypatch):
         assert info["subtype"] == "PCM_24" and info["channels"] == 2 and info["frames"] == x.shape[1]
         y, _ = audio_io.read_wav(os.path.join(common["output_dir"], n))
         assert 0.1 < np.abs(y).max() <= 0.9 + 1e-6
+
+
+def _separate_once(case, wav, **common_over):
+    tag, cls, common, arch, _, custom = case
+    inst = SC.plugin_class(cls)(common_config=dict(common, asx_profile_file=True, **common_over), arch_config=arch)
+    names = inst.separate(wav, None)
+    srcs = (np.array(inst.secondary_source, copy=True), np.array(inst.primary_source, copy=True))
+    timings = dict(inst.file_timings)
+    blobs = []
+    for n in names:
+        with open(os.path.join(common["output_dir"], n), "rb") as f:
+            blobs.append(f.read())
+    inst.clear_gpu_cache()
+    inst.clear_file_specific_paths()
+    assert inst._dev_stems == {}
+    return names, srcs, blobs, timings
+
+
+@pytest.mark.parametrize("subtype,channels", [("PCM_16", 2), ("PCM_24", 2), ("PCM_32", 2), ("FLOAT", 2), ("PCM_16", 1)])
+def test_device_resident_file_path_equals_host_path(tmp_path, monkeypatch, subtype, channels):
+    """The file-level fast path (data chunk -> pinned -> HBM -> asx_pcm_decode_dev -> asx_separate_dev -> asx_pcm16_rows_dev,
+    stems never re-uploaded) against the generic path (host decode, host stems, asx_pcm16 per stem): the same stem arrays and
+    the same stem FILES, byte for byte, for every WAVE sample format and for a mono input."""
+    from audio_separator_amd import audio_io
+    case = SC.cases("mdx", str(tmp_path))[0]
+    x, sr = audio_io.read_wav(case[4])
+    if channels == 1:
+        x = x[:1]
+    src = str(tmp_path / f"in_{subtype}_{channels}.wav")
+    audio_io.write_wav(src, np.ascontiguousarray(x.T), sr, subtype)
+    monkeypatch.setenv("ASX_FILE_FASTPATH", "1")
+    names_d, srcs_d, blobs_d, t_d = _separate_once(case, src)
+    assert "h2d_decode" in t_d and "demix" in t_d, t_d            # the device path ran
+    monkeypatch.setenv("ASX_FILE_FASTPATH", "0")
+    names_h, srcs_h, blobs_h, t_h = _separate_once(case, src)
+    assert "h2d_decode" not in t_h
+    assert names_d == names_h
+    for a, b in zip(srcs_d, srcs_h):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert blobs_d == blobs_h
+
+
+def test_device_path_silent_file_raises_like_prepare_mix(tmp_path):
+    from audio_separator_amd import audio_io
+    case = SC.cases("mdx", str(tmp_path))[0]
+    tag, cls, common, arch, _, _ = case
+    src = str(tmp_path / "silent.wav")
+    audio_io.write_wav(src, np.zeros((4000, 2), np.int16), 44100, "PCM_16")
+    inst = SC.plugin_class(cls)(common_config=common, arch_config=arch)
+    with pytest.raises(ValueError, match="empty or not valid"):
+        inst.separate(src, None)
+
+
+def test_foreign_array_still_takes_the_upload_path(tmp_path):
+    """write_audio with an array separate() did not produce (the ensembler's output, separator.py:1379) must not hit the
+    device cache: same file as eng.pcm16 of that array."""
+    from audio_separator_amd import audio_io
+    case = SC.cases("mdx", str(tmp_path))[0]
+    tag, cls, common, arch, wav, _ = case
+    inst = SC.plugin_class(cls)(common_config=common, arch_config=arch)
+    inst.separate(wav, None)
+    foreign = np.array(inst.primary_source, copy=True) * np.float32(0.5)
+    assert inst._device_stem_for(foreign) is None and inst._device_stem_for(inst.primary_source) is not None
+    inst.write_audio("foreign.wav", foreign)
+    pcm, _ = audio_io.read_wav(os.path.join(common["output_dir"], "foreign.wav"))
+    want, _ = inst.engine.pcm16(foreign, 0.9, 0.0)
+    assert np.array_equal(np.rint(pcm.T * 32768.0).astype(np.int16), want)

@@ -136,6 +136,32 @@ def test_demucs_package_rejects_foreign_globals(tmp_path):
         MF.read_demucs_package(p)
 
 
+def test_state_dict_readers_refuse_foreign_globals(tmp_path, monkeypatch):
+    """a .pth / .ckpt that needs arbitrary pickle globals is refused by read_state_dict / read_checkpoint -- there is
+    no silent retry with weights_only=False; the opt-in is explicit (ASX_ALLOW_UNSAFE_PICKLE=1)."""
+    import torch
+
+    marker = tmp_path / "ran"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+    p = str(tmp_path / "evil.pth")
+    torch.save({"state_dict": {"w": torch.zeros(2)}, "extra": Evil()}, p)
+    monkeypatch.delenv(MF.UNSAFE_ENV, raising=False)
+    for reader in (MF.read_state_dict, RC.read_checkpoint):
+        with pytest.raises(MF.ModelLoadingError, match="refused"):
+            reader(p)
+    assert not marker.exists()
+    good = str(tmp_path / "good.pth")
+    torch.save({"state_dict": {"w": torch.ones(3)}}, good)
+    assert float(MF.read_state_dict(good)["w"].sum()) == 3.0
+    assert float(RC.read_checkpoint(good)["w"].sum()) == 3.0
+    monkeypatch.setenv(MF.UNSAFE_ENV, "1")       # the explicit opt-in un-pickles (and therefore runs) the file
+    assert "w" in MF.read_state_dict(p)
+    assert marker.exists()
+
+
 # ---- Roformer configuration mirror vs the reference's normaliser --------------------------------------------------------------
 YAMLS = {
     "ep317": {"audio": {"chunk_size": 352800, "dim_f": 1024, "dim_t": 801, "hop_length": 441, "n_fft": 2048, "num_channels": 2, "sample_rate": 44100},
