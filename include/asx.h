@@ -22,11 +22,12 @@
  * reference object is not re-entrant either).  "host" pointers are
  * pageable or pinned host memory, "dev" pointers are HIP device pointers on the
  * engine's GPU.  `stream` is a hipStream_t passed as void* (NULL = the null
- * stream).  asx_demix_dev / asx_demix_chunks_dev / asx_finalize_dev / asx_separate_dev and the
- * asx_mdxc_*_dev calls only enqueue work on `stream` once the engine's workspace has reached its
- * size (first call): no host copy, no host synchronisation -- they can be captured into a hipGraph and a
- * collective on step k can overlap the compute of step k + 1.  The Roformer / Demucs / VR *_dev calls
- * upload small index tables from the host and synchronise `stream` once per call.
+ * stream).  asx_demix_dev / asx_demix_chunks_dev / asx_finalize_dev / asx_separate_dev, the
+ * asx_mdxc_*_dev, asx_rof_*_dev, asx_ht_*_dev and asx_hd_*_dev calls only enqueue work on `stream` once the
+ * engine's workspace has reached its size (first call): no host copy, no host synchronisation (chunk / segment
+ * start tables are built by a kernel or travel in the kernel arguments) -- they can be captured into a hipGraph
+ * and a collective on step k can overlap the compute of step k + 1.  asx_vr_separate_dev synchronises `stream`
+ * only when enable_post_process asks for merge_artifacts (its run-length pass is host code).
  *
  * All audio is float32.  Layouts are C-order.
  */
@@ -391,6 +392,20 @@ int asx_vr_separate(asx_engine *e, const float *wave_host, int64_t n_samples, co
                     float *secondary_host);
 int asx_vr_separate_dev(asx_engine *e, const float *wave_dev, int64_t n_samples, const asx_vr_params *params, float *primary_dev,
                         float *secondary_dev, void *stream);
+
+/* BagOfModels on the device (uvr_lib_v5/demucs/apply.py:169-196 + demucs_separator.py:171-189; ABI 4).  Every member of a
+ * bag keeps its own engine (weights resident across files); the caller demixes the STANDARDISED mix with each member
+ * (flags 0) and combines without a host round trip:
+ *   asx_ht_standardize_dev     out = (mix - ref.mean()) / ref.std(), ref = mix.mean(0)          [2, N] -> [2, N]
+ *   asx_ht_bag_accumulate_dev  est = first ? member * w[k] : est + member * w[k]                 [S, 2, N]; w: S host floats
+ *   asx_ht_bag_finish_dev      out = est / totals[k] (* ref.std() + ref.mean() with ASX_HT_STANDARDIZE; sources 0 / 1 swapped
+ *                              with ASX_HT_SWAP01); est and out are different buffers.
+ * The engine passed in only provides the device, the stream plumbing and the mix statistics (any member's engine). */
+int asx_ht_standardize_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, float *out_dev, void *stream);
+int asx_ht_bag_accumulate_dev(asx_engine *e, float *est_dev, const float *member_dev, const float *weights, int32_t n_sources,
+                              int64_t n_samples, int32_t first, void *stream);
+int asx_ht_bag_finish_dev(asx_engine *e, const float *est_dev, const float *totals, int32_t n_sources, const float *mix_dev,
+                          int64_t n_samples, uint32_t flags, float *out_dev, void *stream);
 
 /* Writer edge: spec_utils.normalize + (stem * 32767).astype(np.int16) + channel interleave of
  * CommonSeparator.write_audio_pydub (common_separator.py:309-337).  stem [2, N] planar -> pcm [N, 2]; bit-exact.

@@ -129,6 +129,17 @@ struct HdNet;
 struct VrNet;
 struct EnsCtx;
 
+// what the fold's divider table was built for (asx_finalize_dev)
+struct DivKey {
+  int64_t N = -1;
+  int n_chunks = 0;
+  int64_t C = 0, step = 0, L = 0;
+  int trim = 0, win = 0;
+  bool operator==(const DivKey &o) const {
+    return N == o.N && n_chunks == o.n_chunks && C == o.C && step == o.step && L == o.L && trim == o.trim && win == o.win;
+  }
+};
+
 struct asx_engine {
   int device = 0;
   V3Net *v3 = nullptr;
@@ -160,6 +171,8 @@ struct asx_engine {
   // workspace
   int ws_batch = 0;  // chunks the workspace is sized for
   DevBuf spec_in, spec_out, R[3], H, frames, chunk_out, d_starts, d_nact, d_peak, d_demixed;
+  DevBuf d_div;      // divider of the chunk fold for div_key's plan (input-independent: built once, asx_finalize_dev)
+  DivKey div_key;
   std::vector<DevBuf> skip;
   bool winograd = false;  // use conv_wino_kernel for the 3x3 convs (asx_set_option)
   // profiling
@@ -566,6 +579,7 @@ static int tdf2_mode() {
 static bool tdf2_ok(const TdfDmaArgs &d) {
   auto a16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const int64_t lda = d.lda ? d.lda : d.K, ldy = d.ldy ? d.ldy : d.N, ldr = d.ldr ? d.ldr : d.N;
+  if (d.relu == 1 && (d.rscale != nullptr || d.rot_tab != nullptr)) return false;   // its ReLU ring epilogue applies neither
   return tdf2_mode() > 0 && d.K % 32 == 0 && d.K >= 32 && d.M % 8 == 0 && d.M >= 8 && d.M < (1ll << 31) && d.T > 0 && d.C > 0 && d.N % 8 == 0 && d.N >= 8 && lda % 4 == 0 &&
          ldy % 4 == 0 && ldr % 4 == 0 && a16(d.x) && a16(d.w) && a16(d.y) && (!d.res || a16(d.res)) && (!d.bias || a16(d.bias)) &&
          (uint64_t)8 * (uint64_t)lda * 4 < (1ull << 31) && (uint64_t)8 * (uint64_t)d.K * 4 < (1ull << 31) &&
@@ -795,7 +809,8 @@ static int ola_launch(asx_engine *e, const float *frames, const float *env, cons
 // ring and writes the chunk directly (kernels_fft3.h); every other geometry runs istft_kernel -> frames -> ola_kernel.
 static int istft_ola_launch(asx_engine *e, const float *spec, int B, int T, int combine, const int64_t *d_nact, int64_t C,
                             float *out, hipStream_t s) {
-  if (!(e->fft3 && e->cfg.dim_f <= f3::NH && C == (int64_t)f3::HOP * (T - 1))) {
+  // emit_hop / emit_finish / seam3_kernel store float4: `out` (the caller's chunk buffer + a chunk offset) must be 16-byte aligned
+  if (!(e->fft3 && e->cfg.dim_f <= f3::NH && C == (int64_t)f3::HOP * (T - 1) && (reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
     CHK(istft_launch(e, spec, B, T, 1, combine, e->frames.f(), s));
     return ola_launch(e, e->frames.f(), e->d_env.f(), d_nact, B, T, C, out, s);
   }
@@ -823,7 +838,7 @@ static int istft_ola_launch(asx_engine *e, const float *spec, int B, int T, int 
   // algorithmic bytes: the spectrogram read once, the chunk written once (the seam buffer's round trip is overhead, not counted)
   const double bytes = 4.0 * ((double)B * 4 * T * e->cfg.dim_f * (combine ? 2 : 1) + (double)B * 2 * C);
   return timed(e, ASX_PROF_ISTFT, 0.0, bytes, s, [&]() {
-    const bool aligned = e->cfg.dim_f % 4 == 0 && (reinterpret_cast<uintptr_t>(spec) & 15) == 0 && f.in_bstride % 4 == 0;
+    const bool aligned = e->cfg.dim_f % 4 == 0 && (reinterpret_cast<uintptr_t>(spec) & 15) == 0;
     if (e->fft3p && combine == 0 && aligned)
     {
       static const int abl = getenv("ASX_ISTFT_ABL") ? atoi(getenv("ASX_ISTFT_ABL")) : 0;   // timing probes (results invalid)
@@ -1097,6 +1112,7 @@ void asx_engine_destroy(asx_engine *e) {
   e->d_nact.release();
   e->d_peak.release();
   e->d_demixed.release();
+  e->d_div.release();
   for (auto &sk : e->skip) sk.release();
   if (e->v3) v3_destroy(e->v3);
   if (e->rof) rof_destroy(e->rof);
@@ -1370,10 +1386,29 @@ int asx_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t N, float
   CHK(asx_plan_query(e, N, flags, &p));
   const int win = windowed_mode(e, flags) ? 1 : 0;
   const double bytes = 4.0 * ((double)p.n_chunks * 2 * p.chunk_size + 2.0 * N);
+  const double *hann = (e->fft3 && e->d_hann3.p) ? reinterpret_cast<const double *>(e->d_hann3.p) : nullptr;
+  static const bool fin4 = !(getenv("ASX_FINALIZE4") && atoi(getenv("ASX_FINALIZE4")) == 0);
+  // vector path: the divider (input-independent) comes from a table built once per plan; needs 4-sample alignment of the
+  // chunk geometry and 16-byte aligned buffers
+  if (fin4 && p.chunk_size % 4 == 0 && p.step % 4 == 0 && p.trim % 4 == 0 && N % 4 == 0 && p.chunk_size + (int64_t)p.trim >= 0 &&
+      (((uintptr_t)chunk_out_dev | (uintptr_t)out_dev) & 15) == 0) {
+    const DivKey key{N, p.n_chunks, p.chunk_size, p.step, p.padded_len, p.trim, win};
+    if (!(e->div_key == key) || !e->d_div.p) {
+      CHK(e->d_div.ensure((size_t)N * 4));
+      CHK(timed(e, ASX_PROF_MISC, 0.0, 4.0 * N, s, [&]() {
+        hipLaunchKernelGGL(finalize_div_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, p.n_chunks, p.chunk_size, p.step,
+                           p.padded_len, p.trim, N, win, e->d_div.f(), hann);
+      }));
+      e->div_key = key;
+    }
+    return timed(e, ASX_PROF_FINALIZE, 0.0, bytes, s, [&]() {
+      hipLaunchKernelGGL(finalize4_kernel, dim3((unsigned)((N / 4 + 255) / 256), 2), dim3(256), 0, s, chunk_out_dev, p.n_chunks,
+                         p.chunk_size, p.step, p.padded_len, p.trim, N, e->d_div.f(), out_dev);
+    });
+  }
   return timed(e, ASX_PROF_FINALIZE, 0.0, bytes, s, [&]() {
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, s, chunk_out_dev,
-                       p.n_chunks, p.chunk_size, p.step, p.padded_len, p.trim, N, win, out_dev,
-                       (e->fft3 && e->d_hann3.p) ? reinterpret_cast<const double *>(e->d_hann3.p) : nullptr);
+                       p.n_chunks, p.chunk_size, p.step, p.padded_len, p.trim, N, win, out_dev, hann);
   });
 }
 
@@ -2128,6 +2163,14 @@ int asx_rof_forward(asx_engine *e, const float *wave_host, int32_t B, float *out
   return ASX_OK;
 }
 
+// start of Roformer chunk k0 + t: t * step, the last one re-anchored to N - C (mdxc_separator.py:323-336)
+__global__ void rof_starts_kernel(int k0, int nk, int64_t step, int64_t N, int64_t C, int64_t *__restrict__ starts) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nk) return;
+  const int64_t i = (int64_t)(k0 + t) * step;
+  starts[t] = i + C > N ? N - C : i;
+}
+
 static int rof_starts(asx_engine *e, int64_t N, int64_t step, std::vector<int64_t> &starts) {
   const int64_t C = (int64_t)e->cfg.hop_length * (e->cfg.segment_size - 1);
   REQUIRE(N >= C, "mix (%lld samples) shorter than one chunk (%lld): not supported on the Roformer path", (long long)N, (long long)C);
@@ -2165,8 +2208,10 @@ int asx_rof_chunks_dev(asx_engine *e, const float *mix_dev, int64_t N, int64_t s
   if (k1 == k0) return ASX_OK;
   const int nk = k1 - k0;
   CHK(n.d_starts.ensure((size_t)starts.size() * 8));
-  HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data() + k0, (size_t)nk * 8, hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));
+  // chunk starts built on the device (like chunk_table_kernel for MDX): the call only enqueues work
+  hipLaunchKernelGGL(rof_starts_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, k0, nk, step, N, C,
+                     reinterpret_cast<int64_t *>(n.d_starts.p));
+  HIPCHK(hipGetLastError());
   const int maxB = e->cfg.max_batch > 0 ? e->cfg.max_batch : 8;
   const int nbatch = (nk + maxB - 1) / maxB;
   const int per = (nk + nbatch - 1) / nbatch;
@@ -2193,8 +2238,9 @@ int asx_rof_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t N, i
   CHK(rof_starts(e, N, step, starts));
   const int nk = (int)starts.size();
   CHK(n.d_starts.ensure((size_t)nk * 8));
-  HIPCHK(hipMemcpyAsync(n.d_starts.p, starts.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));
+  hipLaunchKernelGGL(rof_starts_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, 0, nk, step, N, C,
+                     reinterpret_cast<int64_t *>(n.d_starts.p));
+  HIPCHK(hipGetLastError());
   const int n_out = n.cfg.n_out;
   return timed(e, ASX_PROF_FINALIZE, 0.0, 4.0 * ((double)nk * S * 2 * C + 2.0 * n_out * N), s, [&]() {
     hipLaunchKernelGGL(roformer_finalize_kernel, dim3((unsigned)((N + 255) / 256), n_out * 2), dim3(256), 0, s, chunk_out_dev,
@@ -2711,6 +2757,54 @@ int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out_host, c.dout.p, (size_t)2 * (*n_out) * 4, hipMemcpyDeviceToHost));
   return ASX_OK;
+}
+
+// ---- BagOfModels combine on the device (every member keeps its own engine / weights; no float stem visits the host) -------
+int asx_ht_standardize_dev(asx_engine *e, const float *mix_dev, int64_t N, float *out_dev, void *stream) {
+  REQUIRE(e && mix_dev && out_dev && N >= 2, "asx_ht_standardize_dev: bad argument");
+  REQUIRE(e->ht != nullptr, "asx_ht_standardize_dev: no Demucs model committed on this engine");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  CHK(ht_ref_stats(e, mix_dev, N, s));
+  return timed(e, ASX_PROF_MISC, 0.0, 16.0 * N, s, [&]() {
+    hipLaunchKernelGGL(ht_standardize_kernel, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, s, mix_dev, 2 * N, N,
+                       reinterpret_cast<const double *>(e->ht->ref_acc.p), out_dev);
+  });
+}
+
+int asx_ht_bag_accumulate_dev(asx_engine *e, float *est_dev, const float *member_dev, const float *weights, int32_t S, int64_t N,
+                              int32_t first, void *stream) {
+  REQUIRE(e && est_dev && member_dev && weights && S >= 1 && S <= 16 && N >= 1, "asx_ht_bag_accumulate_dev: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  BagWeights w{};
+  for (int i = 0; i < S; ++i) w.v[i] = weights[i];
+  const int64_t per = 2 * N;
+  return timed(e, ASX_PROF_MISC, 0.0, 12.0 * S * per, s, [&]() {
+    hipLaunchKernelGGL(ht_bag_accumulate_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)S), dim3(256), 0, s, est_dev, member_dev, per, w,
+                       (int)first);
+  });
+}
+
+int asx_ht_bag_finish_dev(asx_engine *e, const float *est_dev, const float *totals, int32_t S, const float *mix_dev, int64_t N,
+                          uint32_t flags, float *out_dev, void *stream) {
+  REQUIRE(e && est_dev && totals && out_dev && S >= 1 && S <= 16 && N >= 2, "asx_ht_bag_finish_dev: bad argument");
+  REQUIRE(est_dev != out_dev, "asx_ht_bag_finish_dev: est and out must be different buffers (the stem swap is not in place)");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  const int standardize = (flags & ASX_HT_STANDARDIZE) ? 1 : 0;
+  if (standardize) {
+    REQUIRE(e->ht != nullptr && mix_dev != nullptr, "asx_ht_bag_finish_dev: de-standardising needs the mix and a committed Demucs model");
+    CHK(ht_ref_stats(e, mix_dev, N, s));
+  }
+  BagWeights t{};
+  for (int i = 0; i < S; ++i) t.v[i] = totals[i];
+  const int64_t per = 2 * N;
+  return timed(e, ASX_PROF_MISC, 0.0, 8.0 * S * per, s, [&]() {
+    hipLaunchKernelGGL(ht_bag_finish_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)S), dim3(256), 0, s, est_dev, per, N, t,
+                       standardize ? reinterpret_cast<const double *>(e->ht->ref_acc.p) : nullptr, standardize,
+                       (flags & ASX_HT_SWAP01) ? 1 : 0, out_dev);
+  });
 }
 
 int asx_set_option(asx_engine *e, const char *key, int32_t value) {

@@ -809,9 +809,6 @@ static int hd_segments_dev(asx_engine *e, const float *mix_dev, int64_t N, const
   const int nk = (int)order.size();
   std::vector<int64_t> st(nk);
   for (int i = 0; i < nk; ++i) st[i] = p.starts[order[i]];
-  CHK(h.starts.ensure((size_t)nk * 8));
-  HIPCHK(hipMemcpyAsync(h.starts.p, st.data(), (size_t)nk * 8, hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));   // st is a local
   static const int max_groups = getenv("ASX_HD_GROUPS") ? std::max(1, std::min(HD_MAX_GROUPS, atoi(getenv("ASX_HD_GROUPS")))) : HD_MAX_GROUPS;
   int i = 0;
   while (i < nk) {
@@ -831,9 +828,7 @@ static int hd_segments_dev(asx_engine *e, const float *mix_dev, int64_t N, const
       const int B = j - i;
       CHK(gn->seg.ensure((size_t)B * 2 * L * 4));
       CHK(gh->tmp_out.ensure((size_t)B * S * 2 * L * 4));
-      hipLaunchKernelGGL(ht_gather_kernel, dim3((unsigned)((L + 255) / 256), 2, B), dim3(256), 0, s, mix_dev, N,
-                         reinterpret_cast<const int64_t *>(h.starts.p) + i, L, reinterpret_cast<const double *>(n.ref_acc.p), standardize,
-                         gn->seg.f());
+      ht_gather_launch(mix_dev, N, st.data() + i, B, L, reinterpret_cast<const double *>(n.ref_acc.p), standardize, gn->seg.f(), s);
       HIPCHK(hipGetLastError());
       G.push_back(HdGroup{gn, gh, B, L, gn->seg.f(), gh->tmp_out.f(), HdDims{}});
       first.push_back(i);

@@ -533,9 +533,12 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
   const int cls = mode == GG_CONVT ? ASX_PROF_UP : (q.SI > 1 ? ASX_PROF_DOWN : ASX_PROF_CONV3X3);
   // stride-1 k3 / 3x3 convs with a halo packing run on the halo-tile kernel (the input block enters LDS once for all taps)
   HgGeom hgm;
+  // A/B knob: launches whose halo grid would be smaller than ASX_HALO_MINBLK workgroups stay on gg_kernel (128-row tiles)
+  static const int64_t halo_minblk = getenv("ASX_HALO_MINBLK") ? atoll(getenv("ASX_HALO_MINBLK")) : 0;
   if (g.wh.p != nullptr && q.SI == 1 && q.SO == 1 && q.KI == 3 && (q.KO == 1 || q.KO == 3) && q.KO * q.KI == g.wh_taps &&
       (mode == GG_DENSE || mode == GG_GLU) && res == nullptr && a.row_stat == nullptr && q.IR == q.I && a.OR == q.O &&
-      (q.KO == 3 || q.O == 1) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && hg_geometry(q.O, q.I, q.KO, q.DO, q.DI, &hgm)) {
+      (q.KO == 3 || q.O == 1) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && hg_geometry(q.O, q.I, q.KO, q.DO, q.DI, &hgm) &&
+      (rows_outer / q.O) * hgm.tilesO * hgm.tilesI * ((g.n + g.wh_nt - 1) / g.wh_nt) >= halo_minblk) {
     HgArgs h{};
     h.x = x;
     h.wp = g.wh.f();
@@ -1163,18 +1166,13 @@ static int ht_segments_dev(asx_engine *e, const float *mix_dev, int64_t N, const
   if (k1 <= k0) return ASX_OK;
   if (standardize) CHK(ht_ref_stats(e, mix_dev, N, s));
   const int nk = k1 - k0;
-  CHK(n.d_starts.ensure((size_t)nk * 8));
-  HIPCHK(hipMemcpyAsync(n.d_starts.p, p.starts.data() + k0, (size_t)nk * 8, hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));
   const int maxB = c.max_batch > 0 ? c.max_batch : 16;   // 611 vs 536x real time against batches of 8 (4-min song)
   const int nbatch = (nk + maxB - 1) / maxB;
   const int per = (nk + nbatch - 1) / nbatch;
   CHK(n.seg.ensure((size_t)per * 2 * TL * 4));
   for (int j = 0; j < nk; j += per) {
     const int B = std::min(per, nk - j);
-    hipLaunchKernelGGL(ht_gather_kernel, dim3((unsigned)((TL + 255) / 256), 2, B), dim3(256), 0, s, mix_dev, N,
-                       reinterpret_cast<const int64_t *>(n.d_starts.p) + j, TL, reinterpret_cast<const double *>(n.ref_acc.p), standardize,
-                       n.seg.f());
+    ht_gather_launch(mix_dev, N, p.starts.data() + k0 + j, B, TL, reinterpret_cast<const double *>(n.ref_acc.p), standardize, n.seg.f(), s);
     HIPCHK(hipGetLastError());
     CHK(ht_forward_dev(e, n.seg.f(), B, chunk_out + (size_t)j * S * 2 * TL, s));
   }

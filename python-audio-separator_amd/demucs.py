@@ -93,6 +93,14 @@ def models_from_files(model_path: str, segment_size="Default", max_batch: int = 
     return models, bag["weights"]
 
 
+def _cuda_ready() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
 class DemucsDemixer:
     def __init__(self, common_config: dict, arch_config: dict, models=None, weights=None, max_batch: int = 0):
         """models: list of (HTConfig | HDConfig, state_dict); weights: per-model list of per-source weights
@@ -112,24 +120,87 @@ class DemucsDemixer:
         self.weights = weights if weights is not None else [[1.0] * S for _ in self.models]
         if len(self.weights) != len(self.models) or any(len(w) != S for w in self.weights):
             raise ValueError("weights must give one value per source for every model")
-        self.engine = None
+        self.engine = None            # the engine of the member loaded last (single models: THE engine)
+        self.engines = [None] * len(self.models)   # one resident engine (weights + workspace) per bag member
         self._loaded = None
+        self._own = False
 
     def _load(self, idx: int):
-        if self._loaded == idx:
-            return
+        """Member ``idx`` ready on ``self.engine``.  Every member of a bag gets its OWN engine, created and committed once and
+        kept for the following files (a 4-member htdemucs_ft used to re-pack and re-upload four weight sets per song); an
+        engine injected from outside (``self.engine`` set by the caller: the CPU test double) is shared, members loaded in turn."""
         hc, sd = self.models[idx]
-        if self.engine is None:
-            # the MDX geometry of the engine is unused on this path; any valid one will do
-            self.engine = Engine(MDXConfig(n_fft=hc.nfft, hop_length=hc.nfft // 4, dim_f=hc.nfft // 2, segment_size=8),
-                                 device=self.device)
-        if isinstance(hc, HDConfig):
-            self.engine.load_hd(hc, sd)
-            self._demix = self.engine.hd_demix
+        injected = self.engine is not None and not self._own
+        if injected:
+            if self._loaded == idx:
+                return
+            eng = self.engine
         else:
-            self.engine.load_ht(hc, sd)
-            self._demix = self.engine.ht_demix
+            self._own = True
+            if self.engines[idx] is not None:
+                self.engine, self._loaded = self.engines[idx], idx
+                self._demix = self.engine.hd_demix if isinstance(hc, HDConfig) else self.engine.ht_demix
+                return
+            # the MDX geometry of the engine is unused on this path; any valid one will do
+            eng = Engine(MDXConfig(n_fft=hc.nfft, hop_length=hc.nfft // 4, dim_f=hc.nfft // 2, segment_size=8), device=self.device)
+            self.engines[idx] = eng
+            self.engine = eng
+        if isinstance(hc, HDConfig):
+            eng.load_hd(hc, sd)
+            self._demix = eng.hd_demix
+        else:
+            eng.load_ht(hc, sd)
+            self._demix = eng.ht_demix
         self._loaded = idx
+
+    def close(self):
+        for e in self.engines:
+            if e is not None:
+                e.close()
+        self.engines = [None] * len(self.models)
+        self.engine, self._loaded = None, None
+
+    def _draw_offsets(self, i, offsets):
+        if not self.shifts:
+            return None
+        hc = self.models[i][0]
+        return offsets[i] if offsets is not None else [random.randint(0, int(0.5 * hc.samplerate)) for _ in range(self.shifts)]
+
+    def bag_demix_dev(self, mix_d, out_d, offsets=None):
+        """BagOfModels with everything in HBM (``mix_d`` [2, N] -> ``out_d`` [S, 2, N], CUDA tensors): standardise once, every
+        member demixes the standardised mix on its own resident engine, weighted sum / totals / de-standardise / stem swap by
+        asx_ht_bag_* (apply.py:169-196, demucs_separator.py:171-189).  Only enqueues work on the current stream."""
+        import torch
+        st = torch.cuda.current_stream(mix_d.device).cuda_stream
+        n = mix_d.shape[1]
+        S = len(self.models[0][0].sources)
+        ws = getattr(self, "_bag_ws", None)
+        if ws is None or ws[0].shape != mix_d.shape or ws[0].device != mix_d.device:
+            est = torch.empty((S, 2, n), dtype=torch.float32, device=mix_d.device)
+            ws = self._bag_ws = (torch.empty_like(mix_d), est, torch.empty_like(est))
+        std_d, est_d, mem_d = ws
+        totals = np.zeros(S, np.float64)
+        for i in range(len(self.models)):
+            self._load(i)
+            eng = self.engine
+            if i == 0:
+                eng.ht_standardize_dev(mix_d.data_ptr(), n, std_d.data_ptr(), stream=st)
+            offs = self._draw_offsets(i, offsets)
+            run = eng.hd_demix_dev if isinstance(self.models[i][0], HDConfig) else eng.ht_demix_dev
+            run(std_d.data_ptr(), n, mem_d.data_ptr(), shifts=self.shifts, offsets=offs, overlap=self.overlap, flags=0, stream=st)
+            eng.ht_bag_accumulate_dev(est_d.data_ptr(), mem_d.data_ptr(), self.weights[i], n, first=(i == 0), stream=st)
+            totals += np.asarray(self.weights[i], np.float64)
+        self.engine.ht_bag_finish_dev(est_d.data_ptr(), totals.astype(np.float32), mix_d.data_ptr(), n, out_d.data_ptr(),
+                                      standardize=True, swap01=True, stream=st)
+
+    def _bag_on_device(self, mix: np.ndarray, offsets):
+        """One upload of the mix, one download of the result around bag_demix_dev."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        mix_d = torch.from_numpy(mix).to(dev)
+        out_d = torch.empty((len(self.models[0][0].sources), 2, mix.shape[1]), dtype=torch.float32, device=dev)
+        self.bag_demix_dev(mix_d, out_d, offsets)
+        return out_d.cpu().numpy()
 
     def demix(self, mix: np.ndarray, offsets=None) -> np.ndarray:
         """demix_demucs: [2, N] -> [S, 2, N].  offsets (optional) pins the shift draws, one list per model."""
@@ -139,13 +210,11 @@ class DemucsDemixer:
         est = None
         totals = np.zeros(len(self.models[0][0].sources), np.float64)
         single = len(self.models) == 1 and self.segments_enabled   # split=False combines on the host like a bag
+        if not single and self.segments_enabled and (self._own or self.engine is None) and _cuda_ready():
+            return self._bag_on_device(mix, offsets)
         for i in range(len(self.models)):
             self._load(i)
-            hc = self.models[i][0]
-            offs = None
-            if self.shifts:
-                offs = offsets[i] if offsets is not None else [random.randint(0, int(0.5 * hc.samplerate))
-                                                               for _ in range(self.shifts)]
+            offs = self._draw_offsets(i, offsets)
             # a single model is de-standardised and swapped inside the engine; a bag is combined first (apply.py:186-196)
             out = self._demix(mix, shifts=self.shifts, offsets=offs, overlap=self.overlap, standardize=single,
                               swap01=single) if single else self._bag_member(mix, offs)

@@ -227,7 +227,7 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
            "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev",
            "asx_hd_begin", "asx_hd_commit", "asx_hd_flops", "asx_hd_forward", "asx_hd_demix", "asx_hd_demix_dev", "asx_hd_plan",
-           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_debug_trace"]
+           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev", "asx_ht_standardize_dev", "asx_ht_bag_accumulate_dev", "asx_ht_bag_finish_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_debug_trace"]
 
 
 def load_library():
@@ -316,6 +316,9 @@ def load_library():
     lib.asx_pcm16_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp, _FP, vp]
     lib.asx_pcm16_rows_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp, _FP, vp]
     lib.asx_pcm_decode_dev.argtypes = [vp, vp, i64, i32, i32, vp, _FP, vp]
+    lib.asx_ht_standardize_dev.argtypes = [vp, vp, i64, vp, vp]
+    lib.asx_ht_bag_accumulate_dev.argtypes = [vp, vp, vp, _FP, i32, i64, i32, vp]
+    lib.asx_ht_bag_finish_dev.argtypes = [vp, vp, _FP, i32, vp, i64, C.c_uint32, vp, vp]
     lib.asx_mdxc_chunks_dev.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     lib.asx_mdxc_finalize_dev.argtypes = [vp, vp, i64, i32, vp, vp]
     lib.asx_rof_plan.argtypes = [vp, i64, i64, C.POINTER(i32), C.POINTER(i64)]
@@ -577,6 +580,21 @@ class Engine:
         offs = (C.c_int64 * shifts)(*[int(o) for o in offsets]) if shifts else None
         self._check(self._lib.asx_ht_demix_dev(self._h, mix_ptr, n_samples, int(shifts), offs, float(overlap), flags,
                                                out_ptr, stream or None))
+
+    # -- BagOfModels combine on the device -----------------------------------------
+    def ht_standardize_dev(self, mix_ptr: int, n_samples: int, out_ptr: int, stream: int = 0):
+        self._check(self._lib.asx_ht_standardize_dev(self._h, mix_ptr, n_samples, out_ptr, stream or None))
+
+    def ht_bag_accumulate_dev(self, est_ptr: int, member_ptr: int, weights, n_samples: int, first: bool, stream: int = 0):
+        w = (C.c_float * len(weights))(*[float(v) for v in weights])
+        self._check(self._lib.asx_ht_bag_accumulate_dev(self._h, est_ptr, member_ptr, w, len(weights), n_samples, int(bool(first)),
+                                                        stream or None))
+
+    def ht_bag_finish_dev(self, est_ptr: int, totals, mix_ptr: int, n_samples: int, out_ptr: int, standardize: bool = True,
+                          swap01: bool = True, stream: int = 0):
+        t = (C.c_float * len(totals))(*[float(v) for v in totals])
+        flags = (1 if standardize else 0) | (2 if swap01 else 0)
+        self._check(self._lib.asx_ht_bag_finish_dev(self._h, est_ptr, t, len(totals), mix_ptr, n_samples, flags, out_ptr, stream or None))
 
     # -- Demucs v3 ----------------------------------------------------------------
     def load_hd(self, hc: HDConfig, state_dict: dict):

@@ -123,6 +123,29 @@ def test_bag_of_models(A):
     assert rel_rms(got, est) < TOL, rel_rms(got, est)
 
 
+def test_bag_device_combine_equals_host_combine(A, monkeypatch):
+    """The bag path with everything in HBM (resident member engines, asx_ht_standardize_dev / asx_ht_bag_accumulate_dev /
+    asx_ht_bag_finish_dev) against the same members combined in numpy on the host (round 2's path): float32 arithmetic in the
+    reference's order on both sides -> identical arrays; and the member engines stay resident across calls."""
+    import audio_separator_amd.demucs as DM
+    oc = ocfg_a()
+    sds = [D.make_ht_state(oc, 11), D.make_ht_state(oc, 21), D.make_ht_state(oc, 31)]
+    w = [[1.0, 0.0, 2.0, 0.5], [0.0, 1.0, 1.0, 1.0], [0.25, 0.5, 0.0, 1.0]]
+    offs = [[100, 3000], [2222, 17], [5, 3999]]
+    mix = (0.3 * np.random.default_rng(9).standard_normal((2, 12345)) + 0.01).astype(np.float32)
+    mk = lambda: A.DemucsDemixer({"torch_device": 0}, {"shifts": 2}, models=[(hcfg(A, oc), sd) for sd in sds], weights=w)  # noqa: E731
+    dm = mk()
+    got = dm.demix(mix, offsets=offs)
+    engines = list(dm.engines)
+    assert all(e is not None for e in engines)
+    again = dm.demix(mix, offsets=offs)
+    assert [id(e) for e in dm.engines] == [id(e) for e in engines] and np.array_equal(got, again)
+    monkeypatch.setattr(DM, "_cuda_ready", lambda: False)
+    host = mk().demix(mix, offsets=offs)
+    assert got.shape == host.shape
+    assert rel_rms(got, host) < 2e-7, rel_rms(got, host)
+
+
 def test_error_paths(A):
     oc = ocfg_a()
     dm = demixer(A, oc, 11)

@@ -210,6 +210,40 @@ def run_mdx23c(args):
                  "net_tflops_per_s": round(eng.v3_flops(plan["n_chunks"]) / dt / 1e12, 1)})
 
 
+def run_htdemucs_ft(args):
+    """htdemucs_ft layout: a BagOfModels of FOUR htdemucs-size members (one per source in the published bag; here per-source
+    weights like its YAML) through DemucsDemixer's device path -- resident engines, combine on the device."""
+    from oracle import demucs_oracle as D
+    oc = D.HTConfig()
+    hc = A.HTConfig(segment=Fraction(39, 5))
+    models = [(hc, D.make_ht_state(oc, seed)) for seed in range(4)]
+    weights = [[1.0 if k == i else 0.0 for k in range(4)] for i in range(4)]     # htdemucs_ft.yaml: member i carries source i
+    dm = A.DemucsDemixer({"torch_device": 0}, {"shifts": 2, "overlap": 0.25}, models=models, weights=weights)
+    n = int(SR * args.seconds)
+    mix = torch.from_numpy(synth(n)).cuda()
+    out = torch.empty((4, 2, n), dtype=torch.float32, device="cuda")
+    offs = [[11025, 3000]] * 4
+    step = lambda: dm.bag_demix_dev(mix, out, offs)  # noqa: E731
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    first = time.perf_counter() - t0            # includes the four weight commits (once per process, not per file)
+    dt = timed(step, args.steps, args.warmup)
+    dm._load(0)
+    single = lambda: dm.engine.ht_demix_dev(mix.data_ptr(), n, out.data_ptr(), shifts=2, offsets=offs[0], flags=3,  # noqa: E731
+                                            stream=torch.cuda.current_stream().cuda_stream)
+    ds = timed(single, args.steps, args.warmup)
+    res = {"metric": "audio-sec separated / wall-sec (RTF)", "value": round(args.seconds / dt, 2), "unit": "audio-s/wall-s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": "htdemucs_ft layout: BagOfModels of 4 htdemucs-size members, shifts=2, overlap 0.25, 4-min song, device resident",
+                      "single_member_ms": round(ds * 1e3, 2), "bag_over_single": round(dt / ds, 3),
+                      "first_call_ms_with_weight_commits": round(first * 1e3, 1)},
+           "roofline": None, "cpu_baseline": None}
+    dm.close()
+    return res
+
+
 def run_hdemucs(args):
     from oracle import hdemucs_oracle as H
     oc = H.HDConfig(segment=44)
@@ -260,7 +294,8 @@ def main():
     ap.add_argument("--cpu", type=int, default=1)
     args = ap.parse_args()
     torch.cuda.set_device(0)
-    fns = {"vr": run_vr, "htdemucs": run_htdemucs, "hdemucs": run_hdemucs, "roformer": run_roformer, "mdx23c": run_mdx23c}
+    fns = {"vr": run_vr, "htdemucs": run_htdemucs, "hdemucs": run_hdemucs, "roformer": run_roformer, "mdx23c": run_mdx23c,
+           "htdemucs_ft": run_htdemucs_ft}
     for w in args.workloads.split(","):
         print(json.dumps(fns[w](args)), flush=True)
 
