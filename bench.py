@@ -59,10 +59,21 @@ def cpu_baseline(seconds: float, seed: int):
     out = O.demix(mix, O.MDXParams(), run)
     dt = time.perf_counter() - t0
     n_chunks = len(O.chunk_plan(mix.shape[1], O.MDXParams())[5])
+    # the whole 4-minute song through the same oracle has been timed once per round (tools/fullsong_*.py); quote the stored runs
+    whole = []
+    for name, key in (("r02_fullsong_parity.json", None), ("r03_fullsong_parity.json", "cases")):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                rec = json.load(fh)
+            c = rec["cases"]["mdx_hq3"]["cpu_oracle"] if key else rec["mdx_hq3_plain"]
+            whole.append(f"{c['cpu_wall_s']:g} s at {c['cpu_threads']} threads (profiles/{name})")
+        except Exception:
+            pass
+    note = ("; whole 4-min song on the same oracle: " + ", ".join(whole)) if whole else ""
     return out, mix, {"value": seconds / dt, "unit": "audio-s/wall-s", "cores": int(torch.get_num_threads()),
                       "kind": "port",
                       "sample": f"{seconds:g} s of the same synthetic song ({n_chunks} chunks), torch-CPU fp32 oracle, "
-                                f"{dt:.1f} s wall"}
+                                f"{dt:.1f} s wall" + note}
 
 
 _JSON_FD = None

@@ -282,10 +282,15 @@ static int hd_ensure_workspace(asx_engine *e, int B, int64_t L) {
       const int hp = (n.C[i] / c.dconv_comp + 3) & ~3;
       const size_t rows = std::max((size_t)B * d.T * n.F[i + 1], (size_t)B * n.L[i + 1]);
       hcap = std::max(hcap, rows * hp);
-      rcap = std::max(rcap, rows * ((2 * (size_t)n.C[i] + 95) / 96) * 2);
+      const int np = ht_glu_rows(n.C[i]);
+      rcap = std::max(rcap, rows * std::max<size_t>((np + gg_tile_n(np, true) - 1) / gg_tile_n(np, true), 1) * 2);
     }
     const size_t hneed = std::max((size_t)B * d.T * HA, (size_t)B * d.T2 * HZ);
-    const size_t rneed = std::max((size_t)B * d.T * ((2 * (size_t)CA + 15) / 16), (size_t)B * d.T2 * ((2 * (size_t)CZ + 15) / 16)) * 2;
+    auto gtiles = [](int ch) {
+      const int np = ht_glu_rows(ch);
+      return (size_t)std::max((np + gg_tile_n(np, true) - 1) / gg_tile_n(np, true), (ch / 2 + 15) / 16);   // c2 (GLU rows) and c1 (hid columns)
+    };
+    const size_t rneed = std::max((size_t)B * d.T * gtiles(CA), (size_t)B * d.T2 * gtiles(CZ)) * 2;
     REQUIRE(hneed <= hcap && rneed <= rcap, "DConv scratch of the strided levels is too small for the inner levels (%zu/%zu, %zu/%zu)",
             hneed, hcap, rneed, rcap);
   }
@@ -482,11 +487,17 @@ static int hd_local_state(asx_engine *e, const HdAttn &A, float *hbuf, int B, in
       a.exact = attn_exact;
       a.decay = b.qkvd + 3 * H;
       a.ldd = ld;
-      const dim3 grid((unsigned)((T + 63) / 64), 4, (unsigned)B);
+      a.nqt = (T + 63) / 64;
+      a.heads = 4;
+      const dim3 grid((unsigned)(a.nqt * 4 * B));   // 1-D, XCD-aware (kernels_ht.h)
+      static const bool hd_mha_db = !(getenv("ASX_MHA_DB") && atoi(getenv("ASX_MHA_DB")) == 0);
       switch (dh / 16) {
         case 1: hipLaunchKernelGGL((mha_kernel<1, true>), grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL((mha_kernel<2, true>), grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((mha_kernel<3, true>), grid, dim3(256), 0, s, a); break;
+        case 3:
+          if (hd_mha_db) hipLaunchKernelGGL((mha_kernel<3, true, true>), grid, dim3(256), 0, s, a);
+          else hipLaunchKernelGGL((mha_kernel<3, true>), grid, dim3(256), 0, s, a);
+          break;
         case 4: hipLaunchKernelGGL((mha_kernel<4, true>), grid, dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL((mha_kernel<6, true>), grid, dim3(256), 0, s, a); break;
       }

@@ -16,6 +16,7 @@ struct HtGemm {
   int n = 0, k = 0;
   DevBuf wh;                    // halo-tile packing of a k3 / 3x3 conv (kernels_halo.h); empty: not eligible
   int wh_nt = 0, wh_taps = 0;   // its N tile and tap count
+  int glu_c = 0;                // != 0: rows are in GLU order (ht_glu_perm) for glu_c output channels
 };
 struct HtDconv {
   HtGemm c1, c2;
@@ -131,13 +132,19 @@ static int ht_halo_pack(HtGemm &g, const std::vector<float> &pw, int taps, int c
   return ht_up(g.wh, ph);
 }
 
-// rows (a_2q, a_2q+1, g_2q, g_2q+1): a lane of the GEMM epilogue holds both halves of two GLU outputs
+// GLU row order: blocks of 32 rows = [a_c .. a_c+15 | g_c .. g_c+15] (c a multiple of 16), i.e. one MFMA fragment of 16 value
+// rows followed by the fragment of their 16 gates.  A lane of the GEMM epilogue then holds a[c + 4 lk .. + 3] in fragment 2 j and
+// the matching gates in fragment 2 j + 1: FOUR consecutive GLU outputs, written (and, in the DConv epilogue, read-modified) as one
+// 16-byte access.  (Rounds 1-2 interleaved (a, a, g, g) per four rows: two outputs per lane, 8-byte accesses -- the memory-bound
+// 1x1 / DConv launches ran at 1.4-2.6 TB/s.)  The channel count is padded to a multiple of 16 (zero rows): N = 32 ceil(c / 16).
+static inline int ht_glu_rows(int c) { return 32 * ((c + 15) / 16); }
 static void ht_glu_perm(std::vector<float> &w, std::vector<float> &b, int c, int k) {
-  std::vector<float> w2(w.size()), b2(b.size());
-  for (int q = 0; q < c / 2; ++q)
-    for (int r = 0; r < 4; ++r) {
-      const int src = (r < 2) ? 2 * q + r : c + 2 * q + (r - 2);
-      const int dst = 4 * q + r;
+  const int np = ht_glu_rows(c);
+  std::vector<float> w2((size_t)np * k, 0.f), b2((size_t)np, 0.f);
+  for (int ch = 0; ch < c; ++ch)
+    for (int half = 0; half < 2; ++half) {
+      const int src = half * c + ch;
+      const int dst = 32 * (ch >> 4) + 16 * half + (ch & 15);
       std::copy(w.begin() + (size_t)src * k, w.begin() + (size_t)(src + 1) * k, w2.begin() + (size_t)dst * k);
       b2[dst] = b[src];
     }
@@ -163,7 +170,13 @@ static int ht_pack_conv(asx_engine *e, HtGemm &g, const std::string &name, int c
         for (int c = 0; c < kb; ++c)
           pw[(size_t)n * K + ((size_t)c * ka + a) * cinp + ci] = w[(((size_t)n * cin + ci) * ka + a) * kb + c];
   }
-  if (glu) ht_glu_perm(pw, pb, cout / 2, K);
+  if (glu) {
+    pw.resize((size_t)cout * K);      // (npad == cout for every GLU layer)
+    pb.resize((size_t)cout);
+    ht_glu_perm(pw, pb, cout / 2, K);
+    npad = ht_glu_rows(cout / 2);
+    g.glu_c = cout / 2;
+  }
   g.n = npad;
   g.k = K;
   CHK(ht_up(g.w, pw));
@@ -505,7 +518,12 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
   a.mode = mode;
   a.act = act;
   a.Iout = Iout;
-  a.Cout = Cout;
+  a.Cout = (mode == GG_GLU || mode == GG_GNGLU) ? g.glu_c : Cout;
+  a.glu_rows = g.glu_c;
+  if ((mode == GG_GLU || mode == GG_GNGLU) && (g.glu_c == 0 || (g.glu_c & 3) || (ldy & 3) || (res && (ldr & 3)))) {
+    set_err("ht_gg: GLU epilogue on a GEMM without GLU row order, or channels / row strides not multiples of 4");
+    return ASX_ERR_INVALID;
+  }
   a.crop = q.crop;
   a.So = q.So;
   a.ldy = ldy;
@@ -566,6 +584,7 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
     h.inb = hgm.inb;
     h.mode = mode;
     h.act = act;
+    h.Cout = g.glu_c;
     const int Bn = (int)(rows_outer / q.O);
     return timed(e, cls, flops, bytes, s, [&]() {
       hg_dispatch(h, g.wh_nt, q.KO, Bn, s);
@@ -667,9 +686,13 @@ static int ht_mha(asx_engine *e, const float *q, int64_t ldq, const float *k, co
   a.exact = attn_exact;
   const double flops = 4.0 * (double)B * heads * (double)nq * nk * dh;
   const double bytes = 4.0 * (double)B * heads * dh * (2.0 * nq + 2.0 * nk);
-  const dim3 grid((unsigned)((nq + 63) / 64), (unsigned)heads, (unsigned)B);
+  a.nqt = (nq + 63) / 64;
+  a.heads = heads;
+  const dim3 grid((unsigned)(a.nqt * heads * B));   // 1-D, XCD-aware (kernels_ht.h)
   return timed(e, ASX_PROF_CONV1X1, flops, bytes, s, [&]() {   // profile class shared with the Roformer attention
-    if (dh == 48) hipLaunchKernelGGL((mha_kernel<3>), grid, dim3(256), 0, s, a);
+    static const bool mha_db = !(getenv("ASX_MHA_DB") && atoi(getenv("ASX_MHA_DB")) == 0);   // A/B: one barrier per key tile
+    if (dh == 48 && mha_db) hipLaunchKernelGGL((mha_kernel<3, false, true>), grid, dim3(256), 0, s, a);
+    else if (dh == 48) hipLaunchKernelGGL((mha_kernel<3>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((mha_kernel<4>), grid, dim3(256), 0, s, a);
   });
 }
@@ -735,7 +758,8 @@ static int ht_ensure_workspace(asx_engine *e, int B) {
   {   // per-row GroupNorm partials of the DConv GEMMs: [N tiles][rows][2]
     size_t rsz = 0;
     for (int i = 0; i < D; ++i) {
-      const size_t tiles = (2 * (size_t)n.C[i] + 95) / 96;
+      const int np = ht_glu_rows(n.C[i]);
+      const size_t tiles = std::max<size_t>((np + gg_tile_n(np, true) - 1) / gg_tile_n(np, true), 1);
       rsz = std::max(rsz, std::max(BT * n.F[i + 1], (size_t)B * n.L[i + 1]) * tiles * 2);
     }
     want(b.rowstat, rsz);
@@ -773,8 +797,8 @@ static int ht_dconv_layer(asx_engine *e, const HtEnc &E, size_t d, int part, flo
   const int G2 = along_outer ? I : 1;
   const int64_t R = along_outer ? O : I;
   const int64_t M = (int64_t)B * O * I;
-  auto fold = [&](int ncols, double count, double *acc, float2 *mr) {
-    const int ntile = (ncols + gg_tile_n(ncols) - 1) / gg_tile_n(ncols);   // N tiles of ht_gg's launch choice
+  auto fold = [&](int ncols, double count, double *acc, float2 *mr, bool glu = false) {
+    const int ntile = (ncols + gg_tile_n(ncols, glu) - 1) / gg_tile_n(ncols, glu);   // N tiles of ht_gg's launch choice
     unsigned gx = (unsigned)((G2 + 15) / 16);
     if (G2 == 1) {
       gx = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, R / 4096));
@@ -817,7 +841,7 @@ static int ht_dconv_layer(asx_engine *e, const HtEnc &E, size_t d, int part, flo
     g1.ldc = dc.hp;
     g1.IR = I;
     CHK(ht_gg(e, dc.c2, n.b.h, g1, (int64_t)B * O, nullptr, 2 * C, GG_STATS, 0, nullptr, 0, 0, 0, 0, s, &f1));
-    CHK(fold(2 * C, (double)R * 2 * C, n.b.acc_g2, reinterpret_cast<float2 *>(n.b.mr_g)));
+    CHK(fold(dc.c2.n, (double)R * 2 * C, n.b.acc_g2, reinterpret_cast<float2 *>(n.b.mr_g), true));
     HtFuse f3 = f1;
     f3.row_stat = nullptr;
     f3.stat_in = reinterpret_cast<const float2 *>(n.b.mr_g);

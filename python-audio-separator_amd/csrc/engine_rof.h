@@ -332,11 +332,21 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
       const double fl = 4.0 * (double)nseq * H * (double)aa.len * aa.len * c.dim_head;
       CHK(timed(e, ASX_PROF_CONV1X1, fl, 4.0 * M * 4 * inner, s, [&]() {
         static const bool v1 = getenv("ASX_ATTN_V1") && atoi(getenv("ASX_ATTN_V1")) != 0;   // the 4-byte-fragment kernel (A/B)
+        static const bool attn_db = getenv("ASX_ATTN_DB") && atoi(getenv("ASX_ATTN_DB")) != 0;   // A/B (default off until measured)
         static const int qw = getenv("ASX_ATTN_QW") ? atoi(getenv("ASX_ATTN_QW")) : 1;   // 2: 128 queries per workgroup (measured slower: 357 vs 328 ms)
         if (v1) hipLaunchKernelGGL(attention_kernel, dim3(qtiles, H, (unsigned)nseq), dim3(256), 0, s, aa);
-        else if (qw >= 2 && aa.len > 64)
-          hipLaunchKernelGGL(attention2_kernel<2>, dim3((aa.len + 127) / 128, H, (unsigned)nseq), dim3(256), 0, s, aa);
-        else hipLaunchKernelGGL(attention2_kernel<1>, dim3(qtiles, H, (unsigned)nseq), dim3(256), 0, s, aa);
+        else if (qw >= 2 && aa.len > 64) {
+          AttnArgs a2 = aa;
+          a2.nqt = (aa.len + 127) / 128;
+          hipLaunchKernelGGL(attention2_kernel<2>, dim3((unsigned)(a2.nqt * H * nseq)), dim3(256), 0, s, a2);
+        } else {
+          AttnArgs a2 = aa;
+          a2.nqt = qtiles;
+          const dim3 grid((unsigned)((int64_t)qtiles * H * nseq));   // 1-D, XCD-aware (kernels_rof.h)
+          if (attn_db && aa.len > 128)   // several key tiles: one barrier per tile (double-buffered K / V)
+            hipLaunchKernelGGL((attention2_kernel<1, true>), grid, dim3(256), 0, s, a2);
+          else hipLaunchKernelGGL(attention2_kernel<1>, grid, dim3(256), 0, s, a2);
+        }
       }));
     }
     CHK(rof_gemm(e, L.attn.out, n.ATT.f(), inner, Mg, n.TOK.f(), D, 0, n.TOK.f(), D, s));   // + x (in place: each

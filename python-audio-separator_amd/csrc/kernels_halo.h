@@ -15,8 +15,12 @@
 //           contiguous bytes of global memory); the swap of the halves on every second group of 8 pixels makes the fragment
 //           read -- lanes (li, lk) read 8 bytes of pixel q0 + li, half lk >> 1 -- cover 64 distinct banks per 32-lane group
 //           for ANY q0 (ds_read_b64: bank = (a / 4) mod 64).
-//   weight: [tap][half][NT columns][4 channels], packed on the host in exactly that order (hg_pack_weights), so a sub-stage
-//           is one contiguous copy and lanes (li, lk) of a fragment read 256 contiguous bytes per 32-lane group.
+//   weight: [tap][lk (4 channel pairs)][NT columns][2 channels] with a plane stride of 2 NT + 32 floats, packed on the host in
+//           exactly that order (hg_pack_weights), so a sub-stage is one contiguous copy.  The 16 lanes of a fragment row read
+//           128 contiguous bytes and the planes of lk and lk + 1 start 32 banks apart: conflict-free both as ds_read_b64
+//           (2 x 32 lanes, 64 banks) and as the ds_read2_b64 the compiler merges neighbouring fragments into (4 x 16 lanes,
+//           32 banks) -- the first layout ([tap][half][NT][4]) was 2-way conflicting under ds_read2_b64:
+//           SQ_LDS_BANK_CONFLICT 45 % of the LDS cycles (profiles/r03_pmc_halo.txt).
 // One MFMA k-step = 4 channels: k index lk carries channel 4 (lk >> 1) + 2 (lk & 1) + kk for the kk-th of the two MFMAs fed
 // by one 8-byte read -- the same permutation on both operands.
 #pragma once
@@ -38,12 +42,14 @@ struct HgArgs {
   int til2, tilesO, tilesI;     // TI = 1 << til2, TO = 256 >> til2
   int IWt, NPIX, inb;           // haloed block width, pixels, floats per input buffer (multiple of 256)
   int mode, act;                // GG_DENSE / GG_GLU, tdf_act() enum
+  int Cout;                     // GG_GLU: output channels (the GEMM's rows are value / gate fragment pairs, engine_ht.h: ht_glu_perm)
 };
 
 template <int NREP, int KO>
 __global__ __launch_bounds__(256, (NREP <= 6 ? 3 : 2)) void hg_kernel(HgArgs a) {
   constexpr int KI = 3, MREP = 4, NT = 16 * NREP;
-  constexpr int WSUB = KI * 2 * NT * 4;      // floats per weight sub-stage (one tap row)
+  constexpr int PS = 2 * NT + 32;            // floats per (tap, lk) weight plane
+  constexpr int WSUB = (KI * 4 * PS + 255) / 256 * 256;   // floats per weight sub-stage (one tap row), whole 1-KiB DMA pieces
   constexpr int NWI = WSUB / 256;            // wave-issues per sub-stage
   extern __shared__ float lds_f[];
 
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256, (NREP <= 6 ? 3 : 2)) void hg_kernel(HgArgs a) 
     for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int NS = a.NCH * KO;
-  const int wlane = ((lk >> 1) * NT + li) * 4 + (lk & 1) * 2;   // this lane's float offset inside a tap's weight image
+  const int wlane = lk * PS + li * 2;   // this lane's float offset inside a tap's weight image
   const int hsel = lk >> 1, lo2 = (lk & 1) * 2;
   issue_in(0, 0);
   issue_w(0, 0);
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256, (NREP <= 6 ? 3 : 2)) void hg_kernel(HgArgs a) 
       const int toff = ky * a.DO * a.IWt + kx * a.DI;
       f32x2 wb[NREP];
 #pragma unroll
-      for (int n = 0; n < NREP; ++n) wb[n] = *reinterpret_cast<const f32x2 *>(&w_s[kx * (2 * NT * 4) + n * 64 + wlane]);
+      for (int n = 0; n < NREP; ++n) wb[n] = *reinterpret_cast<const f32x2 *>(&w_s[kx * (4 * PS) + n * 32 + wlane]);
       f32x2 xa[MREP];
 #pragma unroll
       for (int m = 0; m < MREP; ++m) {
@@ -170,8 +176,17 @@ __global__ __launch_bounds__(256, (NREP <= 6 ? 3 : 2)) void hg_kernel(HgArgs a) 
       f32x4 v = acc[n][m];
       if (a.bias != nullptr) v += *reinterpret_cast<const f32x4 *>(a.bias + col);
       if (a.mode == GG_GLU) {
-        const float2 o2 = make_float2(v.x * fast_sigmoid(v.z), v.y * fast_sigmoid(v.w));
-        *reinterpret_cast<float2 *>(yr + (col >> 1)) = o2;
+        if (n & 1) continue;                       // gate fragment: consumed with its value fragment
+        const int oc = ((n0 + n * 16) >> 1) + lk * 4;
+        if (oc >= a.Cout) continue;
+        f32x4 g4 = acc[n + 1 < NREP ? n + 1 : n][m];
+        if (a.bias != nullptr) g4 += *reinterpret_cast<const f32x4 *>(a.bias + col + 16);
+        f32x4 o4;
+        o4.x = v.x * fast_sigmoid(g4.x);
+        o4.y = v.y * fast_sigmoid(g4.y);
+        o4.z = v.z * fast_sigmoid(g4.z);
+        o4.w = v.w * fast_sigmoid(g4.w);
+        *reinterpret_cast<f32x4 *>(yr + oc) = o4;
       } else {
         f32x4 o4;
         o4.x = tdf_act(v.x, a.act);
@@ -194,20 +209,26 @@ static inline int hg_tile_n(int n) {
   return p96 <= p128 ? 96 : 128;
 }
 
-// [N, K = tap*Cin + ci] row-major (the gg_kernel layout) -> [N tile][chunk][tap][half][NT][4]
+// floats of one weight sub-stage (a tap row of 3 taps) in the packed image
+static inline int hg_wsub(int NT) { return (3 * 4 * (2 * NT + 32) + 255) / 256 * 256; }
+
+// [N, K = tap*Cin + ci] row-major (the gg_kernel layout) -> [N tile][chunk][tap row][tap][lk][NT (+16 pad)][2], every tap row
+// padded to whole 1-KiB pieces; lk carries channels 2 lk, 2 lk + 1 of the chunk
 static inline void hg_pack_weights(const std::vector<float> &w, int N, int taps, int cin, int NT, std::vector<float> &out) {
-  const int nbn = (N + NT - 1) / NT, nch = cin / HG_KC, K = taps * cin;
-  out.assign((size_t)nbn * nch * taps * 2 * NT * 4, 0.f);
-  size_t p = 0;
+  const int nbn = (N + NT - 1) / NT, nch = cin / HG_KC, K = taps * cin, KO = taps / 3, PS = 2 * NT + 32, WSUB = hg_wsub(NT);
+  out.assign((size_t)nbn * nch * KO * WSUB, 0.f);
   for (int t = 0; t < nbn; ++t)
     for (int c = 0; c < nch; ++c)
-      for (int tap = 0; tap < taps; ++tap)
-        for (int h = 0; h < 2; ++h)
-          for (int n = 0; n < NT; ++n)
-            for (int j = 0; j < 4; ++j, ++p) {
-              const int row = t * NT + n;
-              if (row < N) out[p] = w[(size_t)row * K + (size_t)tap * cin + c * HG_KC + h * 4 + j];
-            }
+      for (int ky = 0; ky < KO; ++ky) {
+        float *sub = out.data() + ((size_t)(t * nch + c) * KO + ky) * WSUB;
+        for (int kx = 0; kx < 3; ++kx)
+          for (int lk = 0; lk < 4; ++lk)
+            for (int n = 0; n < NT; ++n)
+              for (int j = 0; j < 2; ++j) {
+                const int row = t * NT + n;
+                if (row < N) sub[(kx * 4 + lk) * PS + n * 2 + j] = w[(size_t)row * K + (size_t)(ky * 3 + kx) * cin + c * HG_KC + lk * 2 + j];
+              }
+      }
 }
 
 struct HgGeom {
@@ -235,7 +256,7 @@ static inline bool hg_geometry(int O, int I, int KO, int DO, int DI, HgGeom *g) 
 
 template <int NREP, int KO>
 static void hg_launch(const HgArgs &a, int64_t nblocks, hipStream_t s) {
-  constexpr int WSUB = 3 * 2 * 16 * NREP * 4;
+  const int WSUB = hg_wsub(16 * NREP);
   const int lds = (2 * a.inb + 2 * WSUB) * 4;
   static int granted = 0;
   if (lds > granted) {

@@ -42,6 +42,7 @@ struct GgArgs {
   int64_t g_outer;
   int g_mod;
   const float *gamma, *beta, *ls;   // GG_GNGLU: GroupNorm affine (row order of w) and the LayerScale of the GLU outputs
+  int glu_rows;                 // != 0: w's rows are in GLU order (ht_glu_perm) -- GG_GLU / GG_GNGLU and the GG_STATS pass of the same GEMM
 };
 
 // Wave layout: MS = false -- the four waves split the N tile (wave w owns columns [16*NREP*w, +16*NREP) of all BM = 16*MREP
@@ -187,8 +188,11 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
   // epilogue: lane (li, lk) holds 4 consecutive columns of row m*16 + li
   const bool want_stats = a.row_stat != nullptr;
   if (a.mode == GG_GNGLU) {
-    // y[row, c] += ls[c] * glu(groupnorm(z))[c]; all read-modify-write loads are issued before the first store
-    float2 old[MREP][NREP];
+    // y[row, c] += ls[c] * glu(groupnorm(z))[c].  GLU row order (engine_ht.h: ht_glu_perm): fragment 2 j holds 16 values, fragment
+    // 2 j + 1 their gates, so this lane owns FOUR consecutive output channels per fragment pair: 16-byte read-modify-write.
+    // All loads are issued before the first store.
+    constexpr int NP = NREP / 2;
+    f32x4 old[MREP][NP > 0 ? NP : 1];
     float2 mr[MREP];
     int64_t gb = (m0 + xrow0 + li) / a.g_outer;
     int64_t gr = (m0 + xrow0 + li) - gb * a.g_outer;     // row inside the batch item
@@ -206,31 +210,35 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
         ++gb;
       }
 #pragma unroll
-      for (int n = 0; n < NREP; ++n) {
-        const int col = n0 + wcol0 + n * 16 + lk * 4;
-        old[m][n] = make_float2(0.f, 0.f);
-        if (row < a.M && col < a.N) old[m][n] = *reinterpret_cast<const float2 *>(a.y + row * a.ldy + (col >> 1));
+      for (int j = 0; j < NP; ++j) {
+        const int oc = ((n0 + wcol0 + j * 32) >> 1) + lk * 4;      // output channel of this lane's four values
+        old[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (row < a.M && oc < a.Cout) old[m][j] = *reinterpret_cast<const f32x4 *>(a.y + row * a.ldy + oc);
       }
     }
 #pragma unroll
-    for (int n = 0; n < NREP; ++n) {
-      const int col = n0 + wcol0 + n * 16 + lk * 4;
-      if (col >= a.N) continue;
-      const f32x4 bz = *reinterpret_cast<const f32x4 *>(a.bias + col);
-      const f32x4 ga = *reinterpret_cast<const f32x4 *>(a.gamma + col), be = *reinterpret_cast<const f32x4 *>(a.beta + col);
-      const float2 l2 = *reinterpret_cast<const float2 *>(a.ls + (col >> 1));
+    for (int j = 0; j < NP; ++j) {
+      const int ca = n0 + wcol0 + j * 32 + lk * 4, cg = ca + 16;   // value / gate columns of the GEMM
+      const int oc = ((n0 + wcol0 + j * 32) >> 1) + lk * 4;
+      if (oc >= a.Cout) continue;
+      const f32x4 bza = *reinterpret_cast<const f32x4 *>(a.bias + ca), bzg = *reinterpret_cast<const f32x4 *>(a.bias + cg);
+      const f32x4 gaa = *reinterpret_cast<const f32x4 *>(a.gamma + ca), gag = *reinterpret_cast<const f32x4 *>(a.gamma + cg);
+      const f32x4 bea = *reinterpret_cast<const f32x4 *>(a.beta + ca), beg = *reinterpret_cast<const f32x4 *>(a.beta + cg);
+      const f32x4 l4 = *reinterpret_cast<const f32x4 *>(a.ls + oc);
 #pragma unroll
       for (int m = 0; m < MREP; ++m) {
         const int64_t row = m0 + xrow0 + m * 16 + li;
         if (row >= a.M) continue;
-        const f32x4 v = acc[n][m] + bz;
-        const float gm = mr[m].x, gr = mr[m].y;
-        const float nx = (v.x - gm) * gr * ga.x + be.x, ny = (v.y - gm) * gr * ga.y + be.y;
-        const float nz = (v.z - gm) * gr * ga.z + be.z, nw = (v.w - gm) * gr * ga.w + be.w;
-        float2 o = old[m][n];
-        o.x += l2.x * (nx * fast_sigmoid(nz));
-        o.y += l2.y * (ny * fast_sigmoid(nw));
-        *reinterpret_cast<float2 *>(a.y + row * a.ldy + (col >> 1)) = o;
+        const f32x4 va = acc[2 * j][m] + bza, vg = acc[2 * j + 1][m] + bzg;
+        const float gmn = mr[m].x, grs = mr[m].y;
+        f32x4 o = old[m][j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float nv = (va[r] - gmn) * grs * gaa[r] + bea[r];
+          const float ng = (vg[r] - gmn) * grs * gag[r] + beg[r];
+          o[r] += l4[r] * (nv * fast_sigmoid(ng));
+        }
+        *reinterpret_cast<f32x4 *>(a.y + row * a.ldy + oc) = o;
       }
     }
     return;
@@ -267,14 +275,19 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(GgArgs a) {
       }
       if (a.mode == GG_STATS) continue;
       if (a.mode == GG_GLU) {
-        float2 o = make_float2(v.x * fast_sigmoid(v.z), v.y * fast_sigmoid(v.w));
-        const int c2 = col >> 1;
-        if (a.res != nullptr) {
-          const float2 r = *reinterpret_cast<const float2 *>(a.res + rrow * a.ldr + c2);
-          o.x += r.x;
-          o.y += r.y;
-        }
-        *reinterpret_cast<float2 *>(a.y + yrow + c2) = o;
+        // fragment pairs (values, gates): four consecutive GLU outputs per lane, one 16-byte store (ht_glu_perm)
+        if (n & 1) continue;                         // handled together with its value fragment
+        const int oc = ((n0 + wcol0 + n * 16) >> 1) + lk * 4;
+        if (oc >= a.Cout) continue;
+        f32x4 g4 = acc[n + 1 < NREP ? n + 1 : n][m];
+        if (a.bias != nullptr) g4 += *reinterpret_cast<const f32x4 *>(a.bias + col + 16);
+        f32x4 o;
+        o.x = v.x * fast_sigmoid(g4.x);
+        o.y = v.y * fast_sigmoid(g4.y);
+        o.z = v.z * fast_sigmoid(g4.z);
+        o.w = v.w * fast_sigmoid(g4.w);
+        if (a.res != nullptr) o += *reinterpret_cast<const f32x4 *>(a.res + rrow * a.ldr + oc);
+        *reinterpret_cast<f32x4 *>(a.y + yrow + oc) = o;
       } else {
         f32x4 o;
         o.x = tdf_act(v.x, a.act);
@@ -448,9 +461,15 @@ static void ht_launch_gg(const GgArgs &a, hipStream_t s) {
 }
 
 // N tile width ht_gg_dispatch will use for an output of n columns (rowstat_reduce_kernel needs the tile count)
-static inline int gg_tile_n(int n) {
+// glu: the launch runs a GLU epilogue (value / gate fragment pairs must sit in ONE wave: no 16- or 48-column tiles, and not
+// the 64-column tile whose four waves own 16 columns each)
+static inline int gg_tile_n(int n, bool glu = false) {
   static const bool legacy = getenv("ASX_GG_LEGACY") != nullptr;
-  if (legacy) return n > 64 ? 128 : 64;
+  if (legacy && !glu) return n > 64 ? 128 : 64;
+  if (glu) {
+    if (n <= 32) return 32;
+    if (n <= 64) return 32;
+  }
   if (n <= 16) return 16;
   if (n <= 32) return 32;
   if (n <= 48) return 48;
@@ -460,7 +479,7 @@ static inline int gg_tile_n(int n) {
 }
 
 static void ht_gg_dispatch(const GgArgs &a, hipStream_t s) {
-  switch (gg_tile_n(a.N)) {
+  switch (gg_tile_n(a.N, a.glu_rows != 0)) {
     case 16: ht_launch_gg<1, 4, true>(a, s); break;
     case 32: ht_launch_gg<2, 4, true>(a, s); break;
     case 48: ht_launch_gg<3, 4, true>(a, s); break;
@@ -488,18 +507,31 @@ struct MhaArgs {
   // slope D = 1/4 * sum_f (f + 1) * sigmoid(logit_f); score -= |key - query| * D, and the diagonal is set to -100
   const float *decay;
   int64_t ldd;
+  int nqt, heads;   // query tiles and heads: the 1-D grid is nqt * heads * batch workgroups
 };
 
-template <int DT, bool DECAY = false>
+// DB (double-buffered key / value tiles, head dims up to 48): tile t + 1 is written into the other LDS buffer while tile t is
+// consumed, so ONE workgroup barrier per key tile remains instead of two (the barriers between the three co-resident
+// workgroups, not the fragment reads or the K / V stream, are what held this kernel at ~57 % of the MFMA peak -- kernels_rof.h);
+// 52 KB of LDS at DH = 48 keeps three workgroups per CU, and the global loads run two tiles ahead.
+template <int DT, bool DECAY = false, bool DB = false>
 __global__ __launch_bounds__(256) void mha_kernel(MhaArgs a) {
   constexpr int DH = 16 * DT, QS = DH + 2, VS = DH + 4, C4 = DH / 4;
-  // Q is staged through the K tile's space (its fragments move to registers before the first K tile is written):
+  constexpr int TILE = 64 * QS + 64 * VS;
+  // Q is staged through a K tile's space (its fragments move to registers before that tile is written):
   // head dim 96 fits the 64 KB of static LDS
-  __shared__ float lds[64 * QS + 64 * VS];
-  float *Qs = lds, *Ks = lds, *Vs = lds + 64 * QS;
+  __shared__ float lds[(DB ? 2 : 1) * TILE];
+  float *Qs = DB ? lds + TILE : lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // 1-D grid, XCD-aware: the query tiles of one (batch item, head) get consecutive logical ids, i.e. run on ONE XCD and share
+  // its L2 copy of that head's K / V (1 MB at 2688 tokens).  With the (q tile, head, batch) grid the dispatcher dealt the
+  // query tiles of a head round-robin over the eight XCDs and every L2 had to hold every head: 6.8x the algorithmic bytes
+  // came from HBM (rocprofv3 FETCH_SIZE, profiles/r03_pmc_halo.txt).
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = lid % a.nqt;
+  lid /= a.nqt;
+  const int h = lid % a.heads, b = lid / a.heads;
   const int q0 = qt * 64;
   const float *qp = a.q + (int64_t)b * a.nq * a.ldq + h * DH;
   const float *kp = a.k + (int64_t)b * a.nk * a.ldk + h * DH;
@@ -540,6 +572,22 @@ __global__ __launch_bounds__(256) void mha_kernel(MhaArgs a) {
       }
     }
   };
+  auto stage = [&](int buf) {          // registers -> LDS tile `buf`
+    float *Kb = lds + buf * TILE, *Vb = Kb + 64 * QS;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + i * 256;
+      if (e < 64 * C4) {
+        const int r = e / C4, c4 = e - r * C4;
+        float *dk = &Kb[r * QS + c4 * 4];
+        dk[0] = kreg[i].x;
+        dk[1] = kreg[i].y;
+        dk[2] = kreg[i].z;
+        dk[3] = kreg[i].w;
+        *reinterpret_cast<float4 *>(&Vb[r * VS + c4 * 4]) = vreg[i];
+      }
+    }
+  };
   fetch(0);
   __syncthreads();   // Q staged
   float bqr[DH / 4];
@@ -553,24 +601,30 @@ __global__ __launch_bounds__(256) void mha_kernel(MhaArgs a) {
     for (int f = 0; f < 4; ++f) slope += (float)(f + 1) * (1.0f / (1.0f + expf(-dr[f])));
     slope *= 0.25f;
   }
+  if (DB) {
+    stage(0);                          // buffer 0 is untouched so far (Q sits in buffer 1)
+    if (nkt > 1) fetch(1);
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * 64;
-    __syncthreads();   // previous tile fully consumed
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int e = tid + i * 256;
-      if (e < 64 * C4) {
-        const int r = e / C4, c4 = e - r * C4;
-        float *dk = &Ks[r * QS + c4 * 4];
-        dk[0] = kreg[i].x;
-        dk[1] = kreg[i].y;
-        dk[2] = kreg[i].z;
-        dk[3] = kreg[i].w;
-        *reinterpret_cast<float4 *>(&Vs[r * VS + c4 * 4]) = vreg[i];
+    const float *Ks, *Vs;
+    if (DB) {
+      // tile kt is visible in buffer kt & 1; everyone has finished with buffer (kt + 1) & 1 (tile kt - 1, or the Q stage)
+      __syncthreads();
+      if (kt + 1 < nkt) {
+        stage((kt + 1) & 1);
+        if (kt + 2 < nkt) fetch(kt + 2);
       }
+      Ks = lds + (kt & 1) * TILE;
+      Vs = Ks + 64 * QS;
+    } else {
+      __syncthreads();   // previous tile fully consumed
+      stage(0);
+      __syncthreads();
+      if (kt + 1 < nkt) fetch(kt + 1);
+      Ks = lds;
+      Vs = lds + 64 * QS;
     }
-    __syncthreads();
-    if (kt + 1 < nkt) fetch(kt + 1);
 
     f32x4 st[4];
 #pragma unroll

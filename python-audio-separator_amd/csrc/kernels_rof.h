@@ -98,6 +98,7 @@ struct AttnArgs {
   int64_t outer_stride, inner_stride;
   float scale;
   int exact;          // 1: libm expf in the softmax; 0: the hardware exp unit (2 ulp, ASX_ATTN_EXACT unset)
+  int nqt;            // attention2_kernel: query tiles per sequence (its grid is nqt * heads * sequences workgroups, 1-D)
 };
 
 constexpr int ATT_QS = 66;  // LDS row strides (floats): Q/K == 2 (mod 32), V == 4 (mod 8)
@@ -270,15 +271,24 @@ constexpr int ATT2_S = 68;
 // layout: QW = 2 357 ms, QW = 1 328 ms (the 4-byte-fragment attention_kernel: 335 ms) -- neither the fragment reads nor the
 // K / V stream bind this kernel; the two workgroup barriers per key tile between three co-resident workgroups do.  QW = 1 is
 // the default.
-template <int QW>
-__global__ __launch_bounds__(256, QW == 1 ? 3 : 2) void attention2_kernel(AttnArgs a) {
+// DB: two K / V tile buffers (Q staged through the second one), tile t + 1 written while tile t is consumed -> ONE barrier
+// per key tile; 69.6 KB of LDS, two workgroups per CU (A/B against three workgroups with two barriers: ASX_ATTN_DB).
+template <int QW, bool DB = false>
+__global__ __launch_bounds__(256, (QW == 1 && !DB) ? 3 : 2) void attention2_kernel(AttnArgs a) {
   constexpr int NQ = 64 * QW;                               // queries per workgroup
-  __shared__ float lds[(NQ + 128) * ATT2_S];
-  float *Qs = lds, *Ks = lds + NQ * ATT2_S, *Vt = Ks + 64 * ATT2_S;
+  constexpr int TILE = 128 * ATT2_S;
+  static_assert(!DB || NQ * ATT2_S <= TILE, "Q must fit a K / V tile buffer");
+  __shared__ float lds[DB ? 2 * TILE : (NQ + 128) * ATT2_S];
+  float *Qs = DB ? lds + TILE : lds;
+  float *const kv0 = DB ? lds : lds + NQ * ATT2_S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  const int qt = blockIdx.x, h = blockIdx.y;
-  const int64_t sq = blockIdx.z;
+  // 1-D grid, XCD-aware: the query tiles of one (sequence, head) run on one XCD and share its L2 copy of that head's K / V
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = lid % a.nqt;
+  lid /= a.nqt;
+  const int h = lid % a.heads;
+  const int64_t sq = lid / a.heads;
   const int64_t base = (sq / a.inner_cnt) * a.outer_stride + (sq % a.inner_cnt) * a.inner_stride;
   const int inner = a.heads * 64;
   const int64_t ld = 3 * (int64_t)inner;
@@ -319,6 +329,18 @@ __global__ __launch_bounds__(256, QW == 1 ? 3 : 2) void attention2_kernel(AttnAr
       }
     }
   };
+  auto stage = [&](int buf) {          // registers -> K / V^T tile `buf`
+    float *Kb = kv0 + buf * TILE, *Vb = Kb + 64 * ATT2_S;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      const int r = e >> 4, c4 = e & 15;
+      *reinterpret_cast<f32x4 *>(&Kb[r * ATT2_S + c4 * 4]) = kreg[i];
+      const int rs = r ^ (4 * (c4 >> 2));                 // key swizzle of the transposed V: 4 * (d >> 4), d = 4 c4 + j
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Vb[(c4 * 4 + j) * ATT2_S + rs] = vreg[i][j];
+    }
+  };
   fetch(0);
   __syncthreads();   // Q staged
   f32x4 bq[QW][4];   // head dims lk * 16 .. + 15 of query (wave * QW + g) * 16 + li
@@ -327,20 +349,28 @@ __global__ __launch_bounds__(256, QW == 1 ? 3 : 2) void attention2_kernel(AttnAr
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       bq[g][q] = *reinterpret_cast<const f32x4 *>(&Qs[((wave * QW + g) * 16 + li) * ATT2_S + lk * 16 + 4 * q]);
+  if (DB) {
+    stage(0);                          // buffer 0 is untouched so far (Q sits in buffer 1)
+    if (nkt > 1) fetch(1);
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * 64;
-    __syncthreads();  // previous tile fully consumed
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256;
-      const int r = e >> 4, c4 = e & 15;
-      *reinterpret_cast<f32x4 *>(&Ks[r * ATT2_S + c4 * 4]) = kreg[i];
-      const int rs = r ^ (4 * (c4 >> 2));                 // key swizzle of the transposed V: 4 * (d >> 4), d = 4 c4 + j
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Vt[(c4 * 4 + j) * ATT2_S + rs] = vreg[i][j];
+    const float *Ks, *Vt;
+    if (DB) {
+      __syncthreads();   // tile kt visible in buffer kt & 1; buffer (kt + 1) & 1 (tile kt - 1 or the Q stage) is free
+      if (kt + 1 < nkt) {
+        stage((kt + 1) & 1);
+        if (kt + 2 < nkt) fetch(kt + 2);
+      }
+      Ks = kv0 + (kt & 1) * TILE;
+    } else {
+      __syncthreads();  // previous tile fully consumed
+      stage(0);
+      __syncthreads();
+      if (kt + 1 < nkt) fetch(kt + 1);
+      Ks = kv0;
     }
-    __syncthreads();
-    if (kt + 1 < nkt) fetch(kt + 1);
+    Vt = Ks + 64 * ATT2_S;
 
     f32x4 st[QW][4];
 #pragma unroll

@@ -110,7 +110,7 @@ class VRDemixer:
                              device=_device_index(common_config.get("torch_device", 0)))
         self.engine.load_vr(self.model_params, nn_arch_size,
                             None if self.is_vr_51_model else (capacity or model_capacity(nn_arch_size)), state_dict,
-                            window_size=self.window_size, offset=offset, max_batch=max_batch or max(self.batch_size, 4),
+                            window_size=self.window_size, offset=offset, max_batch=max_batch or max(self.batch_size, 32),   # engine knob: see engine_vr.h vr_mask_pass
                             v51=self.model_capacity if self.is_vr_51_model else None)
 
     def separate_stems(self, wave: np.ndarray, want_primary: bool = True, want_secondary: bool = True):

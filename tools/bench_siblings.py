@@ -78,7 +78,7 @@ def run_vr(args):
     arch = 123821
     sd = V.make_vr_state(arch, 0)
     dm = A.VRDemixer({"model_params": VR_MP, "primary_stem_name": "Instrumental", "torch_device": 0},
-                     {"window_size": 512, "batch_size": 8, "aggression": 5}, state_dict=sd, nn_arch_size=arch, max_batch=8)
+                     {"window_size": 512, "batch_size": 8, "aggression": 5}, state_dict=sd, nn_arch_size=arch)   # engine default: <= 32 patches per pass, evened out
     eng = dm.engine
     n = int(SR * args.seconds)
     wave = synth(n)
