@@ -434,6 +434,11 @@ int asx_pcm_decode_dev(asx_engine *e, const void *raw_dev, int64_t frames, int32
  * *peak_before (optional) = max |wave| before scaling.  has_min_peak = 0 mirrors min_peak=None. */
 int asx_normalize(asx_engine *e, float *wave_host, int64_t numel, float max_peak, float min_peak, int32_t has_min, float *peak_before);
 
+/* The same on an array already in HBM, in place, no host synchronisation (ABI 4); and the residual stem of a single-target
+ * MDXC / Roformer model, out = mix - stem (mdxc_separator.py:406-468). */
+int asx_normalize_dev(asx_engine *e, float *wave_dev, int64_t numel, float max_peak, float min_peak, int32_t has_min, void *stream);
+int asx_residual_dev(asx_engine *e, const float *mix_dev, const float *stem_dev, float *out_dev, int64_t numel, void *stream);
+
 /* Spectral edges, librosa STFT(2048, 1024) semantics:
  * asx_ensemble   = Ensembler.ensemble (audio_separator/separator/ensembler.py:12-160) over K equal-length stereo waves
  *                  [K, 2, N]; algorithm: 0 avg_wave, 1 median_wave, 2 min_wave, 3 max_wave, 4 avg_fft, 5 median_fft,

@@ -53,13 +53,36 @@ class DemucsSeparator(CommonSeparator):
         self.engine = dm.engine
         return out
 
+    def _demix_on_device(self):
+        """RIFF/WAVE input at the model's rate: data chunk -> pinned -> HBM -> asx_pcm_decode_dev -> the demix (single model or
+        bag) -> stems [S, 2, N] that STAY in HBM; ``source`` is their pinned host mirror and every ``source[i].T`` view handed to
+        write_audio is registered against its device tensor, so the int16 pass runs on the device (asx_pcm16_dev) without a
+        second upload.  (None, None) when the file needs the host decoder or the configuration the host combine."""
+        dm = self.load_model()                      # binds self.engine, which the device decode needs
+        mix_d = self._device_mix(self.audio_file_path)
+        if mix_d is None:
+            return None, None
+        t0 = self._now()
+        dm.shifts, dm.overlap, dm.segments_enabled = self.shifts, self.overlap, self.segments_enabled
+        out_d = dm.demix_dev(mix_d) if hasattr(dm, "demix_dev") else None
+        self.engine = dm.engine
+        if out_d is None:
+            return None, None
+        t0 = self._tick("demix", t0)
+        source, views = self._host_planar_stems(out_d)
+        self._sync()
+        self._tick("stems_d2h", t0)
+        return source, views
+
     def separate(self, audio_file_path, custom_output_names=None):
         """demucs_separator.py:83-160."""
         self._begin_file(audio_file_path)
-        mix = self.prepare_mix(self.audio_file_path)
-        self.load_model()
-        source = self.demix_demucs(mix)
-        self.clear_gpu_cache()
+        source, views = self._demix_on_device()
+        if source is None:
+            mix = self.prepare_mix(self.audio_file_path)
+            self.load_model()
+            source = self.demix_demucs(mix)
+            self.clear_gpu_cache()
 
         n = len(source)
         self.demucs_source_map = {2: DEMUCS_2_SOURCE_MAPPER, 6: DEMUCS_6_SOURCE_MAPPER}.get(n, DEMUCS_4_SOURCE_MAPPER)
@@ -69,6 +92,6 @@ class DemucsSeparator(CommonSeparator):
                 self.logger.debug(f"{stem_name}: not written (output_single_stem = {self.output_single_stem})")
                 continue
             path = self.get_stem_output_path(stem_name, custom_output_names)
-            self.final_process(path, source[index].T, stem_name)
+            self.final_process(path, views[index] if views is not None else source[index].T, stem_name)
             files.append(path)
         return files

@@ -72,10 +72,69 @@ class MDXCSeparator(CommonSeparator):
         """mdxc_separator.py:257-468: dict of stems, or the primary array for a single-target model without residual."""
         return self._demixer().demix(mix)
 
+    def _separate_on_device(self, custom_output_names):
+        """The same steps with every array in HBM (RIFF/WAVE input at the model's rate): decode on the device, normalise the mix in
+        place (asx_normalize_dev), demix, residual stem, normalise every stem in place, host mirrors (pinned) for
+        ``primary_source`` / ``secondary_source``, int16 pass on the device per written stem.  None: take the generic path."""
+        if self.engine is None:
+            self._demixer()
+        mix_d = self._device_mix(self.audio_file_path)
+        if mix_d is None:
+            return None
+        n = mix_d.shape[1]
+        seconds = n / self.sample_rate
+        if seconds < 10.0 and not self.override_model_segment_size:
+            self.override_model_segment_size = True
+            self.logger.warning(f"{seconds:.2f} s of audio (< 10 s): switching to the configured segment size "
+                                "(override_model_segment_size), as the reference does for short files")
+        dm = self._demixer()
+        if dm.engine.device != mix_d.device.index:
+            return None
+        t0 = self._now()
+        eng, st = dm.engine, self._stream()
+        thr, amp = self.normalization_threshold, self.amplification_threshold
+        eng.normalize_dev(mix_d.data_ptr(), 2 * n, thr, amp, stream=st)
+        names, stems_d = dm.demix_dev(mix_d)
+        training = self.model_data.get("training", {}) or {}
+        single = names == [None]
+        if single:
+            wanted = [0]
+        else:
+            order = [training["target_instrument"]] if training.get("target_instrument") else list(training.get("instruments") or [])
+            if self.process_all_stems and len(order) > 2:
+                wanted = [names.index(k) for k in order]
+            else:
+                wanted = [names.index(self.primary_stem_name), names.index(self.secondary_stem_name)]
+            for i in sorted(set(wanted)):           # norm(source[name]) of the reference, once per stem, in place
+                eng.normalize_dev(stems_d[i].data_ptr(), 2 * n, thr, amp, stream=st)
+        t0 = self._tick("demix", t0)
+        _, views = self._host_planar_stems(stems_d)
+        self._sync()
+        self._tick("stems_d2h", t0)
+        files = []
+        if single:
+            if self._wanted(self.primary_stem_name):
+                if not isinstance(self.primary_source, np.ndarray):
+                    self.primary_source = views[0]
+                self.primary_stem_output_path = self._emit_stem(self.primary_stem_name, self.primary_source, custom_output_names, files)
+            return files
+        if self.process_all_stems and len(wanted) > 2:
+            for k, i in zip(order, wanted):
+                self._emit_stem(k, views[i], custom_output_names, files)
+            return files
+        if not isinstance(self.primary_source, np.ndarray):
+            self.primary_source = views[wanted[0]]
+        if not isinstance(self.secondary_source, np.ndarray):
+            self.secondary_source = views[wanted[1]]
+        return self._emit_pair(custom_output_names)
+
     def separate(self, audio_file_path, custom_output_names=None):
         """mdxc_separator.py:118-227."""
         self._reset_file_state()
         self._begin_file(audio_file_path)
+        files = self._separate_on_device(custom_output_names)
+        if files is not None:
+            return files
         mix = self.prepare_mix(self.audio_file_path)
 
         seconds = mix.shape[1] / self.sample_rate

@@ -116,20 +116,35 @@ class VRSeparator(CommonSeparator):
         dm = self.load_model()
         bands = self.model_params["band"]
         top = bands[len(bands)]
-        # loading_mix (:255-291): the top band is the file decoded at the band's rate; everything below happens on the device
-        wave, _ = audio_io.load(audio_file_path, sr=top["sr"], mono=False)
-        if wave.ndim == 1:
-            wave = np.asarray([wave, wave])
-        wave = np.ascontiguousarray(wave, np.float32)
 
         if self.output_single_stem and self.output_single_stem.lower() not in (self.primary_stem_name.lower(),
                                                                                self.secondary_stem_name.lower()):
             self.logger.warning(f"output_single_stem = '{self.output_single_stem}' names neither '{self.primary_stem_name}' nor "
                                 f"'{self.secondary_stem_name}' (model {self.model_name}): ignored, both stems are written")
             self.output_single_stem = None
-
         want_p, want_s = self._wanted(self.primary_stem_name), self._wanted(self.secondary_stem_name)
-        primary, secondary = dm.separate_stems(wave, want_primary=want_p, want_secondary=want_s)
+
+        primary = secondary = None
+        # device-resident path (RIFF/WAVE at the top band's rate, which is also the rate the stems are written at): the data
+        # chunk is decoded on the device and both stems stay in HBM until the writer's int16 pass
+        keep = (self.input_subtype, self.input_bit_depth)
+        wave_d = self._device_mix(audio_file_path) if (top["sr"] == self.sample_rate and self.model_samplerate == 44100) else None
+        self.input_subtype, self.input_bit_depth = keep          # _device_mix records prepare_mix's fields; VR keeps its own (above)
+        if wave_d is not None:
+            t0 = self._now()
+            stems_d = dm.separate_stems_dev(wave_d)
+            t0 = self._tick("demix", t0)
+            _, views = self._host_planar_stems(stems_d)
+            self._sync()
+            self._tick("stems_d2h", t0)
+            primary, secondary = (views[0] if want_p else None), (views[1] if want_s else None)
+        else:
+            # loading_mix (:255-291): the top band is the file decoded at the band's rate; everything below happens on the device
+            wave, _ = audio_io.load(audio_file_path, sr=top["sr"], mono=False)
+            if wave.ndim == 1:
+                wave = np.asarray([wave, wave])
+            wave = np.ascontiguousarray(wave, np.float32)
+            primary, secondary = dm.separate_stems(wave, want_primary=want_p, want_secondary=want_s)
 
         # primary first here (vr_separator.py:211-246), unlike the MDX family
         files = []

@@ -10,10 +10,12 @@ a subclass without an engine cannot write audio.
 """
 from __future__ import annotations
 
+import functools
 import gc
 import logging
 import os
 import re
+import threading
 
 import numpy as np
 
@@ -50,6 +52,23 @@ class CommonSeparator:
                     "normalization_threshold", "amplification_threshold", "enable_denoise", "output_single_stem",
                     "invert_using_spec", "sample_rate", "use_soundfile")
 
+    def __init_subclass__(cls, **kw):
+        """Every architecture's ``separate`` returns only after the container writes it started have finished (the built-in WAV
+        writer runs on worker threads so that the files of a song are written concurrently and overlap the next stem's int16
+        pass; the orchestrator may open the files as soon as ``separate`` returns)."""
+        super().__init_subclass__(**kw)
+        inner = cls.__dict__.get("separate")
+        if inner is not None:
+            @functools.wraps(inner)
+            def separate(self, *args, **kwargs):
+                self._in_separate = True
+                try:
+                    return inner(self, *args, **kwargs)
+                finally:
+                    self._in_separate = False
+                    self._drain_writes()
+            cls.separate = separate
+
     def __init__(self, config: dict):
         """common_separator.py:55-148."""
         self.logger = config.get("logger") or logging.getLogger("audio_separator_amd")
@@ -60,6 +79,7 @@ class CommonSeparator:
         self.engine = None                       # the libasx.so handle; set by the architecture subclass
         self.asx_profile_file = bool(config.get("asx_profile_file"))   # per-phase wall times of separate() in file_timings
         self.file_timings = {}
+        self._pending_writes = []                # (thread, error box) of container writes in flight
 
         self.roformer_loader = None
         self.is_roformer_model = self._detect_roformer_model()
@@ -121,6 +141,38 @@ class CommonSeparator:
         self.file_timings = {}        # seconds per phase of this file when ``asx_profile_file`` is set (bench.py file_level)
 
     # ---- device-resident file path (load / normalise / write edges without host round trips) -----------------
+    # ---- concurrent container writes -----------------------------------------------------------------------------
+    def _write_wav_async(self, stem_path, pcm, subtype):
+        """audio_io.write_wav on a worker thread (the file write releases the GIL); drained before ``separate`` returns."""
+        # a write_audio call from outside separate() (the orchestrator's ensemble output, separator.py:1379) is synchronous:
+        # nobody would drain it
+        if os.environ.get("ASX_ASYNC_WRITES", "1") == "0" or not getattr(self, "_in_separate", False):
+            audio_io.write_wav(stem_path, pcm, self.sample_rate, subtype)
+            return
+        box = []
+
+        def work():
+            try:
+                audio_io.write_wav(stem_path, pcm, self.sample_rate, subtype)
+            except BaseException as e:          # re-raised by _drain_writes on the caller's thread
+                box.append(e)
+        t = threading.Thread(target=work, name="asx-wav-writer", daemon=True)
+        t.start()
+        self._pending_writes.append((t, box))
+
+    def _drain_writes(self):
+        t0 = self._now()
+        pending, self._pending_writes = self._pending_writes, []
+        err = None
+        for t, box in pending:
+            t.join()
+            if box and err is None:
+                err = box[0]
+        if pending and getattr(self, "asx_profile_file", False):
+            self.file_timings["write_drain"] = self.file_timings.get("write_drain", 0.0) + (self._now() - t0)
+        if err is not None:
+            raise err
+
     def _tick(self, phase: str, t0: float) -> float:
         """Accumulate wall time of ``phase`` since ``t0`` (device drained first) when per-file profiling is on."""
         if not getattr(self, "asx_profile_file", False):
@@ -205,12 +257,30 @@ class CommonSeparator:
         host = torch.empty(dev_stem.shape, dtype=dev_stem.dtype, pin_memory=True)
         host.copy_(dev_stem, non_blocking=True)
         arr = host.numpy()
-        self._dev_stems[id(arr)] = (arr, dev_stem, host)
+        self._dev_stems[id(arr)] = (arr, dev_stem, host, "rows")
         return arr
 
-    def _device_stem_for(self, stem_source):
+    def _host_planar_stems(self, dev_stems):
+        """Device stems [S, 2, N] -> their pinned host mirror [S, 2, N] plus the [N, 2] VIEWS (``source[i].T``) the reference hands to
+        write_audio, each registered against its planar device tensor (the Demucs / MDXC layouts)."""
+        import torch
+        host = torch.empty(dev_stems.shape, dtype=dev_stems.dtype, pin_memory=True)
+        host.copy_(dev_stems, non_blocking=True)
+        arr = host.numpy()
+        views = []
+        for i in range(arr.shape[0]):
+            v = arr[i].T
+            self._dev_stems[id(v)] = (v, dev_stems[i], host, "planar")
+            views.append(v)
+        return arr, views
+
+    def _device_stem_entry(self, stem_source):
         hit = self._dev_stems.get(id(stem_source))
-        return hit[1] if hit is not None and hit[0] is stem_source else None
+        return hit if hit is not None and hit[0] is stem_source else None
+
+    def _device_stem_for(self, stem_source):
+        hit = self._device_stem_entry(stem_source)
+        return hit[1] if hit is not None else None
 
     def _wanted(self, stem_name: str) -> bool:
         """``output_single_stem`` filter (mdx_separator.py:185,193)."""
@@ -338,14 +408,17 @@ class CommonSeparator:
         eng = self._require_engine()
         a = self._stereo_rows(stem_source)
         t0 = self._now()
-        dev_stem = self._device_stem_for(stem_source)
+        entry = self._device_stem_entry(stem_source)
+        dev_stem = entry[1] if entry is not None else None
         if dev_stem is not None:
             # the stem is still in HBM (same array object separate() produced): normalise + quantise there, bring back int16 only
             import torch
-            n = dev_stem.shape[0]
+            planar = entry[3] == "planar"                     # [2, N] (Demucs / MDXC stems) or [N, 2] (asx_separate_dev)
+            n = dev_stem.shape[1] if planar else dev_stem.shape[0]
             pcm_dev = torch.empty((n, 2), dtype=torch.int16, device=dev_stem.device)
-            peak = eng.pcm16_rows_dev(dev_stem.data_ptr(), n, self.normalization_threshold, self.amplification_threshold,
-                                      pcm_dev.data_ptr(), stream=self._stream())
+            quantise = eng.pcm16_planar_dev if planar else eng.pcm16_rows_dev
+            peak = quantise(dev_stem.data_ptr(), n, self.normalization_threshold, self.amplification_threshold,
+                            pcm_dev.data_ptr(), stream=self._stream())
             pcm_host = torch.empty((n, 2), dtype=torch.int16, pin_memory=True)
             pcm_host.copy_(pcm_dev, non_blocking=True)
             self._sync()
@@ -389,7 +462,7 @@ class CommonSeparator:
             return
         if file_format != "wav":
             raise audio_io.AudioIOError(f"writing .{file_format} needs pydub + ffmpeg (not installed); WAV is built in")
-        audio_io.write_wav(stem_path, pcm, self.sample_rate, {16: "PCM_16", 24: "PCM_24", 32: "PCM_32"}.get(depth, "PCM_16"))
+        self._write_wav_async(stem_path, pcm, {16: "PCM_16", 24: "PCM_24", 32: "PCM_32"}.get(depth, "PCM_16"))
         self._tick("container_write", t0)
 
     def write_audio_soundfile(self, stem_path: str, stem_source):

@@ -1537,6 +1537,33 @@ int asx_normalize(asx_engine *e, float *wave_host, int64_t numel, float max_peak
   return rc;
 }
 
+// the same on an array that is already in HBM (MDXCSeparator.separate normalises the mix and every stem, mdxc_separator.py:147,
+// 170-190): in place, only enqueues work
+int asx_normalize_dev(asx_engine *e, float *wave_dev, int64_t numel, float max_peak, float min_peak, int32_t has_min, void *stream) {
+  REQUIRE(e && wave_dev && numel >= 1, "asx_normalize_dev: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  CHK(e->d_peak.ensure(256));
+  unsigned int *pk = reinterpret_cast<unsigned int *>(e->d_peak.p) + 2;   // its own word (0: separate / pcm16, 1: decode)
+  HIPCHK(hipMemsetAsync(pk, 0, 4, s));
+  const unsigned nb = (unsigned)std::min<int64_t>((numel + 255) / 256, 2048);
+  CHK(timed(e, ASX_PROF_MISC, 0.0, 4.0 * numel, s, [&]() { hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, s, wave_dev, numel, pk); }));
+  return timed(e, ASX_PROF_MISC, 0.0, 8.0 * numel, s, [&]() {
+    hipLaunchKernelGGL(normalize_kernel, dim3(nb), dim3(256), 0, s, wave_dev, numel, pk, max_peak, min_peak, has_min);
+  });
+}
+
+// out = mix - stem (the residual stem of a single-target MDXC / Roformer model, mdxc_separator.py:406-468), float32
+int asx_residual_dev(asx_engine *e, const float *mix_dev, const float *stem_dev, float *out_dev, int64_t numel, void *stream) {
+  REQUIRE(e && mix_dev && stem_dev && out_dev && numel >= 1, "asx_residual_dev: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipSetDevice(e->device));
+  const unsigned nb = (unsigned)std::min<int64_t>((numel + 255) / 256, 4096);
+  return timed(e, ASX_PROF_MISC, 0.0, 12.0 * numel, s, [&]() {
+    hipLaunchKernelGGL(residual_kernel, dim3(nb), dim3(256), 0, s, mix_dev, stem_dev, numel, out_dev);
+  });
+}
+
 // ---- stage hooks -------------------------------------------------------------
 static int to_dev(DevBuf &d, const float *h, size_t n) {
   CHK(d.ensure(n * 4));

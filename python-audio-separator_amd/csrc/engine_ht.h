@@ -1190,7 +1190,10 @@ static int ht_segments_dev(asx_engine *e, const float *mix_dev, int64_t N, const
   if (k1 <= k0) return ASX_OK;
   if (standardize) CHK(ht_ref_stats(e, mix_dev, N, s));
   const int nk = k1 - k0;
-  const int maxB = c.max_batch > 0 ? c.max_batch : 16;   // 611 vs 536x real time against batches of 8 (4-min song)
+  // segments per forward: an engine knob (results do not depend on it).  4-minute song, 84 segments: 14 / 21 / 28 / 42 per batch
+  // -> 871 / 899 / 926 / 928x real time (round 3; round 1: 611 vs 536x for 16 vs 8) -- the inner levels and the transformer fill
+  // the chip only with many segments.
+  const int maxB = c.max_batch > 0 ? c.max_batch : 32;
   const int nbatch = (nk + maxB - 1) / maxB;
   const int per = (nk + nbatch - 1) / nbatch;
   CHK(n.seg.ensure((size_t)per * 2 * TL * 4));

@@ -916,9 +916,9 @@ static int vr_mask_pass(asx_engine *e, int T, int pad_l, int shift, int patches,
   VrNet &n = *e->vr;
   const asx_vr_config &c = n.cfg;
   const int W = c.window_size, roi = W - 2 * c.offset;
-  // patches per net pass: an engine knob (results do not depend on it).  21 per pass instead of 8 is worth 6.5 % on a 4-minute
-  // song (476 -> 507x: the deep levels of the cascade fill the chip only with many patches); batches are evened out so that no
-  // short tail batch runs alone.  ~1 GB of workspace per patch at the 4band_44100 layout.
+  // patches per net pass: an engine knob (results do not depend on it).  4-minute song, 84 patches: 8 / 21 / 28 / 42 / 84 per pass
+  // -> 476 / 507 / 489 / 509 / 513x real time (the deep levels of the cascade fill the chip only with many patches); batches are
+  // evened out so that no short tail batch runs alone.  ~1 GB of workspace per patch at the 4band_44100 layout (vr.py asks for 48).
   const int maxB0 = c.max_batch > 0 ? c.max_batch : 4;
   const int nbatch = (patches + maxB0 - 1) / maxB0;
   const int maxB = (patches + nbatch - 1) / nbatch;

@@ -516,6 +516,12 @@ __global__ __launch_bounds__(256) void pcm16_kernel(const float *__restrict__ st
   reinterpret_cast<short2 *>(pcm)[i] = o;
 }
 
+// secondary = mix - primary (mdxc_separator.py:406-468: the residual stem of a single-target model), float32
+__global__ __launch_bounds__(256) void residual_kernel(const float *__restrict__ mix, const float *__restrict__ stem, int64_t n,
+                                                       float *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = mix[i] - stem[i];
+}
+
 // The same writer edge for a stem that is already [N, 2] interleaved (what asx_separate_dev produces and write_audio consumes):
 // purely elementwise over the 2 N values, four per thread.  Bit-identical to pcm16_kernel on the transposed input.
 __global__ __launch_bounds__(256) void pcm16_rows_kernel(const float *__restrict__ stem, int64_t n2, const unsigned int *peak_bits,

@@ -193,6 +193,24 @@ class DemucsDemixer:
         self.engine.ht_bag_finish_dev(est_d.data_ptr(), totals.astype(np.float32), mix_d.data_ptr(), n, out_d.data_ptr(),
                                       standardize=True, swap01=True, stream=st)
 
+    def demix_dev(self, mix_d, offsets=None):
+        """demix_demucs with input and output in HBM: CUDA tensor [2, N] -> CUDA tensor [S, 2, N] (sources 0 / 1 swapped), or None
+        when this configuration has no device-resident path (``segments_enabled=False`` windows on the host)."""
+        import torch
+        if not self.segments_enabled:
+            return None
+        n = mix_d.shape[1]
+        out_d = torch.empty((len(self.models[0][0].sources), 2, n), dtype=torch.float32, device=mix_d.device)
+        if len(self.models) > 1:
+            self.bag_demix_dev(mix_d, out_d, offsets)
+            return out_d
+        self._load(0)
+        offs = self._draw_offsets(0, offsets)
+        run = self.engine.hd_demix_dev if isinstance(self.models[0][0], HDConfig) else self.engine.ht_demix_dev
+        run(mix_d.data_ptr(), n, out_d.data_ptr(), shifts=self.shifts, offsets=offs, overlap=self.overlap, flags=3,
+            stream=torch.cuda.current_stream(mix_d.device).cuda_stream)
+        return out_d
+
     def _bag_on_device(self, mix: np.ndarray, offsets):
         """One upload of the mix, one download of the result around bag_demix_dev."""
         import torch

@@ -227,7 +227,7 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
            "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev",
            "asx_hd_begin", "asx_hd_commit", "asx_hd_flops", "asx_hd_forward", "asx_hd_demix", "asx_hd_demix_dev", "asx_hd_plan",
-           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev", "asx_ht_standardize_dev", "asx_ht_bag_accumulate_dev", "asx_ht_bag_finish_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_debug_trace"]
+           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev", "asx_ht_standardize_dev", "asx_ht_bag_accumulate_dev", "asx_ht_bag_finish_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_normalize_dev", "asx_residual_dev", "asx_debug_trace"]
 
 
 def load_library():
@@ -316,6 +316,8 @@ def load_library():
     lib.asx_pcm16_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp, _FP, vp]
     lib.asx_pcm16_rows_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp, _FP, vp]
     lib.asx_pcm_decode_dev.argtypes = [vp, vp, i64, i32, i32, vp, _FP, vp]
+    lib.asx_normalize_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp]
+    lib.asx_residual_dev.argtypes = [vp, vp, vp, vp, i64, vp]
     lib.asx_ht_standardize_dev.argtypes = [vp, vp, i64, vp, vp]
     lib.asx_ht_bag_accumulate_dev.argtypes = [vp, vp, vp, _FP, i32, i64, i32, vp]
     lib.asx_ht_bag_finish_dev.argtypes = [vp, vp, _FP, i32, vp, i64, C.c_uint32, vp, vp]
@@ -729,9 +731,11 @@ class Engine:
 
     def vr_separate_dev(self, wave_ptr: int, n_samples: int, primary_ptr: int, secondary_ptr: int, aggr_value: float,
                         split_bin: int, is_non_accom: bool = False, enable_tta: bool = False, enable_post_process: bool = False,
-                        post_thres: float = 0.2, stream: int = 0):
-        pr = _VrParams(float(aggr_value), int(split_bin), int(bool(is_non_accom)), 0, 0.0, 0.0, int(bool(enable_tta)),
-                       int(bool(enable_post_process)), float(post_thres), 0)
+                        post_thres: float = 0.2, stream: int = 0, aggr_correction=None, high_end_process: bool = False):
+        corr = aggr_correction or {}
+        pr = _VrParams(float(aggr_value), int(split_bin), int(bool(is_non_accom)), int(aggr_correction is not None),
+                       float(corr.get("left", 0.0)), float(corr.get("right", 0.0)), int(bool(enable_tta)),
+                       int(bool(enable_post_process)), float(post_thres), int(bool(high_end_process)))
         self._check(self._lib.asx_vr_separate_dev(self._h, wave_ptr, n_samples, C.byref(pr), primary_ptr or None,
                                                   secondary_ptr or None, stream or None))
 
@@ -791,6 +795,15 @@ class Engine:
                                                  int(min_peak is not None), pcm_ptr, C.byref(pk) if want_peak else None, stream or None))
         return pk.value if want_peak else None
 
+    def pcm16_planar_dev(self, stem_ptr: int, n_samples: int, max_peak: float, min_peak, pcm_ptr: int, stream: int = 0,
+                         want_peak: bool = True):
+        """asx_pcm16_dev: a device-resident planar [2, N] stem -> int16 [N, 2] on the device; returns the peak after
+        normalisation (synchronises the stream) or None."""
+        pk = C.c_float()
+        self._check(self._lib.asx_pcm16_dev(self._h, stem_ptr, n_samples, float(max_peak), float(min_peak or 0.0),
+                                            int(min_peak is not None), pcm_ptr, C.byref(pk) if want_peak else None, stream or None))
+        return pk.value if want_peak else None
+
     PCM_FORMATS = {"PCM_16": 16, "PCM_24": 24, "PCM_32": 32, "FLOAT": 0x120}
 
     def pcm_decode_dev(self, raw_ptr: int, frames: int, channels: int, subtype: str, mix_ptr: int, stream: int = 0,
@@ -816,6 +829,13 @@ class Engine:
             wave[...] = buf                      # non-contiguous view (e.g. a transposed stem): write the result back
             return wave
         return buf
+
+    def normalize_dev(self, wave_ptr: int, numel: int, max_peak: float = 1.0, min_peak=None, stream: int = 0):
+        self._check(self._lib.asx_normalize_dev(self._h, wave_ptr, numel, float(max_peak), float(min_peak or 0.0),
+                                                int(min_peak is not None), stream or None))
+
+    def residual_dev(self, mix_ptr: int, stem_ptr: int, out_ptr: int, numel: int, stream: int = 0):
+        self._check(self._lib.asx_residual_dev(self._h, mix_ptr, stem_ptr, out_ptr, numel, stream or None))
 
     ENSEMBLE_ALGORITHMS = ("avg_wave", "median_wave", "min_wave", "max_wave", "avg_fft", "median_fft", "min_fft", "max_fft",
                            "uvr_max_spec", "uvr_min_spec", "ensemble_wav")

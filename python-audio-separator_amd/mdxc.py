@@ -179,6 +179,33 @@ class MDXCDemixer:
             return {self.primary_stem_name: primary, self.secondary_stem_name: mix - primary}
         return primary
 
+    def demix_dev(self, mix_d):
+        """``demix`` with the (already normalised) mix [2, N] and the stems in HBM: returns (names, CUDA tensor [S, 2, N]) -- the
+        stems in the order of ``names``; a single-target model without residual gives ([None], [1, 2, N]).  The residual stem
+        ``mix - primary`` (mdxc_separator.py:406-468) is asx_residual_dev.  Only enqueues work."""
+        import torch
+        n = mix_d.shape[1]
+        st = torch.cuda.current_stream(mix_d.device).cuda_stream
+        if self.is_roformer:
+            chunk_size = self.engine.cfg.hop_length * (self.mdx_segment_size - 1)
+            desired_step = int(self.overlap * self.sample_rate)
+            step = chunk_size if desired_step <= 0 else min(desired_step, chunk_size)
+            n_out = int(self.engine.rof_cfg.n_out)
+            multi = not self.target_instrument and len(self.instruments) > 1
+            raw = torch.empty((n_out + 1, 2, n), dtype=torch.float32, device=mix_d.device)      # + one row for a residual stem
+            self.engine.rof_demix_dev(mix_d.data_ptr(), n, step, raw.data_ptr(), stream=st)
+        else:
+            n_out = self.v3.num_targets
+            multi = n_out > 1
+            raw = torch.empty((n_out + 1, 2, n), dtype=torch.float32, device=mix_d.device)
+            self.engine.mdxc_demix_dev(mix_d.data_ptr(), n, int(self.overlap), raw.data_ptr(), stream=st)
+        if multi:
+            return list(self.instruments)[:n_out], raw[:n_out]
+        if self.is_primary_stem_main_target:
+            self.engine.residual_dev(mix_d.data_ptr(), raw[0].data_ptr(), raw[1].data_ptr(), 2 * n, stream=st)
+            return [self.primary_stem_name, self.secondary_stem_name], raw[:2]
+        return [None], raw[:1]
+
     def _demix_roformer(self, mix: np.ndarray):
         """mdxc_separator.py:272-343 + :406-468 for Roformer models."""
         chunk_size = self.engine.cfg.hop_length * (self.mdx_segment_size - 1)

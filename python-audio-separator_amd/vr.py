@@ -110,8 +110,23 @@ class VRDemixer:
                              device=_device_index(common_config.get("torch_device", 0)))
         self.engine.load_vr(self.model_params, nn_arch_size,
                             None if self.is_vr_51_model else (capacity or model_capacity(nn_arch_size)), state_dict,
-                            window_size=self.window_size, offset=offset, max_batch=max_batch or max(self.batch_size, 32),   # engine knob: see engine_vr.h vr_mask_pass
+                            window_size=self.window_size, offset=offset, max_batch=max_batch or max(self.batch_size, 48),   # engine knob: see engine_vr.h vr_mask_pass
                             v51=self.model_capacity if self.is_vr_51_model else None)
+
+    def separate_stems_dev(self, wave_d):
+        """The same with the wave [2, n] and both stems in HBM: returns one CUDA tensor [2 (primary, secondary), 2, n_out]
+        (planar stems; ``stems[i].T`` is what the reference hands to write_audio)."""
+        import torch
+        n = wave_d.shape[1]
+        _, n_out = self.engine.vr_plan(n)
+        out = torch.empty((2, 2, n_out), dtype=torch.float32, device=wave_d.device)
+        self.engine.vr_separate_dev(wave_d.data_ptr(), n, out[0].data_ptr(), out[1].data_ptr(), self.aggressiveness["value"],
+                                    self.aggressiveness["split_bin"], is_non_accom=self.primary_stem_name in NON_ACCOM_STEMS,
+                                    enable_tta=self.enable_tta, enable_post_process=self.enable_post_process,
+                                    post_thres=self.post_process_threshold,
+                                    stream=torch.cuda.current_stream(wave_d.device).cuda_stream,
+                                    aggr_correction=self.aggressiveness["aggr_correction"], high_end_process=self.high_end_process)
+        return out
 
     def separate_stems(self, wave: np.ndarray, want_primary: bool = True, want_secondary: bool = True):
         """(primary_source, secondary_source) as [n', 2] arrays (vr_separator.py:211-236, before final_process), at the

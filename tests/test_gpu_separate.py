@@ -182,3 +182,85 @@ def test_foreign_array_still_takes_the_upload_path(tmp_path):
     pcm, _ = audio_io.read_wav(os.path.join(common["output_dir"], "foreign.wav"))
     want, _ = inst.engine.pcm16(foreign, 0.9, 0.0)
     assert np.array_equal(np.rint(pcm.T * 32768.0).astype(np.int16), want)
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_demucs_device_resident_file_path_equals_host_path(tmp_path, monkeypatch, idx):
+    """DemucsSeparator (single model and a two-member bag): stems that stay in HBM between the demix and the writer's int16 pass
+    (asx_pcm16_dev on the planar device stem) against the generic path (host decode, host stems, upload per stem): same stem
+    files byte for byte, same draws of the random shifts on both sides."""
+    import random
+    case = SC.cases("demucs", str(tmp_path))[idx]
+    tag, cls, common, arch, wav, custom = case
+    seq = [1234, 777, 3999, 42, 2500, 9]
+
+    def run(fast):
+        it = iter(seq)
+        monkeypatch.setattr(random, "randint", lambda a, b: next(it))
+        monkeypatch.setenv("ASX_FILE_FASTPATH", "1" if fast else "0")
+        inst = SC.plugin_class(cls)(common_config=dict(common, asx_profile_file=True), arch_config=arch)
+        names = inst.separate(wav, None)
+        t = dict(inst.file_timings)
+        blobs = []
+        for n in names:
+            with open(os.path.join(common["output_dir"], n), "rb") as f:
+                blobs.append(f.read())
+        inst.clear_gpu_cache()
+        inst.clear_file_specific_paths()
+        return names, blobs, t
+    nd, bd, td = run(True)
+    assert "h2d_decode" in td and "demix" in td, td
+    nh, bh, th = run(False)
+    assert "h2d_decode" not in th
+    assert nd == nh and bd == bh
+
+
+def test_vr_device_resident_file_path_equals_host_path(tmp_path, monkeypatch):
+    """VRSeparator: the wave decoded on the device, both stems kept in HBM until the int16 pass -- same files as the generic path."""
+    case = SC.cases("vr", str(tmp_path))[0]
+    tag, cls, common, arch, wav, custom = case
+
+    def run(fast):
+        monkeypatch.setenv("ASX_FILE_FASTPATH", "1" if fast else "0")
+        inst = SC.plugin_class(cls)(common_config=dict(common, asx_profile_file=True), arch_config=arch)
+        names = inst.separate(wav, None)
+        t = dict(inst.file_timings)
+        blobs = []
+        for n in names:
+            with open(os.path.join(common["output_dir"], n), "rb") as f:
+                blobs.append(f.read())
+        inst.clear_gpu_cache()
+        inst.clear_file_specific_paths()
+        return names, blobs, t, (inst.input_subtype, inst.input_bit_depth)
+    nd, bd, td, sd = run(True)
+    assert "h2d_decode" in td and "demix" in td, td
+    nh, bh, th, sh = run(False)
+    assert "h2d_decode" not in th
+    assert nd == nh and bd == bh and sd == sh
+
+
+@pytest.mark.parametrize("family,idx", [("mdxc", 0), ("mdxc", 1), ("mdxc", 2), ("roformer", 0)])
+def test_mdxc_device_resident_file_path_equals_host_path(tmp_path, monkeypatch, family, idx):
+    """MDXCSeparator (TFC-TDF v3 with two targets / one target + residual / single stem, and a Roformer): decode, normalise, demix,
+    residual and per-stem normalise in HBM (asx_pcm_decode_dev, asx_normalize_dev, asx_residual_dev) against the generic path:
+    byte-identical stem files."""
+    case = SC.cases(family, str(tmp_path))[idx]
+    tag, cls, common, arch, wav, custom = case
+
+    def run(fast):
+        monkeypatch.setenv("ASX_FILE_FASTPATH", "1" if fast else "0")
+        inst = SC.plugin_class(cls)(common_config=dict(common, asx_profile_file=True), arch_config=arch)
+        names = inst.separate(wav, custom)
+        t = dict(inst.file_timings)
+        blobs = []
+        for n in names:
+            with open(os.path.join(common["output_dir"], n), "rb") as f:
+                blobs.append(f.read())
+        inst.clear_gpu_cache()
+        inst.clear_file_specific_paths()
+        return names, blobs, t
+    nd, bd, td = run(True)
+    assert "h2d_decode" in td and "demix" in td, td
+    nh, bh, th = run(False)
+    assert "h2d_decode" not in th
+    assert nd == nh and bd == bh

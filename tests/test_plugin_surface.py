@@ -54,3 +54,40 @@ def test_demucs(tmp_path, monkeypatch):
 
 def test_vr(tmp_path, monkeypatch):
     _run("vr", tmp_path, monkeypatch, tol=5e-5)
+
+
+def test_container_writes_run_concurrently_and_are_drained(tmp_path, monkeypatch):
+    """The built-in WAV writer runs on worker threads inside separate(): both files exist and are complete when separate() returns,
+    a failing writer surfaces as an exception of separate() (not a lost thread), and a write_audio call from OUTSIDE separate()
+    (the orchestrator's ensemble output) is synchronous."""
+    import threading
+    from audio_separator_amd import audio_io
+    fake_engine.install(monkeypatch)
+    case = SC.cases("mdx", str(tmp_path))[0]
+    tag, cls, common, arch, wav, custom = case
+    inst = SC.plugin_class(cls)(common_config=common, arch_config=arch)
+    seen = []
+    real = audio_io.write_wav
+
+    def spy(path, data, sr, subtype="PCM_16"):
+        seen.append(threading.current_thread().name)
+        return real(path, data, sr, subtype)
+    monkeypatch.setattr(audio_io, "write_wav", spy)
+    names = inst.separate(wav, None)
+    assert len(names) == 2 and all(n.startswith("asx-wav-writer") for n in seen) and inst._pending_writes == []
+    for n in names:
+        info = audio_io.wav_info(os.path.join(common["output_dir"], n))
+        assert info["frames"] == 3000 and info["subtype"] == "PCM_16"
+    inst.clear_file_specific_paths()
+    # outside separate(): synchronous, on the caller's thread
+    seen.clear()
+    inst.write_audio("direct.wav", np.zeros((100, 2), np.float32) + 0.25)
+    assert seen == [threading.current_thread().name] and os.path.isfile(os.path.join(common["output_dir"], "direct.wav"))
+
+    # a failing writer is re-raised by separate()
+    def boom(path, data, sr, subtype="PCM_16"):
+        raise audio_io.AudioIOError("disk full")
+    monkeypatch.setattr(audio_io, "write_wav", boom)
+    with pytest.raises(audio_io.AudioIOError, match="disk full"):
+        inst.separate(wav, None)
+    assert inst._pending_writes == []
