@@ -41,7 +41,7 @@ SR = 44100
 SONG_SECONDS = 240
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 METRIC = "audio-sec separated / wall-sec (RTF), UVR-MDX-NET 44.1kHz stereo, 1/2/4/8 GPU"
-PMC_FILES = ("r02_pmc_conv3x3.json", "r01_pmc_conv3x3.json")
+PMC_FILES = ("r03_pmc_conv3x3.json", "r02_pmc_conv3x3.json", "r01_pmc_conv3x3.json")
 
 
 def cpu_baseline(seconds: float, seed: int):
@@ -429,7 +429,9 @@ def sibling_lines(args):
         try:
             r = fn(a)
             out[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
-                         "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "unit", "frac", "share_of_step_ms")},
+                         "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "unit", "frac", "share_of_step_ms",
+                                                                     "mfma_bound_launches", "hbm_bound_launches", "stage_roofline")
+                                      if k in r["roofline"]},
                          "net_tflops_per_s": r["config"].get("net_tflops_per_s")}
         except Exception as e:                      # a sibling must never take the headline line down
             out[name] = {"error": f"{type(e).__name__}: {e}"}

@@ -490,6 +490,15 @@ int asx_set_option(asx_engine *e, const char *key, int32_t value);
 /* ---- profiling ---------------------------------------------------------- */
 int asx_profile_enable(asx_engine *e, int32_t on); /* clears the counters */
 int asx_profile_read(asx_engine *e, asx_profile *out); /* synchronises the device */
+/* The launches behind those sums, one record each (class, hipEvent milliseconds, algorithmic flops and bytes), in launch order:
+ * a profile class can mix MFMA-bound and HBM-bound launches (the Demucs "conv" class does), and a roofline is a per-launch
+ * statement.  Writes min(*n, cap) records, *n = launches recorded.  Synchronises the device.  (ABI 4) */
+typedef struct asx_launch_rec {
+  int32_t cls;
+  float ms;
+  double flops, bytes;
+} asx_launch_rec;
+int asx_profile_launches(asx_engine *e, asx_launch_rec *out, int32_t cap, int32_t *n);
 
 #ifdef __cplusplus
 }

@@ -2874,4 +2874,20 @@ int asx_profile_read(asx_engine *e, asx_profile *out) {
   return ASX_OK;
 }
 
+int asx_profile_launches(asx_engine *e, asx_launch_rec *out, int32_t cap, int32_t *n) {
+  REQUIRE(e && n && (out || cap == 0), "asx_profile_launches: null argument");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  *n = (int32_t)e->recs.size();
+  for (int32_t i = 0; i < *n && i < cap; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->recs[i].a, e->recs[i].b));
+    out[i].cls = e->recs[i].cls;
+    out[i].ms = ms;
+    out[i].flops = e->recs[i].flops;
+    out[i].bytes = e->recs[i].bytes;
+  }
+  return ASX_OK;
+}
+
 }  // extern "C"

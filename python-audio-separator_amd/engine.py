@@ -227,7 +227,11 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
            "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev",
            "asx_hd_begin", "asx_hd_commit", "asx_hd_flops", "asx_hd_forward", "asx_hd_demix", "asx_hd_demix_dev", "asx_hd_plan",
-           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev", "asx_ht_standardize_dev", "asx_ht_bag_accumulate_dev", "asx_ht_bag_finish_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_normalize_dev", "asx_residual_dev", "asx_debug_trace"]
+           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev", "asx_ht_standardize_dev", "asx_ht_bag_accumulate_dev", "asx_ht_bag_finish_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_normalize_dev", "asx_residual_dev", "asx_profile_launches", "asx_debug_trace"]
+
+
+class _LaunchRec(C.Structure):     # struct asx_launch_rec
+    _fields_ = [("cls", C.c_int32), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
 def load_library():
@@ -316,6 +320,7 @@ def load_library():
     lib.asx_pcm16_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp, _FP, vp]
     lib.asx_pcm16_rows_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp, _FP, vp]
     lib.asx_pcm_decode_dev.argtypes = [vp, vp, i64, i32, i32, vp, _FP, vp]
+    lib.asx_profile_launches.argtypes = [vp, C.POINTER(_LaunchRec), i32, C.POINTER(i32)]
     lib.asx_normalize_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, i32, vp]
     lib.asx_residual_dev.argtypes = [vp, vp, vp, vp, i64, vp]
     lib.asx_ht_standardize_dev.argtypes = [vp, vp, i64, vp, vp]
@@ -992,6 +997,14 @@ class Engine:
     # -- profiling --------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         self._check(self._lib.asx_profile_enable(self._h, int(on)))
+
+    def profile_launches(self):
+        """Per-launch records of the current profile: [(class name, ms, flops, bytes)] in launch order."""
+        n = C.c_int32()
+        self._check(self._lib.asx_profile_launches(self._h, None, 0, C.byref(n)))
+        recs = (_LaunchRec * max(1, n.value))()
+        self._check(self._lib.asx_profile_launches(self._h, recs, n.value, C.byref(n)))
+        return [(PROF_CLASSES[r.cls], float(r.ms), float(r.flops), float(r.bytes)) for r in recs[: n.value]]
 
     def profile_read(self) -> dict:
         p = _Profile()

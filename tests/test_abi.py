@@ -50,6 +50,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(E._NetCfg) == 36
     assert C.sizeof(E._Plan) == 64
     assert C.sizeof(E._Profile) == 320
+    assert C.sizeof(E._LaunchRec) == 24          # struct asx_launch_rec: int32 + float + 2 doubles
 
 
 def test_no_cpu_fallback(lib):
@@ -81,7 +82,7 @@ def test_header_is_plain_c_and_struct_layouts_match(tmp_path):
         pytest.skip("gcc not available")
     pairs = [("asx_mdx_config", E._MdxCfg), ("asx_net_config", E._NetCfg), ("asx_plan", E._Plan), ("asx_profile", E._Profile),
              ("asx_v3_config", E._V3Cfg), ("asx_rof_config", E._RofCfg), ("asx_ht_config", E._HtCfg), ("asx_hd_config", E._HdCfg), ("asx_vr_band", E._VrBand),
-             ("asx_vr_config", E._VrCfg), ("asx_vr_params", E._VrParams)]
+             ("asx_vr_config", E._VrCfg), ("asx_vr_params", E._VrParams), ("asx_launch_rec", E._LaunchRec)]
     src = '#include <stdio.h>\n#include "asx.h"\nint main(void) {\n' + \
           "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n, _ in pairs) + "  return 0;\n}\n"
     c = tmp_path / "sizes.c"

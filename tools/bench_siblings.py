@@ -55,15 +55,39 @@ def timed(step, steps, warmup):
 
 
 def dominant(eng, step, names):
+    """Roofline of the kernel class that takes most of the step (class sums, as in round 2) PLUS a per-launch split of that class:
+    a class can mix MFMA-bound and HBM-bound launches (Demucs "conv": 3x3 rewrites vs DConv / 1x1), so the launches are sorted
+    by arithmetic intensity -- >= 40 flop/B (the fp32-MFMA / achievable-HBM ridge is ~25-30) count as MFMA-bound and are priced
+    against 157.3 TFLOP/s, the rest against 8 TB/s."""
     eng.profile_enable(True)
     step()
     prof = eng.profile_read()
+    recs = eng.profile_launches()
     eng.profile_enable(False)
     k, v = max(((k, v) for k, v in prof.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
     tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
-    return {"kernel": names.get(k, k), "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK, 4), "traffic": None, "launches": v["launches"], "share_of_step_ms": round(v["ms"], 2)}, \
-        {names.get(k, k): round(v["ms"], 2) for k, v in prof.items() if v["launches"]}
+    roof = {"kernel": names.get(k, k), "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK, 4), "traffic": None, "launches": v["launches"], "share_of_step_ms": round(v["ms"], 2)}
+    mf = [r for r in recs if r[0] == k and r[3] > 0 and r[2] / r[3] >= 40.0]
+    hb = [r for r in recs if r[0] == k and not (r[3] > 0 and r[2] / r[3] >= 40.0)]
+    if mf:
+        ms, fl = sum(r[1] for r in mf), sum(r[2] for r in mf)
+        roof["mfma_bound_launches"] = {"launches": len(mf), "ms": round(ms, 2), "achieved": round(fl / ms / 1e9, 2), "unit": "TFLOP/s",
+                                       "frac": round(fl / ms / 1e9 / PEAK, 4)}
+    if hb:
+        ms, by = sum(r[1] for r in hb), sum(r[3] for r in hb)
+        roof["hbm_bound_launches"] = {"launches": len(hb), "ms": round(ms, 2), "achieved": round(by / ms / 1e6, 1), "unit": "GB/s",
+                                      "frac": round(by / ms / 1e6 / 8000.0, 4)}
+    stages = {}
+    for kk, vv in prof.items():
+        if not vv["launches"] or vv["ms"] <= 0:
+            continue
+        t, g = vv["flops"] / (vv["ms"] * 1e-3) / 1e12, vv["bytes"] / (vv["ms"] * 1e-3) / 1e9
+        stages[names.get(kk, kk)] = ({"bound": "mfma", "achieved": round(t, 2), "unit": "TFLOP/s", "frac": round(t / PEAK, 4)}
+                                     if t / PEAK >= g / 8000.0 else
+                                     {"bound": "hbm", "achieved": round(g, 1), "unit": "GB/s", "frac": round(g / 8000.0, 4)})
+    roof["stage_roofline"] = stages
+    return roof, {names.get(k, k): round(v["ms"], 2) for k, v in prof.items() if v["launches"]}
 
 
 def line(workload, secs, dt, steps, warmup, roof, kms, cpu, extra):
