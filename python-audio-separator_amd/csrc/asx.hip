@@ -636,7 +636,7 @@ static void launch_tdf_dma_auto(const TdfDmaArgs &d, hipStream_t s) {
   static const int t128 = getenv("ASX_GEMM_T128") ? atoi(getenv("ASX_GEMM_T128")) : 1;
   const bool v2 = tdf2_ok(d);
   static const int small = getenv("ASX_TDF2_SMALL") ? atoi(getenv("ASX_TDF2_SMALL")) : 0;   // A/B: 64 x 128 tiles (3+ workgroups per CU) on short-K layers
-  if (v2 && small && d.K <= small && d.N > 128) return launch_tdf2<2, 4>(d, s);
+  if (v2 && ((small && d.K <= small) || d.prefer_small) && d.N > 128) return launch_tdf2<2, 4>(d, s);
   if (d.N > 128) {
     const double rows = (double)((d.M + 127) / 128);
     auto cost = [&](int bn, double eff) {

@@ -549,6 +549,17 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
   const double out_elems = mode == GG_STATS ? 0.0 : (mode == GG_GNGLU ? (double)a.M * g.n : (double)a.M * g.n / (mode == GG_GLU ? 2 : 1));
   const double bytes = 4.0 * ((double)rows_outer * q.I * q.Cin + out_elems + (double)g.n * g.k + (res ? out_elems : 0.0));
   const int cls = mode == GG_CONVT ? ASX_PROF_UP : (q.SI > 1 ? ASX_PROF_DOWN : ASX_PROF_CONV3X3);
+  // 64-row instead of 128-row tiles (three workgroups per CU instead of two, twice the weight traffic per flop) for launches that
+  // are HBM-bound (algorithmic flop / byte under ASX_GG_LOWAI) or whose 128-row grid would not fill the chip twice
+  // (ASX_GG_SMALLGRID workgroups: the inner Demucs levels).  Measured (profiles/NOTES.md): threshold 0 / 40 / 90 / 200 / inf ->
+  // htdemucs 956 / 965 / 975 / 974 / 976x, hdemucs_mmi 1120 / 1130 / 1148 / 1163 / 1181x, VR 522 / 520 / 521 / 517 / 516x.
+  static const double lowai_thr = getenv("ASX_GG_LOWAI") ? atof(getenv("ASX_GG_LOWAI")) : 90.0;
+  static const int64_t small_grid = getenv("ASX_GG_SMALLGRID") ? atoll(getenv("ASX_GG_SMALLGRID")) : 1024;
+  {
+    const int tn = gg_tile_n(a.N, g.glu_c != 0);
+    const int64_t blocks128 = ((a.M + 127) / 128) * ((a.N + tn - 1) / tn);
+    a.lowai = ((bytes > 0.0 && flops / bytes < lowai_thr) || blocks128 < small_grid) ? 1 : 0;
+  }
   // stride-1 k3 / 3x3 convs with a halo packing run on the halo-tile kernel (the input block enters LDS once for all taps)
   HgGeom hgm;
   // A/B knob: launches whose halo grid would be smaller than ASX_HALO_MINBLK workgroups stay on gg_kernel (128-row tiles)
@@ -614,6 +625,9 @@ static int ht_linear(asx_engine *e, const HtGemm &g, const float *x, int64_t lda
   d.lda = lda;
   d.ldy = ldy;
   d.ldr = ldr;
+  // 64 x 128 tiles, three workgroups per CU: 56.2 -> 53.7 ms per song on the transformer linears (ASX_HT_LINEAR_SMALL=0: A/B)
+  static const bool lin_small = !(getenv("ASX_HT_LINEAR_SMALL") && atoi(getenv("ASX_HT_LINEAR_SMALL")) == 0);
+  d.prefer_small = lin_small ? 1 : 0;
   if ((g.k & 3) || (lda & 3) || (ldy & 3) || (g.n & 3) || (res && (ldr & 3))) {
     set_err("ht_linear: K, N and row strides must be multiples of 4 floats");
     return ASX_ERR_INVALID;
@@ -690,7 +704,9 @@ static int ht_mha(asx_engine *e, const float *q, int64_t ldq, const float *k, co
   a.heads = heads;
   const dim3 grid((unsigned)(a.nqt * heads * B));   // 1-D, XCD-aware (kernels_ht.h)
   return timed(e, ASX_PROF_CONV1X1, flops, bytes, s, [&]() {   // profile class shared with the Roformer attention
-    static const bool mha_db = !(getenv("ASX_MHA_DB") && atoi(getenv("ASX_MHA_DB")) == 0);   // A/B: one barrier per key tile
+    // dh = 48: the single-buffered build runs FOUR workgroups per CU (118 registers, 26 KB of LDS): 55.0 -> 51.5 ms per song
+    // against the double-buffered, one-barrier build with three (ASX_MHA_DB=1: A/B) -- occupancy, not the barrier count
+    static const bool mha_db = getenv("ASX_MHA_DB") && atoi(getenv("ASX_MHA_DB")) != 0;
     if (dh == 48 && mha_db) hipLaunchKernelGGL((mha_kernel<3, false, true>), grid, dim3(256), 0, s, a);
     else if (dh == 48) hipLaunchKernelGGL((mha_kernel<3>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((mha_kernel<4>), grid, dim3(256), 0, s, a);

@@ -42,6 +42,7 @@ struct GgArgs {
   int64_t g_outer;
   int g_mod;
   const float *gamma, *beta, *ls;   // GG_GNGLU: GroupNorm affine (row order of w) and the LayerScale of the GLU outputs
+  int lowai;                    // != 0: HBM-bound launch (ht_gg): prefer the small-tile variants
   int glu_rows;                 // != 0: w's rows are in GLU order (ht_glu_perm) -- GG_GLU / GG_GNGLU and the GG_STATS pass of the same GEMM
 };
 
@@ -457,7 +458,10 @@ static void ht_launch_gg(const GgArgs &a, hipStream_t s) {
   }
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gg_kernel<NREP, MREP, MS>), dim3((unsigned)(nbm * nbn)), dim3(256), lds, s, a);
+  // a single-stage K loop (K <= 32: the DConv 1x1 -> 2C GEMMs of the outer levels) only ever touches LDS buffer 0: ask for half
+  // the LDS, so that four workgroups instead of two share a CU -- these launches are HBM-bound and want loads in flight
+  const int lds_launch = a.K <= 32 ? lds / 2 : lds;
+  hipLaunchKernelGGL((gg_kernel<NREP, MREP, MS>), dim3((unsigned)(nbm * nbn)), dim3(256), lds_launch, s, a);
 }
 
 // N tile width ht_gg_dispatch will use for an output of n columns (rowstat_reduce_kernel needs the tile count)
@@ -479,13 +483,18 @@ static inline int gg_tile_n(int n, bool glu = false) {
 }
 
 static void ht_gg_dispatch(const GgArgs &a, hipStream_t s) {
+  // narrow outputs (N <= 48: DConv k3 -> C/8, small VR / encoder layers) are HBM-bound: 128-row tiles (37-45 KB of LDS, three to
+  // four workgroups per CU) instead of 256-row tiles (70-78 KB, two) keep more loads in flight (ASX_GG_M128=0: the 256-row tiles)
+  static const bool m128 = !(getenv("ASX_GG_M128") && atoi(getenv("ASX_GG_M128")) == 0);
   switch (gg_tile_n(a.N, a.glu_rows != 0)) {
-    case 16: ht_launch_gg<1, 4, true>(a, s); break;
-    case 32: ht_launch_gg<2, 4, true>(a, s); break;
-    case 48: ht_launch_gg<3, 4, true>(a, s); break;
-    case 64: ht_launch_gg<1, 8>(a, s); break;
-    case 96: ht_launch_gg<6, 2, true>(a, s); break;
-    default: ht_launch_gg<2, 8>(a, s); break;
+    case 16: m128 ? ht_launch_gg<1, 2, true>(a, s) : ht_launch_gg<1, 4, true>(a, s); break;
+    case 32: m128 ? ht_launch_gg<2, 2, true>(a, s) : ht_launch_gg<2, 4, true>(a, s); break;
+    case 48: m128 ? ht_launch_gg<3, 2, true>(a, s) : ht_launch_gg<3, 4, true>(a, s); break;
+    // HBM-bound launches (a.lowai: algorithmic flop / byte under the threshold of ht_gg) take 64-row tiles: 41-49 KB of LDS, three
+    // workgroups per CU instead of two -- loads in flight, not operand reuse, is what they lack
+    case 64: a.lowai ? ht_launch_gg<1, 4>(a, s) : ht_launch_gg<1, 8>(a, s); break;
+    case 96: a.lowai ? ht_launch_gg<6, 1, true>(a, s) : ht_launch_gg<6, 2, true>(a, s); break;
+    default: a.lowai ? ht_launch_gg<2, 4>(a, s) : ht_launch_gg<2, 8>(a, s); break;
   }
 }
 
@@ -514,8 +523,9 @@ struct MhaArgs {
 // consumed, so ONE workgroup barrier per key tile remains instead of two (the barriers between the three co-resident
 // workgroups, not the fragment reads or the K / V stream, are what held this kernel at ~57 % of the MFMA peak -- kernels_rof.h);
 // 52 KB of LDS at DH = 48 keeps three workgroups per CU, and the global loads run two tiles ahead.
+// (the single-buffered build of head dims <= 48 is compiled for FOUR workgroups per CU: <= 128 registers, 26 KB of LDS)
 template <int DT, bool DECAY = false, bool DB = false>
-__global__ __launch_bounds__(256) void mha_kernel(MhaArgs a) {
+__global__ __launch_bounds__(256, (DT <= 3 && !DB) ? 4 : 1) void mha_kernel(MhaArgs a) {
   constexpr int DH = 16 * DT, QS = DH + 2, VS = DH + 4, C4 = DH / 4;
   constexpr int TILE = 64 * QS + 64 * VS;
   // Q is staged through a K tile's space (its fragments move to registers before that tile is written):

@@ -792,6 +792,7 @@ struct TdfDmaArgs {
   // Honoured by the generic-activation epilogues (not by the ReLU + residual path of the TDF layers).
   const float *rscale;
   int nt;                   // bit 0: non-temporal output stores, bit 1: non-temporal residual loads (ReLU path; A/B switch ASX_NT)
+  int prefer_small;         // launcher hint: 64-row tiles (three workgroups per CU) -- the Demucs transformer linears (M ~ 1e5 rows)
 };
 
 // rotary step of the row-GEMM epilogues on the float4 (row, col .. col + 3), col % 4 == 0.  Every product and sum is rounded
