@@ -205,6 +205,8 @@ static inline int hg_tile_n(int n) {
   if (force == 32 || force == 64 || force == 96 || force == 128) return force;
   if (n <= 32) return 32;
   if (n <= 64) return 64;
+  static const bool split128 = getenv("ASX_HALO_SPLIT128") && atoi(getenv("ASX_HALO_SPLIT128")) != 0;   // A/B: 64-column tiles (3 workgroups per CU) where 128 would fit
+  if (split128 && n % 128 == 0) return 64;
   const int p96 = (n + 95) / 96 * 96, p128 = (n + 127) / 128 * 128;
   return p96 <= p128 ? 96 : 128;
 }
