@@ -173,6 +173,13 @@ struct RofRot {
   int64_t pos_div = 1;
 };
 
+// activation code of the feed-forward GELU: 2 = libm erff, 6 = fast_erf (kernels_net.h); ASX_ROF_GELU overrides (1 = ReLU: a timing
+// probe with wrong results)
+static int rof_gelu_act() {
+  static const int v = getenv("ASX_ROF_GELU") ? atoi(getenv("ASX_ROF_GELU")) : 2;
+  return v;
+}
+
 static int rof_gemm(asx_engine *e, const RofLin &L, const float *x, int64_t lda, int64_t M, float *y, int64_t ldy,
                     int act, const float *res, int64_t ldr, hipStream_t s, const RofRot *rot = nullptr,
                     const float *rscale = nullptr) {
@@ -354,10 +361,10 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
     // feed-forward: x = ff(x) + x
     if (L.ff.norm_folded) {
       CHK(rof_rownorm(e, n.TOK.f(), D, D, n.RS.f(), Mg, s));
-      CHK(rof_gemm(e, L.ff.l1, n.TOK.f(), D, Mg, n.FFH.f(), 4 * D, 2, nullptr, 0, s, nullptr, n.RS.f()));   // GELU
+      CHK(rof_gemm(e, L.ff.l1, n.TOK.f(), D, Mg, n.FFH.f(), 4 * D, rof_gelu_act(), nullptr, 0, s, nullptr, n.RS.f()));   // GELU
     } else {
       CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.ff.norm_g.f(), n.XN.f(), D, Mg, s));
-      CHK(rof_gemm(e, L.ff.l1, n.XN.f(), D, Mg, n.FFH.f(), 4 * D, 2, nullptr, 0, s));          // GELU
+      CHK(rof_gemm(e, L.ff.l1, n.XN.f(), D, Mg, n.FFH.f(), 4 * D, rof_gelu_act(), nullptr, 0, s));          // GELU
     }
     CHK(rof_gemm(e, L.ff.l2, n.FFH.f(), 4 * D, Mg, n.TOK.f(), D, 0, n.TOK.f(), D, s));
   }

@@ -351,9 +351,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 // Fragments are fetched with ds_read_b128 (4 consecutive k per lane); the k
 // order inside a 16-wide step is permuted identically for both operands.
 // ---------------------------------------------------------------------------
-// row-GEMM activations: 0 none, 1 relu, 2 gelu (erf), 3 tanh, 4 leaky relu (slope 0.01), 5 sigmoid
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute), branch-free: one v_rcp, one v_exp, seven fma -- against libm's
+// erff (two polynomial branches + an exp branch, ~3x the VALU work).  GELU's absolute error is then <= 0.75e-7 |v|.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__fmaf_rn(0.3275911f, ax, 1.0f));
+  float p = __fmaf_rn(1.061405429f, t, -1.453152027f);
+  p = __fmaf_rn(p, t, 1.421413741f);
+  p = __fmaf_rn(p, t, -0.284496736f);
+  p = __fmaf_rn(p, t, 0.254829592f);
+  const float r = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+
+// row-GEMM activations: 0 none, 1 relu, 2 gelu (erf), 3 tanh, 4 leaky relu (slope 0.01), 5 sigmoid, 6 gelu on fast_erf
 __device__ __forceinline__ float tdf_act(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
+  if (act == 6) return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
   if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
   if (act == 3) return tanhf(v);
   if (act == 4) return v > 0.f ? v : 0.01f * v;
