@@ -63,10 +63,14 @@ class CommonSeparator:
             def separate(self, *args, **kwargs):
                 self._in_separate = True
                 try:
-                    return inner(self, *args, **kwargs)
-                finally:
+                    result = inner(self, *args, **kwargs)
+                except BaseException:
                     self._in_separate = False
-                    self._drain_writes()
+                    self._drain_writes(raise_errors=False)      # the caller's exception wins over a writer's
+                    raise
+                self._in_separate = False
+                self._drain_writes()
+                return result
             cls.separate = separate
 
     def __init__(self, config: dict):
@@ -160,7 +164,7 @@ class CommonSeparator:
         t.start()
         self._pending_writes.append((t, box))
 
-    def _drain_writes(self):
+    def _drain_writes(self, raise_errors: bool = True):
         t0 = self._now()
         pending, self._pending_writes = self._pending_writes, []
         err = None
@@ -171,7 +175,9 @@ class CommonSeparator:
         if pending and getattr(self, "asx_profile_file", False):
             self.file_timings["write_drain"] = self.file_timings.get("write_drain", 0.0) + (self._now() - t0)
         if err is not None:
-            raise err
+            if raise_errors:
+                raise err
+            self.logger.error(f"a container write failed: {err}")
 
     def _tick(self, phase: str, t0: float) -> float:
         """Accumulate wall time of ``phase`` since ``t0`` (device drained first) when per-file profiling is on."""

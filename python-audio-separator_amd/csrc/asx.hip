@@ -250,6 +250,7 @@ static void host_env(int n, int hop, int T, std::vector<float> &env, int win_len
 
 static size_t stft_lds(const FftPlan &p) { return (size_t)p.nh * 2 * sizeof(float2); }
 static size_t istft_lds(const FftPlan &p) { return ((size_t)p.nh * 3 + 1) * sizeof(float2); }
+static size_t ht_istft_lds(const FftPlan &p) { return ((size_t)p.nh * 2 + 1) * sizeof(float2); }   // ht_istft_kernel stages X in bufB
 
 // ----------------------------------------------------------------------------
 // kernel launchers

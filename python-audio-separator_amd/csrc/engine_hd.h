@@ -237,7 +237,7 @@ static int hd_commit(asx_engine *e) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ht_stft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)stft_lds(n.plan));
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ht_istft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)istft_lds(n.plan));
+                            (int)ht_istft_lds(n.plan));
   h.ready = true;
   return ASX_OK;
 }
@@ -680,7 +680,7 @@ static int hd_phase_after(asx_engine *e, const HdGroup &gr, bool levelZ, size_t 
   // CaC -> iSTFT, + waveform branch (hdemucs.py:760-781)
   const int64_t nf = (int64_t)T * F0 * 4;
   CHK(timed(e, ASX_PROF_ISTFT, 0.0, 4.0 * (double)B * S * 2 * T * (2.0 * F0 + c.nfft), s, [&]() {
-    hipLaunchKernelGGL(ht_istft_kernel, dim3(T, S * 2, B), dim3(256), istft_lds(n.plan), s, b.df[0], T, 4 * S, b.acc_f, (double)nf, b.frames,
+    hipLaunchKernelGGL(ht_istft_kernel, dim3(T, S * 2, B), dim3(256), ht_istft_lds(n.plan), s, b.df[0], T, 4 * S, b.acc_f, (double)nf, b.frames,
                        n.window.f(), reinterpret_cast<const float2 *>(n.tw.p), n.plan);
   }));
   return timed(e, ASX_PROF_OLA, 0.0, 4.0 * (double)B * S * 2 * (T * (double)c.nfft + 2.0 * L), s, [&]() {

@@ -460,7 +460,7 @@ static int ht_commit(asx_engine *e) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ht_stft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)stft_lds(n.plan));
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ht_istft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)istft_lds(n.plan));
+                            (int)ht_istft_lds(n.plan));
   n.ready = true;
   return ASX_OK;
 }
@@ -566,7 +566,8 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
   static const int64_t halo_minblk = getenv("ASX_HALO_MINBLK") ? atoll(getenv("ASX_HALO_MINBLK")) : 0;
   if (g.wh.p != nullptr && q.SI == 1 && q.SO == 1 && q.KI == 3 && (q.KO == 1 || q.KO == 3) && q.KO * q.KI == g.wh_taps &&
       (mode == GG_DENSE || mode == GG_GLU) && res == nullptr && a.row_stat == nullptr && q.IR == q.I && a.OR == q.O &&
-      (q.KO == 3 || q.O == 1) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && hg_geometry(q.O, q.I, q.KO, q.DO, q.DI, &hgm) &&
+      (q.KO == 3 || q.O == 1) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && hg_geometry(q.O, q.I, q.KO, q.DO, q.DI, &hgm) && (int64_t)q.O * q.I * q.ldc < (1ll << 31) &&   // 32-bit lane offsets inside an image
+     
       (rows_outer / q.O) * hgm.tilesO * hgm.tilesI * ((g.n + g.wh_nt - 1) / g.wh_nt) >= halo_minblk) {
     HgArgs h{};
     h.x = x;
@@ -1108,7 +1109,7 @@ static int ht_forward_dev(asx_engine *e, const float *seg, int B, float *out, hi
   for (int i = D - 1; i >= 0; --i) CHK(ht_dec_level(e, i, B, s));
   // CaC -> iSTFT, + waveform branch (htdemucs.py:589-612)
   CHK(timed(e, ASX_PROF_ISTFT, 0.0, 4.0 * (double)B * S * 2 * T * (2.0 * F0 + c.nfft), s, [&]() {
-    hipLaunchKernelGGL(ht_istft_kernel, dim3(T, S * 2, B), dim3(256), istft_lds(n.plan), s, b.df[0], T, 4 * S, b.acc_f,
+    hipLaunchKernelGGL(ht_istft_kernel, dim3(T, S * 2, B), dim3(256), ht_istft_lds(n.plan), s, b.df[0], T, 4 * S, b.acc_f,
                        (double)nf, b.frames, n.window.f(), reinterpret_cast<const float2 *>(n.tw.p), n.plan);
   }));
   return timed(e, ASX_PROF_OLA, 0.0, 4.0 * (double)B * S * 2 * (T * (double)c.nfft + 2.0 * TL), s, [&]() {

@@ -920,9 +920,11 @@ __global__ __launch_bounds__(256) void ht_istft_kernel(const float *__restrict__
                                                        float *__restrict__ frames, const float *__restrict__ window,
                                                        const float2 *__restrict__ tw, FftPlan p) {
   extern __shared__ float2 lds[];
+  // the staged spectrum X[0 .. nh] lives in bufB's space (+ 1 element): it is dead once the merge loop has written bufA, and
+  // fft_lds starts with a barrier before its first stage writes bufB -- 32 KB instead of 48 KB, five workgroups per CU
   float2 *bufA = lds;
   float2 *bufB = lds + p.nh;
-  float2 *bufX = lds + 2 * p.nh;
+  float2 *bufX = bufB;
   const int t = blockIdx.x, sc_ = blockIdx.y, b = blockIdx.z;
   const int nh = p.nh;
   float mean, stdv;
