@@ -103,6 +103,55 @@ def test_sharded_demix_gloo(world, n, match):
     assert np.array_equal(got, ref)
 
 
+def _worker_ws(rank, world, port, lengths, q):
+    """Three songs through ONE ShardWorkspace (bench.py --mode chunks): buffers are allocated once per shape and reused, equal
+    chunk ranges take the no-compaction path (the gathered slab IS the chunk list), unequal ones the copy path."""
+    from audio_separator_amd.sharding import ShardWorkspace
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ws = ShardWorkspace()
+    ad = OracleAdapter()
+    outs, ptrs = [], []
+    for i, n in enumerate(lengths):
+        mix = torch.from_numpy((0.4 * np.random.default_rng(20 + i).standard_normal((2, n))).astype(np.float32))
+        out = sharded_demix(ad, mix, workspace=ws)
+        if rank == 0:
+            outs.append(out.numpy().copy())
+            ptrs.append(ws.bufs["local"].data_ptr())
+        else:
+            assert out is None
+    if rank == 0:
+        q.put((outs, ptrs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_demix_with_workspace_gloo():
+    lengths = [3000, 3000, 2100]          # same shape twice (buffers reused), then another plan (re-allocated once)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ws, args=(r, world, port, lengths, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs, ptrs = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    run = O.make_model_run(O.make_convtdf_state(DIMS, seed=3), DIMS)
+    even = []
+    for i, n in enumerate(lengths):
+        mix = (0.4 * np.random.default_rng(20 + i).standard_normal((2, n))).astype(np.float32)
+        assert np.array_equal(outs[i], O.demix(mix, P, run))
+        nk = len(O.chunk_plan(n, P)[5])
+        even.append(nk % world == 0)
+    assert ptrs[0] == ptrs[1]                     # the second song of the same length allocated nothing
+    assert True in even and False in even, even   # both the slab-is-the-list path and the compaction path ran
+
+
 # ---- sibling loops: Roformer chunks and Demucs segment-forwards through the same driver ------------------------------
 from fractions import Fraction  # noqa: E402
 
