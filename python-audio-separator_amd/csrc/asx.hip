@@ -217,6 +217,19 @@ static bool make_plan(int n_fft, FftPlan *p) {
   p->nh = n_fft / 2;
   p->n_stage = 0;
   int n = p->nh;
+  // large radices first: a 2048-point transform is 16 x 16 x 8 -- three barrier-separated LDS passes instead of six radix-4 / 2
+  // ones (the generic kernels are bound by their passes, not by memory: profiles/NOTES.md).  ASX_FFT_RADIX4=1: the old plans.
+  static const bool r4only = getenv("ASX_FFT_RADIX4") && atoi(getenv("ASX_FFT_RADIX4")) != 0;
+  if (!r4only) {
+    while (n % 16 == 0) {
+      p->radix[p->n_stage++] = 16;
+      n /= 16;
+    }
+    if (n % 8 == 0) {
+      p->radix[p->n_stage++] = 8;
+      n /= 8;
+    }
+  }
   while (n % 4 == 0) {
     p->radix[p->n_stage++] = 4;
     n /= 4;

@@ -68,6 +68,53 @@ __device__ __forceinline__ void butterfly(float2 *v) {
     v[4] = csub(p1, q1);
     v[2] = cadd(p2, q2);
     v[3] = csub(p2, q2);
+  } else if constexpr (R == 8) {
+    // 8 = 4 x 2: n = 2 n1 + n2, k = k1 + 4 k2:  X[k1 + 4 k2] = sum_n2 (-1)^(n2 k2) W8^(n2 k1) DFT4_n1(v[2 n1 + n2])[k1]
+    const float h = 0.70710678118654752440f;
+    float2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+    butterfly<4, SIGN>(e);
+    butterfly<4, SIGN>(o);
+    // W8^k1 (forward: exp(-i pi k1 / 4); inverse: conjugate)
+    o[1] = SIGN < 0 ? make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x)) : make_float2(h * (o[1].x - o[1].y), h * (o[1].y + o[1].x));
+    o[2] = crot<SIGN>(o[2]);
+    o[3] = SIGN < 0 ? make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y)) : make_float2(-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y));
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+      v[k1] = cadd(e[k1], o[k1]);
+      v[k1 + 4] = csub(e[k1], o[k1]);
+    }
+  } else if constexpr (R == 16) {
+    // 16 = 4 x 4: n = 4 n1 + n2, k = k1 + 4 k2:  X[k1 + 4 k2] = DFT4_n2( W16^(n2 k1) DFT4_n1(v[4 n1 + n2])[k1] )[k2]
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    float2 t[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+      float2 c[4] = {v[n2], v[4 + n2], v[8 + n2], v[12 + n2]};
+      butterfly<4, SIGN>(c);
+#pragma unroll
+      for (int k1 = 0; k1 < 4; ++k1) t[n2][k1] = c[k1];
+    }
+    // twiddles W16^(n2 k1), exponent m = n2 k1 in {1, 2, 3, 2, 4, 6, 3, 6, 9}; forward W = (cos, -sin)
+    auto twm = [&](float2 a, float wr, float wi) {      // a * (wr + i wi), wi given for the FORWARD transform
+      const float im = SIGN < 0 ? wi : -wi;
+      return make_float2(a.x * wr - a.y * im, a.x * im + a.y * wr);
+    };
+    t[1][1] = twm(t[1][1], c1, -s1);
+    t[1][2] = twm(t[1][2], h, -h);
+    t[1][3] = twm(t[1][3], s1, -c1);
+    t[2][1] = twm(t[2][1], h, -h);
+    t[2][2] = crot<SIGN>(t[2][2]);                       // W16^4 = -i (forward)
+    t[2][3] = twm(t[2][3], -h, -h);
+    t[3][1] = twm(t[3][1], s1, -c1);
+    t[3][2] = twm(t[3][2], -h, -h);
+    t[3][3] = twm(t[3][3], -c1, s1);                     // W16^9 = -W16^1 = (-cos(pi/8), +sin(pi/8))
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+      float2 c[4] = {t[0][k1], t[1][k1], t[2][k1], t[3][k1]};
+      butterfly<4, SIGN>(c);
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = c[k2];
+    }
   }
 }
 
@@ -106,6 +153,8 @@ __device__ float2 *fft_lds(float2 *a, float2 *b, const FftPlan &p, const float2 
     const int R = p.radix[s];
     __syncthreads();
     switch (R) {
+      case 16: stockham_stage<16, SIGN>(a, b, p.nh, ns, tw); break;
+      case 8: stockham_stage<8, SIGN>(a, b, p.nh, ns, tw); break;
       case 4: stockham_stage<4, SIGN>(a, b, p.nh, ns, tw); break;
       case 2: stockham_stage<2, SIGN>(a, b, p.nh, ns, tw); break;
       case 3: stockham_stage<3, SIGN>(a, b, p.nh, ns, tw); break;
