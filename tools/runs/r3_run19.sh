@@ -2,7 +2,7 @@
 # round-3 evidence run (final tree, after the occupancy changes): whole GPU suite, the default bench line (driver's command), rocprofv3 stats of the bench and of the sibling probes,
 # PMC passes of the bench configuration (3x3 conv) and of the VR probe (halo kernel), RCCL code path with one rank
 set -u
-O=gpurun_out/r3s
+O=gpurun_out/r3y
 mkdir -p $O
 export PYTHONPATH=$GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
@@ -10,7 +10,7 @@ tail -4 $O/pytest_gpu.log
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
 python - <<'PY'
 import json
-r=json.loads(open('gpurun_out/r3s/bench_n1.json').read().strip().splitlines()[-1])
+r=json.loads(open('gpurun_out/r3y/bench_n1.json').read().strip().splitlines()[-1])
 print(r['value'], r['ms_per_step'], r['roofline']['frac'], r['cpu_baseline'], r.get('parity_rel_rms_vs_cpu'))
 print({k:v.get('value') for k,v in r['siblings'].items()}, r['file_level']['rtf'] if 'rtf' in r['file_level'] else r['file_level'])
 print({k:(v['frac'],v['bound']) for k,v in r['stage_roofline'].items()})
@@ -22,7 +22,7 @@ python - <<'PY'
 import json
 for f in ('b_forced_files','b_forced_chunks'):
     try:
-        r=json.loads(open(f'gpurun_out/r3s/{f}.json').read().strip().splitlines()[-1]); print(f, r['value'], r['ms_per_step'], r['scaling'], r['rccl'], r['config']['workload'][-120:])
+        r=json.loads(open(f'gpurun_out/r3y/{f}.json').read().strip().splitlines()[-1]); print(f, r['value'], r['ms_per_step'], r['scaling'], r['rccl'], r['config']['workload'][-120:])
     except Exception as e: print(f,'ERR',e)
 PY
 cd /tmp && export TMPDIR=/tmp
@@ -34,8 +34,6 @@ done
 cd $GRAFT_REPO_ROOT
 bash tools/pmc_run.sh $O/pmc_bench bench.py --steps 1 --warmup 1 --cpu-seconds 0 --siblings 0 --file-level 0
 python tools/pmc_summary.py $O/pmc_bench > $O/pmc_bench_summary.txt 2>&1
-ASX_HALO_SPLIT128=1 timeout 300 python tools/bench_siblings.py --cpu 0 --steps 2 --workloads vr > $O/sib_vr_split128.jsonl 2> $O/sib_vr_split128.err
-python -c "import json;r=json.loads(open('$O/sib_vr_split128.jsonl').read());print('vr split128', r['value'], r['ms_per_step'])"
 bash tools/pmc_run.sh $O/pmc_ht tools/probe_demucs.py 60 16 2
 python tools/pmc_summary.py $O/pmc_ht > $O/pmc_ht_summary.txt 2>&1
 bash tools/pmc_run.sh $O/pmc_vr tools/probe_vr.py 60 21
