@@ -23,6 +23,7 @@
 #include "kernels_fft3.h"
 #include "kernels_net.h"
 #include "kernels_gemm2.h"
+#include "kernels_wino.h"
 #ifndef ASX_TDF2_DEFAULT
 #define ASX_TDF2_DEFAULT 1
 #endif
@@ -101,6 +102,7 @@ struct ConvLayer {
   int relu = 1;
   DevBuf w, b;
   DevBuf wu;       // CK_3X3 only: Winograd F(2x2,3x3) transformed weights [CG48][NCI8][xi][pair][48][2]
+  DevBuf wu2;      // the same values as [CG48][NCI8][xi][channel 8][48] (conv_wino2_kernel)
   int wu_cg = 0, wu_nci = 0;
 };
 
@@ -174,7 +176,7 @@ struct asx_engine {
   DevBuf d_div;      // divider of the chunk fold for div_key's plan (input-independent: built once, asx_finalize_dev)
   DivKey div_key;
   std::vector<DevBuf> skip;
-  bool winograd = false;  // use conv_wino_kernel for the 3x3 convs (asx_set_option)
+  int winograd = 0;       // 3x3 convs (asx_set_option): 0 direct, 1 conv_wino_kernel, 2 / 3 conv_wino2_kernel<4> / <8>
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -367,7 +369,7 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     L.wu_cg = (L.cout + 47) / 48;
     L.wu_nci = (L.cin + 7) / 8;
-    std::vector<float> wu((size_t)L.wu_cg * L.wu_nci * WinoCfg::USTAGE, 0.f);
+    std::vector<float> wu((size_t)L.wu_cg * L.wu_nci * WinoCfg::USTAGE, 0.f), wu2(wu.size(), 0.f);
     for (int co = 0; co < L.cout; ++co)
       for (int c = 0; c < L.cin; ++c) {
         const float *g = &w[((size_t)co * L.cin + c) * 9];
@@ -378,11 +380,17 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b) {
           for (int bb = 0; bb < 4; ++bb) U[a][bb] = t[a][0] * G[bb][0] + t[a][1] * G[bb][1] + t[a][2] * G[bb][2];
         const int cgi = co / 48, col = co % 48, ci = c / 8, pair = (c % 8) / 2, e = c & 1;
         float *dst = &wu[((size_t)cgi * L.wu_nci + ci) * WinoCfg::USTAGE];
+        float *dst2 = &wu2[((size_t)cgi * L.wu_nci + ci) * WinoCfg::USTAGE];
         for (int a = 0; a < 4; ++a)
-          for (int bb = 0; bb < 4; ++bb) dst[(((a * 4 + bb) * 4 + pair) * 48 + col) * 2 + e] = (float)U[a][bb];
+          for (int bb = 0; bb < 4; ++bb) {
+            dst[(((a * 4 + bb) * 4 + pair) * 48 + col) * 2 + e] = (float)U[a][bb];
+            dst2[((a * 4 + bb) * 8 + (c % 8)) * 48 + col] = (float)U[a][bb];
+          }
       }
     CHK(L.wu.ensure(wu.size() * 4));
     HIPCHK(hipMemcpy(L.wu.p, wu.data(), wu.size() * 4, hipMemcpyHostToDevice));
+    CHK(L.wu2.ensure(wu2.size() * 4));
+    HIPCHK(hipMemcpy(L.wu2.p, wu2.data(), wu2.size() * 4, hipMemcpyHostToDevice));
   }
   const int nb = (L.kind == CK_UP) ? CT * 16 : std::max(L.cg * NW, ((L.cout + 47) / 48) * 48);
   std::vector<float> bp(nb, 0.f);
@@ -474,7 +482,30 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
   const bool dma = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (a.x_bstride % 4 == 0) &&
                    getenv("ASX_NO_DMA") == nullptr;
   const ConvArgs &d = a;
-  if (L.kind == CK_3X3 && e->winograd && dma && L.wu.p != nullptr) {
+  if (L.kind == CK_3X3 && e->winograd >= 2 && dma && L.wu2.p != nullptr) {
+    ConvArgs wa = a;
+    wa.wp = L.wu2.f();
+    wa.CG = L.wu_cg;
+    wa.NCI = L.wu_nci;
+    const bool tall = e->winograd == 3 && a.To >= 16;
+    const int th = tall ? 16 : 8;
+    wa.tilesT = (a.To + th - 1) / th;
+    wa.tilesF = (a.Fo + 31) / 32;
+    const int nb = wa.CG * wa.tilesT * wa.tilesF * B;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                Wino2Cfg<4>::LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                Wino2Cfg<8>::LDS_BYTES);
+      attr_done = true;
+    }
+    return timed(e, cls, flops, bytes, s, [&]() {
+      if (tall) hipLaunchKernelGGL(conv_wino2_kernel<8>, dim3(nb), dim3(512), Wino2Cfg<8>::LDS_BYTES, s, wa);
+      else hipLaunchKernelGGL(conv_wino2_kernel<4>, dim3(nb), dim3(256), Wino2Cfg<4>::LDS_BYTES, s, wa);
+    });
+  }
+  if (L.kind == CK_3X3 && e->winograd == 1 && dma && L.wu.p != nullptr) {
     ConvArgs wa = a;
     wa.wp = L.wu.f();
     wa.CG = L.wu_cg;
@@ -1082,6 +1113,7 @@ static void free_conv(ConvLayer &L) {
   L.w.release();
   L.b.release();
   L.wu.release();
+  L.wu2.release();
 }
 static void free_tdf(TdfLayer &L) {
   L.w.release();
@@ -2851,7 +2883,7 @@ int asx_ht_bag_finish_dev(asx_engine *e, const float *est_dev, const float *tota
 int asx_set_option(asx_engine *e, const char *key, int32_t value) {
   REQUIRE(e && key, "asx_set_option: null argument");
   if (!strcmp(key, "winograd")) {
-    e->winograd = value != 0;
+    e->winograd = value < 0 ? 0 : (int)value;
     return ASX_OK;
   }
   set_err("asx_set_option: unknown option '%s'", key);

@@ -1,0 +1,188 @@
+// Winograd F(2x2, 3x3) for the 3x3 / pad-1 convolutions of the TFC blocks (uvr_lib_v5/modules.py:22-54), second
+// generation: the input transform happens IN REGISTERS, in the MFMA operand layout.
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        (Lavin & Gray 2016; 2.25x fewer multiply-accumulates)
+//
+// The sixteen transform-domain products are sixteen independent [tiles x cin] x [cin x cout] GEMMs on
+// v_mfma_f32_16x16x4_f32.  The A operand of such an MFMA wants, in lane (li, lk), the value V_xi[tile li][channel lk]: the
+// lane reads the 4 x 4 input patch of ITS tile and channel from the staged (haloed) plane and forms all sixteen V_xi with
+// 32 additions -- no transformed tile ever goes through LDS (conv_wino_kernel, kernels_net.h, wrote V to LDS and needed
+// a second barrier per stage, 114 KB of LDS and one wave per SIMD).
+//
+// Workgroup: TR waves; wave w owns tile-row w (16 tiles = 2 x 32 output pixels) for all sixteen positions and 48 output
+// channels: 48 accumulator tiles = 192 VGPRs, so the output transform A^T m A stays lane-local.  Stage = 8 input
+// channels: haloed raw planes ((2 TR + 2) x 40 floats, rows 16-byte aligned) + the pre-transformed weights
+// U [xi][channel][48] (host, fp64 -> fp32), both by LDS-DMA, double buffered, one barrier per stage.
+// LDS: TR = 4: 2 x (12.8 + 24.6) KB = 74.8 KB -> two workgroups per CU; TR = 8: 2 x (23 + 24.6) KB, one 512-thread workgroup.
+#pragma once
+#include "kernels_net.h"
+
+namespace asx {
+
+template <int TR_>
+struct Wino2Cfg {
+  static constexpr int TR = TR_, TC = 16, KC = 8, NREP = 3, NW = 48;
+  static constexpr int TH = 2 * TR, TW = 2 * TC;
+  static constexpr int IH = TH + 2, LP = 3, IWA = 40, C4 = IWA / 4;
+  static constexpr int SLOTS = IH * C4;              // float4 per raw plane
+  static constexpr int NI = (SLOTS + 63) / 64;
+  static constexpr int PS = IH * IWA;                // 400 / 720 floats: = 16 (mod 32), channel lk + 1 sits 16 banks further
+  static constexpr int RAW = KC * PS;
+  static constexpr int USTAGE = 16 * KC * NW;        // [xi][channel][cout] = 6144 floats
+  static constexpr int UWI = USTAGE / 256;
+  static constexpr int BUF = RAW + USTAGE;
+  static constexpr int THREADS = 64 * TR;
+  static constexpr int LDS_BYTES = 2 * BUF * 4;
+  static_assert(KC % TR == 0 || TR % KC == 0, "planes per wave");
+  static_assert(UWI % TR == 0, "weight issues per wave");
+};
+
+template <int TR>
+__global__ __launch_bounds__(64 * TR, (TR == 4 ? 2 : 1)) void conv_wino2_kernel(ConvArgs a) {
+  using CFG = Wino2Cfg<TR>;
+  extern __shared__ float lds_f[];
+  constexpr int KC = CFG::KC, NREP = CFG::NREP, NW = CFG::NW, IWA = CFG::IWA, C4 = CFG::C4, PS = CFG::PS, LP = CFG::LP;
+  constexpr int NI = CFG::NI, SLOTS = CFG::SLOTS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cg = lid % a.CG;
+  lid /= a.CG;
+  const int tf = lid % a.tilesF;
+  lid /= a.tilesF;
+  const int tt = lid % a.tilesT;
+  const int b = lid / a.tilesT;
+  const int to0 = tt * CFG::TH, fo0 = tf * CFG::TW;
+  const int ti0 = to0 - 1, fa0 = fo0 - 1 - LP;   // aligned input origin (fo0 % 32 == 0 -> fa0 % 4 == 0)
+
+  const float *xb = a.x + (int64_t)b * a.x_bstride;
+  const float *ug = a.wp + (int64_t)cg * a.NCI * CFG::USTAGE;
+  const int64_t plane_sz = (int64_t)a.T * a.F;
+
+  int sp_off[NI];
+  bool sp_ok[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int sidx = j * 64 + lane;
+    const int row = sidx / C4, c4 = sidx - row * C4;
+    const int t = ti0 + row, f = fa0 + c4 * 4;
+    sp_ok[j] = (sidx < SLOTS) && t >= 0 && t < a.T && f >= 0 && f < a.F;
+    sp_off[j] = t * a.F + f;
+  }
+
+  auto issue = [&](int ci, int buf) {
+    float *raw = lds_f + buf * CFG::BUF;
+    float *us = raw + CFG::RAW;
+#pragma unroll
+    for (int p = 0; p < (KC + TR - 1) / TR; ++p) {
+      const int pl = wave + TR * p;
+      if (TR > KC && pl >= KC) continue;
+      const int c = ci * KC + pl;
+      const float *xc = xb + (int64_t)c * plane_sz;
+      const bool cok = c < a.Cin;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const float *src = (cok && sp_ok[j]) ? xc + sp_off[j] : a.zeros;
+        if (j * 64 + lane < SLOTS) ASX_GLDS16(src, raw + pl * PS + j * 256);
+      }
+    }
+    const float *ws = ug + (int64_t)ci * CFG::USTAGE;
+#pragma unroll
+    for (int i = 0; i < CFG::UWI / TR; ++i) {
+      const int q = wave + TR * i;
+      ASX_GLDS16(ws + q * 256 + lane * 4, us + q * 256);
+    }
+  };
+
+  f32x4 acc[16][NREP];
+#pragma unroll
+  for (int x = 0; x < 16; ++x)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) acc[x][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  for (int ci = 0; ci < a.NCI; ++ci) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // stage ci landed; every wave is done reading the buffer stage ci + 1 goes into
+    if (ci + 1 < a.NCI) issue(ci + 1, (ci + 1) & 1);
+    const float *raw = lds_f + (ci & 1) * CFG::BUF;
+    const float *us = raw + CFG::RAW;
+#pragma unroll
+    for (int kq = 0; kq < KC / 4; ++kq) {
+      // V = B^T d B of this lane's (tile (wave, li), channel 4 kq + lk)
+      const float *pl = raw + (kq * 4 + lk) * PS + (2 * wave) * IWA + LP + 2 * li;
+      float r[4][4];   // r[col][a] = (B^T d)[a][col]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d0 = pl[j], d1 = pl[IWA + j], d2 = pl[2 * IWA + j], d3 = pl[3 * IWA + j];
+        r[j][0] = d0 - d2;
+        r[j][1] = d1 + d2;
+        r[j][2] = d2 - d1;
+        r[j][3] = d1 - d3;
+      }
+      const float *uk = us + (kq * 4 + lk) * NW + li;
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int ax = x >> 2, bx = x & 3;
+        const float v = bx == 0 ? r[0][ax] - r[2][ax] : (bx == 1 ? r[1][ax] + r[2][ax] : (bx == 2 ? r[2][ax] - r[1][ax] : r[1][ax] - r[3][ax]));
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[x][n] = ASX_MFMA(v, uk[x * KC * NW + n * 16], acc[x][n]);
+      }
+    }
+  }
+
+  // ---- Y = A^T m A, bias, activation, store: lane holds tiles (tile-row = wave, tile-col = 4 lk + r) of cout li ----
+  float *yb = a.y + (int64_t)b * a.y_bstride;
+  const float *rb = a.res ? a.res + (int64_t)b * a.aux_bstride : nullptr;
+  const int t0 = to0 + 2 * wave;
+  const int f0 = fo0 + 8 * lk;
+  const bool full = ((a.Fo & 3) == 0) && (to0 + CFG::TH <= a.To) && (fo0 + CFG::TW <= a.Fo);
+#pragma unroll
+  for (int n = 0; n < NREP; ++n) {
+    const int co = cg * NW + n * 16 + li;
+    const float bv = a.bias[co];
+    if (co >= a.Cout) continue;
+    float o[2][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float c[4][2];   // c[col][p] = (A^T m)[p][col]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m0 = acc[j][n][r], m1 = acc[4 + j][n][r], m2 = acc[8 + j][n][r], m3 = acc[12 + j][n][r];
+        c[j][0] = m0 + m1 + m2;
+        c[j][1] = m1 - m2 - m3;
+      }
+#pragma unroll
+      for (int pq = 0; pq < 2; ++pq) {
+        o[pq][2 * r] = c[0][pq] + c[1][pq] + c[2][pq];
+        o[pq][2 * r + 1] = c[1][pq] - c[2][pq] - c[3][pq];
+      }
+    }
+#pragma unroll
+    for (int pq = 0; pq < 2; ++pq) {
+      const int t = t0 + pq;
+      const int64_t off = ((int64_t)co * a.To + t) * a.Fo + f0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[pq][q] = act_fn(o[pq][q] + bv, a.act);
+      if (full) {
+        f32x4 v0 = {o[pq][0], o[pq][1], o[pq][2], o[pq][3]}, v1 = {o[pq][4], o[pq][5], o[pq][6], o[pq][7]};
+        if (rb != nullptr) {
+          v0 += *reinterpret_cast<const f32x4 *>(rb + off);
+          v1 += *reinterpret_cast<const f32x4 *>(rb + off + 4);
+        }
+        *reinterpret_cast<f32x4 *>(yb + off) = v0;
+        *reinterpret_cast<f32x4 *>(yb + off + 4) = v1;
+      } else if (t < a.To) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (f0 + q < a.Fo) yb[off + q] = o[pq][q] + (rb != nullptr ? rb[off + q] : 0.f);
+      }
+    }
+  }
+}
+
+}  // namespace asx

@@ -20,7 +20,7 @@ out = torch.empty_like(mix)
 eng = A.Engine(A.MDXConfig(max_batch=mb))
 import os
 if os.environ.get('WINO'):
-    eng.set_option('winograd', 1)
+    eng.set_option('winograd', int(os.environ['WINO']))
 eng.load_net(A.NetConfig(), A.fold_convtdf_state(sd, d.num_blocks, d.l))
 s = torch.cuda.current_stream().cuda_stream
 eng.demix_dev(mix.data_ptr(), N, out.data_ptr(), stream=s)
