@@ -103,7 +103,8 @@ struct ConvLayer {
   DevBuf w, b;
   DevBuf wu;       // CK_3X3 only: Winograd F(2x2,3x3) transformed weights [CG48][NCI8][xi][pair][48][2]
   DevBuf wu2;      // the same values as [CG48][NCI8][xi][channel 8][48] (conv_wino2_kernel)
-  int wu_cg = 0, wu_nci = 0;
+  DevBuf wu3;      // and as [CG48][NCI4][channel 4][cout % 16][52: (xi, cout / 16) in MFMA order, 4 pad] (conv_wino3_kernel)
+  int wu_cg = 0, wu_nci = 0, wu3_nci = 0;
 };
 
 struct TdfLayer {
@@ -176,7 +177,7 @@ struct asx_engine {
   DevBuf d_div;      // divider of the chunk fold for div_key's plan (input-independent: built once, asx_finalize_dev)
   DivKey div_key;
   std::vector<DevBuf> skip;
-  int winograd = 0;       // 3x3 convs (asx_set_option): 0 direct, 1 conv_wino_kernel, 2 / 3 conv_wino2_kernel<4> / <8>
+  int winograd = 0;       // 3x3 convs (asx_set_option): 0 direct, 1 conv_wino_kernel, 2 / 4 conv_wino2_kernel<4> / <8>, 3 conv_wino3_kernel
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -369,7 +370,9 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     L.wu_cg = (L.cout + 47) / 48;
     L.wu_nci = (L.cin + 7) / 8;
+    L.wu3_nci = (L.cin + 3) / 4;
     std::vector<float> wu((size_t)L.wu_cg * L.wu_nci * WinoCfg::USTAGE, 0.f), wu2(wu.size(), 0.f);
+    std::vector<float> wu3((size_t)L.wu_cg * L.wu3_nci * Wino3Cfg::USTAGE, 0.f);
     for (int co = 0; co < L.cout; ++co)
       for (int c = 0; c < L.cin; ++c) {
         const float *g = &w[((size_t)co * L.cin + c) * 9];
@@ -381,16 +384,20 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b) {
         const int cgi = co / 48, col = co % 48, ci = c / 8, pair = (c % 8) / 2, e = c & 1;
         float *dst = &wu[((size_t)cgi * L.wu_nci + ci) * WinoCfg::USTAGE];
         float *dst2 = &wu2[((size_t)cgi * L.wu_nci + ci) * WinoCfg::USTAGE];
+        float *dst3 = &wu3[((size_t)cgi * L.wu3_nci + c / 4) * Wino3Cfg::USTAGE + ((size_t)(c % 4) * 16 + col % 16) * Wino3Cfg::ULS];
         for (int a = 0; a < 4; ++a)
           for (int bb = 0; bb < 4; ++bb) {
             dst[(((a * 4 + bb) * 4 + pair) * 48 + col) * 2 + e] = (float)U[a][bb];
             dst2[((a * 4 + bb) * 8 + (c % 8)) * 48 + col] = (float)U[a][bb];
+            dst3[(a * 4 + bb) * 3 + col / 16] = (float)U[a][bb];
           }
       }
     CHK(L.wu.ensure(wu.size() * 4));
     HIPCHK(hipMemcpy(L.wu.p, wu.data(), wu.size() * 4, hipMemcpyHostToDevice));
     CHK(L.wu2.ensure(wu2.size() * 4));
     HIPCHK(hipMemcpy(L.wu2.p, wu2.data(), wu2.size() * 4, hipMemcpyHostToDevice));
+    CHK(L.wu3.ensure(wu3.size() * 4));
+    HIPCHK(hipMemcpy(L.wu3.p, wu3.data(), wu3.size() * 4, hipMemcpyHostToDevice));
   }
   const int nb = (L.kind == CK_UP) ? CT * 16 : std::max(L.cg * NW, ((L.cout + 47) / 48) * 48);
   std::vector<float> bp(nb, 0.f);
@@ -482,12 +489,30 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
   const bool dma = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (a.x_bstride % 4 == 0) &&
                    getenv("ASX_NO_DMA") == nullptr;
   const ConvArgs &d = a;
+  if (L.kind == CK_3X3 && e->winograd == 3 && dma && L.wu3.p != nullptr) {
+    ConvArgs wa = a;
+    wa.wp = L.wu3.f();
+    wa.CG = L.wu_cg;
+    wa.NCI = L.wu3_nci;
+    wa.tilesT = (a.To + Wino3Cfg::TH - 1) / Wino3Cfg::TH;
+    wa.tilesF = (a.Fo + Wino3Cfg::TW - 1) / Wino3Cfg::TW;
+    const int nb = wa.CG * wa.tilesT * wa.tilesF * B;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                Wino3Cfg::LDS_BYTES);
+      attr_done = true;
+    }
+    return timed(e, cls, flops, bytes, s, [&]() {
+      hipLaunchKernelGGL(conv_wino3_kernel<0>, dim3(nb), dim3(256), Wino3Cfg::LDS_BYTES, s, wa);
+    });
+  }
   if (L.kind == CK_3X3 && e->winograd >= 2 && dma && L.wu2.p != nullptr) {
     ConvArgs wa = a;
     wa.wp = L.wu2.f();
     wa.CG = L.wu_cg;
     wa.NCI = L.wu_nci;
-    const bool tall = e->winograd == 3 && a.To >= 16;
+    const bool tall = e->winograd == 4 && a.To >= 16;
     const int th = tall ? 16 : 8;
     wa.tilesT = (a.To + th - 1) / th;
     wa.tilesF = (a.Fo + 31) / 32;
@@ -499,6 +524,23 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 Wino2Cfg<8>::LDS_BYTES);
       attr_done = true;
+    }
+    static const int abl = getenv("ASX_WINO_ABL") ? atoi(getenv("ASX_WINO_ABL")) : 0;   // timing probes (results invalid)
+    if (abl && !tall) {
+      auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wino2Cfg<4>::LDS_BYTES);
+        return timed(e, cls, flops, bytes, s, [&]() { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), Wino2Cfg<4>::LDS_BYTES, s, wa); });
+      };
+      switch (abl) {
+        case 1: return go(&conv_wino2_kernel<4, 1>);
+        case 2: return go(&conv_wino2_kernel<4, 2>);
+        case 4: return go(&conv_wino2_kernel<4, 4>);
+        case 8: return go(&conv_wino2_kernel<4, 8>);
+        case 3: return go(&conv_wino2_kernel<4, 3>);
+        case 11: return go(&conv_wino2_kernel<4, 11>);
+        case 15: return go(&conv_wino2_kernel<4, 15>);
+        default: break;
+      }
     }
     return timed(e, cls, flops, bytes, s, [&]() {
       if (tall) hipLaunchKernelGGL(conv_wino2_kernel<8>, dim3(nb), dim3(512), Wino2Cfg<8>::LDS_BYTES, s, wa);
@@ -1114,6 +1156,7 @@ static void free_conv(ConvLayer &L) {
   L.b.release();
   L.wu.release();
   L.wu2.release();
+  L.wu3.release();
 }
 static void free_tdf(TdfLayer &L) {
   L.w.release();

@@ -37,7 +37,9 @@ struct Wino2Cfg {
   static_assert(UWI % TR == 0, "weight issues per wave");
 };
 
-template <int TR>
+// ABL (ASX_WINO_ABL, measurement-only builds whose results are garbage): 1 = no DMA after the first stage, 2 = no raw reads /
+// input transform (V from registers), 4 = no output stores, 8 = no weight-fragment reads
+template <int TR, int ABL = 0>
 __global__ __launch_bounds__(64 * TR, (TR == 4 ? 2 : 1)) void conv_wino2_kernel(ConvArgs a) {
   using CFG = Wino2Cfg<TR>;
   extern __shared__ float lds_f[];
@@ -108,8 +110,10 @@ __global__ __launch_bounds__(64 * TR, (TR == 4 ? 2 : 1)) void conv_wino2_kernel(
   for (int ci = 0; ci < a.NCI; ++ci) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // stage ci landed; every wave is done reading the buffer stage ci + 1 goes into
-    if (ci + 1 < a.NCI) issue(ci + 1, (ci + 1) & 1);
-    const float *raw = lds_f + (ci & 1) * CFG::BUF;
+    if constexpr (!(ABL & 1)) {
+      if (ci + 1 < a.NCI) issue(ci + 1, (ci + 1) & 1);
+    }
+    const float *raw = lds_f + ((ABL & 1) ? 0 : (ci & 1)) * CFG::BUF;
     const float *us = raw + CFG::RAW;
 #pragma unroll
     for (int kq = 0; kq < KC / 4; ++kq) {
@@ -118,7 +122,12 @@ __global__ __launch_bounds__(64 * TR, (TR == 4 ? 2 : 1)) void conv_wino2_kernel(
       float r[4][4];   // r[col][a] = (B^T d)[a][col]
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float d0 = pl[j], d1 = pl[IWA + j], d2 = pl[2 * IWA + j], d3 = pl[3 * IWA + j];
+        float d0, d1, d2, d3;
+        if constexpr (ABL & 2) {
+          d0 = (float)(ci + j), d1 = (float)(kq + lane), d2 = (float)(ci * j), d3 = (float)(lane - ci);
+        } else {
+          d0 = pl[j], d1 = pl[IWA + j], d2 = pl[2 * IWA + j], d3 = pl[3 * IWA + j];
+        }
         r[j][0] = d0 - d2;
         r[j][1] = d1 + d2;
         r[j][2] = d2 - d1;
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(64 * TR, (TR == 4 ? 2 : 1)) void conv_wino2_kernel(
         const int ax = x >> 2, bx = x & 3;
         const float v = bx == 0 ? r[0][ax] - r[2][ax] : (bx == 1 ? r[1][ax] + r[2][ax] : (bx == 2 ? r[2][ax] - r[1][ax] : r[1][ax] - r[3][ax]));
 #pragma unroll
-        for (int n = 0; n < NREP; ++n) acc[x][n] = ASX_MFMA(v, uk[x * KC * NW + n * 16], acc[x][n]);
+        for (int n = 0; n < NREP; ++n) acc[x][n] = ASX_MFMA(v, (ABL & 8) ? (float)(x + n + ci) : uk[x * KC * NW + n * 16], acc[x][n]);
       }
     }
   }
@@ -141,6 +150,15 @@ __global__ __launch_bounds__(64 * TR, (TR == 4 ? 2 : 1)) void conv_wino2_kernel(
   const int t0 = to0 + 2 * wave;
   const int f0 = fo0 + 8 * lk;
   const bool full = ((a.Fo & 3) == 0) && (to0 + CFG::TH <= a.To) && (fo0 + CFG::TW <= a.Fo);
+  if constexpr ((ABL & 4) != 0) {
+    float chk = 0.f;
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) chk += acc[x][n][0] + acc[x][n][1] + acc[x][n][2] + acc[x][n][3];
+    if (chk == 1.2345e-30f) a.y[0] = chk;
+    return;
+  }
 #pragma unroll
   for (int n = 0; n < NREP; ++n) {
     const int co = cg * NW + n * 16 + li;
@@ -160,6 +178,193 @@ __global__ __launch_bounds__(64 * TR, (TR == 4 ? 2 : 1)) void conv_wino2_kernel(
       for (int pq = 0; pq < 2; ++pq) {
         o[pq][2 * r] = c[0][pq] + c[1][pq] + c[2][pq];
         o[pq][2 * r + 1] = c[1][pq] - c[2][pq] - c[3][pq];
+      }
+    }
+#pragma unroll
+    for (int pq = 0; pq < 2; ++pq) {
+      const int t = t0 + pq;
+      const int64_t off = ((int64_t)co * a.To + t) * a.Fo + f0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[pq][q] = act_fn(o[pq][q] + bv, a.act);
+      if (full) {
+        f32x4 v0 = {o[pq][0], o[pq][1], o[pq][2], o[pq][3]}, v1 = {o[pq][4], o[pq][5], o[pq][6], o[pq][7]};
+        if (rb != nullptr) {
+          v0 += *reinterpret_cast<const f32x4 *>(rb + off);
+          v1 += *reinterpret_cast<const f32x4 *>(rb + off + 4);
+        }
+        *reinterpret_cast<f32x4 *>(yb + off) = v0;
+        *reinterpret_cast<f32x4 *>(yb + off + 4) = v1;
+      } else if (t < a.To) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (f0 + q < a.Fo) yb[off + q] = o[pq][q] + (rb != nullptr ? rb[off + q] : 0.f);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Third generation: the same register transform, with the measured costs of conv_wino2_kernel addressed (ASX_WINO_ABL on the
+// 4-minute song: full 160.7 ms; without the DMA stream after the first stage 128.9; without weight-fragment reads 146.6;
+// without raw reads 151.4; without stores 143.2; MFMA + transform alone 106.5):
+//   * stages of FOUR channels in a ring of four LDS buffers, three stages of LDS-DMA in flight (counted vmcnt + raw s_barrier:
+//     a stage has ~3.8 us to land instead of one stage time);
+//   * weight fragments as ds_read_b128: the stage image is [channel][cout % 16][52] with the 48 values a lane needs
+//     ((xi, cout / 16) in MFMA order) contiguous, 52-float lane stride = conflict-free quads; 12 reads per k-step instead of 48.
+// LDS: 4 x (6.4 + 13.3) KB = 78.8 KB -> two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Wino3Cfg {
+  static constexpr int TR = 4, TC = 16, KC = 4, NREP = 3, NW = 48, NB = 4, D = NB - 1;
+  static constexpr int TH = 2 * TR, TW = 2 * TC;
+  static constexpr int IH = TH + 2, LP = 3, IWA = 40, C4 = IWA / 4;
+  static constexpr int SLOTS = IH * C4, NI = (SLOTS + 63) / 64;
+  static constexpr int PS = IH * IWA, RAW = KC * PS;
+  static constexpr int ULS = 52;                       // lane stride of the weight image (floats)
+  static constexpr int USTAGE = KC * 16 * ULS;         // 3328 floats
+  static constexpr int UWI = USTAGE / 256;             // 13 wave-issues: waves 0..3 take 3 each, wave 0 one more
+  static constexpr int BUF = RAW + USTAGE;
+  static constexpr int LDS_BYTES = NB * BUF * 4;
+  static_assert(USTAGE % 256 == 0 && UWI == 13 && NI == 2, "issue counts are hard-wired into the vmcnt immediates");
+};
+
+#define ASX_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a) {
+  using CFG = Wino3Cfg;
+  extern __shared__ float lds_f[];
+  constexpr int KC = CFG::KC, NREP = CFG::NREP, NW = CFG::NW, IWA = CFG::IWA, C4 = CFG::C4, PS = CFG::PS, LP = CFG::LP;
+  constexpr int NI = CFG::NI, SLOTS = CFG::SLOTS, NB = CFG::NB, D = CFG::D;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cg = lid % a.CG;
+  lid /= a.CG;
+  const int tf = lid % a.tilesF;
+  lid /= a.tilesF;
+  const int tt = lid % a.tilesT;
+  const int b = lid / a.tilesT;
+  const int to0 = tt * CFG::TH, fo0 = tf * CFG::TW;
+  const int ti0 = to0 - 1, fa0 = fo0 - 1 - LP;
+
+  const float *xb = a.x + (int64_t)b * a.x_bstride;
+  const float *ug = a.wp + (int64_t)cg * a.NCI * CFG::USTAGE;
+  const int64_t plane_sz = (int64_t)a.T * a.F;
+
+  int sp_off[NI];
+  bool sp_ok[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int sidx = j * 64 + lane;
+    const int row = sidx / C4, c4 = sidx - row * C4;
+    const int t = ti0 + row, f = fa0 + c4 * 4;
+    sp_ok[j] = (sidx < SLOTS) && t >= 0 && t < a.T && f >= 0 && f < a.F;
+    sp_off[j] = t * a.F + f;
+  }
+
+  // per wave and stage: 2 raw issues (plane = wave) + 3 weight issues (+ 1 on wave 0) -- the vmcnt immediates below count them
+  auto issue = [&](int ci, int buf) {
+    float *raw = lds_f + buf * CFG::BUF;
+    float *us = raw + CFG::RAW;
+    const int c = ci * KC + wave;
+    const float *xc = xb + (int64_t)c * plane_sz;
+    const bool cok = c < a.Cin;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const float *src = (cok && sp_ok[j]) ? xc + sp_off[j] : a.zeros;
+      if (j * 64 + lane < SLOTS) ASX_GLDS16(src, raw + wave * PS + j * 256);
+    }
+    const float *ws = ug + (int64_t)ci * CFG::USTAGE;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int q = wave + 4 * i;
+      ASX_GLDS16(ws + q * 256 + lane * 4, us + q * 256);
+    }
+    if (wave == 0) ASX_GLDS16(ws + 12 * 256 + lane * 4, us + 12 * 256);
+  };
+
+  f32x4 acc[16][NREP];
+#pragma unroll
+  for (int x = 0; x < 16; ++x)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) acc[x][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < a.NCI) issue(s, s);
+
+  const float *plb = lds_f + lk * PS + (2 * wave) * IWA + LP + 2 * li;
+  const float *uqb = lds_f + CFG::RAW + (lk * 16 + li) * CFG::ULS;
+  int buf = 0;
+  for (int ci = 0; ci < a.NCI; ++ci) {
+    // retire stage ci (this wave's share), leave the younger stages in flight
+    const int rem = min(D - 1, a.NCI - 1 - ci);
+    if (wave == 0) {
+      if (rem >= 2) ASX_VMCNT(12);
+      else if (rem == 1) ASX_VMCNT(6);
+      else ASX_VMCNT(0);
+    } else {
+      if (rem >= 2) ASX_VMCNT(10);
+      else if (rem == 1) ASX_VMCNT(5);
+      else ASX_VMCNT(0);
+    }
+    asm volatile("s_barrier" ::: "memory");   // stage ci landed for every wave; every wave is done with stage ci - 1's buffer
+    if constexpr (!(ABL & 1)) {
+      if (ci + D < a.NCI) issue(ci + D, (buf + D) % NB);
+    }
+    const float *pl = plb + buf * CFG::BUF;
+    const f32x4 *uq = reinterpret_cast<const f32x4 *>(uqb + buf * CFG::BUF);
+    float r[4][4];   // r[col][a] = (B^T d)[a][col]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d0 = pl[j], d1 = pl[IWA + j], d2 = pl[2 * IWA + j], d3 = pl[3 * IWA + j];
+      r[j][0] = d0 - d2;
+      r[j][1] = d1 + d2;
+      r[j][2] = d2 - d1;
+      r[j][3] = d1 - d3;
+    }
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const int ax = x >> 2, bx = x & 3;
+      const float v = bx == 0 ? r[0][ax] - r[2][ax] : (bx == 1 ? r[1][ax] + r[2][ax] : (bx == 2 ? r[2][ax] - r[1][ax] : r[1][ax] - r[3][ax]));
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) {
+        const int idx = x * 3 + n;
+        acc[x][n] = ASX_MFMA(v, uq[idx >> 2][idx & 3], acc[x][n]);
+      }
+    }
+    buf = buf + 1 == NB ? 0 : buf + 1;
+  }
+
+  // ---- Y = A^T m A, bias, activation, store: lane holds tiles (tile-row = wave, tile-col = 4 lk + r) of cout li ----
+  float *yb = a.y + (int64_t)b * a.y_bstride;
+  const float *rb = a.res ? a.res + (int64_t)b * a.aux_bstride : nullptr;
+  const int t0 = to0 + 2 * wave;
+  const int f0 = fo0 + 8 * lk;
+  const bool full = ((a.Fo & 3) == 0) && (to0 + CFG::TH <= a.To) && (fo0 + CFG::TW <= a.Fo);
+#pragma unroll
+  for (int n = 0; n < NREP; ++n) {
+    const int co = cg * NW + n * 16 + li;
+    const float bv = a.bias[co];
+    if (co >= a.Cout) continue;
+    float o[2][8];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      float c[4][2];   // c[col][p] = (A^T m)[p][col]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m0 = acc[j][n][r4], m1 = acc[4 + j][n][r4], m2 = acc[8 + j][n][r4], m3 = acc[12 + j][n][r4];
+        c[j][0] = m0 + m1 + m2;
+        c[j][1] = m1 - m2 - m3;
+      }
+#pragma unroll
+      for (int pq = 0; pq < 2; ++pq) {
+        o[pq][2 * r4] = c[0][pq] + c[1][pq] + c[2][pq];
+        o[pq][2 * r4 + 1] = c[1][pq] - c[2][pq] - c[3][pq];
       }
     }
 #pragma unroll
