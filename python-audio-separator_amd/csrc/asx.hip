@@ -177,7 +177,10 @@ struct asx_engine {
   DevBuf d_div;      // divider of the chunk fold for div_key's plan (input-independent: built once, asx_finalize_dev)
   DivKey div_key;
   std::vector<DevBuf> skip;
-  int winograd = 0;       // 3x3 convs (asx_set_option): 0 direct, 1 conv_wino_kernel, 2 / 4 conv_wino2_kernel<4> / <8>, 3 conv_wino3_kernel
+  // 3x3 / pad-1 convs of the ConvTDFNet and TFC-TDF-v3 nets: 3 = Winograd F(2x2,3x3) (conv_wino3_kernel, the default), 0 = the
+  // direct kernel (conv_dma_kernel), 1 / 2 = the earlier Winograd generations (kept for A/B runs).  ASX_WINOGRAD or
+  // asx_set_option("winograd", n).
+  int winograd = getenv("ASX_WINOGRAD") ? std::max(0, atoi(getenv("ASX_WINOGRAD"))) : 3;
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -503,6 +506,22 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
                                 Wino3Cfg::LDS_BYTES);
       attr_done = true;
     }
+    static const int abl3 = getenv("ASX_WINO_ABL") ? atoi(getenv("ASX_WINO_ABL")) : 0;   // timing probes (results invalid)
+    if (abl3) {
+      auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wino3Cfg::LDS_BYTES);
+        return timed(e, cls, flops, bytes, s, [&]() { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), Wino3Cfg::LDS_BYTES, s, wa); });
+      };
+      switch (abl3) {
+        case 1: return go(&conv_wino3_kernel<1>);
+        case 2: return go(&conv_wino3_kernel<2>);
+        case 4: return go(&conv_wino3_kernel<4>);
+        case 8: return go(&conv_wino3_kernel<8>);
+        case 16: return go(&conv_wino3_kernel<16>);
+        case 15: return go(&conv_wino3_kernel<15>);
+        default: break;
+      }
+    }
     return timed(e, cls, flops, bytes, s, [&]() {
       hipLaunchKernelGGL(conv_wino3_kernel<0>, dim3(nb), dim3(256), Wino3Cfg::LDS_BYTES, s, wa);
     });
@@ -512,21 +531,17 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     wa.wp = L.wu2.f();
     wa.CG = L.wu_cg;
     wa.NCI = L.wu_nci;
-    const bool tall = e->winograd == 4 && a.To >= 16;
-    const int th = tall ? 16 : 8;
-    wa.tilesT = (a.To + th - 1) / th;
+    wa.tilesT = (a.To + 7) / 8;
     wa.tilesF = (a.Fo + 31) / 32;
     const int nb = wa.CG * wa.tilesT * wa.tilesF * B;
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 Wino2Cfg<4>::LDS_BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                Wino2Cfg<8>::LDS_BYTES);
       attr_done = true;
     }
     static const int abl = getenv("ASX_WINO_ABL") ? atoi(getenv("ASX_WINO_ABL")) : 0;   // timing probes (results invalid)
-    if (abl && !tall) {
+    if (abl) {
       auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wino2Cfg<4>::LDS_BYTES);
         return timed(e, cls, flops, bytes, s, [&]() { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), Wino2Cfg<4>::LDS_BYTES, s, wa); });
@@ -543,8 +558,7 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
       }
     }
     return timed(e, cls, flops, bytes, s, [&]() {
-      if (tall) hipLaunchKernelGGL(conv_wino2_kernel<8>, dim3(nb), dim3(512), Wino2Cfg<8>::LDS_BYTES, s, wa);
-      else hipLaunchKernelGGL(conv_wino2_kernel<4>, dim3(nb), dim3(256), Wino2Cfg<4>::LDS_BYTES, s, wa);
+      hipLaunchKernelGGL(conv_wino2_kernel<4>, dim3(nb), dim3(256), Wino2Cfg<4>::LDS_BYTES, s, wa);
     });
   }
   if (L.kind == CK_3X3 && e->winograd == 1 && dma && L.wu.p != nullptr) {

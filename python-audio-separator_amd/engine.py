@@ -401,6 +401,7 @@ class Engine:
     def __init__(self, cfg: MDXConfig, device: int = 0):
         self._lib = load_library()
         self._h = C.c_void_p()
+        self._options = {}
         self.cfg = cfg
         self.device = device
         self.net_cfg = None
@@ -429,6 +430,12 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         self._check(self._lib.asx_set_option(self._h, key.encode(), int(value)))
+        self._options[key] = int(value)
+
+    def option(self, key: str) -> int:
+        """Current value of an engine option (the library default when it was never set here)."""
+        defaults = {"winograd": max(0, int(os.environ.get("ASX_WINOGRAD", "3")))}
+        return self._options.get(key, defaults[key])
 
     # -- weights ------------------------------------------------------------
     def load_net(self, net_cfg: NetConfig, tensors: dict):
