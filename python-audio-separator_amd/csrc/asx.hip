@@ -16,6 +16,7 @@
 #include <functional>
 #include <map>
 #include <string>
+#include <set>
 #include <vector>
 
 #include "../../include/asx.h"
@@ -373,7 +374,7 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     L.wu_cg = (L.cout + 47) / 48;
     L.wu_nci = (L.cin + 7) / 8;
-    L.wu3_nci = (L.cin + 3) / 4;
+    L.wu3_nci = ((L.cin + 7) / 8) * 2;     // four-channel stage images, an even number of them (zero padded): the kernel's 8-channel build reads pairs
     std::vector<float> wu((size_t)L.wu_cg * L.wu_nci * WinoCfg::USTAGE, 0.f), wu2(wu.size(), 0.f);
     std::vector<float> wu3((size_t)L.wu_cg * L.wu3_nci * Wino3Cfg::USTAGE, 0.f);
     for (int co = 0; co < L.cout; ++co)
@@ -500,31 +501,30 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     wa.tilesT = (a.To + Wino3Cfg::TH - 1) / Wino3Cfg::TH;
     wa.tilesF = (a.Fo + Wino3Cfg::TW - 1) / Wino3Cfg::TW;
     const int nb = wa.CG * wa.tilesT * wa.tilesF * B;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                Wino3Cfg::LDS_BYTES);
-      attr_done = true;
-    }
     static const int abl3 = getenv("ASX_WINO_ABL") ? atoi(getenv("ASX_WINO_ABL")) : 0;   // timing probes (results invalid)
+    static const int wcfg = getenv("ASX_WINO_CFG") ? atoi(getenv("ASX_WINO_CFG")) : 0;   // 0: 4-channel stages x 4 buffers, 1: 8 x 2, 2: 4 x 3, 3: 4 x 4 with the next stage's raw reads pipelined
+    auto go = [&](auto kern, int lds, int stages) {
+      static std::set<const void *> attr_done;
+      if (attr_done.insert(reinterpret_cast<const void *>(kern)).second)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      wa.NCI = stages;
+      return timed(e, cls, flops, bytes, s, [&]() { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, s, wa); });
+    };
     if (abl3) {
-      auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wino3Cfg::LDS_BYTES);
-        return timed(e, cls, flops, bytes, s, [&]() { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), Wino3Cfg::LDS_BYTES, s, wa); });
-      };
       switch (abl3) {
-        case 1: return go(&conv_wino3_kernel<1>);
-        case 2: return go(&conv_wino3_kernel<2>);
-        case 4: return go(&conv_wino3_kernel<4>);
-        case 8: return go(&conv_wino3_kernel<8>);
-        case 16: return go(&conv_wino3_kernel<16>);
-        case 15: return go(&conv_wino3_kernel<15>);
+        case 1: return go(&conv_wino3_kernel<1>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
+        case 2: return go(&conv_wino3_kernel<2>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
+        case 4: return go(&conv_wino3_kernel<4>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
+        case 8: return go(&conv_wino3_kernel<8>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
+        case 16: return go(&conv_wino3_kernel<16>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
+        case 15: return go(&conv_wino3_kernel<15>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
         default: break;
       }
     }
-    return timed(e, cls, flops, bytes, s, [&]() {
-      hipLaunchKernelGGL(conv_wino3_kernel<0>, dim3(nb), dim3(256), Wino3Cfg::LDS_BYTES, s, wa);
-    });
+    if (wcfg == 1) return go(&conv_wino3_kernel<0, 8, 2>, Wino3CfgT<8, 2>::LDS_BYTES, L.wu3_nci / 2);
+    if (wcfg == 2) return go(&conv_wino3_kernel<0, 4, 3>, Wino3CfgT<4, 3>::LDS_BYTES, L.wu3_nci);
+    if (wcfg == 3) return go(&conv_wino3_kernel<0, 4, 4, 1>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
+    return go(&conv_wino3_kernel<0>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
   }
   if (L.kind == CK_3X3 && e->winograd >= 2 && dma && L.wu2.p != nullptr) {
     ConvArgs wa = a;

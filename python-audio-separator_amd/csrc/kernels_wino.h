@@ -213,25 +213,30 @@ __global__ __launch_bounds__(64 * TR, (TR == 4 ? 2 : 1)) void conv_wino2_kernel(
 //     ((xi, cout / 16) in MFMA order) contiguous, 52-float lane stride = conflict-free quads; 12 reads per k-step instead of 48.
 // LDS: 4 x (6.4 + 13.3) KB = 78.8 KB -> two workgroups per CU.
 // ---------------------------------------------------------------------------------------------------------------------------
-struct Wino3Cfg {
-  static constexpr int TR = 4, TC = 16, KC = 4, NREP = 3, NW = 48, NB = 4, D = NB - 1;
+template <int KC_ = 4, int NB_ = 4>
+struct Wino3CfgT {
+  static constexpr int TR = 4, TC = 16, KC = KC_, NREP = 3, NW = 48, NB = NB_, D = NB - 1;
   static constexpr int TH = 2 * TR, TW = 2 * TC;
   static constexpr int IH = TH + 2, LP = 3, IWA = 40, C4 = IWA / 4;
   static constexpr int SLOTS = IH * C4, NI = (SLOTS + 63) / 64;
   static constexpr int PS = IH * IWA, RAW = KC * PS;
   static constexpr int ULS = 52;                       // lane stride of the weight image (floats)
-  static constexpr int USTAGE = KC * 16 * ULS;         // 3328 floats
-  static constexpr int UWI = USTAGE / 256;             // 13 wave-issues: waves 0..3 take 3 each, wave 0 one more
+  static constexpr int USTAGE = KC * 16 * ULS;         // 3328 floats per four channels
+  static constexpr int UWI = USTAGE / 256;             // 13 / 26 wave-issues, dealt round-robin to the four waves
   static constexpr int BUF = RAW + USTAGE;
   static constexpr int LDS_BYTES = NB * BUF * 4;
-  static_assert(USTAGE % 256 == 0 && UWI == 13 && NI == 2, "issue counts are hard-wired into the vmcnt immediates");
+  static_assert(USTAGE % 256 == 0 && NI == 2 && (KC == 4 || KC == 8), "issue counts are hard-wired into the vmcnt immediates");
 };
+typedef Wino3CfgT<4, 4> Wino3Cfg;   // the weight image / stage size the host packs for (KC = 8 stages are two of them)
 
 #define ASX_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int ABL = 0>
+// PIPE (four-channel stages only): the raw reads and the row transform of stage s + 1 are issued among the MFMAs of stage s (the
+// barrier that publishes stage s + 1 sits at the top of stage s), so a wave leaves a stage boundary with its next operands already
+// in registers; the price is one stage less for the DMA to land (two instead of three).
+template <int ABL = 0, int KC_ = 4, int NB_ = 4, int PIPE = 0>
 __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a) {
-  using CFG = Wino3Cfg;
+  using CFG = Wino3CfgT<KC_, NB_>;
   extern __shared__ float lds_f[];
   constexpr int KC = CFG::KC, NREP = CFG::NREP, NW = CFG::NW, IWA = CFG::IWA, C4 = CFG::C4, PS = CFG::PS, LP = CFG::LP;
   constexpr int NI = CFG::NI, SLOTS = CFG::SLOTS, NB = CFG::NB, D = CFG::D;
@@ -278,29 +283,36 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return reinterpret_cast<const char *>(((uint64_t)hi << 32) | lo);
   };
-  // per wave and stage: 2 raw issues (plane = wave) + 3 weight issues (+ 1 on wave 0) -- the vmcnt immediates below count them
+  // per wave and stage: 2 raw issues per four channels (plane = wave, wave + 4) + the weight issues q = wave, wave + 4, ... < UWI
+  // -- the vmcnt immediates below count them
+  constexpr int UWI = CFG::UWI;
+  const int my_pieces = NI * (KC / 4) + (UWI - wave + 3) / 4;
   auto issue = [&](int ci, int buf) {
     float *raw = lds_f + buf * CFG::BUF;
     float *us = raw + CFG::RAW;
-    const int c = ci * KC + wave;
-    const float *xc = xb + (int64_t)c * plane_sz;
-    const bool cok = c < a.Cin;
-    if (interior && cok) {
-      const char *xs = sbase(xc);
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-        if (j * 64 + lane < SLOTS) ASX_GLDS16(xs + voff[j], raw + wave * PS + j * 256);
-    } else {
+    for (int p = 0; p < KC / 4; ++p) {
+      const int pl = wave + 4 * p;
+      const int c = ci * KC + pl;
+      const float *xc = xb + (int64_t)c * plane_sz;
+      const bool cok = c < a.Cin;
+      if (interior && cok) {
+        const char *xs = sbase(xc);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const float *src = (cok && sp_ok[j]) ? xc + sp_off[j] : a.zeros;
-        if (j * 64 + lane < SLOTS) ASX_GLDS16(src, raw + wave * PS + j * 256);
+        for (int j = 0; j < NI; ++j)
+          if (j * 64 + lane < SLOTS) ASX_GLDS16(xs + voff[j], raw + pl * PS + j * 256);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const float *src = (cok && sp_ok[j]) ? xc + sp_off[j] : a.zeros;
+          if (j * 64 + lane < SLOTS) ASX_GLDS16(src, raw + pl * PS + j * 256);
+        }
       }
     }
     const char *ws = sbase(ug + (int64_t)ci * CFG::USTAGE + wave * 256);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) ASX_GLDS16(ws + i * 4096 + voff_u, us + (wave + 4 * i) * 256);
-    if (wave == 0) ASX_GLDS16(ws + 12 * 1024 + voff_u, us + 12 * 256);
+    for (int i = 0; i < (UWI + 3) / 4; ++i)
+      if (wave + 4 * i < UWI) ASX_GLDS16(ws + i * 4096 + voff_u, us + (wave + 4 * i) * 256);
   };
 
   f32x4 acc[16][NREP];
@@ -315,25 +327,98 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a) {
 
   const float *plb = lds_f + lk * PS + (2 * wave) * IWA + LP + 2 * li;
   const float *uqb = lds_f + CFG::RAW + (lk * 16 + li) * CFG::ULS;
+  auto wait_pieces = [&](int n) {               // wave-uniform: pieces of the younger stages that may stay in flight
+    switch (n) {
+      case 5: ASX_VMCNT(5); break;
+      case 6: ASX_VMCNT(6); break;
+      case 10: ASX_VMCNT(10); break;
+      case 12: ASX_VMCNT(12); break;
+      default: ASX_VMCNT(0); break;
+    }
+  };
+  auto row_transform = [&](const float *pl, float (&r)[4][4]) {   // r[col][a] = (B^T d)[a][col]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d0 = pl[j], d1 = pl[IWA + j], d2 = pl[2 * IWA + j], d3 = pl[3 * IWA + j];
+      r[j][0] = d0 - d2;
+      r[j][1] = d1 + d2;
+      r[j][2] = d2 - d1;
+      r[j][3] = d1 - d3;
+    }
+  };
+  if constexpr (PIPE != 0) {
+    static_assert(PIPE == 0 || (KC == 4 && NB >= 3), "the pipelined loop is written for four-channel stages");
+    float rn[4][4];
+    wait_pieces(min(D - 1, a.NCI - 1) * my_pieces);
+    asm volatile("s_barrier" ::: "memory");
+    row_transform(plb, rn);
+    int buf = 0;
+    for (int ci = 0; ci < a.NCI; ++ci) {
+      const int nbuf = buf + 1 == NB ? 0 : buf + 1;
+      if (ci + 1 < a.NCI) {
+        wait_pieces(min(D - 2, a.NCI - 2 - ci) * my_pieces);
+        asm volatile("s_barrier" ::: "memory");   // stage ci + 1 landed for every wave; every wave is done with stage ci - 1's buffer
+        if (ci + D < a.NCI) issue(ci + D, (buf + D) % NB);
+      }
+      float r[4][4], dn[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[j][q] = rn[j][q];
+      const f32x4 *uq = reinterpret_cast<const f32x4 *>(uqb + buf * CFG::BUF);
+      const float *pn = plb + nbuf * CFG::BUF;
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int ax = x >> 2, bx = x & 3;
+        const float v = bx == 0 ? r[0][ax] - r[2][ax] : (bx == 1 ? r[1][ax] + r[2][ax] : (bx == 2 ? r[2][ax] - r[1][ax] : r[1][ax] - r[3][ax]));
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+          const int idx = x * 3 + n;
+          acc[x][n] = ASX_MFMA(v, uq[idx >> 2][idx & 3], acc[x][n]);
+        }
+        // next stage's raw patch: requested early, transformed late, so the LDS latency sits under this stage's MFMAs
+        if (x == 1 && ci + 1 < a.NCI) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dn[i][j] = pn[i * IWA + j];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (x == 12 && ci + 1 < a.NCI) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            rn[j][0] = dn[0][j] - dn[2][j];
+            rn[j][1] = dn[1][j] + dn[2][j];
+            rn[j][2] = dn[2][j] - dn[1][j];
+            rn[j][3] = dn[1][j] - dn[3][j];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      buf = nbuf;
+    }
+  } else {
   int buf = 0;
   for (int ci = 0; ci < a.NCI; ++ci) {
     // retire stage ci (this wave's share), leave the younger stages in flight
     const int rem = min(D - 1, a.NCI - 1 - ci);
-    if (wave == 0) {
-      if (rem >= 2) ASX_VMCNT(12);
-      else if (rem == 1) ASX_VMCNT(6);
-      else ASX_VMCNT(0);
-    } else {
-      if (rem >= 2) ASX_VMCNT(10);
-      else if (rem == 1) ASX_VMCNT(5);
-      else ASX_VMCNT(0);
+    switch (rem * my_pieces) {                 // wave-uniform: pieces of the younger stages that may stay in flight
+      case 5: ASX_VMCNT(5); break;
+      case 6: ASX_VMCNT(6); break;
+      case 10: ASX_VMCNT(10); break;
+      case 12: ASX_VMCNT(12); break;
+      default: ASX_VMCNT(0); break;
     }
     asm volatile("s_barrier" ::: "memory");   // stage ci landed for every wave; every wave is done with stage ci - 1's buffer
     if constexpr (!(ABL & 1)) {
       if (ci + D < a.NCI) issue(ci + D, (buf + D) % NB);
     }
-    const float *pl = plb + buf * CFG::BUF;
-    const f32x4 *uq = reinterpret_cast<const f32x4 *>(uqb + buf * CFG::BUF);
+#pragma unroll
+    for (int kq = 0; kq < KC / 4; ++kq) {
+    const float *pl = plb + buf * CFG::BUF + kq * 4 * PS;
+    const f32x4 *uq = reinterpret_cast<const f32x4 *>(uqb + buf * CFG::BUF + kq * 64 * CFG::ULS);
     float r[4][4];   // r[col][a] = (B^T d)[a][col]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -355,10 +440,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a) {
 #pragma unroll
       for (int n = 0; n < NREP; ++n) {
         const int idx = x * 3 + n;
-        acc[x][n] = ASX_MFMA(v, (ABL & 8) ? (float)(idx + ci) : uq[idx >> 2][idx & 3], acc[x][n]);
+        acc[x][n] = ASX_MFMA(v, (ABL & 8) ? r[n][bx] : uq[idx >> 2][idx & 3], acc[x][n]);
       }
     }
+    }
     buf = buf + 1 == NB ? 0 : buf + 1;
+  }
+
   }
 
   // ---- Y = A^T m A, bias, activation, store: lane holds tiles (tile-row = wave, tile-col = 4 lk + r) of cout li ----

@@ -22,8 +22,12 @@ eng.demix_dev(mix.data_ptr(), n, out.data_ptr(), stream=st)
 torch.cuda.synchronize()
 eng.profile_enable(True)
 eng.demix_dev(mix.data_ptr(), n, out.data_ptr(), stream=st)
-recs = [r for r in eng.profile_launches() if r[0] == "conv3x3"]
+allrecs = eng.profile_launches()
+recs = [r for r in allrecs if r[0] == "conv3x3"]
 eng.profile_enable(False)
+if os.environ.get("TDF"):
+    t = [r for r in allrecs if r[0] == "tdf"]
+    print("tdf total %.2f ms;" % sum(r[1] for r in t), "per launch (ms | TF/s):", " ".join(f"{r[1]:.2f}|{r[2] / r[1] / 1e9:.0f}" for r in t), flush=True)
 tot = sum(r[1] for r in recs)
 tag = f"WINO={os.environ.get('WINO', '0')} ABL={os.environ.get('ASX_WINO_ABL', '0')}"
 print(tag, f"conv3x3 total {tot:.2f} ms;", "per launch (ms | direct-equivalent TF/s):",
