@@ -211,15 +211,20 @@ __global__ __launch_bounds__(64 * TR, (TR == 4 ? 2 : 1)) void conv_wino2_kernel(
 //     a stage has ~3.8 us to land instead of one stage time);
 //   * weight fragments as ds_read_b128: the stage image is [channel][cout % 16][52] with the 48 values a lane needs
 //     ((xi, cout / 16) in MFMA order) contiguous, 52-float lane stride = conflict-free quads; 12 reads per k-step instead of 48.
-// LDS: 4 x (6.4 + 13.3) KB = 78.8 KB -> two workgroups per CU.
+//   * raw planes at an ODD float stride (401): the sixteen tiles of a ds_read_b32 pass are two floats apart and so hit banks of one
+//     parity only; the odd stride puts the pass's second channel on the other parity (conflict-free instead of 2-way; the LDS-DMA
+//     destination of a plane is then only 4-byte aligned, which the hardware accepts -- the parity tests run this build).
+// LDS: 4 x (6.4 + 13.3) KB = 78.9 KB -> two workgroups per CU.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int KC_ = 4, int NB_ = 4>
+template <int KC_ = 4, int NB_ = 4, int PSPAD_ = 0>
 struct Wino3CfgT {
   static constexpr int TR = 4, TC = 16, KC = KC_, NREP = 3, NW = 48, NB = NB_, D = NB - 1;
   static constexpr int TH = 2 * TR, TW = 2 * TC;
   static constexpr int IH = TH + 2, LP = 3, IWA = 40, C4 = IWA / 4;
   static constexpr int SLOTS = IH * C4, NI = (SLOTS + 63) / 64;
-  static constexpr int PS = IH * IWA, RAW = KC * PS;
+  // PSPAD = 1: planes at an ODD float stride, so that the two channels (lk, lk + 1) of a 32-lane ds_read_b32 pass fall on banks of
+  // opposite parity (the 16 tiles of a pass are 2 floats apart: same-parity banks only) -- needs LDS-DMA to a 4-byte aligned address
+  static constexpr int PS = IH * IWA + PSPAD_, RAW = ((KC * PS + 3) / 4) * 4;
   static constexpr int ULS = 52;                       // lane stride of the weight image (floats)
   static constexpr int USTAGE = KC * 16 * ULS;         // 3328 floats per four channels
   static constexpr int UWI = USTAGE / 256;             // 13 / 26 wave-issues, dealt round-robin to the four waves
@@ -234,9 +239,9 @@ typedef Wino3CfgT<4, 4> Wino3Cfg;   // the weight image / stage size the host pa
 // PIPE (four-channel stages only): the raw reads and the row transform of stage s + 1 are issued among the MFMAs of stage s (the
 // barrier that publishes stage s + 1 sits at the top of stage s), so a wave leaves a stage boundary with its next operands already
 // in registers; the price is one stage less for the DMA to land (two instead of three).
-template <int ABL = 0, int KC_ = 4, int NB_ = 4, int PIPE = 0>
+template <int ABL = 0, int KC_ = 4, int NB_ = 4, int PIPE = 0, int PSPAD = 0>
 __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a) {
-  using CFG = Wino3CfgT<KC_, NB_>;
+  using CFG = Wino3CfgT<KC_, NB_, PSPAD>;
   extern __shared__ float lds_f[];
   constexpr int KC = CFG::KC, NREP = CFG::NREP, NW = CFG::NW, IWA = CFG::IWA, C4 = CFG::C4, PS = CFG::PS, LP = CFG::LP;
   constexpr int NI = CFG::NI, SLOTS = CFG::SLOTS, NB = CFG::NB, D = CFG::D;
