@@ -236,10 +236,7 @@ typedef Wino3CfgT<4, 4> Wino3Cfg;   // the weight image / stage size the host pa
 
 #define ASX_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-// PIPE (four-channel stages only): the raw reads and the row transform of stage s + 1 are issued among the MFMAs of stage s (the
-// barrier that publishes stage s + 1 sits at the top of stage s), so a wave leaves a stage boundary with its next operands already
-// in registers; the price is one stage less for the DMA to land (two instead of three).
-template <int ABL = 0, int KC_ = 4, int NB_ = 4, int PIPE = 0, int PSPAD = 0>
+template <int ABL = 0, int KC_ = 4, int NB_ = 4, int PSPAD = 0>
 __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a) {
   using CFG = Wino3CfgT<KC_, NB_, PSPAD>;
   extern __shared__ float lds_f[];
@@ -332,79 +329,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a) {
 
   const float *plb = lds_f + lk * PS + (2 * wave) * IWA + LP + 2 * li;
   const float *uqb = lds_f + CFG::RAW + (lk * 16 + li) * CFG::ULS;
-  auto wait_pieces = [&](int n) {               // wave-uniform: pieces of the younger stages that may stay in flight
-    switch (n) {
-      case 5: ASX_VMCNT(5); break;
-      case 6: ASX_VMCNT(6); break;
-      case 10: ASX_VMCNT(10); break;
-      case 12: ASX_VMCNT(12); break;
-      default: ASX_VMCNT(0); break;
-    }
-  };
-  auto row_transform = [&](const float *pl, float (&r)[4][4]) {   // r[col][a] = (B^T d)[a][col]
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float d0 = pl[j], d1 = pl[IWA + j], d2 = pl[2 * IWA + j], d3 = pl[3 * IWA + j];
-      r[j][0] = d0 - d2;
-      r[j][1] = d1 + d2;
-      r[j][2] = d2 - d1;
-      r[j][3] = d1 - d3;
-    }
-  };
-  if constexpr (PIPE != 0) {
-    static_assert(PIPE == 0 || (KC == 4 && NB >= 3), "the pipelined loop is written for four-channel stages");
-    float rn[4][4];
-    wait_pieces(min(D - 1, a.NCI - 1) * my_pieces);
-    asm volatile("s_barrier" ::: "memory");
-    row_transform(plb, rn);
-    int buf = 0;
-    for (int ci = 0; ci < a.NCI; ++ci) {
-      const int nbuf = buf + 1 == NB ? 0 : buf + 1;
-      if (ci + 1 < a.NCI) {
-        wait_pieces(min(D - 2, a.NCI - 2 - ci) * my_pieces);
-        asm volatile("s_barrier" ::: "memory");   // stage ci + 1 landed for every wave; every wave is done with stage ci - 1's buffer
-        if (ci + D < a.NCI) issue(ci + D, (buf + D) % NB);
-      }
-      float r[4][4], dn[4][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) r[j][q] = rn[j][q];
-      const f32x4 *uq = reinterpret_cast<const f32x4 *>(uqb + buf * CFG::BUF);
-      const float *pn = plb + nbuf * CFG::BUF;
-#pragma unroll
-      for (int x = 0; x < 16; ++x) {
-        const int ax = x >> 2, bx = x & 3;
-        const float v = bx == 0 ? r[0][ax] - r[2][ax] : (bx == 1 ? r[1][ax] + r[2][ax] : (bx == 2 ? r[2][ax] - r[1][ax] : r[1][ax] - r[3][ax]));
-#pragma unroll
-        for (int n = 0; n < NREP; ++n) {
-          const int idx = x * 3 + n;
-          acc[x][n] = ASX_MFMA(v, uq[idx >> 2][idx & 3], acc[x][n]);
-        }
-        // next stage's raw patch: requested early, transformed late, so the LDS latency sits under this stage's MFMAs
-        if (x == 1 && ci + 1 < a.NCI) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dn[i][j] = pn[i * IWA + j];
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (x == 12 && ci + 1 < a.NCI) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            rn[j][0] = dn[0][j] - dn[2][j];
-            rn[j][1] = dn[1][j] + dn[2][j];
-            rn[j][2] = dn[2][j] - dn[1][j];
-            rn[j][3] = dn[1][j] - dn[3][j];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      buf = nbuf;
-    }
-  } else {
   int buf = 0;
   for (int ci = 0; ci < a.NCI; ++ci) {
     // retire stage ci (this wave's share), leave the younger stages in flight
@@ -421,37 +345,35 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a) {
       if (ci + D < a.NCI) issue(ci + D, (buf + D) % NB);
     }
 #pragma unroll
-    for (int kq = 0; kq < KC / 4; ++kq) {
-    const float *pl = plb + buf * CFG::BUF + kq * 4 * PS;
-    const f32x4 *uq = reinterpret_cast<const f32x4 *>(uqb + buf * CFG::BUF + kq * 64 * CFG::ULS);
-    float r[4][4];   // r[col][a] = (B^T d)[a][col]
+    for (int kq = 0; kq < KC / 4; ++kq) {      // one MFMA k-step = four channels
+      const float *pl = plb + buf * CFG::BUF + kq * 4 * PS;
+      const f32x4 *uq = reinterpret_cast<const f32x4 *>(uqb + buf * CFG::BUF + kq * 64 * CFG::ULS);
+      float r[4][4];   // r[col][a] = (B^T d)[a][col]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float d0, d1, d2, d3;
-      if constexpr (ABL & 2) {
-        d0 = (float)(ci + j), d1 = (float)(lane), d2 = (float)(ci * j), d3 = (float)(lane - ci);
-      } else {
-        d0 = pl[j], d1 = pl[IWA + j], d2 = pl[2 * IWA + j], d3 = pl[3 * IWA + j];
+      for (int j = 0; j < 4; ++j) {
+        float d0, d1, d2, d3;
+        if constexpr (ABL & 2) {
+          d0 = (float)(ci + j), d1 = (float)(lane), d2 = (float)(ci * j), d3 = (float)(lane - ci);
+        } else {
+          d0 = pl[j], d1 = pl[IWA + j], d2 = pl[2 * IWA + j], d3 = pl[3 * IWA + j];
+        }
+        r[j][0] = d0 - d2;
+        r[j][1] = d1 + d2;
+        r[j][2] = d2 - d1;
+        r[j][3] = d1 - d3;
       }
-      r[j][0] = d0 - d2;
-      r[j][1] = d1 + d2;
-      r[j][2] = d2 - d1;
-      r[j][3] = d1 - d3;
-    }
 #pragma unroll
-    for (int x = 0; x < 16; ++x) {
-      const int ax = x >> 2, bx = x & 3;
-      const float v = bx == 0 ? r[0][ax] - r[2][ax] : (bx == 1 ? r[1][ax] + r[2][ax] : (bx == 2 ? r[2][ax] - r[1][ax] : r[1][ax] - r[3][ax]));
+      for (int x = 0; x < 16; ++x) {
+        const int ax = x >> 2, bx = x & 3;
+        const float v = bx == 0 ? r[0][ax] - r[2][ax] : (bx == 1 ? r[1][ax] + r[2][ax] : (bx == 2 ? r[2][ax] - r[1][ax] : r[1][ax] - r[3][ax]));
 #pragma unroll
-      for (int n = 0; n < NREP; ++n) {
-        const int idx = x * 3 + n;
-        acc[x][n] = ASX_MFMA(v, (ABL & 8) ? r[n][bx] : uq[idx >> 2][idx & 3], acc[x][n]);
+        for (int n = 0; n < NREP; ++n) {
+          const int idx = x * 3 + n;
+          acc[x][n] = ASX_MFMA(v, (ABL & 8) ? r[n][bx] : uq[idx >> 2][idx & 3], acc[x][n]);
+        }
       }
-    }
     }
     buf = buf + 1 == NB ? 0 : buf + 1;
-  }
-
   }
 
   // ---- Y = A^T m A, bias, activation, store: lane holds tiles (tile-row = wave, tile-col = 4 lk + r) of cout li ----
