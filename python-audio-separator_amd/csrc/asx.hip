@@ -502,9 +502,9 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     wa.tilesF = (a.Fo + Wino3Cfg::TW - 1) / Wino3Cfg::TW;
     const int nb = wa.CG * wa.tilesT * wa.tilesF * B;
     static const int abl3 = getenv("ASX_WINO_ABL") ? atoi(getenv("ASX_WINO_ABL")) : 0;   // timing probes (results invalid)
-    // A/B builds: 4 (default): 4-channel stages x 4 buffers, raw planes at an odd float stride; 0: the same at an even stride;
-    // 1: 8-channel stages x 2 buffers; 2: 4 x 3
-    static const int wcfg = getenv("ASX_WINO_CFG") ? atoi(getenv("ASX_WINO_CFG")) : 4;
+    // A/B builds: 6 (default): 4-channel stages x 2 LDS buffers, raw planes at an odd float stride; 5 / 4: rings of 3 / 4 buffers
+    // (two / three stages of DMA in flight, counted vmcnt); 0 / 2: 4 / 3 buffers at the even stride; 1: 8-channel stages x 2 buffers
+    static const int wcfg = getenv("ASX_WINO_CFG") ? atoi(getenv("ASX_WINO_CFG")) : 6;
     auto go = [&](auto kern, int lds, int stages) {
       static std::set<const void *> attr_done;
       if (attr_done.insert(reinterpret_cast<const void *>(kern)).second)
@@ -526,7 +526,9 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     if (wcfg == 1) return go(&conv_wino3_kernel<0, 8, 2>, Wino3CfgT<8, 2>::LDS_BYTES, L.wu3_nci / 2);
     if (wcfg == 2) return go(&conv_wino3_kernel<0, 4, 3>, Wino3CfgT<4, 3>::LDS_BYTES, L.wu3_nci);
     if (wcfg == 0) return go(&conv_wino3_kernel<0>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
-    return go(&conv_wino3_kernel<0, 4, 4, 1>, Wino3CfgT<4, 4, 1>::LDS_BYTES, L.wu3_nci);
+    if (wcfg == 4) return go(&conv_wino3_kernel<0, 4, 4, 1>, Wino3CfgT<4, 4, 1>::LDS_BYTES, L.wu3_nci);
+    if (wcfg == 5) return go(&conv_wino3_kernel<0, 4, 3, 1>, Wino3CfgT<4, 3, 1>::LDS_BYTES, L.wu3_nci);
+    return go(&conv_wino3_kernel<0, 4, 2, 1>, Wino3CfgT<4, 2, 1>::LDS_BYTES, L.wu3_nci);
   }
   if (L.kind == CK_3X3 && e->winograd >= 2 && dma && L.wu2.p != nullptr) {
     ConvArgs wa = a;

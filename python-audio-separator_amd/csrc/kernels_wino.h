@@ -207,14 +207,16 @@ __global__ __launch_bounds__(64 * TR, (TR == 4 ? 2 : 1)) void conv_wino2_kernel(
 // Third generation: the same register transform, with the measured costs of conv_wino2_kernel addressed (ASX_WINO_ABL on the
 // 4-minute song: full 160.7 ms; without the DMA stream after the first stage 128.9; without weight-fragment reads 146.6;
 // without raw reads 151.4; without stores 143.2; MFMA + transform alone 106.5):
-//   * stages of FOUR channels in a ring of four LDS buffers, three stages of LDS-DMA in flight (counted vmcnt + raw s_barrier:
-//     a stage has ~3.8 us to land instead of one stage time);
+//   * stages of FOUR channels (half the LDS image and twice the barriers of the second generation's eight), double buffered.  The
+//     kernel is templated on the ring depth NB (NB - 1 stages of LDS-DMA in flight, counted `s_waitcnt vmcnt(N)` + a raw s_barrier
+//     because __syncthreads() would drain the queue): depth does not pay -- 2 / 3 / 4 buffers measure 143.2 / 144.0 / 146.7 ms on
+//     one box -- so the default is the plain double buffer;
 //   * weight fragments as ds_read_b128: the stage image is [channel][cout % 16][52] with the 48 values a lane needs
 //     ((xi, cout / 16) in MFMA order) contiguous, 52-float lane stride = conflict-free quads; 12 reads per k-step instead of 48.
 //   * raw planes at an ODD float stride (401): the sixteen tiles of a ds_read_b32 pass are two floats apart and so hit banks of one
 //     parity only; the odd stride puts the pass's second channel on the other parity (conflict-free instead of 2-way; the LDS-DMA
 //     destination of a plane is then only 4-byte aligned, which the hardware accepts -- the parity tests run this build).
-// LDS: 4 x (6.4 + 13.3) KB = 78.9 KB -> two workgroups per CU.
+// LDS: 2 x (6.4 + 13.3) KB = 39.5 KB; 232 VGPRs -> two workgroups per CU (the registers, not LDS, set the limit).
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int KC_ = 4, int NB_ = 4, int PSPAD_ = 0>
 struct Wino3CfgT {

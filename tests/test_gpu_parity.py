@@ -527,8 +527,10 @@ def test_separate_on_device_bit_exact_algebra(A):
 @pytest.mark.parametrize("B,cin,cout,T,F", [(1, 48, 48, 16, 128), (2, 96, 96, 8, 64), (1, 32, 32, 24, 200),
                                             (2, 8, 8, 16, 32), (1, 24, 24, 4, 8), (1, 144, 144, 8, 96),
                                             (1, 80, 80, 10, 36), (1, 288, 288, 8, 96), (1, 50, 70, 6, 44)])
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_conv3x3_winograd(A, B, cin, cout, T, F, mode):
+    # mode 3 is the engine's default; 0 = the direct MFMA kernel (kept covered here now that it is not the default), 1 / 2 = the
+    # earlier Winograd generations
     eng = A.Engine(small_cfg(A))
     eng.set_option("winograd", mode)
     rng = np.random.default_rng(cin * 1000 + cout + T + 7)
@@ -541,17 +543,27 @@ def test_conv3x3_winograd(A, B, cin, cout, T, F, mode):
     assert max_abs(y, ref) < 5e-5, (max_abs(y, ref), rel_rms(y, ref))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+_HQ3_EXCERPT = {}
+
+
+def _hq3_excerpt():
+    if not _HQ3_EXCERPT:
+        d = O.NetDims()
+        sd = O.make_convtdf_state(d, seed=0)
+        mix = O.synth_mix(44100 * 12, seed=0)
+        _HQ3_EXCERPT.update(d=d, sd=sd, mix=mix, ref=O.demix(mix, O.MDXParams(), O.make_model_run(sd, d)))
+    return _HQ3_EXCERPT
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_winograd_hq3_excerpt_vs_oracle(A, mode):
-    d = O.NetDims()
-    sd = O.make_convtdf_state(d, seed=0)
-    N = 44100 * 12
-    mix = O.synth_mix(N, seed=0)
+    c = _hq3_excerpt()
+    d, sd, mix, ref = c["d"], c["sd"], c["mix"], c["ref"]
     eng = A.Engine(A.MDXConfig(max_batch=2))
     eng.set_option("winograd", mode)
+    assert eng.option("winograd") == mode
     eng.load_net(A.NetConfig(), A.fold_convtdf_state(sd, d.num_blocks, d.l))
     got = eng.demix(mix)
-    ref = O.demix(mix, O.MDXParams(), O.make_model_run(sd, d))
     e = rel_rms(got, ref)
     print("HQ_3 excerpt rel-RMS (winograd):", e)
     assert e < TOL_STEM, e

@@ -6,6 +6,7 @@ O=gpurun_out/r3v
 mkdir -p $O
 export PYTHONPATH=$GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2
 tail -4 $O/pytest_gpu.log
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
 python - <<'PY'
@@ -16,7 +17,7 @@ print({k:v.get('value') for k,v in r['siblings'].items()}, r['file_level']['rtf'
 print({k:(v['frac'],v['bound']) for k,v in r['stage_roofline'].items()})
 PY
 B="python bench.py --steps 5 --warmup 2 --cpu-seconds 0 --siblings 0 --file-level 0"
-for c in 4 2 4 2; do ASX_WINO_CFG=$c timeout 300 $B 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('CFG=$c', r['value'], r['ms_per_step'], r['kernel_ms']['conv3x3'])"; done | tee $O/ring_ab.txt
+for c in 6 5 6 5; do ASX_WINO_CFG=$c timeout 300 $B 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('CFG=$c', r['value'], r['ms_per_step'], r['kernel_ms']['conv3x3'])"; done | tee $O/ring_ab.txt
 ASX_WINOGRAD=0 timeout 300 $B > $O/bench_direct.json 2>/dev/null
 BENCH_FORCE_DIST=1 timeout 300 $B --config5 --songs-per-rank 2 > $O/b_forced_files.json 2> $O/b_forced_files.err
 BENCH_FORCE_DIST=1 timeout 300 $B --mode chunks > $O/b_forced_chunks.json 2> $O/b_forced_chunks.err
