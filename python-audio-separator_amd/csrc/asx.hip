@@ -339,7 +339,10 @@ static int conv_setup(ConvLayer &L, int kind, int cin, int cout, int relu) {
 
 // w layouts: 3x3 [cout,cin,3,3]; down [cout,cin,2,2]; 1x1 [cout,cin]; up [cin,cout,2,2]
 // packed: [CG][NCI][WSTAGE] with WSTAGE = roundup(ntap*kc*NWP, 256) floats; row (tap, kc) holds NWP floats
-static int conv_pack(ConvLayer &L, const float *w, const float *b) {
+// wino_mode: the engine's "winograd" option at load time.  The image of the default kernel (3) is always built -- the option may be
+// switched between 0 and 3 on a loaded net (bench.py's direct_kernel leg does) -- the images of the earlier generations (1, 2) only
+// when the option selects them before the weights arrive.
+static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode = 3) {
   const int ntap = L.kind == CK_3X3 ? 9 : (L.kind == CK_DOWN ? 4 : 1);
   const int NW = 16 * L.nrep;
   const int NWP = (L.nrep % 2 == 0) ? NW + 16 : NW;
@@ -396,10 +399,14 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b) {
             dst3[(a * 4 + bb) * 3 + col / 16] = (float)U[a][bb];
           }
       }
-    CHK(L.wu.ensure(wu.size() * 4));
-    HIPCHK(hipMemcpy(L.wu.p, wu.data(), wu.size() * 4, hipMemcpyHostToDevice));
-    CHK(L.wu2.ensure(wu2.size() * 4));
-    HIPCHK(hipMemcpy(L.wu2.p, wu2.data(), wu2.size() * 4, hipMemcpyHostToDevice));
+    if (wino_mode == 1) {
+      CHK(L.wu.ensure(wu.size() * 4));
+      HIPCHK(hipMemcpy(L.wu.p, wu.data(), wu.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (wino_mode == 2) {
+      CHK(L.wu2.ensure(wu2.size() * 4));
+      HIPCHK(hipMemcpy(L.wu2.p, wu2.data(), wu2.size() * 4, hipMemcpyHostToDevice));
+    }
     CHK(L.wu3.ensure(wu3.size() * 4));
     HIPCHK(hipMemcpy(L.wu3.p, wu3.data(), wu3.size() * 4, hipMemcpyHostToDevice));
   }
@@ -1289,7 +1296,7 @@ static int build_block(asx_engine *e, Block &blk, const std::string &pre, int c,
     CHK(get_tensor(e, pre + ".tfc" + std::to_string(j) + ".w", (int64_t)c * c * 9, &w));
     CHK(get_tensor(e, pre + ".tfc" + std::to_string(j) + ".b", c, &b));
     CHK(conv_setup(blk.tfc[j], CK_3X3, c, c, 1));
-    CHK(conv_pack(blk.tfc[j], w, b));
+    CHK(conv_pack(blk.tfc[j], w, b, e->winograd));
   }
   const int fb = f / n.bn;
   const float *w, *bias, *sc, *sh;
@@ -1319,7 +1326,7 @@ int asx_net_commit(asx_engine *e) {
   CHK(get_tensor(e, "first.w", (int64_t)n.g * n.dim_c, &w));
   CHK(get_tensor(e, "first.b", n.g, &b));
   CHK(conv_setup(e->first, CK_1X1, n.dim_c, n.g, 1));
-  CHK(conv_pack(e->first, w, b));
+  CHK(conv_pack(e->first, w, b, e->winograd));
   e->enc.assign(nn, Block());
   e->dec.assign(nn, Block());
   e->ds.assign(nn, ConvLayer());
@@ -1330,7 +1337,7 @@ int asx_net_commit(asx_engine *e) {
     CHK(get_tensor(e, "ds" + std::to_string(i) + ".w", (int64_t)(c + n.g) * c * 4, &w));
     CHK(get_tensor(e, "ds" + std::to_string(i) + ".b", c + n.g, &b));
     CHK(conv_setup(e->ds[i], CK_DOWN, c, c + n.g, 1));
-    CHK(conv_pack(e->ds[i], w, b));
+    CHK(conv_pack(e->ds[i], w, b, e->winograd));
     c += n.g;
     t /= 2;
     f /= 2;
@@ -1340,7 +1347,7 @@ int asx_net_commit(asx_engine *e) {
     CHK(get_tensor(e, "us" + std::to_string(i) + ".w", (int64_t)c * (c - n.g) * 4, &w));
     CHK(get_tensor(e, "us" + std::to_string(i) + ".b", c - n.g, &b));
     CHK(conv_setup(e->us[i], CK_UP, c, c - n.g, 1));
-    CHK(conv_pack(e->us[i], w, b));
+    CHK(conv_pack(e->us[i], w, b, e->winograd));
     c -= n.g;
     t *= 2;
     f *= 2;
@@ -1349,7 +1356,7 @@ int asx_net_commit(asx_engine *e) {
   CHK(get_tensor(e, "final.w", (int64_t)n.dim_c * n.g, &w));
   CHK(get_tensor(e, "final.b", n.dim_c, &b));
   CHK(conv_setup(e->final_, CK_1X1, n.g, n.dim_c, 0));
-  CHK(conv_pack(e->final_, w, b));
+  CHK(conv_pack(e->final_, w, b, e->winograd));
   e->host_tensors.clear();
   e->net_ready = true;
   return ASX_OK;
@@ -1915,7 +1922,7 @@ int asx_op_conv(asx_engine *e, const char *op, const float *x_host, int32_t B, i
   DevBuf dx, dy, dskip;
   BufGuard g{{&dx, &dy, &dskip, &L.w, &L.b}};
   CHK(conv_setup(L, kind, cin, cout, kind == CK_1X1 ? relu : 1));
-  CHK(conv_pack(L, w_host, b_host));
+  CHK(conv_pack(L, w_host, b_host, e->winograd));
   CHK(to_dev(dx, x_host, (size_t)B * cin * t * f));
   const size_t ny = (size_t)B * cout * to * fo;
   CHK(dy.ensure(ny * 4));

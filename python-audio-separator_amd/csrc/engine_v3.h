@@ -94,7 +94,7 @@ static int v3_load_conv(asx_engine *e, ConvLayer &L, int kind, const std::string
   const float *w;
   CHK(get_tensor(e, name, (int64_t)cin * cout * ntap, &w));
   CHK(conv_setup(L, kind, cin, cout, 0));
-  CHK(conv_pack(L, w, nullptr));
+  CHK(conv_pack(L, w, nullptr, e->winograd));
   return ASX_OK;
 }
 
