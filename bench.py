@@ -290,6 +290,9 @@ def main():
             # is why the algorithmic rate can exceed the MFMA peak.  What the matrix pipe really sustains is `executed`;
             # `direct_kernel` is the round-2 kernel on the same workload in the same process (ASX_WINOGRAD=0 selects it).
             ex = ach * 4.0 / 9.0
+            roofline["note"] = ("achieved / frac are ALGORITHMIC (direct-convolution FLOPs / launch time, the contract's definition); the kernel "
+                                "is Winograd F(2x2,3x3) and executes 4/9 of them, so frac can exceed 1 -- `executed` is the MFMA pipe's own "
+                                "rate and utilisation, `direct_kernel` the non-Winograd kernel measured in this same run")
             roofline["executed"] = {"mfma_flops_per_launch": roofline["flops_per_launch"] * 4.0 / 9.0, "achieved": round(ex, 2),
                                     "unit": "TFLOP/s", "frac": round(ex / PEAK_FP32_MFMA_TFLOPS, 4),
                                     "note": "Winograd F(2x2,3x3): 4/9 of the algorithmic multiply-adds are executed; frac above is "

@@ -16,6 +16,7 @@
 #include <functional>
 #include <map>
 #include <string>
+#include <mutex>
 #include <set>
 #include <vector>
 
@@ -513,9 +514,13 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     // (two / three stages of DMA in flight, counted vmcnt); 0 / 2: 4 / 3 buffers at the even stride; 1: 8-channel stages x 2 buffers
     static const int wcfg = getenv("ASX_WINO_CFG") ? atoi(getenv("ASX_WINO_CFG")) : 6;
     auto go = [&](auto kern, int lds, int stages) {
-      static std::set<const void *> attr_done;
-      if (attr_done.insert(reinterpret_cast<const void *>(kern)).second)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      {
+        static std::mutex attr_mutex;            // engines may be driven from several host threads (one per bag member / rank)
+        static std::set<const void *> attr_done;
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (attr_done.insert(reinterpret_cast<const void *>(kern)).second)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      }
       wa.NCI = stages;
       return timed(e, cls, flops, bytes, s, [&]() { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, s, wa); });
     };
@@ -524,9 +529,7 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
         case 1: return go(&conv_wino3_kernel<1>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
         case 2: return go(&conv_wino3_kernel<2>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
         case 4: return go(&conv_wino3_kernel<4>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
-        case 8: return go(&conv_wino3_kernel<8>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
         case 16: return go(&conv_wino3_kernel<16>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
-        case 15: return go(&conv_wino3_kernel<15>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
         default: break;
       }
     }
@@ -550,23 +553,6 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 Wino2Cfg<4>::LDS_BYTES);
       attr_done = true;
-    }
-    static const int abl = getenv("ASX_WINO_ABL") ? atoi(getenv("ASX_WINO_ABL")) : 0;   // timing probes (results invalid)
-    if (abl) {
-      auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wino2Cfg<4>::LDS_BYTES);
-        return timed(e, cls, flops, bytes, s, [&]() { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), Wino2Cfg<4>::LDS_BYTES, s, wa); });
-      };
-      switch (abl) {
-        case 1: return go(&conv_wino2_kernel<4, 1>);
-        case 2: return go(&conv_wino2_kernel<4, 2>);
-        case 4: return go(&conv_wino2_kernel<4, 4>);
-        case 8: return go(&conv_wino2_kernel<4, 8>);
-        case 3: return go(&conv_wino2_kernel<4, 3>);
-        case 11: return go(&conv_wino2_kernel<4, 11>);
-        case 15: return go(&conv_wino2_kernel<4, 15>);
-        default: break;
-      }
     }
     return timed(e, cls, flops, bytes, s, [&]() {
       hipLaunchKernelGGL(conv_wino2_kernel<4>, dim3(nb), dim3(256), Wino2Cfg<4>::LDS_BYTES, s, wa);
