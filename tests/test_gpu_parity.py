@@ -526,7 +526,8 @@ def test_separate_on_device_bit_exact_algebra(A):
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("B,cin,cout,T,F", [(1, 48, 48, 16, 128), (2, 96, 96, 8, 64), (1, 32, 32, 24, 200),
                                             (2, 8, 8, 16, 32), (1, 24, 24, 4, 8), (1, 144, 144, 8, 96),
-                                            (1, 80, 80, 10, 36), (1, 288, 288, 8, 96), (1, 50, 70, 6, 44)])
+                                            (1, 80, 80, 10, 36), (1, 288, 288, 8, 96), (1, 50, 70, 6, 44),
+                                            (1, 16, 16, 5, 8), (2, 8, 12, 7, 12), (1, 4, 48, 9, 100), (1, 48, 4, 3, 4)])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_conv3x3_winograd(A, B, cin, cout, T, F, mode):
     # mode 3 is the engine's default; 0 = the direct MFMA kernel (kept covered here now that it is not the default), 1 / 2 = the
