@@ -9,6 +9,7 @@ SRC = os.path.join(HERE, "csrc", "asx.hip")
 DEPS = [SRC] + sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")) + \
        [os.path.join(os.path.dirname(HERE), "include", "asx.h")]
 OUT = os.path.join(HERE, "libasx.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result"]
 
 
 def hipcc_path():
@@ -18,18 +19,33 @@ def hipcc_path():
     raise RuntimeError("hipcc not found")
 
 
+STAMP = OUT + ".srchash"
+
+
+def source_hash():
+    """sha256 over every source the library is built from (names + contents) and the compile flags"""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in DEPS:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(OUT):
+    """True unless libasx.so exists AND was built from exactly the current sources (hash stamp beside it; file times are not
+    trusted -- a checkout or a snapshot copy resets them)."""
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-result", "-o", OUT, SRC]
+    cmd = [hipcc_path()] + FLAGS + ["-o", OUT, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -37,6 +53,8 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
     if verbose:
         print(r.stderr)
+    with open(STAMP, "w") as fh:
+        fh.write(source_hash() + "\n")
     return OUT
 
 

@@ -121,7 +121,10 @@ class DemucsDemixer:
         if len(self.weights) != len(self.models) or any(len(w) != S for w in self.weights):
             raise ValueError("weights must give one value per source for every model")
         self.engine = None            # the engine of the member loaded last (single models: THE engine)
-        self.engines = [None] * len(self.models)   # one resident engine (weights + workspace) per bag member
+        # one resident engine (weights + workspace) per bag member: htdemucs_ft keeps 4 x (108 MB of weights + the workspace of
+        # `max_batch` segments, ~0.6 GB per segment at 7.8 s) = ~70 GB at the default 28 segments per pass -- sized for the
+        # 288 GB of an MI355X; lower `asx_max_batch` on smaller devices.  close() releases all of it, bag buffers included.
+        self.engines = [None] * len(self.models)
         self._loaded = None
         self._own = False
 
@@ -159,6 +162,7 @@ class DemucsDemixer:
                 e.close()
         self.engines = [None] * len(self.models)
         self.engine, self._loaded = None, None
+        self._bag_ws = None           # three song-sized device buffers of bag_demix_dev
 
     def _draw_offsets(self, i, offsets):
         if not self.shifts:

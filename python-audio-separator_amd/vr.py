@@ -110,8 +110,29 @@ class VRDemixer:
                              device=_device_index(common_config.get("torch_device", 0)))
         self.engine.load_vr(self.model_params, nn_arch_size,
                             None if self.is_vr_51_model else (capacity or model_capacity(nn_arch_size)), state_dict,
-                            window_size=self.window_size, offset=offset, max_batch=max_batch or max(self.batch_size, 48),   # engine knob: see engine_vr.h vr_mask_pass
+                            window_size=self.window_size, offset=offset, max_batch=self._patches_per_pass(max_batch, common_config),
                             v51=self.model_capacity if self.is_vr_51_model else None)
+
+    # patches per net pass -- an engine knob, results do not depend on it (engine_vr.h vr_mask_pass).  The workspace costs about
+    # 1 GB per patch on the 4band_44100 layout (activations of the cascade at window 512), so:
+    #   * an explicit ``asx_max_batch`` (arch config) / ``max_batch`` argument is honoured as given;
+    #   * otherwise DEFAULT_PATCHES (48: the measured-best pass size on a 288 GB MI355X), clamped to what fits in 60 % of the HBM
+    #     that is free right now, and never below the user's ``batch_size`` clamp of 1.
+    DEFAULT_PATCHES = 48
+    BYTES_PER_PATCH = 1.1e9
+
+    def _patches_per_pass(self, explicit: int, common_config: dict) -> int:
+        if explicit and explicit > 0:
+            return int(explicit)
+        want = self.DEFAULT_PATCHES
+        try:
+            import torch
+            free, _total = torch.cuda.mem_get_info(_device_index(common_config.get("torch_device", 0)))
+            per = self.BYTES_PER_PATCH * (self.window_size / 512.0)
+            want = max(1, min(want, int(0.6 * free / per)))
+        except Exception:          # no torch / no device query: keep the default, the engine reports an allocation failure itself
+            pass
+        return want
 
     def separate_stems_dev(self, wave_d):
         """The same with the wave [2, n] and both stems in HBM: returns one CUDA tensor [2 (primary, secondary), 2, n_out]

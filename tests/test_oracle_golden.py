@@ -119,3 +119,9 @@ def test_chunk_plan_hq3():
 def test_net_flops_hq3():
     # 0.7589 TFLOP per chunk counted on the reference class
     assert abs(O.net_flops(O.NetDims()) / 0.7589e12 - 1) < 0.01
+    # exact, against FlopCounterMode on the reference's own ConvTDFNet (tests/golden/make_flops_fixture.py)
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "flops.json")) as fh:
+        want = json.load(fh)
+    assert O.net_flops(O.NetDims()) == want["convtdf_hq3_g48"]
+    assert O.net_flops(O.NetDims(g=8)) == want["convtdf_hq3_g8"]
