@@ -45,7 +45,7 @@ extern "C" {
 #define ASX_ERR_HIP 2     /* a HIP runtime call failed (no GPU, OOM, launch) */
 #define ASX_ERR_STATE 3   /* call order violated (e.g. demix before commit)  */
 
-#define ASX_ABI_VERSION 4
+#define ASX_ABI_VERSION 5
 
 /* flags of asx_demix*(): */
 #define ASX_FLAG_MATCH_MIX 1u /* demix(mix, is_match_mix=True): overlap 0.02, no net (mdx_separator.py:308-313, :429-432) */
@@ -347,12 +347,22 @@ int asx_hd_fold_dev(asx_engine *e, const float *mix_dev, int64_t n_samples, int3
  * uvr_lib_v5/vr_network/nets.py:65-93), VRSeparator.loading_mix (:255-291), inference_vr (:293-366) and spec_to_wav
  * (:368-375) with the spec_utils functions they call (wave_to_spectrogram, combine_spectrograms, preprocess,
  * make_padding, adjust_aggr, merge_artifacts, cmb_spectrogram_to_wave, spectrogram_to_wave, fft_lp/hp_filter).
- * band[d-1] = modelparams JSON "band"[d] (uvr_lib_v5/vr_network/modelparams/ *.json); resampling between bands is the
- * polyphase path (scipy.signal.resample_poly) -- the reference's behaviour on ARM / MPS (spec_utils.py:33-38).
+ * band[d-1] = modelparams JSON "band"[d] (uvr_lib_v5/vr_network/modelparams/ *.json).  Resampling between bands (ABI 5):
+ *   ASX_VR_RES_POLYPHASE     scipy.signal.resample_poly as librosa.resample(res_type="polyphase") calls it;
+ *   ASX_VR_RES_SINC_FASTEST  libsamplerate's SRC_SINC_FASTEST as librosa.resample(res_type="sinc_fastest") reaches it through
+ *                            python-samplerate (float32 in / out, src_simple): the library's published algorithm (src_sinc.c) on a
+ *                            regenerated Kaiser-sinc coefficient table -- the library and fastest_coeffs.h are not available, so this
+ *                            converter is "parity unpinned" (INTEGRATION.md "VR resampler").
+ * band[d-1].res_type converts band d+1 -> d in loading_mix (vr_separator.py:267,282: the band's own "res_type"; every type other
+ * than "sinc_fastest" is served by the polyphase filter); synth_res_type converts band d -> d+1 in cmb_spectrogram_to_wave
+ * (spec_utils.py:374,390: the module-level `wav_resolution`, "sinc_fastest" everywhere except macOS on ARM, :33-38).
  */
+#define ASX_VR_RES_POLYPHASE 0
+#define ASX_VR_RES_SINC_FASTEST 1
 typedef struct asx_vr_band {
   int32_t sr, hl, n_fft, crop_start, crop_stop, hpf_start, hpf_stop, lpf_start, lpf_stop;
   int32_t convert;        /* VR 5.1 "convert_channels" (spec_utils.py:232-247): 0 none, 1 mid_side, 4 mid_side_c, 5 stereo_n */
+  int32_t res_type;       /* ASX_VR_RES_*: analysis converter of this band (band d+1 -> d); ABI 5 */
 } asx_vr_band;
 typedef struct asx_vr_config {
   int32_t bins, n_bands, pre_filter_start, pre_filter_stop;
@@ -364,6 +374,7 @@ typedef struct asx_vr_config {
   int32_t max_batch;      /* patches per forward batch (0 = 4); no effect on the result */
   int32_t v51;            /* 1: VR 5.1 -- nets_new.CascadedNet(n_fft, nn_arch_size, nout = cap[0], nout_lstm = cap[1]) and the
                              is_v51_model branches of spec_utils (per-band convert_channels, get_lp/hp_filter_mask); offset 64 */
+  int32_t synth_res_type; /* ASX_VR_RES_*: converter of the synthesis chain (`wav_resolution`, spec_utils.py:33-38); ABI 5 */
   asx_vr_band band[8];
 } asx_vr_config;
 typedef struct asx_vr_params {

@@ -18,7 +18,9 @@ Third-party arithmetic the reference delegates to libraries that are ABSENT here
     calls it: up/down = target/orig over their gcd, then fix_length to ceil(n * ratio)).  The ``sinc_*`` types are
     libsamplerate (absent).  The synthesis chain of the reference hard-codes ``wav_resolution = "sinc_fastest"`` off
     ARM / MPS and "polyphase" on them (spec_utils.py:33-38, vr_separator.py:266-267); this oracle (and the engine)
-    implement the polyphase chain, i.e. the reference's ARM / MPS behaviour, for every platform.
+    implement BOTH: the polyphase chain (the reference's ARM / MPS behaviour and every per-band "polyphase" entry) and, since
+    round 4, ``sinc_fastest`` as a restatement of libsamplerate's published algorithm on a regenerated coefficient table
+    (`src_simple_sinc_fastest` below; PARITY UNPINNED -- the library and its table are absent).
 
 Everything else (spec_utils band logic, nets) is pinned on golden vectors written by the reference's own functions
 and classes, driven with a stand-in `librosa` module that exposes the three restatements above
@@ -90,13 +92,22 @@ def lr_istft(S, hop_length=None, n_fft=None, length=None, **_):
 
 
 def lr_resample(y, orig_sr=None, target_sr=None, res_type="polyphase", axis=-1, **_):
-    """librosa.resample(..., res_type="polyphase") (see the header for the sinc_* types)."""
+    """librosa.resample: ``res_type="polyphase"`` -> scipy.signal.resample_poly; ``"sinc_fastest"`` -> the restated
+    libsamplerate converter below (see the header).  Every other type falls back to polyphase, as the engine does."""
     if orig_sr == target_sr:
         return y
     ratio = float(target_sr) / orig_sr
     n_samples = int(np.ceil(y.shape[axis] * ratio))
-    g = gcd(int(orig_sr), int(target_sr))
-    y_hat = scipy.signal.resample_poly(y, int(target_sr) // g, int(orig_sr) // g, axis=axis)
+    if res_type == "sinc_fastest":
+        # librosa 0.11 resample -> samplerate.resample(y.T, ratio, converter_type) (python-samplerate 0.1.0: float32 in / out,
+        # output_frames = int(n * ratio)) -> util.fix_length(ceil(n * ratio)) -> cast back to y.dtype
+        ym = np.moveaxis(np.asarray(y), axis, -1)
+        flat = np.ascontiguousarray(ym.reshape(-1, ym.shape[-1]), dtype=np.float32)
+        y_hat = src_simple_sinc_fastest(flat, ratio).reshape(ym.shape[:-1] + (-1,))
+        y_hat = np.moveaxis(y_hat, -1, axis)
+    else:
+        g = gcd(int(orig_sr), int(target_sr))
+        y_hat = scipy.signal.resample_poly(y, int(target_sr) // g, int(orig_sr) // g, axis=axis)
     n = y_hat.shape[axis]
     if n > n_samples:
         sl = [slice(None)] * y_hat.ndim
@@ -107,6 +118,108 @@ def lr_resample(y, orig_sr=None, target_sr=None, res_type="polyphase", axis=-1, 
         pw[axis] = (0, n_samples - n)
         y_hat = np.pad(y_hat, pw)
     return np.asarray(y_hat, dtype=y.dtype)
+
+
+# --------------------------------------------------------------------------
+# libsamplerate SRC_SINC_FASTEST, restated.  PARITY UNPINNED: python-samplerate 0.1.0 (poetry.lock) bundles libsamplerate
+# 0.1.9, neither of which is in this image or in /root/reference; what follows restates the library's PUBLISHED algorithm
+# (src_sinc.c: sinc_stereo_vari_process + calc_output_stereo -- fixed-point table walk with 12 fractional bits, linear
+# interpolation between table entries, double accumulation left half then right half, zero history before the first and
+# after the last input frame, float32 in / out) on a REGENERATED coefficient table: fastest_coeffs.h itself (2464 floats,
+# increment 128) is not reproducible from documentation, so the table is a Kaiser-windowed sinc sized to the converter's
+# documented figures (97 dB SNR, 80 % bandwidth; 2464 entries at 128 per input sample = 19.25 samples per side).
+# tools/vr_resampler_deviation.py --sweep bounds what that substitution can cost: tables consistent with the documented
+# figures differ by <= 1.2e-4 relative RMS on the synthesis chain, against ~1e-3 for the polyphase converter.
+# --------------------------------------------------------------------------
+SRC_SHIFT_BITS = 12
+SRC_FP_ONE = 1 << SRC_SHIFT_BITS
+SRC_FASTEST_LEN, SRC_FASTEST_INC = 2464, 128      # ARRAY_LEN(fastest_coeffs.coeffs), fastest_coeffs.increment
+SRC_FASTEST_ATTEN_DB, SRC_FASTEST_BANDWIDTH = 97.0, 0.80
+
+_SRC_TABLE = None
+
+
+def src_fastest_table() -> np.ndarray:
+    """The stand-in for fastest_coeffs.coeffs: float32 [2464], entry i at i / 128 input samples from the centre."""
+    global _SRC_TABLE
+    if _SRC_TABLE is None:
+        i = np.arange(SRC_FASTEST_LEN, dtype=np.float64)
+        t = i / SRC_FASTEST_INC
+        half = SRC_FASTEST_LEN / SRC_FASTEST_INC                    # 19.25 input samples: where the window reaches zero
+        fc = 0.5 * (SRC_FASTEST_BANDWIDTH + 1.0)                    # cutoff midway between the pass-band edge and Nyquist
+        beta = 0.1102 * (SRC_FASTEST_ATTEN_DB - 8.7)
+        win = np.i0(beta * np.sqrt(np.clip(1.0 - (t / half) ** 2, 0.0, None))) / np.i0(beta)
+        _SRC_TABLE = (fc * np.sinc(fc * t) * win).astype(np.float32)
+    return _SRC_TABLE
+
+
+def _src_positions(n_out: int, ratio: float):
+    """(frame index b, fractional position) of every output frame, by the library's own recurrence:
+    input_index += 1 / ratio; rem = fmod_one(input_index); b += lrint(input_index - rem); input_index = rem."""
+    step = 1.0 / ratio
+    m, e = math.frexp(step)
+    if m == 0.5 and e <= 1:            # 1 / ratio is a power of two <= 1: the recurrence is exact, vectorise
+        k = np.arange(n_out, dtype=np.int64)
+        den = int(round(1.0 / step))
+        return k // den, (k % den).astype(np.float64) * step
+    b = np.empty(n_out, np.int64)
+    frac = np.empty(n_out, np.float64)
+    bi, idx = 0, 0.0
+    for k in range(n_out):
+        b[k], frac[k] = bi, idx
+        idx += step
+        rem = math.fmod(idx, 1.0)
+        if rem < 0.0:
+            rem += 1.0
+        bi += int(round(idx - rem))
+        idx = rem
+    return b, frac
+
+
+def src_simple_sinc_fastest(x: np.ndarray, ratio: float) -> np.ndarray:
+    """src_simple(SRC_SINC_FASTEST) on channels-first float32 data x [C >= 2, n] -> float32 [C, int(n * ratio)].
+    (With two or more interleaved channels the library's termination test lets every one of the int(n * ratio) output
+    frames be generated; the VR chain always resamples stereo.)"""
+    x = np.asarray(x, np.float32)
+    coeffs = src_fastest_table()
+    C, n = x.shape
+    n_out = int(n * ratio)
+    half_len = SRC_FASTEST_LEN - 2                                   # coeff_half_len = ARRAY_LEN(coeffs) - 2
+    float_inc = SRC_FASTEST_INC * (ratio if ratio < 1.0 else 1.0)
+    inc = int(np.rint(float_inc * SRC_FP_ONE))
+    scale = float_inc / SRC_FASTEST_INC
+    max_fi = half_len << SRC_SHIFT_BITS
+    b, frac = _src_positions(n_out, ratio)
+    sfi = np.rint(frac * float_inc * SRC_FP_ONE).astype(np.int64)    # start_filter_index = double_to_fp(input_index * float_increment)
+    kmax = max_fi // inc + 2
+    xp = np.zeros((C, n + 2 * kmax + 4), np.float64)                 # zero history either side (prepare_data)
+    xp[:, kmax:kmax + n] = x
+    diff = np.append(coeffs[1:] - coeffs[:-1], np.float32(0)).astype(np.float32)    # float subtraction, as in C
+
+    def icoeff(fi):
+        indx = fi >> SRC_SHIFT_BITS
+        fr = (fi & (SRC_FP_ONE - 1)).astype(np.float64) / SRC_FP_ONE
+        return coeffs[indx].astype(np.float64) + fr * diff[indx].astype(np.float64)
+
+    # left half: taps b - k, filter_index = sfi + k * inc, summed from the farthest tap (k = coeff_count) down WHILE
+    # filter_index >= 0 -- when the recurrence leaves the fraction at 1 - ulp, sfi == inc and the loop runs on to k = -1
+    # (filter_index 0 at frame b + 1: the centre tap, which the right half's `> 0` test then leaves out)
+    cc = (max_fi - sfi) // inc
+    left = np.zeros((C, n_out), np.float64)
+    for j in range(int(cc.max()), -2, -1):
+        ok = (j <= cc) & (sfi + j * inc >= 0)
+        fi = np.where(ok, sfi + j * inc, 0)
+        left += np.where(ok, icoeff(fi), 0.0) * xp[:, b - j + kmax]
+    # right half: taps b + 1 + k, filter_index = inc - sfi + k * inc, from the farthest tap down while filter_index > 0
+    # (the do-while of calc_output runs its body once even when the first index is <= 0)
+    fr0 = inc - sfi
+    cr = (max_fi - fr0) // inc
+    right = np.zeros((C, n_out), np.float64)
+    for j in range(int(cr.max()), -1, -1):
+        fi = fr0 + j * inc
+        ok = (j <= cr) & ((fi > 0) | (j == cr))
+        right += np.where(ok, icoeff(np.where(ok, fi, 0)), 0.0) * xp[:, b + 1 + j + kmax]
+    return (scale * (left + right)).astype(np.float32)
 
 
 # --------------------------------------------------------------------------
@@ -539,8 +652,10 @@ def inference_vr(X_spec, mask_fn, window_size, offset, batch_size, aggressivenes
 
 
 def vr_separate(wave, sd, arch, mp: ModelParams, window_size=512, batch_size=1, aggression=5, is_non_accom_stem=False,
-                enable_tta=False, enable_post_process=False, post_process_threshold=0.2, offset=128, high_end_process=False):
-    """VRSeparator.separate on arrays (vr_separator.py:168-236): wave [2, n] at mp sr -> (primary [n', 2], secondary)."""
+                enable_tta=False, enable_post_process=False, post_process_threshold=0.2, offset=128, high_end_process=False,
+                wav_resolution="polyphase"):
+    """VRSeparator.separate on arrays (vr_separator.py:168-236): wave [2, n] at mp sr -> (primary [n', 2], secondary).
+    ``wav_resolution``: the synthesis chain's res_type, spec_utils.py:33-38 ("sinc_fastest" off macOS-ARM, else "polyphase")."""
     aggr = {"value": float(int(aggression) / 100), "split_bin": mp.param["band"][1]["crop_stop"],
             "aggr_correction": mp.param.get("aggr_correction")}
     X_spec = loading_mix(wave, mp)
@@ -551,9 +666,9 @@ def vr_separate(wave, sd, arch, mp: ModelParams, window_size=512, batch_size=1, 
     v_spec = np.nan_to_num(v_spec, nan=0.0, posinf=0.0, neginf=0.0)
     if high_end_process:
         h, ihe = high_end(wave, mp)
-        return (cmb_spectrogram_to_wave(y_spec, mp, extra_bins_h=h, extra_bins=mirroring(y_spec, ihe, mp)).T,
-                cmb_spectrogram_to_wave(v_spec, mp, extra_bins_h=h, extra_bins=mirroring(v_spec, ihe, mp)).T)
-    return cmb_spectrogram_to_wave(y_spec, mp).T, cmb_spectrogram_to_wave(v_spec, mp).T
+        return (cmb_spectrogram_to_wave(y_spec, mp, wav_resolution, extra_bins_h=h, extra_bins=mirroring(y_spec, ihe, mp)).T,
+                cmb_spectrogram_to_wave(v_spec, mp, wav_resolution, extra_bins_h=h, extra_bins=mirroring(v_spec, ihe, mp)).T)
+    return cmb_spectrogram_to_wave(y_spec, mp, wav_resolution).T, cmb_spectrogram_to_wave(v_spec, mp, wav_resolution).T
 
 
 def params_path(name: str) -> str:
@@ -807,7 +922,7 @@ def predict_mask51(x, sd, n_fft_bins, offset=64):
 
 
 def vr_separate_v51(wave, sd, mp: ModelParams, window_size=512, batch_size=1, aggression=5, is_non_accom_stem=False,
-                    enable_tta=False, enable_post_process=False, post_process_threshold=0.2, offset=64):
+                    enable_tta=False, enable_post_process=False, post_process_threshold=0.2, offset=64, wav_resolution="polyphase"):
     aggr = {"value": float(int(aggression) / 100), "split_bin": mp.param["band"][1]["crop_stop"],
             "aggr_correction": mp.param.get("aggr_correction")}
     X_spec = loading_mix_v51(wave, mp)
@@ -816,4 +931,4 @@ def vr_separate_v51(wave, sd, mp: ModelParams, window_size=512, batch_size=1, ag
                                   is_non_accom_stem, enable_tta, enable_post_process, post_process_threshold)
     y_spec = np.nan_to_num(y_spec, nan=0.0, posinf=0.0, neginf=0.0)
     v_spec = np.nan_to_num(v_spec, nan=0.0, posinf=0.0, neginf=0.0)
-    return cmb_spectrogram_to_wave_v51(y_spec, mp).T, cmb_spectrogram_to_wave_v51(v_spec, mp).T
+    return cmb_spectrogram_to_wave_v51(y_spec, mp, wav_resolution).T, cmb_spectrogram_to_wave_v51(v_spec, mp, wav_resolution).T

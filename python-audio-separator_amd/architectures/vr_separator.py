@@ -4,34 +4,26 @@ Same constructor, attributes and ``separate`` contract (:115-253).  ``loading_mi
 and the spec_utils functions under them are one C call (``asx_vr_separate``, vr.py:VRDemixer); the network is built and
 the ``.pth`` read once, at the first file, instead of at every ``separate`` (:158-178).
 
-Resampler: the reference's *synthesis* chain uses libsamplerate's ``sinc_fastest`` off macOS-ARM
-(uvr_lib_v5/spec_utils.py:33-38), and band entries may ask for ``sinc_*`` / ``kaiser_*`` on analysis; the engine has the
-``polyphase`` chain (the reference's ARM / MPS behaviour) and a windowed-sinc converter built from libsamplerate's
-published algorithm with a regenerated Kaiser table (``arch_config["asx_res_type"]``: "polyphase" | "sinc").  Neither
-is bit-comparable with libsamplerate's shipped coefficient table: see INTEGRATION.md "VR resampler" for the measured
-deviation.  A warning is logged once whenever the model parameters or the platform would have selected a libsamplerate
-converter in the reference.
+Resampler (vr.py ``resolve_res_type``): like the reference, the *synthesis* chain runs libsamplerate's ``sinc_fastest``
+everywhere except macOS on ARM, where it runs ``polyphase`` (uvr_lib_v5/spec_utils.py:33-38), and the analysis chain runs each
+band's own ``res_type``.  ``sinc_fastest`` is the library's published algorithm on a regenerated Kaiser-sinc table -- the
+library's own table cannot be had here (INTEGRATION.md "VR resampler": parity unpinned for this converter, measured bounds
+there); ``arch_config["asx_res_type"]`` = "polyphase" | "sinc_fastest" overrides the platform rule.  A warning is logged once
+when a band asks for a converter the engine serves with the polyphase filter instead (``sinc_medium``, ``sinc_best``,
+``kaiser_*`` -- in the shipped parameter files only top bands carry those, where they matter for non-44.1 kHz input files
+decoded on the host).
 """
 from __future__ import annotations
 
 import math
 import os
-import platform
 
 import numpy as np
 
 from .. import audio_io
 from ..common_separator import CommonSeparator
 from ..model_files import read_state_dict
-from ..vr import NN_ARCH_SIZES, VR_5_1, VRDemixer, load_model_params, reference_params_dir
-
-
-def reference_wav_resolution() -> str:
-    """spec_utils.py:33-38: the synthesis res_type the reference picks on this platform."""
-    if platform.system() == "Darwin":
-        arm = "arm" in platform.processor().lower() or "arm" in platform.platform().lower()
-        return "polyphase" if arm else "sinc_fastest"
-    return "sinc_fastest"
+from ..vr import NN_ARCH_SIZES, VR_5_1, VRDemixer, load_model_params, reference_params_dir, reference_wav_resolution, resolve_res_type  # noqa: F401
 
 
 class VRSeparator(CommonSeparator):
@@ -54,7 +46,7 @@ class VRSeparator(CommonSeparator):
         self.aggressiveness = {"value": self.aggression, "split_bin": self.model_params["band"][1]["crop_stop"],
                                "aggr_correction": self.model_params.get("aggr_correction")}
         self.model_samplerate = self.model_params["sr"]
-        self.res_type = arch_config.get("asx_res_type", "polyphase")
+        self.res_type = resolve_res_type(arch_config.get("asx_res_type"))
         self._common, self._arch = dict(common_config), dict(arch_config)
         self._dm = None
         self.model_run = None
@@ -64,12 +56,12 @@ class VRSeparator(CommonSeparator):
         self.logger.info(f"VR plugin ready ({self.model_data['vr_model_param']}, {'5.1' if self.is_vr_51_model else '5.0'} net on the HIP engine)")
 
     def _warn_resampler(self):
-        wanted = {reference_wav_resolution()} | {str(b.get("res_type")) for b in self.model_params["band"].values()}
-        foreign = sorted(w for w in wanted if w not in ("polyphase", "None"))
+        bands = self.model_params["band"]
+        lower = {str(bands[d].get("res_type")) for d in bands if d != max(bands)}     # converters loading_mix really runs
+        foreign = sorted(w for w in lower if w not in ("polyphase", "sinc_fastest", "None"))
         if foreign:
-            self.logger.warning(f"VR resampling: the reference would use {foreign} (libsamplerate / resampy) here; this engine runs "
-                                f"its '{self.res_type}' converter for every band.  Stems differ from the reference's by the "
-                                "converter's pass-band ripple (INTEGRATION.md, 'VR resampler').")
+            self.logger.warning(f"VR analysis resampling: band entries ask for {foreign} (libsamplerate / resampy); this engine "
+                                "serves them with the polyphase filter (INTEGRATION.md, 'VR resampler').")
 
     def load_model(self):
         """vr_separator.py:158-178: architecture size from the file size, CascadedASPPNet / CascadedNet, load_state_dict."""

@@ -22,6 +22,9 @@ struct VrBase {
 struct VrFilt {
   int up = 1, down = 1, hlen = 0, n_pre_remove = 0;
   DevBuf h32, h64;
+  // ASX_VR_RES_SINC_FASTEST (libsamplerate's converter, kernels_vr.h vr_sinc_kernel): no per-ratio filter, one shared table
+  int kind = ASX_VR_RES_POLYPHASE;
+  double ratio = 1.0;       // float(target_sr) / orig_sr, as librosa forms it
 };
 struct VrBand {
   asx_vr_band b{};
@@ -63,7 +66,7 @@ struct VrNet {
     float *hc, *y2, *y3, *h3, *mk, *pool, *pool2, *tmp, *cat, *bn;
     std::vector<float *> D, E, O;
   } b;
-  DevBuf X, M, M2, peak, fmin, wgt, frames, wss, HE;
+  DevBuf X, M, M2, peak, fmin, wgt, frames, wss, HE, sinc_tab;
   int he_n = 0;   // rows kept for high_end_process (0 = off for the current call)
   std::vector<DevBuf> wav_ana, wav_syn, wav_up;
 };
@@ -279,6 +282,25 @@ static int vr_design_filter(VrFilt &f, int orig_sr, int target_sr) {
   return ASX_OK;
 }
 
+// Stand-in for libsamplerate's fastest_coeffs.h (2464 floats, increment 128): a Kaiser-windowed sinc sized to the converter's
+// documented figures -- 97 dB SNR, 80 % bandwidth -- cutoff midway between the pass-band edge and Nyquist, window reaching
+// zero at 2464 / 128 = 19.25 input samples.  float64 design, rounded to float32 like the library's coeff_t (the CPU-side checker
+// of the test suite builds the same table).  [0, TL): coefficients; [TL, 2 TL): float differences c[i + 1] - c[i].
+static constexpr int VR_SINC_TL = 2464, VR_SINC_INC = 128;
+static int vr_sinc_table(DevBuf &buf) {
+  std::vector<float> t(2 * (size_t)VR_SINC_TL, 0.f);
+  const double half = (double)VR_SINC_TL / VR_SINC_INC, fc = 0.5 * (0.80 + 1.0), beta = 0.1102 * (97.0 - 8.7);
+  const double i0b = vr_i0(beta);
+  for (int i = 0; i < VR_SINC_TL; ++i) {
+    const double x = (double)i / VR_SINC_INC, r = x / half;
+    const double a = fc * x;
+    const double sinc = a == 0.0 ? 1.0 : sin(M_PI * a) / (M_PI * a);
+    t[i] = (float)(fc * sinc * vr_i0(beta * sqrt(std::max(0.0, 1.0 - r * r))) / i0b);
+  }
+  for (int i = 0; i + 1 < VR_SINC_TL; ++i) t[VR_SINC_TL + i] = t[i + 1] - t[i];
+  return ht_up(buf, t);
+}
+
 static int vr51_commit_net(asx_engine *e);
 
 static int vr_commit(asx_engine *e) {
@@ -384,6 +406,11 @@ static int vr_commit(asx_engine *e) {
     if (d + 1 < NB) {
       CHK(vr_design_filter(B.ana, c.band[d + 1].sr, B.b.sr));
       CHK(vr_design_filter(B.syn, B.b.sr, c.band[d + 1].sr));
+      B.ana.kind = B.b.res_type == ASX_VR_RES_SINC_FASTEST ? ASX_VR_RES_SINC_FASTEST : ASX_VR_RES_POLYPHASE;
+      B.syn.kind = c.synth_res_type == ASX_VR_RES_SINC_FASTEST ? ASX_VR_RES_SINC_FASTEST : ASX_VR_RES_POLYPHASE;
+      B.ana.ratio = (double)B.b.sr / (double)c.band[d + 1].sr;
+      B.syn.ratio = (double)c.band[d + 1].sr / (double)B.b.sr;
+      if ((B.ana.kind | B.syn.kind) == ASX_VR_RES_SINC_FASTEST && n.sinc_tab.p == nullptr) CHK(vr_sinc_table(n.sinc_tab));
     }
     off += B.b.crop_stop - B.b.crop_start;
   }
@@ -855,13 +882,23 @@ static double vr_flops_patch(const asx_engine *e) {
 
 // ---- signal chain ---------------------------------------------------------------------------------------------------
 static int vr_resample(asx_engine *e, const VrFilt &f, const float *x, int64_t n_in, float *y, int64_t n_out, int acc64, hipStream_t s) {
+  if (f.kind == ASX_VR_RES_SINC_FASTEST) {
+    const float *tab = e->vr->sinc_tab.f();
+    const double float_inc = VR_SINC_INC * (f.ratio < 1.0 ? f.ratio : 1.0);
+    const long long inc_fp = llrint(float_inc * 4096.0);
+    const int64_t n_gen = std::min<int64_t>(n_out, (int64_t)((double)n_in * f.ratio));   // python-samplerate: int(num_frames * ratio)
+    return timed(e, ASX_PROF_MISC, 0.0, 8.0 * (n_in + n_out), s, [&]() {
+      hipLaunchKernelGGL(vr_sinc_kernel, dim3((unsigned)((n_out + 255) / 256), 2), dim3(256), 2 * VR_SINC_TL * sizeof(float), s, x, n_in, tab,
+                         tab + VR_SINC_TL, VR_SINC_TL, VR_SINC_TL - 2, f.up, f.down, float_inc, inc_fp, float_inc / VR_SINC_INC, n_gen, y, n_out);
+    });
+  }
   return timed(e, ASX_PROF_MISC, 0.0, 8.0 * (n_in + n_out), s, [&]() {
     hipLaunchKernelGGL(vr_resample_kernel, dim3((unsigned)((n_out + 255) / 256), 2), dim3(256), 0, s, x, n_in, f.h32.f(),
                        reinterpret_cast<const double *>(f.h64.p), f.hlen, f.up, f.down, f.n_pre_remove, y, n_out, acc64);
   });
 }
 
-static int64_t vr_resampled_len(const VrFilt &f, int64_t n_in) {   // ceil(n * ratio) == resample_poly's n_out
+static int64_t vr_resampled_len(const VrFilt &f, int64_t n_in) {   // ceil(n * ratio) == resample_poly's n_out == librosa's fix_length
   const int64_t t = n_in * f.up;
   return t / f.down + (t % f.down ? 1 : 0);
 }

@@ -147,6 +147,73 @@ __global__ __launch_bounds__(256) void vr_resample_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------
+// libsamplerate SRC_SINC_FASTEST as librosa.resample(res_type="sinc_fastest") reaches it (python-samplerate: float32 planar
+// data interleaved into frames, src_simple, float32 out), restating src_sinc.c's sinc_stereo_vari_process / calc_output_stereo:
+// output frame m sits at input position m / ratio = b + frac; the coefficient table (`tab`, TL floats at INC entries per input
+// sample, `dtab` = float differences of neighbours) is walked in 20.12 fixed point from start_filter_index =
+// lrint(frac * float_increment * 4096) in steps of `inc_fp` = lrint(float_increment * 4096), float_increment = INC * min(ratio, 1),
+// entries linearly interpolated in double; the LEFT half (frames b - k, farthest tap first, down to filter index >= 0) and the
+// RIGHT half (frames b + 1 + k, farthest first, while filter index > 0) are accumulated in double in the library's order and
+// summed, times `scale` = min(ratio, 1).  History before frame 0 and after the last frame is zero (prepare_data).  Frames
+// m >= n_gen = int(n_in * ratio) are librosa's fix_length zero padding.  The position is formed from the exact rational
+// m * down / up rather than by the library's running double sum (equal up to the sum's rounding, ~1e-13 frames).
+// Table in LDS: the threads of a block walk it at a common stride from a handful of distinct start indices.  grid.y = channel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vr_sinc_kernel(const float *__restrict__ x, int64_t n_in, const float *__restrict__ tab,
+                                                      const float *__restrict__ dtab, int TL, int half_len, int up, int down,
+                                                      double float_inc, long long inc_fp, double scale, int64_t n_gen,
+                                                      float *__restrict__ y, int64_t n_out) {
+  extern __shared__ float sinc_lds[];
+  float *c = sinc_lds, *dc = sinc_lds + TL;
+  for (int i = threadIdx.x; i < TL; i += blockDim.x) {
+    c[i] = tab[i];
+    dc[i] = dtab[i];
+  }
+  __syncthreads();
+  const int ch = blockIdx.y;
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_out) return;
+  float *yp = y + (int64_t)ch * n_out;
+  if (m >= n_gen) {
+    yp[m] = 0.f;
+    return;
+  }
+  const float *xp = x + (int64_t)ch * n_in;
+  const int64_t q = m * down;
+  const int64_t b = q / up;
+  const double frac = (double)(q - b * up) / (double)up;
+  const long long max_fi = (long long)half_len << 12;
+  const long long sfi = llrint(frac * float_inc * 4096.0);
+  auto icoeff = [&](long long fi) -> double {
+    const int idx = (int)(fi >> 12);
+    return (double)c[idx] + (double)(fi & 4095) * (1.0 / 4096.0) * (double)dc[idx];
+  };
+  double left = 0.0, right = 0.0;
+  {
+    const long long cc = (max_fi - sfi) / inc_fp;
+    long long fi = sfi + cc * inc_fp;
+    int64_t i = b - cc;
+    do {
+      if (i >= 0 && i < n_in) left += icoeff(fi) * (double)xp[i];
+      fi -= inc_fp;
+      ++i;
+    } while (fi >= 0);
+  }
+  {
+    long long fi = inc_fp - sfi;
+    const long long cr = (max_fi - fi) / inc_fp;
+    fi += cr * inc_fp;
+    int64_t i = b + 1 + cr;
+    do {
+      if (i >= 0 && i < n_in) right += icoeff(fi) * (double)xp[i];
+      fi -= inc_fp;
+      --i;
+    } while (fi > 0);
+  }
+  yp[m] = (float)(scale * (left + right));
+}
+
+// ---------------------------------------------------------------------------
 // librosa.stft (centre, zero padding, periodic Hann) of one band, written straight into the combined spectrogram
 // (combine_spectrograms, spec_utils.py:250-281): bins [crop_start, crop_stop) * gain[bin] -> rows row_off + ...
 // of X [2, Tmin, bins+1] (bin fastest).  Channel conversion of wave_to_spectrogram (spec_utils.py:289-300) on load:

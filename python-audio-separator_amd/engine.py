@@ -63,15 +63,18 @@ class _HdCfg(C.Structure):
                [("freq_emb_scale", C.c_float), ("max_batch", C.c_int32)]
 
 
+VR_RES_TYPES = {"polyphase": 0, "sinc_fastest": 1}      # ASX_VR_RES_*
+
+
 class _VrBand(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("sr", "hl", "n_fft", "crop_start", "crop_stop", "hpf_start", "hpf_stop", "lpf_start",
-                                         "lpf_stop", "convert")]
+                                         "lpf_stop", "convert", "res_type")]
 
 
 class _VrCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("bins", "n_bands", "pre_filter_start", "pre_filter_stop", "channel_mode", "arch")] + \
                [("cap", C.c_int32 * 6), ("window_size", C.c_int32), ("offset", C.c_int32), ("max_batch", C.c_int32),
-                ("v51", C.c_int32), ("band", _VrBand * 8)]
+                ("v51", C.c_int32), ("synth_res_type", C.c_int32), ("band", _VrBand * 8)]
 
 
 class _VrParams(C.Structure):
@@ -212,7 +215,7 @@ class HDConfig:
 _FP = C.POINTER(C.c_float)
 _lib = None
 
-ABI_VERSION = 4   # ASX_ABI_VERSION of include/asx.h the structures below mirror
+ABI_VERSION = 5   # ASX_ABI_VERSION of include/asx.h the structures below mirror
 
 # every symbol include/asx.h declares
 SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_create", "asx_engine_destroy",
@@ -671,10 +674,12 @@ class Engine:
 
     # -- VR -----------------------------------------------------------------------
     def load_vr(self, model_params: dict, arch: int, capacity, state_dict: dict, window_size: int = 512, offset: int = 128,
-                max_batch: int = 0, v51=None):
+                max_batch: int = 0, v51=None, wav_resolution: str = "polyphase"):
         """nets.determine_model_capacity(bins * 2, arch) + load_state_dict.  model_params: the modelparams JSON dict
         (int band keys); capacity: the model_capacity_data table of nets.py:74-86.  v51 = (nout, nout_lstm) selects
-        nets_new.CascadedNet and the is_v51_model branches instead (capacity is then ignored)."""
+        nets_new.CascadedNet and the is_v51_model branches instead (capacity is then ignored).  ``wav_resolution``: the
+        synthesis chain's converter (spec_utils.py:33-38), "sinc_fastest" or "polyphase"; the analysis converters follow each
+        band's own "res_type" ("sinc_fastest" -> the sinc converter, anything else -> polyphase)."""
         mp = model_params
         mode = 3 if mp.get("reverse") else (1 if mp.get("mid_side") else (2 if mp.get("mid_side_b2") else 0))
         nb = len(mp["band"])
@@ -683,6 +688,9 @@ class Engine:
         for i, v in enumerate(caps):
             c.cap[i] = int(v)
         c.window_size, c.offset, c.max_batch, c.v51 = int(window_size), int(offset), int(max_batch), int(bool(v51))
+        if wav_resolution not in VR_RES_TYPES:
+            raise ValueError(f"wav_resolution {wav_resolution!r}: expected one of {sorted(VR_RES_TYPES)}")
+        c.synth_res_type = VR_RES_TYPES[wav_resolution]
         conv = {None: 0, "mid_side": 1, "mid_side_c": 4, "stereo_n": 5}
         for d in range(1, nb + 1):
             bp = mp["band"][d]
@@ -690,7 +698,8 @@ class Engine:
             if cc not in conv:
                 raise NotImplementedError(f"convert_channels {cc!r}")
             c.band[d - 1] = _VrBand(bp["sr"], bp["hl"], bp["n_fft"], bp["crop_start"], bp["crop_stop"], bp.get("hpf_start", 0),
-                                    bp.get("hpf_stop", 0), bp.get("lpf_start", 0), bp.get("lpf_stop", 0), conv[cc])
+                                    bp.get("hpf_stop", 0), bp.get("lpf_start", 0), bp.get("lpf_stop", 0), conv[cc],
+                                    VR_RES_TYPES.get(bp.get("res_type", "polyphase"), 0))
         self._check(self._lib.asx_vr_begin(self._h, C.byref(c)))
         for name, t in state_dict.items():
             if hasattr(t, "detach"):

@@ -7,7 +7,10 @@ secondary [n', 2])`` where wave is what ``librosa.load(file, sr=band[N].sr, mono
 reference).  Multiband analysis, patching, the CascadedASPPNet, mask post-processing and the multiband synthesis all run
 in libasx.so (asx_vr_separate).
 
-Resampling between bands uses the polyphase path on every platform (the reference's ARM / MPS behaviour).  VR 5.1
+Resampling between bands follows the reference's choices (``resolve_res_type``): the synthesis chain runs ``sinc_fastest``
+everywhere except macOS on ARM, where it runs ``polyphase`` (uvr_lib_v5/spec_utils.py:33-38); the analysis chain runs each
+band's own ``res_type`` (vr_separator.py:267,282).  ``arch_config["asx_res_type"]`` = "polyphase" | "sinc_fastest" overrides
+the platform rule (the golden vectors were written through a polyphase stand-in for librosa and say so).  VR 5.1
 checkpoints (nets_new.CascadedNet: model_data with nout / nout_lstm, or file sizes 56817 / 218409) take the same path
 with the is_v51_model branches.
 """
@@ -25,6 +28,26 @@ NON_ACCOM_STEMS = ("Vocals", "Other", "Bass", "Drums", "Guitar", "Piano", "Synth
                    "Wind Inst")   # common_separator.py:46
 NN_ARCH_SIZES = [31191, 33966, 56817, 123821, 123812, 129605, 218409, 537238, 537227]
 VR_5_1 = (56817, 218409)
+
+
+def reference_wav_resolution() -> str:
+    """spec_utils.py:33-38: the synthesis res_type the reference picks on this platform."""
+    import platform
+    if platform.system() == "Darwin":
+        arm = "arm" in platform.processor().lower() or "arm" in platform.platform().lower()
+        return "polyphase" if arm else "sinc_fastest"
+    return "sinc_fastest"
+
+
+def resolve_res_type(asked) -> str:
+    """``arch_config["asx_res_type"]``: None / "auto" -> the reference's platform rule; "sinc" is short for "sinc_fastest"."""
+    if asked in (None, "auto"):
+        return reference_wav_resolution()
+    if asked == "sinc":
+        return "sinc_fastest"
+    if asked not in ("polyphase", "sinc_fastest"):
+        raise ValueError(f"asx_res_type {asked!r}: expected 'polyphase', 'sinc_fastest' or 'auto'")
+    return asked
 
 
 def load_model_params(path_or_dict) -> dict:
@@ -101,6 +124,7 @@ class VRDemixer:
         self.batch_size = arch_config.get("batch_size", 1)
         self.window_size = arch_config.get("window_size", 512)
         self.high_end_process = bool(arch_config.get("high_end_process", False))
+        self.wav_resolution = resolve_res_type(arch_config.get("asx_res_type"))
         self.aggression = float(int(arch_config.get("aggression", 5)) / 100)
         self.aggressiveness = {"value": self.aggression, "split_bin": self.model_params["band"][1]["crop_stop"],
                                "aggr_correction": self.model_params.get("aggr_correction")}
@@ -111,7 +135,7 @@ class VRDemixer:
         self.engine.load_vr(self.model_params, nn_arch_size,
                             None if self.is_vr_51_model else (capacity or model_capacity(nn_arch_size)), state_dict,
                             window_size=self.window_size, offset=offset, max_batch=self._patches_per_pass(max_batch, common_config),
-                            v51=self.model_capacity if self.is_vr_51_model else None)
+                            v51=self.model_capacity if self.is_vr_51_model else None, wav_resolution=self.wav_resolution)
 
     # patches per net pass -- an engine knob, results do not depend on it (engine_vr.h vr_mask_pass).  The workspace costs about
     # 1 GB per patch on the 4band_44100 layout (activations of the cascade at window 512), so:

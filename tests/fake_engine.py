@@ -153,8 +153,10 @@ class OracleEngine:
         raise NotImplementedError("the CPU double covers HTDemucs packages only")
 
     # ---- VR ---------------------------------------------------------------------------------------------
-    def load_vr(self, model_params, arch, capacity, state_dict, window_size=512, offset=128, max_batch=0, v51=None):
+    def load_vr(self, model_params, arch, capacity, state_dict, window_size=512, offset=128, max_batch=0, v51=None,
+                wav_resolution="polyphase"):
         assert v51 is None
+        self._vr_res = wav_resolution
         self._vr = (V.ModelParams(model_params), int(arch), {k: _t(v) for k, v in state_dict.items()}, int(window_size), int(offset))
         self.vr_bins = model_params["bins"]
         self.vr_window = int(window_size)
@@ -165,7 +167,7 @@ class OracleEngine:
         p, s = V.vr_separate(np.asarray(wave, np.float32), sd, arch, mp, window_size=win, batch_size=2,
                              aggression=round(aggr_value * 100), is_non_accom_stem=is_non_accom, enable_tta=enable_tta,
                              enable_post_process=enable_post_process, post_process_threshold=post_thres, offset=off,
-                             high_end_process=high_end_process)
+                             high_end_process=high_end_process, wav_resolution=self._vr_res)
         return np.asarray(p, np.float32).T, np.asarray(s, np.float32).T
 
     def vr_forward(self, x):

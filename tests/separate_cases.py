@@ -98,12 +98,15 @@ def write_vr_model(directory, arch=31191, seed=21):
 MDX_DATA = {"compensate": 1.035, "mdx_dim_f_set": 32, "mdx_dim_t_set": 4, "mdx_n_fft_scale_set": 96, "primary_stem": "Vocals"}
 MDX_ARCH = {"hop_length": 16, "segment_size": 16, "overlap": 0.25, "batch_size": 1, "enable_denoise": False}
 MDXC_ARCH = {"segment_size": 12, "override_model_segment_size": False, "batch_size": 2, "overlap": 4, "pitch_shift": 0}
+# "asx_res_type": the goldens were written by the reference's VRSeparator through a stand-in librosa whose resample is the
+# polyphase restatement (libsamplerate is absent), so this repo's class is told to run the same converter instead of the
+# platform rule (sinc_fastest on Linux); the reference ignores the key.
 VR_ARCHS = {
     "vr_plain": {"batch_size": 2, "window_size": 320, "aggression": 5, "enable_tta": False, "enable_post_process": False,
-                 "post_process_threshold": 0.2, "high_end_process": False},
+                 "post_process_threshold": 0.2, "high_end_process": False, "asx_res_type": "polyphase"},
     "vr_tta_single": {"batch_size": 1, "window_size": 320, "aggression": 10, "enable_tta": True, "enable_post_process": True,
-                      "post_process_threshold": 0.2, "high_end_process": True},
-    "vr_badsingle": {"batch_size": 4, "window_size": 512, "aggression": 5},
+                      "post_process_threshold": 0.2, "high_end_process": True, "asx_res_type": "polyphase"},
+    "vr_badsingle": {"batch_size": 4, "window_size": 512, "aggression": 5, "asx_res_type": "polyphase"},
 }
 
 

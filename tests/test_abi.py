@@ -30,7 +30,9 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.asx_abi_version() == 4
+    hdr = open(os.path.join(ROOT, "include", "asx.h")).read()
+    declared = int(re.search(r"#define\s+ASX_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert lib.asx_abi_version() == declared == E.ABI_VERSION == 5
 
 
 def test_binding_refuses_a_library_of_another_abi(monkeypatch):

@@ -60,13 +60,16 @@ def test_vr_clip(A):
                    4: {"sr": 44100, "hl": 512, "n_fft": 768, "crop_start": 121, "crop_stop": 382, "hpf_start": 138, "hpf_stop": 123, "res_type": "sinc_medium"}}}
     arch = 123821
     sd = V.make_vr_state(arch, 0)
-    dm = A.VRDemixer({"model_params": mp, "primary_stem_name": "Instrumental", "torch_device": 0},
-                     {"window_size": 512, "batch_size": 4, "aggression": 5}, state_dict=sd, nn_arch_size=arch)
     wave = (0.3 * np.random.default_rng(1).standard_normal((2, 44100 * 5))).astype(np.float32)
-    gp, gs = dm.separate_stems(wave)
-    wp, ws = V.vr_separate(wave, sd, arch, V.ModelParams(mp), window_size=512, batch_size=2, aggression=5)
-    assert rel_rms(gp, wp) < TOL, rel_rms(gp, wp)
-    assert rel_rms(gs, ws) < TOL, rel_rms(gs, ws)
+    for res in ("polyphase", "sinc_fastest"):     # the reference's ARM / MPS chain and its Linux / x86 chain (restated libsamplerate)
+        dm = A.VRDemixer({"model_params": mp, "primary_stem_name": "Instrumental", "torch_device": 0},
+                         {"window_size": 512, "batch_size": 4, "aggression": 5, "asx_res_type": res}, state_dict=sd, nn_arch_size=arch)
+        gp, gs = dm.separate_stems(wave)
+        wp, ws = V.vr_separate(wave, sd, arch, V.ModelParams(mp), window_size=512, batch_size=2, aggression=5, wav_resolution=res)
+        print(f"VR 4band_44100 full size, {res}: rel-RMS {rel_rms(gp, wp):.3e} / {rel_rms(gs, ws):.3e}")
+        assert rel_rms(gp, wp) < TOL, rel_rms(gp, wp)
+        assert rel_rms(gs, ws) < TOL, rel_rms(gs, ws)
+        dm.engine.close()
 
 
 def test_mdx23c_chunk(A):
@@ -121,7 +124,7 @@ def test_vr51_clip(A):
     mp = {"bins": 768, "unstable_bins": 7, "reduction_bins": 668, "sr": 44100, "pre_filter_start": 740, "pre_filter_stop": 768, "band": band}
     sd = V.make_vr51_state(1536, 32, 128, 3)
     dm = A.VRDemixer({"model_params": mp, "primary_stem_name": "Instrumental", "torch_device": 0, "model_data": {"nout": 32, "nout_lstm": 128}},
-                     {"window_size": 512, "batch_size": 2, "aggression": 5}, state_dict=sd, nn_arch_size=56817)
+                     {"window_size": 512, "batch_size": 2, "aggression": 5, "asx_res_type": "polyphase"}, state_dict=sd, nn_arch_size=56817)
     wave = (0.3 * np.random.default_rng(5).standard_normal((2, 44100 * 3))).astype(np.float32)
     gp, gs = dm.separate_stems(wave)
     wp, ws = V.vr_separate_v51(wave, sd, V.ModelParams(mp), window_size=512, batch_size=2, aggression=5)

@@ -32,7 +32,9 @@ def g(golden_dir):
 
 def demixer(A, arch=123821, seed=5, params=None, max_batch=0, **arch_cfg):
     mp = params or V.small_params().param
-    cfg = {"window_size": 64, "batch_size": 2, "aggression": 5}
+    # the goldens were written through a polyphase stand-in for librosa.resample: pin the converter (the class default is the
+    # reference's platform rule, sinc_fastest on Linux)
+    cfg = {"window_size": 64, "batch_size": 2, "aggression": 5, "asx_res_type": "polyphase"}
     cfg.update(arch_cfg)
     return A.VRDemixer({"model_params": mp, "primary_stem_name": "Instrumental", "torch_device": 0}, cfg,
                        state_dict=V.make_vr_state(arch, seed, SMALL_CAP), nn_arch_size=arch, capacity=SMALL_CAP, offset=16,
@@ -89,9 +91,87 @@ def test_mid_side_and_non_accom(A, g):
     wave = g["wave"][:, :9001]
     wp, ws = V.vr_separate(wave, sd, 123821, mp, window_size=64, batch_size=1, aggression=10, is_non_accom_stem=True, offset=16)
     dm = A.VRDemixer({"model_params": pm, "primary_stem_name": "Vocals", "torch_device": 0},
-                     {"window_size": 64, "batch_size": 1, "aggression": 10}, state_dict=sd, nn_arch_size=123821,
+                     {"window_size": 64, "batch_size": 1, "aggression": 10, "asx_res_type": "polyphase"}, state_dict=sd, nn_arch_size=123821,
                      capacity=SMALL_CAP, offset=16)
     p, s = dm.separate_stems(wave)
+    assert rel_rms(p, wp) < TOL, rel_rms(p, wp)
+    assert rel_rms(s, ws) < TOL, rel_rms(s, ws)
+
+
+# ---- sinc_fastest: libsamplerate's converter (restated; parity unpinned: oracle/vr_oracle.py src_simple_sinc_fastest) --------------
+def test_default_converter_follows_the_reference_platform_rule(A):
+    """spec_utils.py:33-38: sinc_fastest everywhere but macOS on ARM"""
+    import platform
+    from audio_separator_amd import vr
+    want = "polyphase" if (platform.system() == "Darwin" and "arm" in (platform.processor() + platform.platform()).lower()) else "sinc_fastest"
+    assert vr.resolve_res_type(None) == want == vr.resolve_res_type("auto")
+    assert vr.resolve_res_type("sinc") == "sinc_fastest" and vr.resolve_res_type("polyphase") == "polyphase"
+    cfg = {"window_size": 64, "batch_size": 2, "aggression": 5}
+    dm = A.VRDemixer({"model_params": V.small_params().param, "primary_stem_name": "Instrumental", "torch_device": 0}, cfg,
+                     state_dict=V.make_vr_state(123821, 5, SMALL_CAP), nn_arch_size=123821, capacity=SMALL_CAP, offset=16)
+    assert dm.wav_resolution == want
+    with pytest.raises(ValueError):
+        vr.resolve_res_type("kaiser_best")
+
+
+@pytest.mark.parametrize("res", ["polyphase", "sinc_fastest"])
+@pytest.mark.parametrize("kw", [dict(), dict(enable_tta=True, aggression=10), dict(high_end_process=True)])
+def test_separate_both_converters_vs_oracle(A, g, res, kw):
+    """Synthesis chain (band d -> d + 1, ratio 2) on either converter against the oracle's restatement of it"""
+    mp = V.small_params()
+    sd = V.make_vr_state(123821, 5, SMALL_CAP)
+    wp, ws = V.vr_separate(g["wave"], sd, 123821, mp, window_size=64, batch_size=2, aggression=kw.get("aggression", 5),
+                           enable_tta=kw.get("enable_tta", False), offset=16, high_end_process=kw.get("high_end_process", False),
+                           wav_resolution=res)
+    p, s = demixer(A, asx_res_type=res, **kw).separate_stems(g["wave"])
+    assert p.shape == wp.shape
+    assert rel_rms(p, wp) < TOL, rel_rms(p, wp)
+    assert rel_rms(s, ws) < TOL, rel_rms(s, ws)
+    if res == "sinc_fastest":       # and the two converters really are different chains (about 1e-3 apart on this layout)
+        pp, _ = demixer(A, asx_res_type="polyphase", **kw).separate_stems(g["wave"])
+        assert rel_rms(p, pp) > 1e-5
+
+
+def two_band_params(ratio_lo, res_lo="sinc_fastest"):
+    """2band_44100_lofi.json's structure scaled down: band 1 is reached by DOWN-sampling with libsamplerate (analysis) and left by
+    up-sampling with it (synthesis); sr_lo / sr_hi = 1/4 (lofi), 3/16 (2band_32000) or 1/8 (2band_48000)."""
+    sr_hi = 8000
+    sr_lo = int(sr_hi * ratio_lo)
+    hl_lo = {0.25: 16, 0.1875: 12, 0.125: 8}[ratio_lo]
+    return V.ModelParams({
+        "bins": 96, "unstable_bins": 2, "reduction_bins": 90,
+        "band": {1: {"sr": sr_lo, "hl": hl_lo, "n_fft": 128, "crop_start": 0, "crop_stop": 36, "lpf_start": 10, "lpf_stop": 30, "res_type": res_lo},
+                 2: {"sr": sr_hi, "hl": 64, "n_fft": 192, "crop_start": 4, "crop_stop": 64, "hpf_start": 10, "hpf_stop": 4, "res_type": "sinc_medium"}},
+        "sr": sr_hi, "pre_filter_start": 94, "pre_filter_stop": 96})
+
+
+@pytest.mark.parametrize("ratio_lo", [0.25, 0.1875, 0.125])
+def test_two_band_sinc_analysis_and_synthesis_vs_oracle(A, g, ratio_lo):
+    """Band 1 with res_type "sinc_fastest": the analysis chain down-samples through the converter (ratio < 1: the table is walked at
+    128 * ratio entries per input sample, gain ratio), the synthesis chain up-samples by 4 / 16:3 / 8 (non-dyadic position recurrence)"""
+    mp = two_band_params(ratio_lo)
+    sd = V.make_vr_state(123821, 7, SMALL_CAP)
+    wave = g["wave"][:, :16000]
+    X = V.loading_mix(wave, mp)
+    dm = demixer(A, seed=7, params=mp.param, asx_res_type="sinc_fastest")
+    Xg = dm.engine.vr_analysis(wave)
+    assert Xg.shape == X.shape
+    assert rel_rms(Xg, X) < 2e-5, rel_rms(Xg, X)
+    wp, ws = V.vr_separate(wave, sd, 123821, mp, window_size=64, batch_size=2, aggression=5, offset=16, wav_resolution="sinc_fastest")
+    p, s = dm.separate_stems(wave)
+    assert p.shape == wp.shape
+    assert rel_rms(p, wp) < TOL, rel_rms(p, wp)
+    assert rel_rms(s, ws) < TOL, rel_rms(s, ws)
+    # the polyphase analysis of the same band is a different spectrogram: the band's res_type is honoured
+    Xp = demixer(A, seed=7, params=two_band_params(ratio_lo, "polyphase").param, asx_res_type="sinc_fastest").engine.vr_analysis(wave)
+    assert rel_rms(Xp, X) > 1e-5
+
+
+def test_v51_sinc_vs_oracle(A, g):
+    mp = V.small_params_v51()
+    sd = V.make_vr51_state(192, 16, 16, 9)
+    wp, ws = V.vr_separate_v51(g["wave"][:, :12001], sd, mp, window_size=64, batch_size=2, aggression=5, offset=16, wav_resolution="sinc_fastest")
+    p, s = demixer51(A, asx_res_type="sinc_fastest").separate_stems(g["wave"][:, :12001])
     assert rel_rms(p, wp) < TOL, rel_rms(p, wp)
     assert rel_rms(s, ws) < TOL, rel_rms(s, ws)
 
@@ -111,7 +191,7 @@ def g51(golden_dir):
 
 
 def demixer51(A, **arch_cfg):
-    cfg = {"window_size": 64, "batch_size": 2, "aggression": 5}
+    cfg = {"window_size": 64, "batch_size": 2, "aggression": 5, "asx_res_type": "polyphase"}
     cfg.update(arch_cfg)
     return A.VRDemixer({"model_params": V.small_params_v51().param, "primary_stem_name": "Instrumental", "torch_device": 0,
                         "model_data": {"nout": 16, "nout_lstm": 16}}, cfg, state_dict=V.make_vr51_state(192, 16, 16, 9),
