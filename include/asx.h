@@ -497,7 +497,10 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
 /* "winograd": kernel of the 3x3 / pad-1 TFC convolutions.  3 (default; also ASX_WINOGRAD in the environment) = Winograd
  * F(2x2,3x3) in fp32 (2.25x fewer multiply-accumulates; results differ from the direct kernel by a few float32 ulps per
  * layer, whole-song deviation from the CPU oracle stays below 1e-5 relative RMS, profiles/r03_fullsong_parity.json);
- * 0 = the direct MFMA kernel; 1 / 2 = earlier Winograd generations kept for A/B measurements. */
+ * 0 = the direct MFMA kernel; 1 / 2 = earlier Winograd generations kept for A/B measurements.
+ * "winograd_stationary": 1 (also ASX_WINOS) = layers with at most 96 input channels run the weight-stationary form of the same
+ * transform (csrc/kernels_winos.h: the transformed weights stay in registers, positions split over eight waves) when "winograd"
+ * is 3; 0 (default: the stationary form measured slower, profiles/NOTES.md) = conv_wino3_kernel for every layer. */
 int asx_set_option(asx_engine *e, const char *key, int32_t value);
 
 /* ---- profiling ---------------------------------------------------------- */

@@ -26,6 +26,7 @@
 #include "kernels_net.h"
 #include "kernels_gemm2.h"
 #include "kernels_wino.h"
+#include "kernels_winos.h"
 #ifndef ASX_TDF2_DEFAULT
 #define ASX_TDF2_DEFAULT 1
 #endif
@@ -107,6 +108,8 @@ struct ConvLayer {
   DevBuf wu2;      // the same values as [CG48][NCI8][xi][channel 8][48] (conv_wino2_kernel)
   DevBuf wu3;      // and as [CG48][NCI4][channel 4][cout % 16][52: (xi, cout / 16) in MFMA order, 4 pad] (conv_wino3_kernel)
   int wu_cg = 0, wu_nci = 0, wu3_nci = 0;
+  DevBuf wus;      // weight-stationary image [CG48][wave 8][6 KS / 4][lane 64][4] (conv_winos_kernel<KS>), Cin <= 96 only
+  int wus_ks = 0;  // 12 / 24 (k-steps of four channels the image was packed for), 0 = none
 };
 
 struct TdfLayer {
@@ -183,6 +186,10 @@ struct asx_engine {
   // direct kernel (conv_dma_kernel), 1 / 2 = the earlier Winograd generations (kept for A/B runs).  ASX_WINOGRAD or
   // asx_set_option("winograd", n).
   int winograd = getenv("ASX_WINOGRAD") ? std::max(0, atoi(getenv("ASX_WINOGRAD"))) : 3;
+  // 1: layers with Cin <= 96 run the weight-stationary Winograd kernel (conv_winos_kernel, kernels_winos.h) when the option above
+  // is 3; 0 (default -- the stationary form measured 3-8 % slower, profiles/NOTES.md round 4): conv_wino3_kernel everywhere.
+  // ASX_WINOS or asx_set_option("winograd_stationary", n).
+  int winos = getenv("ASX_WINOS") ? std::max(0, atoi(getenv("ASX_WINOS"))) : 0;
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -410,6 +417,27 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
     }
     CHK(L.wu3.ensure(wu3.size() * 4));
     HIPCHK(hipMemcpy(L.wu3.p, wu3.data(), wu3.size() * 4, hipMemcpyHostToDevice));
+    // weight-stationary image: only where all of U fits the registers of eight waves (Cin <= 96) without much zero padding
+    L.wus_ks = (L.cin > 40 && L.cin <= 48) ? 12 : ((L.cin > 88 && L.cin <= 96) ? 24 : 0);
+    if (L.wus_ks) {
+      const size_t per = (size_t)8 * (6 * L.wus_ks / 4) * 64 * 4;
+      std::vector<float> wus((size_t)L.wu_cg * per, 0.f);
+      for (int co = 0; co < L.cout; ++co)
+        for (int c = 0; c < L.cin; ++c) {
+          const float *g = &w[((size_t)co * L.cin + c) * 9];
+          double t[4][3];
+          for (int a = 0; a < 4; ++a)
+            for (int j = 0; j < 3; ++j) t[a][j] = G[a][0] * g[0 * 3 + j] + G[a][1] * g[1 * 3 + j] + G[a][2] * g[2 * 3 + j];
+          float *dst = &wus[(size_t)(co / 48) * per];
+          for (int a = 0; a < 4; ++a)
+            for (int bb = 0; bb < 4; ++bb) {
+              const float u = (float)(t[a][0] * G[bb][0] + t[a][1] * G[bb][1] + t[a][2] * G[bb][2]);
+              dst[L.wus_ks == 12 ? winos_u_index<12>(a, bb, c, co % 48) : winos_u_index<24>(a, bb, c, co % 48)] = u;
+            }
+        }
+      CHK(L.wus.ensure(wus.size() * 4));
+      HIPCHK(hipMemcpy(L.wus.p, wus.data(), wus.size() * 4, hipMemcpyHostToDevice));
+    }
   }
   const int nb = (L.kind == CK_UP) ? CT * 16 : std::max(L.cg * NW, ((L.cout + 47) / 48) * 48);
   std::vector<float> bp(nb, 0.f);
@@ -501,6 +529,48 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
   const bool dma = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (a.x_bstride % 4 == 0) &&
                    getenv("ASX_NO_DMA") == nullptr;
   const ConvArgs &d = a;
+  if (L.kind == CK_3X3 && e->winograd == 3 && e->winos == 1 && dma && L.wus.p != nullptr && a.Fo % 32 == 0 && v.res == nullptr &&
+      (a.act == ACT_RELU || a.act == ACT_NONE) && (int64_t)L.cin * T * F < ((int64_t)1 << 30)) {
+    // weight-stationary Winograd (kernels_winos.h): a workgroup walks a 32-pixel-wide column strip, one tile row per step
+    ConvArgs wa = a;
+    wa.wp = L.wus.f();
+    wa.CG = L.wu_cg;
+    wa.tilesF = a.Fo / 32;
+    const int NS = (a.To + 1) / 2;
+    const int base = wa.CG * wa.tilesF * B;
+    // row blocks: enough workgroups to fill the chip a few times over, but at least 8 tile rows each (prologue: weights + 4 rows)
+    int RB = std::max(1, std::min((NS + 7) / 8, (2048 + base - 1) / base));
+    const int SPB = (NS + RB - 1) / RB;
+    RB = (NS + SPB - 1) / SPB;
+    wa.tilesT = RB;
+    wa.NCI = SPB;
+    const int nb = base * RB;
+    auto gos = [&](auto kern, int lds) {
+      {
+        static std::mutex attr_mutex;
+        static std::set<const void *> attr_done;
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (attr_done.insert(reinterpret_cast<const void *>(kern)).second)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      }
+      return timed(e, cls, flops, bytes, s, [&]() { hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, wa); });
+    };
+    static const int abls = getenv("ASX_WINOS_ABL") ? atoi(getenv("ASX_WINOS_ABL")) : 0;   // timing probes (results invalid)
+    const bool k12 = L.wus_ks == 12;
+    const bool ragged = (a.To & 1) || (L.cout % 48) != 0;
+    if (abls && !ragged) {
+      switch (abls) {
+        case 1: return k12 ? gos(&conv_winos_kernel<12, 1>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 1>, WinoSCfg<24>::LDS_BYTES);
+        case 2: return k12 ? gos(&conv_winos_kernel<12, 2>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 2>, WinoSCfg<24>::LDS_BYTES);
+        case 4: return k12 ? gos(&conv_winos_kernel<12, 4>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 4>, WinoSCfg<24>::LDS_BYTES);
+        case 5: return k12 ? gos(&conv_winos_kernel<12, 5>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 5>, WinoSCfg<24>::LDS_BYTES);
+        case 13: return k12 ? gos(&conv_winos_kernel<12, 13>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 13>, WinoSCfg<24>::LDS_BYTES);
+        default: break;
+      }
+    }
+    if (ragged) return k12 ? gos(&conv_winos_kernel<12, 0, true>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 0, true>, WinoSCfg<24>::LDS_BYTES);
+    return k12 ? gos(&conv_winos_kernel<12, 0, false>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 0, false>, WinoSCfg<24>::LDS_BYTES);
+  }
   if (L.kind == CK_3X3 && e->winograd == 3 && dma && L.wu3.p != nullptr) {
     ConvArgs wa = a;
     wa.wp = L.wu3.f();
@@ -2938,6 +3008,10 @@ int asx_set_option(asx_engine *e, const char *key, int32_t value) {
   REQUIRE(e && key, "asx_set_option: null argument");
   if (!strcmp(key, "winograd")) {
     e->winograd = value < 0 ? 0 : (int)value;
+    return ASX_OK;
+  }
+  if (!strcmp(key, "winograd_stationary")) {
+    e->winos = value < 0 ? 0 : (int)value;
     return ASX_OK;
   }
   set_err("asx_set_option: unknown option '%s'", key);

@@ -437,7 +437,10 @@ class Engine:
 
     def option(self, key: str) -> int:
         """Current value of an engine option (the library default when it was never set here)."""
-        defaults = {"winograd": max(0, int(os.environ.get("ASX_WINOGRAD", "3")))}
+        defaults = {"winograd": max(0, int(os.environ.get("ASX_WINOGRAD", "3"))),
+                    "winograd_stationary": max(0, int(os.environ.get("ASX_WINOS", "0")))}
+        if key not in defaults:
+            raise AsxError(f"unknown engine option {key!r} (known: {sorted(defaults)})")
         return self._options.get(key, defaults[key])
 
     # -- weights ------------------------------------------------------------

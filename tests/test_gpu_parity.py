@@ -123,7 +123,9 @@ def _torch_ref(op, x, w, b, aux=None, relu=True):
     import torch.nn.functional as F
     xt, wt, bt = torch.tensor(x), torch.tensor(w), torch.tensor(b)
     if op == "conv3x3":
-        y = F.relu(F.conv2d(xt, wt, bt, padding=1))
+        y = F.conv2d(xt, wt, bt, padding=1)
+        if relu:
+            y = F.relu(y)
     elif op == "down":
         y = F.relu(F.conv2d(xt, wt, bt, stride=2))
     elif op == "conv1x1":
@@ -544,6 +546,30 @@ def test_conv3x3_winograd(A, B, cin, cout, T, F, mode):
     assert max_abs(y, ref) < 5e-5, (max_abs(y, ref), rel_rms(y, ref))
 
 
+@pytest.mark.parametrize("B,cin,cout,T,F", [(1, 48, 48, 16, 128), (2, 96, 96, 8, 64), (1, 48, 96, 64, 64), (3, 96, 48, 33, 32),
+                                            (1, 44, 50, 7, 96), (1, 90, 4, 2, 32), (1, 96, 144, 1, 64), (2, 48, 48, 130, 3072 // 8),
+                                            (1, 144, 144, 9, 96), (2, 144, 50, 16, 32), (1, 48, 20, 5, 64)])
+def test_conv3x3_winograd_stationary(A, B, cin, cout, T, F, variant=1, relu=True):
+    """conv_winos_kernel (kernels_winos.h): weights resident in registers, positions split over eight waves, column strips of 32
+    pixels walked one tile row per step -- selectable for 3x3 layers with 41..48 / 89..96 input channels on planes whose width is
+    a multiple of 32 (option "winograd_stationary").  Against torch, and against conv_wino3_kernel (option off)."""
+    eng = A.Engine(small_cfg(A))
+    assert eng.option("winograd") == 3
+    assert eng.option("winograd_stationary") == 0       # measured slower than conv_wino3_kernel: selectable, not the default
+    eng.set_option("winograd_stationary", variant)
+    rng = np.random.default_rng(cin * 1000 + cout + T + 11)
+    x = rng.standard_normal((B, cin, T, F)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    y = eng.op_conv("conv3x3", x, w, b, relu=relu)
+    ref = _torch_ref("conv3x3", x, w, b, relu=relu)
+    assert np.isfinite(y).all(), "unwritten (NaN canary) output elements"
+    assert max_abs(y, ref) < 5e-5, (max_abs(y, ref), rel_rms(y, ref))
+    eng.set_option("winograd_stationary", 0)
+    y3 = eng.op_conv("conv3x3", x, w, b, relu=relu)
+    assert max_abs(y, y3) < 2e-5, max_abs(y, y3)
+
+
 _HQ3_EXCERPT = {}
 
 
@@ -556,11 +582,15 @@ def _hq3_excerpt():
     return _HQ3_EXCERPT
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 30])
 def test_winograd_hq3_excerpt_vs_oracle(A, mode):
+    # 3 = the default (conv_wino3_kernel everywhere); 30 = the weight-stationary kernel on the two outer levels
     c = _hq3_excerpt()
     d, sd, mix, ref = c["d"], c["sd"], c["mix"], c["ref"]
     eng = A.Engine(A.MDXConfig(max_batch=2))
+    if mode == 30:
+        mode = 3
+        eng.set_option("winograd_stationary", 1)
     eng.set_option("winograd", mode)
     assert eng.option("winograd") == mode
     eng.load_net(A.NetConfig(), A.fold_convtdf_state(sd, d.num_blocks, d.l))
