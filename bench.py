@@ -17,7 +17,8 @@ which case WORLD_SIZE must equal N -- anything else is an error, never a silent 
                 gather per step over xGMI, inside the timed region; the gather of step k overlaps the compute of step
                 k + 1 (asynchronous collective on RCCL's stream, double-buffered stems).
   --mode chunks (strong scaling) ONE song, its chunk list split across the ranks (sharding.sharded_demix): contiguous
-                chunk ranges, one gather of windowed chunks, fold on rank 0.
+                chunk ranges, every rank folds its own sample range (one 2-MB seam chunk from the left neighbour), one gather
+                of the folded [2, N / G] slabs to rank 0.
 
 ``--dry-gloo`` replaces the GPU work by a copy and RCCL by gloo so that the launcher / rendezvous / collective plumbing
 can be exercised on a CPU-only box (tests/test_bench_launcher.py); its line says ``"dry": true`` and carries no rate.
@@ -246,8 +247,8 @@ def main():
             comm["fold_ms"] = round(shard_ws.timings["fold_ms"], 3)
             comm["compute_ms"] = round(shard_ws.timings["compute_ms"], 3)
         cs = plan["chunk_size"]
-        per = -(-plan["n_chunks"] // world)
-        comm["gather_bytes_per_step"] = per * 2 * cs * 4 * (world - 1)
+        # local fold: (world - 1) seam chunks point-to-point + the folded slabs of the other ranks to rank 0
+        comm["gather_bytes_per_step"] = (world - 1) * 2 * cs * 4 + int(2 * N * 4 * (world - 1) / world)
         if use_dist:
             dist.barrier()
 
@@ -321,7 +322,7 @@ def main():
     if rank == 0:
         par = (f"files sharded over {world} GPU(s), {S} song(s) per rank" + (", stems gathered to rank 0 (one RCCL gather per step"
                + (", blocking" if args.no_overlap else ", overlapped with the next step's compute") + ")" if world > 1 else "")) \
-            if args.mode == "files" else f"chunks of one song sharded over {world} GPU(s), one RCCL gather of windowed chunks, fold on rank 0"
+            if args.mode == "files" else f"chunks of one song sharded over {world} GPU(s), seam chunk to the right neighbour, local fold, one RCCL gather of [2, N / G] slabs"
         res = {
             "metric": METRIC, "value": round(value, 2), "unit": "audio-s/wall-s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

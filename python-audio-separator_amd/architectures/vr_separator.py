@@ -120,7 +120,7 @@ class VRSeparator(CommonSeparator):
         # device-resident path (RIFF/WAVE at the top band's rate, which is also the rate the stems are written at): the data
         # chunk is decoded on the device and both stems stay in HBM until the writer's int16 pass
         keep = (self.input_subtype, self.input_bit_depth)
-        wave_d = self._device_mix(audio_file_path) if (top["sr"] == self.sample_rate and self.model_samplerate == 44100) else None
+        wave_d = self._device_mix(audio_file_path, check_silent=False) if (top["sr"] == self.sample_rate and self.model_samplerate == 44100) else None
         self.input_subtype, self.input_bit_depth = keep          # _device_mix records prepare_mix's fields; VR keeps its own (above)
         if wave_d is not None:
             t0 = self._now()

@@ -215,12 +215,14 @@ class CommonSeparator:
         except Exception:
             return False
 
-    def _device_mix(self, path):
+    def _device_mix(self, path, check_silent=True):
         """prepare_mix for a RIFF/WAVE file at the model's rate WITHOUT a host float array: the data chunk is read into pinned
         memory, copied to HBM once and converted to the planar float32 mix [2, N] on the device (asx_pcm_decode_dev: the same
         x / 2^(bits-1) conversion libsndfile applies under librosa.load, common_separator.py:252).  Returns a CUDA tensor, or
         None when the file needs the host decoder (other container, other rate, exotic subtype) -- the caller then takes
-        prepare_mix.  Raises the reference's ValueError for a silent file (:268-271)."""
+        prepare_mix.  Raises the reference's ValueError for a silent file (:268-271) unless ``check_silent`` is False: the VR
+        plugin never calls prepare_mix (vr_separator.py:255-291 loads with librosa directly), so a silent file must come out the
+        same whichever decode path it took (the writer's "nothing to write" branch handles silent stems)."""
         if not self._fast_file_path_enabled() or not isinstance(path, str):
             return None
         import torch
@@ -249,7 +251,7 @@ class CommonSeparator:
         mix = torch.empty((2, frames), dtype=torch.float32, device=dev)
         peak = self.engine.pcm_decode_dev(raw.data_ptr(), frames, ch, st, mix.data_ptr(), stream=self._stream())
         self._tick("h2d_decode", t0)
-        if not peak > 0.0:
+        if check_silent and not peak > 0.0:
             msg = f"Audio file {path} is empty or not valid"
             self.logger.error(msg)
             raise ValueError(msg)
@@ -263,6 +265,9 @@ class CommonSeparator:
         host = torch.empty(dev_stem.shape, dtype=dev_stem.dtype, pin_memory=True)
         host.copy_(dev_stem, non_blocking=True)
         arr = host.numpy()
+        # the mirror is READ-ONLY: write_audio quantises from the device tensor, so an in-place edit of the host array between
+        # separate() and write_audio would be silently dropped -- it raises instead (assign a NEW array to take the generic path)
+        arr.flags.writeable = False
         self._dev_stems[id(arr)] = (arr, dev_stem, host, "rows")
         return arr
 
@@ -273,6 +278,7 @@ class CommonSeparator:
         host = torch.empty(dev_stems.shape, dtype=dev_stems.dtype, pin_memory=True)
         host.copy_(dev_stems, non_blocking=True)
         arr = host.numpy()
+        arr.flags.writeable = False        # as in _host_stem: the views below inherit it
         views = []
         for i in range(arr.shape[0]):
             v = arr[i].T
@@ -429,6 +435,9 @@ class CommonSeparator:
             pcm_host.copy_(pcm_dev, non_blocking=True)
             self._sync()
             pcm = pcm_host.numpy()
+            # written: the device stem and its pinned mirror are released with this entry (planar stems share one mirror, which
+            # lives until the last of them is written)
+            self._dev_stems.pop(id(stem_source), None)
         elif a.dtype == np.int16:
             pcm, peak = np.ascontiguousarray(a), float(np.abs(a).max()) if a.size else 0.0
         else:

@@ -143,8 +143,10 @@ struct DivKey {
   int n_chunks = 0;
   int64_t C = 0, step = 0, L = 0;
   int trim = 0, win = 0;
+  int hann_tab = 0;    // 1: the window came from the fast-FFT path's float64 table (d_hann3), 0: computed in place
   bool operator==(const DivKey &o) const {
-    return N == o.N && n_chunks == o.n_chunks && C == o.C && step == o.step && L == o.L && trim == o.trim && win == o.win;
+    return N == o.N && n_chunks == o.n_chunks && C == o.C && step == o.step && L == o.L && trim == o.trim && win == o.win &&
+           hann_tab == o.hann_tab;
   }
 };
 
@@ -181,6 +183,8 @@ struct asx_engine {
   DevBuf spec_in, spec_out, R[3], H, frames, chunk_out, d_starts, d_nact, d_peak, d_demixed;
   DevBuf d_div;      // divider of the chunk fold for div_key's plan (input-independent: built once, asx_finalize_dev)
   DivKey div_key;
+  hipEvent_t div_ev = nullptr;       // recorded behind the kernel that built d_div; a call on ANOTHER stream waits for it
+  hipStream_t div_stream = nullptr;
   std::vector<DevBuf> skip;
   // 3x3 / pad-1 convs of the ConvTDFNet and TFC-TDF-v3 nets: 3 = Winograd F(2x2,3x3) (conv_wino3_kernel, the default), 0 = the
   // direct kernel (conv_dma_kernel), 1 / 2 = the earlier Winograd generations (kept for A/B runs).  ASX_WINOGRAD or
@@ -1258,6 +1262,7 @@ void asx_engine_destroy(asx_engine *e) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
+  if (e->div_ev) (void)hipEventDestroy(e->div_ev);
   e->d_window.release();
   e->d_tw.release();
   e->d_env.release();
@@ -1562,7 +1567,7 @@ int asx_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t N, float
   // chunk geometry and 16-byte aligned buffers
   if (fin4 && p.chunk_size % 4 == 0 && p.step % 4 == 0 && p.trim % 4 == 0 && N % 4 == 0 && p.chunk_size + (int64_t)p.trim >= 0 &&
       (((uintptr_t)chunk_out_dev | (uintptr_t)out_dev) & 15) == 0) {
-    const DivKey key{N, p.n_chunks, p.chunk_size, p.step, p.padded_len, p.trim, win};
+    const DivKey key{N, p.n_chunks, p.chunk_size, p.step, p.padded_len, p.trim, win, hann != nullptr ? 1 : 0};
     if (!(e->div_key == key) || !e->d_div.p) {
       CHK(e->d_div.ensure((size_t)N * 4));
       CHK(timed(e, ASX_PROF_MISC, 0.0, 4.0 * N, s, [&]() {
@@ -1570,6 +1575,18 @@ int asx_finalize_dev(asx_engine *e, const float *chunk_out_dev, int64_t N, float
                            p.padded_len, p.trim, N, win, e->d_div.f(), hann);
       }));
       e->div_key = key;
+      // the table is shared by later calls: a call on a different stream must be ordered behind this build
+      if (e->div_ev == nullptr) HIPCHK(hipEventCreateWithFlags(&e->div_ev, hipEventDisableTiming));
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(s, &cap);
+      if (cap == hipStreamCaptureStatusNone) {
+        HIPCHK(hipEventRecord(e->div_ev, s));
+        e->div_stream = s;
+      } else {
+        e->div_stream = s;          // built inside a capture: the graph owns the ordering, nothing to wait for outside it
+      }
+    } else if (s != e->div_stream && e->div_ev != nullptr && hipEventQuery(e->div_ev) == hipErrorNotReady) {
+      HIPCHK(hipStreamWaitEvent(s, e->div_ev, 0));
     }
     return timed(e, ASX_PROF_FINALIZE, 0.0, bytes, s, [&]() {
       hipLaunchKernelGGL(finalize4_kernel, dim3((unsigned)((N / 4 + 255) / 256), 2), dim3(256), 0, s, chunk_out_dev, p.n_chunks,

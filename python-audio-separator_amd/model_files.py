@@ -157,10 +157,16 @@ def safe_torch_load(path: str):
     on torch >= 2.6).  A file that needs arbitrary pickle globals is REFUSED: un-pickling it would run code from a downloaded
     model.  Setting ASX_ALLOW_UNSAFE_PICKLE=1 opts into the unrestricted loader for a file the user trusts (logged)."""
     import logging
+    import pickle
     import torch
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception as e:
+    except pickle.UnpicklingError as e:
+        # only a REFUSAL (a global outside the allow-list) is answered with the opt-out hint; a missing, truncated or corrupt
+        # file (OSError, EOFError, zipfile.BadZipFile, RuntimeError from the zip reader ...) propagates as what it is
+        if "weights_only" not in str(e).lower() and "unsupported global" not in str(e).lower() and "unsupported class" not in str(e).lower() \
+                and "unsupported operand" not in str(e).lower():
+            raise
         if os.environ.get(UNSAFE_ENV, "") != "1":
             raise ModelLoadingError(
                 f"{path}: refused by the restricted (weights_only) loader: {e}.  If you trust this file, set {UNSAFE_ENV}=1 "

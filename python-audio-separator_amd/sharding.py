@@ -2,9 +2,16 @@
 
 The chunks of MDXSeparator.demix are independent given the replicated mix
 (mdx_separator.py:348-392), so rank r runs a contiguous chunk range
-on its own engine and the only exchange is ONE gather of the windowed chunk
-outputs to rank 0, which folds them (result / divider) exactly like the
-single-GPU path -- the gathered result is bit-identical to a one-GPU run.
+on its own engine.  Two exchange schemes, both bit-identical to a one-GPU run
+(the fold is a gather over covering chunks in fixed chunk order):
+
+  * fold="local" (default for uniform-stride loops; SURVEY.md 8e's sketch): every rank folds ITS OWN contiguous sample
+    range.  A chunk reaches chunk_size - step samples into the next chunk's stride, so rank r needs, besides its own
+    chunks, only the last ceil(C / step) - 1 chunks of the ranks before it (one 2-MB chunk on the HQ_3 geometry, of which
+    the 65,280-sample tail is what overlaps): point-to-point sends to the right neighbour, no fold and no 115-MB chunk
+    gather on the destination's critical path.  The folded slabs [2, ~N / G] are then gathered to rank ``dst``.
+  * fold="dst": ONE gather of all windowed chunks to rank ``dst``, which folds them (loops without a uniform chunk stride:
+    the Roformer tail chunk, the Demucs shifts).
 
 The driver is backend agnostic: it talks to an *engine adapter* with three
 methods operating on torch tensors that live on the adapter's device,
@@ -38,8 +45,30 @@ def partition_chunks(n_chunks: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
+def owned_samples(plan: dict, ranges, n: int):
+    """Output sample ranges [j0, j1) of the ranks for the local fold: rank r owns the padded positions its chunks START in,
+    [k0 step, k1 step) -- the last non-empty rank up to the padded end -- shifted by the plan's trim and clipped to [0, n)."""
+    step, trim, L = int(plan["step"]), int(plan.get("trim", 0)), int(plan["padded_len"])
+    last = max((r for r, (a, b) in enumerate(ranges) if b > a), default=-1)
+    out = []
+    for r, (a, b) in enumerate(ranges):
+        if b <= a:
+            out.append((0, 0))
+            continue
+        p0, p1 = a * step, (L if r == last else b * step)
+        out.append((min(n, max(0, p0 - trim)), min(n, max(0, p1 - trim))))
+    return out
+
+
+def halo_chunks(plan: dict) -> int:
+    """How many chunks before a rank's first one reach into its sample range: ceil(chunk_size / step) - 1."""
+    C, step = int(plan["chunk_size"]), int(plan["step"])
+    return -(-C // step) - 1
+
+
 class HipEngineAdapter:
     """Engine adapter over libasx.so for CUDA(HIP) torch tensors."""
+    local_fold = True          # chunk k starts at k * step: a rank can fold its own sample range (sharded_demix fold="local")
 
     def __init__(self, engine, is_match_mix: bool = False):
         self.engine = engine
@@ -202,13 +231,82 @@ class ShardWorkspace:
         return self.bufs
 
 
-def sharded_demix(adapter, mix, group=None, dst: int = 0, workspace: ShardWorkspace | None = None):
+def _sharded_demix_local_fold(adapter, mix, plan, ranges, group, dst, workspace, world, rank, is_dst):
+    """fold="local": own chunks + the halo chunks of the ranks before -> fold of the own sample range -> gather of the slabs."""
+    import torch
+    import torch.distributed as dist
+    n = mix.shape[-1]
+    nk, C = plan["n_chunks"], plan["chunk_size"]
+    k0, k1 = ranges[rank]
+    own = owned_samples(plan, ranges, n)
+    W = max(1, max(j1 - j0 for j0, j1 in own))
+    h = halo_chunks(plan)
+    owner = [r for r, (a, b) in enumerate(ranges) for _ in range(a, b)]          # chunk -> rank
+
+    def make():
+        bufs = {"allc": torch.zeros((nk, 2, C), dtype=torch.float32, device=mix.device),
+                "full": torch.empty(tuple(mix.shape), dtype=torch.float32, device=mix.device),
+                "slab": torch.zeros((2, W), dtype=torch.float32, device=mix.device)}
+        if is_dst:
+            bufs["out"] = torch.empty(tuple(mix.shape), dtype=torch.float32, device=mix.device)
+            bufs["slabs"] = [torch.empty((2, W), dtype=torch.float32, device=mix.device) for _ in range(world)]
+        return bufs
+    bufs = workspace.get(("local", nk, C, n, W, world, str(mix.device), is_dst), make) if workspace is not None else make()
+    timed = workspace is not None and workspace.timed and mix.is_cuda
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+    allc = bufs["allc"]
+    if timed:
+        ev[0].record()
+    if k1 > k0:
+        adapter.demix_chunks(mix, n, k0, k1, allc[k0:k1])
+    if timed:
+        ev[1].record()
+    # seam halos: chunk k goes to every LATER rank whose first chunk lies within h chunks of it (its right neighbour, unless
+    # ranges are shorter than the halo)
+    ops = []
+    to_global = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    for r, (a, b) in enumerate(ranges):
+        if b <= a or r == 0:
+            continue
+        for k in range(max(0, a - h), a):
+            q = owner[k]
+            if q == rank and r != rank:
+                ops.append(dist.P2POp(dist.isend, allc[k], to_global(r), group))
+            elif r == rank and q != rank:
+                ops.append(dist.P2POp(dist.irecv, allc[k], to_global(q), group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    j0, j1 = own[rank]
+    if j1 > j0:
+        adapter.finalize(allc, n, bufs["full"])        # only [j0, j1) of it is complete: the chunks that cover it are all here
+        bufs["slab"][:, : j1 - j0].copy_(bufs["full"][:, j0:j1])
+    if timed:
+        ev[2].record()
+    dist.gather(bufs["slab"], bufs["slabs"] if is_dst else None, dst=dst, group=group)
+    out = None
+    if is_dst:
+        out = bufs["out"]
+        for r, (a, b) in enumerate(own):
+            if b > a:
+                out[:, a:b].copy_(bufs["slabs"][r][:, : b - a])
+    if timed:
+        ev[3].record()
+        torch.cuda.synchronize()
+        workspace.timings = {"compute_ms": ev[0].elapsed_time(ev[1]), "fold_ms": ev[1].elapsed_time(ev[2]),
+                             "gather_ms": ev[2].elapsed_time(ev[3]), "scheme": "local fold: halo send/recv + fold of the own sample "
+                             "range (fold_ms), then one gather of [2, N / G] slabs + placement on dst (gather_ms)"}
+    return out
+
+
+def sharded_demix(adapter, mix, group=None, dst: int = 0, workspace: ShardWorkspace | None = None, fold: str = "auto"):
     """Demix one song across all ranks of ``group``.
 
     ``mix``: float32 tensor [2, N] on the adapter's device, identical on every
     rank.  Returns the separated [2, N] tensor on rank ``dst`` and None elsewhere.
     With a ``workspace`` no tensor is allocated after the first call and the returned tensor is the workspace's (it is
-    overwritten by the next call).
+    overwritten by the next call).  ``fold``: "local" / "dst" (module docstring); "auto" = local when the adapter declares
+    ``local_fold`` (uniform chunk stride, one [2, N] output) and its plan carries ``step`` / ``padded_len``.
     """
     import torch
     import torch.distributed as dist
@@ -220,6 +318,12 @@ def sharded_demix(adapter, mix, group=None, dst: int = 0, workspace: ShardWorksp
     plan = adapter.plan(n)
     nk, C = plan["n_chunks"], plan["chunk_size"]
     ranges = partition_chunks(nk, world)
+    can_local = getattr(adapter, "local_fold", False) and "step" in plan and "padded_len" in plan and \
+        getattr(adapter, "stems", None) is None and getattr(adapter, "out_stems", None) is None
+    if fold == "local" and not can_local:
+        raise ValueError("fold='local' needs a uniform-stride adapter (local_fold) whose plan has step / padded_len")
+    if world > 1 and (fold == "local" or (fold == "auto" and can_local)):
+        return _sharded_demix_local_fold(adapter, mix, plan, ranges, group, dst, workspace, world, rank, is_dst)
     k0, k1 = ranges[rank]
     per = max(b - a for a, b in ranges)          # equal-size slabs keep it a single gather
     stems = getattr(adapter, "stems", None)

@@ -162,6 +162,21 @@ def test_state_dict_readers_refuse_foreign_globals(tmp_path, monkeypatch):
     assert marker.exists()
 
 
+def test_damaged_files_are_not_reported_as_refusals(tmp_path, monkeypatch):
+    """a missing or truncated download must surface as what it is, not as "refused ... set ASX_ALLOW_UNSAFE_PICKLE=1"."""
+    import torch
+    monkeypatch.delenv(MF.UNSAFE_ENV, raising=False)
+    with pytest.raises(FileNotFoundError):
+        MF.safe_torch_load(str(tmp_path / "absent.pth"))
+    good = tmp_path / "good.pth"
+    torch.save({"w": torch.ones(1000)}, str(good))
+    cut = tmp_path / "cut.pth"
+    cut.write_bytes(good.read_bytes()[:900])
+    with pytest.raises(Exception) as ei:
+        MF.safe_torch_load(str(cut))
+    assert not isinstance(ei.value, MF.ModelLoadingError) and "UNSAFE" not in str(ei.value)
+
+
 # ---- Roformer configuration mirror vs the reference's normaliser --------------------------------------------------------------
 YAMLS = {
     "ep317": {"audio": {"chunk_size": 352800, "dim_f": 1024, "dim_t": 801, "hop_length": 441, "n_fft": 2048, "num_channels": 2, "sample_rate": 44100},

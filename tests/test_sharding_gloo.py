@@ -20,6 +20,7 @@ DIMS = O.NetDims(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=4)
 
 class OracleAdapter:
     """Test double for HipEngineAdapter (tests only; the product binds libasx.so)."""
+    local_fold = True
 
     def __init__(self, match=False):
         self.run = O.make_model_run(O.make_convtdf_state(DIMS, seed=3), DIMS)
@@ -27,7 +28,7 @@ class OracleAdapter:
 
     def plan(self, n):
         cs, gen, pad, L, step, starts, _ = O.chunk_plan(n, P, self.match)
-        return {"chunk_size": cs, "n_chunks": len(starts), "step": step, "padded_len": L}
+        return {"chunk_size": cs, "n_chunks": len(starts), "step": step, "padded_len": L, "trim": P.trim}
 
     def demix_chunks(self, mix, n, k0, k1, out):
         out.copy_(torch.from_numpy(O.demix_chunks(mix.numpy(), P, self.run, k0, k1, self.match)))
@@ -70,13 +71,13 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, match, q):
+def _worker(rank, world, port, n, match, q, fold="auto"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mix = torch.from_numpy((0.4 * np.random.default_rng(7).standard_normal((2, n))).astype(np.float32))
-    out = sharded_demix(OracleAdapter(match), mix)
+    out = sharded_demix(OracleAdapter(match), mix, fold=fold)
     if rank == 0:
         q.put(out.numpy())
     else:
@@ -85,17 +86,47 @@ def _worker(rank, world, port, n, match, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,match", [(2, 3000, False), (2, 150, False), (3, 2000, True)])
-def test_sharded_demix_gloo(world, n, match):
+def test_local_fold_ownership():
+    """fold="local": the ranks' sample ranges tile [0, N), and every chunk that covers a rank's range is its own or one of the
+    `halo_chunks` before its first (HQ_3 geometry: 55 chunks over 8 ranks = 7 x 7 + 6, one halo chunk, 65,280 overlapping samples)"""
+    from audio_separator_amd.sharding import halo_chunks, owned_samples
+    p = O.MDXParams()
+    n = 10_584_000
+    cs, gen, pad, L, step, starts, _ = O.chunk_plan(n, p, False)
+    plan = {"chunk_size": cs, "n_chunks": len(starts), "step": step, "padded_len": L, "trim": p.trim}
+    assert halo_chunks(plan) == 1 and cs - step == 65280
+    for world in (1, 2, 4, 8, 55, 64):
+        ranges = partition_chunks(len(starts), world)
+        own = owned_samples(plan, ranges, n)
+        live = [(a, b) for a, b in own if b > a]
+        assert live[0][0] == 0 and live[-1][1] == n and all(x[1] == y[0] for x, y in zip(live, live[1:]))
+        for (k0, k1), (j0, j1) in zip(ranges, own):
+            if j1 <= j0:
+                continue
+            for j in (j0, j1 - 1):
+                pos = j + p.trim
+                cover = [k for k, st in enumerate(starts) if st <= pos < st + cs]
+                assert min(cover) >= k0 - 1 and max(cover) < k1
+
+
+@pytest.mark.parametrize("world,n,match,fold", [(2, 3000, False, "auto"), (2, 150, False, "auto"), (3, 2000, True, "auto"),
+                                                (2, 3000, False, "dst"), (3, 2000, True, "dst"),
+                                                (4, 9700, False, "local"), (8, 9700, False, "local"), (8, 9700, False, "dst"),
+                                                (8, 700, False, "local")])
+def test_sharded_demix_gloo(world, n, match, fold):
+    """world 2 / 3 / 4 / 8, both exchange schemes; n = 9700 is 55 chunks on this geometry (uneven ranges: 7 x 7 + 6 at world 8,
+    14 + 14 + 14 + 13 at world 4), n = 700 fewer chunks than ranks (empty ranges at the end)"""
+    if n == 9700:
+        assert len(O.chunk_plan(n, P, match)[5]) == 55
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, match, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, match, q, fold)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = q.get(timeout=300)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     mix = (0.4 * np.random.default_rng(7).standard_normal((2, n))).astype(np.float32)
     run = None if match else O.make_model_run(O.make_convtdf_state(DIMS, seed=3), DIMS)
@@ -103,7 +134,7 @@ def test_sharded_demix_gloo(world, n, match):
     assert np.array_equal(got, ref)
 
 
-def _worker_ws(rank, world, port, lengths, q):
+def _worker_ws(rank, world, port, lengths, q, fold="dst"):
     """Three songs through ONE ShardWorkspace (bench.py --mode chunks): buffers are allocated once per shape and reused, equal
     chunk ranges take the no-compaction path (the gathered slab IS the chunk list), unequal ones the copy path."""
     from audio_separator_amd.sharding import ShardWorkspace
@@ -116,10 +147,10 @@ def _worker_ws(rank, world, port, lengths, q):
     outs, ptrs = [], []
     for i, n in enumerate(lengths):
         mix = torch.from_numpy((0.4 * np.random.default_rng(20 + i).standard_normal((2, n))).astype(np.float32))
-        out = sharded_demix(ad, mix, workspace=ws)
+        out = sharded_demix(ad, mix, workspace=ws, fold=fold)
         if rank == 0:
             outs.append(out.numpy().copy())
-            ptrs.append(ws.bufs["local"].data_ptr())
+            ptrs.append(ws.bufs["local" if fold == "dst" else "allc"].data_ptr())
         else:
             assert out is None
     if rank == 0:
@@ -128,13 +159,14 @@ def _worker_ws(rank, world, port, lengths, q):
     dist.destroy_process_group()
 
 
-def test_sharded_demix_with_workspace_gloo():
+@pytest.mark.parametrize("fold", ["dst", "local"])
+def test_sharded_demix_with_workspace_gloo(fold):
     lengths = [3000, 3000, 2100]          # same shape twice (buffers reused), then another plan (re-allocated once)
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_ws, args=(r, world, port, lengths, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_ws, args=(r, world, port, lengths, q, fold)) for r in range(world)]
     for p in procs:
         p.start()
     outs, ptrs = q.get(timeout=180)
