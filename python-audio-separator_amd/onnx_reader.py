@@ -8,15 +8,20 @@ and maps the ConvTDFNet pattern (uvr_lib_v5/mdxnet.py:54-120) onto the engine's
 canonical tensors (include/asx.h), folding BatchNormalization nodes in float64.
 
 Only the ONNX features such exports use are understood: Conv, ConvTranspose,
-MatMul (+ optional bias Add), BatchNormalization (fused into the Conv by the
-exporter or left as its own node), Relu, Add, Mul, Transpose; weights as fp32
-initialisers (``raw_data`` or ``float_data``) or derived from them through
-Constant / Identity / Transpose / Reshape / Squeeze / Unsqueeze / Cast nodes (exports
-made without constant folding).  Anything else raises ``OnnxFormatError`` rather
-than guessing.
+MatMul (+ optional bias Add) or Gemm (behind a Reshape pair) for the TDF linears,
+BatchNormalization (fused into the Conv by the exporter or left as its own node, in
+inference or training-export form), Relu, Add, Mul, Transpose / Identity / Dropout on
+activations, and the shape arithmetic of run-time Reshape targets (Shape, Gather,
+Concat, Slice ... on shape vectors only); weights as fp32 initialisers (``raw_data``
+or ``float_data``, also when repeated in ``graph.input`` as old IR versions do) or
+derived from them through Constant / Identity / Transpose / Reshape / Squeeze /
+Unsqueeze / Cast nodes (exports made without constant folding).  EVERY node of the
+graph must be one of those: anything else raises ``OnnxFormatError`` naming the node
+rather than being skipped (``check_ops``) -- an activation-side op the engine does not
+run would otherwise silently change the model.
 
 Field numbers follow onnx.proto3 (ModelProto.graph = 7; GraphProto.node = 1,
-initializer = 5, input = 11; NodeProto.input = 1, output = 2, op_type = 4,
+initializer = 5, input = 11; NodeProto.input = 1, output = 2, name = 3, op_type = 4,
 attribute = 5; AttributeProto.name = 1, f = 2, i = 3, ints = 8; TensorProto.dims = 1,
 data_type = 2, float_data = 4, name = 8, raw_data = 9).
 """
@@ -89,6 +94,7 @@ def _sint64(x: int) -> int:
 @dataclass
 class Node:
     op: str = ""
+    name: str = ""
     inputs: list = field(default_factory=list)
     outputs: list = field(default_factory=list)
     attrs: dict = field(default_factory=dict)
@@ -150,12 +156,18 @@ def _parse_node(b) -> Node:
             n.inputs.append(bytes(v).decode())
         elif fno == 2:
             n.outputs.append(bytes(v).decode())
+        elif fno == 3:
+            n.name = bytes(v).decode()
         elif fno == 4:
             n.op = bytes(v).decode()
         elif fno == 5:
             k, val = _parse_attr(v)
             n.attrs[k] = val
     return n
+
+
+def _where(n: Node) -> str:
+    return f"node '{n.name or (n.outputs[0] if n.outputs else '?')}' (op {n.op})"
 
 
 def _parse_value_info_shape(b):
@@ -248,7 +260,38 @@ def fold_constants(nodes, inits) -> dict:
     return vals
 
 
+# ops of the ConvTDFNet eval graph (weights + structure), pass-through ops on activations, and ops that may only touch
+# constants or SHAPE vectors (run-time Reshape targets)
+_STRUCT_OPS = {"Conv", "ConvTranspose", "MatMul", "Gemm", "BatchNormalization", "Relu", "Add", "Mul"}
+_PASS_OPS = {"Identity", "Dropout", "Transpose", "Reshape", "Flatten", "Cast"}
+_SHAPE_OPS = {"Shape", "Gather", "Concat", "Slice", "Squeeze", "Unsqueeze", "Constant", "ConstantOfShape", "Sub", "Div", "Size", "Range"}
+
+
+def check_ops(nodes, consts) -> None:
+    """Every node must be an op this reader accounts for.  Ops that would change ACTIVATIONS and are not part of the net
+    (Sigmoid, LeakyRelu, Pad, Resize, InstanceNormalization ...) raise; so do shape-arithmetic ops fed with activations."""
+    shapeish = set(consts)                    # constants and everything computed from Shape(...) of an activation
+    for n in nodes:
+        if n.op == "Shape":
+            shapeish.update(n.outputs)
+            continue
+        all_shape = bool(n.inputs) and all((i in shapeish or i == "") for i in n.inputs)
+        if n.op in _SHAPE_OPS or (all_shape and n.op in _STRUCT_OPS | _PASS_OPS):
+            if n.op in ("Constant", "ConstantOfShape") or all_shape:
+                shapeish.update(n.outputs)
+                continue
+            if n.op in ("Squeeze", "Unsqueeze"):          # also legal on weights; never emitted on ConvTDFNet activations
+                raise OnnxFormatError(f"{_where(n)}: acts on an activation; not part of ConvTDFNet")
+            raise OnnxFormatError(f"{_where(n)}: shape arithmetic applied to an activation tensor; not part of ConvTDFNet")
+        if n.op not in _STRUCT_OPS and n.op not in _PASS_OPS:
+            raise OnnxFormatError(f"{_where(n)}: unsupported op -- this reader runs the BatchNorm ConvTDFNet only "
+                                  "(Conv, ConvTranspose, MatMul / Gemm, BatchNormalization, Relu, Add, Mul, Transpose, Reshape)")
+
+
 def _bn_affine(node: Node, inits):
+    missing = [n for n in node.inputs[1:5] if n not in inits]
+    if len(node.inputs) < 5 or missing:
+        raise OnnxFormatError(f"{_where(node)}: scale / bias / mean / var must be constants (missing {missing})")
     g, b, m, v = (np.asarray(inits[n], np.float64) for n in node.inputs[1:5])
     eps = float(node.attrs.get("epsilon", 1e-5))
     scale = g / np.sqrt(v + eps)
@@ -263,17 +306,27 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
     segment_size != dim_t, mdx_separator.py:126-132)."""
     nodes, raw_inits, ginputs = parse_onnx(path_or_bytes)
     inits = fold_constants(nodes, raw_inits)
+    check_ops(nodes, inits)
     consumers: dict = {}
     for idx, n in enumerate(nodes):
         for i in n.inputs:
             consumers.setdefault(i, []).append(idx)
 
     def next_op(idx, op):
-        """The single consumer of node idx's output if it is `op` (else None)."""
-        outs = consumers.get(nodes[idx].outputs[0], [])
-        if len(outs) == 1 and nodes[outs[0]].op == op:
-            return outs[0]
-        return None
+        """The single consumer of node idx's FIRST output if it is `op` (else None); Reshape / Identity / Dropout / Flatten
+        behind it are looked through (the Gemm lowering of a Linear puts a Reshape between the product and its BatchNorm)."""
+        while True:
+            outs = [j for j in consumers.get(nodes[idx].outputs[0], []) if nodes[j].inputs and nodes[j].inputs[0] == nodes[idx].outputs[0]
+                    or nodes[j].op in ("Add", "Mul")]
+            if len(outs) != 1:
+                return None
+            j = outs[0]
+            if nodes[j].op == op:
+                return j
+            if nodes[j].op in ("Reshape", "Identity", "Dropout", "Flatten") and op not in ("Reshape", "Identity", "Dropout", "Flatten"):
+                idx = j
+                continue
+            return None
 
     layers = []   # ("conv", k, stride, w[cout,cin,kh,kw], b) | ("convT", w[cin,cout,2,2], b) | ("lin", w[n,k], bias|None, scale, shift)
     for idx, n in enumerate(nodes):
@@ -287,7 +340,9 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
             ks = n.attrs.get("kernel_shape", list(w.shape[2:]))
             st = n.attrs.get("strides", [1, 1])
             if n.attrs.get("group", 1) != 1 or any(d != 1 for d in n.attrs.get("dilations", [1, 1])):
-                raise OnnxFormatError("grouped / dilated Conv is not part of ConvTDFNet")
+                raise OnnxFormatError(f"{_where(n)}: grouped / dilated Conv is not part of ConvTDFNet")
+            if n.inputs[1] not in inits:
+                raise OnnxFormatError(f"{_where(n)}: weight is not a constant")
             layers.append(("conv", int(ks[0]), int(st[0]), w, b))
         elif n.op == "ConvTranspose":
             w = np.asarray(inits[n.inputs[1]], np.float64)
@@ -300,7 +355,7 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
         elif n.op == "MatMul":
             wname = n.inputs[1] if n.inputs[1] in inits else (n.inputs[0] if n.inputs[0] in inits else None)
             if wname is None:
-                raise OnnxFormatError("MatMul without a constant operand")
+                raise OnnxFormatError(f"{_where(n)}: MatMul without a constant operand")
             w = np.asarray(inits[wname], np.float64).T            # exporter stores W^T [in, out]
             bias = None
             j = idx
@@ -310,11 +365,28 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
                 j = ja
             jb = next_op(j, "BatchNormalization")
             if jb is None:
-                raise OnnxFormatError("TDF Linear without BatchNormalization (adamw/GroupNorm variant is unsupported)")
+                raise OnnxFormatError(f"{_where(n)}: TDF Linear without BatchNormalization (adamw/GroupNorm variant is unsupported)")
             s, sh = _bn_affine(nodes[jb], inits)
             layers.append(("lin", w, bias, s, sh))
-        elif n.op in ("Gemm", "GroupNormalization", "InstanceNormalization", "LSTM"):
-            raise OnnxFormatError(f"op {n.op} is not part of the BatchNorm ConvTDFNet this engine runs")
+        elif n.op == "Gemm":
+            # Linear lowered as Reshape([-1, K]) -> Gemm(A, B, C) -> Reshape: Y = alpha * A * op(B) + beta * C
+            if len(n.inputs) < 2 or n.inputs[1] not in inits or n.inputs[0] in inits:
+                raise OnnxFormatError(f"{_where(n)}: expected activation x constant weight")
+            if float(n.attrs.get("alpha", 1.0)) != 1.0 or float(n.attrs.get("beta", 1.0)) != 1.0 or int(n.attrs.get("transA", 0)) != 0:
+                raise OnnxFormatError(f"{_where(n)}: alpha / beta / transA other than 1 / 1 / 0")
+            w = np.asarray(inits[n.inputs[1]], np.float64)
+            if not int(n.attrs.get("transB", 0)):
+                w = w.T                                            # B is [K, N]: Linear's weight is its transpose
+            bias = None
+            if len(n.inputs) > 2 and n.inputs[2]:
+                if n.inputs[2] not in inits:
+                    raise OnnxFormatError(f"{_where(n)}: bias operand is not a constant")
+                bias = np.asarray(inits[n.inputs[2]], np.float64).reshape(-1)
+            jb = next_op(idx, "BatchNormalization")
+            if jb is None:
+                raise OnnxFormatError(f"{_where(n)}: TDF Linear without BatchNormalization (adamw/GroupNorm variant is unsupported)")
+            s, sh = _bn_affine(nodes[jb], inits)
+            layers.append(("lin", w, bias, s, sh))
 
     if len(layers) < 4 or layers[0][0] != "conv" or layers[0][1] != 1:
         raise OnnxFormatError("graph does not start with the 1x1 first_conv of ConvTDFNet")

@@ -63,3 +63,60 @@ def test_rejects_garbage(tmp_path):
     p.write_bytes(b"\x08\x01\x12\x03abc")          # a valid protobuf without a graph
     with pytest.raises(OnnxFormatError):
         convtdf_from_onnx(str(p))
+
+
+# ---- graph idioms torch's exporter does not produce (hand-written files: tests/onnx_writer.py) --------------------------------
+from tests import onnx_writer as W  # noqa: E402
+
+IDIOMS = [(), ("gemm",), ("gemm", "shape_ops"), ("bn_training",), ("opset9",), ("opset9", "bn_training", "gemm", "shape_ops"),
+          ("transposes",), ("gemm", "transposes", "bn_training", "opset9")]
+
+
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("idioms", IDIOMS, ids=["+".join(i) or "plain" for i in IDIOMS])
+def test_reader_other_exporter_lineages(idioms, bias):
+    """Gemm-lowered Linear (Reshape -> Gemm(transB) -> Reshape, with the Reshape target from run-time Shape / Gather / Concat),
+    unfused BatchNormalization in training-export form (five outputs, training_mode / spatial / momentum attributes), opset 9
+    (initialisers repeated in graph.input, float_data payloads, axes attributes), NHWC Transpose pairs and Identity nodes on the
+    activations: the reader must recover exactly what folding the state dict in float64 gives."""
+    d = O.NetDims(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=4, bias=bias)
+    sd = O.make_convtdf_state(d, seed=4)
+    blob = W.convtdf_graph(sd, d, idioms)
+    nodes, inits, inputs = parse_onnx(blob)
+    ops = [n.op for n in nodes]
+    if "gemm" in idioms:
+        assert ops.count("Gemm") == 10 and "MatMul" not in ops
+    if "bn_training" in idioms:
+        assert all(len(n.outputs) == 5 for n in nodes if n.op == "BatchNormalization")
+    if "opset9" in idioms:
+        assert len(inputs) > 100 and inputs["input"] == [1, 4, 32, 16]        # every initialiser is also listed as a graph input
+    if "transposes" in idioms:
+        assert ops.count("Transpose") == 2 + 2 * 5 and ops.count("Identity") == ops.count("Relu")
+    cfg, tensors = convtdf_from_onnx(blob)
+    assert (cfg.dim_c, cfg.dim_f, cfg.dim_t, cfg.g, cfg.l, cfg.num_blocks, cfg.k, cfg.bn, cfg.tdf_bias) == (4, 32, 16, 8, 2, 5, 3, 4, bias)
+    want = fold_convtdf_state(sd, d.num_blocks, d.l, tdf_bias=bias)
+    assert sorted(tensors) == sorted(want)
+    for k in want:
+        assert tensors[k].shape == want[k].shape and np.array_equal(tensors[k], want[k]), k
+
+
+@pytest.mark.parametrize("op,what", [("Sigmoid", "unsupported op"), ("LeakyRelu", "unsupported op"), ("Pad", "unsupported op"),
+                                     ("InstanceNormalization", "unsupported op"), ("Slice", "shape arithmetic"), ("Squeeze", "activation")])
+def test_reader_fails_loudly_on_ops_it_cannot_account_for(op, what):
+    """An activation-side node that is not part of the BatchNorm ConvTDFNet must stop the load, with the node named -- skipping
+    it would silently run a different model."""
+    d = O.NetDims(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=4)
+    sd = O.make_convtdf_state(d, seed=4)
+    with pytest.raises(OnnxFormatError, match=f"unexpected_{op}.*{what}"):
+        convtdf_from_onnx(W.convtdf_graph(sd, d, (), extra_node=op))
+
+
+def test_writer_files_equal_exporter_files_semantically(golden_dir):
+    """The hand-written plain graph and torch's export of the same net give the same engine tensors (exporter: float32 fold)."""
+    d = O.NetDims(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=4, bias=True)
+    sd = O.make_convtdf_state(d, seed=4)
+    _, mine = convtdf_from_onnx(W.convtdf_graph(sd, d, ()))
+    _, theirs = convtdf_from_onnx(os.path.join(golden_dir, "net_small_bias.onnx"))
+    assert sorted(mine) == sorted(theirs)
+    for k in mine:
+        assert np.allclose(mine[k], theirs[k], rtol=2e-6, atol=2e-7), k
