@@ -404,6 +404,18 @@ int asx_vr_separate(asx_engine *e, const float *wave_host, int64_t n_samples, co
 int asx_vr_separate_dev(asx_engine *e, const float *wave_dev, int64_t n_samples, const asx_vr_params *params, float *primary_dev,
                         float *secondary_dev, void *stream);
 
+/* librosa.resample(y, orig_sr, target_sr, res_type="sinc_fastest") for ANY ratio = float(target_sr) / orig_sr, i.e. libsamplerate's
+ * SRC_SINC_FASTEST through python-samplerate as above (restated algorithm, regenerated table: parity unpinned).  Replaces
+ * spec_utils.change_pitch_semitones (uvr_lib_v5/spec_utils.py:783-790; MDXC pitch_shift, mdxc_separator.py:230-243,268-270) and
+ * is the test hook of the converter.  x [channels, n_in] planar -> y [channels, n_out], n_out = ceil(n_in * ratio) (librosa's
+ * fix_length; frames the library does not generate are zero).  mono_calls != 0: every channel is its own one-channel call -- the
+ * library's end-of-input test then drops the last frame when n_in * ratio is an integer (change_pitch_semitones resamples channel
+ * by channel); 0: the channels are the interleaved channels of one call (the VR chain).  ABI 5. */
+int asx_resample_sinc(asx_engine *e, const float *x_host, int32_t channels, int64_t n_in, double ratio, int32_t mono_calls,
+                      float *y_host, int64_t n_out);
+int asx_resample_sinc_dev(asx_engine *e, const float *x_dev, int32_t channels, int64_t n_in, double ratio, int32_t mono_calls,
+                          float *y_dev, int64_t n_out, void *stream);
+
 /* BagOfModels on the device (uvr_lib_v5/demucs/apply.py:169-196 + demucs_separator.py:171-189; ABI 4).  Every member of a
  * bag keeps its own engine (weights resident across files); the caller demixes the STANDARDISED mix with each member
  * (flags 0) and combines without a host round trip:

@@ -209,3 +209,34 @@ def mdxc_demix(mix: np.ndarray, sd: dict, cfg: V3Config, overlap: int = 8, segme
         out = v3_forward(chunk[None], sd, cfg)[0]
         acc[..., k * hop_size: k * hop_size + chunk_size] += out
     return acc[..., front: -(pad_size + chunk_size - hop_size)] / overlap
+
+
+# --------------------------------------------------------------------------
+# pitch shift around the demix call (mdxc_separator.py:230-243, 268-270, 417-419; spec_utils.change_pitch_semitones :783-790,
+# match_array_shapes :752-769).  On Linux / x86 `wav_resolution_float_resampling` is "sinc_fastest" (spec_utils.py:33-38):
+# librosa.resample -> libsamplerate, channel by channel -- restated (parity unpinned) in oracle/vr_oracle.py.
+# --------------------------------------------------------------------------
+def change_pitch_semitones(y: np.ndarray, sr, semitone_shift):
+    from oracle import vr_oracle as V
+    factor = 2 ** (semitone_shift / 12)
+    out = np.array([V.lr_resample(np.asarray(ch), orig_sr=sr, target_sr=sr * factor, res_type="sinc_fastest") for ch in y])
+    return out, sr * factor
+
+
+def match_array_shapes(a1: np.ndarray, a2: np.ndarray):
+    if a1.shape[1] > a2.shape[1]:
+        return a1[:, : a2.shape[1]]
+    if a1.shape[1] < a2.shape[1]:
+        return np.pad(a1, ((0, 0), (0, a2.shape[1] - a1.shape[1])), "constant", constant_values=0)
+    return a1
+
+
+def mdxc_demix_pitched(mix: np.ndarray, sd: dict, cfg: V3Config, overlap: int, pitch_shift: int, sample_rate=44100):
+    """MDXCSeparator.demix with pitch_shift != 0, multi-stem TFC branch: resample the mix to sr * 2^(-p/12), demix, resample every
+    stem back by 2^(p/12) and pad / trim to the original length."""
+    mix = np.asarray(mix, np.float32)
+    mixp, srp = change_pitch_semitones(mix, sample_rate, -pitch_shift)
+    stems = mdxc_demix(mixp.astype(np.float32), sd, cfg, overlap=overlap)
+    if stems.ndim == 2:
+        stems = stems[None]
+    return np.stack([match_array_shapes(change_pitch_semitones(s_, srp, pitch_shift)[0], mix) for s_ in stems])

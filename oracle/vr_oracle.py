@@ -103,7 +103,9 @@ def lr_resample(y, orig_sr=None, target_sr=None, res_type="polyphase", axis=-1, 
         # output_frames = int(n * ratio)) -> util.fix_length(ceil(n * ratio)) -> cast back to y.dtype
         ym = np.moveaxis(np.asarray(y), axis, -1)
         flat = np.ascontiguousarray(ym.reshape(-1, ym.shape[-1]), dtype=np.float32)
-        y_hat = src_simple_sinc_fastest(flat, ratio).reshape(ym.shape[:-1] + (-1,))
+        # a 1-D signal is ONE src_simple call with one channel (the library's end-of-input test then drops an output frame that
+        # would need input up to the very end: change_pitch_semitones resamples channel by channel); [C, n] is one call with C
+        y_hat = src_simple_sinc_fastest(flat, ratio, mono=(ym.ndim == 1)).reshape(ym.shape[:-1] + (-1,))
         y_hat = np.moveaxis(y_hat, -1, axis)
     else:
         g = gcd(int(orig_sr), int(target_sr))
@@ -176,14 +178,30 @@ def _src_positions(n_out: int, ratio: float):
     return b, frac
 
 
-def src_simple_sinc_fastest(x: np.ndarray, ratio: float) -> np.ndarray:
-    """src_simple(SRC_SINC_FASTEST) on channels-first float32 data x [C >= 2, n] -> float32 [C, int(n * ratio)].
-    (With two or more interleaved channels the library's termination test lets every one of the int(n * ratio) output
-    frames be generated; the VR chain always resamples stereo.)"""
+def src_generated_frames(n: int, ratio: float, channels: int) -> int:
+    """Output frames src_simple really generates from n input frames: at most int(n * ratio) (python-samplerate's buffer), and
+    the main loop stops at the first frame for which  channels * frame + fraction + 1 / ratio + 1e-20 >= channels * n  (the
+    library's termination test mixes a sample count with a frame fraction; sinc_*_vari_process).  With two or more channels
+    that never bites; with ONE channel the last frame goes whenever it sits closer than 1 / ratio to the end of the input."""
+    n_out = int(n * ratio)
+    if channels >= 2 or n_out == 0:
+        return n_out
+    b, frac = _src_positions(n_out, ratio)
+    ok = b.astype(np.float64) + frac + (1.0 / ratio + 1e-20) < float(n)
+    bad = np.nonzero(~ok)[0]
+    return int(bad[0]) if bad.size else n_out
+
+
+def src_simple_sinc_fastest(x: np.ndarray, ratio: float, mono: bool = False) -> np.ndarray:
+    """src_simple(SRC_SINC_FASTEST) on channels-first float32 data x [C, n] -> float32 [C, frames generated].
+    ``mono``: every row is its own one-channel call (see src_generated_frames); else the rows are the interleaved channels of
+    ONE call (the VR chain always resamples stereo: every one of the int(n * ratio) output frames is generated)."""
     x = np.asarray(x, np.float32)
     coeffs = src_fastest_table()
     C, n = x.shape
-    n_out = int(n * ratio)
+    n_out = src_generated_frames(n, ratio, 1 if (mono or C == 1) else C)
+    if n_out == 0:
+        return np.zeros((C, 0), np.float32)
     half_len = SRC_FASTEST_LEN - 2                                   # coeff_half_len = ARRAY_LEN(coeffs) - 2
     float_inc = SRC_FASTEST_INC * (ratio if ratio < 1.0 else 1.0)
     inc = int(np.rint(float_inc * SRC_FP_ONE))

@@ -76,6 +76,8 @@ class MDXCSeparator(CommonSeparator):
         """The same steps with every array in HBM (RIFF/WAVE input at the model's rate): decode on the device, normalise the mix in
         place (asx_normalize_dev), demix, residual stem, normalise every stem in place, host mirrors (pinned) for
         ``primary_source`` / ``secondary_source``, int16 pass on the device per written stem.  None: take the generic path."""
+        if self.pitch_shift != 0:
+            return None               # the pitch round trip runs through demix() on host arrays (mdxc.py _demix_pitched)
         if self.engine is None:
             self._demixer()
         mix_d = self._device_mix(self.audio_file_path)

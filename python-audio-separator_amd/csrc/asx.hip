@@ -183,6 +183,7 @@ struct asx_engine {
   DevBuf spec_in, spec_out, R[3], H, frames, chunk_out, d_starts, d_nact, d_peak, d_demixed;
   DevBuf d_div;      // divider of the chunk fold for div_key's plan (input-independent: built once, asx_finalize_dev)
   DivKey div_key;
+  DevBuf sinc_tab;   // coefficient table of asx_resample_sinc (built on first use)
   hipEvent_t div_ev = nullptr;       // recorded behind the kernel that built d_div; a call on ANOTHER stream waits for it
   hipStream_t div_stream = nullptr;
   std::vector<DevBuf> skip;
@@ -1263,6 +1264,7 @@ void asx_engine_destroy(asx_engine *e) {
     (void)hipEventDestroy(r.b);
   }
   if (e->div_ev) (void)hipEventDestroy(e->div_ev);
+  e->sinc_tab.release();
   e->d_window.release();
   e->d_tw.release();
   e->d_env.release();
@@ -1751,6 +1753,15 @@ int asx_residual_dev(asx_engine *e, const float *mix_dev, const float *stem_dev,
   });
 }
 
+// librosa.resample(res_type="sinc_fastest") for an arbitrary ratio (engine_vr.h resample_sinc_dev)
+int asx_resample_sinc_dev(asx_engine *e, const float *x_dev, int32_t channels, int64_t n_in, double ratio, int32_t mono_calls,
+                          float *y_dev, int64_t n_out, void *stream) {
+  REQUIRE(e && x_dev && y_dev && channels >= 1 && channels <= 65535 && n_in >= 1 && n_out >= 1, "asx_resample_sinc_dev: bad argument");
+  REQUIRE(ratio > 1.0 / 256 && ratio < 256.0, "asx_resample_sinc_dev: ratio %g outside libsamplerate's (1/256, 256)", ratio);
+  HIPCHK(hipSetDevice(e->device));
+  return resample_sinc_dev(e, e->sinc_tab, x_dev, channels, n_in, ratio, mono_calls, y_dev, n_out, reinterpret_cast<hipStream_t>(stream));
+}
+
 // ---- stage hooks -------------------------------------------------------------
 static int to_dev(DevBuf &d, const float *h, size_t n) {
   CHK(d.ensure(n * 4));
@@ -1868,6 +1879,18 @@ int asx_pcm16(asx_engine *e, const float *stem_host, int64_t N, float max_peak, 
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(pcm_host, dp.p, (size_t)2 * N * 2, hipMemcpyDeviceToHost));
   return ASX_OK;
+}
+
+int asx_resample_sinc(asx_engine *e, const float *x_host, int32_t channels, int64_t n_in, double ratio, int32_t mono_calls,
+                      float *y_host, int64_t n_out) {
+  REQUIRE(e && x_host && y_host && channels >= 1 && n_in >= 1 && n_out >= 1, "asx_resample_sinc: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  DevBuf dx, dy;
+  BufGuard g{{&dx, &dy}};
+  CHK(to_dev(dx, x_host, (size_t)channels * n_in));
+  CHK(dy.ensure((size_t)channels * n_out * 4));
+  CHK(asx_resample_sinc_dev(e, dx.f(), channels, n_in, ratio, mono_calls, dy.f(), n_out, nullptr));
+  return to_host(y_host, dy, (size_t)channels * n_out);
 }
 
 int asx_stft(asx_engine *e, const float *wave_host, int32_t B, int64_t C, float *spec_host) {

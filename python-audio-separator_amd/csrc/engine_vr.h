@@ -889,12 +889,33 @@ static int vr_resample(asx_engine *e, const VrFilt &f, const float *x, int64_t n
     const int64_t n_gen = std::min<int64_t>(n_out, (int64_t)((double)n_in * f.ratio));   // python-samplerate: int(num_frames * ratio)
     return timed(e, ASX_PROF_MISC, 0.0, 8.0 * (n_in + n_out), s, [&]() {
       hipLaunchKernelGGL(vr_sinc_kernel, dim3((unsigned)((n_out + 255) / 256), 2), dim3(256), 2 * VR_SINC_TL * sizeof(float), s, x, n_in, tab,
-                         tab + VR_SINC_TL, VR_SINC_TL, VR_SINC_TL - 2, f.up, f.down, float_inc, inc_fp, float_inc / VR_SINC_INC, n_gen, y, n_out);
+                         tab + VR_SINC_TL, VR_SINC_TL, VR_SINC_TL - 2, f.up, f.down, 0.0, float_inc, inc_fp, float_inc / VR_SINC_INC, n_gen, y, n_out);
     });
   }
   return timed(e, ASX_PROF_MISC, 0.0, 8.0 * (n_in + n_out), s, [&]() {
     hipLaunchKernelGGL(vr_resample_kernel, dim3((unsigned)((n_out + 255) / 256), 2), dim3(256), 0, s, x, n_in, f.h32.f(),
                        reinterpret_cast<const double *>(f.h64.p), f.hlen, f.up, f.down, f.n_pre_remove, y, n_out, acc64);
+  });
+}
+
+// librosa.resample(y, orig_sr, target_sr, res_type="sinc_fastest") on planar data [channels, n_in] -> [channels, n_out] for ANY
+// ratio = float(target_sr) / orig_sr (spec_utils.change_pitch_semitones, :783-790: ratio = 2^(semitones / 12)).  n_out is librosa's
+// fix_length target ceil(n_in * ratio); mono_calls: every channel is its own one-channel src_simple call, whose termination test
+// drops the last frame when n_in * ratio is an integer (the reference resamples channel by channel there).
+static int resample_sinc_dev(asx_engine *e, DevBuf &tabbuf, const float *x, int channels, int64_t n_in, double ratio, int mono_calls,
+                             float *y, int64_t n_out, hipStream_t s) {
+  if (tabbuf.p == nullptr) CHK(vr_sinc_table(tabbuf));
+  const float *tab = tabbuf.f();
+  const double float_inc = VR_SINC_INC * (ratio < 1.0 ? ratio : 1.0);
+  const long long inc_fp = llrint(float_inc * 4096.0);
+  const double t = (double)n_in * ratio;
+  int64_t n_gen = (int64_t)t;                                       // python-samplerate: int(num_frames * ratio)
+  if ((mono_calls || channels == 1) && (double)n_gen == t && n_gen > 0) --n_gen;   // frame + 1 / ratio would reach the end of the input
+  n_gen = std::min(n_gen, n_out);
+  return timed(e, ASX_PROF_MISC, 0.0, 4.0 * channels * (n_in + n_out), s, [&]() {
+    hipLaunchKernelGGL(vr_sinc_kernel, dim3((unsigned)((n_out + 255) / 256), channels), dim3(256), 2 * VR_SINC_TL * sizeof(float), s, x, n_in,
+                       tab, tab + VR_SINC_TL, VR_SINC_TL, VR_SINC_TL - 2, 0, 1, 1.0 / ratio, float_inc, inc_fp, float_inc / VR_SINC_INC, n_gen,
+                       y, n_out);
   });
 }
 

@@ -155,13 +155,15 @@ __global__ __launch_bounds__(256) void vr_resample_kernel(const float *__restric
 // entries linearly interpolated in double; the LEFT half (frames b - k, farthest tap first, down to filter index >= 0) and the
 // RIGHT half (frames b + 1 + k, farthest first, while filter index > 0) are accumulated in double in the library's order and
 // summed, times `scale` = min(ratio, 1).  History before frame 0 and after the last frame is zero (prepare_data).  Frames
-// m >= n_gen = int(n_in * ratio) are librosa's fix_length zero padding.  The position is formed from the exact rational
-// m * down / up rather than by the library's running double sum (equal up to the sum's rounding, ~1e-13 frames).
+// m >= n_gen (the frames src_simple really generates, computed by the host) are librosa's fix_length zero padding.  The
+// position is formed from the exact rational m * down / up -- or, for an irrational ratio (up == 0: the pitch-shift round
+// trip of the MDXC path), from m * pos_step in double -- rather than by the library's running double sum (equal up to the
+// sum's rounding, ~1e-13 frames for rational ratios, ~1e-9 at ten million frames otherwise).
 // Table in LDS: the threads of a block walk it at a common stride from a handful of distinct start indices.  grid.y = channel.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vr_sinc_kernel(const float *__restrict__ x, int64_t n_in, const float *__restrict__ tab,
                                                       const float *__restrict__ dtab, int TL, int half_len, int up, int down,
-                                                      double float_inc, long long inc_fp, double scale, int64_t n_gen,
+                                                      double pos_step, double float_inc, long long inc_fp, double scale, int64_t n_gen,
                                                       float *__restrict__ y, int64_t n_out) {
   extern __shared__ float sinc_lds[];
   float *c = sinc_lds, *dc = sinc_lds + TL;
@@ -179,9 +181,17 @@ __global__ __launch_bounds__(256) void vr_sinc_kernel(const float *__restrict__ 
     return;
   }
   const float *xp = x + (int64_t)ch * n_in;
-  const int64_t q = m * down;
-  const int64_t b = q / up;
-  const double frac = (double)(q - b * up) / (double)up;
+  int64_t b;
+  double frac;
+  if (up > 0) {
+    const int64_t q = m * down;
+    b = q / up;
+    frac = (double)(q - b * up) / (double)up;
+  } else {
+    const double p = (double)m * pos_step;
+    b = (int64_t)floor(p);
+    frac = p - (double)b;
+  }
   const long long max_fi = (long long)half_len << 12;
   const long long sfi = llrint(frac * float_inc * 4096.0);
   auto icoeff = [&](long long fi) -> double {

@@ -230,7 +230,8 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
            "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev",
            "asx_hd_begin", "asx_hd_commit", "asx_hd_flops", "asx_hd_forward", "asx_hd_demix", "asx_hd_demix_dev", "asx_hd_plan",
-           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev", "asx_ht_standardize_dev", "asx_ht_bag_accumulate_dev", "asx_ht_bag_finish_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_normalize_dev", "asx_residual_dev", "asx_profile_launches", "asx_debug_trace"]
+           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev", "asx_ht_standardize_dev", "asx_ht_bag_accumulate_dev", "asx_ht_bag_finish_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_normalize_dev", "asx_residual_dev", "asx_profile_launches", "asx_debug_trace",
+           "asx_resample_sinc", "asx_resample_sinc_dev"]
 
 
 class _LaunchRec(C.Structure):     # struct asx_launch_rec
@@ -315,6 +316,8 @@ def load_library():
     lib.asx_vr_separate.argtypes = [vp, _FP, i64, C.POINTER(_VrParams), _FP, _FP]
     lib.asx_vr_separate_dev.argtypes = [vp, vp, i64, C.POINTER(_VrParams), vp, vp, vp]
     lib.asx_debug_fetch.argtypes = [vp, C.c_char_p, _FP, i64]
+    lib.asx_resample_sinc.argtypes = [vp, _FP, i32, i64, C.c_double, i32, _FP, i64]
+    lib.asx_resample_sinc_dev.argtypes = [vp, vp, i32, i64, C.c_double, i32, vp, i64, vp]
     lib.asx_ensemble.argtypes = [vp, _FP, i32, i64, i32, C.POINTER(C.c_double), _FP, C.POINTER(i64)]
     lib.asx_ensemble_dev.argtypes = [vp, vp, i32, i64, i32, C.POINTER(C.c_double), vp, C.POINTER(i64), vp]
     lib.asx_invert_stem.argtypes = [vp, _FP, _FP, i64, _FP, C.POINTER(i64)]
@@ -712,6 +715,24 @@ class Engine:
         self._check(self._lib.asx_vr_commit(self._h))
         self.vr_bins = mp["bins"]
         self.vr_window = int(window_size)
+
+    def resample_sinc(self, x: np.ndarray, ratio: float, mono_calls: bool = False) -> np.ndarray:
+        """librosa.resample(x, orig_sr, target_sr, res_type="sinc_fastest") with ratio = float(target_sr) / orig_sr on x [C, n]
+        (or [n]) -> [C, ceil(n * ratio)].  ``mono_calls``: channel by channel, as spec_utils.change_pitch_semitones calls it."""
+        x = _f32(x)
+        one = x.ndim == 1
+        x2 = np.ascontiguousarray(x[None] if one else x)
+        if x2.ndim != 2 or x2.shape[1] < 1:
+            raise ValueError(f"resample_sinc expects [channels, n], got {x.shape}")
+        n_out = int(np.ceil(x2.shape[1] * float(ratio)))
+        y = np.empty((x2.shape[0], n_out), np.float32)
+        self._check(self._lib.asx_resample_sinc(self._h, _ptr(x2), x2.shape[0], x2.shape[1], float(ratio), int(bool(mono_calls) or one),
+                                                _ptr(y), n_out))
+        return y[0] if one else y
+
+    def resample_sinc_dev(self, x_ptr: int, channels: int, n_in: int, ratio: float, mono_calls: bool, y_ptr: int, n_out: int, stream: int = 0):
+        self._check(self._lib.asx_resample_sinc_dev(self._h, x_ptr, int(channels), int(n_in), float(ratio), int(bool(mono_calls)), y_ptr,
+                                                    int(n_out), stream or None))
 
     def vr_flops(self) -> float:
         return float(self._lib.asx_vr_flops(self._h))

@@ -79,7 +79,10 @@ class MDXCDemixer:
         self.batch_size = arch_config.get("batch_size", 1)
         self.pitch_shift = arch_config.get("pitch_shift", 0)
         if self.pitch_shift != 0:
-            raise NotImplementedError("pitch_shift is outside the accelerated path")
+            from .vr import reference_wav_resolution
+            if reference_wav_resolution() != "sinc_fastest":
+                # spec_utils.py:33-35: macOS on ARM resamples the pitch round trip with resampy's kaiser_best
+                raise NotImplementedError("pitch_shift on a platform where the reference uses resampy (kaiser_best)")
         audio, model, training = (self.model_data.get(k, {}) for k in ("audio", "model", "training"))
         # CommonSeparator._detect_roformer_model (common_separator.py:521-543): the flag, or "roformer" in the path / name
         self.is_roformer = bool(self.model_data.get("is_roformer")) or any(
@@ -169,6 +172,8 @@ class MDXCDemixer:
             raise ValueError(f"Expected a 2-channel audio signal, but got {mix.shape[0] if mix.ndim else 0} channels")
         if mix.shape[1] == 0:
             raise ValueError("Audio file is empty or not valid")
+        if self.pitch_shift != 0:
+            return self._demix_pitched(mix)
         if self.is_roformer:
             return self._demix_roformer(mix)
         out = self.engine.mdxc_demix(mix, int(self.overlap))
@@ -177,6 +182,43 @@ class MDXCDemixer:
         primary = out[0]
         if self.is_primary_stem_main_target:
             return {self.primary_stem_name: primary, self.secondary_stem_name: mix - primary}
+        return primary
+
+    # ---- pitch_shift (mdxc_separator.py:230-243, 268-270, 417-419, 450-466) -----------------------------------------------------
+    def change_pitch_semitones(self, y: np.ndarray, sr, semitone_shift):
+        """spec_utils.change_pitch_semitones (:783-790): every channel through librosa.resample(res_type="sinc_fastest") to
+        sr * 2^(shift / 12) -- on the device (asx_resample_sinc, one mono libsamplerate call per channel)."""
+        factor = 2 ** (semitone_shift / 12)
+        target = sr * factor
+        return self.engine.resample_sinc(np.ascontiguousarray(y, np.float32), float(target) / sr, mono_calls=True), target
+
+    def pitch_fix(self, source, sr_pitched, orig_mix):
+        source = self.change_pitch_semitones(source, sr_pitched, self.pitch_shift)[0]
+        n = orig_mix.shape[1]                                    # spec_utils.match_array_shapes (:752-769)
+        if source.shape[1] > n:
+            return source[:, :n]
+        if source.shape[1] < n:
+            return np.pad(source, ((0, 0), (0, n - source.shape[1])), "constant", constant_values=0)
+        return source
+
+    def _demix_pitched(self, orig_mix: np.ndarray):
+        """demix with pitch_shift != 0: the mix is resampled to sr * 2^(-p / 12), separated, and every stem resampled back by
+        2^(p / 12) and padded / trimmed to the mix's length; the residual stem is taken against the ORIGINAL mix."""
+        mix, sr_pitched = self.change_pitch_semitones(orig_mix, self.sample_rate, -self.pitch_shift)
+        if self.is_roformer:
+            chunk_size = self.engine.cfg.hop_length * (self.mdx_segment_size - 1)
+            desired_step = int(self.overlap * self.sample_rate)
+            step = chunk_size if desired_step <= 0 else min(desired_step, chunk_size)
+            out = self.engine.rof_demix(mix, step)
+            num_stems = 1 if self.target_instrument else len(self.instruments)
+        else:
+            out = self.engine.mdxc_demix(mix, int(self.overlap))
+            num_stems = self.v3.num_targets
+        if num_stems > 1:
+            return {k: self.pitch_fix(out[i], sr_pitched, orig_mix) for i, k in enumerate(self.instruments)}
+        primary = self.pitch_fix(out[0], sr_pitched, orig_mix)
+        if self.is_primary_stem_main_target:
+            return {self.primary_stem_name: primary, self.secondary_stem_name: orig_mix - primary}
         return primary
 
     def demix_dev(self, mix_d):

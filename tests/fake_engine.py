@@ -170,6 +170,15 @@ class OracleEngine:
                              high_end_process=high_end_process, wav_resolution=self._vr_res)
         return np.asarray(p, np.float32).T, np.asarray(s, np.float32).T
 
+    def resample_sinc(self, x, ratio, mono_calls=False):
+        x = np.asarray(x, np.float32)
+        one = x.ndim == 1
+        x2 = x[None] if one else x
+        y = V.src_simple_sinc_fastest(x2, float(ratio), mono=bool(mono_calls) or one)
+        n_out = int(np.ceil(x2.shape[1] * float(ratio)))
+        y = np.pad(y, ((0, 0), (0, n_out - y.shape[1])))
+        return y[0] if one else y
+
     def vr_forward(self, x):
         mp, arch, sd, win, off = self._vr
         return np.asarray(V.cascaded_forward(_t(x), sd, arch, mp.param["bins"] * 2))

@@ -34,9 +34,9 @@ def g(golden_dir):
     return np.load(os.path.join(golden_dir, "mdxc_small.npz"))
 
 
-def demixer(A, cfg, seed, overlap, seg=None, max_batch=0):
+def demixer(A, cfg, seed, overlap, seg=None, max_batch=0, pitch_shift=0):
     md = cfg.as_model_data()
-    arch = {"overlap": overlap, "batch_size": 2}
+    arch = {"overlap": overlap, "batch_size": 2, "pitch_shift": pitch_shift}
     if seg is not None:
         arch.update(segment_size=seg, override_model_segment_size=True)
     return A.MDXCDemixer({"model_data": md, "torch_device": 0, "secondary_stem_name": "Instrumental"}, arch,
@@ -105,6 +105,21 @@ def test_mdx23c_shape_excerpt_vs_oracle(A):
     with open(os.path.join(os.path.dirname(__file__), "golden", "flops.json")) as fh:
         want = json.load(fh)["mdx23c_excerpt"]
     assert abs(dm.engine.v3_flops(1) - want) <= 1e-9 * want, (dm.engine.v3_flops(1), want)
+
+
+@pytest.mark.parametrize("semis", [2, -3])
+def test_pitch_shift_round_trip_vs_oracle(A, semis):
+    """mdxc_separator.py:230-243, 268-270, 417-419: the mix resampled to sr * 2^(-p / 12) (libsamplerate sinc_fastest, channel by
+    channel), separated, every stem resampled back and padded / trimmed to the mix's length"""
+    mix = (0.4 * np.random.default_rng(21).standard_normal((2, 5000))).astype(np.float32)
+    d = demixer(A, CFG2, 5, 4, pitch_shift=semis)
+    out = d.demix(mix)
+    got = np.stack([out[k] for k in CFG2.instruments])
+    ref = M.mdxc_demix_pitched(mix, M.make_v3_state(CFG2, 5), CFG2, overlap=4, pitch_shift=semis)
+    assert got.shape == ref.shape == (len(CFG2.instruments), 2, 5000)
+    assert rel_rms(got, ref) < TOL, rel_rms(got, ref)
+    plain = np.stack(list(demixer(A, CFG2, 5, 4).demix(mix).values()))
+    assert rel_rms(got, plain) > 1e-3          # and it really is a different computation
 
 
 def test_batching_is_invisible(A):

@@ -177,7 +177,12 @@ def test_foreign_array_still_takes_the_upload_path(tmp_path):
     inst = SC.plugin_class(cls)(common_config=common, arch_config=arch)
     inst.separate(wav, None)
     foreign = np.array(inst.primary_source, copy=True) * np.float32(0.5)
-    assert inst._device_stem_for(foreign) is None and inst._device_stem_for(inst.primary_source) is not None
+    #  a written stem's device tensor and pinned mirror are released with its registry entry, and the mirror that
+    # stays in ``primary_source`` is read-only: an in-place edit raises instead of being silently ignored by a later write_audio
+    assert inst._device_stem_for(foreign) is None and inst._device_stem_for(inst.primary_source) is None
+    assert not inst.primary_source.flags.writeable
+    with pytest.raises(ValueError):
+        inst.primary_source[0, 0] = 1.0
     inst.write_audio("foreign.wav", foreign)
     pcm, _ = audio_io.read_wav(os.path.join(common["output_dir"], "foreign.wav"))
     want, _ = inst.engine.pcm16(foreign, 0.9, 0.0)

@@ -176,6 +176,28 @@ def test_v51_sinc_vs_oracle(A, g):
     assert rel_rms(s, ws) < TOL, rel_rms(s, ws)
 
 
+@pytest.mark.parametrize("ratio", [2.0, 3.0, 16 / 3, 4.0, 8.0, 0.25, 0.1875, 0.125, 2 ** (2 / 12), 2 ** (-3 / 12), 44100 / 32000])
+@pytest.mark.parametrize("mono", [False, True])
+def test_resample_sinc_hook_vs_oracle(A, ratio, mono):
+    """asx_resample_sinc -- the converter itself, outside the VR chain -- against the restated libsamplerate algorithm: rational
+    up / down ratios of the shipped band layouts, the irrational ratios of the pitch-shift round trip, one stereo call or one
+    call per channel (the library's end-of-input test drops the last frame of a mono call when n * ratio is an integer)"""
+    eng = A.Engine(A.MDXConfig(n_fft=96, hop_length=16, dim_f=32, segment_size=16))
+    rng = np.random.default_rng(3)
+    for n in (1, 37, 4096, 30011):
+        x = rng.standard_normal((2, n)).astype(np.float32)
+        got = eng.resample_sinc(x, ratio, mono_calls=mono)
+        ref = V.src_simple_sinc_fastest(x, float(ratio), mono=mono)
+        n_out = int(np.ceil(n * float(ratio)))
+        assert got.shape == (2, n_out)
+        ref = np.pad(ref, ((0, 0), (0, n_out - ref.shape[1])))
+        if ref.size and np.abs(ref).max() > 0:
+            assert rel_rms(got, ref) < 2e-6, (n, rel_rms(got, ref))
+        else:
+            assert not got.any()
+    eng.close()
+
+
 def test_error_paths(A):
     dm = demixer(A)
     with pytest.raises(ValueError):
