@@ -103,6 +103,11 @@ def parse_args(argv=None):
     ap.add_argument("--file-level", type=int, default=1, help="1: time Separator-level separate(wav) -> stem files after the timed region (N = 1 only)")
     ap.add_argument("--no-overlap", action="store_true", help="blocking gather (A/B of the gather / compute overlap)")
     ap.add_argument("--config5", action="store_true", help="BASELINE config 5 preset: --mode files --songs-per-rank 8 (64 songs on 8 GPUs)")
+    ap.add_argument("--traffic", choices=("live", "stored"), default="live",
+                    help="roofline.traffic: 'live' = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a one-song child of this "
+                         "script, inside this run (N = 1 only; falls back to 'stored' when rocprofv3 is missing or fails); "
+                         "'stored' = the ratio kept under profiles/")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-gloo", action="store_true")
     ap.add_argument("--master-port", type=int, default=0)
     args = ap.parse_args(argv)
@@ -128,8 +133,69 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def pmc_child(args):
+    """What the live-traffic passes profile: one warm-up and one measured demix of the bench song, nothing else."""
+    import torch
+    from oracle import mdx_oracle as O
+    import audio_separator_amd as A
+    d = O.NetDims()
+    sd = O.make_convtdf_state(d, seed=0)
+    eng = A.Engine(A.MDXConfig(max_batch=args.max_batch), device=0)
+    eng.load_net(A.NetConfig(), A.fold_convtdf_state(sd, d.num_blocks, d.l))
+    N = int(SR * args.seconds)
+    mix = torch.from_numpy(O.synth_mix(N, seed=0)).to("cuda:0")
+    out = torch.empty_like(mix)
+    for _ in range(2):
+        eng.demix_dev(mix.data_ptr(), N, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    eng.close()
+
+
+def live_traffic(args, kernel_substr):
+    """HBM bytes per launch of the dominant kernel, measured in THIS run: rocprofv3 --kernel-trace --pmc <counter> around a
+    one-song child of this script, one counter per pass (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass),
+    FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads), both in KiB.  -> (bytes per launch, launches seen, note)
+    or (None, 0, why)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, 0, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="asx_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--seconds", str(args.seconds), "--max-batch", str(args.max_batch)]
+            env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            tot, cnt = 0.0, 0
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                            tot += float(row["Counter_Value"])
+                            cnt += 1
+            if cnt == 0:
+                return None, 0, f"rocprofv3 pass {ctr}: rc {r.returncode}, no dispatch of {kernel_substr} in its output ({r.stderr.decode(errors='replace')[-200:]!r})"
+            vals[ctr] = (tot / cnt, cnt)
+    except Exception as e:                       # never take the headline line down
+        return None, 0, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
+    return fetch + write, vals["FETCH_SIZE"][1], (f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) around a one-song child of "
+                                                   f"bench.py inside this run, {vals['FETCH_SIZE'][1]} dispatches averaged; FETCH_SIZE x 2 per the gfx950 note "
+                                                   f"of MI355X_MICROARCH.md (fetch {fetch / 1e9:.3f} GB + write {write / 1e9:.3f} GB per launch)")
+
+
 def main():
     args = parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ:
@@ -282,6 +348,14 @@ def main():
         # The direct-convolution (algorithmic) rate -- SURVEY 8d's per-unit figure over the same launch time -- is kept
         # under `algorithmic`; it can exceed the peak and is NOT a roofline fraction.
         exf = (4.0 / 9.0) if wino else 1.0
+        if world == 1 and args.traffic == "live":
+            eng_free = True
+            live, nlaunch, why = live_traffic(args, "conv_wino3_kernel" if wino else "conv_dma_kernel<asx::ConvDmaCfg<3, 3, 1, 1")
+            if live is not None:
+                traffic, source = round(live, 1), why
+            else:
+                source = (source or "") + f" [live measurement unavailable: {why}]"
+            del eng_free
         roofline = {"kernel": ("conv_wino3_kernel (TFC 3x3 convs, Winograd F(2x2,3x3) on fp32 MFMA)" if wino
                                else "conv_dma_kernel<3,3,1,1,3,4,2,0> (TFC 3x3 convs)"),
                     "bound": "mfma", "achieved": round(ach * exf, 2),
