@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 SR = 44100
 SONG_SECONDS = 240
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the row GEMMs run six bf16 products per fp32 multiply-add)
 METRIC = "audio-sec separated / wall-sec (RTF), UVR-MDX-NET 44.1kHz stereo, 1/2/4/8 GPU"
 PMC_FILES = ("r03_pmc_conv3x3.json", "r02_pmc_conv3x3.json", "r01_pmc_conv3x3.json")
 PMC_FILES_WINO = ("r03_pmc_wino3.json",)
@@ -431,6 +432,13 @@ def main():
                     if k == "conv3x3" and eng.option("winograd") > 0:   # executed MFMA rate (4/9 of the algorithmic one, see roofline)
                         stages[k] = {"bound": "mfma", "achieved": round(tf * 4.0 / 9.0, 2), "unit": "TFLOP/s",
                                      "frac": round(tf * 4.0 / 9.0 / PEAK_FP32_MFMA_TFLOPS, 4), "algorithmic_achieved": round(tf, 2)}
+                    elif k == "tdf" and eng.option("gemm_bf16x6") > 0:
+                        # csrc/kernels_gemm3.h: six bf16 MFMA products per fp32 multiply-add on exactly split operands.  achieved /
+                        # frac = EXECUTED bf16 FLOPs (6 x the GEMM's) against the dense bf16 peak; fp32_equivalent = the GEMM's own
+                        # FLOPs over the same time (what the fp32-MFMA kernel would have to reach: its peak is 157.3)
+                        stages[k] = {"bound": "mfma", "achieved": round(tf * 6.0, 1), "unit": "TFLOP/s", "peak": PEAK_BF16_MFMA_TFLOPS,
+                                     "frac": round(tf * 6.0 / PEAK_BF16_MFMA_TFLOPS, 4), "dtype": "bf16 x 6 products (fp32-exact split operands)",
+                                     "fp32_equivalent": round(tf, 2), "fp32_equivalent_over_fp32_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
                     else:
                         stages[k] = {"bound": "mfma", "achieved": round(tf, 2), "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
                 else:

@@ -475,7 +475,8 @@ int asx_ensemble_dev(asx_engine *e, const float *waves_dev, int32_t k, int64_t n
                      float *out_dev, int64_t *n_out, void *stream);
 int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host, int64_t n_samples, float *out_host, int64_t *n_out);
 
-/* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host. */
+/* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host; "counter.tdf3_launches" writes the
+ * number of bf16x6 row-GEMM launches of this process into host[0]. */
 int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel);
 /* measurement hook: the s_memtime timeline the ASX_TDF2_ABL=16 build of the row GEMM records (8 x uint64 per workgroup). */
 int asx_debug_trace(uint64_t *host, int64_t n_u64);
@@ -512,7 +513,12 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
  * 0 = the direct MFMA kernel; 1 / 2 = earlier Winograd generations kept for A/B measurements.
  * "winograd_stationary": 1 (also ASX_WINOS) = layers with at most 96 input channels run the weight-stationary form of the same
  * transform (csrc/kernels_winos.h: the transformed weights stay in registers, positions split over eight waves) when "winograd"
- * is 3; 0 (default: the stationary form measured slower, profiles/NOTES.md) = conv_wino3_kernel for every layer. */
+ * is 3; 0 (default: the stationary form measured slower, profiles/NOTES.md) = conv_wino3_kernel for every layer.
+ * "gemm_bf16x6" (PROCESS-wide; also ASX_GEMM_BF16X6 in the environment): 1 (default) = every row GEMM whose shape allows it
+ * (K % 64 == 0, N > 64, N % 8 == 0, 16-byte aligned rows) runs csrc/kernels_gemm3.h -- both fp32 operands split EXACTLY into three
+ * bf16 parts, six bf16 MFMA products with fp32 accumulation, the dropped cross terms below 2^-24 of a product: fp32-grade results
+ * (closer to a float64 GEMM than the fp32-MFMA kernel on every measured shape) at 1.7-1.9x its speed; 0 = the fp32-MFMA kernels
+ * (csrc/kernels_gemm2.h) everywhere. */
 int asx_set_option(asx_engine *e, const char *key, int32_t value);
 
 /* ---- profiling ---------------------------------------------------------- */

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -25,6 +26,7 @@
 #include "kernels_fft3.h"
 #include "kernels_net.h"
 #include "kernels_gemm2.h"
+#include "kernels_gemm3.h"
 #include "kernels_wino.h"
 #include "kernels_winos.h"
 #ifndef ASX_TDF2_DEFAULT
@@ -805,10 +807,92 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
   launch_tdf2_abl<NREP, MREP, 0>(a, s);
 }
 
+// ---- third-generation row GEMM (kernels_gemm3.h): fp32 results from six bf16 MFMA products on exactly split operands ----------
+// Process-wide switch: ASX_GEMM_BF16X6 (default 1) or asx_set_option(e, "gemm_bf16x6", n); 0 = the fp32-MFMA kernels only.
+static std::atomic<int> g_gemm_bf16x6{getenv("ASX_GEMM_BF16X6") ? atoi(getenv("ASX_GEMM_BF16X6")) : 1};
+// launches of tdf3_kernel since the process started (tests assert that the path under test is the one that ran)
+static std::atomic<long long> g_tdf3_launches{0};
+
+// The split image of a weight matrix is built on first use and cached by (pointer, N, K).  Every entry point that uploads or frees
+// weights bumps the epoch (w3_epoch_bump), which flushes the whole cache at the next lookup -- an address reused by another
+// tensor of the same shape can therefore never meet a stale image.
+struct W3Entry {
+  const float *w;
+  int N, K;
+  void *img;
+};
+static std::mutex g_w3_mu;
+static std::vector<W3Entry> g_w3;
+static std::atomic<uint64_t> g_w3_epoch{1};
+static uint64_t g_w3_cache_epoch = 0;
+static void w3_epoch_bump() { g_w3_epoch.fetch_add(1); }
+
+static const u32x4 *w3_image(const float *w, int N, int K, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_w3_mu);
+  const uint64_t ep = g_w3_epoch.load();
+  if (ep != g_w3_cache_epoch) {
+    for (auto &en : g_w3) (void)hipFree(en.img);
+    g_w3.clear();
+    g_w3_cache_epoch = ep;
+  }
+  for (auto &en : g_w3)
+    if (en.w == w && en.N == N && en.K == K) return reinterpret_cast<const u32x4 *>(en.img);
+  const int ntiles = (N + 15) / 16, nk = K / 32;
+  W3Entry en{w, N, K, nullptr};
+  if (hipMalloc(&en.img, (size_t)ntiles * nk * 3 * 1024) != hipSuccess) return nullptr;
+  const int64_t total = (int64_t)ntiles * nk * 64;
+  hipLaunchKernelGGL(w3_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<u32x4 *>(en.img), N, K,
+                     total);
+  // built once per weight tensor: make the image visible to every stream before it is published
+  if (hipStreamSynchronize(s) != hipSuccess) {
+    (void)hipFree(en.img);
+    return nullptr;
+  }
+  g_w3.push_back(en);
+  return reinterpret_cast<const u32x4 *>(en.img);
+}
+
+static bool tdf3_ok(const TdfDmaArgs &d) {
+  auto a16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int64_t lda = d.lda ? d.lda : d.K, ldy = d.ldy ? d.ldy : d.N, ldr = d.ldr ? d.ldr : d.N;
+  if (d.relu == 1 && (d.rscale != nullptr || d.rot_tab != nullptr)) return false;   // as tdf2_ok: the ReLU ring epilogue applies neither
+  return g_gemm_bf16x6.load() > 0 && d.K % 64 == 0 && d.K >= 64 && d.M >= 1 && d.M < (1ll << 31) && d.T > 0 && d.C > 0 && d.N % 8 == 0 &&
+         d.N > 64 && lda % 4 == 0 && ldy % 4 == 0 && ldr % 4 == 0 && a16(d.x) && a16(d.w) && a16(d.y) && (!d.res || a16(d.res)) &&
+         (!d.bias || a16(d.bias)) && (uint64_t)16 * (uint64_t)ldy * 4 < (1ull << 31) && (uint64_t)16 * (uint64_t)ldr * 4 < (1ull << 31);
+}
+template <int NREP, int MREP, int ABL>
+static void launch_tdf3_abl(const TdfDmaArgs &a, const u32x4 *w3, hipStream_t s) {
+  constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = 2 * 3 * BM * 64;
+  const int64_t nbm = (a.M + BM - 1) / BM;
+  const int nbn = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3);
+  g_tdf3_launches.fetch_add(1);
+}
+template <int NREP, int MREP>
+static bool launch_tdf3(const TdfDmaArgs &a, hipStream_t s) {
+  const u32x4 *w3 = w3_image(a.w, a.N, a.K, s);
+  if (!w3) return false;                               // out of memory for the image: the caller falls back to the fp32 kernels
+  static const int abl = getenv("ASX_TDF3_ABL") ? atoi(getenv("ASX_TDF3_ABL")) : 0;   // ablation builds exist for the 128 x 192 tile only
+  if constexpr (NREP == 3 && MREP == 8) {
+    switch (abl) {
+      case 1: launch_tdf3_abl<3, 8, 1>(a, w3, s); return true;
+      case 2: launch_tdf3_abl<3, 8, 2>(a, w3, s); return true;
+      case 4: launch_tdf3_abl<3, 8, 4>(a, w3, s); return true;
+      case 8: launch_tdf3_abl<3, 8, 8>(a, w3, s); return true;
+      case 13: launch_tdf3_abl<3, 8, 13>(a, w3, s); return true;
+      default: break;
+    }
+  }
+  launch_tdf3_abl<NREP, MREP, 0>(a, w3, s);
+  return true;
+}
+
 static void launch_tdf_dma_auto(const TdfDmaArgs &d, hipStream_t s) {
   static const int t128 = getenv("ASX_GEMM_T128") ? atoi(getenv("ASX_GEMM_T128")) : 1;
   const bool v2 = tdf2_ok(d);
   static const int small = getenv("ASX_TDF2_SMALL") ? atoi(getenv("ASX_TDF2_SMALL")) : 0;   // A/B: 64 x 128 tiles (3+ workgroups per CU) on short-K layers
+  const bool v3 = tdf3_ok(d);
+  if (v3 && ((small && d.K <= small) || d.prefer_small) && d.N > 128 && launch_tdf3<2, 4>(d, s)) return;
   if (v2 && ((small && d.K <= small) || d.prefer_small) && d.N > 128) return launch_tdf2<2, 4>(d, s);
   if (d.N > 128) {
     const double rows = (double)((d.M + 127) / 128);
@@ -817,9 +901,11 @@ static void launch_tdf_dma_auto(const TdfDmaArgs &d, hipStream_t s) {
       return ceil(blocks / 512.0) * bn / eff;
     };
     const bool narrow = t128 == 2 || (t128 == 1 && cost(128, 0.96) < cost(192, 1.0));
+    if (v3 && (narrow ? launch_tdf3<2, 8>(d, s) : launch_tdf3<3, 8>(d, s))) return;
     if (narrow) v2 ? launch_tdf2<2, 8>(d, s) : launch_tdf_dma_t<2, 8>(d, s);
     else v2 ? launch_tdf2<3, 8>(d, s) : launch_tdf_dma_t<3, 8>(d, s);
   } else if (d.N > 64) {
+    if (v3 && launch_tdf3<2, 4>(d, s)) return;
     v2 ? launch_tdf2<2, 4>(d, s) : launch_tdf_dma_t<2, 4>(d, s);
   } else {
     launch_tdf_dma_t<1, 4>(d, s);
@@ -876,6 +962,7 @@ static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const fl
 
 static int tdf_pack(TdfLayer &L, int n, int k, int c, const float *w, const float *bias, const float *scale,
                     const float *shift) {
+  w3_epoch_bump();
   L.n = n;
   L.k = k;
   L.c = c;
@@ -1257,6 +1344,7 @@ static void free_block(Block &b) {
 }
 
 void asx_engine_destroy(asx_engine *e) {
+  w3_epoch_bump();
   if (!e) return;
   (void)hipSetDevice(e->device);
   for (auto &r : e->recs) {
@@ -1303,6 +1391,7 @@ void asx_engine_destroy(asx_engine *e) {
 
 // ---- weights ---------------------------------------------------------------
 int asx_net_begin(asx_engine *e, const asx_net_config *cfg) {
+  w3_epoch_bump();
   REQUIRE(e && cfg, "asx_net_begin: null argument");
   REQUIRE(cfg->dim_f == e->cfg.dim_f, "net dim_f %d != engine dim_f %d", cfg->dim_f, e->cfg.dim_f);
   REQUIRE(cfg->dim_t == e->cfg.segment_size, "net dim_t %d != segment_size %d", cfg->dim_t, e->cfg.segment_size);
@@ -1377,6 +1466,7 @@ static int build_block(asx_engine *e, Block &blk, const std::string &pre, int c,
 }
 
 int asx_net_commit(asx_engine *e) {
+  w3_epoch_bump();
   REQUIRE(e, "asx_net_commit: null engine");
   if (!e->net_begun) {
     set_err("asx_net_commit before asx_net_begin");
@@ -2051,6 +2141,7 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t B, int32_t c, int32_t
 
 // ---- MDXC / TFC-TDF v3 --------------------------------------------------------------
 int asx_v3_begin(asx_engine *e, const asx_v3_config *cfg) {
+  w3_epoch_bump();
   REQUIRE(e && cfg, "asx_v3_begin: null argument");
   REQUIRE(cfg->num_channels == 2, "only stereo (num_channels = 2) is supported");
   REQUIRE(cfg->num_subbands >= 1 && e->cfg.dim_f % cfg->num_subbands == 0, "dim_f must be divisible by num_subbands");
@@ -2074,6 +2165,7 @@ int asx_v3_begin(asx_engine *e, const asx_v3_config *cfg) {
 }
 
 int asx_v3_commit(asx_engine *e) {
+  w3_epoch_bump();
   REQUIRE(e, "asx_v3_commit: null engine");
   if (!e->v3 || !e->v3->begun) {
     set_err("asx_v3_commit before asx_v3_begin");
@@ -2242,6 +2334,7 @@ int asx_mdxc_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t over
 
 // ---- BS-Roformer ------------------------------------------------------------------
 int asx_rof_begin(asx_engine *e, const asx_rof_config *cfg) {
+  w3_epoch_bump();
   REQUIRE(e && cfg, "asx_rof_begin: null argument");
   REQUIRE(cfg->dim_head == 64, "dim_head must be 64 (got %d)", cfg->dim_head);
   REQUIRE(cfg->dim > 0 && cfg->dim % 4 == 0 && cfg->depth >= 1 && cfg->heads >= 1 && cfg->num_stems >= 1 &&
@@ -2288,6 +2381,7 @@ int asx_rof_begin(asx_engine *e, const asx_rof_config *cfg) {
 }
 
 int asx_rof_commit(asx_engine *e) {
+  w3_epoch_bump();
   REQUIRE(e, "asx_rof_commit: null engine");
   if (!e->rof || !e->rof->begun) {
     set_err("asx_rof_commit before asx_rof_begin");
@@ -2520,6 +2614,7 @@ int asx_rof_demix(asx_engine *e, const float *mix_host, int64_t N, int64_t step,
 // ---- options -----------------------------------------------------------------------
 // ---- Demucs v4 ---------------------------------------------------------------------
 int asx_ht_begin(asx_engine *e, const asx_ht_config *cfg) {
+  w3_epoch_bump();
   REQUIRE(e && cfg, "asx_ht_begin: null argument");
   REQUIRE(cfg->n_sources >= 1 && cfg->channels >= 4 && cfg->growth >= 1 && cfg->depth >= 1 && cfg->depth <= 8,
           "bad HTDemucs hyper-parameters");
@@ -2543,6 +2638,7 @@ int asx_ht_begin(asx_engine *e, const asx_ht_config *cfg) {
 }
 
 int asx_ht_commit(asx_engine *e) {
+  w3_epoch_bump();
   REQUIRE(e, "asx_ht_commit: null engine");
   if (!e->ht || !e->ht->begun) {
     set_err("asx_ht_commit before asx_ht_begin");
@@ -2653,6 +2749,7 @@ int asx_ht_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t shifts
 
 // ---- Demucs v3 (HDemucs) -------------------------------------------------------------
 int asx_hd_begin(asx_engine *e, const asx_hd_config *cfg) {
+  w3_epoch_bump();
   REQUIRE(e && cfg, "asx_hd_begin: null argument");
   REQUIRE(cfg->n_sources >= 1 && cfg->channels >= 4 && cfg->growth >= 1 && cfg->depth >= 3 && cfg->depth <= 8, "bad HDemucs hyper-parameters");
   REQUIRE(cfg->kernel_size == 8 && cfg->stride == 4 && cfg->time_stride == 2,
@@ -2692,6 +2789,7 @@ int asx_hd_begin(asx_engine *e, const asx_hd_config *cfg) {
 }
 
 int asx_hd_commit(asx_engine *e) {
+  w3_epoch_bump();
   REQUIRE(e, "asx_hd_commit: null engine");
   if (!e->hd || !e->hd->begun) {
     set_err("asx_hd_commit before asx_hd_begin");
@@ -2785,6 +2883,7 @@ int asx_hd_fold_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t shif
 
 // ---- VR ------------------------------------------------------------------------------
 int asx_vr_begin(asx_engine *e, const asx_vr_config *cfg) {
+  w3_epoch_bump();
   REQUIRE(e && cfg, "asx_vr_begin: null argument");
   REQUIRE(cfg->n_bands >= 1 && cfg->n_bands <= 8 && cfg->bins >= 32, "bad band layout");
   REQUIRE(cfg->channel_mode >= 0 && cfg->channel_mode <= 3, "bad channel_mode");
@@ -2803,6 +2902,7 @@ int asx_vr_begin(asx_engine *e, const asx_vr_config *cfg) {
 }
 
 int asx_vr_commit(asx_engine *e) {
+  w3_epoch_bump();
   REQUIRE(e, "asx_vr_commit: null engine");
   if (!e->vr || !e->vr->begun) {
     set_err("asx_vr_commit before asx_vr_begin");
@@ -2914,6 +3014,10 @@ int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel)
   HIPCHK(hipSetDevice(e->device));
   const float *src = nullptr;
   const std::string nm(name);
+  if (nm == "counter.tdf3_launches") {                 // launches of the bf16x6 row GEMM since the process started (as a float)
+    host[0] = (float)g_tdf3_launches.load();
+    return ASX_OK;
+  }
   if (e->vr && e->vr->ws_batch > 0) {
     auto &b = e->vr->b;
     if (nm == "vr.hc") src = b.hc;
@@ -3052,6 +3156,10 @@ int asx_set_option(asx_engine *e, const char *key, int32_t value) {
   }
   if (!strcmp(key, "winograd_stationary")) {
     e->winos = value < 0 ? 0 : (int)value;
+    return ASX_OK;
+  }
+  if (!strcmp(key, "gemm_bf16x6")) {                 // process-wide (every engine of this process)
+    g_gemm_bf16x6.store(value > 0 ? 1 : 0);
     return ASX_OK;
   }
   set_err("asx_set_option: unknown option '%s'", key);

@@ -1,0 +1,388 @@
+// Row GEMM  y[M,N] = act(scale * (x[M,K] . W[N,K]^T + bias) + shift) (+ res), third generation: fp32 results from the bf16
+// matrix pipe.  Replaces tdf2_kernel (kernels_gemm2.h) on the TDF blocks of ConvTDFNet (uvr_lib_v5/modules.py:57-74) and on every
+// nn.Linear of the sibling nets whenever the launcher's preconditions hold (asx.hip: tdf3_ok).
+//
+// Arithmetic.  gfx950 has no TF32 and its fp32 MFMA runs at 1/16 of the bf16 rate.  Every fp32 operand is therefore written as an
+// EXACT sum of three bf16 numbers, v = h + m + l (h = RNE_bf16(v), m = RNE_bf16(v - h), l = v - h - m: 8 + 8 + 8 significand bits,
+// the two subtractions are exact in fp32 and l is representable, so nothing is lost), and a product of two operands as
+//     w x  =  wh xh + (wh xm + wm xh) + (wm xm + wh xl + wl xh)   +   [wm xl + wl xm + wl xl  <= 2^-24 |w x|, dropped]
+// -- six bf16 MFMAs (`v_mfma_f32_16x16x32_bf16`, products exact, fp32 accumulation) instead of eight fp32 MFMAs per 32-deep k
+// step, at 1/16 of the cycles each: 2.67x the fp32 matrix peak for a per-product error of one fp32 rounding.  The dropped terms
+// are of the size of the rounding an fp32 FMA chain commits on every product anyway; measured against a float64 GEMM the kernel
+// is as close as the fp32-MFMA kernel it replaces (tests/test_gpu_parity.py::test_rowgemm_bf16x6_*).
+//
+// Dataflow per workgroup (4 waves, tile BM = 16 MREP rows x BN = 64 NREP columns, k step 32):
+//   * W is split ONCE per weight tensor (w3_split_kernel) into an image in MFMA-fragment order, [n / 16][k / 32][part][lane][8 bf16]:
+//     a wave reads the fragments of ITS 16 NREP columns straight from L2 into registers with one fully coalesced 1-KiB
+//     `global_load_dwordx4` per fragment, a stage ahead -- no LDS space, no LDS reads and no barrier for the weight operand;
+//   * x arrives as fp32 rows (one 128-byte line per row and stage), a stage ahead in registers; each element is split once
+//     per workgroup (5.5 VALU instructions) and written to LDS as three bf16 images [part][row][4 chunks of 8 k], the chunk index
+//     XOR-ed with (row >> 2) & 3 so that both the 16-byte writes and the `ds_read_b128` fragment reads are conflict-free;
+//   * LDS holds only the x parts: 2 x 3 x BM x 64 bytes = 48 KB at BM = 128 -- two workgroups (8 waves) per CU, bounded by the
+//     register file (96 accumulators + 72 for two stages of weight fragments).
+// Accumulator layout, tile -> workgroup map and epilogues are those of tdf2_kernel (the epilogue code is the same arithmetic,
+// expression for expression, so activation / residual / rotary rounding is identical between the two kernels).
+#pragma once
+#include "kernels_net.h"
+
+namespace asx {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define ASX_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// exact three-way split of two floats into packed bf16 pairs (low half = first float)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+  h = cvt_pk_bf16(x0, x1);
+  float r0 = __fsub_rn(x0, __uint_as_float(h << 16));
+  float r1 = __fsub_rn(x1, __uint_as_float(h & 0xffff0000u));
+  m = cvt_pk_bf16(r0, r1);
+  r0 = __fsub_rn(r0, __uint_as_float(m << 16));
+  r1 = __fsub_rn(r1, __uint_as_float(m & 0xffff0000u));
+  l = cvt_pk_bf16(r0, r1);
+}
+
+__device__ __forceinline__ void split3_oct(const f32x4 &a, const f32x4 &b, u32x4 &h, u32x4 &m, u32x4 &l) {
+  unsigned hh[4], mm[4], ll[4];
+  split3_pair(a.x, a.y, hh[0], mm[0], ll[0]);
+  split3_pair(a.z, a.w, hh[1], mm[1], ll[1]);
+  split3_pair(b.x, b.y, hh[2], mm[2], ll[2]);
+  split3_pair(b.z, b.w, hh[3], mm[3], ll[3]);
+  h = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+  m = (u32x4){mm[0], mm[1], mm[2], mm[3]};
+  l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+}
+
+// W[N, K] fp32 -> fragment-ordered bf16 x 3 image: img[((nt * nk + ks) * 3 + part) * 64 + lane] = 8 bf16 of row nt * 16 + (lane & 15),
+// k = ks * 32 + (lane >> 4) * 8 .. + 7; rows >= N are zero.  One thread per (nt, ks, lane).
+__global__ __launch_bounds__(256) void w3_split_kernel(const float *__restrict__ w, u32x4 *__restrict__ img, int N, int K, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int nk = K >> 5;
+  const int lane = (int)(idx & 63);
+  const int64_t f = idx >> 6;
+  const int ks = (int)(f % nk);
+  const int nt = (int)(f / nk);
+  const int n = nt * 16 + (lane & 15);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    const float *p = w + (int64_t)n * K + ks * 32 + (lane >> 4) * 8;
+    a = *reinterpret_cast<const f32x4 *>(p);
+    b = *reinterpret_cast<const f32x4 *>(p + 4);
+  }
+  u32x4 h, m, l;
+  split3_oct(a, b, h, m, l);
+  u32x4 *o = img + (f * 3) * 64 + lane;
+  o[0] = h;
+  o[64] = m;
+  o[128] = l;
+}
+
+template <int V>
+struct IntC {
+  static constexpr int value = V;
+};
+
+// ABL (ASX_TDF3_ABL, measurement-only instantiations, results are garbage): bit 0 = no x loads / split after the prologue,
+// bit 1 = no MFMA, bit 2 = no epilogue traffic, bit 3 = no weight loads after the prologue
+template <int NREP, int MREP, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 *__restrict__ w3) {
+  constexpr int BM = 16 * MREP, BN = 64 * NREP;
+  constexpr int XC = MREP / 4;                        // 8-float chunks per thread and stage (BM * 4 chunks / 256 threads)
+  constexpr int PART = BM * 64;                       // bytes of one part image
+  constexpr int BUFB = 3 * PART;                      // bytes of one stage buffer
+  static_assert(MREP % 4 == 0, "tile shape");
+  extern __shared__ float lds_f[];
+  char *lds = reinterpret_cast<char *>(lds_f);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+
+  // ---- tile -> workgroup map (kernels_gemm2.h: column tiles partitioned over the XCDs so that an XCD keeps its slice of W hot)
+  const int nbn = (a.N + BN - 1) / BN;
+  int bg;
+  int64_t bm_i;
+  {
+    const int nbm_i = (int)((a.M + BM - 1) / BM);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if ((gridDim.x & 7) == 0 && nbn >= 8 && (nbn & 7) == 0) {
+      const int cx = nbn >> 3;
+      bg = xcd * cx + slot % cx;
+      bm_i = slot / cx;
+    } else if ((gridDim.x & 7) == 0 && nbn < 8 && (8 % nbn) == 0 && nbm_i % (8 / nbn) == 0) {
+      const int r = 8 / nbn;
+      bg = xcd / r;
+      bm_i = (int64_t)slot * r + (xcd % r);
+    } else {
+      const int lid = xcd_remap(blockIdx.x, gridDim.x);
+      bg = lid % nbn;
+      bm_i = lid / nbn;
+    }
+  }
+  const int64_t m0 = bm_i * BM;
+  const int n0 = bg * BN;
+  const int64_t lda = a.lda ? a.lda : a.K, ldy = a.ldy ? a.ldy : a.N, ldr = a.ldr ? a.ldr : a.N;
+  const int nk = a.K >> 5;
+
+  // ---- weight fragments: wave-uniform base per 16-column tile + lane * 16 bytes; tiles past N are clamped (masked at the store)
+  const int ntiles = (a.N + 15) >> 4;
+  const u32x4 *wb[NREP];
+#pragma unroll
+  for (int n = 0; n < NREP; ++n) {
+    int nt = (n0 >> 4) + wave * NREP + n;
+    nt = nt < ntiles ? nt : ntiles - 1;
+    wb[n] = w3 + (int64_t)nt * nk * 192 + lane;
+  }
+  u32x4 wr[2][NREP][3];
+  auto load_w = [&](auto par, int ks) {
+    constexpr int P = decltype(par)::value;
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wr[P][n][p] = wb[n][(int64_t)ks * 192 + p * 64];
+  };
+
+  // ---- x rows: chunk q = tid + 256 i -> row q >> 2 of the tile, floats (q & 3) * 8 .. + 7 of the stage
+  const float *xp[XC];
+  int xw[XC];                                          // LDS byte offset of the chunk inside a part image
+#pragma unroll
+  for (int i = 0; i < XC; ++i) {
+    const int q = tid + 256 * i;
+    const int row = q >> 2, c = q & 3;
+    int64_t r = m0 + row;
+    r = r < a.M ? r : a.M - 1;
+    xp[i] = a.x + r * lda + c * 8;
+    xw[i] = row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+  }
+  f32x4 xr[XC][2];
+  auto load_x = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < XC; ++i) {
+      xr[i][0] = *reinterpret_cast<const f32x4 *>(xp[i] + ks * 32);
+      xr[i][1] = *reinterpret_cast<const f32x4 *>(xp[i] + ks * 32 + 4);
+    }
+  };
+  auto split_chunk = [&](int buf, int i) {             // chunk i of the stage held in xr -> the three part images of `buf`
+    char *dst = lds + buf * BUFB;
+    u32x4 h, m, l;
+    split3_oct(xr[i][0], xr[i][1], h, m, l);
+    *reinterpret_cast<u32x4 *>(dst + xw[i]) = h;
+    *reinterpret_cast<u32x4 *>(dst + PART + xw[i]) = m;
+    *reinterpret_cast<u32x4 *>(dst + 2 * PART + xw[i]) = l;
+  };
+  const int xf_off = li * 64 + ((lk ^ ((li >> 2) & 3)) << 4);   // fragment read: row 16 t + li, chunk lk
+
+  f32x4 acc[NREP][MREP];
+#pragma unroll
+  for (int n = 0; n < NREP; ++n)
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: stage 0 in LDS / registers, x of stage 1 in flight (same issue order as a steady stage: W, split, x)
+  load_x(0);
+  load_w(IntC<0>{}, 0);
+#pragma unroll
+  for (int i = 0; i < XC; ++i) split_chunk(0, i);
+  if (nk > 1) load_x(1);
+
+  // One stage.  MODE 0 (steady): fetch W of stage ks + 1, split x of stage ks + 1 (in registers since the previous stage) into the
+  // other buffer, fetch x of stage ks + 2.  MODE 1 (second last): no x fetch.  MODE 2 (last): nothing but the MFMAs.  The modes
+  // are separate code paths, not run-time conditions: a merged path made hipcc's counter pass wait for the just-issued prefetch
+  // (`s_waitcnt vmcnt(0)` in front of the first MFMA of every stage).
+  // Within a stage: fragment reads run one 16-row group ahead; the split of chunk i (44 VALU + 3 ds_write) is spread among the
+  // MFMAs of row group 1 + 3 i by a scheduling-group pattern (one MFMA, three VALU).
+  auto stage = [&](auto par, auto mode, int ks) {
+    constexpr int P = decltype(par)::value;
+    constexpr int MODE = decltype(mode)::value;
+    __syncthreads();                                   // x parts of stage ks visible; the other buffer is free
+    if constexpr (MODE < 2 && !(ABL & 8)) load_w(IntC<P ^ 1>{}, ks + 1);
+    const char *xs = lds + P * BUFB + xf_off;
+    bf16x8 xf[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) xf[0][p] = *reinterpret_cast<const bf16x8 *>(xs + p * PART);
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+      if (m + 1 < MREP) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) xf[(m + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(xs + p * PART + (m + 1) * 1024);
+      }
+#ifndef ASX_G3_NOSB
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      const bool has_split = MODE < 2 && !(ABL & 1) && (m >= 1) && ((m - 1) % 3 == 0) && ((m - 1) / 3 < XC);
+      if (has_split) split_chunk(P ^ 1, (m - 1) / 3);
+      const bf16x8 xh = xf[m & 1][0], xm = xf[m & 1][1], xl = xf[m & 1][2];
+      if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+          acc[n][m].x += (float)xh[0] + (float)xm[1] + (float)xl[2] + __uint_as_float(wr[P][n][0].x) + __uint_as_float(wr[P][n][1].y) +
+                         __uint_as_float(wr[P][n][2].z);
+        }
+      } else {
+        // smallest terms first; for a given product the NREP column tiles are independent accumulators (no back-to-back dependency)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[n][m] = ASX_MFMA_BF16(__builtin_bit_cast(bf16x8, wr[P][n][2]), xh, acc[n][m]);
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[n][m] = ASX_MFMA_BF16(__builtin_bit_cast(bf16x8, wr[P][n][0]), xl, acc[n][m]);
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[n][m] = ASX_MFMA_BF16(__builtin_bit_cast(bf16x8, wr[P][n][1]), xm, acc[n][m]);
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[n][m] = ASX_MFMA_BF16(__builtin_bit_cast(bf16x8, wr[P][n][1]), xh, acc[n][m]);
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[n][m] = ASX_MFMA_BF16(__builtin_bit_cast(bf16x8, wr[P][n][0]), xm, acc[n][m]);
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[n][m] = ASX_MFMA_BF16(__builtin_bit_cast(bf16x8, wr[P][n][0]), xh, acc[n][m]);
+      }
+#ifndef ASX_G3_NOSGB
+      if (has_split) {
+#pragma unroll
+        for (int g = 0; g < 6 * NREP; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // three VALU
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);     // the chunk's three ds_write
+      }
+#endif
+#ifndef ASX_G3_NOSB
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if constexpr (MODE == 0 && !(ABL & 1)) {
+        if (m == 1 + 3 * (XC - 1)) load_x(ks + 2);            // the registers of the chunk just split are free
+      }
+    }
+  };
+  {
+    // launcher: K % 64 == 0, i.e. an even number of stages >= 2 -- one tail sequence instead of three
+    int ks = 0;
+    for (; ks + 2 < nk; ks += 2) {
+      stage(IntC<0>{}, IntC<0>{}, ks);
+      stage(IntC<1>{}, IntC<0>{}, ks + 1);
+    }
+    stage(IntC<0>{}, IntC<1>{}, ks);
+    stage(IntC<1>{}, IntC<2>{}, ks + 1);
+  }
+
+  // ---- epilogue (the arithmetic of tdf2_kernel's three paths) ----------------------------------------------------------------
+  const bool full = (m0 + BM <= a.M) && (n0 + BN <= a.N);
+  if constexpr ((ABL & 4) != 0) {
+    float chk = 0.f;
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) chk += acc[n][m].x + acc[n][m].y + acc[n][m].z + acc[n][m].w;
+    if (chk == 1.2345e-30f) a.y[0] = chk;
+    return;
+  }
+  if (full) {
+    f32x4 bz[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+      bz[n] = (a.bias != nullptr) ? *reinterpret_cast<const f32x4 *>(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const uint32_t voff_r = (uint32_t)((li * ldr + wave * 16 * NREP + lk * 4) * 4);
+    const uint32_t voff_y = (uint32_t)((li * ldy + wave * 16 * NREP + lk * 4) * 4);
+    if (a.relu == 1) {
+      // ReLU + residual (every TDF layer of ConvTDFNet): the residual of RING 16-row groups stays in flight
+      constexpr int RING = MREP < 4 ? MREP : 4;
+      f32x4 rs[RING][NREP];
+      auto fetch = [&](int m) {
+        const char *rb = reinterpret_cast<const char *>(a.res) + ((m0 + m * 16) * ldr + n0) * 4;
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+          rs[m % RING][n] = (a.res == nullptr) ? (f32x4){0.f, 0.f, 0.f, 0.f}
+                            : ((a.nt & 2) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rb + voff_r + n * 64))
+                                          : *reinterpret_cast<const f32x4 *>(rb + voff_r + n * 64));
+      };
+#pragma unroll
+      for (int m = 0; m < RING; ++m) fetch(m);
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) {
+        const uint32_t row = (uint32_t)(m0 + m * 16 + li);
+        const int c = (int)((row / (uint32_t)a.T) % (uint32_t)a.C);
+        const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
+        char *yb = reinterpret_cast<char *>(a.y) + ((m0 + m * 16) * ldy + n0) * 4;
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+          const f32x4 v = acc[n][m];
+          const f32x4 r = rs[m % RING][n];
+          f32x4 o;
+          o.x = fmaxf(sc * (v.x + bz[n].x) + sh, 0.f) + r.x;
+          o.y = fmaxf(sc * (v.y + bz[n].y) + sh, 0.f) + r.y;
+          o.z = fmaxf(sc * (v.z + bz[n].z) + sh, 0.f) + r.z;
+          o.w = fmaxf(sc * (v.w + bz[n].w) + sh, 0.f) + r.w;
+          if (a.nt & 1) __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(yb + voff_y + n * 64));
+          else *reinterpret_cast<f32x4 *>(yb + voff_y + n * 64) = o;
+        }
+        if (m + RING < MREP) fetch(m + RING);
+      }
+    } else {
+#pragma unroll
+      for (int mg = 0; mg < MREP; mg += 2) {
+        float sc[2], sh[2], rw[2];
+        f32x4 rs[2][NREP];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const uint32_t row = (uint32_t)(m0 + (mg + m) * 16 + li);
+          const int c = (int)((row / (uint32_t)a.T) % (uint32_t)a.C);
+          sc[m] = a.scale ? a.scale[c] : 1.f;
+          sh[m] = a.shift ? a.shift[c] : 0.f;
+          rw[m] = a.rscale ? a.rscale[row] : 1.f;
+          const char *rb = reinterpret_cast<const char *>(a.res) + ((m0 + (mg + m) * 16) * ldr + n0) * 4;
+#pragma unroll
+          for (int n = 0; n < NREP; ++n)
+            rs[m][n] = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(rb + voff_r + n * 64) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          char *yb = reinterpret_cast<char *>(a.y) + ((m0 + (mg + m) * 16) * ldy + n0) * 4;
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) {
+            const f32x4 v = acc[n][mg + m];
+            f32x4 o;
+            o.x = tdf_act(sc[m] * __fmaf_rn(v.x, rw[m], bz[n].x) + sh[m], a.relu) + rs[m][n].x;
+            o.y = tdf_act(sc[m] * __fmaf_rn(v.y, rw[m], bz[n].y) + sh[m], a.relu) + rs[m][n].y;
+            o.z = tdf_act(sc[m] * __fmaf_rn(v.z, rw[m], bz[n].z) + sh[m], a.relu) + rs[m][n].z;
+            o.w = tdf_act(sc[m] * __fmaf_rn(v.w, rw[m], bz[n].w) + sh[m], a.relu) + rs[m][n].w;
+            *reinterpret_cast<f32x4 *>(yb + voff_y + n * 64) =
+                tdf_rot4(a, o, m0 + (mg + m) * 16 + li, n0 + wave * 16 * NREP + n * 16 + lk * 4);
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+      const int64_t row = m0 + m * 16 + li;
+      const bool rok = row < a.M;
+      const int c = rok ? (int)(((uint32_t)row / (uint32_t)a.T) % (uint32_t)a.C) : 0;
+      const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
+      const float rw = (rok && a.rscale) ? a.rscale[row] : 1.f;
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) {
+        const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+        const f32x4 v = acc[n][m];
+        if (!rok || col >= a.N) continue;            // N % 8 == 0 and col % 4 == 0: a float4 is inside or outside as a whole
+        const f32x4 b4 = (a.bias != nullptr) ? *reinterpret_cast<const f32x4 *>(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 r4 = (a.res != nullptr) ? *reinterpret_cast<const f32x4 *>(a.res + row * ldr + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 o;
+        o.x = tdf_act(sc * __fmaf_rn(v.x, rw, b4.x) + sh, a.relu) + r4.x;
+        o.y = tdf_act(sc * __fmaf_rn(v.y, rw, b4.y) + sh, a.relu) + r4.y;
+        o.z = tdf_act(sc * __fmaf_rn(v.z, rw, b4.z) + sh, a.relu) + r4.z;
+        o.w = tdf_act(sc * __fmaf_rn(v.w, rw, b4.w) + sh, a.relu) + r4.w;
+        *reinterpret_cast<f32x4 *>(a.y + row * ldy + col) = tdf_rot4(a, o, row, col);
+      }
+    }
+  }
+}
+
+}  // namespace asx

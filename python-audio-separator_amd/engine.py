@@ -215,6 +215,8 @@ class HDConfig:
 _FP = C.POINTER(C.c_float)
 _lib = None
 
+_PROCESS_OPTIONS_KEYS = ("gemm_bf16x6",)
+_PROCESS_OPTIONS = {}
 ABI_VERSION = 5   # ASX_ABI_VERSION of include/asx.h the structures below mirror
 
 # every symbol include/asx.h declares
@@ -436,15 +438,27 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         self._check(self._lib.asx_set_option(self._h, key.encode(), int(value)))
-        self._options[key] = int(value)
+        if key in _PROCESS_OPTIONS_KEYS:                 # process-wide switches of the library (include/asx.h)
+            _PROCESS_OPTIONS[key] = 1 if int(value) > 0 else 0
+        else:
+            self._options[key] = int(value)
 
     def option(self, key: str) -> int:
         """Current value of an engine option (the library default when it was never set here)."""
         defaults = {"winograd": max(0, int(os.environ.get("ASX_WINOGRAD", "3"))),
-                    "winograd_stationary": max(0, int(os.environ.get("ASX_WINOS", "0")))}
+                    "winograd_stationary": max(0, int(os.environ.get("ASX_WINOS", "0"))),
+                    "gemm_bf16x6": 1 if int(os.environ.get("ASX_GEMM_BF16X6", "1")) > 0 else 0}
         if key not in defaults:
             raise AsxError(f"unknown engine option {key!r} (known: {sorted(defaults)})")
+        if key in _PROCESS_OPTIONS_KEYS:
+            return _PROCESS_OPTIONS.get(key, defaults[key])
         return self._options.get(key, defaults[key])
+
+    def counter(self, name: str) -> int:
+        """A library counter (asx_debug_fetch "counter.<name>"): "tdf3_launches" = bf16x6 row-GEMM launches of this process."""
+        out = np.zeros(1, np.float32)
+        self._check(self._lib.asx_debug_fetch(self._h, ("counter." + name).encode(), _ptr(out), 1))
+        return int(out[0])
 
     # -- weights ------------------------------------------------------------
     def load_net(self, net_cfg: NetConfig, tensors: dict):

@@ -205,6 +205,61 @@ def test_tdf_layers(A, B, c, T, K, N, bias, res):
     assert max_abs(y, ref) < 3e-5, (max_abs(y, ref), rel_rms(y, ref))
 
 
+# bf16x6 row GEMM (csrc/kernels_gemm3.h): the same layer through the split-operand kernel and through the fp32-MFMA kernel, both
+# against a float64 GEMM.  The bar is "at least as close as the fp32 kernel" (a reduced-precision shortcut would fail it by 100x),
+# plus proof that the kernel under test is the one that ran (library launch counter).
+ROWGEMM_CASES = [
+    # B, c, T, K, N, res, x scale
+    (2, 48, 64, 3072, 384, False, 3.0), (2, 48, 64, 384, 3072, True, 1.0), (1, 96, 37, 1536, 192, False, 1e4),
+    (1, 3, 41, 512, 2048, True, 1e-3), (1, 1, 1000, 64, 72, True, 1.0), (3, 5, 7, 128, 200, False, 30.0),
+]
+
+
+@pytest.mark.parametrize("B,c,T,K,N,res,xs", ROWGEMM_CASES)
+def test_rowgemm_bf16x6_vs_float64(A, B, c, T, K, N, res, xs):
+    eng = A.Engine(small_cfg(A))
+    rng = np.random.default_rng(K * 11 + N)
+    x = (xs * rng.standard_normal((B, c, T, K)) * np.exp2(rng.integers(-6, 7, (B, c, T, 1)))).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    sc = (0.5 + rng.random(c)).astype(np.float32)
+    sh = (0.2 * xs * rng.standard_normal(c)).astype(np.float32)
+    r = (xs * rng.standard_normal((B, c, T, N))).astype(np.float32) if res else None
+    ref = np.maximum(sc[None, :, None, None].astype(np.float64) * (x.astype(np.float64) @ w.astype(np.float64).T)
+                     + sh[None, :, None, None], 0)
+    if res:
+        ref = ref + r
+    try:
+        eng.set_option("gemm_bf16x6", 1)
+        n0 = eng.counter("tdf3_launches")
+        y6 = eng.op_tdf(x, w, None, sc, sh, r)
+        assert eng.counter("tdf3_launches") == n0 + 1, "the bf16x6 kernel did not run"
+        y6b = eng.op_tdf(x, w, None, sc, sh, r)
+        eng.set_option("gemm_bf16x6", 0)
+        n1 = eng.counter("tdf3_launches")
+        y32 = eng.op_tdf(x, w, None, sc, sh, r)
+        assert eng.counter("tdf3_launches") == n1, "the fp32 run went through the bf16x6 kernel"
+    finally:
+        eng.set_option("gemm_bf16x6", 1)
+    assert np.isfinite(y6).all(), "unwritten (NaN canary) output elements"
+    assert np.array_equal(y6, y6b), "not deterministic"
+    e6, e32 = rel_rms(y6, ref), rel_rms(y32, ref)
+    assert e6 < 2e-6 and e6 <= 1.25 * e32 + 1e-8, (e6, e32)
+    assert np.abs(y6 - ref).max() <= 1.5 * np.abs(y32 - ref).max() + 1e-6 * np.abs(ref).max(), (np.abs(y6 - ref).max(), np.abs(y32 - ref).max())
+
+
+def test_rowgemm_bf16x6_weight_cache_follows_reloads(A):
+    """The split image is cached per weight tensor; a second layer uploaded to (possibly) the same address must not see the first's."""
+    eng = A.Engine(small_cfg(A))
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 2, 64, 128)).astype(np.float32)
+    sc, sh = np.ones(2, np.float32), np.zeros(2, np.float32)
+    for seed in range(3):
+        w = (np.random.default_rng(seed).standard_normal((128, 128)) / 11.0).astype(np.float32)
+        y = eng.op_tdf(x, w, None, sc, sh, None)
+        ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T, 0)
+        assert rel_rms(y, ref) < 1e-6, (seed, rel_rms(y, ref))
+
+
 # ---------------------------------------------------------------------------
 # whole net
 # ---------------------------------------------------------------------------
