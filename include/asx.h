@@ -515,7 +515,7 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
  * transform (csrc/kernels_winos.h: the transformed weights stay in registers, positions split over eight waves) when "winograd"
  * is 3; 0 (default: the stationary form measured slower, profiles/NOTES.md) = conv_wino3_kernel for every layer.
  * "gemm_bf16x6" (PROCESS-wide; also ASX_GEMM_BF16X6 in the environment): 1 (default) = every row GEMM whose shape allows it
- * (K % 64 == 0, N > 64, N % 8 == 0, 16-byte aligned rows) runs csrc/kernels_gemm3.h -- both fp32 operands split EXACTLY into three
+ * (K % 32 == 0, K >= 64, N > 64, N % 8 == 0, 16-byte aligned rows) runs csrc/kernels_gemm3.h -- both fp32 operands split EXACTLY into three
  * bf16 parts, six bf16 MFMA products with fp32 accumulation, the dropped cross terms below 2^-24 of a product: fp32-grade results
  * (closer to a float64 GEMM than the fp32-MFMA kernel on every measured shape) at 1.7-1.9x its speed; 0 = the fp32-MFMA kernels
  * (csrc/kernels_gemm2.h) everywhere. */

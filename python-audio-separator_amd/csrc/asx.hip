@@ -837,7 +837,7 @@ static const u32x4 *w3_image(const float *w, int N, int K, hipStream_t s) {
   }
   for (auto &en : g_w3)
     if (en.w == w && en.N == N && en.K == K) return reinterpret_cast<const u32x4 *>(en.img);
-  const int ntiles = (N + 15) / 16, nk = K / 32;
+  const int ntiles = (N + 15) / 16, nk = ((K + 63) / 64) * 2;   // the image holds an even number of 32-wide stages (zeros past K)
   W3Entry en{w, N, K, nullptr};
   if (hipMalloc(&en.img, (size_t)ntiles * nk * 3 * 1024) != hipSuccess) return nullptr;
   const int64_t total = (int64_t)ntiles * nk * 64;
@@ -856,7 +856,7 @@ static bool tdf3_ok(const TdfDmaArgs &d) {
   auto a16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const int64_t lda = d.lda ? d.lda : d.K, ldy = d.ldy ? d.ldy : d.N, ldr = d.ldr ? d.ldr : d.N;
   if (d.relu == 1 && (d.rscale != nullptr || d.rot_tab != nullptr)) return false;   // as tdf2_ok: the ReLU ring epilogue applies neither
-  return g_gemm_bf16x6.load() > 0 && d.K % 64 == 0 && d.K >= 64 && d.M >= 1 && d.M < (1ll << 31) && d.T > 0 && d.C > 0 && d.N % 8 == 0 &&
+  return g_gemm_bf16x6.load() > 0 && d.K % 32 == 0 && d.K >= 64 && d.M >= 1 && d.M < (1ll << 31) && d.T > 0 && d.C > 0 && d.N % 8 == 0 &&
          d.N > 64 && lda % 4 == 0 && ldy % 4 == 0 && ldr % 4 == 0 && a16(d.x) && a16(d.w) && a16(d.y) && (!d.res || a16(d.res)) &&
          (!d.bias || a16(d.bias)) && (uint64_t)16 * (uint64_t)ldy * 4 < (1ull << 31) && (uint64_t)16 * (uint64_t)ldr * 4 < (1ull << 31);
 }

@@ -212,6 +212,7 @@ ROWGEMM_CASES = [
     # B, c, T, K, N, res, x scale
     (2, 48, 64, 3072, 384, False, 3.0), (2, 48, 64, 384, 3072, True, 1.0), (1, 96, 37, 1536, 192, False, 1e4),
     (1, 3, 41, 512, 2048, True, 1e-3), (1, 1, 1000, 64, 72, True, 1.0), (3, 5, 7, 128, 200, False, 30.0),
+    (2, 144, 16, 96, 768, True, 1.0), (1, 2, 33, 160, 136, False, 5.0),      # odd stage counts (K = 96, 160)
 ]
 
 

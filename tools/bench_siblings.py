@@ -23,6 +23,7 @@ import audio_separator_amd as A  # noqa: E402
 
 SR = 44100
 PEAK = 157.3
+PEAK_BF16 = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 VR_MP = {"bins": 768, "unstable_bins": 7, "reduction_bins": 668, "sr": 44100, "pre_filter_start": 740, "pre_filter_stop": 768,
          "band": {1: {"sr": 11025, "hl": 128, "n_fft": 1024, "crop_start": 0, "crop_stop": 186, "lpf_start": 37, "lpf_stop": 73, "res_type": "polyphase"},
                   2: {"sr": 11025, "hl": 128, "n_fft": 512, "crop_start": 4, "crop_stop": 185, "hpf_start": 36, "hpf_stop": 18, "lpf_start": 93, "lpf_stop": 185, "res_type": "polyphase"},
@@ -66,14 +67,25 @@ def dominant(eng, step, names):
     eng.profile_enable(False)
     k, v = max(((k, v) for k, v in prof.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
     tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
-    roof = {"kernel": names.get(k, k), "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK, 4), "traffic": None, "launches": v["launches"], "share_of_step_ms": round(v["ms"], 2)}
+    # The row-GEMM class ("tdf": every nn.Linear) runs csrc/kernels_gemm3.h when the option is on: six bf16 MFMA products per fp32
+    # multiply-add on exactly split operands.  Its roofline is then the dense bf16 peak against EXECUTED work (6 x the GEMM's
+    # FLOPs; the few launches outside the kernel's preconditions run fp32 MFMA and are over-counted by this), with the GEMM's own
+    # FLOP rate kept as `fp32_equivalent`.
+    x6 = eng.option("gemm_bf16x6") > 0
+
+    def mfma_roof(cls, t):
+        if cls == "tdf" and x6:
+            return {"achieved": round(6.0 * t, 1), "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": round(6.0 * t / PEAK_BF16, 4),
+                    "dtype": "bf16 x 6 products (fp32-exact split operands)", "fp32_equivalent": round(t, 2),
+                    "fp32_equivalent_over_fp32_peak": round(t / PEAK, 4)}
+        return {"achieved": round(t, 2), "peak": PEAK, "unit": "TFLOP/s", "frac": round(t / PEAK, 4)}
+    roof = dict({"kernel": names.get(k, k), "bound": "mfma"}, **mfma_roof(k, tf))
+    roof.update({"traffic": None, "launches": v["launches"], "share_of_step_ms": round(v["ms"], 2)})
     mf = [r for r in recs if r[0] == k and r[3] > 0 and r[2] / r[3] >= 40.0]
     hb = [r for r in recs if r[0] == k and not (r[3] > 0 and r[2] / r[3] >= 40.0)]
     if mf:
         ms, fl = sum(r[1] for r in mf), sum(r[2] for r in mf)
-        roof["mfma_bound_launches"] = {"launches": len(mf), "ms": round(ms, 2), "achieved": round(fl / ms / 1e9, 2), "unit": "TFLOP/s",
-                                       "frac": round(fl / ms / 1e9 / PEAK, 4)}
+        roof["mfma_bound_launches"] = dict({"launches": len(mf), "ms": round(ms, 2)}, **mfma_roof(k, fl / ms / 1e9))
     if hb:
         ms, by = sum(r[1] for r in hb), sum(r[3] for r in hb)
         roof["hbm_bound_launches"] = {"launches": len(hb), "ms": round(ms, 2), "achieved": round(by / ms / 1e6, 1), "unit": "GB/s",
@@ -83,7 +95,7 @@ def dominant(eng, step, names):
         if not vv["launches"] or vv["ms"] <= 0:
             continue
         t, g = vv["flops"] / (vv["ms"] * 1e-3) / 1e12, vv["bytes"] / (vv["ms"] * 1e-3) / 1e9
-        stages[names.get(kk, kk)] = ({"bound": "mfma", "achieved": round(t, 2), "unit": "TFLOP/s", "frac": round(t / PEAK, 4)}
+        stages[names.get(kk, kk)] = (dict({"bound": "mfma"}, **mfma_roof(kk, t))
                                      if t / PEAK >= g / 8000.0 else
                                      {"bound": "hbm", "achieved": round(g, 1), "unit": "GB/s", "frac": round(g / 8000.0, 4)})
     roof["stage_roofline"] = stages
@@ -146,7 +158,7 @@ def run_htdemucs(args):
     offs = [11025, 3000]
     step = lambda: eng.ht_demix_dev(mix.data_ptr(), n, out.data_ptr(), shifts=2, offsets=offs, flags=3, stream=st)  # noqa: E731
     dt = timed(step, args.steps, args.warmup)
-    roof, kms = dominant(eng, step, {"conv3x3": "gg_kernel (rewrite 3x3 / DConv / 1x1)", "tdf": "tdf_dma_kernel (transformer linears)",
+    roof, kms = dominant(eng, step, {"conv3x3": "gg_kernel (rewrite 3x3 / DConv / 1x1)", "tdf": "row GEMM tdf3_kernel / tdf2_kernel (transformer linears)",
                                      "conv1x1": "mha_kernel<3>", "down": "gg_kernel (k8/s4 convs)", "up": "gg_kernel (transposed convs)"})
     TL = hc.segment_samples
     nseg = sum(len(range(0, n + 22050 - o, int(0.75 * TL))) for o in offs)
@@ -183,7 +195,7 @@ def run_roformer(args):
     C = 441 * 800
     step = lambda: eng.rof_demix_dev(mix.data_ptr(), n, C, out.data_ptr(), stream=st)  # noqa: E731
     dt = timed(step, args.steps, args.warmup)
-    roof, kms = dominant(eng, step, {"tdf": "tdf_dma_kernel (linears)", "conv1x1": "attention_kernel"})
+    roof, kms = dominant(eng, step, {"tdf": "row GEMM tdf3_kernel / tdf2_kernel (linears)", "conv1x1": "attention_kernel"})
     nch = len(R.roformer_plan(n, cfg, 8)[2])
     cpu = None
     if args.cpu:
@@ -283,7 +295,7 @@ def run_hdemucs(args):
     offs = [11025, 3000]
     step = lambda: eng.hd_demix_dev(mix.data_ptr(), n, out.data_ptr(), shifts=2, offsets=offs, flags=3, stream=st)  # noqa: E731
     dt = timed(step, args.steps, args.warmup)
-    roof, kms = dominant(eng, step, {"conv3x3": "gg_kernel (rewrite 3x3 / DConv / 1x1)", "tdf": "tdf_dma_kernel (LSTM input / LocalState projections)",
+    roof, kms = dominant(eng, step, {"conv3x3": "gg_kernel (rewrite 3x3 / DConv / 1x1)", "tdf": "row GEMM tdf3_kernel / tdf2_kernel (LSTM input / LocalState projections)",
                                      "conv1x1": "hd_lstm_step_kernel + hd_local_attn_kernel", "down": "gg_kernel (k8/s4 convs)",
                                      "up": "gg_kernel (transposed convs)"})
     TL = hc.segment_samples

@@ -74,7 +74,7 @@ static double run_shape(const Shape &sh, int abl, int reps) {
   CK(hipMalloc(&dr, (size_t)M * N * 4));
   CK(hipMalloc(&dy2, (size_t)M * N * 4));
   CK(hipMalloc(&dy3, (size_t)M * N * 4));
-  const int ntiles = (N + 15) / 16, nk = K / 32;
+  const int ntiles = (N + 15) / 16, nk = ((K + 63) / 64) * 2;
   CK(hipMalloc(&dw3, (size_t)ntiles * nk * 3 * 1024));
   for (int64_t r0 = 0; r0 < M; r0 += HB) {
     const int64_t n = std::min<int64_t>(HB, M - r0);
@@ -189,6 +189,8 @@ int main(int argc, char **argv) {
   std::vector<Shape> shapes = {
       {"small ragged", 1000, 200, 192, 3, 8, 1, 1, 1},
       {"small gelu", 4096 + 64, 512, 256, 1, 1, 2, 1, 1},
+      {"odd stages", 1000, 200, 96, 3, 8, 1, 1, 1},
+      {"tdf L2 gemm2", 506880, 768, 96, 144, 64, 1, 1, 0},
       {"tdf L0 gemm1", 675840, 384, 3072, 48, 256, 1, 0, 0},
       {"tdf L0 gemm2", 675840, 3072, 384, 48, 256, 1, 1, 0},
       {"tdf L1 gemm1", 675840, 192, 1536, 96, 128, 1, 0, 0},
