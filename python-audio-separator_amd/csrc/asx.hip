@@ -812,6 +812,7 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
 static std::atomic<int> g_gemm_bf16x6{getenv("ASX_GEMM_BF16X6") ? atoi(getenv("ASX_GEMM_BF16X6")) : 1};
 // launches of tdf3_kernel since the process started (tests assert that the path under test is the one that ran)
 static std::atomic<long long> g_tdf3_launches{0};
+static std::atomic<long long> g_attn6_launches{0};   // launches of attention6_kernel (kernels_rof.h)
 
 // The split image of a weight matrix is built on first use and cached by (pointer, N, K).  Every entry point that uploads or frees
 // weights bumps the epoch (w3_epoch_bump), which flushes the whole cache at the next lookup -- an address reused by another
@@ -3016,6 +3017,10 @@ int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel)
   const std::string nm(name);
   if (nm == "counter.tdf3_launches") {                 // launches of the bf16x6 row GEMM since the process started (as a float)
     host[0] = (float)g_tdf3_launches.load();
+    return ASX_OK;
+  }
+  if (nm == "counter.attn6_launches") {
+    host[0] = (float)g_attn6_launches.load();
     return ASX_OK;
   }
   if (e->vr && e->vr->ws_batch > 0) {

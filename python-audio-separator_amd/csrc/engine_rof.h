@@ -341,6 +341,20 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
         static const bool v1 = getenv("ASX_ATTN_V1") && atoi(getenv("ASX_ATTN_V1")) != 0;   // the 4-byte-fragment kernel (A/B)
         static const bool attn_db = getenv("ASX_ATTN_DB") && atoi(getenv("ASX_ATTN_DB")) != 0;   // A/B (default off until measured)
         static const int qw = getenv("ASX_ATTN_QW") ? atoi(getenv("ASX_ATTN_QW")) : 1;   // 2: 128 queries per workgroup (measured slower: 357 vs 328 ms)
+        // bf16 x 6 form (kernels_rof.h: attention6_kernel) under the process-wide switch of the row GEMM; ASX_ATTN6=0: A/B
+        static const bool attn6 = !(getenv("ASX_ATTN6") && atoi(getenv("ASX_ATTN6")) == 0);
+        if (attn6 && g_gemm_bf16x6.load() > 0 && !v1) {
+          AttnArgs a2 = aa;
+          static const int qw6 = getenv("ASX_ATTN6_QW") ? atoi(getenv("ASX_ATTN6_QW")) : 2;   // 128 queries per workgroup on long sequences
+          if (qw6 >= 2 && aa.len > 128) {
+            a2.nqt = (aa.len + 127) / 128;
+            hipLaunchKernelGGL(attention6_kernel<2>, dim3((unsigned)((int64_t)a2.nqt * H * nseq)), dim3(256), 0, s, a2);
+          } else {
+            a2.nqt = qtiles;
+            hipLaunchKernelGGL(attention6_kernel<1>, dim3((unsigned)((int64_t)qtiles * H * nseq)), dim3(256), 0, s, a2);
+          }
+          g_attn6_launches.fetch_add(1);
+        } else
         if (v1) hipLaunchKernelGGL(attention_kernel, dim3(qtiles, H, (unsigned)nseq), dim3(256), 0, s, aa);
         else if (qw >= 2 && aa.len > 64) {
           AttnArgs a2 = aa;

@@ -463,6 +463,233 @@ __global__ __launch_bounds__(256, (QW == 1 && !DB) ? 3 : 2) void attention2_kern
 }
 
 // ---------------------------------------------------------------------------
+// attention6_kernel: the same flash-style algorithm on the bf16 matrix pipe with fp32 results -- both matmuls as six bf16 MFMA
+// products on EXACTLY split fp32 operands (kernels_gemm3.h: v = h + m + l, dropped cross terms <= 2^-24 of a product).
+//   S^T = K Q^T   : k = head dim in natural order (lane group lk: dims 32 ks + 8 lk .. + 7).  Q is split once per workgroup in
+//                   registers (a lane's 16 values are 64 contiguous bytes of its query row); K is split by the staging threads and
+//                   written as three bf16 images Kp[part][key][64 dims] (128-byte rows).
+//   O^T += V^T P^T: k = key.  The S^T accumulators of a lane hold keys 16 t + 4 lk + r (t = 16-key tile, r = 0..3); the k order
+//                   of a 32-key step kp is DEFINED as 8 lk + e <-> key (2 kp + (e >> 2)) * 16 + 4 lk + (e & 3), so that a lane's
+//                   P operand is its own eight probabilities of tiles 2 kp, 2 kp + 1 (split in registers, no cross-lane move),
+//                   and V is staged TRANSPOSED in that key order: Vp[part][dim][pos(key)], pos = (t >> 1) * 32 + g * 8 +
+//                   (t & 1) * 4 + r for key = 16 t + 4 g + r -- a staging thread owns 4 consecutive keys x 4 dims, transposes
+//                   them in registers and writes 8 bytes per (dim, part).
+// Both images have 128-byte rows; the 16-byte slot index is XOR-ed with (row >> 1) & 7, which puts the sixteen lanes of every
+// (non-contiguous) lane group of `ds_read_b128` on sixteen distinct slots of the 256-byte bank row.
+// LDS 48 KB (three workgroups per CU), two barriers per 64-key tile, K / V of the next tile in registers meanwhile.
+// ---------------------------------------------------------------------------
+// QW = 16-query groups per wave (64 QW queries per workgroup): the K / V split of a tile (176 VALU per thread, the kernel is VALU-bound)
+// serves QW times the MFMA work.
+template <int QW>
+__global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(AttnArgs a) {
+  constexpr int PARTB = 64 * 128;                      // bytes of one part image (64 rows x 64 bf16)
+  __shared__ __attribute__((aligned(16))) char lds6[6 * PARTB];
+  char *Kp = lds6, *Vp = lds6 + 3 * PARTB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = lid % a.nqt;
+  lid /= a.nqt;
+  const int h = lid % a.heads;
+  const int64_t sq = lid / a.heads;
+  const int64_t base = (sq / a.inner_cnt) * a.outer_stride + (sq % a.inner_cnt) * a.inner_stride;
+  const int inner = a.heads * 64;
+  const int64_t ld = 3 * (int64_t)inner;
+  const int q0 = qt * 64 * QW;
+
+  // ---- Q operand of this lane: query q0 + 16 wave + li, dims 32 ks + 8 lk .. + 7, split into three bf16 fragments per k step
+  u32x4 qf[QW][2][3];
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+    const int q = q0 + (wave * QW + g) * 16 + li;
+    const bool ok = q < a.len;
+    const float *qr = a.qkv + (base + (int64_t)(ok ? q : 0) * a.row_stride) * ld + h * 64 + 8 * lk;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if (ok) {
+        v0 = *reinterpret_cast<const f32x4 *>(qr + 32 * ks);
+        v1 = *reinterpret_cast<const f32x4 *>(qr + 32 * ks + 4);
+      }
+      split3_oct(v0, v1, qf[g][ks][0], qf[g][ks][1], qf[g][ks][2]);
+    }
+  }
+
+  f32x4 acc_o[QW][4];
+  float m_run[QW], l_run[QW];
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_o[g][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m_run[g] = -INFINITY;
+    l_run[g] = 0.f;
+  }
+
+  // ---- staging: thread (kb = tid >> 4, c4 = tid & 15) owns keys 4 kb .. + 3 x dims 4 c4 .. + 3 of a tile
+  const int kb = tid >> 4, c4 = tid & 15;
+  const int nkt = (a.len + 63) / 64;
+  f32x4 kreg[4], vreg[4];
+  auto fetch = [&](int kt) {
+    const int k0 = kt * 64 + 4 * kb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      kreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      vreg[j] = kreg[j];
+      if (k0 + j < a.len) {
+        const float *rowp = a.qkv + (base + (int64_t)(k0 + j) * a.row_stride) * ld + h * 64 + c4 * 4;
+        kreg[j] = *reinterpret_cast<const f32x4 *>(rowp + inner);
+        vreg[j] = *reinterpret_cast<const f32x4 *>(rowp + 2 * inner);
+      }
+    }
+  };
+  // K image: row = key, 8-byte unit c4 of the row (dims 4 c4 .. + 3): slot c4 >> 1, half c4 & 1
+  // V image: row = dim, keys 4 kb .. + 3 at pos (t >> 1) * 32 + g * 8 + (t & 1) * 4 (t = kb >> 2, g = kb & 3): slot (t >> 1) * 4 + g, half t & 1
+  const int vslot = ((kb >> 3) << 2) | (kb & 3), vhalf = (kb >> 2) & 1;
+  auto stage = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 4 * kb + j;
+      unsigned hh[2], mm[2], ll[2];
+      split3_pair(kreg[j].x, kreg[j].y, hh[0], mm[0], ll[0]);
+      split3_pair(kreg[j].z, kreg[j].w, hh[1], mm[1], ll[1]);
+      char *d = Kp + row * 128 + ((((c4 >> 1) ^ ((row >> 1) & 7)) << 4) | ((c4 & 1) << 3));
+      *reinterpret_cast<uint2 *>(d) = make_uint2(hh[0], hh[1]);
+      *reinterpret_cast<uint2 *>(d + PARTB) = make_uint2(mm[0], mm[1]);
+      *reinterpret_cast<uint2 *>(d + 2 * PARTB) = make_uint2(ll[0], ll[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * c4 + i;
+      unsigned hh[2], mm[2], ll[2];
+      split3_pair(vreg[0][i], vreg[1][i], hh[0], mm[0], ll[0]);
+      split3_pair(vreg[2][i], vreg[3][i], hh[1], mm[1], ll[1]);
+      char *d = Vp + row * 128 + (((vslot ^ ((row >> 1) & 7)) << 4) | (vhalf << 3));
+      *reinterpret_cast<uint2 *>(d) = make_uint2(hh[0], hh[1]);
+      *reinterpret_cast<uint2 *>(d + PARTB) = make_uint2(mm[0], mm[1]);
+      *reinterpret_cast<uint2 *>(d + 2 * PARTB) = make_uint2(ll[0], ll[1]);
+    }
+  };
+  // fragment reads: row 16 t + li, logical slot s -> physical s ^ ((li >> 1) & 7)
+  const int frow = li * 128, fsw = (li >> 1) & 7;
+
+  fetch(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int k0 = kt * 64;
+    __syncthreads();   // previous tile fully consumed
+    stage();
+    __syncthreads();
+    if (kt + 1 < nkt) fetch(kt + 1);
+
+    // ---- S^T[key, query] for this wave's 16 QW queries (a K fragment serves every query group) ----
+    f32x4 st[QW][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int g = 0; g < QW; ++g) st[g][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const char *kp = Kp + mt * 2048 + frow + (((ks * 4 + lk) ^ fsw) << 4);
+        const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(kp);
+        const bf16x8 km = *reinterpret_cast<const bf16x8 *>(kp + PARTB);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8 *>(kp + 2 * PARTB);
+#pragma unroll
+        for (int g = 0; g < QW; ++g) {
+          const bf16x8 qh = __builtin_bit_cast(bf16x8, qf[g][ks][0]), qm = __builtin_bit_cast(bf16x8, qf[g][ks][1]),
+                       ql = __builtin_bit_cast(bf16x8, qf[g][ks][2]);
+          st[g][mt] = ASX_MFMA_BF16(kl, qh, st[g][mt]);
+          st[g][mt] = ASX_MFMA_BF16(kh, ql, st[g][mt]);
+          st[g][mt] = ASX_MFMA_BF16(km, qm, st[g][mt]);
+          st[g][mt] = ASX_MFMA_BF16(km, qh, st[g][mt]);
+          st[g][mt] = ASX_MFMA_BF16(kh, qm, st[g][mt]);
+          st[g][mt] = ASX_MFMA_BF16(kh, qh, st[g][mt]);
+        }
+      }
+    }
+    // ---- scale, mask keys beyond len, online softmax per query group ----
+#pragma unroll
+    for (int g = 0; g < QW; ++g) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + mt * 16 + 4 * lk + r;
+          const float sv = (key < a.len) ? st[g][mt][r] * a.scale : -INFINITY;
+          st[g][mt][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[g], mx);
+      const float corr = (m_run[g] == -INFINITY) ? 0.f : (a.exact ? expf(m_run[g] - m_new) : __expf(m_run[g] - m_new));
+      float psum = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = (st[g][mt][r] == -INFINITY) ? 0.f : (a.exact ? expf(st[g][mt][r] - m_new) : __expf(st[g][mt][r] - m_new));
+          st[g][mt][r] = p;
+          psum += p;
+        }
+      }
+      psum += __shfl_xor(psum, 16);
+      psum += __shfl_xor(psum, 32);
+      l_run[g] = l_run[g] * corr + psum;
+      m_run[g] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) acc_o[g][dt] *= corr;
+    }
+    // ---- O^T[d, query] += V^T[d, key] P^T[key, query], 32 keys per k step (a V fragment serves every query group) ----
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      bf16x8 p_h[QW], p_m[QW], p_l[QW];
+#pragma unroll
+      for (int g = 0; g < QW; ++g) {
+        u32x4 ph, pm, pl;
+        split3_oct(st[g][2 * kp], st[g][2 * kp + 1], ph, pm, pl);
+        p_h[g] = __builtin_bit_cast(bf16x8, ph);
+        p_m[g] = __builtin_bit_cast(bf16x8, pm);
+        p_l[g] = __builtin_bit_cast(bf16x8, pl);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const char *vp = Vp + dt * 2048 + frow + (((kp * 4 + lk) ^ fsw) << 4);
+        const bf16x8 vh = *reinterpret_cast<const bf16x8 *>(vp);
+        const bf16x8 vm = *reinterpret_cast<const bf16x8 *>(vp + PARTB);
+        const bf16x8 vl = *reinterpret_cast<const bf16x8 *>(vp + 2 * PARTB);
+#pragma unroll
+        for (int g = 0; g < QW; ++g) {
+          acc_o[g][dt] = ASX_MFMA_BF16(vl, p_h[g], acc_o[g][dt]);
+          acc_o[g][dt] = ASX_MFMA_BF16(vh, p_l[g], acc_o[g][dt]);
+          acc_o[g][dt] = ASX_MFMA_BF16(vm, p_m[g], acc_o[g][dt]);
+          acc_o[g][dt] = ASX_MFMA_BF16(vm, p_h[g], acc_o[g][dt]);
+          acc_o[g][dt] = ASX_MFMA_BF16(vh, p_m[g], acc_o[g][dt]);
+          acc_o[g][dt] = ASX_MFMA_BF16(vh, p_h[g], acc_o[g][dt]);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+    const int q = q0 + (wave * QW + g) * 16 + li;
+    if (q < a.len) {
+      const int64_t row = base + (int64_t)q * a.row_stride;
+      const float gt = a.gate[row * a.gate_ld + h];
+      const float gs = 1.0f / (1.0f + expf(-gt));
+      const float inv = gs / l_run[g];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        f32x4 o = acc_o[g][dt];
+        o *= inv;
+        *reinterpret_cast<f32x4 *>(a.out + row * inner + h * 64 + dt * 16 + 4 * lk) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // GLU of the mask MLP output (bs_roformer.py:216) scattered into the mask tensor [B, S, T, W]:
 //   mask[b, st, t, off + j] = a[m, j] * sigmoid(a[m, din + j]),   m = b*T + t
 // ---------------------------------------------------------------------------

@@ -51,6 +51,28 @@ def test_forward_golden(A, g):
     assert rel_rms(y2, g["fwd2"]) < TOL, rel_rms(y2, g["fwd2"])
 
 
+def test_forward_golden_both_matrix_pipes(A, g):
+    """The same golden vector through the bf16 x 6 kernels (row GEMM tdf3_kernel + attention6_kernel, the default) and through the
+    fp32-MFMA kernels (gemm_bf16x6 = 0), with proof of which attention kernel ran (library launch counter)."""
+    w = (0.4 * np.random.default_rng(81).standard_normal((2, 2, 320))).astype(np.float32)
+    eng = demixer(A, CFG, 7, 8).engine
+    try:
+        eng.set_option("gemm_bf16x6", 1)
+        n0 = eng.counter("attn6_launches")
+        y6 = eng.rof_forward(w)
+        assert eng.counter("attn6_launches") > n0, "attention6_kernel did not run"
+        eng.set_option("gemm_bf16x6", 0)
+        n1 = eng.counter("attn6_launches")
+        y32 = eng.rof_forward(w)
+        assert eng.counter("attn6_launches") == n1, "the fp32 run went through attention6_kernel"
+    finally:
+        eng.set_option("gemm_bf16x6", 1)
+    e6, e32 = rel_rms(y6[:, 0], g["fwd1"]), rel_rms(y32[:, 0], g["fwd1"])
+    assert e6 < TOL and e32 < TOL, (e6, e32)
+    assert e6 <= 2.0 * e32 + 1e-6, (e6, e32)             # fp32-grade, not a reduced-precision mode
+    assert rel_rms(y6, y32) < 2e-5, rel_rms(y6, y32)
+
+
 def test_forward_win_length_golden(A, g):
     """stft_win_length < stft_n_fft: the Hann window is zero padded to n_fft at both ends (torch.stft / istft), vector written by
     the reference BSRoformer (asx_mdx_config.win_length, ABI 3)."""
