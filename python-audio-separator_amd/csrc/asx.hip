@@ -866,8 +866,34 @@ static void launch_tdf3_abl(const TdfDmaArgs &a, const u32x4 *w3, hipStream_t s)
   constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = 2 * 3 * BM * 64;
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3);
+  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3, RowGather{});
   g_tdf3_launches.fetch_add(1);
+}
+// GATHER mode (kernels_gemm3.h): stride-1 convolutions of the channels-last nets as implicit GEMMs on the same kernel
+static std::atomic<long long> g_tdf3_gather_launches{0};
+template <int NREP, int MREP>
+static bool launch_tdf3_gather(const TdfDmaArgs &a, const RowGather &gq, hipStream_t s) {
+  const u32x4 *w3 = w3_image(a.w, a.N, a.K, s);
+  if (!w3) return false;
+  constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = 2 * 3 * BM * 64;
+  const int64_t nbm = (a.M + BM - 1) / BM;
+  const int nbn = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, 0, true>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3, gq);
+  g_tdf3_gather_launches.fetch_add(1);
+  return true;
+}
+static bool launch_tdf3_gather_auto(const TdfDmaArgs &d, const RowGather &gq, hipStream_t s) {
+  if (d.glu_cout > 0) {                                // value / gate fragment pairs: 128-column tiles (two fragments per wave)
+    const bool small = (d.M + 127) / 128 * ((d.N + 127) / 128) < 1024;   // grid too small for 128-row tiles to fill the chip twice
+    return small ? launch_tdf3_gather<2, 4>(d, gq, s) : launch_tdf3_gather<2, 8>(d, gq, s);
+  }
+  if (d.N <= 64) return launch_tdf3_gather<1, 8>(d, gq, s);   // narrow layers (48 .. 64 columns): one fragment per wave
+  if (d.N > 128) {
+    const double rows = (double)((d.M + 127) / 128);
+    auto cost = [&](int bn, double eff) { return ceil(rows * (double)((d.N + bn - 1) / bn) / 512.0) * bn / eff; };
+    return cost(128, 0.96) < cost(192, 1.0) ? launch_tdf3_gather<2, 8>(d, gq, s) : launch_tdf3_gather<3, 8>(d, gq, s);
+  }
+  return launch_tdf3_gather<2, 4>(d, gq, s);
 }
 template <int NREP, int MREP>
 static bool launch_tdf3(const TdfDmaArgs &a, hipStream_t s) {
@@ -3021,6 +3047,10 @@ int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel)
   }
   if (nm == "counter.attn6_launches") {
     host[0] = (float)g_attn6_launches.load();
+    return ASX_OK;
+  }
+  if (nm == "counter.tdf3_gather_launches") {
+    host[0] = (float)g_tdf3_gather_launches.load();
     return ASX_OK;
   }
   if (e->vr && e->vr->ws_batch > 0) {

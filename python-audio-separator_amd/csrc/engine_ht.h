@@ -560,6 +560,48 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
     const int64_t blocks128 = ((a.M + 127) / 128) * ((a.N + tn - 1) / tn);
     a.lowai = ((bytes > 0.0 && flops / bytes < lowai_thr) || blocks128 < small_grid) ? 1 : 0;
   }
+  // stride-1 dense convs with 32-aligned channel counts: the bf16 x 6 row GEMM in GATHER mode (kernels_gemm3.h) -- an implicit GEMM
+  // whose A rows are the pixels of the channels-last image, one (tap, 32-channel chunk) per stage.  ASX_GATHER6=0: A/B.
+  {
+    static const bool gather6 = !(getenv("ASX_GATHER6") && atoi(getenv("ASX_GATHER6")) == 0);
+    auto a16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    static const int gather_minn = getenv("ASX_GATHER6_MINN") ? atoi(getenv("ASX_GATHER6_MINN")) : 48;   // narrowest dense layer routed here
+    static const bool gather_glu = !(getenv("ASX_GATHER6_GLU") && atoi(getenv("ASX_GATHER6_GLU")) == 0);
+    const bool glu = mode == GG_GLU && gather_glu && g.glu_c > 0 && g.n % 32 == 0;
+    if (gather6 && g_gemm_bf16x6.load() > 0 && (mode == GG_DENSE || glu) && res == nullptr && fz == nullptr && q.SI == 1 && q.SO == 1 &&
+        q.IR == q.I && a.OR == q.O && q.KO * q.KI > 1 && q.Cin % 32 == 0 && g.n % 8 == 0 && g.n >= (glu ? 65 : gather_minn) && (q.ldc & 3) == 0 && (ldy & 3) == 0 &&
+        a.y_bs == (int64_t)q.O * q.I * ldy && a16(x) && a16(y) && a16(g.w.p) && a16(g.b.p) && a.M < (1ll << 31) &&
+        (int64_t)(q.KO * q.DO + q.PO + 1) * q.I * q.ldc < (1ll << 31) && (uint64_t)16 * (uint64_t)ldy * 4 < (1ull << 31)) {
+      TdfDmaArgs d{};
+      d.x = x;
+      d.w = g.w.f();
+      d.bias = g.b.f();
+      d.zeros = e->d_zeros.f();
+      d.y = y;
+      d.M = a.M;
+      d.N = g.n;
+      d.K = g.k;
+      d.C = 1;
+      d.T = 1;
+      d.relu = act;
+      d.ldy = ldy;
+      d.glu_cout = glu ? g.glu_c : 0;
+      RowGather gq{};
+      gq.O = q.O;
+      gq.I = q.I;
+      gq.KI = q.KI;
+      gq.DO = q.KO > 1 ? q.DO : 0;
+      gq.DI = q.DI;
+      gq.PO = q.KO > 1 ? q.PO : 0;
+      gq.PI = q.PI;
+      gq.nch = q.Cin / 32;
+      gq.ldc = q.ldc;
+      gq.x_bs = a.x_bs;
+      bool done = false;
+      CHK(timed(e, cls, flops, bytes, s, [&]() { done = launch_tdf3_gather_auto(d, gq, s); }));
+      if (done) return ASX_OK;
+    }
+  }
   // stride-1 k3 / 3x3 convs with a halo packing run on the halo-tile kernel (the input block enters LDS once for all taps)
   HgGeom hgm;
   // A/B knob: launches whose halo grid would be smaller than ASX_HALO_MINBLK workgroups stay on gg_kernel (128-row tiles)

@@ -94,8 +94,18 @@ struct IntC {
 
 // ABL (ASX_TDF3_ABL, measurement-only instantiations, results are garbage): bit 0 = no x loads / split after the prologue,
 // bit 1 = no MFMA, bit 2 = no epilogue traffic, bit 3 = no weight loads after the prologue
-template <int NREP, int MREP, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 *__restrict__ w3) {
+// GATHER mode: the same GEMM with its A rows GATHERED from a channels-last image -- a stride-1 KO x KI convolution of the halo /
+// gather kernels (kernels_halo.h, kernels_ht.h) as an implicit GEMM: row r = pixel (b, o, i) in raster order, stage = (tap,
+// 32-channel chunk), the x fetch of a stage reads 128 contiguous bytes of pixel (o + ky DO - PO, i + kx DI - PI) or the zero page.
+// Per stage the work is exactly that of the plain GEMM (split cost per MFMA unchanged); the taps' re-reads hit L2.
+struct RowGather {
+  int O, I, KI, DO, DI, PO, PI, nch;                  // image, taps per row, dilations, paddings, Cin / 32
+  int ldc;                                            // floats per pixel of x
+  int64_t x_bs;                                       // floats per image of x
+};
+
+template <int NREP, int MREP, int ABL = 0, bool GATHER = false>
+__global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 *__restrict__ w3, RowGather gq) {
   constexpr int BM = 16 * MREP, BN = 64 * NREP;
   constexpr int XC = MREP / 4;                        // 8-float chunks per thread and stage (BM * 4 chunks / 256 threads)
   constexpr int PART = BM * 64;                       // bytes of one part image
@@ -164,22 +174,51 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
   // ---- x rows: chunk q = tid + 256 i -> row q >> 2 of the tile, floats (q & 3) * 8 .. + 7 of the stage
   const float *xp[XC];
   int xw[XC];                                          // LDS byte offset of the chunk inside a part image
+  int po[XC], pi[XC];                                  // GATHER: the row's pixel (o, i); o = -2^20 for rows past M (never valid)
 #pragma unroll
   for (int i = 0; i < XC; ++i) {
     const int q = tid + 256 * i;
     const int row = q >> 2, c = q & 3;
     int64_t r = m0 + row;
-    r = r < a.M ? r : a.M - 1;
-    xp[i] = a.x + r * lda + c * 8;
+    if constexpr (GATHER) {
+      const bool rok = r < a.M;
+      r = rok ? r : a.M - 1;
+      const int64_t img = (int64_t)gq.O * gq.I;
+      const int64_t b = r / img;
+      const int rem = (int)(r - b * img);
+      po[i] = rem / gq.I;
+      pi[i] = rem - po[i] * gq.I;
+      xp[i] = a.x + b * gq.x_bs + (int64_t)rem * gq.ldc + c * 8;
+      if (!rok) po[i] = -(1 << 20);
+    } else {
+      r = r < a.M ? r : a.M - 1;
+      xp[i] = a.x + r * lda + c * 8;
+      po[i] = pi[i] = 0;
+    }
     xw[i] = row * 64 + ((c ^ hsw((row >> 2) & 3)) << 4);
   }
   f32x4 xr[XC][2];
   auto load_x = [&](int ks) {
-    const int kc = (ks < nkx ? ks : nkx - 1) * 32;     // wave-uniform clamp (see nk above)
+    const int kcs = ks < nkx ? ks : nkx - 1;           // wave-uniform clamp (see nk above)
+    if constexpr (GATHER) {
+      const int tap = kcs / gq.nch, ch = kcs - tap * gq.nch;
+      const int ky = tap / gq.KI, kx = tap - ky * gq.KI;
+      const int dy = ky * gq.DO - gq.PO, dx = kx * gq.DI - gq.PI;
+      const int off = (dy * gq.I + dx) * gq.ldc + ch * 32;   // launcher: |off| < 2^31
 #pragma unroll
-    for (int i = 0; i < XC; ++i) {
-      xr[i][0] = *reinterpret_cast<const f32x4 *>(xp[i] + kc);
-      xr[i][1] = *reinterpret_cast<const f32x4 *>(xp[i] + kc + 4);
+      for (int i = 0; i < XC; ++i) {
+        const bool ok = (unsigned)(po[i] + dy) < (unsigned)gq.O && (unsigned)(pi[i] + dx) < (unsigned)gq.I;
+        const float *src = ok ? xp[i] + off : a.zeros;
+        xr[i][0] = *reinterpret_cast<const f32x4 *>(src);
+        xr[i][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+      }
+    } else {
+      const int kc = kcs * 32;
+#pragma unroll
+      for (int i = 0; i < XC; ++i) {
+        xr[i][0] = *reinterpret_cast<const f32x4 *>(xp[i] + kc);
+        xr[i][1] = *reinterpret_cast<const f32x4 *>(xp[i] + kc + 4);
+      }
     }
   };
   auto split_chunk = [&](int buf, int i) {             // chunk i of the stage held in xr -> the three part images of `buf`
@@ -284,6 +323,34 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
 
   // ---- epilogue (the arithmetic of tdf2_kernel's three paths) ----------------------------------------------------------------
   const bool full = (m0 + BM <= a.M) && (n0 + BN <= a.N);
+  if constexpr (GATHER && NREP == 2) {
+    if (a.glu_cout > 0) {
+      // GLU epilogue of the Demucs rewrite convs (kernels_halo.h: hg_kernel, GG_GLU): a wave's two column fragments are a value /
+      // gate pair; output channel of value column c: c / 2 (fragment granularity), same arithmetic as hg_kernel
+      const int c0 = n0 + wave * 32;                   // first column of the value fragment
+      const int oc = (c0 >> 1) + lk * 4;
+      if (c0 < a.N && oc < a.glu_cout) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = bv;
+        if (a.bias != nullptr) {
+          bv = *reinterpret_cast<const f32x4 *>(a.bias + c0 + lk * 4);
+          bg = *reinterpret_cast<const f32x4 *>(a.bias + c0 + 16 + lk * 4);
+        }
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int64_t row = m0 + m * 16 + li;
+          if (row >= a.M) continue;
+          const f32x4 v = acc[0][m] + bv, g4 = acc[1][m] + bg;
+          f32x4 o4;
+          o4.x = v.x * __builtin_amdgcn_rcpf(1.0f + __expf(-g4.x));
+          o4.y = v.y * __builtin_amdgcn_rcpf(1.0f + __expf(-g4.y));
+          o4.z = v.z * __builtin_amdgcn_rcpf(1.0f + __expf(-g4.z));
+          o4.w = v.w * __builtin_amdgcn_rcpf(1.0f + __expf(-g4.w));
+          *reinterpret_cast<f32x4 *>(a.y + row * ldy + oc) = o4;
+        }
+      }
+      return;
+    }
+  }
   if constexpr ((ABL & 4) != 0) {
     float chk = 0.f;
 #pragma unroll

@@ -807,6 +807,8 @@ struct TdfDmaArgs {
   const float *rscale;
   int nt;                   // bit 0: non-temporal output stores, bit 1: non-temporal residual loads (ReLU path; A/B switch ASX_NT)
   int prefer_small;         // launcher hint: 64-row tiles (three workgroups per CU) -- the Demucs transformer linears (M ~ 1e5 rows)
+  int glu_cout;             // tdf3_kernel GATHER mode, 128-column tiles only: > 0 = GLU epilogue over value / gate fragment pairs (the rows of W are in
+                            // ht_glu_perm order), glu_cout output channels: y[row][c / 2 + ...] = (acc_v + b) * sigmoid(acc_g + b)
 };
 
 // rotary step of the row-GEMM epilogues on the float4 (row, col .. col + 3), col % 4 == 0.  Every product and sum is rounded

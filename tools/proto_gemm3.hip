@@ -29,7 +29,7 @@ static void launch3(const TdfDmaArgs &a, const u32x4 *w3, hipStream_t s) {
   constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS = 2 * 3 * BM * 64;
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS, s, a, w3);
+  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS, s, a, w3, RowGather{});
 }
 template <int NREP, int MREP>
 static void launch2(const TdfDmaArgs &a, hipStream_t s) {
