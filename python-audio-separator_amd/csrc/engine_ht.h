@@ -568,9 +568,11 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
     static const int gather_minn = getenv("ASX_GATHER6_MINN") ? atoi(getenv("ASX_GATHER6_MINN")) : 48;   // narrowest dense layer routed here
     static const bool gather_glu = !(getenv("ASX_GATHER6_GLU") && atoi(getenv("ASX_GATHER6_GLU")) == 0);
     const bool glu = mode == GG_GLU && gather_glu && g.glu_c > 0 && g.n % 32 == 0;
-    if (gather6 && g_gemm_bf16x6.load() > 0 && (mode == GG_DENSE || glu) && res == nullptr && fz == nullptr && q.SI == 1 && q.SO == 1 &&
-        q.IR == q.I && a.OR == q.O && q.KO * q.KI > 1 && q.Cin % 32 == 0 && g.n % 8 == 0 && g.n >= (glu ? 65 : gather_minn) && (q.ldc & 3) == 0 && (ldy & 3) == 0 &&
-        a.y_bs == (int64_t)q.O * q.I * ldy && a16(x) && a16(y) && a16(g.w.p) && a16(g.b.p) && a.M < (1ll << 31) &&
+    static const bool gather_strided = !(getenv("ASX_GATHER6_STRIDED") && atoi(getenv("ASX_GATHER6_STRIDED")) == 0);
+    const bool unit = q.SI == 1 && q.SO == 1 && q.IR == q.I && a.OR == q.O;
+    if (gather6 && g_gemm_bf16x6.load() > 0 && (mode == GG_DENSE || glu) && res == nullptr && fz == nullptr && (unit || gather_strided) &&
+        q.SI >= 1 && q.SO >= 1 && q.KO <= 3 && q.KO * q.KI > 1 && q.Cin % 32 == 0 && g.n % 8 == 0 && g.n >= (glu ? 65 : gather_minn) && (q.ldc & 3) == 0 && (ldy & 3) == 0 &&
+        a.y_bs == (int64_t)a.OR * q.IR * ldy && a16(x) && a16(y) && a16(g.w.p) && a16(g.b.p) && a.M < (1ll << 31) &&
         (int64_t)(q.KO * q.DO + q.PO + 1) * q.I * q.ldc < (1ll << 31) && (uint64_t)16 * (uint64_t)ldy * 4 < (1ull << 31)) {
       TdfDmaArgs d{};
       d.x = x;
@@ -590,11 +592,15 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
       gq.O = q.O;
       gq.I = q.I;
       gq.KI = q.KI;
-      gq.DO = q.KO > 1 ? q.DO : 0;
+      gq.DO = q.DO;
       gq.DI = q.DI;
-      gq.PO = q.KO > 1 ? q.PO : 0;
+      gq.PO = q.PO;
       gq.PI = q.PI;
       gq.nch = q.Cin / 32;
+      gq.SO = q.SO;
+      gq.SI = q.SI;
+      gq.OR = a.OR;
+      gq.IR = q.IR;
       gq.ldc = q.ldc;
       gq.x_bs = a.x_bs;
       bool done = false;
@@ -750,6 +756,24 @@ static int ht_mha(asx_engine *e, const float *q, int64_t ldq, const float *k, co
     // dh = 48: the single-buffered build runs FOUR workgroups per CU (118 registers, 26 KB of LDS): 55.0 -> 51.5 ms per song
     // against the double-buffered, one-barrier build with three (ASX_MHA_DB=1: A/B) -- occupancy, not the barrier count
     static const bool mha_db = getenv("ASX_MHA_DB") && atoi(getenv("ASX_MHA_DB")) != 0;
+    // bf16 x 6 form (kernels_ht.h: mha6_kernel) under the process-wide switch of the row GEMM; ASX_MHA6=0: A/B
+    static const bool mha6 = !(getenv("ASX_MHA6") && atoi(getenv("ASX_MHA6")) == 0);
+    if (mha6 && g_gemm_bf16x6.load() > 0 && a.decay == nullptr && (dh == 48 || dh == 64) && (ldq & 3) == 0 && (ldkv & 3) == 0 &&
+        (ldo & 3) == 0) {
+      MhaArgs a6 = a;
+      const bool wide = nq > 128;                      // 128 queries per workgroup on long sequences
+      a6.nqt = wide ? (nq + 127) / 128 : (nq + 63) / 64;
+      const dim3 grid6((unsigned)(a6.nqt * heads * B));
+      if (dh == 48) {
+        if (wide) hipLaunchKernelGGL((mha6_kernel<3, 2>), grid6, dim3(256), 0, s, a6);
+        else hipLaunchKernelGGL((mha6_kernel<3, 1>), grid6, dim3(256), 0, s, a6);
+      } else {
+        if (wide) hipLaunchKernelGGL((mha6_kernel<4, 2>), grid6, dim3(256), 0, s, a6);
+        else hipLaunchKernelGGL((mha6_kernel<4, 1>), grid6, dim3(256), 0, s, a6);
+      }
+      g_attn6_launches.fetch_add(1);
+      return;
+    }
     if (dh == 48 && mha_db) hipLaunchKernelGGL((mha_kernel<3, false, true>), grid, dim3(256), 0, s, a);
     else if (dh == 48) hipLaunchKernelGGL((mha_kernel<3>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((mha_kernel<4>), grid, dim3(256), 0, s, a);

@@ -95,11 +95,13 @@ struct IntC {
 // ABL (ASX_TDF3_ABL, measurement-only instantiations, results are garbage): bit 0 = no x loads / split after the prologue,
 // bit 1 = no MFMA, bit 2 = no epilogue traffic, bit 3 = no weight loads after the prologue
 // GATHER mode: the same GEMM with its A rows GATHERED from a channels-last image -- a stride-1 KO x KI convolution of the halo /
-// gather kernels (kernels_halo.h, kernels_ht.h) as an implicit GEMM: row r = pixel (b, o, i) in raster order, stage = (tap,
-// 32-channel chunk), the x fetch of a stage reads 128 contiguous bytes of pixel (o + ky DO - PO, i + kx DI - PI) or the zero page.
+// gather kernels (kernels_halo.h, kernels_ht.h) as an implicit GEMM: row r = OUTPUT pixel (b, oo, j) in raster order, stage = (tap,
+// 32-channel chunk), the x fetch of a stage reads 128 contiguous bytes of input pixel (oo SO + ky DO - PO, j SI + kx DI - PI) or the
+// zero page (strided convolutions included).
 // Per stage the work is exactly that of the plain GEMM (split cost per MFMA unchanged); the taps' re-reads hit L2.
 struct RowGather {
-  int O, I, KI, DO, DI, PO, PI, nch;                  // image, taps per row, dilations, paddings, Cin / 32
+  int O, I, KI, DO, DI, PO, PI, nch;                  // input image, taps per row, dilations, paddings, Cin / 32
+  int SO, SI, OR, IR;                                 // strides and OUTPUT image: row r = (b, oo, j), input origin (oo SO - PO, j SI - PI)
   int ldc;                                            // floats per pixel of x
   int64_t x_bs;                                       // floats per image of x
 };
@@ -183,12 +185,13 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
     if constexpr (GATHER) {
       const bool rok = r < a.M;
       r = rok ? r : a.M - 1;
-      const int64_t img = (int64_t)gq.O * gq.I;
+      const int64_t img = (int64_t)gq.OR * gq.IR;
       const int64_t b = r / img;
       const int rem = (int)(r - b * img);
-      po[i] = rem / gq.I;
-      pi[i] = rem - po[i] * gq.I;
-      xp[i] = a.x + b * gq.x_bs + (int64_t)rem * gq.ldc + c * 8;
+      const int oo = rem / gq.IR, jj = rem - oo * gq.IR;
+      po[i] = oo * gq.SO;
+      pi[i] = jj * gq.SI;
+      xp[i] = a.x + b * gq.x_bs + ((int64_t)po[i] * gq.I + pi[i]) * gq.ldc + c * 8;
       if (!rok) po[i] = -(1 << 20);
     } else {
       r = r < a.M ? r : a.M - 1;

@@ -1117,4 +1117,219 @@ __global__ __launch_bounds__(256) void ht_fold_kernel(const float *__restrict__ 
   *op = v;
 }
 
+// ---------------------------------------------------------------------------
+// mha6_kernel: mha_kernel on the bf16 matrix pipe with fp32 results (kernels_rof.h: attention6_kernel has the scheme -- six bf16
+// MFMA products on exactly split operands, Q split in registers, K and the transposed V split by the staging threads, P split
+// from the S accumulators in place).  Head dims 16 DT <= 64: the K image and the Q fragments are 64 dims wide (dims >= DH are
+// zero on the Q side, so whatever the K image holds there contributes nothing -- it is zeroed once all the same), the V^T
+// image has DH rows.  No decay variant (Demucs v3's LocalState keeps mha_kernel).  QW = 16-query groups per wave.
+// ---------------------------------------------------------------------------
+template <int DT, int QW>
+__global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void mha6_kernel(MhaArgs a) {
+  constexpr int DH = 16 * DT, C4 = DH / 4;
+  constexpr int PARTB = 64 * 128;
+  static_assert(DT >= 1 && DT <= 4, "head dim");
+  __shared__ __attribute__((aligned(16))) char lds6[6 * PARTB];
+  char *Kp = lds6, *Vp = lds6 + 3 * PARTB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = lid % a.nqt;
+  lid /= a.nqt;
+  const int h = lid % a.heads, b = lid / a.heads;
+  const int q0 = qt * 64 * QW;
+  const float *qp = a.q + (int64_t)b * a.nq * a.ldq + h * DH;
+  const float *kp = a.k + (int64_t)b * a.nk * a.ldk + h * DH;
+  const float *vp = a.v + (int64_t)b * a.nk * a.ldv + h * DH;
+
+  if constexpr (DH < 64) {                             // dims DH .. 63 of the K image are never written below
+    for (int e = tid; e < 3 * PARTB / 16; e += 256) reinterpret_cast<u32x4 *>(Kp)[e] = (u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
+
+  // ---- Q operand of this lane: query q0 + 16 (wave QW + g) + li, dims 32 ks + 8 lk .. + 7 (zero past DH) ----
+  u32x4 qf[QW][2][3];
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+    const int q = q0 + (wave * QW + g) * 16 + li;
+    const bool ok = q < a.nq;
+    const float *qr = qp + (int64_t)(ok ? q : 0) * a.ldq + 8 * lk;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if (ok && 32 * ks + 8 * lk < DH) {               // DH % 8 == 0: an 8-dim group is inside the head or past it as a whole
+        v0 = *reinterpret_cast<const f32x4 *>(qr + 32 * ks);
+        v1 = *reinterpret_cast<const f32x4 *>(qr + 32 * ks + 4);
+      }
+      split3_oct(v0, v1, qf[g][ks][0], qf[g][ks][1], qf[g][ks][2]);
+    }
+  }
+
+  f32x4 acc_o[QW][DT];
+  float m_run[QW], l_run[QW];
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+#pragma unroll
+    for (int i = 0; i < DT; ++i) acc_o[g][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m_run[g] = -INFINITY;
+    l_run[g] = 0.f;
+  }
+
+  // ---- staging: thread (kb = tid >> 4, c4 = tid & 15) owns keys 4 kb .. + 3 x dims 4 c4 .. + 3 (idle for c4 >= DH / 4) ----
+  const int kb = tid >> 4, c4 = tid & 15;
+  const bool stg = c4 < C4;
+  const int nkt = (a.nk + 63) / 64;
+  f32x4 kreg[4], vreg[4];
+  auto fetch = [&](int kt) {
+    const int k0 = kt * 64 + 4 * kb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      kreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      vreg[j] = kreg[j];
+      if (stg && k0 + j < a.nk) {
+        kreg[j] = *reinterpret_cast<const f32x4 *>(kp + (int64_t)(k0 + j) * a.ldk + c4 * 4);
+        vreg[j] = *reinterpret_cast<const f32x4 *>(vp + (int64_t)(k0 + j) * a.ldv + c4 * 4);
+      }
+    }
+  };
+  const int vslot = ((kb >> 3) << 2) | (kb & 3), vhalf = (kb >> 2) & 1;
+  auto stage = [&]() {
+    if (!stg) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 4 * kb + j;
+      unsigned hh[2], mm[2], ll[2];
+      split3_pair(kreg[j].x, kreg[j].y, hh[0], mm[0], ll[0]);
+      split3_pair(kreg[j].z, kreg[j].w, hh[1], mm[1], ll[1]);
+      char *d = Kp + row * 128 + ((((c4 >> 1) ^ ((row >> 1) & 7)) << 4) | ((c4 & 1) << 3));
+      *reinterpret_cast<uint2 *>(d) = make_uint2(hh[0], hh[1]);
+      *reinterpret_cast<uint2 *>(d + PARTB) = make_uint2(mm[0], mm[1]);
+      *reinterpret_cast<uint2 *>(d + 2 * PARTB) = make_uint2(ll[0], ll[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * c4 + i;
+      unsigned hh[2], mm[2], ll[2];
+      split3_pair(vreg[0][i], vreg[1][i], hh[0], mm[0], ll[0]);
+      split3_pair(vreg[2][i], vreg[3][i], hh[1], mm[1], ll[1]);
+      char *d = Vp + row * 128 + (((vslot ^ ((row >> 1) & 7)) << 4) | (vhalf << 3));
+      *reinterpret_cast<uint2 *>(d) = make_uint2(hh[0], hh[1]);
+      *reinterpret_cast<uint2 *>(d + PARTB) = make_uint2(mm[0], mm[1]);
+      *reinterpret_cast<uint2 *>(d + 2 * PARTB) = make_uint2(ll[0], ll[1]);
+    }
+  };
+  const int frow = li * 128, fsw = (li >> 1) & 7;
+
+  fetch(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int k0 = kt * 64;
+    __syncthreads();   // previous tile fully consumed
+    stage();
+    __syncthreads();
+    if (kt + 1 < nkt) fetch(kt + 1);
+
+    f32x4 st[QW][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int g = 0; g < QW; ++g) st[g][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < (DH + 31) / 32; ++ks) {
+        const char *kq = Kp + mt * 2048 + frow + (((ks * 4 + lk) ^ fsw) << 4);
+        const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(kq);
+        const bf16x8 km = *reinterpret_cast<const bf16x8 *>(kq + PARTB);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8 *>(kq + 2 * PARTB);
+#pragma unroll
+        for (int g = 0; g < QW; ++g) {
+          const bf16x8 qh = __builtin_bit_cast(bf16x8, qf[g][ks][0]), qm = __builtin_bit_cast(bf16x8, qf[g][ks][1]),
+                       ql = __builtin_bit_cast(bf16x8, qf[g][ks][2]);
+          st[g][mt] = ASX_MFMA_BF16(kl, qh, st[g][mt]);
+          st[g][mt] = ASX_MFMA_BF16(kh, ql, st[g][mt]);
+          st[g][mt] = ASX_MFMA_BF16(km, qm, st[g][mt]);
+          st[g][mt] = ASX_MFMA_BF16(km, qh, st[g][mt]);
+          st[g][mt] = ASX_MFMA_BF16(kh, qm, st[g][mt]);
+          st[g][mt] = ASX_MFMA_BF16(kh, qh, st[g][mt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < QW; ++g) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + mt * 16 + 4 * lk + r;
+          const float sv = (key < a.nk) ? st[g][mt][r] * a.scale : -INFINITY;
+          st[g][mt][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[g], mx);
+      const float corr = (m_run[g] == -INFINITY) ? 0.f : (a.exact ? expf(m_run[g] - m_new) : __expf(m_run[g] - m_new));
+      float psum = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = (st[g][mt][r] == -INFINITY) ? 0.f : (a.exact ? expf(st[g][mt][r] - m_new) : __expf(st[g][mt][r] - m_new));
+          st[g][mt][r] = p;
+          psum += p;
+        }
+      }
+      psum += __shfl_xor(psum, 16);
+      psum += __shfl_xor(psum, 32);
+      l_run[g] = l_run[g] * corr + psum;
+      m_run[g] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc_o[g][dt] *= corr;
+    }
+#pragma unroll
+    for (int kp2 = 0; kp2 < 2; ++kp2) {
+      bf16x8 p_h[QW], p_m[QW], p_l[QW];
+#pragma unroll
+      for (int g = 0; g < QW; ++g) {
+        u32x4 ph, pm, pl;
+        split3_oct(st[g][2 * kp2], st[g][2 * kp2 + 1], ph, pm, pl);
+        p_h[g] = __builtin_bit_cast(bf16x8, ph);
+        p_m[g] = __builtin_bit_cast(bf16x8, pm);
+        p_l[g] = __builtin_bit_cast(bf16x8, pl);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const char *vq = Vp + dt * 2048 + frow + (((kp2 * 4 + lk) ^ fsw) << 4);
+        const bf16x8 vh = *reinterpret_cast<const bf16x8 *>(vq);
+        const bf16x8 vm = *reinterpret_cast<const bf16x8 *>(vq + PARTB);
+        const bf16x8 vl = *reinterpret_cast<const bf16x8 *>(vq + 2 * PARTB);
+#pragma unroll
+        for (int g = 0; g < QW; ++g) {
+          acc_o[g][dt] = ASX_MFMA_BF16(vl, p_h[g], acc_o[g][dt]);
+          acc_o[g][dt] = ASX_MFMA_BF16(vh, p_l[g], acc_o[g][dt]);
+          acc_o[g][dt] = ASX_MFMA_BF16(vm, p_m[g], acc_o[g][dt]);
+          acc_o[g][dt] = ASX_MFMA_BF16(vm, p_h[g], acc_o[g][dt]);
+          acc_o[g][dt] = ASX_MFMA_BF16(vh, p_m[g], acc_o[g][dt]);
+          acc_o[g][dt] = ASX_MFMA_BF16(vh, p_h[g], acc_o[g][dt]);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+    const int q = q0 + (wave * QW + g) * 16 + li;
+    if (q < a.nq) {
+      const float inv = 1.0f / l_run[g];
+      float *orow = a.out + ((int64_t)b * a.nq + q) * a.ldo + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        f32x4 o = acc_o[g][dt];
+        o *= inv;
+        *reinterpret_cast<f32x4 *>(orow + dt * 16 + 4 * lk) = o;
+      }
+    }
+  }
+}
+
 }  // namespace asx
