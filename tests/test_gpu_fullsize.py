@@ -37,6 +37,30 @@ def test_htdemucs_segment(A):
     assert rel_rms(got, want) < TOL, rel_rms(got, want)
 
 
+def test_htdemucs_segment_both_matrix_pipes(A):
+    """The bf16 x 6 kernels (tdf3_kernel incl. GATHER mode for the GLU rewrite convs and the k8 / s4 encoders, mha6_kernel) against
+    the fp32-MFMA kernels on the same segment, with proof of which ran (library launch counters)."""
+    from oracle import demucs_oracle as D
+    oc = D.HTConfig()
+    sd = D.make_ht_state(oc, 0)
+    eng = A.Engine(A.MDXConfig(n_fft=4096, hop_length=1024, dim_f=2048, segment_size=8))
+    eng.load_ht(A.HTConfig(segment=Fraction(39, 5)), sd)
+    x = (0.3 * np.random.default_rng(0).standard_normal((1, 2, oc.training_length))).astype(np.float32)
+    names = ("tdf3_launches", "tdf3_gather_launches", "attn6_launches")
+    try:
+        eng.set_option("gemm_bf16x6", 1)
+        c0 = [eng.counter(n) for n in names]
+        y6 = eng.ht_forward(x)
+        c1 = [eng.counter(n) for n in names]
+        assert all(b > a for a, b in zip(c0, c1)), dict(zip(names, zip(c0, c1)))
+        eng.set_option("gemm_bf16x6", 0)
+        y32 = eng.ht_forward(x)
+        assert [eng.counter(n) for n in names] == c1, "the fp32 run went through a bf16 x 6 kernel"
+    finally:
+        eng.set_option("gemm_bf16x6", 1)
+    assert rel_rms(y6, y32) < 2e-5, rel_rms(y6, y32)
+
+
 def test_hdemucs_chunk(A):
     # Demucs v3 at the hdemucs_mmi layout: BLSTM hidden 192 / 384 on overlapped frames (517 and 259 frames), LocalState head dims
     # 48 / 96 on the flash kernel, odd length, batch 2 (two 16-sequence tiles share the recurrence launches)
@@ -69,6 +93,17 @@ def test_vr_clip(A):
         print(f"VR 4band_44100 full size, {res}: rel-RMS {rel_rms(gp, wp):.3e} / {rel_rms(gs, ws):.3e}")
         assert rel_rms(gp, wp) < TOL, rel_rms(gp, wp)
         assert rel_rms(gs, ws) < TOL, rel_rms(gs, ws)
+        if res == "polyphase":
+            # the same clip through the fp32-MFMA conv kernels: the GATHER-mode launches above must have happened, and stop here
+            n_on = dm.engine.counter("tdf3_gather_launches")
+            assert n_on > 0, "no conv of the full-size VR net ran on the bf16 x 6 GATHER kernel"
+            try:
+                dm.engine.set_option("gemm_bf16x6", 0)
+                gp32, gs32 = dm.separate_stems(wave)
+                assert dm.engine.counter("tdf3_gather_launches") == n_on
+            finally:
+                dm.engine.set_option("gemm_bf16x6", 1)
+            assert rel_rms(gp, gp32) < 2e-5 and rel_rms(gs, gs32) < 2e-5, (rel_rms(gp, gp32), rel_rms(gs, gs32))
         dm.engine.close()
 
 

@@ -55,7 +55,7 @@ def timed(step, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def dominant(eng, step, names):
+def dominant(eng, step, names, x6_classes=("tdf",)):
     """Roofline of the kernel class that takes most of the step (class sums, as in round 2) PLUS a per-launch split of that class:
     a class can mix MFMA-bound and HBM-bound launches (Demucs "conv": 3x3 rewrites vs DConv / 1x1), so the launches are sorted
     by arithmetic intensity -- >= 40 flop/B (the fp32-MFMA / achievable-HBM ridge is ~25-30) count as MFMA-bound and are priced
@@ -67,14 +67,15 @@ def dominant(eng, step, names):
     eng.profile_enable(False)
     k, v = max(((k, v) for k, v in prof.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
     tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
-    # The row-GEMM class ("tdf": every nn.Linear) runs csrc/kernels_gemm3.h when the option is on: six bf16 MFMA products per fp32
-    # multiply-add on exactly split operands.  Its roofline is then the dense bf16 peak against EXECUTED work (6 x the GEMM's
-    # FLOPs; the few launches outside the kernel's preconditions run fp32 MFMA and are over-counted by this), with the GEMM's own
-    # FLOP rate kept as `fp32_equivalent`.
+    # The classes in `x6_classes` run the bf16 x 6 kernels when the option is on (row GEMM tdf3_kernel -- also in GATHER mode for
+    # the stride-1 / strided convs of the channels-last nets -- and attention6_kernel / mha6_kernel): six bf16 MFMA products per
+    # fp32 multiply-add on exactly split operands.  Their roofline is then the dense bf16 peak against EXECUTED work (6 x the
+    # algorithmic FLOPs; the launches outside the kernels' preconditions still run fp32 MFMA and are over-counted by this), with
+    # the algorithmic FLOP rate kept as `fp32_equivalent`.
     x6 = eng.option("gemm_bf16x6") > 0
 
     def mfma_roof(cls, t):
-        if cls == "tdf" and x6:
+        if cls in x6_classes and x6:
             return {"achieved": round(6.0 * t, 1), "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": round(6.0 * t / PEAK_BF16, 4),
                     "dtype": "bf16 x 6 products (fp32-exact split operands)", "fp32_equivalent": round(t, 2),
                     "fp32_equivalent_over_fp32_peak": round(t / PEAK, 4)}
@@ -125,7 +126,8 @@ def run_vr(args):
     st = torch.cuda.current_stream().cuda_stream
     step = lambda: eng.vr_separate_dev(dw.data_ptr(), n, p.data_ptr(), s.data_ptr(), 0.05, 186, stream=st)  # noqa: E731
     dt = timed(step, args.steps, args.warmup)
-    roof, kms = dominant(eng, step, {"conv3x3": "gg_kernel (3x3 / 1x1 convs)", "down": "gg_kernel (stride-2 convs)"})
+    roof, kms = dominant(eng, step, {"conv3x3": "tdf3_kernel<GATHER> / hg_kernel / gg_kernel (3x3 / 1x1 convs)",
+                                     "down": "tdf3_kernel<GATHER> / gg_kernel (stride-2 convs)"}, x6_classes=("conv3x3", "down"))
     cpu = None
     if args.cpu:
         torch.set_num_threads(min(os.cpu_count() or 1, 32))
@@ -158,8 +160,10 @@ def run_htdemucs(args):
     offs = [11025, 3000]
     step = lambda: eng.ht_demix_dev(mix.data_ptr(), n, out.data_ptr(), shifts=2, offsets=offs, flags=3, stream=st)  # noqa: E731
     dt = timed(step, args.steps, args.warmup)
-    roof, kms = dominant(eng, step, {"conv3x3": "gg_kernel (rewrite 3x3 / DConv / 1x1)", "tdf": "row GEMM tdf3_kernel / tdf2_kernel (transformer linears)",
-                                     "conv1x1": "mha_kernel<3>", "down": "gg_kernel (k8/s4 convs)", "up": "gg_kernel (transposed convs)"})
+    roof, kms = dominant(eng, step, {"conv3x3": "tdf3_kernel<GATHER> (rewrite 3x3 GLU) + gg_kernel (DConv / 1x1)",
+                                     "tdf": "row GEMM tdf3_kernel / tdf2_kernel (transformer linears)",
+                                     "conv1x1": "mha6_kernel<3> (attention)", "down": "tdf3_kernel<GATHER> / gg_kernel (k8/s4 convs)",
+                                     "up": "gg_kernel (transposed convs)"}, x6_classes=("conv3x3", "tdf", "conv1x1", "down"))
     TL = hc.segment_samples
     nseg = sum(len(range(0, n + 22050 - o, int(0.75 * TL))) for o in offs)
     cpu = None
@@ -195,7 +199,8 @@ def run_roformer(args):
     C = 441 * 800
     step = lambda: eng.rof_demix_dev(mix.data_ptr(), n, C, out.data_ptr(), stream=st)  # noqa: E731
     dt = timed(step, args.steps, args.warmup)
-    roof, kms = dominant(eng, step, {"tdf": "row GEMM tdf3_kernel / tdf2_kernel (linears)", "conv1x1": "attention_kernel"})
+    roof, kms = dominant(eng, step, {"tdf": "row GEMM tdf3_kernel / tdf2_kernel (linears)", "conv1x1": "attention6_kernel"},
+                         x6_classes=("tdf", "conv1x1"))
     nch = len(R.roformer_plan(n, cfg, 8)[2])
     cpu = None
     if args.cpu:
@@ -295,9 +300,10 @@ def run_hdemucs(args):
     offs = [11025, 3000]
     step = lambda: eng.hd_demix_dev(mix.data_ptr(), n, out.data_ptr(), shifts=2, offsets=offs, flags=3, stream=st)  # noqa: E731
     dt = timed(step, args.steps, args.warmup)
-    roof, kms = dominant(eng, step, {"conv3x3": "gg_kernel (rewrite 3x3 / DConv / 1x1)", "tdf": "row GEMM tdf3_kernel / tdf2_kernel (LSTM input / LocalState projections)",
-                                     "conv1x1": "hd_lstm_step_kernel + hd_local_attn_kernel", "down": "gg_kernel (k8/s4 convs)",
-                                     "up": "gg_kernel (transposed convs)"})
+    roof, kms = dominant(eng, step, {"conv3x3": "tdf3_kernel<GATHER> (rewrite 3x3 GLU) + gg_kernel (DConv / 1x1)",
+                                     "tdf": "row GEMM tdf3_kernel / tdf2_kernel (LSTM input / LocalState projections)",
+                                     "conv1x1": "hd_lstm_step_kernel + hd_local_attn_kernel", "down": "tdf3_kernel<GATHER> / gg_kernel (k8/s4 convs)",
+                                     "up": "gg_kernel (transposed convs)"}, x6_classes=("conv3x3", "tdf", "down"))
     TL = hc.segment_samples
     lens = []
     for o in offs:
