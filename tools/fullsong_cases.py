@@ -33,7 +33,10 @@ CASES = {
                        "* peak, secondary = mix - compensate * primary) + the writer's int16 pass, final conv rescaled to stem RMS ~0.1"),
     "htdemucs": (240.0, "BASELINE config 2: htdemucs layout, 4 stems, shifts 2 (offsets 11025, 3000), overlap 0.25, segment 7.8 s"),
     "hdemucs_mmi": (240.0, "hdemucs_mmi layout (Demucs v3), 4 stems, shifts 2 (offsets 11025, 3000), overlap 0.25, 44-s chunks"),
-    "vr_2hp": (10.0, "BASELINE config 0: 10 s, VR arch 123821 (2_HP-UVR shape) on the 4band_44100 parameters, window 512, both stems"),
+    "vr_2hp": (10.0, "BASELINE config 0: 10 s, VR arch 123821 (2_HP-UVR shape) on the 4band_44100 parameters, window 512, both stems; "
+                     "synthesis chain with the polyphase converter (the reference's ARM / MPS rule) on both sides"),
+    "vr_2hp_sinc": (10.0, "the same clip with the sinc_fastest converter on both sides (the reference's Linux / x86 rule, the plugin default here; "
+                          "restated libsamplerate algorithm: INTEGRATION.md \"VR resampler\")"),
     "mdx23c": (60.0, "MDX23C (TFC-TDF v3) default layout, 60 s, overlap 4"),
 }
 OFFSETS = [11025, 3000]

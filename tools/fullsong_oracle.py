@@ -2,7 +2,7 @@
 """CPU leg of the whole-song parity records: runs the oracle (oracle/*.py, the pinned restatement of the reference) on a
 whole BASELINE workload and stores its output at the comparison windows of tools/fullsong_cases.py.
 
-    python tools/fullsong_oracle.py --cases mdx_hq3,htdemucs,hdemucs_mmi,vr_2hp,mdx23c [--threads 8]
+    python tools/fullsong_oracle.py --cases mdx_hq3,htdemucs,hdemucs_mmi,vr_2hp,vr_2hp_sinc,mdx23c [--threads 8]
 
 Writes gpurun_cache/fullsong/<case>.npz (git-ignored; it travels to the GPU box with the snapshot, where
 tools/fullsong_parity.py runs the HIP engine on the same seeded inputs and compares).  The CPU work is minutes per case
@@ -75,13 +75,13 @@ def run_demucs(seconds, v3):
     return {"starts": starts, "width": w, "stems": FC.take(src, starts, w)}, {"stems": [stats(s) for s in src], "mix": stats(mix)}
 
 
-def run_vr(seconds):
+def run_vr(seconds, res="polyphase"):
     from oracle import vr_oracle as V
     n = int(FC.SR * seconds)
     wave = FC.synth(n, seed=1)
     arch = 123821
     sd = V.make_vr_state(arch, 0)
-    p, s = V.vr_separate(wave, sd, arch, V.ModelParams(FC.VR_MP), window_size=512, batch_size=2, aggression=5)
+    p, s = V.vr_separate(wave, sd, arch, V.ModelParams(FC.VR_MP), window_size=512, batch_size=2, aggression=5, wav_resolution=res)
     return {"primary": np.asarray(p, np.float32), "secondary": np.asarray(s, np.float32)}, {"primary": stats(p), "secondary": stats(s), "mix": stats(wave)}
 
 
@@ -96,7 +96,7 @@ def run_mdx23c(seconds):
     return {"starts": starts, "width": w, "stems": FC.take(out, starts, w)}, {"stems": [stats(s) for s in out], "mix": stats(mix)}
 
 
-RUN = {"mdx_hq3": run_mdx, "htdemucs": lambda s: run_demucs(s, False), "hdemucs_mmi": lambda s: run_demucs(s, True), "vr_2hp": run_vr,
+RUN = {"mdx_hq3": run_mdx, "htdemucs": lambda s: run_demucs(s, False), "hdemucs_mmi": lambda s: run_demucs(s, True), "vr_2hp": run_vr, "vr_2hp_sinc": lambda s: run_vr(s, "sinc_fastest"),
        "mdx23c": run_mdx23c}
 
 

@@ -2,7 +2,7 @@
 """GPU leg of the whole-song parity records (one per BASELINE config): the HIP engine on the same seeded inputs as
 tools/fullsong_oracle.py, compared with the oracle's stored output at the comparison windows of tools/fullsong_cases.py.
 
-    python tools/fullsong_parity.py [--cases mdx_hq3,htdemucs,hdemucs_mmi,vr_2hp,mdx23c] > profiles/r03_fullsong_parity.json
+    python tools/fullsong_parity.py [--cases mdx_hq3,htdemucs,hdemucs_mmi,vr_2hp,vr_2hp_sinc,mdx23c] > profiles/r03_fullsong_parity.json
 
 A case whose oracle record (gpurun_cache/fullsong/<case>.npz) is missing is computed on the spot with the oracle (slow: the
 CPU leg of a 4-minute htdemucs song is minutes).  Reported per stem: relative RMS error (the north-star metric, bar 1e-4),
@@ -96,13 +96,13 @@ def gpu_demucs(z, meta, v3):
     return out
 
 
-def gpu_vr(z, meta):
+def gpu_vr(z, meta, res="polyphase"):
     n = int(FC.SR * meta["seconds"])
     wave = FC.synth(n, seed=1)
     from oracle import vr_oracle as V
     arch = 123821
     dm = A.VRDemixer({"model_params": FC.VR_MP, "primary_stem_name": "Instrumental", "torch_device": 0},
-                     {"window_size": 512, "batch_size": 4, "aggression": 5}, state_dict=V.make_vr_state(arch, 0), nn_arch_size=arch)
+                     {"window_size": 512, "batch_size": 4, "aggression": 5, "asx_res_type": res}, state_dict=V.make_vr_state(arch, 0), nn_arch_size=arch)
     t0 = time.perf_counter()
     gp, gs = dm.separate_stems(wave)
     dt = time.perf_counter() - t0
@@ -142,7 +142,7 @@ def gpu_mdx23c(z, meta):
 
 
 RUN = {"mdx_hq3": gpu_mdx, "htdemucs": lambda z, m: gpu_demucs(z, m, False), "hdemucs_mmi": lambda z, m: gpu_demucs(z, m, True),
-       "vr_2hp": gpu_vr, "mdx23c": gpu_mdx23c}
+       "vr_2hp": gpu_vr, "vr_2hp_sinc": lambda z, m: gpu_vr(z, m, "sinc_fastest"), "mdx23c": gpu_mdx23c}
 
 
 def main():
