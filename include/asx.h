@@ -24,7 +24,9 @@
  * engine's GPU.  `stream` is a hipStream_t passed as void* (NULL = the null
  * stream).  asx_demix_dev / asx_demix_chunks_dev / asx_finalize_dev / asx_separate_dev, the
  * asx_mdxc_*_dev, asx_rof_*_dev, asx_ht_*_dev and asx_hd_*_dev calls only enqueue work on `stream` once the
- * engine's workspace has reached its size (first call): no host copy, no host synchronisation (chunk / segment
+ * engine's workspace has reached its size and the split weight images of the bf16 x 6 kernels exist (both happen in the first
+ * call after weights were loaded: the images are built lazily, with one stream synchronisation each): no host copy, no host
+ * synchronisation afterwards (chunk / segment
  * start tables are built by a kernel or travel in the kernel arguments) -- they can be captured into a hipGraph
  * and a collective on step k can overlap the compute of step k + 1.  asx_vr_separate_dev synchronises `stream`
  * only when enable_post_process asks for merge_artifacts (its run-length pass is host code).
@@ -475,8 +477,9 @@ int asx_ensemble_dev(asx_engine *e, const float *waves_dev, int32_t k, int64_t n
                      float *out_dev, int64_t *n_out, void *stream);
 int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host, int64_t n_samples, float *out_host, int64_t *n_out);
 
-/* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host; "counter.tdf3_launches" writes the
- * number of bf16x6 row-GEMM launches of this process into host[0]. */
+/* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host.  "counter.<name>" writes a launch counter
+ * of this process into host[0] (tests use them to prove which kernel family ran): tdf3_launches (bf16 x 6 row GEMM),
+ * tdf3_gather_launches (its GATHER mode: channels-last convolutions), attn6_launches (attention6_kernel / mha6_kernel). */
 int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel);
 /* measurement hook: the s_memtime timeline the ASX_TDF2_ABL=16 build of the row GEMM records (8 x uint64 per workgroup). */
 int asx_debug_trace(uint64_t *host, int64_t n_u64);
@@ -517,8 +520,10 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
  * "gemm_bf16x6" (PROCESS-wide; also ASX_GEMM_BF16X6 in the environment): 1 (default) = every row GEMM whose shape allows it
  * (K % 32 == 0, K >= 64, N > 64, N % 8 == 0, 16-byte aligned rows) runs csrc/kernels_gemm3.h -- both fp32 operands split EXACTLY into three
  * bf16 parts, six bf16 MFMA products with fp32 accumulation, the dropped cross terms below 2^-24 of a product: fp32-grade results
- * (closer to a float64 GEMM than the fp32-MFMA kernel on every measured shape) at 1.7-1.9x its speed; 0 = the fp32-MFMA kernels
- * (csrc/kernels_gemm2.h) everywhere. */
+ * (closer to a float64 GEMM than the fp32-MFMA kernel on every measured shape) at 1.7-1.9x its speed; the same switch covers the
+ * GATHER mode of that kernel (stride-1 / strided convolutions of the channels-last VR and Demucs nets with Cin % 32 == 0 and at least
+ * 48 output channels) and the attention kernels of the Roformer / HTDemucs transformers (attention6_kernel, mha6_kernel);
+ * 0 = the fp32-MFMA kernels (csrc/kernels_gemm2.h, kernels_halo.h, kernels_ht.h, kernels_rof.h) everywhere. */
 int asx_set_option(asx_engine *e, const char *key, int32_t value);
 
 /* ---- profiling ---------------------------------------------------------- */
