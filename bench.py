@@ -415,6 +415,13 @@ def main():
                           "launcher": "self" if os.environ.get("ASX_BENCH_LAUNCHED") == "1" else ("external" if "WORLD_SIZE" in os.environ else None)},
                          **comm),
             "roofline": roofline, "cpu_baseline": cpu,
+            # what "f32" means inside: nothing runs in a reduced-precision mode
+            "arithmetic": {"io": "float32", "conv3x3": "Winograd F(2x2,3x3) on fp32 MFMA (exact fma chains)",
+                           "row_gemm": ("six bf16 MFMA products on fp32 operands split EXACTLY into three bf16 parts each (dropped cross "
+                                        "terms < 2^-24 of a product; closer to a float64 GEMM than the fp32-MFMA kernel, "
+                                        "tests/test_gpu_parity.py::test_rowgemm_bf16x6_vs_float64)") if eng.option("gemm_bf16x6") > 0
+                           else "fp32 MFMA (gemm_bf16x6 = 0)",
+                           "switch": "ASX_GEMM_BF16X6 / asx_set_option(gemm_bf16x6)"},
         }
         if parity is not None:
             res["parity_rel_rms_vs_cpu"] = float(f"{parity:.3e}")

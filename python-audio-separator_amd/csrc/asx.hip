@@ -928,7 +928,12 @@ static void launch_tdf_dma_auto(const TdfDmaArgs &d, hipStream_t s) {
       return ceil(blocks / 512.0) * bn / eff;
     };
     const bool narrow = t128 == 2 || (t128 == 1 && cost(128, 0.96) < cost(192, 1.0));
-    if (v3 && (narrow ? launch_tdf3<2, 8>(d, s) : launch_tdf3<3, 8>(d, s))) return;
+    // ASX_TDF3_EFF128: relative efficiency charged to the 128-column tile of the bf16 x 6 kernel.  Measured on the BS-Roformer and
+    // HTDemucs linears: 0.96 / 0.85 / 0.75 -> 1251 / 1262 / 1262 ms and 30.5 / 30.4 / 30.5 ms per song -- no reason to move off
+    // the fp32 kernel's figure (N = 512 stays on four 128-column tiles).
+    static const double eff128 = getenv("ASX_TDF3_EFF128") ? atof(getenv("ASX_TDF3_EFF128")) : 0.96;
+    const bool narrow3 = t128 == 2 || (t128 == 1 && cost(128, eff128) < cost(192, 1.0));
+    if (v3 && (narrow3 ? launch_tdf3<2, 8>(d, s) : launch_tdf3<3, 8>(d, s))) return;
     if (narrow) v2 ? launch_tdf2<2, 8>(d, s) : launch_tdf_dma_t<2, 8>(d, s);
     else v2 ? launch_tdf2<3, 8>(d, s) : launch_tdf_dma_t<3, 8>(d, s);
   } else if (d.N > 64) {
