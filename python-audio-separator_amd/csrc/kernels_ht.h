@@ -11,6 +11,7 @@
 // (gg_kernel).  The A tile is fetched by LDS-DMA exactly like tdf_dma_kernel (kernels_net.h); only the
 // source address of each 16-byte chunk differs.
 #pragma once
+#include "kernels_gemm3.h"   // split3_pair / split3_oct, bf16x8, ASX_MFMA_BF16 (the bf16 x 6 attention kernels)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -5,6 +5,7 @@
 // sequence is (base row, row stride, length) -- time attention walks rows with stride Fb,
 // frequency attention walks consecutive rows.
 #pragma once
+#include "kernels_gemm3.h"   // split3_pair / split3_oct, bf16x8, ASX_MFMA_BF16 (the bf16 x 6 attention kernels)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
