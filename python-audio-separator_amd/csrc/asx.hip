@@ -819,7 +819,7 @@ static std::atomic<long long> g_attn6_launches{0};   // launches of attention6_k
 // tensor of the same shape can therefore never meet a stale image.
 struct W3Entry {
   const float *w;
-  int N, K;
+  int N, K, cin;                                       // cin > 0: the (tap, chunk)-padded image of the GATHER mode, else 0
   void *img;
 };
 static std::mutex g_w3_mu;
@@ -828,7 +828,7 @@ static std::atomic<uint64_t> g_w3_epoch{1};
 static uint64_t g_w3_cache_epoch = 0;
 static void w3_epoch_bump() { g_w3_epoch.fetch_add(1); }
 
-static const u32x4 *w3_image(const float *w, int N, int K, hipStream_t s) {
+static const u32x4 *w3_image(const float *w, int N, int K, hipStream_t s, int cin = 0) {
   std::lock_guard<std::mutex> lk(g_w3_mu);
   const uint64_t ep = g_w3_epoch.load();
   if (ep != g_w3_cache_epoch) {
@@ -837,13 +837,14 @@ static const u32x4 *w3_image(const float *w, int N, int K, hipStream_t s) {
     g_w3_cache_epoch = ep;
   }
   for (auto &en : g_w3)
-    if (en.w == w && en.N == N && en.K == K) return reinterpret_cast<const u32x4 *>(en.img);
-  const int ntiles = (N + 15) / 16, nk = ((K + 63) / 64) * 2;   // the image holds an even number of 32-wide stages (zeros past K)
-  W3Entry en{w, N, K, nullptr};
+    if (en.w == w && en.N == N && en.K == K && en.cin == cin) return reinterpret_cast<const u32x4 *>(en.img);
+  const int nst = cin > 0 ? (K / cin) * ((cin + 31) / 32) : 0;
+  const int ntiles = (N + 15) / 16, nk = cin > 0 ? ((nst + 1) & ~1) : ((K + 63) / 64) * 2;   // an even number of 32-wide stages (zero padded)
+  W3Entry en{w, N, K, cin, nullptr};
   if (hipMalloc(&en.img, (size_t)ntiles * nk * 3 * 1024) != hipSuccess) return nullptr;
   const int64_t total = (int64_t)ntiles * nk * 64;
   hipLaunchKernelGGL(w3_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<u32x4 *>(en.img), N, K,
-                     total);
+                     total, cin, nst);
   // built once per weight tensor: make the image visible to every stream before it is published
   if (hipStreamSynchronize(s) != hipSuccess) {
     (void)hipFree(en.img);
@@ -873,7 +874,7 @@ static void launch_tdf3_abl(const TdfDmaArgs &a, const u32x4 *w3, hipStream_t s)
 static std::atomic<long long> g_tdf3_gather_launches{0};
 template <int NREP, int MREP>
 static bool launch_tdf3_gather(const TdfDmaArgs &a, const RowGather &gq, hipStream_t s) {
-  const u32x4 *w3 = w3_image(a.w, a.N, a.K, s);
+  const u32x4 *w3 = w3_image(a.w, a.N, a.K, s, (gq.cin & 31) ? gq.cin : 0);   // channel counts off the 32-grid get their own padded image
   if (!w3) return false;
   constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = 2 * 3 * BM * 64;
   const int64_t nbm = (a.M + BM - 1) / BM;

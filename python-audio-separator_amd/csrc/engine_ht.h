@@ -570,8 +570,12 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
     const bool glu = mode == GG_GLU && gather_glu && g.glu_c > 0 && g.n % 32 == 0;
     static const bool gather_strided = !(getenv("ASX_GATHER6_STRIDED") && atoi(getenv("ASX_GATHER6_STRIDED")) == 0);
     const bool unit = q.SI == 1 && q.SO == 1 && q.IR == q.I && a.OR == q.O;
+    // channel counts off the 32-grid (48, 80, ...): the last chunk of every tap is zero padded -- worth it from 70 % chunk use
+    // (ASX_GATHER6_PARTIAL=0: only multiples of 32)
+    static const bool gather_partial = !(getenv("ASX_GATHER6_PARTIAL") && atoi(getenv("ASX_GATHER6_PARTIAL")) == 0);
+    const bool cin_ok = q.Cin % 32 == 0 || (gather_partial && q.Cin % 8 == 0 && q.Cin > 32 && 10 * q.Cin >= 7 * 32 * ((q.Cin + 31) / 32));
     if (gather6 && g_gemm_bf16x6.load() > 0 && (mode == GG_DENSE || glu) && res == nullptr && fz == nullptr && (unit || gather_strided) &&
-        q.SI >= 1 && q.SO >= 1 && q.KO <= 3 && q.KO * q.KI > 1 && q.Cin % 32 == 0 && g.n % 8 == 0 && g.n >= (glu ? 65 : gather_minn) && (q.ldc & 3) == 0 && (ldy & 3) == 0 &&
+        q.SI >= 1 && q.SO >= 1 && q.KO <= 3 && q.KO * q.KI > 1 && cin_ok && g.n % 8 == 0 && g.n >= (glu ? 65 : gather_minn) && (q.ldc & 3) == 0 && (ldy & 3) == 0 &&
         a.y_bs == (int64_t)a.OR * q.IR * ldy && a16(x) && a16(y) && a16(g.w.p) && a16(g.b.p) && a.M < (1ll << 31) &&
         (int64_t)(q.KO * q.DO + q.PO + 1) * q.I * q.ldc < (1ll << 31) && (uint64_t)16 * (uint64_t)ldy * 4 < (1ull << 31)) {
       TdfDmaArgs d{};
@@ -596,7 +600,8 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
       gq.DI = q.DI;
       gq.PO = q.PO;
       gq.PI = q.PI;
-      gq.nch = q.Cin / 32;
+      gq.nch = (q.Cin + 31) / 32;
+      gq.cin = q.Cin;
       gq.SO = q.SO;
       gq.SI = q.SI;
       gq.OR = a.OR;

@@ -64,17 +64,29 @@ __device__ __forceinline__ void split3_oct(const f32x4 &a, const f32x4 &b, u32x4
 // W[N, K] fp32 -> fragment-ordered bf16 x 3 image: img[((nt * nk + ks) * 3 + part) * 64 + lane] = 8 bf16 of row nt * 16 + (lane & 15),
 // k = ks * 32 + (lane >> 4) * 8 .. + 7; rows >= N and stages past K (the image holds an even number of stages) are zero.  One
 // thread per (nt, ks, lane).
-__global__ __launch_bounds__(256) void w3_split_kernel(const float *__restrict__ w, u32x4 *__restrict__ img, int N, int K, int64_t total) {
+// cin > 0 (GATHER mode with a channel count that is not a multiple of 32): K = taps * cin and a stage is (tap, 32-channel chunk) --
+// the last chunk of every tap is zero padded past cin (cin % 8 == 0), `nst` = taps * ceil(cin / 32) stages exist.
+__global__ __launch_bounds__(256) void w3_split_kernel(const float *__restrict__ w, u32x4 *__restrict__ img, int N, int K, int64_t total,
+                                                       int cin = 0, int nst = 0) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
-  const int nk = ((K + 63) >> 6) * 2;                  // stages of the image: K rounded up to 64 (the kernel runs stage pairs), zeros past K
+  const int nk = cin > 0 ? ((nst + 1) & ~1) : ((K + 63) >> 6) * 2;   // stages of the image: an even number (the kernel runs stage pairs), zeros past the data
   const int lane = (int)(idx & 63);
   const int64_t f = idx >> 6;
   const int ks = (int)(f % nk);
   const int nt = (int)(f / nk);
   const int n = nt * 16 + (lane & 15);
   f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-  if (n < N && ks * 32 < K) {                          // K % 32 == 0: a stage is inside K or past it as a whole
+  if (cin > 0) {
+    const int nch = (cin + 31) >> 5;
+    const int tap = ks / nch, ch = ks - tap * nch;
+    const int kk = ch * 32 + (lane >> 4) * 8;
+    if (n < N && ks < nst && kk < cin) {
+      const float *p = w + (int64_t)n * K + (int64_t)tap * cin + kk;
+      a = *reinterpret_cast<const f32x4 *>(p);
+      b = *reinterpret_cast<const f32x4 *>(p + 4);
+    }
+  } else if (n < N && ks * 32 < K) {                   // K % 32 == 0: a stage is inside K or past it as a whole
     const float *p = w + (int64_t)n * K + ks * 32 + (lane >> 4) * 8;
     a = *reinterpret_cast<const f32x4 *>(p);
     b = *reinterpret_cast<const f32x4 *>(p + 4);
@@ -102,6 +114,7 @@ struct IntC {
 struct RowGather {
   int O, I, KI, DO, DI, PO, PI, nch;                  // input image, taps per row, dilations, paddings, Cin / 32
   int SO, SI, OR, IR;                                 // strides and OUTPUT image: row r = (b, oo, j), input origin (oo SO - PO, j SI - PI)
+  int cin;                                            // channels per tap (nch = ceil(cin / 32); the last chunk of a tap may be partial: cin % 8 == 0)
   int ldc;                                            // floats per pixel of x
   int64_t x_bs;                                       // floats per image of x
 };
@@ -147,7 +160,8 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
   const int64_t lda = a.lda ? a.lda : a.K, ldy = a.ldy ? a.ldy : a.N, ldr = a.ldr ? a.ldr : a.N;
   // K % 32 == 0 (launcher).  The stage loop runs PAIRS of stages: for an odd stage count the image carries one more stage of zero
   // weights, and the x loads of that stage re-read the last real one (finite data times zero).
-  const int nkx = a.K >> 5;                            // stages that exist in x
+  int nkx = a.K >> 5;                                  // stages that exist in x
+  if constexpr (GATHER) nkx = (a.K / gq.cin) * gq.nch; // taps x chunks (a partial last chunk per tap when cin % 32 != 0)
   const int nk = (nkx + 1) & ~1;
 
   // ---- weight fragments: wave-uniform base per 16-column tile + lane * 16 bytes; tiles past N are clamped (masked at the store)
@@ -210,7 +224,8 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
       const int off = (dy * gq.I + dx) * gq.ldc + ch * 32;   // launcher: |off| < 2^31
 #pragma unroll
       for (int i = 0; i < XC; ++i) {
-        const bool ok = (unsigned)(po[i] + dy) < (unsigned)gq.O && (unsigned)(pi[i] + dx) < (unsigned)gq.I;
+        const bool ok = (unsigned)(po[i] + dy) < (unsigned)gq.O && (unsigned)(pi[i] + dx) < (unsigned)gq.I &&
+                        ch * 32 + (tid & 3) * 8 < gq.cin;   // this thread's 8-channel group exists (partial last chunk)
         const float *src = ok ? xp[i] + off : a.zeros;
         xr[i][0] = *reinterpret_cast<const f32x4 *>(src);
         xr[i][1] = *reinterpret_cast<const f32x4 *>(src + 4);
