@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void mha6_kernel(MhaArgs a)
       unsigned hh[2], mm[2], ll[2];
       split3_pair(vreg[0][i], vreg[1][i], hh[0], mm[0], ll[0]);
       split3_pair(vreg[2][i], vreg[3][i], hh[1], mm[1], ll[1]);
-      char *d = Vp + row * 128 + (((vslot ^ ((row >> 1) & 7)) << 4) | (vhalf << 3));
+      char *d = Vp + row * 128 + (((vslot ^ (((row >> 1) ^ (row >> 3)) & 7)) << 4) | (vhalf << 3));   // V^T swizzle: see the fragment read
       *reinterpret_cast<uint2 *>(d) = make_uint2(hh[0], hh[1]);
       *reinterpret_cast<uint2 *>(d + PARTB) = make_uint2(mm[0], mm[1]);
       *reinterpret_cast<uint2 *>(d + 2 * PARTB) = make_uint2(ll[0], ll[1]);
@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void mha6_kernel(MhaArgs a)
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const char *vq = Vp + dt * 2048 + frow + (((kp2 * 4 + lk) ^ fsw) << 4);
+        const char *vq = Vp + dt * 2048 + frow + (((kp2 * 4 + lk) ^ (fsw ^ ((2 * dt + (li >> 3)) & 7))) << 4);   // V^T swizzle ((row >> 1) ^ (row >> 3)) & 7
         const bf16x8 vh = *reinterpret_cast<const bf16x8 *>(vq);
         const bf16x8 vm = *reinterpret_cast<const bf16x8 *>(vq + PARTB);
         const bf16x8 vl = *reinterpret_cast<const bf16x8 *>(vq + 2 * PARTB);

@@ -475,8 +475,10 @@ __global__ __launch_bounds__(256, (QW == 1 && !DB) ? 3 : 2) void attention2_kern
 //                   and V is staged TRANSPOSED in that key order: Vp[part][dim][pos(key)], pos = (t >> 1) * 32 + g * 8 +
 //                   (t & 1) * 4 + r for key = 16 t + 4 g + r -- a staging thread owns 4 consecutive keys x 4 dims, transposes
 //                   them in registers and writes 8 bytes per (dim, part).
-// Both images have 128-byte rows; the 16-byte slot index is XOR-ed with (row >> 1) & 7, which puts the sixteen lanes of every
-// (non-contiguous) lane group of `ds_read_b128` on sixteen distinct slots of the 256-byte bank row.
+// Both images have 128-byte rows; the 16-byte slot index is XOR-ed with (row >> 1) & 7 (K) / ((row >> 1) ^ (row >> 3)) & 7 (V^T), which
+// puts the sixteen lanes of every (non-contiguous) lane group of `ds_read_b128` on sixteen distinct slots of the 256-byte bank row;
+// the extra term of the V^T image halves the conflicts of its transposing 8-byte staging writes (sixteen rows, one logical slot:
+// 4-way -> 2-way, the minimum; first PMC pass: 31 % of the LDS cycles were conflict cycles).
 // LDS 48 KB (three workgroups per CU), two barriers per 64-key tile, K / V of the next tile in registers meanwhile.
 // ---------------------------------------------------------------------------
 // QW = 16-query groups per wave (64 QW queries per workgroup): the K / V split of a tile (176 VALU per thread, the kernel is VALU-bound)
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
       unsigned hh[2], mm[2], ll[2];
       split3_pair(vreg[0][i], vreg[1][i], hh[0], mm[0], ll[0]);
       split3_pair(vreg[2][i], vreg[3][i], hh[1], mm[1], ll[1]);
-      char *d = Vp + row * 128 + (((vslot ^ ((row >> 1) & 7)) << 4) | (vhalf << 3));
+      char *d = Vp + row * 128 + (((vslot ^ (((row >> 1) ^ (row >> 3)) & 7)) << 4) | (vhalf << 3));   // V^T swizzle: see the fragment read
       *reinterpret_cast<uint2 *>(d) = make_uint2(hh[0], hh[1]);
       *reinterpret_cast<uint2 *>(d + PARTB) = make_uint2(mm[0], mm[1]);
       *reinterpret_cast<uint2 *>(d + 2 * PARTB) = make_uint2(ll[0], ll[1]);
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const char *vp = Vp + dt * 2048 + frow + (((kp * 4 + lk) ^ fsw) << 4);
+        const char *vp = Vp + dt * 2048 + frow + (((kp * 4 + lk) ^ (fsw ^ ((2 * dt + (li >> 3)) & 7))) << 4);   // row = 16 dt + li: ((row >> 1) ^ (row >> 3)) & 7
         const bf16x8 vh = *reinterpret_cast<const bf16x8 *>(vp);
         const bf16x8 vm = *reinterpret_cast<const bf16x8 *>(vp + PARTB);
         const bf16x8 vl = *reinterpret_cast<const bf16x8 *>(vp + 2 * PARTB);

@@ -55,6 +55,31 @@ def test_attention_images_are_conflict_free():
             assert conflict_free(wr, [list(range(16))], 8, 32)
 
 
+def test_attention_v_image_swizzle():
+    """V^T image: slot ^ ((row >> 1) ^ (row >> 3)) & 7.  Reads (row 16 dt + li, logical slot 4 kp + lk) stay conflict-free, and the
+    transposing 8-byte staging writes (sixteen lanes = sixteen rows 4 c4 + i, ONE logical (slot, half)) are 2-way instead of 4-way."""
+    g = lambda row: ((row >> 1) ^ (row >> 3)) & 7
+    for dt in range(4):
+        for kp in (0, 1):
+            rd = lambda lane: (dt * 16 + (lane & 15)) * 128 + (((kp * 4 + (lane >> 4)) ^ g(dt * 16 + (lane & 15))) << 4)
+            assert conflict_free(rd, B128_READ_GROUPS, 16, 64)
+
+    def degree(gfun):
+        worst = 0
+        for kb in range(16):
+            vslot, vhalf = ((kb >> 3) << 2) | (kb & 3), (kb >> 2) & 1
+            for i in range(4):
+                banks = {}
+                for c4 in range(16):
+                    row = 4 * c4 + i
+                    a = row * 128 + (((vslot ^ gfun(row)) << 4) | (vhalf << 3))
+                    for w in range(2):
+                        banks.setdefault(((a + 4 * w) // 4) % 32, set()).add(a)
+                worst = max(worst, max(len(v) for v in banks.values()))
+        return worst
+    assert degree(g) == 2 and degree(lambda row: (row >> 1) & 7) == 4
+
+
 def test_attention_key_order_is_shared_by_p_and_v():
     # S^T accumulators: lane group lk, tile t, register r hold key 16 t + 4 lk + r.  k index of 32-key step kp: 8 lk + e <-> key
     # (2 kp + (e >> 2)) * 16 + 4 lk + (e & 3); the V^T image stores key 16 t + 4 g + r at pos (t >> 1) * 32 + g * 8 + (t & 1) * 4 + r
