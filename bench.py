@@ -43,8 +43,8 @@ SONG_SECONDS = 240
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the row GEMMs run six bf16 products per fp32 multiply-add)
 METRIC = "audio-sec separated / wall-sec (RTF), UVR-MDX-NET 44.1kHz stereo, 1/2/4/8 GPU"
-PMC_FILES = ("r03_pmc_conv3x3.json", "r02_pmc_conv3x3.json", "r01_pmc_conv3x3.json")
-PMC_FILES_WINO = ("r03_pmc_wino3.json",)
+PMC_FILES = ("r05_pmc_conv3x3.json", "r03_pmc_conv3x3.json", "r02_pmc_conv3x3.json", "r01_pmc_conv3x3.json")
+PMC_FILES_WINO = ("r05_pmc_wino3.json", "r04_pmc_wino3.json", "r03_pmc_wino3.json")
 
 
 def cpu_baseline(seconds: float, seed: int):
@@ -134,10 +134,58 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def per_level_table(launch_recs, g, wino, num_blocks=11, bf16x6=True):
+    """The 3x3 TFC convs and the TDF row GEMMs of one profiled pass, grouped by U-Net level (VERDICT r4 next #2c).  A conv's level
+    follows from its own algorithmic figures -- 3x3 conv c -> c over a plane P: flops = 18 c^2 P, bytes = 8 c P, so
+    c = 4 flops / (9 bytes), level = c / g - 1; the 2 x num_blocks TDF launches come in the net's block order (encoder levels
+    0 .. n-1, bottleneck n, decoder n-1 .. 0, two linears each).  Per level: launches, summed and average milliseconds, the
+    algorithmic rate and the fraction of the matrix peak the launches EXECUTE (Winograd F(2x2,3x3): 4/9 of the direct
+    convolution's FLOPs on the fp32 pipe; bf16 x 6 row GEMM: six bf16 products per multiply-add against the bf16 peak), and the time
+    the launch's algorithmic bytes take at the 6.29 TB/s a device copy reaches."""
+    def add(tab, key, ms, flops, nbytes):
+        r = tab.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        r["launches"] += 1
+        r["ms"] += ms
+        r["flops"] += flops
+        r["bytes"] += nbytes
+    conv, tdf = {}, {}
+    n = num_blocks // 2
+    order = list(range(n)) + [n] + list(range(n - 1, -1, -1))
+    tdf_recs = [r for r in launch_recs if r[0] == "tdf"]
+    if len(tdf_recs) == 2 * num_blocks:
+        for i, (_, ms, flops, nbytes) in enumerate(tdf_recs):
+            add(tdf, (order[i // 2], i % 2), ms, flops, nbytes)
+    for cls, ms, flops, nbytes in launch_recs:
+        if cls == "conv3x3" and nbytes > 0:
+            add(conv, int(round(4.0 * flops / (9.0 * nbytes) / g)) - 1, ms, flops, nbytes)
+    out = {"conv3x3": {}, "tdf": {}}
+    exf = (4.0 / 9.0) if wino else 1.0
+    for lvl in sorted(conv):
+        r = conv[lvl]
+        tf = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        out["conv3x3"][f"L{lvl}"] = {
+            "channels": g * (lvl + 1), "launches": r["launches"], "ms": round(r["ms"], 3), "avg_launch_ms": round(r["ms"] / r["launches"], 4),
+            "algorithmic_tflops": round(tf, 1), "executed_tflops": round(tf * exf, 1), "frac": round(tf * exf / PEAK_FP32_MFMA_TFLOPS, 4),
+            "algorithmic_gb_per_launch": round(r["bytes"] / r["launches"] / 1e9, 3),
+            "hbm_floor_ms_per_launch": round(r["bytes"] / r["launches"] / 6.29e12 * 1e3, 3)}
+    for (lvl, which) in sorted(tdf):
+        r = tdf[(lvl, which)]
+        tf = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        ent = {"launches": r["launches"], "ms": round(r["ms"], 3), "avg_launch_ms": round(r["ms"] / r["launches"], 4), "fp32_equivalent_tflops": round(tf, 1),
+               "algorithmic_gb_per_launch": round(r["bytes"] / r["launches"] / 1e9, 3),
+               "hbm_floor_ms_per_launch": round(r["bytes"] / r["launches"] / 6.29e12 * 1e3, 3)}
+        if bf16x6:
+            ent.update({"executed_tflops_bf16": round(6 * tf, 1), "frac": round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4)})
+        else:
+            ent["frac"] = round(tf / PEAK_FP32_MFMA_TFLOPS, 4)
+        out["tdf"][f"L{lvl}.{'F_to_F8' if which == 0 else 'F8_to_F'}"] = ent
+    return out
+
+
 def pmc_child(args):
     """What the live-traffic passes profile: one warm-up and one measured demix of the bench song, nothing else."""
     import torch
-    from oracle import mdx_oracle as O
+    from workload import synth as O              # seeded synthetic weights / song (neutral: not the checker package)
     import audio_separator_amd as A
     d = O.NetDims()
     sd = O.make_convtdf_state(d, seed=0)
@@ -221,7 +269,7 @@ def main():
     if args.dry_gloo:
         return dry_run(args, world, rank)
 
-    from oracle import mdx_oracle as O           # synthetic weights/input generator + cpu_baseline leg only
+    from workload import synth as O              # seeded synthetic weights / song; oracle/ is imported by cpu_baseline() only
     import audio_separator_amd as A
     from audio_separator_amd.sharding import HipEngineAdapter, sharded_demix
 
@@ -328,6 +376,7 @@ def main():
         eng.profile_enable(True)
         eng.demix_dev(m0.data_ptr(), N, o0.data_ptr(), stream=stream)
         prof = eng.profile_read()
+        launch_recs = eng.profile_launches()
         eng.profile_enable(False)
         c = prof["conv3x3"]
         ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
@@ -350,13 +399,11 @@ def main():
         # under `algorithmic`; it can exceed the peak and is NOT a roofline fraction.
         exf = (4.0 / 9.0) if wino else 1.0
         if world == 1 and args.traffic == "live":
-            eng_free = True
             live, nlaunch, why = live_traffic(args, "conv_wino3_kernel" if wino else "conv_dma_kernel<asx::ConvDmaCfg<3, 3, 1, 1")
             if live is not None:
                 traffic, source = round(live, 1), why
             else:
                 source = (source or "") + f" [live measurement unavailable: {why}]"
-            del eng_free
         roofline = {"kernel": ("conv_wino3_kernel (TFC 3x3 convs, Winograd F(2x2,3x3) on fp32 MFMA)" if wino
                                else "conv_dma_kernel<3,3,1,1,3,4,2,0> (TFC 3x3 convs)"),
                     "bound": "mfma", "achieved": round(ach * exf, 2),
@@ -367,6 +414,7 @@ def main():
                     "avg_launch_ms": round(c["ms"] / max(1, c["launches"]), 4),
                     "flops_per_launch": c["flops"] / max(1, c["launches"]) * exf,
                     "share_of_step_ms": round(c["ms"], 2)}
+        roofline["per_level"] = per_level_table(launch_recs, d.g, wino, d.num_blocks, eng.option("gemm_bf16x6") > 0)
         if wino:
             roofline["note"] = ("achieved / frac = EXECUTED MFMA FLOPs (Winograd F(2x2,3x3): 4/9 of the direct convolution's) / launch time "
                                 "/ fp32-MFMA peak; `algorithmic` = direct-convolution FLOPs over the same time (may exceed the peak, not a "
@@ -481,7 +529,7 @@ def file_level_line(args, sd):
     import audio_separator_amd as A
     from audio_separator_amd import audio_io
     from audio_separator_amd.architectures.mdx_separator import MDXSeparator
-    from oracle import mdx_oracle as O
+    from workload import synth as O
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     tmp = tempfile.mkdtemp(prefix="asx_file_level_", dir=base)
     try:

@@ -47,7 +47,7 @@ extern "C" {
 #define ASX_ERR_HIP 2     /* a HIP runtime call failed (no GPU, OOM, launch) */
 #define ASX_ERR_STATE 3   /* call order violated (e.g. demix before commit)  */
 
-#define ASX_ABI_VERSION 5
+#define ASX_ABI_VERSION 6
 
 /* flags of asx_demix*(): */
 #define ASX_FLAG_MATCH_MIX 1u /* demix(mix, is_match_mix=True): overlap 0.02, no net (mdx_separator.py:308-313, :429-432) */
@@ -477,9 +477,13 @@ int asx_ensemble_dev(asx_engine *e, const float *waves_dev, int32_t k, int64_t n
                      float *out_dev, int64_t *n_out, void *stream);
 int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host, int64_t n_samples, float *out_host, int64_t *n_out);
 
-/* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host.  "counter.<name>" writes a launch counter
- * of this process into host[0] (tests use them to prove which kernel family ran): tdf3_launches (bf16 x 6 row GEMM),
- * tdf3_gather_launches (its GATHER mode: channels-last convolutions), attn6_launches (attention6_kernel / mha6_kernel). */
+/* Launch counters of this process (tests use them to prove which kernel family ran; ABI 6 -- until ABI 5 they travelled through a
+ * float of asx_debug_fetch, which stops resolving single launches past 2^24): "tdf3_launches" (bf16 x 6 row GEMM),
+ * "tdf3_gather_launches" (its GATHER mode: channels-last convolutions), "attn6_launches" (attention6_kernel / mha6_kernel),
+ * "wino6_launches" (conv_wino6_kernel: Winograd F(2x2,3x3) on the bf16 pipe).  ASX_ERR_INVALID for an unknown name. */
+int asx_counter(const asx_engine *e, const char *name, int64_t *out);
+
+/* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host. */
 int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel);
 /* measurement hook: the s_memtime timeline the ASX_TDF2_ABL=16 build of the row GEMM records (8 x uint64 per workgroup). */
 int asx_debug_trace(uint64_t *host, int64_t n_u64);
@@ -517,13 +521,19 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
  * "winograd_stationary": 1 (also ASX_WINOS) = layers with at most 96 input channels run the weight-stationary form of the same
  * transform (csrc/kernels_winos.h: the transformed weights stay in registers, positions split over eight waves) when "winograd"
  * is 3; 0 (default: the stationary form measured slower, profiles/NOTES.md) = conv_wino3_kernel for every layer.
- * "gemm_bf16x6" (PROCESS-wide; also ASX_GEMM_BF16X6 in the environment): 1 (default) = every row GEMM whose shape allows it
+ * "gemm_bf16x6" (per engine since ABI 6 -- it was process-wide; also ASX_GEMM_BF16X6 in the environment): 1 (default) = every row GEMM whose shape allows it
  * (K % 32 == 0, K >= 64, N > 64, N % 8 == 0, 16-byte aligned rows) runs csrc/kernels_gemm3.h -- both fp32 operands split EXACTLY into three
  * bf16 parts, six bf16 MFMA products with fp32 accumulation, the dropped cross terms below 2^-24 of a product: fp32-grade results
  * (closer to a float64 GEMM than the fp32-MFMA kernel on every measured shape) at 1.7-1.9x its speed; the same switch covers the
  * GATHER mode of that kernel (stride-1 / strided convolutions of the channels-last VR and Demucs nets with Cin % 32 == 0 and at least
  * 48 output channels) and the attention kernels of the Roformer / HTDemucs transformers (attention6_kernel, mha6_kernel);
- * 0 = the fp32-MFMA kernels (csrc/kernels_gemm2.h, kernels_halo.h, kernels_ht.h, kernels_rof.h) everywhere. */
+ * 0 = the fp32-MFMA kernels (csrc/kernels_gemm2.h, kernels_halo.h, kernels_ht.h, kernels_rof.h) everywhere.
+ * The split weight images these kernels read are built on the FIRST forward after a load (one small kernel + one stream
+ * synchronise per weight tensor) and belong to the engine: they are freed only when this engine's weights are re-loaded or the engine
+ * is destroyed, never by another engine of the process -- so a hipGraph captured after one warm-up call stays valid while other
+ * engines load and unload.  Non-finite inputs are outside the parity domain of either setting and behave differently: an Inf / NaN
+ * in a GEMM row makes that row's accumulators NaN under 1 (h = Inf, v - h = NaN) and +-Inf / NaN under 0; the ReLU epilogues then
+ * return 0 for NaN (maxNum).  No other row is affected (tests/test_gpu_parity.py::test_rowgemm_bf16x6_nonfinite_rows). */
 int asx_set_option(asx_engine *e, const char *key, int32_t value);
 
 /* ---- profiling ---------------------------------------------------------- */

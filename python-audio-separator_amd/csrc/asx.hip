@@ -139,6 +139,13 @@ struct HdNet;
 struct VrNet;
 struct EnsCtx;
 
+// split image of one weight matrix for the bf16 x 6 kernels (kernels_gemm3.h); owned by the engine (asx_engine::w3)
+struct W3Entry {
+  const float *w;
+  int N, K, cin;                                       // cin > 0: the (tap, chunk)-padded image of the GATHER mode, else 0
+  void *img;
+};
+
 // what the fold's divider table was built for (asx_finalize_dev)
 struct DivKey {
   int64_t N = -1;
@@ -197,6 +204,13 @@ struct asx_engine {
   // is 3; 0 (default -- the stationary form measured 3-8 % slower, profiles/NOTES.md round 4): conv_wino3_kernel everywhere.
   // ASX_WINOS or asx_set_option("winograd_stationary", n).
   int winos = getenv("ASX_WINOS") ? std::max(0, atoi(getenv("ASX_WINOS"))) : 0;
+  // 1 (default): row GEMMs, channels-last convolutions (GATHER mode) and attention of THIS engine run the bf16 x 6 kernels when their
+  // shapes allow (kernels_gemm3.h); 0: the fp32-MFMA kernels.  ASX_GEMM_BF16X6 or asx_set_option("gemm_bf16x6", n).
+  int gemm_bf16x6 = getenv("ASX_GEMM_BF16X6") ? atoi(getenv("ASX_GEMM_BF16X6")) : 1;
+  // split (bf16 x 3) images of this engine's weight matrices, built on first use and freed only with the engine or when the engine's
+  // own weights are re-loaded: another engine of the process can never invalidate a pointer a captured graph of this one holds
+  std::vector<W3Entry> w3;
+  std::mutex w3_mu;
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -808,35 +822,37 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
 }
 
 // ---- third-generation row GEMM (kernels_gemm3.h): fp32 results from six bf16 MFMA products on exactly split operands ----------
-// Process-wide switch: ASX_GEMM_BF16X6 (default 1) or asx_set_option(e, "gemm_bf16x6", n); 0 = the fp32-MFMA kernels only.
-static std::atomic<int> g_gemm_bf16x6{getenv("ASX_GEMM_BF16X6") ? atoi(getenv("ASX_GEMM_BF16X6")) : 1};
+// Per-engine switch (asx_engine::gemm_bf16x6): ASX_GEMM_BF16X6 (default 1) or asx_set_option(e, "gemm_bf16x6", n); 0 = the fp32-MFMA kernels only.
 // launches of tdf3_kernel since the process started (tests assert that the path under test is the one that ran)
 static std::atomic<long long> g_tdf3_launches{0};
 static std::atomic<long long> g_attn6_launches{0};   // launches of attention6_kernel (kernels_rof.h)
+static std::atomic<long long> g_wino6_launches{0};   // launches of conv_wino6_kernel (kernels_wino6.h)
 
-// The split image of a weight matrix is built on first use and cached by (pointer, N, K).  Every entry point that uploads or frees
-// weights bumps the epoch (w3_epoch_bump), which flushes the whole cache at the next lookup -- an address reused by another
-// tensor of the same shape can therefore never meet a stale image.
-struct W3Entry {
-  const float *w;
-  int N, K, cin;                                       // cin > 0: the (tap, chunk)-padded image of the GATHER mode, else 0
-  void *img;
-};
-static std::mutex g_w3_mu;
-static std::vector<W3Entry> g_w3;
-static std::atomic<uint64_t> g_w3_epoch{1};
-static uint64_t g_w3_cache_epoch = 0;
-static void w3_epoch_bump() { g_w3_epoch.fetch_add(1); }
+// The split image of a weight matrix is built on first use and cached PER ENGINE by (pointer, N, K, cin) (asx_engine::w3).  Every
+// entry point that uploads or frees weights of an engine flushes that engine's images (w3_flush) -- an address reused by another tensor
+// of the same shape can therefore never meet a stale image, and no other engine's load / destroy touches them (round 5: the cache
+// was process-wide, so a second engine's commit freed images a captured hipGraph of the first still pointed at).
+static void w3_flush(asx_engine *e) {
+  std::lock_guard<std::mutex> lk(e->w3_mu);
+  for (auto &en : e->w3) (void)hipFree(en.img);
+  e->w3.clear();
+}
 
-static const u32x4 *w3_image(const float *w, int N, int K, hipStream_t s, int cin = 0) {
-  std::lock_guard<std::mutex> lk(g_w3_mu);
-  const uint64_t ep = g_w3_epoch.load();
-  if (ep != g_w3_cache_epoch) {
-    for (auto &en : g_w3) (void)hipFree(en.img);
-    g_w3.clear();
-    g_w3_cache_epoch = ep;
-  }
-  for (auto &en : g_w3)
+// drop the images of ONE weight buffer (a temporary layer of the single-op test hooks, about to be freed)
+static void w3_drop(asx_engine *e, const void *w) {
+  std::lock_guard<std::mutex> lk(e->w3_mu);
+  for (size_t i = 0; i < e->w3.size();)
+    if (e->w3[i].w == w) {
+      (void)hipFree(e->w3[i].img);
+      e->w3.erase(e->w3.begin() + (long)i);
+    } else {
+      ++i;
+    }
+}
+
+static const u32x4 *w3_image(asx_engine *e, const float *w, int N, int K, hipStream_t s, int cin = 0) {
+  std::lock_guard<std::mutex> lk(e->w3_mu);
+  for (auto &en : e->w3)
     if (en.w == w && en.N == N && en.K == K && en.cin == cin) return reinterpret_cast<const u32x4 *>(en.img);
   const int nst = cin > 0 ? (K / cin) * ((cin + 31) / 32) : 0;
   const int ntiles = (N + 15) / 16, nk = cin > 0 ? ((nst + 1) & ~1) : ((K + 63) / 64) * 2;   // an even number of 32-wide stages (zero padded)
@@ -845,36 +861,40 @@ static const u32x4 *w3_image(const float *w, int N, int K, hipStream_t s, int ci
   const int64_t total = (int64_t)ntiles * nk * 64;
   hipLaunchKernelGGL(w3_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<u32x4 *>(en.img), N, K,
                      total, cin, nst);
-  // built once per weight tensor: make the image visible to every stream before it is published
+  // built once per weight tensor (the first forward after a load): make the image visible to every stream before it is published
   if (hipStreamSynchronize(s) != hipSuccess) {
     (void)hipFree(en.img);
     return nullptr;
   }
-  g_w3.push_back(en);
+  e->w3.push_back(en);
   return reinterpret_cast<const u32x4 *>(en.img);
 }
 
-static bool tdf3_ok(const TdfDmaArgs &d) {
+static bool tdf3_ok(const asx_engine *e, const TdfDmaArgs &d) {
   auto a16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const int64_t lda = d.lda ? d.lda : d.K, ldy = d.ldy ? d.ldy : d.N, ldr = d.ldr ? d.ldr : d.N;
   if (d.relu == 1 && (d.rscale != nullptr || d.rot_tab != nullptr)) return false;   // as tdf2_ok: the ReLU ring epilogue applies neither
-  return g_gemm_bf16x6.load() > 0 && d.K % 32 == 0 && d.K >= 64 && d.M >= 1 && d.M < (1ll << 31) && d.T > 0 && d.C > 0 && d.N % 8 == 0 &&
+  return e->gemm_bf16x6 > 0 && d.K % 32 == 0 && d.K >= 64 && d.M >= 1 && d.M < (1ll << 31) && d.T > 0 && d.C > 0 && d.N % 8 == 0 &&
          d.N > 64 && lda % 4 == 0 && ldy % 4 == 0 && ldr % 4 == 0 && a16(d.x) && a16(d.w) && a16(d.y) && (!d.res || a16(d.res)) &&
          (!d.bias || a16(d.bias)) && (uint64_t)16 * (uint64_t)ldy * 4 < (1ull << 31) && (uint64_t)16 * (uint64_t)ldr * 4 < (1ull << 31);
 }
 template <int NREP, int MREP, int ABL>
-static void launch_tdf3_abl(const TdfDmaArgs &a, const u32x4 *w3, hipStream_t s) {
+static void launch_tdf3_abl(const TdfDmaArgs &a0, const u32x4 *w3, hipStream_t s) {
   constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = 2 * 3 * BM * 64;
+  TdfDmaArgs a = a0;
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
+  // tile -> XCD map (kernels_gemm3.h); ASX_TDF3_MAP = "<narrow><wide>" digits for N < 8 tiles / N >= 8 tiles (A/B switch)
+  static const int map_env = getenv("ASX_TDF3_MAP") ? atoi(getenv("ASX_TDF3_MAP")) : -1;
+  if (map_env >= 0) a.tile_map = nbn >= 8 ? map_env % 10 : map_env / 10;
   hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3, RowGather{});
   g_tdf3_launches.fetch_add(1);
 }
 // GATHER mode (kernels_gemm3.h): stride-1 convolutions of the channels-last nets as implicit GEMMs on the same kernel
 static std::atomic<long long> g_tdf3_gather_launches{0};
 template <int NREP, int MREP>
-static bool launch_tdf3_gather(const TdfDmaArgs &a, const RowGather &gq, hipStream_t s) {
-  const u32x4 *w3 = w3_image(a.w, a.N, a.K, s, (gq.cin & 31) ? gq.cin : 0);   // channel counts off the 32-grid get their own padded image
+static bool launch_tdf3_gather(asx_engine *e, const TdfDmaArgs &a, const RowGather &gq, hipStream_t s) {
+  const u32x4 *w3 = w3_image(e, a.w, a.N, a.K, s, (gq.cin & 31) ? gq.cin : 0);   // channel counts off the 32-grid get their own padded image
   if (!w3) return false;
   constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = 2 * 3 * BM * 64;
   const int64_t nbm = (a.M + BM - 1) / BM;
@@ -883,22 +903,22 @@ static bool launch_tdf3_gather(const TdfDmaArgs &a, const RowGather &gq, hipStre
   g_tdf3_gather_launches.fetch_add(1);
   return true;
 }
-static bool launch_tdf3_gather_auto(const TdfDmaArgs &d, const RowGather &gq, hipStream_t s) {
+static bool launch_tdf3_gather_auto(asx_engine *e, const TdfDmaArgs &d, const RowGather &gq, hipStream_t s) {
   if (d.glu_cout > 0) {                                // value / gate fragment pairs: 128-column tiles (two fragments per wave)
     const bool small = (d.M + 127) / 128 * ((d.N + 127) / 128) < 1024;   // grid too small for 128-row tiles to fill the chip twice
-    return small ? launch_tdf3_gather<2, 4>(d, gq, s) : launch_tdf3_gather<2, 8>(d, gq, s);
+    return small ? launch_tdf3_gather<2, 4>(e, d, gq, s) : launch_tdf3_gather<2, 8>(e, d, gq, s);
   }
-  if (d.N <= 64) return launch_tdf3_gather<1, 8>(d, gq, s);   // narrow layers (48 .. 64 columns): one fragment per wave
+  if (d.N <= 64) return launch_tdf3_gather<1, 8>(e, d, gq, s);   // narrow layers (48 .. 64 columns): one fragment per wave
   if (d.N > 128) {
     const double rows = (double)((d.M + 127) / 128);
     auto cost = [&](int bn, double eff) { return ceil(rows * (double)((d.N + bn - 1) / bn) / 512.0) * bn / eff; };
-    return cost(128, 0.96) < cost(192, 1.0) ? launch_tdf3_gather<2, 8>(d, gq, s) : launch_tdf3_gather<3, 8>(d, gq, s);
+    return cost(128, 0.96) < cost(192, 1.0) ? launch_tdf3_gather<2, 8>(e, d, gq, s) : launch_tdf3_gather<3, 8>(e, d, gq, s);
   }
-  return launch_tdf3_gather<2, 4>(d, gq, s);
+  return launch_tdf3_gather<2, 4>(e, d, gq, s);
 }
 template <int NREP, int MREP>
-static bool launch_tdf3(const TdfDmaArgs &a, hipStream_t s) {
-  const u32x4 *w3 = w3_image(a.w, a.N, a.K, s);
+static bool launch_tdf3(asx_engine *e, const TdfDmaArgs &a, hipStream_t s) {
+  const u32x4 *w3 = w3_image(e, a.w, a.N, a.K, s);
   if (!w3) return false;                               // out of memory for the image: the caller falls back to the fp32 kernels
   static const int abl = getenv("ASX_TDF3_ABL") ? atoi(getenv("ASX_TDF3_ABL")) : 0;   // ablation builds exist for the 128 x 192 tile only
   if constexpr (NREP == 3 && MREP == 8) {
@@ -915,12 +935,12 @@ static bool launch_tdf3(const TdfDmaArgs &a, hipStream_t s) {
   return true;
 }
 
-static void launch_tdf_dma_auto(const TdfDmaArgs &d, hipStream_t s) {
+static void launch_tdf_dma_auto(asx_engine *e, const TdfDmaArgs &d, hipStream_t s) {
   static const int t128 = getenv("ASX_GEMM_T128") ? atoi(getenv("ASX_GEMM_T128")) : 1;
   const bool v2 = tdf2_ok(d);
   static const int small = getenv("ASX_TDF2_SMALL") ? atoi(getenv("ASX_TDF2_SMALL")) : 0;   // A/B: 64 x 128 tiles (3+ workgroups per CU) on short-K layers
-  const bool v3 = tdf3_ok(d);
-  if (v3 && ((small && d.K <= small) || d.prefer_small) && d.N > 128 && launch_tdf3<2, 4>(d, s)) return;
+  const bool v3 = tdf3_ok(e, d);
+  if (v3 && ((small && d.K <= small) || d.prefer_small) && d.N > 128 && launch_tdf3<2, 4>(e, d, s)) return;
   if (v2 && ((small && d.K <= small) || d.prefer_small) && d.N > 128) return launch_tdf2<2, 4>(d, s);
   if (d.N > 128) {
     const double rows = (double)((d.M + 127) / 128);
@@ -934,11 +954,11 @@ static void launch_tdf_dma_auto(const TdfDmaArgs &d, hipStream_t s) {
     // the fp32 kernel's figure (N = 512 stays on four 128-column tiles).
     static const double eff128 = getenv("ASX_TDF3_EFF128") ? atof(getenv("ASX_TDF3_EFF128")) : 0.96;
     const bool narrow3 = t128 == 2 || (t128 == 1 && cost(128, eff128) < cost(192, 1.0));
-    if (v3 && (narrow3 ? launch_tdf3<2, 8>(d, s) : launch_tdf3<3, 8>(d, s))) return;
+    if (v3 && (narrow3 ? launch_tdf3<2, 8>(e, d, s) : launch_tdf3<3, 8>(e, d, s))) return;
     if (narrow) v2 ? launch_tdf2<2, 8>(d, s) : launch_tdf_dma_t<2, 8>(d, s);
     else v2 ? launch_tdf2<3, 8>(d, s) : launch_tdf_dma_t<3, 8>(d, s);
   } else if (d.N > 64) {
-    if (v3 && launch_tdf3<2, 4>(d, s)) return;
+    if (v3 && launch_tdf3<2, 4>(e, d, s)) return;
     v2 ? launch_tdf2<2, 4>(d, s) : launch_tdf_dma_t<2, 4>(d, s);
   } else {
     launch_tdf_dma_t<1, 4>(d, s);
@@ -984,7 +1004,7 @@ static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const fl
   d.nt = ((nt_mode >> 1) & 1) | ((nt_mode >> 2) & 1) << 1;
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
     if (dma) {
-      launch_tdf_dma_auto(d, s);
+      launch_tdf_dma_auto(e, d, s);
     } else {
       if (L.n > 128) launch_tdf_t<3, 8>(a, s);
       else if (L.n > 64) launch_tdf_t<2, 4>(a, s);
@@ -995,7 +1015,6 @@ static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const fl
 
 static int tdf_pack(TdfLayer &L, int n, int k, int c, const float *w, const float *bias, const float *scale,
                     const float *shift) {
-  w3_epoch_bump();
   L.n = n;
   L.k = k;
   L.c = c;
@@ -1377,7 +1396,7 @@ static void free_block(Block &b) {
 }
 
 void asx_engine_destroy(asx_engine *e) {
-  w3_epoch_bump();
+  w3_flush(e);
   if (!e) return;
   (void)hipSetDevice(e->device);
   for (auto &r : e->recs) {
@@ -1424,7 +1443,7 @@ void asx_engine_destroy(asx_engine *e) {
 
 // ---- weights ---------------------------------------------------------------
 int asx_net_begin(asx_engine *e, const asx_net_config *cfg) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e && cfg, "asx_net_begin: null argument");
   REQUIRE(cfg->dim_f == e->cfg.dim_f, "net dim_f %d != engine dim_f %d", cfg->dim_f, e->cfg.dim_f);
   REQUIRE(cfg->dim_t == e->cfg.segment_size, "net dim_t %d != segment_size %d", cfg->dim_t, e->cfg.segment_size);
@@ -1499,7 +1518,7 @@ static int build_block(asx_engine *e, Block &blk, const std::string &pre, int c,
 }
 
 int asx_net_commit(asx_engine *e) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e, "asx_net_commit: null engine");
   if (!e->net_begun) {
     set_err("asx_net_commit before asx_net_begin");
@@ -2167,14 +2186,15 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t B, int32_t c, int32_t
   CHK(dy.ensure((size_t)M * n * 4));
   HIPCHK(hipMemset(dy.p, 0xff, (size_t)M * n * 4));
   if (res_host) CHK(to_dev(dres, res_host, (size_t)M * n));
-  CHK(tdf_launch(e, L, dx.f(), res_host ? dres.f() : nullptr, dy.f(), M, t, nullptr));
-  CHK(to_host(y_host, dy, (size_t)M * n));
-  return ASX_OK;
+  const int rc = tdf_launch(e, L, dx.f(), res_host ? dres.f() : nullptr, dy.f(), M, t, nullptr);
+  const int rc2 = rc == ASX_OK ? to_host(y_host, dy, (size_t)M * n) : rc;   // synchronises: the launch is done with the image
+  w3_drop(e, L.w.p);                                   // the temporary layer's split image goes with its weight buffer
+  return rc2;
 }
 
 // ---- MDXC / TFC-TDF v3 --------------------------------------------------------------
 int asx_v3_begin(asx_engine *e, const asx_v3_config *cfg) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e && cfg, "asx_v3_begin: null argument");
   REQUIRE(cfg->num_channels == 2, "only stereo (num_channels = 2) is supported");
   REQUIRE(cfg->num_subbands >= 1 && e->cfg.dim_f % cfg->num_subbands == 0, "dim_f must be divisible by num_subbands");
@@ -2198,7 +2218,7 @@ int asx_v3_begin(asx_engine *e, const asx_v3_config *cfg) {
 }
 
 int asx_v3_commit(asx_engine *e) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e, "asx_v3_commit: null engine");
   if (!e->v3 || !e->v3->begun) {
     set_err("asx_v3_commit before asx_v3_begin");
@@ -2367,7 +2387,7 @@ int asx_mdxc_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t over
 
 // ---- BS-Roformer ------------------------------------------------------------------
 int asx_rof_begin(asx_engine *e, const asx_rof_config *cfg) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e && cfg, "asx_rof_begin: null argument");
   REQUIRE(cfg->dim_head == 64, "dim_head must be 64 (got %d)", cfg->dim_head);
   REQUIRE(cfg->dim > 0 && cfg->dim % 4 == 0 && cfg->depth >= 1 && cfg->heads >= 1 && cfg->num_stems >= 1 &&
@@ -2414,7 +2434,7 @@ int asx_rof_begin(asx_engine *e, const asx_rof_config *cfg) {
 }
 
 int asx_rof_commit(asx_engine *e) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e, "asx_rof_commit: null engine");
   if (!e->rof || !e->rof->begun) {
     set_err("asx_rof_commit before asx_rof_begin");
@@ -2647,7 +2667,7 @@ int asx_rof_demix(asx_engine *e, const float *mix_host, int64_t N, int64_t step,
 // ---- options -----------------------------------------------------------------------
 // ---- Demucs v4 ---------------------------------------------------------------------
 int asx_ht_begin(asx_engine *e, const asx_ht_config *cfg) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e && cfg, "asx_ht_begin: null argument");
   REQUIRE(cfg->n_sources >= 1 && cfg->channels >= 4 && cfg->growth >= 1 && cfg->depth >= 1 && cfg->depth <= 8,
           "bad HTDemucs hyper-parameters");
@@ -2671,7 +2691,7 @@ int asx_ht_begin(asx_engine *e, const asx_ht_config *cfg) {
 }
 
 int asx_ht_commit(asx_engine *e) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e, "asx_ht_commit: null engine");
   if (!e->ht || !e->ht->begun) {
     set_err("asx_ht_commit before asx_ht_begin");
@@ -2782,7 +2802,7 @@ int asx_ht_demix(asx_engine *e, const float *mix_host, int64_t N, int32_t shifts
 
 // ---- Demucs v3 (HDemucs) -------------------------------------------------------------
 int asx_hd_begin(asx_engine *e, const asx_hd_config *cfg) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e && cfg, "asx_hd_begin: null argument");
   REQUIRE(cfg->n_sources >= 1 && cfg->channels >= 4 && cfg->growth >= 1 && cfg->depth >= 3 && cfg->depth <= 8, "bad HDemucs hyper-parameters");
   REQUIRE(cfg->kernel_size == 8 && cfg->stride == 4 && cfg->time_stride == 2,
@@ -2822,7 +2842,7 @@ int asx_hd_begin(asx_engine *e, const asx_hd_config *cfg) {
 }
 
 int asx_hd_commit(asx_engine *e) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e, "asx_hd_commit: null engine");
   if (!e->hd || !e->hd->begun) {
     set_err("asx_hd_commit before asx_hd_begin");
@@ -2916,7 +2936,7 @@ int asx_hd_fold_dev(asx_engine *e, const float *mix_dev, int64_t N, int32_t shif
 
 // ---- VR ------------------------------------------------------------------------------
 int asx_vr_begin(asx_engine *e, const asx_vr_config *cfg) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e && cfg, "asx_vr_begin: null argument");
   REQUIRE(cfg->n_bands >= 1 && cfg->n_bands <= 8 && cfg->bins >= 32, "bad band layout");
   REQUIRE(cfg->channel_mode >= 0 && cfg->channel_mode <= 3, "bad channel_mode");
@@ -2935,7 +2955,7 @@ int asx_vr_begin(asx_engine *e, const asx_vr_config *cfg) {
 }
 
 int asx_vr_commit(asx_engine *e) {
-  w3_epoch_bump();
+  w3_flush(e);
   REQUIRE(e, "asx_vr_commit: null engine");
   if (!e->vr || !e->vr->begun) {
     set_err("asx_vr_commit before asx_vr_begin");
@@ -3034,6 +3054,21 @@ int asx_vr_separate(asx_engine *e, const float *wave_host, int64_t n_samples, co
   return ASX_OK;
 }
 
+// launch counters of the bf16 x 6 kernels since the process started (tests assert that the path under test is the one that ran)
+int asx_counter(const asx_engine *e, const char *name, int64_t *out) {
+  REQUIRE(e && name && out, "asx_counter: null argument");
+  const std::string nm(name);
+  if (nm == "tdf3_launches") *out = (int64_t)g_tdf3_launches.load();
+  else if (nm == "attn6_launches") *out = (int64_t)g_attn6_launches.load();
+  else if (nm == "tdf3_gather_launches") *out = (int64_t)g_tdf3_gather_launches.load();
+  else if (nm == "wino6_launches") *out = (int64_t)g_wino6_launches.load();
+  else {
+    set_err("asx_counter: unknown counter '%s'", name);
+    return ASX_ERR_INVALID;
+  }
+  return ASX_OK;
+}
+
 // debug hook: copy `numel` floats of a named engine workspace buffer to the host (tests / bring-up only)
 int asx_debug_trace(uint64_t *host, int64_t n_u64) {
   REQUIRE(host && n_u64 > 0 && n_u64 <= 4096 * 8, "asx_debug_trace: bad argument");
@@ -3047,18 +3082,6 @@ int asx_debug_fetch(asx_engine *e, const char *name, float *host, int64_t numel)
   HIPCHK(hipSetDevice(e->device));
   const float *src = nullptr;
   const std::string nm(name);
-  if (nm == "counter.tdf3_launches") {                 // launches of the bf16x6 row GEMM since the process started (as a float)
-    host[0] = (float)g_tdf3_launches.load();
-    return ASX_OK;
-  }
-  if (nm == "counter.attn6_launches") {
-    host[0] = (float)g_attn6_launches.load();
-    return ASX_OK;
-  }
-  if (nm == "counter.tdf3_gather_launches") {
-    host[0] = (float)g_tdf3_gather_launches.load();
-    return ASX_OK;
-  }
   if (e->vr && e->vr->ws_batch > 0) {
     auto &b = e->vr->b;
     if (nm == "vr.hc") src = b.hc;
@@ -3199,8 +3222,8 @@ int asx_set_option(asx_engine *e, const char *key, int32_t value) {
     e->winos = value < 0 ? 0 : (int)value;
     return ASX_OK;
   }
-  if (!strcmp(key, "gemm_bf16x6")) {                 // process-wide (every engine of this process)
-    g_gemm_bf16x6.store(value > 0 ? 1 : 0);
+  if (!strcmp(key, "gemm_bf16x6")) {                 // this engine only (round 5; it was process-wide before)
+    e->gemm_bf16x6 = value > 0 ? 1 : 0;
     return ASX_OK;
   }
   set_err("asx_set_option: unknown option '%s'", key);

@@ -574,7 +574,7 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
     // (ASX_GATHER6_PARTIAL=0: only multiples of 32)
     static const bool gather_partial = !(getenv("ASX_GATHER6_PARTIAL") && atoi(getenv("ASX_GATHER6_PARTIAL")) == 0);
     const bool cin_ok = q.Cin % 32 == 0 || (gather_partial && q.Cin % 8 == 0 && q.Cin > 32 && 10 * q.Cin >= 7 * 32 * ((q.Cin + 31) / 32));
-    if (gather6 && g_gemm_bf16x6.load() > 0 && (mode == GG_DENSE || glu) && res == nullptr && fz == nullptr && (unit || gather_strided) &&
+    if (gather6 && e->gemm_bf16x6 > 0 && (mode == GG_DENSE || glu) && res == nullptr && fz == nullptr && (unit || gather_strided) &&
         q.SI >= 1 && q.SO >= 1 && q.KO <= 3 && q.KO * q.KI > 1 && cin_ok && g.n % 8 == 0 && g.n >= (glu ? 65 : gather_minn) && (q.ldc & 3) == 0 && (ldy & 3) == 0 &&
         a.y_bs == (int64_t)a.OR * q.IR * ldy && a16(x) && a16(y) && a16(g.w.p) && a16(g.b.p) && a.M < (1ll << 31) &&
         (int64_t)(q.KO * q.DO + q.PO + 1) * q.I * q.ldc < (1ll << 31) && (uint64_t)16 * (uint64_t)ldy * 4 < (1ull << 31)) {
@@ -609,7 +609,7 @@ static int ht_gg(asx_engine *e, const HtGemm &g, const float *x, const HtGeom &q
       gq.ldc = q.ldc;
       gq.x_bs = a.x_bs;
       bool done = false;
-      CHK(timed(e, cls, flops, bytes, s, [&]() { done = launch_tdf3_gather_auto(d, gq, s); }));
+      CHK(timed(e, cls, flops, bytes, s, [&]() { done = launch_tdf3_gather_auto(e, d, gq, s); }));
       if (done) return ASX_OK;
     }
   }
@@ -689,7 +689,7 @@ static int ht_linear(asx_engine *e, const HtGemm &g, const float *x, int64_t lda
   const double flops = 2.0 * (double)M * g.n * g.k;
   const double bytes = 4.0 * ((double)M * g.k + (double)M * g.n * (res ? 2 : 1) + (double)g.n * g.k);
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
-    launch_tdf_dma_auto(d, s);
+    launch_tdf_dma_auto(e, d, s);
   });
 }
 
@@ -763,7 +763,7 @@ static int ht_mha(asx_engine *e, const float *q, int64_t ldq, const float *k, co
     static const bool mha_db = getenv("ASX_MHA_DB") && atoi(getenv("ASX_MHA_DB")) != 0;
     // bf16 x 6 form (kernels_ht.h: mha6_kernel) under the process-wide switch of the row GEMM; ASX_MHA6=0: A/B
     static const bool mha6 = !(getenv("ASX_MHA6") && atoi(getenv("ASX_MHA6")) == 0);
-    if (mha6 && g_gemm_bf16x6.load() > 0 && a.decay == nullptr && (dh == 48 || dh == 64) && (ldq & 3) == 0 && (ldkv & 3) == 0 &&
+    if (mha6 && e->gemm_bf16x6 > 0 && a.decay == nullptr && (dh == 48 || dh == 64) && (ldq & 3) == 0 && (ldkv & 3) == 0 &&
         (ldo & 3) == 0) {
       MhaArgs a6 = a;
       const bool wide = nq > 128;                      // 128 queries per workgroup on long sequences

@@ -225,7 +225,7 @@ static int rof_gemm(asx_engine *e, const RofLin &L, const float *x, int64_t lda,
   const double flops = 2.0 * (double)M * L.n * L.k;
   const double bytes = 4.0 * ((double)M * L.k + (double)M * L.n * (res ? 2 : 1) + (double)L.n * L.k);
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
-    launch_tdf_dma_auto(d, s);
+    launch_tdf_dma_auto(e, d, s);
   });
 }
 
@@ -343,7 +343,7 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
         static const int qw = getenv("ASX_ATTN_QW") ? atoi(getenv("ASX_ATTN_QW")) : 1;   // 2: 128 queries per workgroup (measured slower: 357 vs 328 ms)
         // bf16 x 6 form (kernels_rof.h: attention6_kernel) under the process-wide switch of the row GEMM; ASX_ATTN6=0: A/B
         static const bool attn6 = !(getenv("ASX_ATTN6") && atoi(getenv("ASX_ATTN6")) == 0);
-        if (attn6 && g_gemm_bf16x6.load() > 0 && !v1) {
+        if (attn6 && e->gemm_bf16x6 > 0 && !v1) {
           AttnArgs a2 = aa;
           static const int qw6 = getenv("ASX_ATTN6_QW") ? atoi(getenv("ASX_ATTN6_QW")) : 2;   // 128 queries per workgroup on long sequences
           if (qw6 >= 2 && aa.len > 128) {

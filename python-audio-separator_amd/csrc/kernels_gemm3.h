@@ -141,7 +141,17 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
   {
     const int nbm_i = (int)((a.M + BM - 1) / BM);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    if ((gridDim.x & 7) == 0 && nbn >= 8 && (nbn & 7) == 0) {
+    if (a.tile_map == 2 && (nbn & 7) == 0 && (nbm_i & 7) == 0 && (((nbm_i >> 3) * (nbn >> 3)) & 7) == 0) {
+      // 8 x 8 super-tiles, dealt round-robin over the XCDs: the 64 workgroup slots of an XCD hold one super-tile, whose 8 row blocks
+      // of x and 8 column tiles of W are each fetched once per XCD
+      const int sid = (slot >> 6) * 8 + xcd, r = slot & 63, sc = nbn >> 3;
+      bg = (sid % sc) * 8 + (r & 7);
+      bm_i = (int64_t)(sid / sc) * 8 + (r >> 3);
+    } else if (a.tile_map == 1) {
+      const int lid = xcd_remap(blockIdx.x, gridDim.x);
+      bg = lid % nbn;
+      bm_i = lid / nbn;
+    } else if ((gridDim.x & 7) == 0 && nbn >= 8 && (nbn & 7) == 0) {
       const int cx = nbn >> 3;
       bg = xcd * cx + slot % cx;
       bm_i = slot / cx;

@@ -807,6 +807,9 @@ struct TdfDmaArgs {
   const float *rscale;
   int nt;                   // bit 0: non-temporal output stores, bit 1: non-temporal residual loads (ReLU path; A/B switch ASX_NT)
   int prefer_small;         // launcher hint: 64-row tiles (three workgroups per CU) -- the Demucs transformer linears (M ~ 1e5 rows)
+  int tile_map;             // tdf3_kernel tile -> workgroup map: 0 = column tiles partitioned over the XCDs (kernels_gemm2.h), 1 = the column
+                            // tiles of a row block consecutive on ONE XCD (x fetched once, W streamed by every XCD), 2 = 8 x 8 super-tiles
+                            // of (row block, column tile) per XCD
   int glu_cout;             // tdf3_kernel GATHER mode, 128-column tiles only: > 0 = GLU epilogue over value / gate fragment pairs (the rows of W are in
                             // ht_glu_perm order), glu_cout output channels: y[row][c / 2 + ...] = (acc_v + b) * sigmoid(acc_g + b)
 };

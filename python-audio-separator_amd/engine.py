@@ -215,9 +215,7 @@ class HDConfig:
 _FP = C.POINTER(C.c_float)
 _lib = None
 
-_PROCESS_OPTIONS_KEYS = ("gemm_bf16x6",)
-_PROCESS_OPTIONS = {}
-ABI_VERSION = 5   # ASX_ABI_VERSION of include/asx.h the structures below mirror
+ABI_VERSION = 6   # ASX_ABI_VERSION of include/asx.h the structures below mirror
 
 # every symbol include/asx.h declares
 SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_create", "asx_engine_destroy",
@@ -233,7 +231,7 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev",
            "asx_hd_begin", "asx_hd_commit", "asx_hd_flops", "asx_hd_forward", "asx_hd_demix", "asx_hd_demix_dev", "asx_hd_plan",
            "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev", "asx_ht_standardize_dev", "asx_ht_bag_accumulate_dev", "asx_ht_bag_finish_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_normalize_dev", "asx_residual_dev", "asx_profile_launches", "asx_debug_trace",
-           "asx_resample_sinc", "asx_resample_sinc_dev"]
+           "asx_resample_sinc", "asx_resample_sinc_dev", "asx_counter"]
 
 
 class _LaunchRec(C.Structure):     # struct asx_launch_rec
@@ -301,6 +299,7 @@ def load_library():
     lib.asx_rof_demix.argtypes = [vp, _FP, i64, i64, _FP]
     lib.asx_rof_demix_dev.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.asx_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.asx_counter.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     lib.asx_ht_begin.argtypes = [vp, C.POINTER(_HtCfg)]
     lib.asx_ht_commit.argtypes = [vp]
     lib.asx_ht_flops.argtypes = [vp]
@@ -438,10 +437,7 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         self._check(self._lib.asx_set_option(self._h, key.encode(), int(value)))
-        if key in _PROCESS_OPTIONS_KEYS:                 # process-wide switches of the library (include/asx.h)
-            _PROCESS_OPTIONS[key] = 1 if int(value) > 0 else 0
-        else:
-            self._options[key] = int(value)
+        self._options[key] = (1 if int(value) > 0 else 0) if key == "gemm_bf16x6" else int(value)
 
     def option(self, key: str) -> int:
         """Current value of an engine option (the library default when it was never set here)."""
@@ -450,15 +446,13 @@ class Engine:
                     "gemm_bf16x6": 1 if int(os.environ.get("ASX_GEMM_BF16X6", "1")) > 0 else 0}
         if key not in defaults:
             raise AsxError(f"unknown engine option {key!r} (known: {sorted(defaults)})")
-        if key in _PROCESS_OPTIONS_KEYS:
-            return _PROCESS_OPTIONS.get(key, defaults[key])
         return self._options.get(key, defaults[key])
 
     def counter(self, name: str) -> int:
-        """A library counter (asx_debug_fetch "counter.<name>"): "tdf3_launches" = bf16x6 row-GEMM launches of this process."""
-        out = np.zeros(1, np.float32)
-        self._check(self._lib.asx_debug_fetch(self._h, ("counter." + name).encode(), _ptr(out), 1))
-        return int(out[0])
+        """A library launch counter (asx_counter): "tdf3_launches" = bf16x6 row-GEMM launches of this process, ..."""
+        out = C.c_int64(0)
+        self._check(self._lib.asx_counter(self._h, name.encode(), C.byref(out)))
+        return int(out.value)
 
     # -- weights ------------------------------------------------------------
     def load_net(self, net_cfg: NetConfig, tensors: dict):

@@ -68,7 +68,10 @@ def halo_chunks(plan: dict) -> int:
 
 class HipEngineAdapter:
     """Engine adapter over libasx.so for CUDA(HIP) torch tensors."""
-    local_fold = True          # chunk k starts at k * step: a rank can fold its own sample range (sharded_demix fold="local")
+    # chunk k starts at k * step and asx_finalize_dev is a per-sample gather over the covering chunks with an analytic divider
+    # (finalize4_kernel / finalize_div_kernel): a rank can fold its own sample range from its own chunks + the seam halo
+    # (sharded_demix fold="local"; contract spelled out in _sharded_demix_local_fold)
+    local_fold = True
 
     def __init__(self, engine, is_match_mix: bool = False):
         self.engine = engine
@@ -217,11 +220,14 @@ class FilesPipeline:
 class ShardWorkspace:
     """Buffers of sharded_demix, allocated once per (shape, world) and reused: the strong-scaling loop then times compute +
     gather + fold, not the caching allocator.  ``timings`` (when ``timed``) holds event-measured milliseconds of the last
-    call: local compute, gather, fold."""
+    call: local compute, gather, fold.  ``poison`` (tests): the local-fold scheme fills every chunk slot it does NOT hold with NaN
+    before folding, which proves on each call that the fold of the owned sample range reads none of them (the contract of
+    ``local_fold`` below)."""
 
-    def __init__(self, timed: bool = False):
+    def __init__(self, timed: bool = False, poison: bool = False):
         self.key = None
         self.timed = timed
+        self.poison = poison
         self.timings = {}
 
     def get(self, key, make):
@@ -278,8 +284,18 @@ def _sharded_demix_local_fold(adapter, mix, plan, ranges, group, dst, workspace,
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     j0, j1 = own[rank]
+    if workspace is not None and getattr(workspace, "poison", False):
+        held = set(range(k0, k1)) | set(range(max(0, k0 - h), k0))
+        for k in range(nk):
+            if k not in held:
+                allc[k].fill_(float("nan"))
     if j1 > j0:
-        adapter.finalize(allc, n, bufs["full"])        # only [j0, j1) of it is complete: the chunks that cover it are all here
+        # CONTRACT of `local_fold` adapters: finalize is a pure per-sample GATHER -- out[j] depends only on the chunks that cover j
+        # (visited in chunk order) and on an input-independent divider.  Every chunk covering [j0, j1) is here (own range + halo);
+        # all other slots of `allc` are zeros, stale data of the previous song, or NaN under ShardWorkspace(poison=True), and only
+        # [j0, j1) of the result is read.  A scatter / accumulate fold or a measured divider would break this silently: such an
+        # adapter must not set local_fold (tests/test_sharding_gloo.py::test_local_fold_ignores_foreign_chunks).
+        adapter.finalize(allc, n, bufs["full"])
         bufs["slab"][:, : j1 - j0].copy_(bufs["full"][:, j0:j1])
     if timed:
         ev[2].record()

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""Digest of the CPU oracle's output on the WHOLE 4-minute HQ_3-geometry song (BASELINE config 1), for the driver-run GPU test
-tests/test_gpu_fullsong.py.  The oracle run itself is ~4 minutes of CPU (tools/fullsong_oracle.py -> gpurun_cache/fullsong/
-mdx_hq3.npz, 16 windows of 32768 samples); the digest committed here keeps, per window, one contiguous run of 2048 samples
-(anchored at the song's first / last sample for the first / last window) plus every 64th sample of the whole window, float
-stems and the writer's int16 stream, and the calibration scale of the final conv.  Everything else (weights, input) is rebuilt
-from seeds by the test.
+"""Digests of the CPU oracle's output on the WHOLE workload of every BASELINE config, for the driver-run GPU tests in
+tests/test_gpu_fullsong.py.  The oracle runs themselves are minutes of CPU each (tools/fullsong_oracle.py ->
+gpurun_cache/fullsong/<case>.npz: 16 windows of 32768 samples per song, the whole array for the 10-s VR clip); a digest keeps,
+per window, one contiguous run of 2048 samples (anchored at the song's first / last sample for the first / last window) plus
+every 64th sample of the whole window, of every array the record holds (float stems; the writer's int16 stream for the MDX case),
+the whole-song statistics, and the seeds-only parameters the GPU leg needs (the MDX calibration scale).  Weights and input are
+rebuilt from seeds by the test.
 
-    python tools/fullsong_oracle.py --cases mdx_hq3      # only if gpurun_cache/fullsong/mdx_hq3.npz is missing
-    python tests/golden/make_fullsong_digest.py
+    python tools/fullsong_oracle.py --cases <case,...>     # only for records missing under gpurun_cache/fullsong/
+    python tests/golden/make_fullsong_digest.py [case ...]  # default: every case of tools/fullsong_cases.py
 """
 import json
 import os
@@ -18,29 +19,40 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import fullsong_cases as FC  # noqa: E402
+import fullsong_gpu as FG  # noqa: E402
+
 RUN, DEC = 2048, 64
 
 
-def main():
-    src = os.path.join(ROOT, "gpurun_cache", "fullsong", "mdx_hq3.npz")
+def digest(name):
+    src = os.path.join(FC.CACHE, name + ".npz")
     if not os.path.exists(src):
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "fullsong_oracle.py"), "--cases", "mdx_hq3"])
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "fullsong_oracle.py"), "--cases", name])
     z = np.load(src)
     meta = json.loads(str(z["meta"]))
-    starts, w = z["starts"].astype(np.int64), int(z["width"])
-    nwin = len(starts)
+    arrays = FG.record_arrays(z)
+    first = next(iter(arrays.values()))
+    nwin, w = first.shape[-2], first.shape[-1]
+    starts = z["starts"].astype(np.int64) if "starts" in z.files else np.zeros(1, np.int64)
     off = np.zeros(nwin, np.int64)
-    off[-1] = w - RUN                        # the last run ends at the song's last sample
-    out = {"starts": starts, "width": w, "run": RUN, "dec": DEC, "run_offset": off, "scale": z["scale"],
-           "seconds": meta["seconds"], "meta": json.dumps({"stats": meta["stats"], "source": "tools/fullsong_oracle.py --cases mdx_hq3 (oracle/mdx_oracle.py, torch-CPU fp32)",
-                                                           "cpu_wall_s": meta.get("cpu_wall_s"), "cpu_threads": meta.get("cpu_threads")})}
-    for nm in ("primary", "secondary", "primary_pcm", "secondary_pcm"):
-        a = z[nm]                            # [2, nwin, w]
-        out[nm + "_run"] = np.stack([a[:, i, off[i]:off[i] + RUN] for i in range(nwin)], 1)
-        out[nm + "_dec"] = a[:, :, ::DEC]
-    np.savez_compressed(os.path.join(HERE, "fullsong_mdx_hq3_digest.npz"), **out)
-    print({k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k != "meta"})
+    off[-1] = w - RUN                        # the last run ends at the last sample
+    out = {"starts": starts, "width": w, "run": RUN, "dec": DEC, "run_offset": off, "seconds": meta["seconds"],
+           "meta": json.dumps({"case": name, "what": meta["what"], "stats": meta["stats"], "keys": sorted(arrays),
+                               "source": f"tools/fullsong_oracle.py --cases {name} (oracle/*.py, torch-CPU / numpy fp32)",
+                               "cpu_wall_s": meta.get("cpu_wall_s"), "cpu_threads": meta.get("cpu_threads")})}
+    if "scale" in z.files:
+        out["scale"] = z["scale"]
+    for nm, a in arrays.items():             # [..., nwin, w]
+        out[nm + "_run"] = np.stack([a[..., i, off[i]:off[i] + RUN] for i in range(nwin)], -2)
+        out[nm + "_dec"] = a[..., ::DEC]
+    path = os.path.join(HERE, f"fullsong_{name}_digest.npz")
+    np.savez_compressed(path, **out)
+    print(name, os.path.getsize(path) >> 10, "KiB", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim})
 
 
 if __name__ == "__main__":
-    main()
+    for case in (sys.argv[1:] or list(FC.CASES)):
+        digest(case)

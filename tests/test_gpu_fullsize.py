@@ -1,6 +1,6 @@
 """One unit of work at the PUBLIC model layouts (production tile shapes, FFT sizes, head dims -- the small golden
 configs cannot exercise them) against the CPU oracle: one htdemucs segment, one hdemucs_mmi chunk, one VR clip, one MDX23C chunk, one
-BS-Roformer chunk (transformer depth cut to 2 of 12 to keep the CPU side short; every layer has the same shape)."""
+BS-Roformer chunk at the full depth 12 (round 5; rounds 1-4 cut it to 2)."""
 import os
 from fractions import Fraction
 
@@ -120,16 +120,39 @@ def test_mdx23c_chunk(A):
 
 
 def test_bs_roformer_chunk(A):
+    """BASELINE config 3 at ITS OWN SIZE: the ep_317 layout -- dim 512, depth 12 (24 transformer blocks with the
+    softmax in between), 8 heads of 64, 62 bands, n_fft 2048 / hop 441, 159.8 M parameters -- one 8-s chunk against the CPU oracle
+    (~9 TFLOP on the host: half a minute on 32 threads), with proof that the bf16 x 6 row GEMM and attention6_kernel ran, and the
+    fp32-MFMA kernels on the same chunk beside it."""
     from oracle import roformer_oracle as R
-    cfg = R.RoformerConfig(depth=2, freqs_per_bands=R.DEFAULT_FREQS_PER_BANDS)
+    cfg = R.RoformerConfig(freqs_per_bands=R.DEFAULT_FREQS_PER_BANDS)
+    assert cfg.depth == 12 and cfg.dim == 512
     sd = R.make_roformer_state(cfg, 0)
     dm = A.MDXCDemixer({"model_data": cfg.as_model_data(), "torch_device": 0, "secondary_stem_name": "other"}, {"overlap": 8},
                        state_dict=sd, max_batch=1)
     C = cfg.stft_hop_length * (cfg.dim_t - 1)
     x = (0.3 * np.random.default_rng(3).standard_normal((1, 2, C))).astype(np.float32)
-    got = dm.engine.rof_forward(x)
+    eng = dm.engine
+    names = ("tdf3_launches", "attn6_launches")
+    try:
+        eng.set_option("gemm_bf16x6", 1)
+        c0 = [eng.counter(n) for n in names]
+        got = eng.rof_forward(x)
+        c1 = [eng.counter(n) for n in names]
+        # 12 x (time + frequency) transformer blocks: >= 24 attention launches, >= 4 linears per block
+        assert c1[1] - c0[1] >= 24 and c1[0] - c0[0] >= 96, dict(zip(names, zip(c0, c1)))
+        eng.set_option("gemm_bf16x6", 0)
+        got32 = eng.rof_forward(x)
+        assert [eng.counter(n) for n in names] == c1, "the fp32 run went through a bf16 x 6 kernel"
+    finally:
+        eng.set_option("gemm_bf16x6", 1)
     want = R.roformer_forward(x, sd, cfg)
-    assert rel_rms(got[:, 0] if got.ndim == 4 else got, want) < TOL
+    g6 = got[:, 0] if got.ndim == 4 else got
+    g32 = got32[:, 0] if got32.ndim == 4 else got32
+    e6, e32, d = rel_rms(g6, want), rel_rms(g32, want), rel_rms(g6, g32)
+    print(f"BS-Roformer ep_317 layout, depth 12, one chunk: rel-RMS vs oracle bf16x6 {e6:.3e}, fp32-MFMA {e32:.3e}, between them {d:.3e}")
+    assert e6 < TOL and e32 < TOL, (e6, e32)
+    assert e6 < 2e-5 and d < 2e-5, (e6, d)
 
 
 def test_mel_band_roformer_chunk(A):

@@ -1,18 +1,29 @@
-"""Whole-song parity in the driver-run suite: BASELINE config 1 (UVR-MDX-NET-Inst_HQ_3 geometry, 4 minutes, 44.1 kHz stereo)
-through the HIP engine -- normalise, demix (55 chunks, full-size net), * peak, secondary = mix - compensate * primary, the
-writer's int16 pass -- against a committed DIGEST of the CPU oracle's output on the same seeded song and weights
+"""Whole-workload parity in the driver-run suite, one test per BASELINE config: the HIP engine on the whole
+seeded song against a committed DIGEST of the CPU oracle's output on the same song and weights
 (tests/golden/make_fullsong_digest.py: per window a run of 2048 consecutive samples and every 64th sample of 32768, 16 windows
-from the first to the last sample of the song).  The oracle run itself is minutes of CPU and cannot be in the suite; its digest
-can.  Bar: 1e-4 relative RMS (north star), int16 stream within 1 LSB."""
+from the first to the last sample of the song; the whole 10-s clip for VR).  The oracle runs are minutes of CPU each and cannot
+be in the suite; their digests can.
+
+  mdx_hq3      config 1  UVR-MDX-NET-Inst_HQ_3 geometry, 4 min: normalise, demix (55 chunks, full-size net), * peak,
+                         secondary = mix - compensate * primary, the writer's int16 pass (within 1 LSB)
+  htdemucs     config 2  4 stems, shifts 2, 4 min
+  bs_roformer  config 3  ep_317 layout at its own size (dim 512, depth 12), 4 min + 1 s: 31 chunks, Hamming fold, re-anchored tail
+  vr_2hp(_sinc) config 0 10 s through the VR path under either resampler
+  hdemucs_mmi, mdx23c    the other two sibling loops
+
+Bar: 1e-4 relative RMS (north star) at the digest positions, whole-array RMS / peak of every stem within 1e-4 of the oracle's."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
 
-from oracle import mdx_oracle as O
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 pytestmark = pytest.mark.gpu
+TOL = 1e-4
 
 
 def rel_rms(a, b):
@@ -21,43 +32,54 @@ def rel_rms(a, b):
 
 
 def pick(arr, z):
-    """arr [2, N] -> (runs [2, nwin, run], decimated [2, nwin, width / dec]) at the digest's sample positions"""
+    """arr [..., N] -> (runs [..., nwin, run], decimated [..., nwin, width / dec]) at the digest's sample positions"""
     starts, w, run, dec, off = z["starts"], int(z["width"]), int(z["run"]), int(z["dec"]), z["run_offset"]
-    runs = np.stack([arr[:, s + o:s + o + run] for s, o in zip(starts, off)], 1)
-    decs = np.stack([arr[:, s:s + w:dec] for s in starts], 1)
+    runs = np.stack([arr[..., s + o:s + o + run] for s, o in zip(starts, off)], -2)
+    decs = np.stack([arr[..., s:s + w:dec] for s in starts], -2)
     return runs, decs
 
 
-def test_whole_song_hq3_vs_oracle_digest(golden_dir):
+def stat_list(stats, key):
+    """whole-song statistics of the oracle's arrays under `key`: a dict (one array) or a list (one per stem)"""
+    st = stats.get(key)
+    return st if isinstance(st, list) else [st]
+
+
+@pytest.mark.parametrize("case", ["mdx_hq3", "htdemucs", "bs_roformer", "vr_2hp", "vr_2hp_sinc", "hdemucs_mmi", "mdx23c"])
+def test_whole_workload_vs_oracle_digest(golden_dir, case):
+    import torch
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     import audio_separator_amd as A
-    z = np.load(os.path.join(golden_dir, "fullsong_mdx_hq3_digest.npz"))
-    n = int(44100 * float(z["seconds"]))
-    d = O.NetDims()
-    sd = O.make_convtdf_state(d, seed=0)
-    for k in ("final_conv.0.weight", "final_conv.0.bias"):   # the oracle run's calibration (stem RMS ~0.1), stored with the digest
-        sd[k] = sd[k] * float(z["scale"])
-    p = O.MDXParams()
-    eng = A.Engine(A.MDXConfig())
-    eng.load_net(A.NetConfig(), A.fold_convtdf_state(sd, d.num_blocks, d.l))
-    assert eng.plan(n)["n_chunks"] == 55
-    mix = O.synth_mix(n, seed=0)
-    primary, secondary = eng.separate(mix, 0.9, 0.0, p.compensate)
-    stats = json.loads(str(z["meta"]))["stats"]
-    worst = 0.0
-    for nm, arr in (("primary", primary), ("secondary", secondary)):
-        rows = np.ascontiguousarray(arr.T)                     # [2, N]
-        assert np.isfinite(rows).all()
-        runs, decs = pick(rows, z)
-        e_run, e_dec = rel_rms(runs, z[nm + "_run"]), rel_rms(decs, z[nm + "_dec"])
-        print(f"whole song {nm}: rel-RMS runs {e_run:.3e}, decimated {e_dec:.3e}")
-        worst = max(worst, e_run, e_dec)
-        # whole-array statistics of the oracle's stems
-        rms = float(np.sqrt(np.mean(rows.astype(np.float64) ** 2)))
-        assert abs(rms - stats[nm]["rms"]) <= 1e-4 * stats[nm]["rms"]
-        assert abs(float(np.abs(rows).max()) - stats[nm]["peak"]) <= 1e-4 * stats[nm]["peak"]
-        pcm, _ = eng.pcm16(arr, 0.9, 0.0)
-        pr, pd = pick(np.ascontiguousarray(pcm.T), z)
-        dq = max(int(np.abs(pr.astype(np.int64) - z[nm + "_pcm_run"]).max()), int(np.abs(pd.astype(np.int64) - z[nm + "_pcm_dec"]).max()))
-        assert dq <= 1, dq
-    eng.close()
-    assert worst < 1e-4, worst
+    import fullsong_gpu as FG
+    z = np.load(os.path.join(golden_dir, f"fullsong_{case}_digest.npz"))
+    meta = json.loads(str(z["meta"]))
+    arrays, engines = FG.RUN[case](A, float(z["seconds"]), z)
+    try:
+        worst = 0.0
+        for key in meta["keys"]:
+            got = arrays[key]
+            ref_run, ref_dec = z[key + "_run"], z[key + "_dec"]
+            if len(z["starts"]) == 1:                              # one window = the whole clip (VR): the lengths must agree too
+                assert got.shape[-1] == int(z["width"]), (got.shape, int(z["width"]))
+            runs, decs = pick(got, z)
+            assert runs.shape == ref_run.shape and decs.shape == ref_dec.shape, (key, runs.shape, ref_run.shape, decs.shape, ref_dec.shape)
+            if key.endswith("_pcm"):                               # the writer's int16 stream: within 1 LSB
+                dq = max(int(np.abs(runs.astype(np.int64) - ref_run).max()), int(np.abs(decs.astype(np.int64) - ref_dec).max()))
+                assert dq <= 1, (key, dq)
+                continue
+            assert np.isfinite(got).all(), key
+            e_run, e_dec = rel_rms(runs, ref_run), rel_rms(decs, ref_dec)
+            print(f"whole workload {case} / {key}: rel-RMS runs {e_run:.3e}, decimated {e_dec:.3e}")
+            worst = max(worst, e_run, e_dec)
+            # whole-array statistics of the oracle's stems (one entry per stem, or one for the array)
+            sts = stat_list(meta["stats"], key)
+            rows = got.reshape((len(sts), -1)) if len(sts) > 1 else got.reshape((1, -1))
+            for r, st in zip(rows, sts):
+                rms, peak = float(np.sqrt(np.mean(r.astype(np.float64) ** 2))), float(np.abs(r).max())
+                assert abs(rms - st["rms"]) <= 1e-4 * st["rms"] + 1e-9, (key, rms, st["rms"])
+                assert abs(peak - st["peak"]) <= 1e-4 * st["peak"] + 1e-9, (key, peak, st["peak"])
+        print(f"whole workload {case}: worst rel-RMS {worst:.3e}")
+        assert worst < TOL, (case, worst)
+    finally:
+        for e in engines:
+            e.close()

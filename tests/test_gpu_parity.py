@@ -248,6 +248,75 @@ def test_rowgemm_bf16x6_vs_float64(A, B, c, T, K, N, res, xs):
     assert np.abs(y6 - ref).max() <= 1.5 * np.abs(y32 - ref).max() + 1e-6 * np.abs(ref).max(), (np.abs(y6 - ref).max(), np.abs(y32 - ref).max())
 
 
+# ---- edge values of the exact three-way split ------------------------------------------------------------
+# v = h + m + l with h = RNE_bf16(v): what happens where bf16 runs out of range.
+#  * tiny operands: bfloat16 has float32's exponent range, so h and m stay normal down to ~1e-36, but l = v - h - m sits 2^-16 below v
+#    and becomes a bf16 SUBNORMAL below |v| ~ 8e-34; whatever the matrix pipe does with subnormal operands, the dropped part is
+#    <= 2^-16 |v| of an operand that is itself 1e-34 -- the test pins that the result stays within 1e-4 (north-star bar) of float64
+#    there and keeps the full "as close as the fp32 kernel" bar at 1e-30;
+#  * huge operands (1e35, products up to ~1e37: no overflow in either kernel): same bar as ordinary data;
+#  * non-finite operands are OUTSIDE the parity domain (the reference turns the whole chunk into NaN: torch.relu keeps NaN, the next
+#    layer spreads it; its VR path scrubs them first, vr_separator.py:181-182), but what the kernels do is pinned here so that a
+#    change is noticed: h = Inf gives v - h = NaN, so an Inf / NaN in x makes every accumulator of its ROW NaN in the bf16 x 6
+#    kernel where the fp32-MFMA kernel holds +-Inf (NaN when signs cancel); the TDF epilogue's ReLU is a maxNum (v_max_f32), which
+#    returns 0 for NaN -- so the affected row comes out 0 here and {Inf, 0} there.  No other row may change by a single bit.
+@pytest.mark.parametrize("xs,bar", [(1e-30, None), (1e-35, 1e-4), (1e35, None)])
+def test_rowgemm_bf16x6_extreme_magnitudes(A, xs, bar):
+    eng = A.Engine(small_cfg(A))
+    B, c, T, K, N = 1, 3, 50, 256, 200
+    rng = np.random.default_rng(77)
+    x = (xs * rng.standard_normal((B, c, T, K))).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    sc, sh = np.ones(c, np.float32), np.zeros(c, np.float32)
+    ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T, 0)
+    try:
+        eng.set_option("gemm_bf16x6", 1)
+        n0 = eng.counter("tdf3_launches")
+        y6 = eng.op_tdf(x, w, None, sc, sh, None)
+        assert eng.counter("tdf3_launches") == n0 + 1
+        eng.set_option("gemm_bf16x6", 0)
+        y32 = eng.op_tdf(x, w, None, sc, sh, None)
+    finally:
+        eng.set_option("gemm_bf16x6", 1)
+    assert np.isfinite(y6).all() and np.isfinite(y32).all()
+    # compare in float64 at unit scale (rel_rms clamps its denominator at 1e-30)
+    e6, e32 = rel_rms(y6.astype(np.float64) / xs, ref / xs), rel_rms(y32.astype(np.float64) / xs, ref / xs)
+    print(f"bf16x6 row GEMM at |x| ~ {xs:g}: rel-RMS vs float64 {e6:.3e} (fp32-MFMA kernel {e32:.3e})")
+    if bar is None:
+        assert e6 < 2e-6 and e6 <= 1.25 * e32 + 1e-8, (e6, e32)
+    else:
+        assert e6 < bar, (e6, e32)
+
+
+def test_rowgemm_bf16x6_nonfinite_rows(A):
+    eng = A.Engine(small_cfg(A))
+    B, c, T, K, N = 1, 2, 40, 128, 136
+    rng = np.random.default_rng(78)
+    clean = rng.standard_normal((B, c, T, K)).astype(np.float32)
+    x = clean.copy()
+    x[0, 0, 3, 17] = np.inf
+    x[0, 0, 9, 0] = -np.inf
+    x[0, 1, 5, 127] = np.nan
+    x[0, 1, 30, 64] = np.inf
+    x[0, 1, 30, 65] = -np.inf
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    sc, sh = np.ones(c, np.float32), np.zeros(c, np.float32)
+    try:
+        eng.set_option("gemm_bf16x6", 1)
+        y6, y6c = eng.op_tdf(x, w, None, sc, sh, None), eng.op_tdf(clean, w, None, sc, sh, None)
+        eng.set_option("gemm_bf16x6", 0)
+        y32, y32c = eng.op_tdf(x, w, None, sc, sh, None), eng.op_tdf(clean, w, None, sc, sh, None)
+    finally:
+        eng.set_option("gemm_bf16x6", 1)
+    bad = np.zeros((B, c, T), bool)
+    for idx in ((0, 0, 3), (0, 0, 9), (0, 1, 5), (0, 1, 30)):
+        bad[idx] = True
+    assert np.array_equal(y6[~bad], y6c[~bad]) and np.array_equal(y32[~bad], y32c[~bad]), "a non-finite input leaked into another row"
+    assert np.isfinite(y6[~bad]).all()
+    assert (y6[bad] == 0).all(), "bf16 x 6: NaN accumulators through the ReLU maxNum"
+    assert not np.isnan(y32[bad]).any() and np.isinf(y32[0, 0, 3]).any() and ((y32[bad] == 0) | np.isinf(y32[bad])).all()
+
+
 def test_rowgemm_bf16x6_weight_cache_follows_reloads(A):
     """The split image is cached per weight tensor; a second layer uploaded to (possibly) the same address must not see the first's."""
     eng = A.Engine(small_cfg(A))

@@ -134,7 +134,7 @@ def test_sharded_demix_gloo(world, n, match, fold):
     assert np.array_equal(got, ref)
 
 
-def _worker_ws(rank, world, port, lengths, q, fold="dst"):
+def _worker_ws(rank, world, port, lengths, q, fold="dst", poison=False):
     """Three songs through ONE ShardWorkspace (bench.py --mode chunks): buffers are allocated once per shape and reused, equal
     chunk ranges take the no-compaction path (the gathered slab IS the chunk list), unequal ones the copy path."""
     from audio_separator_amd.sharding import ShardWorkspace
@@ -142,7 +142,7 @@ def _worker_ws(rank, world, port, lengths, q, fold="dst"):
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ws = ShardWorkspace()
+    ws = ShardWorkspace(poison=poison)
     ad = OracleAdapter()
     outs, ptrs = [], []
     for i, n in enumerate(lengths):
@@ -182,6 +182,30 @@ def test_sharded_demix_with_workspace_gloo(fold):
         even.append(nk % world == 0)
     assert ptrs[0] == ptrs[1]                     # the second song of the same length allocated nothing
     assert True in even and False in even, even   # both the slab-is-the-list path and the compaction path ran
+
+
+def test_local_fold_ignores_foreign_chunks():
+    """The local-fold scheme hands the fold a chunk list in which only the rank's own chunks and its seam halo are valid.  With every
+    other slot poisoned with NaN (ShardWorkspace(poison=True)) and the workspace reused across two DIFFERENT songs of one length
+    and a third of another, the gathered result must still be bit-identical to one process: the fold of an owned sample range
+    reads nothing but its covering chunks (the invariant was implicit)."""
+    lengths = [3000, 3000, 2100]
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ws, args=(r, world, port, lengths, q, "local", True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs, _ = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    run = O.make_model_run(O.make_convtdf_state(DIMS, seed=3), DIMS)
+    for i, n in enumerate(lengths):
+        mix = (0.4 * np.random.default_rng(20 + i).standard_normal((2, n))).astype(np.float32)
+        assert np.isfinite(outs[i]).all()
+        assert np.array_equal(outs[i], O.demix(mix, P, run))
 
 
 # ---- sibling loops: Roformer chunks and Demucs segment-forwards through the same driver ------------------------------

@@ -122,7 +122,9 @@ inline void wino6_pack(const float *w, int cout, int cin, std::vector<uint32_t> 
 // ABL (ASX_WINO6_ABL, measurement-only builds whose results are garbage): 1 = no LDS-DMA after the first stage, 2 = no patch
 // reads / input transform / split (operands from registers), 4 = no output exchange / stores, 8 = no weight loads after the first
 // stage, 16 = no MFMA
-template <int ABL, int PR>
+// ONE = 1: one workgroup per ITEM (spatial tile, channel group), grid = 8 * ceil(S / 8) * CG, the CG groups of a tile consecutive on
+// one XCD (block b runs on XCD b % 8) so that the re-read of the planes hits that XCD's L2; no cross-item prefetch.
+template <int ABL, int PR, int ONE = 0>
 __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
   using CFG = Wino6Cfg;
   constexpr int IWA = CFG::IWA, C4 = CFG::C4, PS = CFG::PS, LP = CFG::LP, SLOTS = CFG::SLOTS, RAWF = CFG::RAWF;
@@ -141,12 +143,13 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
   // first stage of item i + 1 (planes and weights) is requested during the last stage of item i and lands under i's epilogue.
   // With one 512-thread workgroup per CU nothing else would cover a workgroup's launch, first-stage latency and epilogue.
   const int S = a.tilesT * a.tilesF * a.B;
-  const int nsp = (S - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int nwork = nsp * a.CG;
+  const int nsp = ONE ? 1 : (S - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int one_j = (int)blockIdx.x >> 3, one_sidx = (one_j / a.CG) * 8 + ((int)blockIdx.x & 7);
+  const int nwork = ONE ? (one_sidx < S ? 1 : 0) : nsp * a.CG;
   const int64_t plane_sz = (int64_t)a.T * a.F;
   auto decode = [&](int w, int &b, int &to0, int &fo0, int &cg) {
-    int sidx = (int)blockIdx.x + (int)gridDim.x * (w / a.CG);
-    cg = w % a.CG;
+    int sidx = ONE ? one_sidx : (int)blockIdx.x + (int)gridDim.x * (w / a.CG);
+    cg = ONE ? one_j % a.CG : w % a.CG;
     const int tf = sidx % a.tilesF;
     sidx /= a.tilesF;
     const int tt = sidx % a.tilesT;
@@ -407,13 +410,13 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
   }
 }
 
-template <int ABL = 0>
+template <int ABL = 0, int ONE = 0>
 __global__ __launch_bounds__(512, 1) void conv_wino6_kernel(ConvArgs a) {
   extern __shared__ float lds_f[];
   // the column pair of a wave's positions decides which transform columns it forms: two instantiations of the body, chosen by a
   // wave-uniform branch (both run the same barrier sequence)
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino6_body<ABL, 1>(a, lds_f);
-  else wino6_body<ABL, 0>(a, lds_f);
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino6_body<ABL, 1, ONE>(a, lds_f);
+  else wino6_body<ABL, 0, ONE>(a, lds_f);
 }
 
 }  // namespace asx

@@ -1,7 +1,7 @@
 // Stand-alone harness of the bf16x6 Winograd kernel (csrc/kernels_wino6.h): a float64 direct convolution on small shapes
 // (borders, ragged sizes, channel padding), then time per launch on the HQ_3 level shapes against conv_wino3_kernel.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/experimental/proto_wino6 tools/experimental/proto_wino6.hip
-//   tools/experimental/proto_wino6 [abl] [first shape] [last shape] [nt switches] [grid]
+//   tools/experimental/proto_wino6 [abl] [first shape] [last shape] [nt switches] [grid] [one: 1 = one workgroup per (tile, channel group)]
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -48,14 +48,21 @@ static void pack_wu3(const std::vector<float> &w, int cout, int cin, std::vector
     }
 }
 
+static int g_one = 0;
 template <int ABL>
 static void launch6(const ConvArgs &a, int nb) {
   static bool done = false;
   if (!done) {
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino6_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, Wino6Cfg::LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino6_kernel<ABL, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Wino6Cfg::LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino6_kernel<ABL, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Wino6Cfg::LDS_BYTES));
     done = true;
   }
-  hipLaunchKernelGGL((conv_wino6_kernel<ABL>), dim3(nb), dim3(512), Wino6Cfg::LDS_BYTES, 0, a);
+  if (g_one) {
+    const int S = a.tilesT * a.tilesF * a.B;
+    hipLaunchKernelGGL((conv_wino6_kernel<ABL, 1>), dim3(((S + 7) / 8) * 8 * a.CG), dim3(512), Wino6Cfg::LDS_BYTES, 0, a);
+  } else {
+    hipLaunchKernelGGL((conv_wino6_kernel<ABL, 0>), dim3(nb), dim3(512), Wino6Cfg::LDS_BYTES, 0, a);
+  }
 }
 
 static int g_nt = 0, g_grid = 256;
@@ -234,6 +241,7 @@ int main(int argc, char **argv) {
   const int last = argc > 3 ? atoi(argv[3]) : 99;
   g_nt = argc > 4 ? atoi(argv[4]) : 0;
   g_grid = argc > 5 ? atoi(argv[5]) : 256;
+  g_one = argc > 6 ? atoi(argv[6]) : 0;
   std::vector<Shape> shapes = {
       {"one wg 48", 1, 48, 48, 8, 32, ACT_NONE, 0, 1},
       {"multi wg 40", 1, 40, 20, 16, 64, ACT_NONE, 0, 1},

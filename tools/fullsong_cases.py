@@ -38,6 +38,9 @@ CASES = {
     "vr_2hp_sinc": (10.0, "the same clip with the sinc_fastest converter on both sides (the reference's Linux / x86 rule, the plugin default here; "
                           "restated libsamplerate algorithm: INTEGRATION.md \"VR resampler\")"),
     "mdx23c": (60.0, "MDX23C (TFC-TDF v3) default layout, 60 s, overlap 4"),
+    "bs_roformer": (241.0, "BASELINE config 3: BS-Roformer ep_317 layout at its own size (dim 512, depth 12, 8 heads, 62 bands, n_fft 2048, hop 441, "
+                           "8-s chunks), 4 min + 1 s so that the loop has 31 chunks with the last one re-anchored at N - chunk (Hamming-weighted "
+                           "fold over an 87 % overlap with chunk 29: mdxc_separator.py:310-343), overlap 8 (step = chunk)"),
 }
 OFFSETS = [11025, 3000]
 
@@ -78,3 +81,8 @@ def ht_config():
 
 def segment_fraction():
     return Fraction(39, 5)
+
+
+def roformer_config():
+    from oracle import roformer_oracle as R
+    return R.RoformerConfig(freqs_per_bands=R.DEFAULT_FREQS_PER_BANDS)   # dim 512, depth 12, 8 heads, T = 801, hop 441

@@ -96,8 +96,19 @@ def run_mdx23c(seconds):
     return {"starts": starts, "width": w, "stems": FC.take(out, starts, w)}, {"stems": [stats(s) for s in out], "mix": stats(mix)}
 
 
+def run_roformer(seconds):
+    from oracle import roformer_oracle as R
+    n = int(FC.SR * seconds)
+    mix = FC.synth(n, seed=3)
+    cfg = FC.roformer_config()
+    sd = R.make_roformer_state(cfg, 0)
+    out = R.roformer_demix(mix, sd, cfg, overlap=8)[:1]      # [len(instruments), 2, N] with identical rows (single target): keep one
+    starts, w = FC.windows(n)
+    return {"starts": starts, "width": w, "stems": FC.take(out, starts, w)}, {"stems": [stats(s) for s in out], "mix": stats(mix)}
+
+
 RUN = {"mdx_hq3": run_mdx, "htdemucs": lambda s: run_demucs(s, False), "hdemucs_mmi": lambda s: run_demucs(s, True), "vr_2hp": run_vr, "vr_2hp_sinc": lambda s: run_vr(s, "sinc_fastest"),
-       "mdx23c": run_mdx23c}
+       "mdx23c": run_mdx23c, "bs_roformer": run_roformer}
 
 
 def main():

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """GPU leg of the whole-song parity records (one per BASELINE config): the HIP engine on the same seeded inputs as
-tools/fullsong_oracle.py, compared with the oracle's stored output at the comparison windows of tools/fullsong_cases.py.
+tools/fullsong_oracle.py (tools/fullsong_gpu.py), compared with the oracle's stored output at the comparison windows of
+tools/fullsong_cases.py.
 
-    python tools/fullsong_parity.py [--cases mdx_hq3,htdemucs,hdemucs_mmi,vr_2hp,vr_2hp_sinc,mdx23c] > profiles/r03_fullsong_parity.json
+    python tools/fullsong_parity.py [--cases mdx_hq3,htdemucs,hdemucs_mmi,vr_2hp,vr_2hp_sinc,mdx23c,bs_roformer] > profiles/r05_fullsong_parity.json
 
 A case whose oracle record (gpurun_cache/fullsong/<case>.npz) is missing is computed on the spot with the oracle (slow: the
-CPU leg of a 4-minute htdemucs song is minutes).  Reported per stem: relative RMS error (the north-star metric, bar 1e-4),
-ABSOLUTE RMS error and the stem's own RMS / peak -- the synthetic nets are scaled so that stems are O(0.1), i.e. the 0.9
+CPU leg of a 4-minute htdemucs song is minutes).  Reported per array: relative RMS error (the north-star metric, bar 1e-4),
+ABSOLUTE RMS error and the reference's RMS in the windows -- the synthetic nets are scaled so that stems are O(0.1), i.e. the 0.9
 normalisation threshold, the 1e-6 silence threshold and the int16 quantisation run in their real range; for the MDX case the
-writer's int16 stream is compared too (LSB differences).  One JSON object on stdout."""
+writer's int16 stream is compared too (LSB differences).  One JSON object on stdout.  The driver-run suite holds the same cases
+against committed digests of the same records (tests/test_gpu_fullsong.py)."""
 import argparse
 import json
 import os
@@ -24,6 +26,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import audio_separator_amd as A  # noqa: E402
 import fullsong_cases as FC  # noqa: E402
+import fullsong_gpu as FG  # noqa: E402
 
 TOL = 1e-4
 
@@ -44,105 +47,32 @@ def load(name):
     return z, json.loads(str(z["meta"]))
 
 
-def gpu_mdx(z, meta):
-    from oracle import mdx_oracle as O
-    n = int(FC.SR * meta["seconds"])
-    d, sd = FC.mdx_state(float(z["scale"]))
-    p = O.MDXParams()
-    eng = A.Engine(A.MDXConfig())
-    eng.load_net(A.NetConfig(), A.fold_convtdf_state(sd, d.num_blocks, d.l))
-    mix = FC.synth(n, seed=0)
+def run_case(name):
+    z, meta = load(name)
+    ref = FG.record_arrays(z)                                                # {key: [..., nwin, w]}
     t0 = time.perf_counter()
-    primary, secondary = eng.separate(mix, 0.9, 0.0, p.compensate)
+    arrays, engines = FG.RUN[name](A, meta["seconds"], z)
     dt = time.perf_counter() - t0
-    starts, w = z["starts"], int(z["width"])
-    out = {"stems": {}, "gpu_wall_s_incl_pcie": round(dt, 3)}
-    for nm, arr in (("primary", primary), ("secondary", secondary)):
-        c = cmp(FC.take(np.ascontiguousarray(arr.T), starts, w), z[nm])
-        pcm, peak = eng.pcm16(arr, 0.9, 0.0)
-        dq = np.abs(FC.take(np.ascontiguousarray(pcm.T), starts, w).astype(np.int64) - z[nm + "_pcm"].astype(np.int64))
-        c.update({"pcm16_max_lsb_diff": int(dq.max()), "pcm16_frac_samples_differing": float((dq > 0).mean()), "peak_after_normalize": float(peak),
-                  "whole_song": meta["stats"][nm]})
-        out["stems"][nm] = c
-    eng.close()
+    starts = z["starts"] if "starts" in z.files else np.zeros(1, np.int64)
+    out = {"arrays": {}, "gpu_wall_s_incl_pcie_and_load": round(dt, 3)}
+    for key, r in ref.items():
+        g = FC.take(arrays[key], starts, r.shape[-1])
+        if key.endswith("_pcm"):
+            dq = np.abs(g.astype(np.int64) - r.astype(np.int64))
+            out["arrays"][key] = {"pcm16_max_lsb_diff": int(dq.max()), "pcm16_frac_samples_differing": float((dq > 0).mean())}
+            continue
+        c = cmp(g, r)
+        if r.ndim == 4 and r.shape[0] > 1:                                   # per stem too
+            c["per_stem_rel_rms"] = [cmp(g[i], r[i])["rel_rms"] for i in range(r.shape[0])]
+        out["arrays"][key] = c
+    for e in engines:
+        e.close()
+    worst = max(c["rel_rms"] for c in out["arrays"].values() if "rel_rms" in c)
+    out.update({"what": meta["what"], "seconds": meta["seconds"], "worst_rel_rms": worst, "pass": bool(worst < TOL), "whole_song_stats": meta["stats"],
+                "cpu_oracle": {k: meta[k] for k in ("cpu_wall_s", "cpu_threads", "cpu_rtf", "host")}})
+    if "scale" in z.files:
+        out["final_conv_scale"] = float(z["scale"])
     return out
-
-
-def gpu_demucs(z, meta, v3):
-    n = int(FC.SR * meta["seconds"])
-    mix = FC.synth(n, seed=0)
-    eng = A.Engine(A.MDXConfig(n_fft=4096, hop_length=1024, dim_f=2048, segment_size=8))
-    if v3:
-        from oracle import hdemucs_oracle as H
-        oc = H.HDConfig(segment=44)
-        eng.load_hd(A.HDConfig(segment=44), H.make_hd_state(oc, 0))
-        fn = eng.hd_demix
-    else:
-        from oracle import demucs_oracle as D
-        oc = D.HTConfig()
-        eng.load_ht(A.HTConfig(segment=FC.segment_fraction()), D.make_ht_state(oc, 0))
-        fn = eng.ht_demix
-    t0 = time.perf_counter()
-    got = fn(mix, shifts=2, offsets=list(FC.OFFSETS), overlap=0.25, standardize=True, swap01=True)
-    dt = time.perf_counter() - t0
-    starts, w = z["starts"], int(z["width"])
-    g = FC.take(got, starts, w)
-    out = {"stems": {}, "gpu_wall_s_incl_pcie": round(dt, 3), "all": cmp(g, z["stems"])}
-    for i, nm in enumerate(oc.sources if hasattr(oc, "sources") else range(g.shape[0])):
-        c = cmp(g[i], z["stems"][i])
-        c["whole_song"] = meta["stats"]["stems"][i]
-        out["stems"][str(nm)] = c
-    eng.close()
-    return out
-
-
-def gpu_vr(z, meta, res="polyphase"):
-    n = int(FC.SR * meta["seconds"])
-    wave = FC.synth(n, seed=1)
-    from oracle import vr_oracle as V
-    arch = 123821
-    dm = A.VRDemixer({"model_params": FC.VR_MP, "primary_stem_name": "Instrumental", "torch_device": 0},
-                     {"window_size": 512, "batch_size": 4, "aggression": 5, "asx_res_type": res}, state_dict=V.make_vr_state(arch, 0), nn_arch_size=arch)
-    t0 = time.perf_counter()
-    gp, gs = dm.separate_stems(wave)
-    dt = time.perf_counter() - t0
-    out = {"stems": {}, "gpu_wall_s_incl_pcie": round(dt, 3)}
-    for nm, arr in (("primary", gp), ("secondary", gs)):
-        c = cmp(arr, z[nm])
-        c["whole_song"] = meta["stats"][nm]
-        out["stems"][nm] = c
-    dm.engine.close()
-    return out
-
-
-def gpu_mdx23c(z, meta):
-    from oracle import mdxc_oracle as M
-    n = int(FC.SR * meta["seconds"])
-    mix = FC.synth(n, seed=2)
-    cfg = M.V3Config()
-    dm = A.MDXCDemixer({"model_data": cfg.as_model_data(), "torch_device": 0}, {"overlap": 4}, state_dict=M.make_v3_state(cfg, 0))
-    t0 = time.perf_counter()
-    got = dm.engine.mdxc_demix(mix, 4)
-    dt = time.perf_counter() - t0
-    if got.ndim == 2:
-        got = got[None]
-    ref = z["stems"]
-    if ref.ndim == 3:
-        ref = ref[None]
-    starts, w = z["starts"], int(z["width"])
-    g = FC.take(got, starts, w)
-    out = {"stems": {}, "gpu_wall_s_incl_pcie": round(dt, 3), "all": cmp(g, ref)}
-    st = meta["stats"]["stems"]
-    for i in range(g.shape[0]):
-        c = cmp(g[i], ref[i])
-        c["whole_song"] = st[i] if i < len(st) else None
-        out["stems"][str(i)] = c
-    dm.engine.close()
-    return out
-
-
-RUN = {"mdx_hq3": gpu_mdx, "htdemucs": lambda z, m: gpu_demucs(z, m, False), "hdemucs_mmi": lambda z, m: gpu_demucs(z, m, True),
-       "vr_2hp": gpu_vr, "vr_2hp_sinc": lambda z, m: gpu_vr(z, m, "sinc_fastest"), "mdx23c": gpu_mdx23c}
 
 
 def main():
@@ -156,13 +86,7 @@ def main():
            "cases": {}}
     for name in args.cases.split(","):
         try:
-            z, meta = load(name)
-            r = RUN[name](z, meta)
-            worst = max(c["rel_rms"] for c in r["stems"].values())
-            r.update({"what": meta["what"], "seconds": meta["seconds"], "worst_rel_rms": worst, "pass": bool(worst < TOL),
-                      "cpu_oracle": {k: meta[k] for k in ("cpu_wall_s", "cpu_threads", "cpu_rtf", "host")}})
-            if "scale" in z.files:
-                r["final_conv_scale"] = float(z["scale"])
+            r = run_case(name)
         except Exception as e:
             r = {"error": f"{type(e).__name__}: {e}"}
         res["cases"][name] = r

@@ -1,6 +1,6 @@
 // Stand-alone harness of the bf16x6 row GEMM (csrc/kernels_gemm3.h) against the fp32-MFMA kernel it replaces (kernels_gemm2.h)
 // and a float64 host GEMM on sampled rows: error of both kernels, time per launch on the TDF / Roformer / Demucs shapes.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/proto_gemm3 tools/proto_gemm3.hip && tools/proto_gemm3 [abl]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/proto_gemm3 tools/proto_gemm3.hip && tools/proto_gemm3 [abl] [first] [last] [tile_map]
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -44,6 +44,7 @@ static void launch2(const TdfDmaArgs &a, hipStream_t s) {
   hipLaunchKernelGGL((tdf2_kernel<NREP, MREP, 0, 32>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS, s, a, 1, -1);
 }
 
+static int g_map = 0;   // TdfDmaArgs::tile_map of the tdf3 launches (argv[4])
 struct Shape {
   const char *name;
   int64_t M;
@@ -102,6 +103,7 @@ static double run_shape(const Shape &sh, int abl, int reps) {
   a.C = sh.C;
   a.T = sh.T;
   a.relu = sh.relu;
+  a.tile_map = g_map;
 
   const int64_t total = (int64_t)ntiles * nk * 64;
   hipLaunchKernelGGL(w3_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, dw, dw3, N, K, total);
@@ -186,6 +188,7 @@ int main(int argc, char **argv) {
   const int abl = argc > 1 ? atoi(argv[1]) : 0;
   const int first = argc > 2 ? atoi(argv[2]) : 0;
   const int last = argc > 3 ? atoi(argv[3]) : 99;
+  g_map = argc > 4 ? atoi(argv[4]) : 0;
   std::vector<Shape> shapes = {
       {"small ragged", 1000, 200, 192, 3, 8, 1, 1, 1},
       {"small gelu", 4096 + 64, 512, 256, 1, 1, 2, 1, 1},
