@@ -134,7 +134,7 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def per_level_table(launch_recs, g, wino, num_blocks=11, bf16x6=True):
+def per_level_table(launch_recs, g, wino, num_blocks=11, bf16x6=True, wino6_min_c=0):
     """The 3x3 TFC convs and the TDF row GEMMs of one profiled pass, grouped by U-Net level (VERDICT r4 next #2c).  A conv's level
     follows from its own algorithmic figures -- 3x3 conv c -> c over a plane P: flops = 18 c^2 P, bytes = 8 c P, so
     c = 4 flops / (9 bytes), level = c / g - 1; the 2 x num_blocks TDF launches come in the net's block order (encoder levels
@@ -162,12 +162,21 @@ def per_level_table(launch_recs, g, wino, num_blocks=11, bf16x6=True):
     exf = (4.0 / 9.0) if wino else 1.0
     for lvl in sorted(conv):
         r = conv[lvl]
+        c = g * (lvl + 1)
         tf = r["flops"] / (r["ms"] * 1e-3) / 1e12
-        out["conv3x3"][f"L{lvl}"] = {
-            "channels": g * (lvl + 1), "launches": r["launches"], "ms": round(r["ms"], 3), "avg_launch_ms": round(r["ms"] / r["launches"], 4),
-            "algorithmic_tflops": round(tf, 1), "executed_tflops": round(tf * exf, 1), "frac": round(tf * exf / PEAK_FP32_MFMA_TFLOPS, 4),
-            "algorithmic_gb_per_launch": round(r["bytes"] / r["launches"] / 1e9, 3),
-            "hbm_floor_ms_per_launch": round(r["bytes"] / r["launches"] / 6.29e12 * 1e3, 3)}
+        ent = {"channels": c, "launches": r["launches"], "ms": round(r["ms"], 3), "avg_launch_ms": round(r["ms"] / r["launches"], 4),
+               "algorithmic_tflops": round(tf, 1), "algorithmic_gb_per_launch": round(r["bytes"] / r["launches"] / 1e9, 3),
+               "hbm_floor_ms_per_launch": round(r["bytes"] / r["launches"] / 6.29e12 * 1e3, 3),
+               "flops": r["flops"], "bytes": r["bytes"]}
+        if wino and bf16x6 and wino6_min_c > 0 and c >= wino6_min_c:
+            # conv_wino6_kernel: 4/9 of the direct FLOPs as six bf16 products each, input channels padded to whole 32-channel stages
+            pad = (-(-c // 32) * 32) / c
+            ent.update({"kernel": "conv_wino6_kernel (Winograd F(2x2,3x3), bf16 x 6)", "executed_tflops_bf16": round(tf * exf * 6 * pad, 1),
+                        "frac": round(tf * exf * 6 * pad / PEAK_BF16_MFMA_TFLOPS, 4), "peak": PEAK_BF16_MFMA_TFLOPS})
+        else:
+            ent.update({"kernel": "conv_wino3_kernel (Winograd F(2x2,3x3), fp32 MFMA)" if wino else "conv_dma_kernel<3,3,...> (direct, fp32 MFMA)",
+                        "executed_tflops": round(tf * exf, 1), "frac": round(tf * exf / PEAK_FP32_MFMA_TFLOPS, 4), "peak": PEAK_FP32_MFMA_TFLOPS})
+        out["conv3x3"][f"L{lvl}"] = ent
     for (lvl, which) in sorted(tdf):
         r = tdf[(lvl, which)]
         tf = r["flops"] / (r["ms"] * 1e-3) / 1e12
@@ -378,12 +387,22 @@ def main():
         prof = eng.profile_read()
         launch_recs = eng.profile_launches()
         eng.profile_enable(False)
-        c = prof["conv3x3"]
-        ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
         wino = eng.option("winograd") > 0
-        # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 around the process).  The ratio
-        # traffic / algorithmic bytes comes from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the gfx950
-        # correction + WRITE_SIZE) and is applied to this run's algorithmic bytes per launch; traffic_source says so.
+        x6 = eng.option("gemm_bf16x6") > 0
+        w6c = eng.option("winograd_bf16x6") if (eng.option("winograd") == 3 and x6) else 0
+        per_level = per_level_table(launch_recs, d.g, wino, d.num_blocks, x6, w6c)
+        # the dominant kernel: conv_wino3_kernel (fp32 MFMA) on the levels below the bf16 x 6 threshold -- levels 0 / 1 of the HQ_3 net,
+        # ~100 of the ~139 ms the 3x3 class takes; the deeper levels run conv_wino6_kernel and are listed per level
+        dom = [v for v in per_level["conv3x3"].values() if "wino6" not in v["kernel"]]
+        c = {"flops": sum(v["flops"] for v in dom), "bytes": sum(v["bytes"] for v in dom), "ms": sum(v["ms"] for v in dom),
+             "launches": sum(v["launches"] for v in dom)}
+        for v in per_level["conv3x3"].values():
+            v.pop("flops")
+            v.pop("bytes")
+        call = prof["conv3x3"]
+        ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+        # HBM bytes per launch: the ratio traffic / algorithmic bytes comes from the PMC passes kept under profiles/ (FETCH_SIZE x2 per
+        # the gfx950 correction + WRITE_SIZE) unless it is measured live below; traffic_source says which.
         traffic, source = None, None
         for name in (PMC_FILES_WINO if wino else PMC_FILES):
             pmc_path = os.path.join(ROOT, "profiles", name)
@@ -404,7 +423,9 @@ def main():
                 traffic, source = round(live, 1), why
             else:
                 source = (source or "") + f" [live measurement unavailable: {why}]"
-        roofline = {"kernel": ("conv_wino3_kernel (TFC 3x3 convs, Winograd F(2x2,3x3) on fp32 MFMA)" if wino
+        roofline = {"kernel": ("conv_wino3_kernel (TFC 3x3 convs of the levels below "
+                               f"{w6c} channels, Winograd F(2x2,3x3) on fp32 MFMA)" if (wino and w6c) else
+                               "conv_wino3_kernel (TFC 3x3 convs, Winograd F(2x2,3x3) on fp32 MFMA)" if wino
                                else "conv_dma_kernel<3,3,1,1,3,4,2,0> (TFC 3x3 convs)"),
                     "bound": "mfma", "achieved": round(ach * exf, 2),
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach * exf / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -413,8 +434,9 @@ def main():
                     "launches": c["launches"],
                     "avg_launch_ms": round(c["ms"] / max(1, c["launches"]), 4),
                     "flops_per_launch": c["flops"] / max(1, c["launches"]) * exf,
-                    "share_of_step_ms": round(c["ms"], 2)}
-        roofline["per_level"] = per_level_table(launch_recs, d.g, wino, d.num_blocks, eng.option("gemm_bf16x6") > 0)
+                    "share_of_step_ms": round(c["ms"], 2),
+                    "conv3x3_class_ms": round(call["ms"], 2), "conv3x3_class_launches": call["launches"]}
+        roofline["per_level"] = per_level
         if wino:
             roofline["note"] = ("achieved / frac = EXECUTED MFMA FLOPs (Winograd F(2x2,3x3): 4/9 of the direct convolution's) / launch time "
                                 "/ fp32-MFMA peak; `algorithmic` = direct-convolution FLOPs over the same time (may exceed the peak, not a "
@@ -464,7 +486,7 @@ def main():
                          **comm),
             "roofline": roofline, "cpu_baseline": cpu,
             # what "f32" means inside: nothing runs in a reduced-precision mode
-            "arithmetic": {"io": "float32", "conv3x3": "Winograd F(2x2,3x3) on fp32 MFMA (exact fma chains)",
+            "arithmetic": {"io": "float32", "conv3x3": "Winograd F(2x2,3x3): fp32 MFMA (exact fma chains) below the winograd_bf16x6 channel count (default 144), six bf16 MFMA products on exactly split operands from there up (csrc/kernels_wino6.h)",
                            "row_gemm": ("six bf16 MFMA products on fp32 operands split EXACTLY into three bf16 parts each (dropped cross "
                                         "terms < 2^-24 of a product; closer to a float64 GEMM than the fp32-MFMA kernel, "
                                         "tests/test_gpu_parity.py::test_rowgemm_bf16x6_vs_float64)") if eng.option("gemm_bf16x6") > 0
@@ -484,7 +506,13 @@ def main():
                 tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
                 gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9
                 if tf / PEAK_FP32_MFMA_TFLOPS >= gb / 8000.0:   # the roof the class sits closer to is the one that binds it
-                    if k == "conv3x3" and eng.option("winograd") > 0:   # executed MFMA rate (4/9 of the algorithmic one, see roofline)
+                    if k == "conv3x3" and eng.option("winograd") > 0 and w6c > 0:
+                        # two kernels share the class since round 5: conv_wino3_kernel (fp32 MFMA) below `w6c` channels -- its executed rate
+                        # and fraction are `roofline.achieved / frac` -- and conv_wino6_kernel (bf16 x 6) from there up; per level: roofline.per_level
+                        stages[k] = {"bound": "mfma", "achieved": roofline["achieved"], "unit": "TFLOP/s", "frac": roofline["frac"],
+                                     "frac_is": "conv_wino3_kernel launches only (executed fp32 MFMA FLOPs); conv_wino6_kernel levels: roofline.per_level",
+                                     "algorithmic_achieved": round(tf, 2)}
+                    elif k == "conv3x3" and eng.option("winograd") > 0:   # executed MFMA rate (4/9 of the algorithmic one, see roofline)
                         stages[k] = {"bound": "mfma", "achieved": round(tf * 4.0 / 9.0, 2), "unit": "TFLOP/s",
                                      "frac": round(tf * 4.0 / 9.0 / PEAK_FP32_MFMA_TFLOPS, 4), "algorithmic_achieved": round(tf, 2)}
                     elif k == "tdf" and eng.option("gemm_bf16x6") > 0:

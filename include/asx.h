@@ -80,7 +80,13 @@ typedef struct asx_mdx_config {
 
 /* ConvTDFNet hyper-parameters (uvr_lib_v5/mdxnet.py:31-52); dim_t must equal
  * segment_size, dim_f must equal asx_mdx_config.dim_f.  tdf_bias != 0 when the
- * TDF Linear layers carry a bias (modules.py:57-66). */
+ * TDF Linear layers carry a bias (modules.py:57-66).
+ * bn (modules.py:52-70): > 0 = Linear(f, f / bn) + norm + ReLU + Linear(f / bn, f) + norm + ReLU; 0 = ONE Linear(f, f) + norm + ReLU
+ * (tensors <blk>.tdf0.* only); -1 = `bn is None`, no TDF branch (ABI 6).
+ * norm (ABI 6; mdxnet.py:45-49): 0 = BatchNorm2d (optimizer 'rmsprop'), folded into the weights by the host; 1 = GroupNorm(2, c)
+ * (optimizer 'adamw'): statistics depend on the input, so every conv / linear tensor arrives UNFOLDED and each normalised layer
+ * carries its affine as "<layer>.gn_w" / "<layer>.gn_b" [channels] (layers: first, <blk>.tfc<j>, <blk>.tdf0, <blk>.tdf1, ds<i>, us<i>);
+ * the TDF tensors then have no .scale / .shift. */
 typedef struct asx_net_config {
   int32_t dim_c;
   int32_t dim_f;
@@ -91,6 +97,7 @@ typedef struct asx_net_config {
   int32_t k;
   int32_t bn;
   int32_t tdf_bias;
+  int32_t norm;
 } asx_net_config;
 
 /* Index arithmetic of one demix() call (mdx_separator.py:308-348). */
@@ -502,7 +509,9 @@ int asx_run_model(asx_engine *e, const float *wave_host, int32_t batch, float *o
  *   op = "conv3x3"  w [cout,cin,3,3]  b [cout]                 -> relu(conv(x)+b)
  *   op = "down"     w [cout,cin,2,2]  b [cout]   stride 2      -> relu(conv(x)+b)         [B,cout,T/2,F/2]
  *   op = "up"       w [cin,cout,2,2]  b [cout]   stride 2, aux = skip [B,cout,2T,2F]  -> relu(convT(x)+b)*skip
- *   op = "conv1x1"  w [cout,cin]      b [cout]   relu flag in `relu`
+ *   op = "conv1x1"  w [cout,cin]      b [cout]
+ * `relu` = 0 drops the ReLU of any of them (ABI 6; until ABI 5 only conv1x1 honoured it): the GroupNorm variant of the net runs its
+ * convolutions bare.
  *   op = "tdf"      w [n,k] bias [n] with x viewed as rows of length k=F;
  *                   aux0 = scale [C], aux1 = shift [C], aux2 = residual or NULL -> relu(scale*(xW^T+bias)+shift) (+res)
  */
@@ -521,6 +530,10 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
  * "winograd_stationary": 1 (also ASX_WINOS) = layers with at most 96 input channels run the weight-stationary form of the same
  * transform (csrc/kernels_winos.h: the transformed weights stay in registers, positions split over eight waves) when "winograd"
  * is 3; 0 (default: the stationary form measured slower, profiles/NOTES.md) = conv_wino3_kernel for every layer.
+ * "winograd_bf16x6" (ABI 6; also ASX_WINO6): minimum input-channel count from which a 3x3 TFC convolution runs Winograd F(2x2,3x3) on the
+ * bf16 matrix pipe (conv_wino6_kernel, csrc/kernels_wino6.h: the sixteen transform-domain GEMMs as six bf16 MFMA products on exactly
+ * split operands -- the arithmetic of "gemm_bf16x6", which must be on) instead of conv_wino3_kernel; needs "winograd" = 3.  Default 144
+ * (levels 2 .. 5 of the HQ_3 net: measured 1.08-1.24x faster there, equal at 96 channels, slower at 48); 0 = never.
  * "gemm_bf16x6" (per engine since ABI 6 -- it was process-wide; also ASX_GEMM_BF16X6 in the environment): 1 (default) = every row GEMM whose shape allows it
  * (K % 32 == 0, K >= 64, N > 64, N % 8 == 0, 16-byte aligned rows) runs csrc/kernels_gemm3.h -- both fp32 operands split EXACTLY into three
  * bf16 parts, six bf16 MFMA products with fp32 accumulation, the dropped cross terms below 2^-24 of a product: fp32-grade results

@@ -221,25 +221,34 @@ from workload.synth import NetDims, make_convtdf_state, synth_mix  # noqa: E402,
 
 
 def _bn(x, sd, prefix):
-    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
-                        sd[prefix + ".weight"], sd[prefix + ".bias"], training=False, eps=1e-5)
+    """norm(c) of mdxnet.py:45-49: BatchNorm2d in eval mode (optimizer 'rmsprop': the state_dict carries running statistics), or
+    GroupNorm(2, c) (optimizer 'adamw': affine only, statistics from the input)."""
+    if prefix + ".running_mean" in sd:
+        return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                            sd[prefix + ".weight"], sd[prefix + ".bias"], training=False, eps=1e-5)
+    return F.group_norm(x, 2, sd[prefix + ".weight"], sd[prefix + ".bias"], eps=1e-5)
 
 
 def _tfc_tdf(x, sd, prefix, d: NetDims):
-    """modules.py:45-74 with TFC (modules.py:5-22), BatchNorm2d, eval mode."""
+    """modules.py:45-74 with TFC (modules.py:5-22), eval mode; bn > 0: two linears, bn == 0: one Linear(f, f) (modules.py:55-60),
+    bn is None: no TDF branch.  (DenseTFC, modules.py:25-41, is unreachable: ConvTDFNet never passes dense=True and its forward
+    raises -- its convs are c -> c but receive the 2c-channel concatenation.)"""
     for j in range(d.l):
         x = F.conv2d(x, sd[f"{prefix}.tfc.H.{j}.0.weight"], sd[f"{prefix}.tfc.H.{j}.0.bias"], padding=d.k // 2)
         x = F.relu(_bn(x, sd, f"{prefix}.tfc.H.{j}.1"))
+    if d.bn is None:
+        return x
     t = F.linear(x, sd[f"{prefix}.tdf.0.weight"], sd.get(f"{prefix}.tdf.0.bias"))
     t = F.relu(_bn(t, sd, f"{prefix}.tdf.1"))
-    t = F.linear(t, sd[f"{prefix}.tdf.3.weight"], sd.get(f"{prefix}.tdf.3.bias"))
-    t = F.relu(_bn(t, sd, f"{prefix}.tdf.4"))
+    if d.bn != 0:
+        t = F.linear(t, sd[f"{prefix}.tdf.3.weight"], sd.get(f"{prefix}.tdf.3.bias"))
+        t = F.relu(_bn(t, sd, f"{prefix}.tdf.4"))
     return x + t
 
 
 @torch.no_grad()
 def convtdf_forward(x, sd: dict, d: NetDims):
-    """ConvTDFNet.forward (mdxnet.py:97-120), optimizer='rmsprop' (BatchNorm2d) variant,
+    """ConvTDFNet.forward (mdxnet.py:97-120), either norm (see _bn),
     eval mode.  x: [B, dim_c, dim_f, dim_t] float32 (numpy or torch) -> same shape (numpy)."""
     was_np = isinstance(x, np.ndarray)
     x = torch.as_tensor(np.ascontiguousarray(x) if was_np else x, dtype=torch.float32)
@@ -278,7 +287,8 @@ def net_flops(d: NetDims, batch: int = 1) -> int:
     fl += 2 * d.dim_c * g * T * Fq
 
     def block(c, t, f):
-        return d.l * 2 * d.k * d.k * c * c * t * f + 2 * 2 * c * t * f * (f // d.bn)
+        tdf = 0 if d.bn is None else (2 * c * t * f * f if d.bn == 0 else 2 * 2 * c * t * f * (f // d.bn))
+        return d.l * 2 * d.k * d.k * c * c * t * f + tdf
     c, t, f = g, T, Fq
     for _ in range(d.n):
         fl += block(c, t, f)

@@ -29,6 +29,7 @@
 #include "kernels_gemm3.h"
 #include "kernels_wino.h"
 #include "kernels_winos.h"
+#include "kernels_wino6.h"
 #ifndef ASX_TDF2_DEFAULT
 #define ASX_TDF2_DEFAULT 1
 #endif
@@ -85,6 +86,11 @@ struct DevBuf {
     bytes = 0;
     HIPCHK(hipMalloc(&p, n));
     bytes = n;
+    // ASX_POISON=<byte 0..255>: fill every fresh allocation with that byte (255 = NaN, 127 = 3.39e38 floats) -- a debugging aid that
+    // makes any read of memory the engine never wrote show up in the results, instead of depending on what the allocation held
+    // before (round 5: a first forward on the bf16 x 6 kernels differed from later ones on some boxes and not on others)
+    static const int poison = getenv("ASX_POISON") ? atoi(getenv("ASX_POISON")) : -1;
+    if (poison >= 0) HIPCHK(hipMemset(p, poison & 255, n));
     return ASX_OK;
   }
   void release() {
@@ -112,12 +118,16 @@ struct ConvLayer {
   int wu_cg = 0, wu_nci = 0, wu3_nci = 0;
   DevBuf wus;      // weight-stationary image [CG48][wave 8][6 KS / 4][lane 64][4] (conv_winos_kernel<KS>), Cin <= 96 only
   int wus_ks = 0;  // 12 / 24 (k-steps of four channels the image was packed for), 0 = none
+  DevBuf gn_w, gn_b;  // GroupNorm(2, cout) affine behind this conv (asx_net_config.norm == 1), else empty
+  DevBuf wu6;      // conv_wino6_kernel (kernels_wino6.h): U split three ways into bf16, MFMA-fragment order [CG48][NCI32][wave 8][18][lane 64][4 x u32]
+  int wu6_nci = 0; // 32-channel stages of that image (0 = not packed: Cin < 64)
 };
 
 struct TdfLayer {
   int n = 0, k = 0, c = 0;
   bool has_bias = false;
   DevBuf w, bias, scale, shift;
+  DevBuf gn_w, gn_b;  // GroupNorm(2, c) affine behind this linear (asx_net_config.norm == 1), else empty
 };
 
 struct Block {
@@ -190,6 +200,7 @@ struct asx_engine {
   // workspace
   int ws_batch = 0;  // chunks the workspace is sized for
   DevBuf spec_in, spec_out, R[3], H, frames, chunk_out, d_starts, d_nact, d_peak, d_demixed;
+  DevBuf gn_part;    // per-plane float64 (sum, sum of squares) of the GroupNorm variant of the net (asx_net_config.norm == 1)
   DevBuf d_div;      // divider of the chunk fold for div_key's plan (input-independent: built once, asx_finalize_dev)
   DivKey div_key;
   DevBuf sinc_tab;   // coefficient table of asx_resample_sinc (built on first use)
@@ -207,6 +218,10 @@ struct asx_engine {
   // 1 (default): row GEMMs, channels-last convolutions (GATHER mode) and attention of THIS engine run the bf16 x 6 kernels when their
   // shapes allow (kernels_gemm3.h); 0: the fp32-MFMA kernels.  ASX_GEMM_BF16X6 or asx_set_option("gemm_bf16x6", n).
   int gemm_bf16x6 = getenv("ASX_GEMM_BF16X6") ? atoi(getenv("ASX_GEMM_BF16X6")) : 1;
+  // 3x3 TFC convs with at least this many input channels run Winograd F(2x2,3x3) on the bf16 pipe (conv_wino6_kernel, kernels_wino6.h)
+  // when "winograd" is 3 and "gemm_bf16x6" is on; 0 = never.  Default 144: measured faster than conv_wino3_kernel from level 2 of the
+  // HQ_3 net down, equal on level 1, slower on level 0 (profiles/r05_wino6_forms.txt).  ASX_WINO6 or asx_set_option("winograd_bf16x6", n).
+  int wino6 = getenv("ASX_WINO6") ? std::max(0, atoi(getenv("ASX_WINO6"))) : 144;
   // split (bf16 x 3) images of this engine's weight matrices, built on first use and freed only with the engine or when the engine's
   // own weights are re-loaded: another engine of the process can never invalidate a pointer a captured graph of this one holds
   std::vector<W3Entry> w3;
@@ -438,6 +453,19 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
     }
     CHK(L.wu3.ensure(wu3.size() * 4));
     HIPCHK(hipMemcpy(L.wu3.p, wu3.data(), wu3.size() * 4, hipMemcpyHostToDevice));
+    // bf16 x 6 image (kernels_wino6.h) for every layer wide enough to be worth a 32-channel stage; which layers RUN on it is the
+    // engine's "winograd_bf16x6" option at launch time
+    L.wu6_nci = 0;
+    if (L.cin >= 64) {
+      std::vector<uint32_t> w6;
+      int cg6 = 0, nci6 = 0;
+      wino6_pack(w, L.cout, L.cin, w6, &cg6, &nci6);
+      if (cg6 == L.wu_cg) {
+        CHK(L.wu6.ensure(w6.size() * 4));
+        HIPCHK(hipMemcpy(L.wu6.p, w6.data(), w6.size() * 4, hipMemcpyHostToDevice));
+        L.wu6_nci = nci6;
+      }
+    }
     // weight-stationary image: only where all of U fits the registers of eight waves (Cin <= 96) without much zero padding
     L.wus_ks = (L.cin > 40 && L.cin <= 48) ? 12 : ((L.cin > 88 && L.cin <= 96) ? 24 : 0);
     if (L.wus_ks) {
@@ -480,6 +508,8 @@ static void launch_conv_dma_t(const ConvArgs &a, int nblk, hipStream_t s) {
   }
   hipLaunchKernelGGL(conv_dma_kernel<CFG>, dim3(nblk), dim3(256), CFG::LDS_BYTES, s, a);
 }
+
+static std::atomic<long long> g_wino6_launches{0};   // launches of conv_wino6_kernel (kernels_wino6.h) since the process started
 
 // Optional view description of a conv's operands (channel slices of larger buffers).
 struct ConvView {
@@ -591,6 +621,34 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     }
     if (ragged) return k12 ? gos(&conv_winos_kernel<12, 0, true>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 0, true>, WinoSCfg<24>::LDS_BYTES);
     return k12 ? gos(&conv_winos_kernel<12, 0, false>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 0, false>, WinoSCfg<24>::LDS_BYTES);
+  }
+  if (L.kind == CK_3X3 && e->winograd == 3 && e->gemm_bf16x6 > 0 && e->wino6 > 0 && L.cin >= e->wino6 && dma && L.wu6_nci > 0 &&
+      (int64_t)T * F < ((int64_t)1 << 24)) {
+    // Winograd on the bf16 pipe, one workgroup per (8 x 32 tile, 48-channel group); the groups of a tile are consecutive on one XCD
+    ConvArgs wa = a;
+    wa.wp = reinterpret_cast<const float *>(L.wu6.p);
+    wa.CG = L.wu_cg;
+    wa.NCI = L.wu6_nci;
+    wa.tilesT = (a.To + Wino6Cfg::TH - 1) / Wino6Cfg::TH;
+    wa.tilesF = (a.Fo + Wino6Cfg::TW - 1) / Wino6Cfg::TW;
+    const int64_t S = (int64_t)wa.tilesT * wa.tilesF * B;
+    const int64_t nb = ((S + 7) / 8) * 8 * wa.CG;
+    if (nb < ((int64_t)1 << 31)) {
+      {
+        static std::mutex attr_mutex;
+        static bool attr_done = false;
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (!attr_done) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino6_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Wino6Cfg::LDS_BYTES);
+          attr_done = true;
+        }
+      }
+      g_wino6_launches.fetch_add(1);
+      return timed(e, cls, flops, bytes, s, [&]() {
+        hipLaunchKernelGGL((conv_wino6_kernel<0, 1>), dim3((unsigned)nb), dim3(512), Wino6Cfg::LDS_BYTES, s, wa);
+      });
+    }
   }
   if (L.kind == CK_3X3 && e->winograd == 3 && dma && L.wu3.p != nullptr) {
     ConvArgs wa = a;
@@ -826,7 +884,6 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
 // launches of tdf3_kernel since the process started (tests assert that the path under test is the one that ran)
 static std::atomic<long long> g_tdf3_launches{0};
 static std::atomic<long long> g_attn6_launches{0};   // launches of attention6_kernel (kernels_rof.h)
-static std::atomic<long long> g_wino6_launches{0};   // launches of conv_wino6_kernel (kernels_wino6.h)
 
 // The split image of a weight matrix is built on first use and cached PER ENGINE by (pointer, N, K, cin) (asx_engine::w3).  Every
 // entry point that uploads or frees weights of an engine flushes that engine's images (w3_flush) -- an address reused by another tensor
@@ -885,8 +942,11 @@ static void launch_tdf3_abl(const TdfDmaArgs &a0, const u32x4 *w3, hipStream_t s
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
   // tile -> XCD map (kernels_gemm3.h); ASX_TDF3_MAP = "<narrow><wide>" digits for N < 8 tiles / N >= 8 tiles (A/B switch)
+  // Default (round 5, profiles/r05_tdf3_tile_map_ab.txt + r05_pmc_tdf3.json): fewer than 8 column tiles -> map 1 (the column tiles of a
+  // row block are neighbours on one XCD, so x crosses the fabric once instead of twice: level-0 first TDF linear 6.86 -> 6.69 ms,
+  // fabric traffic 2.0x -> ~1.0x algorithmic); 8 or more -> map 0 (column tiles partitioned over the XCDs; maps 1 / 2 measure the same).
   static const int map_env = getenv("ASX_TDF3_MAP") ? atoi(getenv("ASX_TDF3_MAP")) : -1;
-  if (map_env >= 0) a.tile_map = nbn >= 8 ? map_env % 10 : map_env / 10;
+  a.tile_map = map_env >= 0 ? (nbn >= 8 ? map_env % 10 : map_env / 10) : (nbn < 8 ? 1 : 0);
   hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3, RowGather{});
   g_tdf3_launches.fetch_add(1);
 }
@@ -1168,6 +1228,24 @@ static int istft_ola_launch(asx_engine *e, const float *spec, int B, int T, int 
 // ----------------------------------------------------------------------------
 // net forward on device buffers: spec_in [B,4,T,F] (TF layout) -> spec_out
 // ----------------------------------------------------------------------------
+// GroupNorm(2, C) + ReLU (+ res) (* mul) over a dense [B, C, P] tensor, in place or into y (kernels_fft.h: gn_*_kernel); the ConvTDFNet
+// variant built with optimizer == 'adamw' (uvr_lib_v5/mdxnet.py:48-49) normalises with batch-dependent statistics, so the norm cannot
+// be folded into the weights: every conv / linear runs bare (bias only) and this pass follows it.
+static int gn_launch(asx_engine *e, const float *x, int B, int C, int64_t P, const DevBuf &gw, const DevBuf &gb, const float *res,
+                     const float *mul, float *y, hipStream_t s) {
+  if (B <= 0) return ASX_OK;
+  REQUIRE(C % 2 == 0 && gw.p && gb.p && e->gn_part.bytes >= (size_t)B * C * 16, "GroupNorm(2, %d): channels / workspace", C);
+  double2 *part = reinterpret_cast<double2 *>(e->gn_part.p);
+  const double bytes = 4.0 * (double)B * C * (double)P;
+  CHK(timed(e, ASX_PROF_MISC, 0.0, bytes, s,
+            [&]() { hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, x, C, P, part); }));
+  const int nx = (int)std::max<int64_t>(1, std::min<int64_t>(32, (P / 4 + 1023) / 1024));
+  return timed(e, ASX_PROF_MISC, 0.0, bytes * (2 + (res ? 1 : 0) + (mul ? 1 : 0)), s, [&]() {
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nx, (unsigned)C, (unsigned)B), dim3(256), 0, s, x, C, 2, P, part, gw.f(), gb.f(), 1e-5f, 1, res,
+                       mul, y);
+  });
+}
+
 static int block_forward(asx_engine *e, const Block &blk, float *&cur, float *dest, int B, hipStream_t s) {
   // TFC convs rotate through e->R; the TDF output goes to `dest` (or a free R buffer when dest == nullptr)
   auto next_free = [&](const float *a, const float *b) -> float * {
@@ -1175,12 +1253,45 @@ static int block_forward(asx_engine *e, const Block &blk, float *&cur, float *de
       if (e->R[i].f() != a && e->R[i].f() != b) return e->R[i].f();
     return nullptr;
   };
+  const bool gn = e->net.norm == 1;
+  const int64_t plane = (int64_t)blk.t * blk.f;
   for (size_t j = 0; j < blk.tfc.size(); ++j) {
     float *out = next_free(cur, nullptr);
     CHK(conv_launch(e, blk.tfc[j], cur, nullptr, out, B, blk.t, blk.f, s));
+    if (gn) CHK(gn_launch(e, out, B, blk.c, plane, blk.tfc[j].gn_w, blk.tfc[j].gn_b, nullptr, nullptr, out, s));
     cur = out;
   }
   const int64_t M = (int64_t)B * blk.c * blk.t;
+  const int bnk = e->net.bn;
+  if (bnk < 0) {                                       // bn is None: TFC only (modules.py:52, 74)
+    if (dest) {
+      HIPCHK(hipMemcpyAsync(dest, cur, (size_t)M * blk.f * 4, hipMemcpyDeviceToDevice, s));
+      cur = dest;
+    }
+    return ASX_OK;
+  }
+  if (bnk == 0) {                                      // one Linear(f, f) + norm + ReLU (modules.py:55-60), x + tdf(x)
+    float *out = dest ? dest : next_free(cur, nullptr);
+    if (gn) {
+      float *tmp = next_free(cur, out);
+      CHK(tdf_launch(e, blk.tdf0, cur, nullptr, tmp, M, blk.t, s, 0));
+      CHK(gn_launch(e, tmp, B, blk.c, plane, blk.tdf0.gn_w, blk.tdf0.gn_b, cur, nullptr, out, s));
+    } else {
+      CHK(tdf_launch(e, blk.tdf0, cur, cur, out, M, blk.t, s));
+    }
+    cur = out;
+    return ASX_OK;
+  }
+  if (gn) {
+    CHK(tdf_launch(e, blk.tdf0, cur, nullptr, e->H.f(), M, blk.t, s, 0));
+    CHK(gn_launch(e, e->H.f(), B, blk.c, (int64_t)blk.t * (blk.f / bnk), blk.tdf0.gn_w, blk.tdf0.gn_b, nullptr, nullptr, e->H.f(), s));
+    float *out = dest ? dest : next_free(cur, nullptr);
+    float *tmp = dest ? next_free(cur, nullptr) : out;
+    CHK(tdf_launch(e, blk.tdf1, e->H.f(), nullptr, tmp, M, blk.t, s, 0));
+    CHK(gn_launch(e, tmp, B, blk.c, plane, blk.tdf1.gn_w, blk.tdf1.gn_b, cur, nullptr, out, s));
+    cur = out;
+    return ASX_OK;
+  }
   CHK(tdf_launch(e, blk.tdf0, cur, nullptr, e->H.f(), M, blk.t, s));
   // (A/B ASX_TDF_INPLACE=1: x + tdf(x) written over x where no skip copy is needed -- every output element depends on the
   // same element of x only)
@@ -1198,12 +1309,16 @@ static int net_forward_dev(asx_engine *e, const float *spec_in, float *spec_out,
   }
   const int T = e->net.dim_t, F = e->net.dim_f;
   const int n = e->net.num_blocks / 2;
+  const bool gn = e->net.norm == 1;
   float *cur = e->R[0].f();
   CHK(conv_launch(e, e->first, spec_in, nullptr, cur, B, T, F, s));
+  if (gn) CHK(gn_launch(e, cur, B, e->net.g, (int64_t)T * F, e->first.gn_w, e->first.gn_b, nullptr, nullptr, cur, s));
   for (int i = 0; i < n; ++i) {
     CHK(block_forward(e, e->enc[i], cur, e->skip[i].f(), B, s));
     float *out = e->R[0].f();
     CHK(conv_launch(e, e->ds[i], cur, nullptr, out, B, e->enc[i].t, e->enc[i].f, s));
+    if (gn)
+      CHK(gn_launch(e, out, B, e->ds[i].cout, (int64_t)(e->enc[i].t / 2) * (e->enc[i].f / 2), e->ds[i].gn_w, e->ds[i].gn_b, nullptr, nullptr, out, s));
     cur = out;
   }
   CHK(block_forward(e, e->mid, cur, nullptr, B, s));
@@ -1216,7 +1331,9 @@ static int net_forward_dev(asx_engine *e, const float *spec_in, float *spec_out,
         break;
       }
     // input at (t/2, f/2) -> (t, f), multiplied by the matching encoder output (mdxnet.py:113)
-    CHK(conv_launch(e, e->us[i], cur, e->skip[n - 1 - i].f(), out, B, blk.t / 2, blk.f / 2, s));
+    CHK(conv_launch(e, e->us[i], cur, gn ? nullptr : e->skip[n - 1 - i].f(), out, B, blk.t / 2, blk.f / 2, s));
+    if (gn)   // norm + ReLU first, then `x *= ds_outputs[-i - 1]` (mdxnet.py:111-113)
+      CHK(gn_launch(e, out, B, e->us[i].cout, (int64_t)blk.t * blk.f, e->us[i].gn_w, e->us[i].gn_b, nullptr, e->skip[n - 1 - i].f(), out, s));
     cur = out;
     CHK(block_forward(e, blk, cur, nullptr, B, s));
   }
@@ -1238,6 +1355,7 @@ static int ensure_workspace(asx_engine *e, int Bchunks, bool need_net) {
     const size_t lvl0 = Bn * e->net.g * T * Fq * 4;
     for (int i = 0; i < 3; ++i) CHK(e->R[i].ensure(lvl0));
     CHK(e->H.ensure(Bn * e->net.g * T * (Fq / std::max(1, e->net.bn)) * 4 + 256));
+    if (e->net.norm == 1) CHK(e->gn_part.ensure(Bn * (size_t)e->net.g * (e->net.num_blocks / 2 + 1) * 16));
     const int n = e->net.num_blocks / 2;
     e->skip.resize(n);
     for (int i = 0; i < n; ++i) {
@@ -1382,12 +1500,18 @@ static void free_conv(ConvLayer &L) {
   L.wu.release();
   L.wu2.release();
   L.wu3.release();
+  L.wus.release();
+  L.wu6.release();
+  L.gn_w.release();
+  L.gn_b.release();
 }
 static void free_tdf(TdfLayer &L) {
   L.w.release();
   L.bias.release();
   L.scale.release();
   L.shift.release();
+  L.gn_w.release();
+  L.gn_b.release();
 }
 static void free_block(Block &b) {
   for (auto &c : b.tfc) free_conv(c);
@@ -1448,12 +1572,13 @@ int asx_net_begin(asx_engine *e, const asx_net_config *cfg) {
   REQUIRE(cfg->dim_f == e->cfg.dim_f, "net dim_f %d != engine dim_f %d", cfg->dim_f, e->cfg.dim_f);
   REQUIRE(cfg->dim_t == e->cfg.segment_size, "net dim_t %d != segment_size %d", cfg->dim_t, e->cfg.segment_size);
   REQUIRE(cfg->k == 3, "only k=3 TFC kernels are supported (got %d)", cfg->k);
-  REQUIRE(cfg->dim_c > 0 && cfg->g > 0 && cfg->l > 0 && cfg->bn > 0, "bad net hyper-parameters");
+  REQUIRE(cfg->dim_c > 0 && cfg->g > 0 && cfg->l > 0 && cfg->bn >= -1, "bad net hyper-parameters");
+  REQUIRE(cfg->norm == 0 || (cfg->norm == 1 && cfg->g % 2 == 0), "norm must be 0 (BatchNorm, folded by the host) or 1 (GroupNorm(2, c): even g)");
   REQUIRE(cfg->num_blocks >= 1 && cfg->num_blocks % 2 == 1, "num_blocks must be odd");
   const int n = cfg->num_blocks / 2;
   REQUIRE((cfg->dim_f % (1 << n)) == 0 && (cfg->dim_t % (1 << n)) == 0,
           "dim_f and dim_t must be divisible by 2^%d", n);
-  REQUIRE(((cfg->dim_f >> n) % cfg->bn) == 0, "dim_f / 2^n must be divisible by bn");
+  REQUIRE(cfg->bn <= 0 || ((cfg->dim_f >> n) % cfg->bn) == 0, "dim_f / 2^n must be divisible by bn");
   e->net = *cfg;
   e->host_tensors.clear();
   e->net_begun = true;
@@ -1489,31 +1614,54 @@ static int get_tensor(asx_engine *e, const std::string &name, int64_t numel, con
   return ASX_OK;
 }
 
+// GroupNorm affine of a layer: "<name>.gn_w" / "<name>.gn_b" [c] (asx_net_config.norm == 1)
+static int load_gn(asx_engine *e, const std::string &name, int c, DevBuf &gw, DevBuf &gb) {
+  const float *w, *b;
+  CHK(get_tensor(e, name + ".gn_w", c, &w));
+  CHK(get_tensor(e, name + ".gn_b", c, &b));
+  CHK(gw.ensure((size_t)c * 4));
+  CHK(gb.ensure((size_t)c * 4));
+  HIPCHK(hipMemcpy(gw.p, w, (size_t)c * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(gb.p, b, (size_t)c * 4, hipMemcpyHostToDevice));
+  return ASX_OK;
+}
+
 static int build_block(asx_engine *e, Block &blk, const std::string &pre, int c, int t, int f) {
   const asx_net_config &n = e->net;
+  const bool gn = n.norm == 1;
   blk.c = c;
   blk.t = t;
   blk.f = f;
   blk.tfc.resize(n.l);
   for (int j = 0; j < n.l; ++j) {
     const float *w, *b;
-    CHK(get_tensor(e, pre + ".tfc" + std::to_string(j) + ".w", (int64_t)c * c * 9, &w));
-    CHK(get_tensor(e, pre + ".tfc" + std::to_string(j) + ".b", c, &b));
-    CHK(conv_setup(blk.tfc[j], CK_3X3, c, c, 1));
+    const std::string nm = pre + ".tfc" + std::to_string(j);
+    CHK(get_tensor(e, nm + ".w", (int64_t)c * c * 9, &w));
+    CHK(get_tensor(e, nm + ".b", c, &b));
+    CHK(conv_setup(blk.tfc[j], CK_3X3, c, c, gn ? 0 : 1));
     CHK(conv_pack(blk.tfc[j], w, b, e->winograd));
+    if (gn) CHK(load_gn(e, nm, c, blk.tfc[j].gn_w, blk.tfc[j].gn_b));
   }
-  const int fb = f / n.bn;
-  const float *w, *bias, *sc, *sh;
+  if (n.bn < 0) return ASX_OK;                         // bn is None: no TDF branch (modules.py:52)
+  const int fb = n.bn == 0 ? f : f / n.bn;             // bn == 0: ONE Linear(f, f) (modules.py:55-60)
+  const float *w, *bias, *sc = nullptr, *sh = nullptr;
   CHK(get_tensor(e, pre + ".tdf0.w", (int64_t)fb * f, &w));
   CHK(get_tensor(e, pre + ".tdf0.bias", fb, &bias, !n.tdf_bias));
-  CHK(get_tensor(e, pre + ".tdf0.scale", c, &sc));
-  CHK(get_tensor(e, pre + ".tdf0.shift", c, &sh));
+  if (!gn) {
+    CHK(get_tensor(e, pre + ".tdf0.scale", c, &sc));
+    CHK(get_tensor(e, pre + ".tdf0.shift", c, &sh));
+  }
   CHK(tdf_pack(blk.tdf0, fb, f, c, w, bias, sc, sh));
+  if (gn) CHK(load_gn(e, pre + ".tdf0", c, blk.tdf0.gn_w, blk.tdf0.gn_b));
+  if (n.bn == 0) return ASX_OK;
   CHK(get_tensor(e, pre + ".tdf1.w", (int64_t)f * fb, &w));
   CHK(get_tensor(e, pre + ".tdf1.bias", f, &bias, !n.tdf_bias));
-  CHK(get_tensor(e, pre + ".tdf1.scale", c, &sc));
-  CHK(get_tensor(e, pre + ".tdf1.shift", c, &sh));
+  if (!gn) {
+    CHK(get_tensor(e, pre + ".tdf1.scale", c, &sc));
+    CHK(get_tensor(e, pre + ".tdf1.shift", c, &sh));
+  }
   CHK(tdf_pack(blk.tdf1, f, fb, c, w, bias, sc, sh));
+  if (gn) CHK(load_gn(e, pre + ".tdf1", c, blk.tdf1.gn_w, blk.tdf1.gn_b));
   return ASX_OK;
 }
 
@@ -1530,8 +1678,10 @@ int asx_net_commit(asx_engine *e) {
   const float *w, *b;
   CHK(get_tensor(e, "first.w", (int64_t)n.g * n.dim_c, &w));
   CHK(get_tensor(e, "first.b", n.g, &b));
-  CHK(conv_setup(e->first, CK_1X1, n.dim_c, n.g, 1));
+  const bool gn = n.norm == 1;
+  CHK(conv_setup(e->first, CK_1X1, n.dim_c, n.g, gn ? 0 : 1));
   CHK(conv_pack(e->first, w, b, e->winograd));
+  if (gn) CHK(load_gn(e, "first", n.g, e->first.gn_w, e->first.gn_b));
   e->enc.assign(nn, Block());
   e->dec.assign(nn, Block());
   e->ds.assign(nn, ConvLayer());
@@ -1541,8 +1691,9 @@ int asx_net_commit(asx_engine *e) {
     CHK(build_block(e, e->enc[i], "enc" + std::to_string(i), c, t, f));
     CHK(get_tensor(e, "ds" + std::to_string(i) + ".w", (int64_t)(c + n.g) * c * 4, &w));
     CHK(get_tensor(e, "ds" + std::to_string(i) + ".b", c + n.g, &b));
-    CHK(conv_setup(e->ds[i], CK_DOWN, c, c + n.g, 1));
+    CHK(conv_setup(e->ds[i], CK_DOWN, c, c + n.g, gn ? 0 : 1));
     CHK(conv_pack(e->ds[i], w, b, e->winograd));
+    if (gn) CHK(load_gn(e, "ds" + std::to_string(i), c + n.g, e->ds[i].gn_w, e->ds[i].gn_b));
     c += n.g;
     t /= 2;
     f /= 2;
@@ -1551,8 +1702,9 @@ int asx_net_commit(asx_engine *e) {
   for (int i = 0; i < nn; ++i) {
     CHK(get_tensor(e, "us" + std::to_string(i) + ".w", (int64_t)c * (c - n.g) * 4, &w));
     CHK(get_tensor(e, "us" + std::to_string(i) + ".b", c - n.g, &b));
-    CHK(conv_setup(e->us[i], CK_UP, c, c - n.g, 1));
+    CHK(conv_setup(e->us[i], CK_UP, c, c - n.g, gn ? 0 : 1));
     CHK(conv_pack(e->us[i], w, b, e->winograd));
+    if (gn) CHK(load_gn(e, "us" + std::to_string(i), c - n.g, e->us[i].gn_w, e->us[i].gn_b));
     c -= n.g;
     t *= 2;
     f *= 2;
@@ -1573,7 +1725,8 @@ double asx_net_flops(const asx_engine *e, int32_t batch) {
   const int n = d.num_blocks / 2;
   double fl = 2.0 * d.dim_c * d.g * (double)d.dim_t * d.dim_f;
   auto block = [&](double c, double t, double f) {
-    return d.l * 2.0 * 9.0 * c * c * t * f + 2.0 * 2.0 * c * t * f * (f / d.bn);
+    const double tdf = d.bn > 0 ? 2.0 * 2.0 * c * t * f * (f / d.bn) : (d.bn == 0 ? 2.0 * c * t * f * f : 0.0);
+    return d.l * 2.0 * 9.0 * c * c * t * f + tdf;
   };
   double c = d.g, t = d.dim_t, f = d.dim_f;
   for (int i = 0; i < n; ++i) {
@@ -2158,8 +2311,8 @@ int asx_op_conv(asx_engine *e, const char *op, const float *x_host, int32_t B, i
   }
   ConvLayer L;
   DevBuf dx, dy, dskip;
-  BufGuard g{{&dx, &dy, &dskip, &L.w, &L.b}};
-  CHK(conv_setup(L, kind, cin, cout, kind == CK_1X1 ? relu : 1));
+  BufGuard g{{&dx, &dy, &dskip, &L.w, &L.b, &L.wu, &L.wu2, &L.wu3, &L.wus, &L.wu6}};
+  CHK(conv_setup(L, kind, cin, cout, relu ? 1 : 0));
   CHK(conv_pack(L, w_host, b_host, e->winograd));
   CHK(to_dev(dx, x_host, (size_t)B * cin * t * f));
   const size_t ny = (size_t)B * cout * to * fo;
@@ -3220,6 +3373,10 @@ int asx_set_option(asx_engine *e, const char *key, int32_t value) {
   }
   if (!strcmp(key, "winograd_stationary")) {
     e->winos = value < 0 ? 0 : (int)value;
+    return ASX_OK;
+  }
+  if (!strcmp(key, "winograd_bf16x6")) {
+    e->wino6 = value < 0 ? 0 : (int)value;
     return ASX_OK;
   }
   if (!strcmp(key, "gemm_bf16x6")) {                 // this engine only (round 5; it was process-wide before)

@@ -782,6 +782,109 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const float *__restrict__
   }
 }
 
+// ---------------------------------------------------------------------------
+// GroupNorm(G, C) of the ConvTDFNet variant built with optimizer == 'adamw' (uvr_lib_v5/mdxnet.py:48-49: norm = GroupNorm(2, c)
+// after every conv / linear): x [B, C, P] dense.  Two kernels: per-plane float64 sums, then normalise + affine + ReLU with the
+// optional "+ res" (x + tdf(x), modules.py:74) or "* mul" (x *= ds_outputs[-i-1], mdxnet.py:113) of the consuming statement fused.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float *__restrict__ x, int C, int64_t P, double2 *__restrict__ part) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float *xp = x + ((int64_t)b * C + c) * P;
+  double s = 0.0, q = 0.0;
+  if ((P & 3) == 0) {
+    const float4 *x4 = reinterpret_cast<const float4 *>(xp);
+    for (int64_t i = threadIdx.x; i < P / 4; i += blockDim.x) {
+      const float4 v = x4[i];
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < P; i += blockDim.x) {
+      const double v = xp[i];
+      s += v;
+      q += v * v;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+  __shared__ double ws[4], wq[4];
+  if ((threadIdx.x & 63) == 0) {
+    ws[threadIdx.x >> 6] = s;
+    wq[threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) part[(int64_t)b * C + c] = make_double2(ws[0] + ws[1] + ws[2] + ws[3], wq[0] + wq[1] + wq[2] + wq[3]);
+}
+
+// y[b,c,:] = relu((x - mean_g) * rstd_g * gamma[c] + beta[c]) (+ res[b,c,:]) (* mul[b,c,:]); g = c / (C / G); y may alias x.
+// The group's statistics are folded from the per-plane sums in plane order by every block (C / G <= a few hundred doubles).
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, int C, int G, int64_t P, const double2 *__restrict__ part,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta, float eps, int relu,
+                                                       const float *__restrict__ res, const float *__restrict__ mul, float *__restrict__ y) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int cpg = C / G, g = c / cpg;
+  __shared__ float sm[2];
+  if (threadIdx.x == 0) {
+    double s = 0.0, q = 0.0;
+    for (int j = 0; j < cpg; ++j) {
+      const double2 v = part[(int64_t)b * C + g * cpg + j];
+      s += v.x;
+      q += v.y;
+    }
+    const double n = (double)cpg * (double)P;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    sm[0] = (float)mean;
+    sm[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float mean = sm[0], sc = sm[1] * gamma[c], sh = beta[c];
+  const int64_t base = ((int64_t)b * C + c) * P;
+  auto f = [&](float v) {
+    v = (v - mean) * sc + sh;
+    return relu ? fmaxf(v, 0.f) : v;
+  };
+  if ((P & 3) == 0) {
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + base);
+    const float4 *r4 = res ? reinterpret_cast<const float4 *>(res + base) : nullptr;
+    const float4 *m4 = mul ? reinterpret_cast<const float4 *>(mul + base) : nullptr;
+    float4 *y4 = reinterpret_cast<float4 *>(y + base);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P / 4; i += (int64_t)gridDim.x * blockDim.x) {
+      float4 v = x4[i];
+      v.x = f(v.x);
+      v.y = f(v.y);
+      v.z = f(v.z);
+      v.w = f(v.w);
+      if (r4) {
+        const float4 r = r4[i];
+        v.x += r.x;
+        v.y += r.y;
+        v.z += r.z;
+        v.w += r.w;
+      }
+      if (m4) {
+        const float4 m = m4[i];
+        v.x *= m.x;
+        v.y *= m.y;
+        v.z *= m.z;
+        v.w *= m.w;
+      }
+      y4[i] = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+      float v = f(x[base + i]);
+      if (res) v += res[base + i];
+      if (mul) v *= mul[base + i];
+      y[base + i] = v;
+    }
+  }
+}
+
 // y_view[b, c, :] = a[b, c, :] * m[b, c, :]   ("x * first_conv_out", tfc_tdf_v3.py:257), y is a channel-slice view
 __global__ __launch_bounds__(256) void mul_into_view_kernel(const float *__restrict__ a, const float *__restrict__ m,
                                                             int64_t CP, float *__restrict__ y, int64_t y_bstride) {

@@ -1,4 +1,3 @@
-// EXPERIMENT, not part of libasx.so (measured, not faster than conv_wino3_kernel where it matters: profiles/NOTES.md "Round 4, second session").
 // Winograd F(2x2, 3x3) for the 3x3 / pad-1 convolutions of the TFC blocks (uvr_lib_v5/modules.py:22-54) on the bf16 matrix pipe
 // with fp32 results -- the arithmetic of kernels_gemm3.h applied to the sixteen transform-domain GEMMs of kernels_wino.h:
 //
@@ -24,12 +23,18 @@
 //   * the sixteen partial products M_xi of a tile live in eight different waves: the output transform meets in LDS (the raw
 //     buffers are free by then), one 16-channel column tile per round, and is finished by (tile column, tile row) lanes so that
 //     stores are 128-byte row segments.
-// Workgroup = 512 threads (two waves per SIMD, 256 registers each), one per CU; tile = 8 x 32 output pixels.
-// Preconditions (launcher; otherwise conv_wino3_kernel): To % 8 == 0, Fo % 32 == 0 is NOT required -- border tiles are masked.
+// Workgroup = 512 threads (two waves per SIMD, 256 registers each), one per CU; tile = 8 x 32 output pixels; border tiles are masked.
+// Round 5: part of libasx.so in its ONE-workgroup-per-item form (template parameter ONE = 1: grid = items, the channel groups of a
+// tile consecutive on one XCD), which is what measures faster than conv_wino3_kernel from 144 channels up (per launch, 55 chunks:
+// L2 4.84 -> 4.48 ms, L3 2.29 -> 1.84, L4 0.89 -> 0.79, L5 0.32 -> 0.27; L1 8.31 = 8.31, L0 9.0 -> 13.8: profiles/r05_wino6_forms.txt).
+// The launcher (asx.hip: conv_launch) therefore routes a 3x3 layer here only when Cin >= the engine's "winograd_bf16x6" option
+// (default 144) and keeps conv_wino3_kernel for the wide planes of levels 0 / 1.  The persistent forms (ONE = 0: grid = CUs, the
+// next item's first stage prefetched under the epilogue) stay in the header for the harness tools/experimental/proto_wino6.hip.
 #pragma once
 #include <vector>
-#include "../../python-audio-separator_amd/csrc/kernels_net.h"
-#include "../../python-audio-separator_amd/csrc/kernels_gemm3.h"
+#include <cstring>
+#include "kernels_net.h"
+#include "kernels_gemm3.h"
 
 namespace asx {
 

@@ -34,7 +34,7 @@ class _MdxCfg(C.Structure):
 
 
 class _NetCfg(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("dim_c", "dim_f", "dim_t", "g", "l", "num_blocks", "k", "bn", "tdf_bias")]
+    _fields_ = [(n, C.c_int32) for n in ("dim_c", "dim_f", "dim_t", "g", "l", "num_blocks", "k", "bn", "tdf_bias", "norm")]
 
 
 class _V3Cfg(C.Structure):
@@ -117,8 +117,9 @@ class NetConfig:
     l: int = 3
     num_blocks: int = 11
     k: int = 3
-    bn: int = 8
+    bn: int = 8              # 0 = one Linear(f, f) TDF (modules.py:55-60); -1 = `bn is None`, no TDF branch
     tdf_bias: bool = False
+    norm: str = "batch"      # "batch" (optimizer 'rmsprop', BatchNorm folded by weights.fold_convtdf_state) | "group" (GroupNorm(2, c), 'adamw')
 
 
 @dataclass
@@ -443,7 +444,8 @@ class Engine:
         """Current value of an engine option (the library default when it was never set here)."""
         defaults = {"winograd": max(0, int(os.environ.get("ASX_WINOGRAD", "3"))),
                     "winograd_stationary": max(0, int(os.environ.get("ASX_WINOS", "0"))),
-                    "gemm_bf16x6": 1 if int(os.environ.get("ASX_GEMM_BF16X6", "1")) > 0 else 0}
+                    "gemm_bf16x6": 1 if int(os.environ.get("ASX_GEMM_BF16X6", "1")) > 0 else 0,
+                    "winograd_bf16x6": max(0, int(os.environ.get("ASX_WINO6", "144")))}
         if key not in defaults:
             raise AsxError(f"unknown engine option {key!r} (known: {sorted(defaults)})")
         return self._options.get(key, defaults[key])
@@ -457,8 +459,10 @@ class Engine:
     # -- weights ------------------------------------------------------------
     def load_net(self, net_cfg: NetConfig, tensors: dict):
         """tensors: canonical name -> float32 array (see include/asx.h)."""
+        if net_cfg.norm not in ("batch", "group"):
+            raise ValueError(f"NetConfig.norm must be 'batch' or 'group', got {net_cfg.norm!r}")
         n = _NetCfg(net_cfg.dim_c, net_cfg.dim_f, net_cfg.dim_t, net_cfg.g, net_cfg.l, net_cfg.num_blocks, net_cfg.k,
-                    net_cfg.bn, int(bool(net_cfg.tdf_bias)))
+                    -1 if net_cfg.bn is None else net_cfg.bn, int(bool(net_cfg.tdf_bias)), 1 if net_cfg.norm == "group" else 0)
         self._check(self._lib.asx_net_begin(self._h, C.byref(n)))
         for name, arr in tensors.items():
             a = _f32(arr).reshape(-1)

@@ -147,7 +147,11 @@ class MDXDemixer:
         else:
             if net_config is None:
                 net_config = NetConfig(dim_f=self.dim_f, dim_t=self.segment_size)
-            tensors = fold_convtdf_state(state_dict, net_config.num_blocks, net_config.l, net_config.tdf_bias)
+            from .weights import state_norm_kind
+            if state_norm_kind(state_dict) != net_config.norm:     # GroupNorm(2, c) checkpoints (optimizer 'adamw') carry no running statistics
+                from dataclasses import replace
+                net_config = replace(net_config, norm=state_norm_kind(state_dict))
+            tensors = fold_convtdf_state(state_dict, net_config.num_blocks, net_config.l, net_config.tdf_bias, norm=net_config.norm)
         if net_config.dim_t != self.segment_size or net_config.dim_f != self.dim_f:
             raise ValueError("net dim_t/dim_f must match segment_size/dim_f")
         self.engine.load_net(net_config, tensors)

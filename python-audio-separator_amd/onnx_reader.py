@@ -262,14 +262,15 @@ def fold_constants(nodes, inits) -> dict:
 
 # ops of the ConvTDFNet eval graph (weights + structure), pass-through ops on activations, and ops that may only touch
 # constants or SHAPE vectors (run-time Reshape targets)
-_STRUCT_OPS = {"Conv", "ConvTranspose", "MatMul", "Gemm", "BatchNormalization", "Relu", "Add", "Mul"}
+_STRUCT_OPS = {"Conv", "ConvTranspose", "MatMul", "Gemm", "BatchNormalization", "InstanceNormalization", "Relu", "Add", "Mul"}
 _PASS_OPS = {"Identity", "Dropout", "Transpose", "Reshape", "Flatten", "Cast"}
 _SHAPE_OPS = {"Shape", "Gather", "Concat", "Slice", "Squeeze", "Unsqueeze", "Constant", "ConstantOfShape", "Sub", "Div", "Size", "Range"}
 
 
 def check_ops(nodes, consts) -> None:
     """Every node must be an op this reader accounts for.  Ops that would change ACTIVATIONS and are not part of the net
-    (Sigmoid, LeakyRelu, Pad, Resize, InstanceNormalization ...) raise; so do shape-arithmetic ops fed with activations."""
+    (Sigmoid, LeakyRelu, Pad, Resize ...) raise; so do shape-arithmetic ops fed with activations.  InstanceNormalization is accepted
+    here and must then turn out to be the middle of torch's GroupNorm(2, c) lowering (convtdf_from_onnx: _gn_affine)."""
     shapeish = set(consts)                    # constants and everything computed from Shape(...) of an activation
     for n in nodes:
         if n.op == "Shape":
@@ -284,8 +285,8 @@ def check_ops(nodes, consts) -> None:
                 raise OnnxFormatError(f"{_where(n)}: acts on an activation; not part of ConvTDFNet")
             raise OnnxFormatError(f"{_where(n)}: shape arithmetic applied to an activation tensor; not part of ConvTDFNet")
         if n.op not in _STRUCT_OPS and n.op not in _PASS_OPS:
-            raise OnnxFormatError(f"{_where(n)}: unsupported op -- this reader runs the BatchNorm ConvTDFNet only "
-                                  "(Conv, ConvTranspose, MatMul / Gemm, BatchNormalization, Relu, Add, Mul, Transpose, Reshape)")
+            raise OnnxFormatError(f"{_where(n)}: unsupported op -- this reader runs ConvTDFNet only "
+                                  "(Conv, ConvTranspose, MatMul / Gemm, BatchNormalization or the GroupNorm lowering, Relu, Add, Mul, Transpose, Reshape)")
 
 
 def _bn_affine(node: Node, inits):
@@ -316,8 +317,8 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
         """The single consumer of node idx's FIRST output if it is `op` (else None); Reshape / Identity / Dropout / Flatten
         behind it are looked through (the Gemm lowering of a Linear puts a Reshape between the product and its BatchNorm)."""
         while True:
-            outs = [j for j in consumers.get(nodes[idx].outputs[0], []) if nodes[j].inputs and nodes[j].inputs[0] == nodes[idx].outputs[0]
-                    or nodes[j].op in ("Add", "Mul")]
+            outs = [j for j in consumers.get(nodes[idx].outputs[0], []) if nodes[j].op != "Shape" and (
+                    (nodes[j].inputs and nodes[j].inputs[0] == nodes[idx].outputs[0]) or nodes[j].op in ("Add", "Mul"))]
             if len(outs) != 1:
                 return None
             j = outs[0]
@@ -328,7 +329,39 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
                 continue
             return None
 
-    layers = []   # ("conv", k, stride, w[cout,cin,kh,kw], b) | ("convT", w[cin,cout,2,2], b) | ("lin", w[n,k], bias|None, scale, shift)
+    gn_used = set()
+
+    def gn_affine(idx):
+        """torch's lowering of GroupNorm(2, c) behind node idx (uvr_lib_v5/mdxnet.py:48-49, optimizer 'adamw'):
+        Reshape([0, 2, -1]) -> InstanceNormalization(scale 1, bias 0) -> Reshape(Shape(x)) -> Mul(gamma [c,1,1]) -> Add(beta [c,1,1]).
+        -> (gamma, beta) as float64 vectors, or None when no InstanceNormalization follows."""
+        j = next_op(idx, "InstanceNormalization")
+        if j is None:
+            return None
+        nd = nodes[j]
+        rs = [k for k in range(len(nodes)) if nodes[k].outputs and nodes[k].outputs[0] == nd.inputs[0]]
+        tgt = inits.get(nodes[rs[0]].inputs[1]) if rs and nodes[rs[0]].op == "Reshape" and len(nodes[rs[0]].inputs) > 1 else None
+        if tgt is None or [int(v) for v in np.asarray(tgt).reshape(-1)][1:] != [2, -1]:
+            raise OnnxFormatError(f"{_where(nd)}: InstanceNormalization that is not the GroupNorm(2, c) lowering (Reshape target {tgt})")
+        sc, bi = (np.asarray(inits.get(n_), np.float64) if n_ in inits else None for n_ in nd.inputs[1:3])
+        if sc is None or bi is None or sc.size != 2 or not np.all(sc == 1.0) or not np.all(bi == 0.0):
+            raise OnnxFormatError(f"{_where(nd)}: GroupNorm lowering with a non-trivial per-group scale / bias")
+        if abs(float(nd.attrs.get("epsilon", 1e-5)) - 1e-5) > 1e-9:
+            raise OnnxFormatError(f"{_where(nd)}: GroupNorm epsilon {nd.attrs.get('epsilon')} (the engine uses nn.GroupNorm's 1e-5)")
+        jm = next_op(j, "Mul")
+        ja = next_op(jm, "Add") if jm is not None else None
+        if jm is None or ja is None:
+            raise OnnxFormatError(f"{_where(nd)}: GroupNorm lowering without its affine Mul / Add")
+        gam = [i for i in nodes[jm].inputs if i in inits]
+        bet = [i for i in nodes[ja].inputs if i in inits]
+        if len(gam) != 1 or len(bet) != 1:
+            raise OnnxFormatError(f"{_where(nd)}: GroupNorm affine operands are not constants")
+        gn_used.add(j)
+        return np.asarray(inits[gam[0]], np.float64).reshape(-1), np.asarray(inits[bet[0]], np.float64).reshape(-1)
+
+    # ("conv", k, stride, w[cout,cin,kh,kw], b, gn) | ("convT", w[cin,cout,2,2], b, gn) | ("lin", w[n,k], bias|None, scale, shift, gn);
+    # gn = (gamma, beta) of a GroupNorm(2, c) behind the layer (weights then unfolded, scale / shift None), else None
+    layers = []
     for idx, n in enumerate(nodes):
         if n.op == "Conv":
             w = np.asarray(inits[n.inputs[1]], np.float64)
@@ -337,13 +370,14 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
             if j is not None:
                 s, sh = _bn_affine(nodes[j], inits)
                 w, b = w * s[:, None, None, None], b * s + sh
+            gn = gn_affine(idx) if j is None else None
             ks = n.attrs.get("kernel_shape", list(w.shape[2:]))
             st = n.attrs.get("strides", [1, 1])
             if n.attrs.get("group", 1) != 1 or any(d != 1 for d in n.attrs.get("dilations", [1, 1])):
                 raise OnnxFormatError(f"{_where(n)}: grouped / dilated Conv is not part of ConvTDFNet")
             if n.inputs[1] not in inits:
                 raise OnnxFormatError(f"{_where(n)}: weight is not a constant")
-            layers.append(("conv", int(ks[0]), int(st[0]), w, b))
+            layers.append(("conv", int(ks[0]), int(st[0]), w, b, gn))
         elif n.op == "ConvTranspose":
             w = np.asarray(inits[n.inputs[1]], np.float64)
             b = np.asarray(inits[n.inputs[2]], np.float64) if len(n.inputs) > 2 else np.zeros(w.shape[1])
@@ -351,7 +385,7 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
             if j is not None:
                 s, sh = _bn_affine(nodes[j], inits)
                 w, b = w * s[None, :, None, None], b * s + sh
-            layers.append(("convT", w, b))
+            layers.append(("convT", w, b, gn_affine(idx) if j is None else None))
         elif n.op == "MatMul":
             wname = n.inputs[1] if n.inputs[1] in inits else (n.inputs[0] if n.inputs[0] in inits else None)
             if wname is None:
@@ -365,9 +399,13 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
                 j = ja
             jb = next_op(j, "BatchNormalization")
             if jb is None:
-                raise OnnxFormatError(f"{_where(n)}: TDF Linear without BatchNormalization (adamw/GroupNorm variant is unsupported)")
+                gn = gn_affine(j)
+                if gn is None:
+                    raise OnnxFormatError(f"{_where(n)}: TDF Linear followed neither by BatchNormalization nor by the GroupNorm lowering")
+                layers.append(("lin", w, bias, None, None, gn))
+                continue
             s, sh = _bn_affine(nodes[jb], inits)
-            layers.append(("lin", w, bias, s, sh))
+            layers.append(("lin", w, bias, s, sh, None))
         elif n.op == "Gemm":
             # Linear lowered as Reshape([-1, K]) -> Gemm(A, B, C) -> Reshape: Y = alpha * A * op(B) + beta * C
             if len(n.inputs) < 2 or n.inputs[1] not in inits or n.inputs[0] in inits:
@@ -384,17 +422,35 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
                 bias = np.asarray(inits[n.inputs[2]], np.float64).reshape(-1)
             jb = next_op(idx, "BatchNormalization")
             if jb is None:
-                raise OnnxFormatError(f"{_where(n)}: TDF Linear without BatchNormalization (adamw/GroupNorm variant is unsupported)")
+                gn = gn_affine(idx)
+                if gn is None:
+                    raise OnnxFormatError(f"{_where(n)}: TDF Linear followed neither by BatchNormalization nor by the GroupNorm lowering")
+                layers.append(("lin", w, bias, None, None, gn))
+                continue
             s, sh = _bn_affine(nodes[jb], inits)
-            layers.append(("lin", w, bias, s, sh))
+            layers.append(("lin", w, bias, s, sh, None))
 
     if len(layers) < 4 or layers[0][0] != "conv" or layers[0][1] != 1:
         raise OnnxFormatError("graph does not start with the 1x1 first_conv of ConvTDFNet")
+    stray = [nd for j, nd in enumerate(nodes) if nd.op == "InstanceNormalization" and j not in gn_used]
+    if stray:
+        raise OnnxFormatError(f"{_where(stray[0])}: InstanceNormalization outside the GroupNorm(2, c) lowering of a conv / linear"
+                              + (f" (and {len(stray) - 1} more)" if len(stray) > 1 else ""))
+    normed = [L for L in layers[:-1]]                  # every layer but the final conv carries a norm
+    kinds = {L[-1] is not None for L in normed}
+    if len(kinds) != 1:
+        raise OnnxFormatError("graph mixes BatchNorm and GroupNorm layers (or has layers without a norm); not a ConvTDFNet")
+    group = kinds.pop()
     out: dict = {}
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+
+    def put_gn(dst, L):
+        if L[-1] is not None:
+            out[f"{dst}.gn_w"], out[f"{dst}.gn_b"] = f32(L[-1][0]), f32(L[-1][1])
     first = layers[0]
     g, dim_c = first[3].shape[0], first[3].shape[1]
     out["first.w"], out["first.b"] = f32(first[3].reshape(g, dim_c)), f32(first[4])
+    put_gn("first", first)
     pos = 1
 
     def take_block(dst):
@@ -402,30 +458,43 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
         l = 0
         while pos < len(layers) and layers[pos][0] == "conv" and layers[pos][1] == 3:
             out[f"{dst}.tfc{l}.w"], out[f"{dst}.tfc{l}.b"] = f32(layers[pos][3]), f32(layers[pos][4])
+            put_gn(f"{dst}.tfc{l}", layers[pos])
             l += 1
             pos += 1
         dims = []
+        # TDF branch (modules.py:52-70): two linears (bn > 0), ONE Linear(f, f) (bn == 0), or none (bn is None)
         for t in range(2):
             if pos >= len(layers) or layers[pos][0] != "lin":
-                raise OnnxFormatError(f"{dst}: expected TDF linear #{t}")
-            _, w, bias, s, sh = layers[pos]
+                break
+            _, w, bias, s, sh, _gn = layers[pos]
             out[f"{dst}.tdf{t}.w"] = f32(w)
             if bias is not None:
                 out[f"{dst}.tdf{t}.bias"] = f32(bias)
-            out[f"{dst}.tdf{t}.scale"], out[f"{dst}.tdf{t}.shift"] = f32(s), f32(sh)
+            if s is not None:
+                out[f"{dst}.tdf{t}.scale"], out[f"{dst}.tdf{t}.shift"] = f32(s), f32(sh)
+            put_gn(f"{dst}.tdf{t}", layers[pos])
             dims.append(w.shape)
             pos += 1
+        if len(dims) == 1 and dims[0][0] != dims[0][1]:
+            raise OnnxFormatError(f"{dst}: a single TDF linear must be square (bn == 0), got {dims[0]}")
         return l, dims
 
     l0, dims0 = take_block("enc0")
-    dim_f = dims0[0][1]
-    bn = dim_f // dims0[0][0]
+    if dims0:
+        dim_f = dims0[0][1]
+        bn = 0 if len(dims0) == 1 else dim_f // dims0[0][0]
+    else:                                              # no TDF branch: the frequency size is the graph input's
+        bn = None
+        dim_f = next((int(dims[2]) for name, dims in ginputs.items() if name not in raw_inits and dims and len(dims) == 4 and dims[2]), None)
+        if dim_f is None:
+            raise OnnxFormatError("ConvTDFNet without a TDF branch and without a recorded input shape: dim_f unknown")
     has_bias = "enc0.tdf0.bias" in out
     # encoder: blocks separated by 2x2 stride-2 convs
     enc_blocks = 1
     n = 0
     while pos < len(layers) and layers[pos][0] == "conv" and layers[pos][1] == 2 and layers[pos][2] == 2:
         out[f"ds{n}.w"], out[f"ds{n}.b"] = f32(layers[pos][3]), f32(layers[pos][4])
+        put_gn(f"ds{n}", layers[pos])
         pos += 1
         n += 1
         name = f"enc{enc_blocks}"
@@ -438,6 +507,7 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
         if pos >= len(layers) or layers[pos][0] != "convT":
             raise OnnxFormatError(f"expected ConvTranspose us{i}")
         out[f"us{i}.w"], out[f"us{i}.b"] = f32(layers[pos][1]), f32(layers[pos][2])
+        put_gn(f"us{i}", layers[pos])
         pos += 1
         take_block(f"dec{i}")
     if pos != len(layers) - 1 or layers[pos][0] != "conv" or layers[pos][1] != 1:
@@ -452,5 +522,5 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
         if dim_t is None:
             raise OnnxFormatError("time size not recorded in the graph input; pass dim_t")
     cfg = NetConfig(dim_c=int(dim_c), dim_f=int(dim_f), dim_t=int(dim_t), g=int(g), l=int(l0),
-                    num_blocks=2 * n + 1, k=3, bn=int(bn), tdf_bias=bool(has_bias))
+                    num_blocks=2 * n + 1, k=3, bn=(None if bn is None else int(bn)), tdf_bias=bool(has_bias), norm="group" if group else "batch")
     return cfg, out

@@ -62,6 +62,22 @@ def main():
                                   dynamo=False, **kw)
                 print(out2, os.path.getsize(out2))
 
+    # the ConvTDFNet forms besides BatchNorm / bn > 0 (tests/golden/make_golden_variants.py holds their outputs): GroupNorm(2, c) --
+    # lowered by the exporter to Reshape -> InstanceNormalization -> Reshape -> Mul -> Add --, bn == 0, bn is None
+    variants = {"gn_bias": ("adamw", 4, True, 12, dict(opset_version=13)),
+                "gn_op17_nofold": ("adamw", 4, False, 11, dict(opset_version=17, do_constant_folding=False,
+                                                               dynamic_axes={"input": {0: "b", 3: "t"}, "output": {0: "b", 3: "t"}})),
+                "gn_bn0": ("adamw", 0, True, 14, dict(opset_version=13)), "bn0": ("rmsprop", 0, False, 13, dict(opset_version=13)),
+                "notdf": ("rmsprop", None, False, 15, dict(opset_version=13))}
+    for tag, (opt, bn, bias, seed, kw) in variants.items():
+        d = O.NetDims(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=bn, bias=bias, norm="group" if opt == "adamw" else "batch")
+        net = ConvTDFNet("t", 1e-3, opt, 4, 32, 16, 96, 16, 5, 2, 8, 3, bn, bias, 0)
+        net.load_state_dict(O.make_convtdf_state(d, seed=seed), strict=False)
+        net.eval()
+        out = os.path.join(HERE, f"net_small_{tag}.onnx")
+        torch.onnx.export(net, (torch.randn(1, 4, 32, 16),), out, input_names=["input"], output_names=["output"], dynamo=False, **kw)
+        print(out, os.path.getsize(out))
+
 
 if __name__ == "__main__":
     main()

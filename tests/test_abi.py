@@ -46,10 +46,10 @@ def test_binding_refuses_a_library_of_another_abi(monkeypatch):
 
 
 def test_struct_sizes_match_header():
-    # 8 x 4 bytes + one double, 9 x 4 bytes, 6 x 8 + 4 x 4 bytes, 10 x (8 + 8 + 8 + 8)
+    # 8 x 4 bytes + one double, 10 x 4 bytes (ABI 6: + norm), 6 x 8 + 4 x 4 bytes, 10 x (8 + 8 + 8 + 8)
     import ctypes as C
     assert C.sizeof(E._MdxCfg) == 40
-    assert C.sizeof(E._NetCfg) == 36
+    assert C.sizeof(E._NetCfg) == 40
     assert C.sizeof(E._Plan) == 64
     assert C.sizeof(E._Profile) == 320
     assert C.sizeof(E._LaunchRec) == 24          # struct asx_launch_rec: int32 + float + 2 doubles

@@ -342,6 +342,56 @@ def test_net_small_golden(A, golden_dir, fname, bias, wseed):
     assert rel_rms(y, g["y"]) < 2e-5, rel_rms(y, g["y"])
 
 
+# the ConvTDFNet forms besides BatchNorm / bn > 0 (uvr_lib_v5/mdxnet.py:45-49, modules.py:52-70): goldens written by the reference
+# class (tests/golden/make_golden_variants.py)
+NET_VARIANTS = {"gn": ("group", 4, False, 11), "gn_bias": ("group", 4, True, 12), "bn0": ("batch", 0, False, 13), "gn_bn0": ("group", 0, True, 14),
+                "notdf": ("batch", None, False, 15)}
+
+
+def variant_engine(A, name, max_batch=0):
+    norm, bn, bias, seed = NET_VARIANTS[name]
+    d = O.NetDims(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=bn, bias=bias, norm=norm)
+    sd = O.make_convtdf_state(d, seed=seed)
+    eng = A.Engine(small_cfg(A, 0.25, False, max_batch))
+    eng.load_net(A.NetConfig(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=bn, tdf_bias=bias, norm=norm),
+                 A.fold_convtdf_state(sd, d.num_blocks, d.l, tdf_bias=bias))
+    return eng, sd, d
+
+
+@pytest.mark.parametrize("name", list(NET_VARIANTS))
+def test_net_variants_golden(A, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "net_variants.npz"))
+    eng, sd, d = variant_engine(A, name)
+    x = np.random.default_rng(int(g["x_seed"])).standard_normal((2, 4, 32, 16)).astype(np.float32)
+    y = eng.net_forward(x)
+    assert rel_rms(y, g[name]) < 2e-5, rel_rms(y, g[name])
+    assert eng.net_flops(1) == O.net_flops(d)
+
+
+def test_groupnorm_demix_golden_and_batch_invariance(A, golden_dir):
+    """GroupNorm statistics are per chunk: the chunk loop's result must not depend on how many chunks share a net pass."""
+    g = np.load(os.path.join(golden_dir, "net_variants.npz"))
+    mix = (0.4 * np.random.default_rng(int(g["mix_seed"])).standard_normal((2, int(g["mix_n"])))).astype(np.float32)
+    outs = []
+    for mb in (1, 3, 64):
+        eng, _, _ = variant_engine(A, "gn", max_batch=mb)
+        outs.append(eng.demix(mix))
+    assert rel_rms(outs[0], g["gn_demix"]) < TOL_STEM, rel_rms(outs[0], g["gn_demix"])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_groupnorm_net_mid_vs_oracle(A):
+    # HQ_3's channel plan with GroupNorm(2, c) on a reduced spectrogram: production tile shapes under the unfused norm passes
+    d = O.NetDims(dim_c=4, dim_f=768, dim_t=64, g=48, l=3, num_blocks=11, k=3, bn=8, norm="group")
+    sd = O.make_convtdf_state(d, seed=1)
+    eng = A.Engine(A.MDXConfig(n_fft=1536, hop_length=256, dim_f=768, segment_size=64))
+    eng.load_net(A.NetConfig(dim_c=4, dim_f=768, dim_t=64, g=48, l=3, num_blocks=11, k=3, bn=8, norm="group"), A.fold_convtdf_state(sd, d.num_blocks, d.l))
+    x = np.random.default_rng(2).standard_normal((2, 4, 768, 64)).astype(np.float32)
+    y = eng.net_forward(x)
+    ref = O.convtdf_forward(x, sd, d)
+    assert rel_rms(y, ref) < 2e-5, rel_rms(y, ref)
+
+
 def test_net_mid_vs_oracle(A):
     # HQ_3's channel plan (g=48, 11 blocks, l=3, bn=8) on a reduced spectrogram
     d = O.NetDims(dim_c=4, dim_f=768, dim_t=64, g=48, l=3, num_blocks=11, k=3, bn=8)
@@ -695,6 +745,38 @@ def test_conv3x3_winograd_stationary(A, B, cin, cout, T, F, variant=1, relu=True
     assert max_abs(y, y3) < 2e-5, max_abs(y, y3)
 
 
+@pytest.mark.parametrize("B,cin,cout,T,F,relu", [(1, 144, 144, 8, 96, True), (2, 96, 96, 10, 44, True), (1, 288, 288, 8, 96, True), (1, 64, 20, 16, 64, False),
+                                                 (1, 80, 80, 9, 36, True), (3, 192, 192, 5, 33 * 4, True), (1, 240, 240, 16, 192, True), (2, 160, 50, 3, 8, False)])
+def test_conv3x3_winograd_bf16x6(A, B, cin, cout, T, F, relu):
+    """conv_wino6_kernel (csrc/kernels_wino6.h, round 5: the default for 3x3 TFC layers with >= 144 input channels): Winograd
+    F(2x2,3x3) with the sixteen transform-domain GEMMs as six bf16 MFMA products on exactly split operands.  Against torch, against
+    conv_wino3_kernel on the same layer, with proof of which kernel ran; ragged planes, channel counts off the 32 / 48 grids, border
+    tiles, several batch items."""
+    eng = A.Engine(small_cfg(A))
+    assert eng.option("winograd") == 3 and eng.option("winograd_bf16x6") == 144
+    eng.set_option("winograd_bf16x6", 64)
+    rng = np.random.default_rng(cin * 1000 + cout + T + 13)
+    x = rng.standard_normal((B, cin, T, F)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    n0 = eng.counter("wino6_launches")
+    y = eng.op_conv("conv3x3", x, w, b, relu=relu)
+    assert eng.counter("wino6_launches") == n0 + 1, "conv_wino6_kernel did not run"
+    ref = _torch_ref("conv3x3", x, w, b, relu=relu)
+    assert np.isfinite(y).all(), "unwritten (NaN canary) output elements"
+    assert max_abs(y, ref) < 5e-5, (max_abs(y, ref), rel_rms(y, ref))
+    eng.set_option("winograd_bf16x6", 0)
+    y3 = eng.op_conv("conv3x3", x, w, b, relu=relu)
+    assert eng.counter("wino6_launches") == n0 + 1, "the fp32 run went through conv_wino6_kernel"
+    assert max_abs(y, y3) < 2e-5, max_abs(y, y3)
+    # float64 reference: at least as close as the fp32 Winograd kernel (a reduced-precision shortcut would fail this by 100x)
+    import torch
+    r64 = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1)
+    r64 = (torch.relu(r64) if relu else r64).numpy()
+    e6, e3 = rel_rms(y, r64), rel_rms(y3, r64)
+    assert e6 < 1e-6 and e6 <= 1.25 * e3 + 1e-8, (e6, e3)
+
+
 _HQ3_EXCERPT = {}
 
 
@@ -707,19 +789,31 @@ def _hq3_excerpt():
     return _HQ3_EXCERPT
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 30])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 30, 36, 306])
 def test_winograd_hq3_excerpt_vs_oracle(A, mode):
-    # 3 = the default (conv_wino3_kernel everywhere); 30 = the weight-stationary kernel on the two outer levels
+    # 3 = the default (conv_wino3_kernel on levels 0 / 1, conv_wino6_kernel from 144 channels); 30 = the weight-stationary kernel on the
+    # two outer levels; 36 = conv_wino6_kernel on every level it can take (>= 64 channels: level 1 too); 306 = conv_wino3_kernel everywhere
     c = _hq3_excerpt()
     d, sd, mix, ref = c["d"], c["sd"], c["mix"], c["ref"]
     eng = A.Engine(A.MDXConfig(max_batch=2))
+    want6 = {3: 21, 36: 27, 306: 0}.get(mode)          # 3x3 launches per net pass on conv_wino6_kernel (6 per level, 3 at the bottleneck)
     if mode == 30:
         mode = 3
         eng.set_option("winograd_stationary", 1)
+    elif mode == 36:
+        mode = 3
+        eng.set_option("winograd_bf16x6", 64)
+    elif mode == 306:
+        mode = 3
+        eng.set_option("winograd_bf16x6", 0)
     eng.set_option("winograd", mode)
     assert eng.option("winograd") == mode
     eng.load_net(A.NetConfig(), A.fold_convtdf_state(sd, d.num_blocks, d.l))
+    n6 = eng.counter("wino6_launches")
     got = eng.demix(mix)
+    if want6 is not None:
+        passes = -(-eng.plan(mix.shape[1])["n_chunks"] // 2)        # max_batch = 2
+        assert eng.counter("wino6_launches") - n6 == want6 * passes, (eng.counter("wino6_launches") - n6, want6, passes)
     e = rel_rms(got, ref)
     print("HQ_3 excerpt rel-RMS (winograd):", e)
     assert e < TOL_STEM, e

@@ -45,6 +45,26 @@ def test_reader_other_exporter_settings(golden_dir, fname):
         assert np.allclose(tensors[k], want[k], rtol=2e-6, atol=2e-7), k
 
 
+@pytest.mark.parametrize("tag,norm,bn,bias,seed", [("gn_bias", "group", 4, True, 12), ("gn_op17_nofold", "group", 4, False, 11), ("gn_bn0", "group", 0, True, 14),
+                                                   ("bn0", "batch", 0, False, 13), ("notdf", "batch", None, False, 15)])
+def test_reader_convtdf_variants(golden_dir, tag, norm, bn, bias, seed):
+    """The other ConvTDFNet forms the reference class builds (uvr_lib_v5/mdxnet.py:45-49, modules.py:52-70), exported by torch from
+    that class: GroupNorm(2, c) arrives as Reshape -> InstanceNormalization -> Reshape -> Mul -> Add and is read back as UNFOLDED
+    weights + the affine of every norm; bn == 0 has one square TDF linear per block; bn is None has none."""
+    path = os.path.join(golden_dir, f"net_small_{tag}.onnx")
+    cfg, tensors = convtdf_from_onnx(path, dim_t=16)
+    assert (cfg.dim_c, cfg.dim_f, cfg.dim_t, cfg.g, cfg.l, cfg.num_blocks, cfg.k, cfg.bn, cfg.tdf_bias, cfg.norm) == (4, 32, 16, 8, 2, 5, 3, bn, bias, norm)
+    d = O.NetDims(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=bn, bias=bias, norm=norm)
+    want = fold_convtdf_state(O.make_convtdf_state(d, seed=seed), d.num_blocks, d.l, tdf_bias=bias)
+    assert sorted(tensors) == sorted(want)
+    if norm == "group":
+        # one norm behind every conv / linear but the final conv: 5 blocks x (2 TFC + 2 or 1 TDF) + first + 2 ds + 2 us
+        assert sum(k.endswith(".gn_w") for k in tensors) == (25 if bn else 20) and not any(k.endswith(".scale") for k in tensors)
+    for k in want:
+        assert tensors[k].shape == want[k].shape and tensors[k].dtype == np.float32, k
+        assert np.allclose(tensors[k], want[k], rtol=2e-6, atol=2e-7), k
+
+
 def test_graph_structure(golden_dir):
     nodes, inits, inputs = parse_onnx(os.path.join(golden_dir, "net_small.onnx"))
     ops = [n.op for n in nodes]
@@ -101,7 +121,7 @@ def test_reader_other_exporter_lineages(idioms, bias):
 
 
 @pytest.mark.parametrize("op,what", [("Sigmoid", "unsupported op"), ("LeakyRelu", "unsupported op"), ("Pad", "unsupported op"),
-                                     ("InstanceNormalization", "unsupported op"), ("Slice", "shape arithmetic"), ("Squeeze", "activation")])
+                                     ("InstanceNormalization", "outside the GroupNorm"), ("Slice", "shape arithmetic"), ("Squeeze", "activation")])
 def test_reader_fails_loudly_on_ops_it_cannot_account_for(op, what):
     """An activation-side node that is not part of the BatchNorm ConvTDFNet must stop the load, with the node named -- skipping
     it would silently run a different model."""

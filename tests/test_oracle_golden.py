@@ -68,6 +68,34 @@ def test_net_small(golden_dir, fname, bias, wseed):
     assert rel_rms(y, g["y"]) < 1e-5
 
 
+VARIANTS = {"gn": ("group", 4, False, 11), "gn_bias": ("group", 4, True, 12), "bn0": ("batch", 0, False, 13), "gn_bn0": ("group", 0, True, 14),
+            "notdf": ("batch", None, False, 15)}
+
+
+def variant_dims(name):
+    norm, bn, bias, seed = VARIANTS[name]
+    return O.NetDims(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=bn, bias=bias, norm=norm), seed
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_net_variants(golden_dir, name):
+    """GroupNorm(2, c) (optimizer 'adamw'), bn == 0 and bn is None forms of the reference ConvTDFNet (tests/golden/make_golden_variants.py)"""
+    g = load(golden_dir, "net_variants.npz")
+    d, seed = variant_dims(name)
+    x = np.random.default_rng(int(g["x_seed"])).standard_normal((2, 4, 32, 16)).astype(np.float32)
+    y = O.convtdf_forward(x, O.make_convtdf_state(d, seed=seed), d)
+    assert rel_rms(y, g[name]) < 1e-6
+
+
+def test_groupnorm_net_through_the_chunk_loop(golden_dir):
+    g = load(golden_dir, "net_variants.npz")
+    d, seed = variant_dims("gn")
+    mix = (0.4 * np.random.default_rng(int(g["mix_seed"])).standard_normal((2, int(g["mix_n"])))).astype(np.float32)
+    p = O.MDXParams(n_fft=96, hop_length=16, dim_f=32, segment_size=16, overlap=0.25)
+    y = O.demix(mix, p, O.make_model_run(O.make_convtdf_state(d, seed=seed), d))
+    assert rel_rms(y, g["gn_demix"]) < 1e-5
+
+
 def _small_net():
     d = O.NetDims(dim_c=4, dim_f=32, dim_t=16, g=8, l=2, num_blocks=5, k=3, bn=4, bias=False)
     return O.make_model_run(O.make_convtdf_state(d, seed=3), d)

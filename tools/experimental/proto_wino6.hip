@@ -1,4 +1,4 @@
-// Stand-alone harness of the bf16x6 Winograd kernel (csrc/kernels_wino6.h): a float64 direct convolution on small shapes
+// Stand-alone harness of the bf16x6 Winograd kernel (python-audio-separator_amd/csrc/kernels_wino6.h): a float64 direct convolution on small shapes
 // (borders, ragged sizes, channel padding), then time per launch on the HQ_3 level shapes against conv_wino3_kernel.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/experimental/proto_wino6 tools/experimental/proto_wino6.hip
 //   tools/experimental/proto_wino6 [abl] [first shape] [last shape] [nt switches] [grid] [one: 1 = one workgroup per (tile, channel group)]
@@ -12,7 +12,7 @@
 
 #include "../../python-audio-separator_amd/csrc/kernels_net.h"
 #include "../../python-audio-separator_amd/csrc/kernels_wino.h"
-#include "kernels_wino6.h"
+#include "../../python-audio-separator_amd/csrc/kernels_wino6.h"
 
 using namespace asx;
 

@@ -23,35 +23,43 @@ class NetDims:
     l: int = 3
     num_blocks: int = 11
     k: int = 3
-    bn: int = 8
+    bn: int | None = 8        # 0: one Linear(f, f) in the TDF branch; None: no TDF branch (modules.py:52-70)
     bias: bool = False        # TDF Linear bias (kuielab configs train with bias=False)
+    norm: str = "batch"       # "batch" = BatchNorm2d (optimizer 'rmsprop'), "group" = GroupNorm(2, c) ('adamw'), mdxnet.py:45-49
 
     @property
     def n(self) -> int:
         return self.num_blocks // 2
 
 
-def _bn_init(gen: torch.Generator, c: int, prefix: str, sd: dict):
+def _bn_init(gen: torch.Generator, c: int, prefix: str, sd: dict, group: bool = False):
     sd[prefix + ".weight"] = 0.8 + 0.4 * torch.rand(c, generator=gen)
     sd[prefix + ".bias"] = 0.1 * torch.randn(c, generator=gen)
-    sd[prefix + ".running_mean"] = 0.1 * torch.randn(c, generator=gen)
-    sd[prefix + ".running_var"] = 0.5 + torch.rand(c, generator=gen)
+    if not group:                                      # GroupNorm carries no running statistics
+        sd[prefix + ".running_mean"] = 0.1 * torch.randn(c, generator=gen)
+        sd[prefix + ".running_var"] = 0.5 + torch.rand(c, generator=gen)
 
 
 def _tfc_tdf_init(gen, c, f, d: NetDims, prefix, sd):
+    grp = d.norm == "group"
     for j in range(d.l):
         fan = c * d.k * d.k
         sd[f"{prefix}.tfc.H.{j}.0.weight"] = torch.randn(c, c, d.k, d.k, generator=gen) * math.sqrt(2.0 / fan)
         sd[f"{prefix}.tfc.H.{j}.0.bias"] = 0.05 * torch.randn(c, generator=gen)
-        _bn_init(gen, c, f"{prefix}.tfc.H.{j}.1", sd)
-    sd[f"{prefix}.tdf.0.weight"] = torch.randn(f // d.bn, f, generator=gen) * math.sqrt(1.0 / f)
+        _bn_init(gen, c, f"{prefix}.tfc.H.{j}.1", sd, grp)
+    if d.bn is None:
+        return
+    fb = f if d.bn == 0 else f // d.bn
+    sd[f"{prefix}.tdf.0.weight"] = torch.randn(fb, f, generator=gen) * math.sqrt(1.0 / f)
     if d.bias:
-        sd[f"{prefix}.tdf.0.bias"] = 0.05 * torch.randn(f // d.bn, generator=gen)
-    _bn_init(gen, c, f"{prefix}.tdf.1", sd)
-    sd[f"{prefix}.tdf.3.weight"] = torch.randn(f, f // d.bn, generator=gen) * math.sqrt(1.0 / (f // d.bn))
+        sd[f"{prefix}.tdf.0.bias"] = 0.05 * torch.randn(fb, generator=gen)
+    _bn_init(gen, c, f"{prefix}.tdf.1", sd, grp)
+    if d.bn == 0:
+        return
+    sd[f"{prefix}.tdf.3.weight"] = torch.randn(f, fb, generator=gen) * math.sqrt(1.0 / fb)
     if d.bias:
         sd[f"{prefix}.tdf.3.bias"] = 0.05 * torch.randn(f, generator=gen)
-    _bn_init(gen, c, f"{prefix}.tdf.4", sd)
+    _bn_init(gen, c, f"{prefix}.tdf.4", sd, grp)
 
 
 def make_convtdf_state(d: NetDims, seed: int = 0) -> dict:
@@ -64,20 +72,20 @@ def make_convtdf_state(d: NetDims, seed: int = 0) -> dict:
     g = d.g
     sd["first_conv.0.weight"] = torch.randn(g, d.dim_c, 1, 1, generator=gen) * math.sqrt(2.0 / d.dim_c)
     sd["first_conv.0.bias"] = 0.05 * torch.randn(g, generator=gen)
-    _bn_init(gen, g, "first_conv.1", sd)
+    _bn_init(gen, g, "first_conv.1", sd, d.norm == "group")
     f, c = d.dim_f, g
     for i in range(d.n):
         _tfc_tdf_init(gen, c, f, d, f"encoding_blocks.{i}", sd)
         sd[f"ds.{i}.0.weight"] = torch.randn(c + g, c, 2, 2, generator=gen) * math.sqrt(2.0 / (4 * c))
         sd[f"ds.{i}.0.bias"] = 0.05 * torch.randn(c + g, generator=gen)
-        _bn_init(gen, c + g, f"ds.{i}.1", sd)
+        _bn_init(gen, c + g, f"ds.{i}.1", sd, d.norm == "group")
         f //= 2
         c += g
     _tfc_tdf_init(gen, c, f, d, "bottleneck_block", sd)
     for i in range(d.n):
         sd[f"us.{i}.0.weight"] = torch.randn(c, c - g, 2, 2, generator=gen) * math.sqrt(1.0 / c)
         sd[f"us.{i}.0.bias"] = 0.05 * torch.randn(c - g, generator=gen)
-        _bn_init(gen, c - g, f"us.{i}.1", sd)
+        _bn_init(gen, c - g, f"us.{i}.1", sd, d.norm == "group")
         f *= 2
         c -= g
         _tfc_tdf_init(gen, c, f, d, f"decoding_blocks.{i}", sd)
