@@ -151,6 +151,12 @@ def test_bs_roformer_chunk(A):
     g32 = got32[:, 0] if got32.ndim == 4 else got32
     e6, e32, d = rel_rms(g6, want), rel_rms(g32, want), rel_rms(g6, g32)
     print(f"BS-Roformer ep_317 layout, depth 12, one chunk: rel-RMS vs oracle bf16x6 {e6:.3e}, fp32-MFMA {e32:.3e}, between them {d:.3e}")
+    if d >= 2e-5:          # where the two matrix pipes disagree (round 5: 3e-5 .. 7e-5 on two boxes with one build, 1.9e-6 on every other run)
+        err = (g6.astype(np.float64) - g32) ** 2
+        per_hop = err.reshape(-1, err.shape[-1])[:, : (err.shape[-1] // 441) * 441].reshape(err.reshape(-1, err.shape[-1]).shape[0], -1, 441).sum((0, 2))
+        top = np.argsort(per_hop)[::-1][:8]
+        print("  error energy by 441-sample hop: total", float(per_hop.sum()), "top hops", [(int(i), float(per_hop[i] / per_hop.sum())) for i in top],
+              "second bf16x6 run identical:", bool(np.array_equal(got, eng.rof_forward(x))))
     assert e6 < TOL and e32 < TOL, (e6, e32)
     assert e6 < 2e-5 and d < 2e-5, (e6, d)
 
