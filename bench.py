@@ -486,7 +486,9 @@ def main():
                          **comm),
             "roofline": roofline, "cpu_baseline": cpu,
             # what "f32" means inside: nothing runs in a reduced-precision mode
-            "arithmetic": {"io": "float32", "conv3x3": "Winograd F(2x2,3x3): fp32 MFMA (exact fma chains) below the winograd_bf16x6 channel count (default 144), six bf16 MFMA products on exactly split operands from there up (csrc/kernels_wino6.h)",
+            "arithmetic": {"io": "float32",
+                           "conv3x3": "Winograd F(2x2,3x3): fp32 MFMA (exact fma chains) below the winograd_bf16x6 channel count (default 144), "
+                                      "six bf16 MFMA products on exactly split operands from there up (csrc/kernels_wino6.h)",
                            "row_gemm": ("six bf16 MFMA products on fp32 operands split EXACTLY into three bf16 parts each (dropped cross "
                                         "terms < 2^-24 of a product; closer to a float64 GEMM than the fp32-MFMA kernel, "
                                         "tests/test_gpu_parity.py::test_rowgemm_bf16x6_vs_float64)") if eng.option("gemm_bf16x6") > 0

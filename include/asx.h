@@ -141,6 +141,10 @@ const char *asx_last_error(void);
 int asx_device_count(void);
 int asx_engine_create(int device, const asx_mdx_config *cfg, asx_engine **out);
 void asx_engine_destroy(asx_engine *e);
+/* The `window=` of torch.stft / istft (ABI 6): `n` = n_fft floats -- a window function evaluated over win_length and zero padded to
+ * n_fft at both ends, as torch does -- replacing the periodic Hann the engine builds.  BSRoformer's `stft_window_fn`
+ * (uvr_lib_v5/roformer/bs_roformer.py:333, 386).  Call it before the first forward (it synchronises the device). */
+int asx_set_stft_window(asx_engine *e, const float *window_host, int32_t n);
 
 /* ---- model weights: replaces ort.InferenceSession(model_path)  mdx_separator.py:122 ----
  * The host hands over BatchNorm-folded fp32 tensors by canonical name, the
@@ -247,6 +251,7 @@ typedef struct asx_rof_config {
    * hidden width 4*dim. */
   int32_t mel;
   int32_t band_start[128];
+  int32_t stft_normalized;                    /* ABI 6: torch.stft / istft normalized=True (bs_roformer.py:332, 384) */
 } asx_rof_config;
 int asx_rof_begin(asx_engine *e, const asx_rof_config *cfg);
 int asx_rof_commit(asx_engine *e);

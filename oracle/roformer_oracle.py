@@ -71,6 +71,8 @@ class RoformerConfig:
     sample_rate: int = 44100
     instruments: tuple = ("vocals", "other")
     target_instrument: str | None = "vocals"
+    stft_normalized: bool = False        # torch.stft / istft normalized=True (bs_roformer.py:332, 384)
+    stft_window_fn: str = "hann_window"  # name of the torch window function (bs_roformer.py:333, 386: default torch.hann_window)
     mel: bool = False            # MelBandRoformer (mel_band_roformer.py): overlapping mel bands, see mel_band_layout
     num_bands: int = 60
     band_starts: tuple = ()      # mel only: first frequency bin of each band
@@ -99,17 +101,24 @@ class RoformerConfig:
                         mlp_expansion_factor=self.mlp_expansion_factor, dim_freqs_in=self.stft_n_fft // 2 + 1,
                         sample_rate=self.sample_rate, stft_n_fft=self.stft_n_fft, stft_hop_length=self.stft_hop_length,
                         stft_win_length=self.stft_win_length, mask_estimator_depth=self.mask_estimator_depth)
-        return dict(dim=self.dim, depth=self.depth, stereo=self.stereo, num_stems=self.num_stems,
-                    time_transformer_depth=self.time_transformer_depth,
-                    freq_transformer_depth=self.freq_transformer_depth, freqs_per_bands=tuple(self.freqs_per_bands),
-                    dim_head=self.dim_head, heads=self.heads, mlp_expansion_factor=self.mlp_expansion_factor,
-                    stft_n_fft=self.stft_n_fft, stft_hop_length=self.stft_hop_length,
-                    stft_win_length=self.stft_win_length)
+        kw = dict(dim=self.dim, depth=self.depth, stereo=self.stereo, num_stems=self.num_stems,
+                  time_transformer_depth=self.time_transformer_depth,
+                  freq_transformer_depth=self.freq_transformer_depth, freqs_per_bands=tuple(self.freqs_per_bands),
+                  dim_head=self.dim_head, heads=self.heads, mlp_expansion_factor=self.mlp_expansion_factor,
+                  stft_n_fft=self.stft_n_fft, stft_hop_length=self.stft_hop_length,
+                  stft_win_length=self.stft_win_length)
+        if self.stft_normalized:
+            kw["stft_normalized"] = True
+        if self.stft_window_fn != "hann_window":
+            kw["stft_window_fn"] = getattr(torch, self.stft_window_fn)
+        return kw
 
     def as_model_data(self) -> dict:
         m = self.model_kwargs()
         if not self.mel:
             m["freqs_per_bands"] = list(self.freqs_per_bands)
+        if "stft_window_fn" in m:                      # a YAML carries a callable as its dotted name
+            m["stft_window_fn"] = "torch." + self.stft_window_fn
         return {"audio": {"sample_rate": self.sample_rate, "hop_length": self.stft_hop_length, "n_fft": self.stft_n_fft,
                           "num_channels": 2, "dim_f": self.stft_n_fft // 2, "chunk_size": self.stft_hop_length * (self.dim_t - 1)},
                 "model": m, "training": {"instruments": list(self.instruments), "target_instrument": self.target_instrument},
@@ -265,9 +274,9 @@ def roformer_forward(wave, sd: dict, cfg: RoformerConfig):
     """BSRoformer.forward (bs_roformer.py:418-522), inference branch: [B,2,t] -> [B,(n,)2,t']."""
     raw = torch.as_tensor(np.ascontiguousarray(wave), dtype=torch.float32)
     b, s, t = raw.shape
-    win = torch.hann_window(cfg.stft_win_length)
+    win = getattr(torch, cfg.stft_window_fn)(cfg.stft_win_length)
     st = torch.stft(raw.reshape(b * s, t), n_fft=cfg.stft_n_fft, hop_length=cfg.stft_hop_length,
-                    win_length=cfg.stft_win_length, window=win, return_complex=True)
+                    win_length=cfg.stft_win_length, window=win, normalized=cfg.stft_normalized, return_complex=True)
     st = torch.view_as_real(st).reshape(b, s, st.shape[1], st.shape[2], 2)          # b s f t c
     stft_repr = st.permute(0, 2, 1, 3, 4).reshape(b, -1, st.shape[3], 2)           # b (f s) t c
     x = stft_repr.permute(0, 2, 1, 3).reshape(b, stft_repr.shape[2], -1)            # b t (f c)
@@ -320,7 +329,8 @@ def roformer_forward(wave, sd: dict, cfg: RoformerConfig):
     z = torch.view_as_complex(stft_repr.unsqueeze(1).contiguous()) * torch.view_as_complex(mask.contiguous())
     z = z.reshape(b, cfg.num_stems, -1, s, z.shape[-1]).permute(0, 1, 3, 2, 4)      # b n s f t
     rec = torch.istft(z.reshape(b * cfg.num_stems * s, z.shape[3], z.shape[4]), n_fft=cfg.stft_n_fft,
-                      hop_length=cfg.stft_hop_length, win_length=cfg.stft_win_length, window=win, return_complex=False)
+                      hop_length=cfg.stft_hop_length, win_length=cfg.stft_win_length, window=win, normalized=cfg.stft_normalized,
+                      return_complex=False)
     rec = rec.reshape(b, cfg.num_stems, s, -1)
     if cfg.num_stems == 1:
         rec = rec[:, 0]

@@ -43,6 +43,7 @@ struct RofNet {
   // workspace
   int ws_batch = 0;
   DevBuf X0, XB, TOK, XN, RS, QKV, ATT, GATE, FFH, HID, GLU, MASK, frames, chunk_out, d_starts, d_window;
+  DevBuf win_synth;   // stft_normalized: the synthesis window x sqrt(n_fft) (torch.istft multiplies its input by sqrt(n_fft) first)
 };
 
 static void rof_free_lin(RofLin &l) {
@@ -74,7 +75,7 @@ static void rof_free(RofNet &n) {
     for (auto &b : s)
       for (auto &l : b) rof_free_lin(l);
   DevBuf *bufs[] = {&n.X0, &n.XB, &n.TOK, &n.XN, &n.RS, &n.QKV, &n.ATT, &n.GATE, &n.FFH, &n.HID, &n.GLU,
-                    &n.MASK, &n.frames, &n.chunk_out, &n.d_starts, &n.d_window};
+                    &n.MASK, &n.frames, &n.chunk_out, &n.d_starts, &n.d_window, &n.win_synth};
   for (auto *b : bufs) b->release();
   n.ready = false;
   n.ws_batch = 0;
@@ -387,7 +388,23 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
   return ASX_OK;
 }
 
+// torch.istft(normalized=True) multiplies the spectrum by sqrt(n_fft) before the inverse transform: folded into the synthesis window
+// (the fold's envelope keeps the plain window squared)
+static int rof_build_win_synth(asx_engine *e) {
+  RofNet &n = *e->rof;
+  if (!n.cfg.stft_normalized || n.win_synth.p) return ASX_OK;
+  std::vector<float> w;
+  if ((int)e->custom_window.size() == e->cfg.n_fft) w = e->custom_window;
+  else host_window(e->cfg.n_fft, w, e->cfg.win_length);
+  const float sc = (float)sqrt((double)e->cfg.n_fft);
+  for (auto &v : w) v *= sc;
+  CHK(n.win_synth.ensure(w.size() * 4));
+  HIPCHK(hipMemcpy(n.win_synth.p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+  return ASX_OK;
+}
+
 static int rof_ensure_workspace(asx_engine *e, int B) {
+  CHK(rof_build_win_synth(e));
   RofNet &n = *e->rof;
   if (B <= n.ws_batch) return ASX_OK;
   const asx_rof_config &c = n.cfg;
@@ -438,7 +455,8 @@ static int rof_chunks_dev(asx_engine *e, const float *wave, const int64_t *d_sta
     a.spec = n.X0.f();
     a.window = e->d_window.f();
     a.tw = reinterpret_cast<const float2 *>(e->d_tw.p);
-    a.sign = 1.0f;
+    // torch.stft(normalized=True) (bs_roformer.py:332, 384): the spectrum times n_fft^-1/2
+    a.sign = c.stft_normalized ? (float)(1.0 / sqrt((double)e->cfg.n_fft)) : 1.0f;
     FftPlan p = e->plan;
     CHK(timed(e, ASX_PROF_STFT, 0.0, 4.0 * ((double)B * 2 * C + (double)BT * n.W), s, [&]() {
       hipLaunchKernelGGL(stft_kernel, dim3(T, 2, B), dim3(256), stft_lds(p), s, a, p);
@@ -501,7 +519,7 @@ static int rof_chunks_dev(asx_engine *e, const float *wave, const int64_t *d_sta
     a.tf_layout = 2;
     a.combine = 0;
     a.frames = n.frames.f();
-    a.window = e->d_window.f();
+    a.window = c.stft_normalized ? n.win_synth.f() : e->d_window.f();
     a.tw = reinterpret_cast<const float2 *>(e->d_tw.p);
     a.n_inst = S;
     FftPlan p = e->plan;

@@ -46,7 +46,7 @@ class _V3Cfg(C.Structure):
 class _RofCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "heads", "dim_head", "num_stems", "time_depth", "freq_depth",
                                          "mlp_expansion_factor", "mask_estimator_depth", "n_bands", "n_out")] + \
-               [("freqs_per_bands", C.c_int32 * 128), ("mel", C.c_int32), ("band_start", C.c_int32 * 128)]
+               [("freqs_per_bands", C.c_int32 * 128), ("mel", C.c_int32), ("band_start", C.c_int32 * 128), ("stft_normalized", C.c_int32)]
 
 
 class _HtCfg(C.Structure):
@@ -154,6 +154,7 @@ class RofConfig:
     n_out: int = 2
     mel: bool = False           # MelBandRoformer: band j covers bins [band_starts[j], + freqs_per_bands[j])
     band_starts: tuple = ()
+    stft_normalized: bool = False   # torch.stft / istft normalized=True (bs_roformer.py:332, 384)
 
 
 @dataclass
@@ -221,18 +222,22 @@ ABI_VERSION = 6   # ASX_ABI_VERSION of include/asx.h the structures below mirror
 # every symbol include/asx.h declares
 SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_create", "asx_engine_destroy",
            "asx_net_begin", "asx_net_set_tensor", "asx_net_commit", "asx_net_flops", "asx_plan_query", "asx_demix",
-           "asx_demix_dev", "asx_demix_chunks_dev", "asx_finalize_dev", "asx_separate", "asx_separate_dev", "asx_stft", "asx_istft", "asx_net_forward",
-           "asx_run_model", "asx_op_conv", "asx_op_tdf", "asx_profile_enable", "asx_profile_read", "asx_v3_begin",
-           "asx_v3_commit", "asx_v3_flops", "asx_v3_forward", "asx_mdxc_plan", "asx_mdxc_demix", "asx_mdxc_demix_dev",
-           "asx_set_option", "asx_rof_begin", "asx_rof_commit", "asx_rof_flops", "asx_rof_forward", "asx_rof_demix", "asx_rof_demix_dev",
-           "asx_ht_begin", "asx_ht_commit", "asx_ht_flops", "asx_ht_forward", "asx_ht_demix", "asx_ht_demix_dev",
-           "asx_vr_begin", "asx_vr_commit", "asx_vr_flops", "asx_vr_plan", "asx_vr_forward", "asx_vr_analysis",
-           "asx_vr_separate", "asx_vr_separate_dev", "asx_debug_fetch",
-           "asx_mdxc_chunks_dev", "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev",
-           "asx_ht_plan", "asx_ht_segments_dev", "asx_ht_fold_dev",
-           "asx_hd_begin", "asx_hd_commit", "asx_hd_flops", "asx_hd_forward", "asx_hd_demix", "asx_hd_demix_dev", "asx_hd_plan",
-           "asx_hd_segments_dev", "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev", "asx_ht_standardize_dev", "asx_ht_bag_accumulate_dev", "asx_ht_bag_finish_dev", "asx_ensemble", "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_normalize_dev", "asx_residual_dev", "asx_profile_launches", "asx_debug_trace",
-           "asx_resample_sinc", "asx_resample_sinc_dev", "asx_counter"]
+           "asx_demix_dev", "asx_demix_chunks_dev", "asx_finalize_dev", "asx_separate", "asx_separate_dev",
+           "asx_stft", "asx_istft", "asx_net_forward", "asx_run_model", "asx_op_conv", "asx_op_tdf",
+           "asx_profile_enable", "asx_profile_read", "asx_v3_begin", "asx_v3_commit", "asx_v3_flops",
+           "asx_v3_forward", "asx_mdxc_plan", "asx_mdxc_demix", "asx_mdxc_demix_dev", "asx_set_option",
+           "asx_rof_begin", "asx_rof_commit", "asx_rof_flops", "asx_rof_forward", "asx_rof_demix",
+           "asx_rof_demix_dev", "asx_ht_begin", "asx_ht_commit", "asx_ht_flops", "asx_ht_forward", "asx_ht_demix",
+           "asx_ht_demix_dev", "asx_vr_begin", "asx_vr_commit", "asx_vr_flops", "asx_vr_plan", "asx_vr_forward",
+           "asx_vr_analysis", "asx_vr_separate", "asx_vr_separate_dev", "asx_debug_fetch", "asx_mdxc_chunks_dev",
+           "asx_mdxc_finalize_dev", "asx_rof_plan", "asx_rof_chunks_dev", "asx_rof_finalize_dev", "asx_ht_plan",
+           "asx_ht_segments_dev", "asx_ht_fold_dev", "asx_hd_begin", "asx_hd_commit", "asx_hd_flops",
+           "asx_hd_forward", "asx_hd_demix", "asx_hd_demix_dev", "asx_hd_plan", "asx_hd_segments_dev",
+           "asx_hd_fold_dev", "asx_pcm16", "asx_pcm16_dev", "asx_pcm16_rows_dev", "asx_pcm_decode_dev",
+           "asx_ht_standardize_dev", "asx_ht_bag_accumulate_dev", "asx_ht_bag_finish_dev", "asx_ensemble",
+           "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_normalize_dev", "asx_residual_dev",
+           "asx_profile_launches", "asx_debug_trace", "asx_resample_sinc", "asx_resample_sinc_dev", "asx_counter",
+           "asx_set_stft_window"]
 
 
 class _LaunchRec(C.Structure):     # struct asx_launch_rec
@@ -301,6 +306,7 @@ def load_library():
     lib.asx_rof_demix_dev.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.asx_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.asx_counter.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    lib.asx_set_stft_window.argtypes = [vp, _FP, i32]
     lib.asx_ht_begin.argtypes = [vp, C.POINTER(_HtCfg)]
     lib.asx_ht_commit.argtypes = [vp]
     lib.asx_ht_flops.argtypes = [vp]
@@ -527,6 +533,7 @@ class Engine:
         for i, f in enumerate(rc.freqs_per_bands):
             c.freqs_per_bands[i] = int(f)
         c.mel = int(bool(rc.mel))
+        c.stft_normalized = int(bool(rc.stft_normalized))
         if rc.mel:
             if len(rc.band_starts) != len(rc.freqs_per_bands):
                 raise ValueError("mel: one band start per band")
@@ -540,6 +547,11 @@ class Engine:
             self._check(self._lib.asx_net_set_tensor(self._h, name.encode(), _ptr(a), a.size))
         self._check(self._lib.asx_rof_commit(self._h))
         self.rof_cfg = rc
+
+    def set_stft_window(self, window: np.ndarray):
+        """Replace the periodic Hann of torch.stft / istft by `window` [n_fft] (already zero padded from win_length like torch pads it)."""
+        w = _f32(window).reshape(-1)
+        self._check(self._lib.asx_set_stft_window(self._h, _ptr(w), int(w.size)))
 
     def rof_flops(self, batch: int = 1) -> float:
         return float(self._lib.asx_rof_flops(self._h, batch))

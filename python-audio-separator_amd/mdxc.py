@@ -63,6 +63,24 @@ def _get(d, *path, default=None):
     return d
 
 
+def stft_window_table(window_fn, win_length: int, n_fft: int) -> np.ndarray:
+    """BSRoformer's ``stft_window_fn`` (bs_roformer.py:333, 386: ``partial(default(stft_window_fn, torch.hann_window), stft_win_length)``)
+    as the table torch.stft / istft use: the function evaluated over ``win_length`` in float32 and zero padded to ``n_fft`` at both
+    ends.  ``window_fn`` is a callable, or the dotted name a YAML carries (``torch.hamming_window``, ``hamming_window``); only functions of
+    the ``torch`` namespace are resolved from names."""
+    import torch
+    if isinstance(window_fn, str):
+        name = window_fn.rsplit(".", 1)[-1]
+        if not name.endswith("_window") or not hasattr(torch, name):
+            raise NotImplementedError(f"stft_window_fn {window_fn!r}: not a torch window function")
+        window_fn = getattr(torch, name)
+    w = window_fn(int(win_length)).to(torch.float32).cpu().numpy()
+    out = np.zeros(int(n_fft), np.float32)
+    off = (int(n_fft) - int(win_length)) // 2
+    out[off:off + int(win_length)] = w
+    return out
+
+
 class MDXCDemixer:
     """``common_config["model_data"]`` is the parsed model YAML (separator.py:758-777)."""
 
@@ -127,8 +145,6 @@ class MDXCDemixer:
         win_length = int(a["stft_win_length"])
         if not 0 < win_length <= n_fft:
             raise ValueError(f"stft_win_length {win_length} must be in (0, stft_n_fft = {n_fft}]")
-        if a["stft_normalized"]:
-            raise NotImplementedError("stft_normalized=True")
         # the chunk loop derives its hop from the raw YAML (mdxc_separator.py:289-296), the network from the normalised one
         hop = model.get("stft_hop_length") or audio["hop_length"]
         if int(hop) != int(a["stft_hop_length"]):
@@ -142,7 +158,7 @@ class MDXCDemixer:
                              time_transformer_depth=a["time_transformer_depth"], freq_transformer_depth=a["freq_transformer_depth"],
                              mlp_expansion_factor=a["mlp_expansion_factor"], mask_estimator_depth=a["mask_estimator_depth"],
                              freqs_per_bands=tuple(counts), n_out=max(1, len(self.instruments)), mel=mel,
-                             band_starts=tuple(starts))
+                             band_starts=tuple(starts), stft_normalized=bool(a["stft_normalized"]))
         if not a["stereo"]:
             # (the reference cannot run them either: prepare_mix always yields [2, N] and BSRoformer.forward asserts one channel
             # for a mono model, bs_roformer.py:443-445)
@@ -151,6 +167,9 @@ class MDXCDemixer:
                                        segment_size=self.mdx_segment_size, overlap=0.0, max_batch=max_batch,
                                        win_length=0 if win_length == n_fft else win_length),
                              device=_device_index(self.torch_device))
+        window_fn = a.get("stft_window_fn")
+        if window_fn is not None:
+            self.engine.set_stft_window(stft_window_table(window_fn, win_length, n_fft))
         if self._rof_state is not None:
             self.load_model(self._rof_state)
 

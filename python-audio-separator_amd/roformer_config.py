@@ -173,8 +173,8 @@ def constructor_args(cfg: dict, model_type: str) -> dict:
         a["mask_estimator_depth"] = cfg.get("mask_estimator_depth", 1)
         if "stft_normalized" in cfg:
             a["stft_normalized"] = cfg["stft_normalized"]
-        if cfg.get("stft_window_fn") is not None:
-            raise NotImplementedError("stft_window_fn other than the Hann default")
+        if cfg.get("stft_window_fn") is not None:           # forwarded for the mel class only (roformer_loader.py:175-191)
+            a["stft_window_fn"] = cfg["stft_window_fn"]
     return a
 
 
@@ -191,8 +191,8 @@ def legacy_constructor_args(model_cfg: dict, model_type: str) -> dict:
     for k, v in model_cfg.items():
         if k in a or k in ("dim", "depth"):
             a[k] = tuple(v) if k == "freqs_per_bands" else v
-    if model_cfg.get("stft_window_fn") is not None:
-        raise NotImplementedError("stft_window_fn other than the Hann default")
+    if model_cfg.get("stft_window_fn") is not None:       # a callable, or the dotted name a YAML carries (mdxc.stft_window_table)
+        a["stft_window_fn"] = model_cfg["stft_window_fn"]
     if a["linear_transformer_depth"]:
         raise NotImplementedError("linear_transformer_depth > 0")
     return a

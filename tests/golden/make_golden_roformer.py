@@ -129,6 +129,24 @@ def main():
     np.savez_compressed(os.path.join(HERE, "roformer_small.npz"), **out)
     print(os.path.getsize(os.path.join(HERE, "roformer_small.npz")))
 
+    # STFT options of the constructor (bs_roformer.py:332-333, 384-386): normalized=True, a non-Hann window function, both with a
+    # window shorter than n_fft; forward and the chunk loop
+    opts = {}
+    for key, kw in (("norm", dict(stft_normalized=True)), ("hamming", dict(stft_window_fn="hamming_window")),
+                    ("norm_blackman_win48", dict(stft_normalized=True, stft_window_fn="blackman_window", stft_win_length=48))):
+        c = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64, stft_hop_length=16,
+                             dim_t=21, sample_rate=100, mlp_expansion_factor=2, **{"stft_win_length": 64, **kw})
+        sdo = R.make_roformer_state(c, 10)
+        neto = BSRoformer(**c.model_kwargs(), flash_attn=False)
+        neto.load_state_dict(sdo, strict=True)
+        neto.eval()
+        with torch.no_grad():
+            opts["fwd_" + key] = neto(torch.tensor(w)).numpy()
+        mix = (0.4 * np.random.default_rng(3090).standard_normal((2, 777))).astype(np.float32)
+        opts["demix_" + key] = np.asarray(ref_demix(neto, c, mix, 2.5)["vocals"], np.float32)
+        print(key, "oracle vs reference", float(np.abs(R.roformer_forward(w, sdo, c) - opts["fwd_" + key]).max()))
+    np.savez_compressed(os.path.join(HERE, "roformer_stft_options.npz"), **opts)
+
 
 if __name__ == "__main__":
     main()

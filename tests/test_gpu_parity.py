@@ -615,6 +615,46 @@ def test_demix_dev_is_capturable_into_a_hip_graph(A):
         assert torch.equal(again, replayed)
 
 
+def test_captured_graph_survives_other_engines_loading_and_dying(A):
+    """the split weight images of the bf16 x 6 kernels were ONE process-wide cache that every engine's load or
+    destroy flushed -- a hipGraph captured on engine A embeds those image pointers, so engine B's load freed them under it.  They are
+    per-engine now: capture a demix of A (TDF linears wide enough for tdf3_kernel), then load, run and destroy two other engines
+    (whose own images would reuse the freed memory), then replay."""
+    import torch
+    d = O.NetDims(dim_c=4, dim_f=768, dim_t=64, g=8, l=1, num_blocks=3, k=3, bn=8)
+    cfg = A.MDXConfig(n_fft=1536, hop_length=256, dim_f=768, segment_size=64)
+    ncfg = A.NetConfig(dim_c=4, dim_f=768, dim_t=64, g=8, l=1, num_blocks=3, k=3, bn=8)
+
+    def engine(seed):
+        eng = A.Engine(cfg)
+        eng.load_net(ncfg, A.fold_convtdf_state(O.make_convtdf_state(d, seed=seed), d.num_blocks, d.l))
+        return eng
+    a = engine(1)
+    N = 40_000
+    mix = torch.tensor((0.4 * np.random.default_rng(N).standard_normal((2, N))).astype(np.float32)).cuda()
+    direct, replayed = torch.empty_like(mix), torch.zeros_like(mix)
+    side = torch.cuda.Stream()
+    n0 = a.counter("tdf3_launches")
+    with torch.cuda.stream(side):
+        a.demix_dev(mix.data_ptr(), N, direct.data_ptr(), stream=side.cuda_stream)       # sizes the workspace, builds A's split images
+    torch.cuda.synchronize()
+    assert a.counter("tdf3_launches") > n0, "the TDF linears of this net did not run on tdf3_kernel: the test would prove nothing"
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        a.demix_dev(mix.data_ptr(), N, replayed.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    other = torch.empty_like(mix)
+    for seed in (2, 3):                                   # other engines come, build their own images, and go
+        b = engine(seed)
+        b.demix_dev(mix.data_ptr(), N, other.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert not torch.equal(other, direct)
+        b.close()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(direct, replayed)
+    a.close()
+
+
 # ---------------------------------------------------------------------------
 # HQ_3 geometry (the metric configuration), bounded so the CPU oracle finishes
 # ---------------------------------------------------------------------------

@@ -51,6 +51,43 @@ def test_forward_golden(A, g):
     assert rel_rms(y2, g["fwd2"]) < TOL, rel_rms(y2, g["fwd2"])
 
 
+STFT_OPTS = {"norm": dict(stft_normalized=True), "hamming": dict(stft_window_fn="hamming_window"),
+             "norm_blackman_win48": dict(stft_normalized=True, stft_window_fn="blackman_window", stft_win_length=48)}
+
+
+@pytest.mark.parametrize("key", list(STFT_OPTS))
+def test_stft_options_golden(A, golden_dir, key):
+    """BSRoformer(stft_normalized=True / stft_window_fn=...) (bs_roformer.py:332-333, 384-386) at the ENGINE level, goldens written by
+    the reference class constructed with those arguments (tests/golden/make_golden_roformer.py): `stft_normalized` scales the spectrum
+    by n_fft^-1/2 on the way in and the synthesis window by n_fft^1/2 on the way out; the window function is evaluated with torch by
+    the host (mdxc.stft_window_table) and handed over as a table (asx_set_stft_window).  (Through the reference's loader these options
+    reach the class on the mel and the legacy paths only -- _create_bs_roformer forwards neither, roformer_loader.py:123-150 -- and the
+    plugin mirrors that: test_host_files.)"""
+    from audio_separator_amd.mdxc import stft_window_table
+    go = np.load(os.path.join(golden_dir, "roformer_stft_options.npz"))
+    opt = STFT_OPTS[key]
+    cfg = R.RoformerConfig(dim=32, depth=1, heads=2, dim_head=64, freqs_per_bands=(2, 2, 4, 8, 17), stft_n_fft=64, stft_hop_length=16,
+                           dim_t=21, sample_rate=100, mlp_expansion_factor=2, **{"stft_win_length": 64, **opt})
+    wl = cfg.stft_win_length
+    eng = A.Engine(A.MDXConfig(n_fft=64, hop_length=16, dim_f=33, segment_size=21, overlap=0.0, win_length=0 if wl == 64 else wl))
+    eng.load_rof(A.RofConfig(dim=32, depth=1, heads=2, dim_head=64, num_stems=1, time_transformer_depth=1, freq_transformer_depth=1,
+                             mlp_expansion_factor=2, mask_estimator_depth=2, freqs_per_bands=cfg.freqs_per_bands, n_out=2,
+                             stft_normalized=bool(opt.get("stft_normalized", False))), R.make_roformer_state(cfg, 10))
+    if "stft_window_fn" in opt:
+        eng.set_stft_window(stft_window_table("torch." + opt["stft_window_fn"], wl, 64))
+    w = (0.4 * np.random.default_rng(81).standard_normal((2, 2, 320))).astype(np.float32)
+    y = eng.rof_forward(w)
+    assert rel_rms(y[:, 0], go["fwd_" + key]) < TOL, rel_rms(y[:, 0], go["fwd_" + key])
+    mix = (0.4 * np.random.default_rng(3090).standard_normal((2, 777))).astype(np.float32)
+    chunk = 16 * 20
+    out = eng.rof_demix(mix, min(int(2.5 * 100), chunk))
+    assert rel_rms(out[0], go["demix_" + key]) < TOL, rel_rms(out[0], go["demix_" + key])
+    if "stft_window_fn" in opt:                        # the option is not a no-op: the Hann default gives a different signal
+        eng2 = A.Engine(A.MDXConfig(n_fft=64, hop_length=16, dim_f=33, segment_size=21, overlap=0.0, win_length=0 if wl == 64 else wl))
+        eng2.load_rof(eng.rof_cfg, R.make_roformer_state(cfg, 10))
+        assert rel_rms(eng2.rof_forward(w)[:, 0], go["fwd_" + key]) > 1e-2
+
+
 def test_forward_golden_both_matrix_pipes(A, g):
     """The same golden vector through the bf16 x 6 kernels (row GEMM tdf3_kernel + attention6_kernel, the default) and through the
     fp32-MFMA kernels (gemm_bf16x6 = 0), with proof of which attention kernel ran (library launch counter)."""

@@ -240,6 +240,30 @@ def test_roformer_constructor_args_quirks():
     assert ld.detect_model_type("/x/MelBand_v2.ckpt") == "mel_band_roformer"
 
 
+def test_roformer_stft_options_follow_the_reference_loader():
+    """Where `stft_normalized` / `stft_window_fn` reach the model class in the reference (roformer_loader.py): _create_bs_roformer
+    (:123-150) forwards NEITHER; _create_mel_band_roformer (:152-195) forwards both when the configuration has them; the legacy
+    fallback (:197-236) passes the whole model section.  The window function becomes the table torch.stft / istft use."""
+    import torch
+    from audio_separator_amd.mdxc import stft_window_table
+    bs = dict(YAMLS["ep317"])
+    bs = {**bs, "stft_normalized": True, "stft_window_fn": "torch.hamming_window"}
+    a = RC.constructor_args(RC.normalize_config(bs, "bs_roformer"), "bs_roformer")
+    assert a["stft_normalized"] is False and a.get("stft_window_fn") is None
+    mel = {**YAMLS["mel"], "stft_normalized": True, "stft_window_fn": "torch.hamming_window"}
+    m = RC.constructor_args(RC.normalize_config(mel, "mel_band_roformer"), "mel_band_roformer")
+    assert m["stft_normalized"] is True and m["stft_window_fn"] == "torch.hamming_window"
+    lg = RC.legacy_constructor_args({"dim": 8, "depth": 1, "freqs_per_bands": (2, 3), "stft_normalized": True, "stft_window_fn": torch.blackman_window},
+                                    "bs_roformer")
+    assert lg["stft_normalized"] is True and lg["stft_window_fn"] is torch.blackman_window
+    t = stft_window_table("torch.hamming_window", 48, 64)
+    assert t.dtype == np.float32 and t.shape == (64,) and np.all(t[:8] == 0) and np.all(t[56:] == 0)
+    assert np.array_equal(t[8:56], torch.hamming_window(48).numpy())
+    assert np.array_equal(stft_window_table(torch.blackman_window, 64, 64), torch.blackman_window(64).numpy())
+    with pytest.raises(NotImplementedError):
+        stft_window_table("os.system", 64, 64)
+
+
 def test_install_registers_reference_module_names():
     names = A.install()
     try:
