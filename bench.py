@@ -64,7 +64,7 @@ def cpu_baseline(seconds: float, seed: int):
     n_chunks = len(O.chunk_plan(mix.shape[1], O.MDXParams())[5])
     # the whole 4-minute song through the same oracle has been timed once per round (tools/fullsong_*.py); quote the stored runs
     whole = []
-    for name, key in (("r02_fullsong_parity.json", None), ("r03_fullsong_parity.json", "cases")):
+    for name, key in (("r02_fullsong_parity.json", None), ("r03_fullsong_parity.json", "cases"), ("r05_fullsong_parity.json", "cases")):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 rec = json.load(fh)
