@@ -189,7 +189,7 @@ def run_roformer(args):
     cfg = R.RoformerConfig(freqs_per_bands=R.DEFAULT_FREQS_PER_BANDS)
     sd = R.make_roformer_state(cfg, 0)
     dm = A.MDXCDemixer({"model_data": cfg.as_model_data(), "torch_device": 0, "secondary_stem_name": "other"}, {"overlap": 8},
-                       state_dict=sd, max_batch=8)
+                       state_dict=sd, max_batch=16)   # chunks per net pass: 8 / 16 / 31 -> 151.4 / 154.4 / 154.6x (profiles/r05_sibling_batch_sweep.txt)
     eng = dm.engine
     n = int(SR * args.seconds)
     mixh = synth(n)
