@@ -578,6 +578,7 @@ static std::atomic<long long> g_attn6_launches{0};   // launches of attention6_k
 // of the same shape can therefore never meet a stale image, and no other engine's load / destroy touches them (round 5: the cache
 // was process-wide, so a second engine's commit freed images a captured hipGraph of the first still pointed at).
 static void w3_flush(asx_engine *e) {
+  if (!e) return;                                      // the entry points call this before they validate their arguments
   std::lock_guard<std::mutex> lk(e->w3_mu);
   for (auto &en : e->w3) (void)hipFree(en.img);
   e->w3.clear();

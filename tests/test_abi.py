@@ -95,3 +95,12 @@ def test_header_is_plain_c_and_struct_layouts_match(tmp_path):
     out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
     for name, ct in pairs:
         assert int(out[name]) == C.sizeof(ct), (name, out[name], C.sizeof(ct))
+
+
+def test_null_engine_is_an_error_not_a_crash(lib):
+    """Every model family's begin / commit validates its engine argument before touching it (the weight-image cache flush they
+    start with is per engine)."""
+    for fam in ("net", "v3", "rof", "ht", "hd", "vr"):
+        assert getattr(lib, f"asx_{fam}_begin")(None, None) != 0, fam
+        assert getattr(lib, f"asx_{fam}_commit")(None) != 0, fam
+    assert lib.asx_last_error()
