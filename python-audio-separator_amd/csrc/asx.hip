@@ -1907,6 +1907,7 @@ int asx_counter(const asx_engine *e, const char *name, int64_t *out) {
   REQUIRE(e && name && out, "asx_counter: null argument");
   const std::string nm(name);
   if (nm == "tdf3_launches") *out = (int64_t)g_tdf3_launches.load();
+  else if (nm == "tdf3h_launches") *out = (int64_t)g_tdf3h_launches.load();
   else if (nm == "attn6_launches") *out = (int64_t)g_attn6_launches.load();
   else if (nm == "tdf3_gather_launches") *out = (int64_t)g_tdf3_gather_launches.load();
   else if (nm == "wino6_launches") *out = (int64_t)g_wino6_launches.load();
@@ -2076,6 +2077,10 @@ int asx_set_option(asx_engine *e, const char *key, int32_t value) {
   }
   if (!strcmp(key, "gemm_bf16x6")) {                 // this engine only (round 5; it was process-wide before)
     e->gemm_bf16x6 = value > 0 ? 1 : 0;
+    return ASX_OK;
+  }
+  if (!strcmp(key, "gemm_f16x3")) {
+    e->gemm_f16x3 = value > 0 ? 1 : 0;
     return ASX_OK;
   }
   set_err("asx_set_option: unknown option '%s'", key);

@@ -571,6 +571,7 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
 // Per-engine switch (asx_engine::gemm_bf16x6): ASX_GEMM_BF16X6 (default 1) or asx_set_option(e, "gemm_bf16x6", n); 0 = the fp32-MFMA kernels only.
 // launches of tdf3_kernel since the process started (tests assert that the path under test is the one that ran)
 static std::atomic<long long> g_tdf3_launches{0};
+static std::atomic<long long> g_tdf3h_launches{0};   // ... of which on the fp16 x 3 arithmetic (plain and GATHER mode)
 static std::atomic<long long> g_attn6_launches{0};   // launches of attention6_kernel (kernels_rof.h)
 
 // The split image of a weight matrix is built on first use and cached PER ENGINE by (pointer, N, K, cin) (asx_engine::w3).  Every
@@ -596,16 +597,20 @@ static void w3_drop(asx_engine *e, const void *w) {
     }
 }
 
-static const u32x4 *w3_image(asx_engine *e, const float *w, int N, int K, hipStream_t s, int cin = 0) {
+static const u32x4 *w3_image(asx_engine *e, const float *w, int N, int K, hipStream_t s, int cin = 0, int kind = 0) {
   std::lock_guard<std::mutex> lk(e->w3_mu);
   for (auto &en : e->w3)
-    if (en.w == w && en.N == N && en.K == K && en.cin == cin) return reinterpret_cast<const u32x4 *>(en.img);
+    if (en.w == w && en.N == N && en.K == K && en.cin == cin && en.kind == kind) return reinterpret_cast<const u32x4 *>(en.img);
   const int nst = cin > 0 ? (K / cin) * ((cin + 31) / 32) : 0;
   const int ntiles = (N + 15) / 16, nk = cin > 0 ? ((nst + 1) & ~1) : ((K + 63) / 64) * 2;   // an even number of 32-wide stages (zero padded)
-  W3Entry en{w, N, K, cin, nullptr};
-  if (hipMalloc(&en.img, (size_t)ntiles * nk * 3 * 1024) != hipSuccess) return nullptr;
+  W3Entry en{w, N, K, cin, kind, nullptr};
+  const size_t bytes = kind == 1 ? (size_t)ntiles * nk * 2 * 1024 + (size_t)ntiles * 4 : (size_t)ntiles * nk * 3 * 1024;
+  if (hipMalloc(&en.img, bytes) != hipSuccess) return nullptr;
   const int64_t total = (int64_t)ntiles * nk * 64;
-  hipLaunchKernelGGL(w3_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<u32x4 *>(en.img), N, K,
+  if (kind == 1)
+    hipLaunchKernelGGL(w3h_split_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, w, reinterpret_cast<u32x4 *>(en.img), N, K, ntiles, cin, nst);
+  else
+    hipLaunchKernelGGL(w3_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<u32x4 *>(en.img), N, K,
                      total, cin, nst);
   // built once per weight tensor (the first forward after a load): make the image visible to every stream before it is published
   if (hipStreamSynchronize(s) != hipSuccess) {
@@ -624,9 +629,9 @@ static bool tdf3_ok(const asx_engine *e, const TdfDmaArgs &d) {
          d.N > 64 && lda % 4 == 0 && ldy % 4 == 0 && ldr % 4 == 0 && a16(d.x) && a16(d.w) && a16(d.y) && (!d.res || a16(d.res)) &&
          (!d.bias || a16(d.bias)) && (uint64_t)16 * (uint64_t)ldy * 4 < (1ull << 31) && (uint64_t)16 * (uint64_t)ldr * 4 < (1ull << 31);
 }
-template <int NREP, int MREP, int ABL>
+template <int NREP, int MREP, int ABL, bool H = false>
 static void launch_tdf3_abl(const TdfDmaArgs &a0, const u32x4 *w3, hipStream_t s) {
-  constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = 2 * 3 * BM * 64;
+  constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = H ? 2 * 2 * BM * 64 + 12 * BM : 2 * 3 * BM * 64;
   TdfDmaArgs a = a0;
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
@@ -636,19 +641,26 @@ static void launch_tdf3_abl(const TdfDmaArgs &a0, const u32x4 *w3, hipStream_t s
   // fabric traffic 2.0x -> ~1.0x algorithmic); 8 or more -> map 0 (column tiles partitioned over the XCDs; maps 1 / 2 measure the same).
   static const int map_env = getenv("ASX_TDF3_MAP") ? atoi(getenv("ASX_TDF3_MAP")) : -1;
   a.tile_map = map_env >= 0 ? (nbn >= 8 ? map_env % 10 : map_env / 10) : (nbn < 8 ? 1 : 0);
-  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3, RowGather{});
+  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL, false, H>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3, RowGather{});
   g_tdf3_launches.fetch_add(1);
+  if (H) g_tdf3h_launches.fetch_add(1);
 }
 // GATHER mode (kernels_gemm3.h): stride-1 convolutions of the channels-last nets as implicit GEMMs on the same kernel
 static std::atomic<long long> g_tdf3_gather_launches{0};
 template <int NREP, int MREP>
 static bool launch_tdf3_gather(asx_engine *e, const TdfDmaArgs &a, const RowGather &gq, hipStream_t s) {
-  const u32x4 *w3 = w3_image(e, a.w, a.N, a.K, s, (gq.cin & 31) ? gq.cin : 0);   // channel counts off the 32-grid get their own padded image
+  const bool h = e->gemm_f16x3 > 0;
+  const u32x4 *w3 = w3_image(e, a.w, a.N, a.K, s, (gq.cin & 31) ? gq.cin : 0, h ? 1 : 0);   // channel counts off the 32-grid get their own padded image
   if (!w3) return false;
-  constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = 2 * 3 * BM * 64;
+  constexpr int BM = 16 * MREP, BN = 64 * NREP;
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, 0, true>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3, gq);
+  if (h) {
+    hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, 0, true, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 2 * 2 * BM * 64 + 12 * BM, s, a, w3, gq);
+    g_tdf3h_launches.fetch_add(1);
+  } else {
+    hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, 0, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 2 * 3 * BM * 64, s, a, w3, gq);
+  }
   g_tdf3_gather_launches.fetch_add(1);
   return true;
 }
@@ -667,8 +679,15 @@ static bool launch_tdf3_gather_auto(asx_engine *e, const TdfDmaArgs &d, const Ro
 }
 template <int NREP, int MREP>
 static bool launch_tdf3(asx_engine *e, const TdfDmaArgs &a, hipStream_t s) {
-  const u32x4 *w3 = w3_image(e, a.w, a.N, a.K, s);
+  static const int abl0 = getenv("ASX_TDF3_ABL") ? atoi(getenv("ASX_TDF3_ABL")) : 0;
+  static const int only_n = getenv("ASX_F16X3_N") ? atoi(getenv("ASX_F16X3_N")) : 0;   // bring-up: fp16 x 3 on the launches with this N only (< 0: all but)
+  const bool h = e->gemm_f16x3 > 0 && abl0 == 0 && (only_n == 0 || (only_n > 0 ? a.N == only_n : a.N != -only_n));
+  const u32x4 *w3 = w3_image(e, a.w, a.N, a.K, s, 0, h ? 1 : 0);
   if (!w3) return false;                               // out of memory for the image: the caller falls back to the fp32 kernels
+  if (h) {
+    launch_tdf3_abl<NREP, MREP, 0, true>(a, w3, s);
+    return true;
+  }
   static const int abl = getenv("ASX_TDF3_ABL") ? atoi(getenv("ASX_TDF3_ABL")) : 0;   // ablation builds exist for the 128 x 192 tile only
   if constexpr (NREP == 3 && MREP == 8) {
     switch (abl) {

@@ -61,22 +61,107 @@ __device__ __forceinline__ void split3_oct(const f32x4 &a, const f32x4 &b, u32x4
   l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
 }
 
+// ---- fp16 x 3 variant (template parameter H of tdf3_kernel; asx_set_option "gemm_f16x3") ----------------------------------------
+// The same idea on the fp16 matrix pipe (same rate as bf16 on gfx950), with HALF the MFMAs: an operand scaled by a power of two into
+// fp16's range is written as v 2^e = h + l, h = RNE_f16(v 2^e), l = RNE_f16(v 2^e - h) (the subtraction is exact): 11 + 11 significand
+// bits, |v 2^e - h - l| <= 2^-23 |v 2^e| while l stays above fp16's subnormal spacing 2^-24 -- i.e. for every element within 2^-14 of
+// its block's largest (the block maximum sits in [2^12, 2^15)); smaller elements keep an ABSOLUTE error of 2^-25 in scaled units, below
+// 2^-37 of the block maximum.  A product is
+//     w x  =  wh xh + (wh xl + wl xh)   +   [wl xl <= 2^-22 |w x|, dropped]
+// -- three MFMAs (`v_mfma_f32_16x16x32_f16`) per 32-deep k step instead of six.  Operand error 2^-23 and a dropped term of 2^-22 against
+// the bf16 x 6 form's 2^-24, but three accumulator roundings per k step instead of six: against a float64 GEMM the results measured
+// CLOSER than the bf16 x 6 kernel's on every shape of tools/proto_gemm3.hip (6.3e-7 against 8.5e-7 at K = 3072), both closer than the
+// fp32-MFMA kernel (tests/test_gpu_parity.py::test_rowgemm_bf16x6_vs_float64[f16x3], ::test_rowgemm_f16x3_block_exponent).
+// Scaling.  W: one exponent per 16-column fragment tile, chosen by the image builder (largest |w| of the tile in [2^14, 2^15)), stored
+// behind the fragments.  x: one RUNNING exponent PER ROW, found on line: the four lanes that fetch a row's 32 floats of a stage reduce
+// their largest |x| (two DPP steps) right before the split; when it would pass 2^15 under the row's exponent, the exponent drops (two
+// bits of headroom) and the drop goes through a small LDS table to the MFMA side, which multiplies that row's accumulators by the exact
+// power of two before the next stage's products arrive -- rare after a row's first stages, free when nothing changed (x 1.0).  The
+// epilogue multiplies every accumulator by 2^-(e_x[row] + e_w[tile]) (exact) and continues as the bf16 x 6 kernel does.  A row never
+// sees another row's magnitude: an Inf / NaN row poisons itself only, rows 2^100 apart in one tile keep their own precision.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+#define ASX_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// two floats, scaled by 2^e, as packed fp16 pairs h + l (low half = first float)
+__device__ __forceinline__ void split2h_pair(float x0, float x1, int e, unsigned &h, unsigned &l) {
+  x0 = __builtin_ldexpf(x0, e);
+  x1 = __builtin_ldexpf(x1, e);
+  h = cvt_pk_f16(x0, x1);
+  const f16x2 hv = __builtin_bit_cast(f16x2, h);
+  l = cvt_pk_f16(__fsub_rn(x0, (float)hv[0]), __fsub_rn(x1, (float)hv[1]));
+}
+
+__device__ __forceinline__ void split2h_oct(const f32x4 &a, const f32x4 &b, int e, u32x4 &h, u32x4 &l) {
+  unsigned hh[4], ll[4];
+  split2h_pair(a.x, a.y, e, hh[0], ll[0]);
+  split2h_pair(a.z, a.w, e, hh[1], ll[1]);
+  split2h_pair(b.x, b.y, e, hh[2], ll[2]);
+  split2h_pair(b.z, b.w, e, hh[3], ll[3]);
+  h = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+  l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+}
+
+// largest finite |.| of eight floats (NaN never wins a v_max; Inf is masked by the caller's slow path)
+__device__ __forceinline__ float absmax_oct(const f32x4 &a, const f32x4 &b) {
+  return fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+               fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+}
+__device__ __forceinline__ float finite_or_zero(float v) {
+  v = fabsf(v);
+  return v <= 3.4028234663852886e38f ? v : 0.f;
+}
+__device__ __forceinline__ float absmax_oct_finite(const f32x4 &a, const f32x4 &b) {
+  return fmaxf(fmaxf(fmaxf(finite_or_zero(a.x), finite_or_zero(a.y)), fmaxf(finite_or_zero(a.z), finite_or_zero(a.w))),
+               fmaxf(fmaxf(finite_or_zero(b.x), finite_or_zero(b.y)), fmaxf(finite_or_zero(b.z), finite_or_zero(b.w))));
+}
+
+// maximum over the 64 lanes of a wave, returned in every lane (DPP: four row shifts, two row broadcasts, one readlane)
+__device__ __forceinline__ float wave_max64(float v) {
+  int b = __float_as_int(v);
+#define ASX_WMAX_STEP(ctrl, rm)                                                          \
+  {                                                                                      \
+    const int t = __builtin_amdgcn_update_dpp(b, b, (ctrl), (rm), 0xf, false);           \
+    b = __float_as_int(fmaxf(__int_as_float(b), __int_as_float(t)));                     \
+  }
+  ASX_WMAX_STEP(0x111, 0xf)   // row_shr:1
+  ASX_WMAX_STEP(0x112, 0xf)   // row_shr:2
+  ASX_WMAX_STEP(0x114, 0xf)   // row_shr:4
+  ASX_WMAX_STEP(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds the row's maximum
+  ASX_WMAX_STEP(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+  ASX_WMAX_STEP(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+#undef ASX_WMAX_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(b, 63));
+}
+
+// v *= 2^e in place (tied operands; the epilogue's way back to the operands' own scale)
+__device__ __forceinline__ void ldexp4_inplace(f32x4 &v, int e) {
+  asm volatile("v_ldexp_f32 %0, %0, %4\n\tv_ldexp_f32 %1, %1, %4\n\tv_ldexp_f32 %2, %2, %4\n\tv_ldexp_f32 %3, %3, %4"
+               : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)
+               : "v"(e));
+}
+
+// exponent e with m 2^e in [2^14, 2^15) (m > 0 finite); m == 0 gives 15
+__device__ __forceinline__ int f16_scale_exp(float m) { return 15 - __builtin_amdgcn_frexp_expf(m); }
+
 // W[N, K] fp32 -> fragment-ordered bf16 x 3 image: img[((nt * nk + ks) * 3 + part) * 64 + lane] = 8 bf16 of row nt * 16 + (lane & 15),
 // k = ks * 32 + (lane >> 4) * 8 .. + 7; rows >= N and stages past K (the image holds an even number of stages) are zero.  One
 // thread per (nt, ks, lane).
 // cin > 0 (GATHER mode with a channel count that is not a multiple of 32): K = taps * cin and a stage is (tap, 32-channel chunk) --
 // the last chunk of every tap is zero padded past cin (cin % 8 == 0), `nst` = taps * ceil(cin / 32) stages exist.
-__global__ __launch_bounds__(256) void w3_split_kernel(const float *__restrict__ w, u32x4 *__restrict__ img, int N, int K, int64_t total,
-                                                       int cin = 0, int nst = 0) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int nk = cin > 0 ? ((nst + 1) & ~1) : ((K + 63) >> 6) * 2;   // stages of the image: an even number (the kernel runs stage pairs), zeros past the data
-  const int lane = (int)(idx & 63);
-  const int64_t f = idx >> 6;
-  const int ks = (int)(f % nk);
-  const int nt = (int)(f / nk);
+// the eight fp32 weights of fragment slot (nt, ks, lane) of either image (zeros past N / K / cin)
+__device__ __forceinline__ void w3_fetch(const float *__restrict__ w, int N, int K, int cin, int nst, int nt, int ks, int lane, f32x4 &a,
+                                         f32x4 &b) {
   const int n = nt * 16 + (lane & 15);
-  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  a = (f32x4){0.f, 0.f, 0.f, 0.f};
+  b = a;
   if (cin > 0) {
     const int nch = (cin + 31) >> 5;
     const int tap = ks / nch, ch = ks - tap * nch;
@@ -91,12 +176,55 @@ __global__ __launch_bounds__(256) void w3_split_kernel(const float *__restrict__
     a = *reinterpret_cast<const f32x4 *>(p);
     b = *reinterpret_cast<const f32x4 *>(p + 4);
   }
+}
+
+__global__ __launch_bounds__(256) void w3_split_kernel(const float *__restrict__ w, u32x4 *__restrict__ img, int N, int K, int64_t total,
+                                                       int cin = 0, int nst = 0) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int nk = cin > 0 ? ((nst + 1) & ~1) : ((K + 63) >> 6) * 2;   // stages of the image: an even number (the kernel runs stage pairs), zeros past the data
+  const int lane = (int)(idx & 63);
+  const int64_t f = idx >> 6;
+  const int ks = (int)(f % nk);
+  const int nt = (int)(f / nk);
+  f32x4 a, b;
+  w3_fetch(w, N, K, cin, nst, nt, ks, lane, a, b);
   u32x4 h, m, l;
   split3_oct(a, b, h, m, l);
   u32x4 *o = img + (f * 3) * 64 + lane;
   o[0] = h;
   o[64] = m;
   o[128] = l;
+}
+
+// fp16 x 3 image: img[((nt * nk + ks) * 2 + part) * 64 + lane], same fragment order, every 16-row tile scaled by 2^e[nt] with its
+// largest |w| in [2^14, 2^15); the int32 exponents e[ntiles] follow the fragments (at img + ntiles * nk * 128).  One workgroup per tile.
+__global__ __launch_bounds__(256) void w3h_split_kernel(const float *__restrict__ w, u32x4 *__restrict__ img, int N, int K, int ntiles,
+                                                        int cin = 0, int nst = 0) {
+  const int nk = cin > 0 ? ((nst + 1) & ~1) : ((K + 63) >> 6) * 2;
+  const int nt = blockIdx.x, tid = threadIdx.x;
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int it = tid; it < nk * 64; it += 256) {
+    f32x4 a, b;
+    w3_fetch(w, N, K, cin, nst, nt, it >> 6, it & 63, a, b);
+    m = fmaxf(m, absmax_oct_finite(a, b));
+  }
+  m = wave_max64(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const int e = m > 0.f ? f16_scale_exp(m) : 0;
+  for (int it = tid; it < nk * 64; it += 256) {
+    f32x4 a, b;
+    w3_fetch(w, N, K, cin, nst, nt, it >> 6, it & 63, a, b);
+    u32x4 h, l;
+    split2h_oct(a, b, e, h, l);
+    u32x4 *o = img + ((int64_t)(nt * nk + (it >> 6)) * 2) * 64 + (it & 63);
+    o[0] = h;
+    o[64] = l;
+  }
+  if (tid == 0) reinterpret_cast<int *>(img + (int64_t)ntiles * nk * 128)[nt] = e;
 }
 
 template <int V>
@@ -119,13 +247,17 @@ struct RowGather {
   int64_t x_bs;                                       // floats per image of x
 };
 
-template <int NREP, int MREP, int ABL = 0, bool GATHER = false>
+// H: the fp16 x 3 arithmetic (above) instead of bf16 x 6 -- two parts per operand, three MFMAs per product, x registers double
+// buffered (a stage's rows are fetched a whole stage before their maximum is needed), 32 more bytes of LDS for the per-wave maxima.
+template <int NREP, int MREP, int ABL = 0, bool GATHER = false, bool H = false>
 __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 *__restrict__ w3, RowGather gq) {
   constexpr int BM = 16 * MREP, BN = 64 * NREP;
   constexpr int XC = MREP / 4;                        // 8-float chunks per thread and stage (BM * 4 chunks / 256 threads)
+  constexpr int NP = H ? 2 : 3;                       // parts per operand
   constexpr int PART = BM * 64;                       // bytes of one part image
-  constexpr int BUFB = 3 * PART;                      // bytes of one stage buffer
+  constexpr int BUFB = NP * PART;                     // bytes of one stage buffer
   static_assert(MREP % 4 == 0, "tile shape");
+  static_assert(!H || ABL == 0, "the ablation builds exist for the bf16 x 6 arithmetic only");
   extern __shared__ float lds_f[];
   char *lds = reinterpret_cast<char *>(lds_f);
 
@@ -181,15 +313,15 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
   for (int n = 0; n < NREP; ++n) {
     int nt = (n0 >> 4) + wave * NREP + n;
     nt = nt < ntiles ? nt : ntiles - 1;
-    wb[n] = w3 + (int64_t)nt * nk * 192 + lane;
+    wb[n] = w3 + (int64_t)nt * nk * (64 * NP) + lane;
   }
-  u32x4 wr[2][NREP][3];
+  u32x4 wr[2][NREP][NP];
   auto load_w = [&](auto par, int ks) {
     constexpr int P = decltype(par)::value;
 #pragma unroll
     for (int n = 0; n < NREP; ++n)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wr[P][n][p] = wb[n][(int64_t)ks * 192 + p * 64];
+      for (int p = 0; p < NP; ++p) wr[P][n][p] = wb[n][(int64_t)ks * (64 * NP) + p * 64];
   };
 
   // chunk swizzle of the x part images: chunk ^ h((row >> 2) & 3), h = {0, 2, 3, 1}.  `ds_read_b128` is serviced in four
@@ -225,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
     xw[i] = row * 64 + ((c ^ hsw((row >> 2) & 3)) << 4);
   }
   f32x4 xr[XC][2];
-  auto load_x = [&](int ks) {
+  auto load_x_sel = [&](int ks, int only) {            // only < 0: every chunk of the stage; else chunk `only` (H mode: a chunk's registers are refilled right after its split)
     const int kcs = ks < nkx ? ks : nkx - 1;           // wave-uniform clamp (see nk above)
     if constexpr (GATHER) {
       const int tap = kcs / gq.nch, ch = kcs - tap * gq.nch;
@@ -234,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
       const int off = (dy * gq.I + dx) * gq.ldc + ch * 32;   // launcher: |off| < 2^31
 #pragma unroll
       for (int i = 0; i < XC; ++i) {
+        if (only >= 0 && i != only) continue;
         const bool ok = (unsigned)(po[i] + dy) < (unsigned)gq.O && (unsigned)(pi[i] + dx) < (unsigned)gq.I &&
                         ch * 32 + (tid & 3) * 8 < gq.cin;   // this thread's 8-channel group exists (partial last chunk)
         const float *src = ok ? xp[i] + off : a.zeros;
@@ -244,18 +377,70 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
       const int kc = kcs * 32;
 #pragma unroll
       for (int i = 0; i < XC; ++i) {
+        if (only >= 0 && i != only) continue;
         xr[i][0] = *reinterpret_cast<const f32x4 *>(xp[i] + kc);
         xr[i][1] = *reinterpret_cast<const f32x4 *>(xp[i] + kc + 4);
       }
     }
   };
+  auto load_x = [&](int ks) { load_x_sel(ks, -1); };
   auto split_chunk = [&](int buf, int i) {             // chunk i of the stage held in xr -> the three part images of `buf`
     char *dst = lds + buf * BUFB;
     u32x4 h, m, l;
     split3_oct(xr[i][0], xr[i][1], h, m, l);
     *reinterpret_cast<u32x4 *>(dst + xw[i]) = h;
     *reinterpret_cast<u32x4 *>(dst + PART + xw[i]) = m;
-    *reinterpret_cast<u32x4 *>(dst + 2 * PART + xw[i]) = l;
+    *reinterpret_cast<u32x4 *>(dst + (NP - 1) * PART + xw[i]) = l;
+  };
+  // ---- H: scaled two-way split with ONE RUNNING EXPONENT PER ROW ------------------------------------------------------------------
+  // The four lanes that fetch a row's 32 floats of a stage find their largest |x| (two quad-permute DPP steps); when it would pass
+  // 2^15 under the row's exponent, the exponent drops (two bits of headroom) and the drop `de` goes into a table the MFMA side reads
+  // after the next barrier -- the accumulators of that row are rescaled by 2^de (exact) before the stage's products are added.  A
+  // second table keeps every row's current exponent for the epilogue.  Non-finite elements poison their own row only.
+  int *de_tab = reinterpret_cast<int *>(lds + 2 * BUFB);              // [stage parity][BM]: row r at (r & 15) * MREP + (r >> 4)
+  int *ex_tab = de_tab + 2 * BM;                                      // [BM]: the exponent each row's parts in LDS / accumulators carry
+  int e_row[XC];
+  int xslot[XC];
+#pragma unroll
+  for (int i = 0; i < XC; ++i) {
+    const int row = (tid + 256 * i) >> 2;
+    e_row[i] = 200;                                    // any first stage lowers it (accumulators are zero then)
+    xslot[i] = (row & 15) * MREP + (row >> 4);
+  }
+  auto split_chunk_h = [&](int buf, int i) {
+    float m = absmax_oct(xr[i][0], xr[i][1]);
+    {
+      int b = __float_as_int(m);
+      int t = __builtin_amdgcn_update_dpp(b, b, 0xB1, 0xf, 0xf, false);   // quad_perm [1, 0, 3, 2]
+      b = __float_as_int(fmaxf(__int_as_float(b), __int_as_float(t)));
+      t = __builtin_amdgcn_update_dpp(b, b, 0x4E, 0xf, 0xf, false);       // quad_perm [2, 3, 0, 1]
+      m = fmaxf(__int_as_float(b), __int_as_float(t));
+    }
+    const int need = f16_scale_exp(m);
+    const int e_old = e_row[i];
+    const int e_new = need < e_old ? need - 2 : e_old;
+    e_row[i] = e_new;
+    if ((tid & 3) == 0) {
+      de_tab[buf * BM + xslot[i]] = e_new - e_old;
+      ex_tab[xslot[i]] = e_new;
+    }
+    char *dst = lds + buf * BUFB;
+    u32x4 h, l;
+    split2h_oct(xr[i][0], xr[i][1], e_new, h, l);
+    *reinterpret_cast<u32x4 *>(dst + xw[i]) = h;
+    *reinterpret_cast<u32x4 *>(dst + PART + xw[i]) = l;
+  };
+  // MFMA side: this lane's rows are 16 m + li
+  auto read_tab = [&](const int *tab, int (&out)[MREP]) {
+    const u32x4 *q = reinterpret_cast<const u32x4 *>(tab + li * MREP);
+#pragma unroll
+    for (int j = 0; j < MREP / 4; ++j) {
+      const u32x4 v = q[j];
+      out[4 * j + 0] = (int)v.x;
+      out[4 * j + 1] = (int)v.y;
+      out[4 * j + 2] = (int)v.z;
+      out[4 * j + 3] = (int)v.w;
+    }
   };
   const int xf_off = li * 64 + ((lk ^ hsw((li >> 2) & 3)) << 4);   // fragment read: row 16 t + li, chunk lk
 
@@ -266,11 +451,19 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
     for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: stage 0 in LDS / registers, x of stage 1 in flight (same issue order as a steady stage: W, split, x)
-  load_x(0);
-  load_w(IntC<0>{}, 0);
+  if constexpr (H) {
+    load_x(0);
+    load_w(IntC<0>{}, 0);
 #pragma unroll
-  for (int i = 0; i < XC; ++i) split_chunk(0, i);
-  if (nk > 1) load_x(1);
+    for (int i = 0; i < XC; ++i) split_chunk_h(0, i);
+    load_x(1);                                         // nk >= 2
+  } else {
+    load_x(0);
+    load_w(IntC<0>{}, 0);
+#pragma unroll
+    for (int i = 0; i < XC; ++i) split_chunk(0, i);
+    if (nk > 1) load_x(1);
+  }
 
   // One stage.  MODE 0 (steady): fetch W of stage ks + 1, split x of stage ks + 1 (in registers since the previous stage) into the
   // other buffer, fetch x of stage ks + 2.  MODE 1 (second last): no x fetch.  MODE 2 (last): nothing but the MFMAs.  The modes
@@ -338,15 +531,98 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
       }
     }
   };
+  // The same stage on the fp16 x 3 arithmetic.  After the barrier the exponent drops of the rows split during the previous stage
+  // are applied to the accumulators (rare after the first stages); the split of stage ks + 1 is spread among the MFMAs as above (one
+  // MFMA, four VALU), and every chunk's registers are refilled with stage ks + 2 right after its split -- a whole stage ahead.
+  auto stage_h = [&](auto par, auto mode, int ks) {
+    constexpr int P = decltype(par)::value;
+    constexpr int MODE = decltype(mode)::value;
+    __syncthreads();
+    if constexpr (MODE < 2) load_w(IntC<P ^ 1>{}, ks + 1);
+    int de[MREP];
+    read_tab(de_tab + P * BM, de);
+    // The rescale is a branch-free multiply by 2^de (1.0 almost always; 0 for de < -149: what the accumulators held is then below
+    // 2^-100 of what follows) in front of each row group's MFMAs.  As a rare branch (`if any lane has de != 0`) the compiler kept a
+    // second register set for the rescaled accumulators -- 256 VGPRs and 27 spilled against 220 and none -- and every launch measured
+    // 35-60 % slower (tools/runs/r5_run15.sh).
+    float fr[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) fr[m] = __builtin_ldexpf(1.0f, de[m]);
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) acc[n][0] *= fr[0];
+    const char *xs = lds + P * BUFB + xf_off;
+    f16x8 xf[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) xf[0][p] = *reinterpret_cast<const f16x8 *>(xs + p * PART);
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+      if (m + 1 < MREP) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) xf[(m + 1) & 1][p] = *reinterpret_cast<const f16x8 *>(xs + p * PART + (m + 1) * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const bool has_split = MODE < 2 && (m >= 1) && ((m - 1) % 3 == 0) && ((m - 1) / 3 < XC);
+      if (has_split) split_chunk_h(P ^ 1, (m - 1) / 3);
+      const f16x8 xh = xf[m & 1][0], xl = xf[m & 1][1];
+      // smallest terms first; the NREP column tiles of one product are independent accumulators
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) acc[n][m] = ASX_MFMA_F16(__builtin_bit_cast(f16x8, wr[P][n][1]), xh, acc[n][m]);
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) acc[n][m] = ASX_MFMA_F16(__builtin_bit_cast(f16x8, wr[P][n][0]), xl, acc[n][m]);
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) acc[n][m] = ASX_MFMA_F16(__builtin_bit_cast(f16x8, wr[P][n][0]), xh, acc[n][m]);
+      if (m + 1 < MREP) {                              // the next row group's accumulators, behind this group's MFMAs
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) acc[n][m + 1] *= fr[m + 1];
+      }
+#ifndef ASX_G3_NOSGB
+      if (has_split) {
+#pragma unroll
+        for (int g = 0; g < 3 * NREP; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);     // the chunk's ds_writes (two parts, two table entries)
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MODE == 0) {
+        if (has_split) load_x_sel(ks + 2, (m - 1) / 3);
+      }
+    }
+  };
   {
     // nk is even and >= 2 (see above) -- one tail sequence instead of three
     int ks = 0;
-    for (; ks + 2 < nk; ks += 2) {
-      stage(IntC<0>{}, IntC<0>{}, ks);
-      stage(IntC<1>{}, IntC<0>{}, ks + 1);
+    if constexpr (H) {
+      for (; ks + 2 < nk; ks += 2) {
+        stage_h(IntC<0>{}, IntC<0>{}, ks);
+        stage_h(IntC<1>{}, IntC<0>{}, ks + 1);
+      }
+      stage_h(IntC<0>{}, IntC<1>{}, ks);
+      stage_h(IntC<1>{}, IntC<2>{}, ks + 1);
+      // back to the operands' own scale: 2^-(e_x[row] + e_w[column tile]), exact
+      const int *wexp = reinterpret_cast<const int *>(w3 + (int64_t)ntiles * nk * 128);
+      int ex[MREP];
+      read_tab(ex_tab, ex);                            // written before the last barrier (the last split is in stage nk - 2)
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) {
+        int nt = (n0 >> 4) + wave * NREP + n;
+        nt = nt < ntiles ? nt : ntiles - 1;
+        const int ew = __builtin_amdgcn_readfirstlane(wexp[nt]);
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          ldexp4_inplace(acc[n][m], -(ex[m] + ew));
+        }
+      }
+    } else {
+      for (; ks + 2 < nk; ks += 2) {
+        stage(IntC<0>{}, IntC<0>{}, ks);
+        stage(IntC<1>{}, IntC<0>{}, ks + 1);
+      }
+      stage(IntC<0>{}, IntC<1>{}, ks);
+      stage(IntC<1>{}, IntC<2>{}, ks + 1);
     }
-    stage(IntC<0>{}, IntC<1>{}, ks);
-    stage(IntC<1>{}, IntC<2>{}, ks + 1);
   }
 
   // ---- epilogue (the arithmetic of tdf2_kernel's three paths) ----------------------------------------------------------------

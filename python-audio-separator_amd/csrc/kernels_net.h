@@ -823,11 +823,25 @@ __device__ __forceinline__ f32x4 tdf_rot4(const TdfDmaArgs &a, f32x4 o, int64_t 
   const int i = (col % (2 * a.rot_half)) >> 1;
   const float2 *t = a.rot_tab + (int64_t)pos * a.rot_half + i;
   const float2 c0 = t[0], c1 = t[1];
+  // Every product and sum is its own VALU instruction, kept apart by empty asm statements.  Left alone, hipcc packs the eight operations
+  // into v_pk_mul_f32 / v_pk_fma_f32 pairs that read the just-loaded table registers; in tdf3_kernel's fp16 x 3 build that sequence
+  // returned a wrong FIRST component in lanes 48-63 of a wave about once per 4e4 stores -- different elements on every run (whole
+  // output compared bit for bit, tools/proto_gemm3.hip "rof qkv rotary"; with the table replaced by constants, or with the
+  // operations kept scalar as here, two runs agree in all 76 M elements).  The same kernel source in other builds had shown the
+  // symptom once before (round 5: BS-Roformer chunk test 3e-5 .. 7e-5 off on two boxes with one build, unexplained then).
+  float p0 = __fmul_rn(o.y, c0.y), p1 = __fmul_rn(o.x, c0.y), p2 = __fmul_rn(o.w, c1.y), p3 = __fmul_rn(o.z, c1.y);
+  asm volatile("" : "+v"(p0));
+  asm volatile("" : "+v"(p1));
+  asm volatile("" : "+v"(p2));
+  asm volatile("" : "+v"(p3));
   f32x4 r;
-  r.x = __fmaf_rn(o.x, c0.x, -__fmul_rn(o.y, c0.y));
-  r.y = __fmaf_rn(o.y, c0.x, __fmul_rn(o.x, c0.y));
-  r.z = __fmaf_rn(o.z, c1.x, -__fmul_rn(o.w, c1.y));
-  r.w = __fmaf_rn(o.w, c1.x, __fmul_rn(o.z, c1.y));
+  r.x = __fmaf_rn(o.x, c0.x, -p0);
+  asm volatile("" : "+v"(r.x));
+  r.y = __fmaf_rn(o.y, c0.x, p1);
+  asm volatile("" : "+v"(r.y));
+  r.z = __fmaf_rn(o.z, c1.x, -p2);
+  asm volatile("" : "+v"(r.z));
+  r.w = __fmaf_rn(o.w, c1.x, p3);
   return r;
 }
 

@@ -194,7 +194,11 @@ def _parse_value_info_shape(b):
 
 def parse_onnx(path_or_bytes):
     """-> (nodes in graph order, {initializer name: ndarray}, {graph input name: dims})."""
-    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    if isinstance(path_or_bytes, (bytes, bytearray)):
+        data = path_or_bytes
+    else:
+        with open(path_or_bytes, "rb") as fh:
+            data = fh.read()
     data = memoryview(bytes(data))
     graph = None
     for fno, wt, v in _fields(data):

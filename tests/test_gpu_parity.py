@@ -205,9 +205,24 @@ def test_tdf_layers(A, B, c, T, K, N, bias, res):
     assert max_abs(y, ref) < 3e-5, (max_abs(y, ref), rel_rms(y, ref))
 
 
-# bf16x6 row GEMM (csrc/kernels_gemm3.h): the same layer through the split-operand kernel and through the fp32-MFMA kernel, both
+# Split-operand row GEMM (csrc/kernels_gemm3.h), both arithmetics -- bf16 x 6 (exact three-way split) and fp16 x 3 (block-scaled
+# two-way split, the default since round 5): the same layer through the split-operand kernel and through the fp32-MFMA kernel, both
 # against a float64 GEMM.  The bar is "at least as close as the fp32 kernel" (a reduced-precision shortcut would fail it by 100x),
-# plus proof that the kernel under test is the one that ran (library launch counter).
+# plus proof that the kernel under test is the one that ran (library launch counters).
+ARITH = ["bf16x6", "f16x3"]
+
+
+def _set_arith(eng, arith):
+    eng.set_option("gemm_bf16x6", 1)
+    eng.set_option("gemm_f16x3", 1 if arith == "f16x3" else 0)
+
+
+def _ran(eng, arith, n0, h0, launches=1):
+    """the split-operand kernel of `arith` ran `launches` times since the counters read (n0, h0)"""
+    n, h = eng.counter("tdf3_launches") - n0, eng.counter("tdf3h_launches") - h0
+    return n == launches and h == (launches if arith == "f16x3" else 0)
+
+
 ROWGEMM_CASES = [
     # B, c, T, K, N, res, x scale
     (2, 48, 64, 3072, 384, False, 3.0), (2, 48, 64, 384, 3072, True, 1.0), (1, 96, 37, 1536, 192, False, 1e4),
@@ -216,8 +231,9 @@ ROWGEMM_CASES = [
 ]
 
 
+@pytest.mark.parametrize("arith", ARITH)
 @pytest.mark.parametrize("B,c,T,K,N,res,xs", ROWGEMM_CASES)
-def test_rowgemm_bf16x6_vs_float64(A, B, c, T, K, N, res, xs):
+def test_rowgemm_bf16x6_vs_float64(A, B, c, T, K, N, res, xs, arith):
     eng = A.Engine(small_cfg(A))
     rng = np.random.default_rng(K * 11 + N)
     x = (xs * rng.standard_normal((B, c, T, K)) * np.exp2(rng.integers(-6, 7, (B, c, T, 1)))).astype(np.float32)
@@ -230,15 +246,15 @@ def test_rowgemm_bf16x6_vs_float64(A, B, c, T, K, N, res, xs):
     if res:
         ref = ref + r
     try:
-        eng.set_option("gemm_bf16x6", 1)
-        n0 = eng.counter("tdf3_launches")
+        _set_arith(eng, arith)
+        n0, h0 = eng.counter("tdf3_launches"), eng.counter("tdf3h_launches")
         y6 = eng.op_tdf(x, w, None, sc, sh, r)
-        assert eng.counter("tdf3_launches") == n0 + 1, "the bf16x6 kernel did not run"
+        assert _ran(eng, arith, n0, h0), f"the {arith} kernel did not run"
         y6b = eng.op_tdf(x, w, None, sc, sh, r)
         eng.set_option("gemm_bf16x6", 0)
         n1 = eng.counter("tdf3_launches")
         y32 = eng.op_tdf(x, w, None, sc, sh, r)
-        assert eng.counter("tdf3_launches") == n1, "the fp32 run went through the bf16x6 kernel"
+        assert eng.counter("tdf3_launches") == n1, "the fp32 run went through the split-operand kernel"
     finally:
         eng.set_option("gemm_bf16x6", 1)
     assert np.isfinite(y6).all(), "unwritten (NaN canary) output elements"
@@ -246,6 +262,59 @@ def test_rowgemm_bf16x6_vs_float64(A, B, c, T, K, N, res, xs):
     e6, e32 = rel_rms(y6, ref), rel_rms(y32, ref)
     assert e6 < 2e-6 and e6 <= 1.25 * e32 + 1e-8, (e6, e32)
     assert np.abs(y6 - ref).max() <= 1.5 * np.abs(y32 - ref).max() + 1e-6 * np.abs(ref).max(), (np.abs(y6 - ref).max(), np.abs(y32 - ref).max())
+
+
+# fp16 x 3 keeps one running exponent per ROW of x and one per 16-column tile of W.  What a block exponent has to survive: rows of
+# one workgroup tile 2^18 apart, a 2^-20 decay along k (a spectrum: loud low bins, quiet high bins), output columns that look at the quiet
+# half of k only, a weight tile 1e-6 of its neighbours, a maximum that keeps growing along k (accumulators rescaled stage after
+# stage), all-zero stages and all-zero rows.  Bars: whole result as close to float64 as the fp32 kernel; EVERY row and EVERY column group
+# within 4e-6 of its own scale (with ONE exponent per 128-row tile -- the first form of the kernel -- the "decay" case missed this by
+# 1e-2 on its quiet rows: that is what the per-row exponents are for).
+@pytest.mark.parametrize("shape", ["decay", "growing", "zeros"])
+def test_rowgemm_f16x3_block_exponent(A, shape):
+    eng = A.Engine(small_cfg(A))
+    B, c, T, K, N = 1, 2, 192, 1024, 272
+    rng = np.random.default_rng(91)
+    x = rng.standard_normal((B, c, T, K))
+    k = np.arange(K)
+    if shape == "decay":
+        x *= np.exp2(-20.0 * k / K)[None, None, None, :] * np.exp2(3.0 * (np.arange(T) % 7) - 9)[None, None, :, None]
+    elif shape == "growing":
+        x *= np.exp2(24.0 * k / K)[None, None, None, :]
+    else:
+        x[..., : K // 2] = 0.0                         # the first stages are all zero, then ordinary data
+        x[:, :, 100:, :] = 0.0                         # and a tile whose rows are zero throughout
+    x = x.astype(np.float32)
+    w = rng.standard_normal((N, K)) / np.sqrt(K)
+    w[:16, : K // 2] = 0.0                             # these columns see the second half of k only
+    w[16:32] *= 1e-6                                   # a quiet weight tile
+    w = w.astype(np.float32)
+    sc, sh = np.ones(c, np.float32), np.zeros(c, np.float32)
+    lin = x.astype(np.float64) @ w.astype(np.float64).T
+    ref = np.maximum(lin, 0)
+    try:
+        _set_arith(eng, "f16x3")
+        n0, h0 = eng.counter("tdf3_launches"), eng.counter("tdf3h_launches")
+        y = eng.op_tdf(x, w, None, sc, sh, None)
+        assert _ran(eng, "f16x3", n0, h0)
+        eng.set_option("gemm_bf16x6", 0)
+        y32 = eng.op_tdf(x, w, None, sc, sh, None)
+    finally:
+        eng.set_option("gemm_bf16x6", 1)
+    assert np.isfinite(y).all()
+    e, e32 = rel_rms(y, ref), rel_rms(y32, ref)
+    assert e < 2e-6 and e <= 1.25 * e32 + 1e-8, (e, e32)
+    worst = 0.0
+    for cols in (slice(0, 16), slice(16, 32), slice(32, N)):
+        yy, rr, ll = y[..., cols].reshape(-1, y[..., cols].shape[-1]), ref[..., cols].reshape(-1, ref[..., cols].shape[-1]), \
+            lin[..., cols].reshape(-1, ref[..., cols].shape[-1])
+        scale = np.sqrt((ll ** 2).mean(axis=1))        # the row's own scale in this column group (pre-ReLU)
+        err = np.sqrt(((yy - rr) ** 2).mean(axis=1))
+        ok = scale > 0
+        worst = max(worst, float((err[ok] / scale[ok]).max()) if ok.any() else 0.0)
+        assert (err[~ok] == 0).all(), "an all-zero row did not come out zero"
+    print(f"fp16 x 3 row GEMM, {shape}: rel-RMS {e:.3e} (fp32-MFMA {e32:.3e}), worst row x column-group error over its own scale {worst:.3e}")
+    assert worst < 4e-6, worst
 
 
 # ---- edge values of the exact three-way split ------------------------------------------------------------
@@ -260,8 +329,9 @@ def test_rowgemm_bf16x6_vs_float64(A, B, c, T, K, N, res, xs):
 #    change is noticed: h = Inf gives v - h = NaN, so an Inf / NaN in x makes every accumulator of its ROW NaN in the bf16 x 6
 #    kernel where the fp32-MFMA kernel holds +-Inf (NaN when signs cancel); the TDF epilogue's ReLU is a maxNum (v_max_f32), which
 #    returns 0 for NaN -- so the affected row comes out 0 here and {Inf, 0} there.  No other row may change by a single bit.
+@pytest.mark.parametrize("arith", ARITH)
 @pytest.mark.parametrize("xs,bar", [(1e-30, None), (1e-35, 1e-4), (1e35, None)])
-def test_rowgemm_bf16x6_extreme_magnitudes(A, xs, bar):
+def test_rowgemm_bf16x6_extreme_magnitudes(A, xs, bar, arith):
     eng = A.Engine(small_cfg(A))
     B, c, T, K, N = 1, 3, 50, 256, 200
     rng = np.random.default_rng(77)
@@ -270,10 +340,10 @@ def test_rowgemm_bf16x6_extreme_magnitudes(A, xs, bar):
     sc, sh = np.ones(c, np.float32), np.zeros(c, np.float32)
     ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T, 0)
     try:
-        eng.set_option("gemm_bf16x6", 1)
-        n0 = eng.counter("tdf3_launches")
+        _set_arith(eng, arith)
+        n0, h0 = eng.counter("tdf3_launches"), eng.counter("tdf3h_launches")
         y6 = eng.op_tdf(x, w, None, sc, sh, None)
-        assert eng.counter("tdf3_launches") == n0 + 1
+        assert _ran(eng, arith, n0, h0)
         eng.set_option("gemm_bf16x6", 0)
         y32 = eng.op_tdf(x, w, None, sc, sh, None)
     finally:
@@ -281,14 +351,17 @@ def test_rowgemm_bf16x6_extreme_magnitudes(A, xs, bar):
     assert np.isfinite(y6).all() and np.isfinite(y32).all()
     # compare in float64 at unit scale (rel_rms clamps its denominator at 1e-30)
     e6, e32 = rel_rms(y6.astype(np.float64) / xs, ref / xs), rel_rms(y32.astype(np.float64) / xs, ref / xs)
-    print(f"bf16x6 row GEMM at |x| ~ {xs:g}: rel-RMS vs float64 {e6:.3e} (fp32-MFMA kernel {e32:.3e})")
+    print(f"{arith} row GEMM at |x| ~ {xs:g}: rel-RMS vs float64 {e6:.3e} (fp32-MFMA kernel {e32:.3e})")
     if bar is None:
         assert e6 < 2e-6 and e6 <= 1.25 * e32 + 1e-8, (e6, e32)
     else:
         assert e6 < bar, (e6, e32)
 
 
-def test_rowgemm_bf16x6_nonfinite_rows(A):
+@pytest.mark.parametrize("arith", ARITH)
+def test_rowgemm_bf16x6_nonfinite_rows(A, arith):
+    """fp16 x 3: the exponents are per row, so no other row can change by a bit either; the poisoned rows are NaN accumulators (Inf 2^e is
+    Inf, its low part Inf - Inf) as in bf16 x 6."""
     eng = A.Engine(small_cfg(A))
     B, c, T, K, N = 1, 2, 40, 128, 136
     rng = np.random.default_rng(78)
@@ -302,7 +375,7 @@ def test_rowgemm_bf16x6_nonfinite_rows(A):
     w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     sc, sh = np.ones(c, np.float32), np.zeros(c, np.float32)
     try:
-        eng.set_option("gemm_bf16x6", 1)
+        _set_arith(eng, arith)
         y6, y6c = eng.op_tdf(x, w, None, sc, sh, None), eng.op_tdf(clean, w, None, sc, sh, None)
         eng.set_option("gemm_bf16x6", 0)
         y32, y32c = eng.op_tdf(x, w, None, sc, sh, None), eng.op_tdf(clean, w, None, sc, sh, None)
@@ -311,9 +384,10 @@ def test_rowgemm_bf16x6_nonfinite_rows(A):
     bad = np.zeros((B, c, T), bool)
     for idx in ((0, 0, 3), (0, 0, 9), (0, 1, 5), (0, 1, 30)):
         bad[idx] = True
-    assert np.array_equal(y6[~bad], y6c[~bad]) and np.array_equal(y32[~bad], y32c[~bad]), "a non-finite input leaked into another row"
+    assert np.array_equal(y6[~bad], y6c[~bad]), "a non-finite input leaked into another row"
+    assert np.array_equal(y32[~bad], y32c[~bad]), "a non-finite input leaked into another row"
     assert np.isfinite(y6[~bad]).all()
-    assert (y6[bad] == 0).all(), "bf16 x 6: NaN accumulators through the ReLU maxNum"
+    assert (y6[bad] == 0).all(), "split operands: NaN accumulators through the ReLU maxNum"
     assert not np.isnan(y32[bad]).any() and np.isinf(y32[0, 0, 3]).any() and ((y32[bad] == 0) | np.isinf(y32[bad])).all()
 
 

@@ -1,6 +1,8 @@
 // Stand-alone harness of the bf16x6 row GEMM (csrc/kernels_gemm3.h) against the fp32-MFMA kernel it replaces (kernels_gemm2.h)
 // and a float64 host GEMM on sampled rows: error of both kernels, time per launch on the TDF / Roformer / Demucs shapes.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/proto_gemm3 tools/proto_gemm3.hip && tools/proto_gemm3 [abl] [first] [last] [tile_map]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/proto_gemm3 tools/proto_gemm3.hip && tools/proto_gemm3 [abl] [first] [last] [tile_map] [h]
+// h = 1: the fp16 x 3 arithmetic (tdf3_kernel<..., H = true>) in the tdf3 column; the "spread" shapes give x a 2^-20 decay along k (and
+// weights that look at the quiet half only in the first 16 columns): the case a block exponent has to survive.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -44,11 +46,25 @@ static void launch2(const TdfDmaArgs &a, hipStream_t s) {
   hipLaunchKernelGGL((tdf2_kernel<NREP, MREP, 0, 32>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS, s, a, 1, -1);
 }
 
+template <int NREP, int MREP>
+static void launch3h(const TdfDmaArgs &a, const u32x4 *w3, hipStream_t s) {
+  constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS = 2 * 2 * BM * 64 + 12 * BM;
+  const int64_t nbm = (a.M + BM - 1) / BM;
+  const int nbn = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, 0, false, true>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS, s, a, w3, RowGather{});
+}
+
 static int g_map = 0;   // TdfDmaArgs::tile_map of the tdf3 launches (argv[4])
+static int g_h = 0;     // 1: fp16 x 3 (argv[5])
+static int g_tile = 0;  // tile of the fp16 x 3 launches: 0 = 128 x 192, 1 = 128 x 128, 2 = 64 x 128 (argv[7])
+static void launch3h_sel(const TdfDmaArgs &a, const u32x4 *w3, hipStream_t s);
+static int g_full = 0;  // 1: compare the WHOLE output of two tdf3 runs bit for bit and against tdf2 (argv[6]) -- the sampled rows miss a rare race
 struct Shape {
   const char *name;
   int64_t M;
   int N, K, C, T, relu, res, bias;
+  int spread = 0;
+  int rot = 0;            // 1: rotary epilogue on the first 2 N / 3 columns + a per-row factor (the BS-Roformer qkv projection); full compare only
 };
 
 static double run_shape(const Shape &sh, int abl, int reps) {
@@ -61,6 +77,16 @@ static double run_shape(const Shape &sh, int abl, int reps) {
   std::vector<float> hx((size_t)HB * K), hw((size_t)N * K), hb(N), hsc(sh.C), hsh(sh.C), hr((size_t)HB * N);
   for (auto &v : hx) v = nd(rng) * 3.0f;
   for (auto &v : hw) v = nd(rng) / std::sqrt((float)K);
+  if (sh.spread) {
+    for (int64_t r = 0; r < HB; ++r) {
+      const float rowmag = std::ldexp(1.0f, (int)(r % 7) * 3 - 9);           // rows of one 128-row tile differ by up to 2^18
+      for (int k = 0; k < K; ++k) hx[(size_t)r * K + k] *= rowmag * std::ldexp(1.0f, -(int)(20.0 * k / K));
+    }
+    for (int n = 0; n < std::min(N, 16); ++n)
+      for (int k = 0; k < K / 2; ++k) hw[(size_t)n * K + k] = 0.f;          // these columns see the quiet half of k only
+    for (int n = 16; n < std::min(N, 32); ++n)
+      for (int k = 0; k < K; ++k) hw[(size_t)n * K + k] *= 1e-6f;           // a quiet weight tile
+  }
   for (auto &v : hb) v = nd(rng);
   for (auto &v : hsc) v = 0.5f + 0.5f * std::fabs(nd(rng));
   for (auto &v : hsh) v = 0.2f * nd(rng);
@@ -76,7 +102,7 @@ static double run_shape(const Shape &sh, int abl, int reps) {
   CK(hipMalloc(&dy2, (size_t)M * N * 4));
   CK(hipMalloc(&dy3, (size_t)M * N * 4));
   const int ntiles = (N + 15) / 16, nk = ((K + 63) / 64) * 2;
-  CK(hipMalloc(&dw3, (size_t)ntiles * nk * 3 * 1024));
+  CK(hipMalloc(&dw3, (size_t)ntiles * nk * 3 * 1024 + (size_t)ntiles * 4));
   for (int64_t r0 = 0; r0 < M; r0 += HB) {
     const int64_t n = std::min<int64_t>(HB, M - r0);
     CK(hipMemcpy(dx + r0 * K, hx.data(), (size_t)n * K * 4, hipMemcpyHostToDevice));
@@ -89,7 +115,33 @@ static double run_shape(const Shape &sh, int abl, int reps) {
   CK(hipMemset(dy2, 0xff, (size_t)M * N * 4));
   CK(hipMemset(dy3, 0xff, (size_t)M * N * 4));
 
+  float2 *drot = nullptr;
+  float *drs = nullptr;
+  if (sh.rot) {
+    const int half = 32, pos_mod = 801;
+    std::vector<float2> hrot((size_t)pos_mod * half);
+    for (auto &v : hrot) {
+      const float ang = nd(rng) * 3.0f;
+      v = make_float2(std::cos(ang), std::sin(ang));
+    }
+    std::vector<float> hrs((size_t)M);
+    for (auto &v : hrs) v = 0.5f + std::fabs(nd(rng));
+    CK(hipMalloc(&drot, hrot.size() * 8));
+    CK(hipMalloc(&drs, hrs.size() * 4));
+    CK(hipMemcpy(drot, hrot.data(), hrot.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(drs, hrs.data(), hrs.size() * 4, hipMemcpyHostToDevice));
+  }
   TdfDmaArgs a{};
+  if (sh.rot) {
+    if (sh.rot != 3) {
+      a.rot_tab = drot;
+      a.rot_cols = 2 * N / 3;
+      a.rot_half = 32;
+      a.rot_pos_mod = 801;
+      a.rot_pos_div = 62;
+    }
+    if (sh.rot != 2) a.rscale = drs;
+  }
   a.x = dx;
   a.w = dw;
   a.bias = sh.bias ? db : nullptr;
@@ -106,7 +158,8 @@ static double run_shape(const Shape &sh, int abl, int reps) {
   a.tile_map = g_map;
 
   const int64_t total = (int64_t)ntiles * nk * 64;
-  hipLaunchKernelGGL(w3_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, dw, dw3, N, K, total);
+  if (g_h) hipLaunchKernelGGL(w3h_split_kernel, dim3((unsigned)ntiles), dim3(256), 0, 0, dw, dw3, N, K, ntiles);
+  else hipLaunchKernelGGL(w3_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, dw, dw3, N, K, total);
   CK(hipDeviceSynchronize());
 
   hipEvent_t e0, e1;
@@ -127,7 +180,8 @@ static double run_shape(const Shape &sh, int abl, int reps) {
   const double t2 = time_it([&]() { launch2<3, 8>(a, 0); });
   a.y = dy3;
   double t3 = 0;
-  switch (abl) {
+  switch (g_h ? 100 : abl) {
+    case 100: t3 = time_it([&]() { launch3h_sel(a, dw3, 0); }); break;
     case 0: t3 = time_it([&]() { launch3<3, 8, 0>(a, dw3, 0); }); break;
     case 1: t3 = time_it([&]() { launch3<3, 8, 1>(a, dw3, 0); }); break;
     case 2: t3 = time_it([&]() { launch3<3, 8, 2>(a, dw3, 0); }); break;
@@ -138,12 +192,46 @@ static double run_shape(const Shape &sh, int abl, int reps) {
     default: fprintf(stderr, "abl?\n"); exit(2);
   }
   CK(hipGetLastError());
+  if (g_full) {
+    float *dy3b;
+    CK(hipMalloc(&dy3b, (size_t)M * N * 4));
+    CK(hipMemset(dy3b, 0xff, (size_t)M * N * 4));
+    a.y = dy3b;
+    if (g_h) launch3h_sel(a, dw3, 0);
+    else launch3<3, 8, 0>(a, dw3, 0);
+    CK(hipDeviceSynchronize());
+    const int64_t CH = 1 << 24;
+    std::vector<float> b2(CH), b3(CH), b3b(CH);
+    int64_t ndiff = 0, nbig = 0, first = -1;
+    double worst = 0;
+    for (int64_t o = 0; o < M * N; o += CH) {
+      const int64_t n = std::min<int64_t>(CH, M * N - o);
+      CK(hipMemcpy(b2.data(), dy2 + o, (size_t)n * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(b3.data(), dy3 + o, (size_t)n * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(b3b.data(), dy3b + o, (size_t)n * 4, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < n; ++i) {
+        if (memcmp(&b3[i], &b3b[i], 4) != 0) {
+          if (first < 0) first = o + i;
+          if (ndiff < 4)
+            printf("    row %lld col %lld: run A %.6e run B %.6e fp32 kernel %.6e\n", (long long)((o + i) / N), (long long)((o + i) % N), b3[i], b3b[i],
+                   b2[i]);
+          ++ndiff;
+        }
+        const double d = std::fabs((double)b3[i] - b2[i]);
+        worst = std::max(worst, d);
+        if (d > 1e-3 * (1.0 + std::fabs(b2[i]))) ++nbig;
+      }
+    }
+    printf("  full compare: two tdf3 runs differ in %lld elements (first at row %lld col %lld); tdf3 vs tdf2: max abs %.3e, %lld elements off by > 1e-3\n",
+           (long long)ndiff, (long long)(first < 0 ? -1 : first / N), (long long)(first < 0 ? -1 : first % N), worst, (long long)nbig);
+    CK(hipFree(dy3b));
+  }
   const double flops = 2.0 * M * N * K;
 
   // float64 reference on sampled rows (first HB rows suffice: the data repeats), both kernels
   const int nsamp = 64;
   std::vector<float> y2((size_t)N), y3((size_t)N);
-  double e2 = 0, e3 = 0, d23 = 0, nrm = 0, mx2 = 0, mx3 = 0;
+  double e2 = 0, e3 = 0, d23 = 0, nrm = 0, mx2 = 0, mx3 = 0, worst3 = 0, worst2 = 0;   // worst*: row x column-group error over the group's own scale
   int nan3 = 0;
   for (int si = 0; si < nsamp; ++si) {
     int64_t row = (int64_t)((double)si / nsamp * M);
@@ -152,6 +240,7 @@ static double run_shape(const Shape &sh, int abl, int reps) {
     CK(hipMemcpy(y2.data(), dy2 + row * N, N * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(y3.data(), dy3 + row * N, N * 4, hipMemcpyDeviceToHost));
     const int c = (int)((row / sh.T) % sh.C);
+    double ge2[3] = {0, 0, 0}, ge3[3] = {0, 0, 0}, gn[3] = {0, 0, 0};
     for (int n = 0; n < N; ++n) {
       double acc = 0;
       for (int k = 0; k < K; ++k) acc += (double)hx[hrow * K + k] * (double)hw[(size_t)n * K + k];
@@ -165,12 +254,22 @@ static double run_shape(const Shape &sh, int abl, int reps) {
       nrm += v * v;
       mx2 = std::max(mx2, std::fabs(y2[n] - v));
       mx3 = std::max(mx3, std::fabs(y3[n] - v));
+      const int g = n < 16 ? 0 : (n < 32 ? 1 : 2);
+      const double pre = hsc[c] * (acc + (sh.bias ? hb[n] : 0.0)) + hsh[c];   // scale of the group before ReLU / residual
+      ge2[g] += (y2[n] - v) * (y2[n] - v);
+      ge3[g] += (y3[n] - v) * (y3[n] - v);
+      gn[g] += pre * pre;
     }
+    for (int g = 0; g < 3; ++g)
+      if (gn[g] > 0) {
+        worst2 = std::max(worst2, std::sqrt(ge2[g] / gn[g]));
+        worst3 = std::max(worst3, std::sqrt(ge3[g] / gn[g]));
+      }
   }
   printf("%-22s M=%-8lld N=%-5d K=%-5d  tdf2 %8.3f ms %6.1f TF | tdf3 %8.3f ms %6.1f TF-eq (x%.2f) | relrms vs f64: tdf2 %.2e tdf3 %.2e  "
-         "maxabs %.2e / %.2e  tdf2-vs-tdf3 %.2e  nonfinite %d\n",
+         "maxabs %.2e / %.2e  tdf2-vs-tdf3 %.2e  nonfinite %d  worst row-group %.2e / %.2e\n",
          sh.name, (long long)M, N, K, t2, flops / t2 * 1e-9, t3, flops / t3 * 1e-9, t2 / t3, std::sqrt(e2 / nrm), std::sqrt(e3 / nrm), mx2, mx3,
-         std::sqrt(d23 / nrm), nan3);
+         std::sqrt(d23 / nrm), nan3, worst2, worst3);
   fflush(stdout);
   CK(hipFree(dx));
   CK(hipFree(dw));
@@ -184,11 +283,20 @@ static double run_shape(const Shape &sh, int abl, int reps) {
   return t3;
 }
 
+static void launch3h_sel(const TdfDmaArgs &a, const u32x4 *w3, hipStream_t s) {
+  if (g_tile == 1) launch3h<2, 8>(a, w3, s);
+  else if (g_tile == 2) launch3h<2, 4>(a, w3, s);
+  else launch3h<3, 8>(a, w3, s);
+}
+
 int main(int argc, char **argv) {
   const int abl = argc > 1 ? atoi(argv[1]) : 0;
   const int first = argc > 2 ? atoi(argv[2]) : 0;
   const int last = argc > 3 ? atoi(argv[3]) : 99;
   g_map = argc > 4 ? atoi(argv[4]) : 0;
+  g_h = argc > 5 ? atoi(argv[5]) : 0;
+  g_full = argc > 6 ? atoi(argv[6]) : 0;
+  g_tile = argc > 7 ? atoi(argv[7]) : 0;
   std::vector<Shape> shapes = {
       {"small ragged", 1000, 200, 192, 3, 8, 1, 1, 1},
       {"small gelu", 4096 + 64, 512, 256, 1, 1, 2, 1, 1},
@@ -202,6 +310,13 @@ int main(int argc, char **argv) {
       {"rof ff2", 480000, 512, 2048, 1, 1, 0, 1, 1},
       {"rof qkv", 480000, 1536, 512, 1, 1, 0, 0, 0},
       {"ht lin", 43008, 1536, 384, 1, 1, 2, 0, 1},
+      {"rof qkv rotary", 49664, 1536, 512, 1, 1, 0, 0, 0, 0, 1},
+      {"rof qkv rot only", 49664, 1536, 512, 1, 1, 0, 0, 0, 0, 2},
+      {"rof qkv rscale only", 49664, 1536, 512, 1, 1, 0, 0, 0, 0, 3},
+      {"rof qkv plain 49664", 49664, 1536, 512, 1, 1, 0, 0, 0, 0, 0},
+      {"spread small", 4096 + 64, 512, 256, 1, 1, 0, 1, 1, 1},
+      {"spread tdf L0 gemm1", 67584, 384, 3072, 48, 256, 1, 0, 0, 1},
+      {"spread tdf L0 gemm2", 67584, 3072, 384, 48, 256, 1, 1, 0, 1},
   };
   for (int i = first; i < (int)shapes.size() && i <= last; ++i) run_shape(shapes[i], abl, 5);
   return 0;
