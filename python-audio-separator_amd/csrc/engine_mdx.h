@@ -721,7 +721,12 @@ static void launch_tdf_dma_auto(asx_engine *e, const TdfDmaArgs &d, hipStream_t 
     // HTDemucs linears: 0.96 / 0.85 / 0.75 -> 1251 / 1262 / 1262 ms and 30.5 / 30.4 / 30.5 ms per song -- no reason to move off
     // the fp32 kernel's figure (N = 512 stays on four 128-column tiles).
     static const double eff128 = getenv("ASX_TDF3_EFF128") ? atof(getenv("ASX_TDF3_EFF128")) : 0.96;
-    const bool narrow3 = t128 == 2 || (t128 == 1 && cost(128, eff128) < cost(192, 1.0));
+    // fp16 x 3: the 128-column tile needs 166 registers -- three workgroups per CU -- and measures as fast per MAC as the 192-column
+    // one or faster on the SHORT-K shapes (BS-Roformer FF1 4.45 vs 4.74 ms, qkv 2.85 vs 3.28, HTDemucs linear 0.266 vs 0.328:
+    // profiles/r05_gemm_f16x3.txt, "tile forms"): no handicap there.  Long K keeps it: the level-0 / level-1 first TDF linears
+    // (K = 3072 / 1536) are 3 % / 35 % slower on the narrow tile.
+    const double e128 = (e->gemm_f16x3 > 0 && d.K <= 512 && !getenv("ASX_TDF3_EFF128")) ? 1.0 : eff128;
+    const bool narrow3 = t128 == 2 || (t128 == 1 && cost(128, e128) < cost(192, 1.0));
     if (v3 && (narrow3 ? launch_tdf3<2, 8>(e, d, s) : launch_tdf3<3, 8>(e, d, s))) return;
     if (narrow) v2 ? launch_tdf2<2, 8>(d, s) : launch_tdf_dma_t<2, 8>(d, s);
     else v2 ? launch_tdf2<3, 8>(d, s) : launch_tdf_dma_t<3, 8>(d, s);

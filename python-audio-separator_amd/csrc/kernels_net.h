@@ -829,6 +829,14 @@ __device__ __forceinline__ f32x4 tdf_rot4(const TdfDmaArgs &a, f32x4 o, int64_t 
   // output compared bit for bit, tools/proto_gemm3.hip "rof qkv rotary"; with the table replaced by constants, or with the
   // operations kept scalar as here, two runs agree in all 76 M elements).  The same kernel source in other builds had shown the
   // symptom once before (round 5: BS-Roformer chunk test 3e-5 .. 7e-5 off on two boxes with one build, unexplained then).
+#ifdef ASX_ROT_PACKED   // the form that misbehaves, for tools/proto_gemm3.hip only (hipcc -DASX_ROT_PACKED ...; shape "rof qkv rotary", full compare)
+  f32x4 rp;
+  rp.x = __fmaf_rn(o.x, c0.x, -__fmul_rn(o.y, c0.y));
+  rp.y = __fmaf_rn(o.y, c0.x, __fmul_rn(o.x, c0.y));
+  rp.z = __fmaf_rn(o.z, c1.x, -__fmul_rn(o.w, c1.y));
+  rp.w = __fmaf_rn(o.w, c1.x, __fmul_rn(o.z, c1.y));
+  return rp;
+#endif
   float p0 = __fmul_rn(o.y, c0.y), p1 = __fmul_rn(o.x, c0.y), p2 = __fmul_rn(o.w, c1.y), p3 = __fmul_rn(o.z, c1.y);
   asm volatile("" : "+v"(p0));
   asm volatile("" : "+v"(p1));

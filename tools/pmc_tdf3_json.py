@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-LAYER traffic record of the bf16 x 6 row GEMM (tdf3_kernel) from rocprofv3 --pmc passes of the bench song (tools/pmc_run.sh):
+"""Per-LAYER traffic record of the split-operand row GEMM (tdf3_kernel, bf16 x 6 or fp16 x 3: the record says which ran) from rocprofv3 --pmc passes of the bench song (tools/pmc_run.sh):
 round 4's record averaged every TDF dispatch against `algorithmic_bytes_per_launch: 1.0` ("not filled in").
 Here every dispatch is matched to its layer by its grid -- ceil(M / BM) x ceil(N / BN) workgroups of 256 threads, BM / BN from the
 kernel's template arguments -- and compared with THAT layer's algorithmic bytes: x [M, K] + y [M, N] (+ the residual [M, N] on the
@@ -37,6 +37,7 @@ def main():
         layers.append((f"L{lv}.F_to_F8", m, f // a.bn, f, 4.0 * (m * f + m * (f // a.bn) + (f // a.bn) * f)))
         layers.append((f"L{lv}.F8_to_F", m, f, f // a.bn, 4.0 * (m * (f // a.bn) + 2 * m * f + f * (f // a.bn))))
     # per dispatch: counters keyed by (Dispatch_Id) do not line up across passes; aggregate by (kernel template, grid) instead
+    arith = set()
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(lambda: collections.defaultdict(int))
     for fn in glob.glob(a.root + "/*/p_counter_collection.csv"):
@@ -44,9 +45,13 @@ def main():
             k = r["Kernel_Name"]
             if "tdf3_kernel" not in k:
                 continue
-            mt = re.search(r"tdf3_kernel<(\d+), (\d+), (\d+), (\w+)>", k)
+            mt = re.search(r"tdf3_kernel<(\d+), (\d+), (\d+), (\w+)(?:, (\w+))?>", k)   # NREP, MREP, ABL, GATHER[, H]
             if not mt or mt.group(4) not in ("false", "0"):
                 continue
+            if mt.group(5) in ("true", "1"):
+                arith.add("fp16 x 3")
+            else:
+                arith.add("bf16 x 6")
             nrep, mrep = int(mt.group(1)), int(mt.group(2))
             wgs = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"]))
             key = (nrep, mrep, wgs)
@@ -54,7 +59,7 @@ def main():
             cnt[key][r["Counter_Name"]] += 1
     if not agg:
         sys.exit(f"no tdf3_kernel dispatch under {a.root}")
-    out = {"kernel": "tdf3_kernel<NREP, MREP, 0, false> (bf16 x 6 row GEMM, csrc/kernels_gemm3.h)", "source": a.how, "layers": {},
+    out = {"kernel": "tdf3_kernel<NREP, MREP, 0, false[, H]> (split-operand row GEMM, csrc/kernels_gemm3.h)", "arithmetic": sorted(arith), "source": a.how, "layers": {},
            "note": "per layer of the HQ_3 net (55 chunks per launch): FETCH_SIZE x 2 + WRITE_SIZE per dispatch (KiB counters; gfx950 correction of "
                    "MI355X_MICROARCH.md) against the layer's algorithmic bytes x + y (+ residual) + W; FETCH_SIZE counts L2 misses towards the "
                    "fabric, Infinity-Cache hits included"}
