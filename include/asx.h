@@ -493,6 +493,7 @@ int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host
  * float of asx_debug_fetch, which stops resolving single launches past 2^24): "tdf3_launches" (split-operand row GEMM, either arithmetic),
  * "tdf3h_launches" (those of them, plain or GATHER mode, that ran the fp16 x 3 arithmetic),
  * "tdf3_gather_launches" (its GATHER mode: channels-last convolutions), "attn6_launches" (attention6_kernel / mha6_kernel),
+ * "attn6h_launches" (those of them on the fp16 x 3 arithmetic),
  * "wino6_launches" (conv_wino6_kernel: Winograd F(2x2,3x3) on the bf16 pipe).  ASX_ERR_INVALID for an unknown name. */
 int asx_counter(const asx_engine *e, const char *name, int64_t *out);
 
@@ -552,8 +553,9 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
  * split into TWO fp16 parts (11 + 11 significand bits), three fp16 MFMA products per multiply-add instead of six, the dropped term
  * below 2^-22 of a product; elements more than 2^14 below their row's (tile's) largest keep an absolute error of 2^-37 of that
  * largest instead of a relative one.  Measured against a float64 GEMM: closer than the bf16 x 6 form on every shape (fewer accumulator
- * roundings), 1.1-1.5x its speed (profiles/r05_gemm_f16x3.txt).  0 = bf16 x 6 (exact three-way split).  The attention kernels and
- * conv_wino6_kernel stay on bf16 x 6 under either value.
+ * roundings), 1.1-1.5x its speed (profiles/r05_gemm_f16x3.txt).  The attention kernels follow the same switch (one exponent per query,
+ * per 64-key tile of K, a running one per tile of V, none for the probabilities; 1.16-1.31x, profiles/r05_attention_f16x3.txt).
+ * 0 = bf16 x 6 (exact three-way split) in all of them.  conv_wino6_kernel stays on bf16 x 6 under either value.
  * The split weight images these kernels read are built on the FIRST forward after a load (one small kernel + one stream
  * synchronise per weight tensor) and belong to the engine: they are freed only when this engine's weights are re-loaded or the engine
  * is destroyed, never by another engine of the process -- so a hipGraph captured after one warm-up call stays valid while other

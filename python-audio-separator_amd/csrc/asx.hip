@@ -1909,6 +1909,7 @@ int asx_counter(const asx_engine *e, const char *name, int64_t *out) {
   if (nm == "tdf3_launches") *out = (int64_t)g_tdf3_launches.load();
   else if (nm == "tdf3h_launches") *out = (int64_t)g_tdf3h_launches.load();
   else if (nm == "attn6_launches") *out = (int64_t)g_attn6_launches.load();
+  else if (nm == "attn6h_launches") *out = (int64_t)g_attn6h_launches.load();
   else if (nm == "tdf3_gather_launches") *out = (int64_t)g_tdf3_gather_launches.load();
   else if (nm == "wino6_launches") *out = (int64_t)g_wino6_launches.load();
   else {

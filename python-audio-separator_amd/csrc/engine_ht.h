@@ -769,7 +769,16 @@ static int ht_mha(asx_engine *e, const float *q, int64_t ldq, const float *k, co
       const bool wide = nq > 128;                      // 128 queries per workgroup on long sequences
       a6.nqt = wide ? (nq + 127) / 128 : (nq + 63) / 64;
       const dim3 grid6((unsigned)(a6.nqt * heads * B));
-      if (dh == 48) {
+      if (e->gemm_f16x3 > 0) {                         // fp16 x 3 arithmetic (kernels_ht.h: template parameter H)
+        if (dh == 48) {
+          if (wide) hipLaunchKernelGGL((mha6_kernel<3, 2, true>), grid6, dim3(256), 0, s, a6);
+          else hipLaunchKernelGGL((mha6_kernel<3, 1, true>), grid6, dim3(256), 0, s, a6);
+        } else {
+          if (wide) hipLaunchKernelGGL((mha6_kernel<4, 2, true>), grid6, dim3(256), 0, s, a6);
+          else hipLaunchKernelGGL((mha6_kernel<4, 1, true>), grid6, dim3(256), 0, s, a6);
+        }
+        g_attn6h_launches.fetch_add(1);
+      } else if (dh == 48) {
         if (wide) hipLaunchKernelGGL((mha6_kernel<3, 2>), grid6, dim3(256), 0, s, a6);
         else hipLaunchKernelGGL((mha6_kernel<3, 1>), grid6, dim3(256), 0, s, a6);
       } else {

@@ -572,7 +572,8 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
 // launches of tdf3_kernel since the process started (tests assert that the path under test is the one that ran)
 static std::atomic<long long> g_tdf3_launches{0};
 static std::atomic<long long> g_tdf3h_launches{0};   // ... of which on the fp16 x 3 arithmetic (plain and GATHER mode)
-static std::atomic<long long> g_attn6_launches{0};   // launches of attention6_kernel (kernels_rof.h)
+static std::atomic<long long> g_attn6_launches{0};   // launches of attention6_kernel (kernels_rof.h) / mha6_kernel (kernels_ht.h)
+static std::atomic<long long> g_attn6h_launches{0};  // ... of which on the fp16 x 3 arithmetic
 
 // The split image of a weight matrix is built on first use and cached PER ENGINE by (pointer, N, K, cin) (asx_engine::w3).  Every
 // entry point that uploads or frees weights of an engine flushes that engine's images (w3_flush) -- an address reused by another tensor

@@ -347,14 +347,20 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
         if (attn6 && e->gemm_bf16x6 > 0 && !v1) {
           AttnArgs a2 = aa;
           static const int qw6 = getenv("ASX_ATTN6_QW") ? atoi(getenv("ASX_ATTN6_QW")) : 2;   // 128 queries per workgroup on long sequences
+          const bool h3 = e->gemm_f16x3 > 0;           // fp16 x 3 arithmetic (kernels_rof.h: template parameter H)
           if (qw6 >= 2 && aa.len > 128) {
             a2.nqt = (aa.len + 127) / 128;
-            hipLaunchKernelGGL(attention6_kernel<2>, dim3((unsigned)((int64_t)a2.nqt * H * nseq)), dim3(256), 0, s, a2);
+            const dim3 g2((unsigned)((int64_t)a2.nqt * H * nseq));
+            if (h3) hipLaunchKernelGGL((attention6_kernel<2, true>), g2, dim3(256), 0, s, a2);
+            else hipLaunchKernelGGL(attention6_kernel<2>, g2, dim3(256), 0, s, a2);
           } else {
             a2.nqt = qtiles;
-            hipLaunchKernelGGL(attention6_kernel<1>, dim3((unsigned)((int64_t)qtiles * H * nseq)), dim3(256), 0, s, a2);
+            const dim3 g1((unsigned)((int64_t)qtiles * H * nseq));
+            if (h3) hipLaunchKernelGGL((attention6_kernel<1, true>), g1, dim3(256), 0, s, a2);
+            else hipLaunchKernelGGL(attention6_kernel<1>, g1, dim3(256), 0, s, a2);
           }
           g_attn6_launches.fetch_add(1);
+          if (h3) g_attn6h_launches.fetch_add(1);
         } else
         if (v1) hipLaunchKernelGGL(attention_kernel, dim3(qtiles, H, (unsigned)nseq), dim3(256), 0, s, aa);
         else if (qw >= 2 && aa.len > 64) {

@@ -483,11 +483,18 @@ __global__ __launch_bounds__(256, (QW == 1 && !DB) ? 3 : 2) void attention2_kern
 // ---------------------------------------------------------------------------
 // QW = 16-query groups per wave (64 QW queries per workgroup): the K / V split of a tile (176 VALU per thread, the kernel is VALU-bound)
 // serves QW times the MFMA work.
-template <int QW>
+// H: the fp16 x 3 arithmetic of kernels_gemm3.h (two fp16 parts per operand, three MFMAs per product).  Block exponents: one per QUERY for Q
+// (its 64 dims live in one lane quadruple: two shuffles), one per 64-key TILE for K (the S^T accumulators are fresh every tile: the factor
+// 2^-(e_k + e_q) rides on the logit scale), a running one per tile for V (it only drops, with two bits of headroom; the drop rides on the
+// online-softmax correction the O accumulators are multiplied by anyway), none for P (probabilities are in [0, 1]: absolute error 2^-25).
+// The tile maxima cross the workgroup through eight LDS floats written in front of the barrier that already separates two tiles.
+template <int QW, bool H = false>
 __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(AttnArgs a) {
-  constexpr int PARTB = 64 * 128;                      // bytes of one part image (64 rows x 64 bf16)
-  __shared__ __attribute__((aligned(16))) char lds6[6 * PARTB];
-  char *Kp = lds6, *Vp = lds6 + 3 * PARTB;
+  constexpr int NP = H ? 2 : 3;                        // parts per operand
+  constexpr int PARTB = 64 * 128;                      // bytes of one part image (64 rows x 64 16-bit values)
+  __shared__ __attribute__((aligned(16))) char lds6[2 * NP * PARTB];
+  __shared__ __attribute__((aligned(16))) float tile_mx[8];   // H: per-wave largest |K|, |V| of the tile about to be staged
+  char *Kp = lds6, *Vp = lds6 + NP * PARTB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -501,20 +508,34 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
   const int q0 = qt * 64 * QW;
 
   // ---- Q operand of this lane: query q0 + 16 wave + li, dims 32 ks + 8 lk .. + 7, split into three bf16 fragments per k step
-  u32x4 qf[QW][2][3];
+  u32x4 qf[QW][2][NP];
+  int eq[QW];                                          // H: exponent of this lane's query
 #pragma unroll
   for (int g = 0; g < QW; ++g) {
     const int q = q0 + (wave * QW + g) * 16 + li;
     const bool ok = q < a.len;
     const float *qr = a.qkv + (base + (int64_t)(ok ? q : 0) * a.row_stride) * ld + h * 64 + 8 * lk;
+    f32x4 qv[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      qv[ks][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      qv[ks][1] = qv[ks][0];
       if (ok) {
-        v0 = *reinterpret_cast<const f32x4 *>(qr + 32 * ks);
-        v1 = *reinterpret_cast<const f32x4 *>(qr + 32 * ks + 4);
+        qv[ks][0] = *reinterpret_cast<const f32x4 *>(qr + 32 * ks);
+        qv[ks][1] = *reinterpret_cast<const f32x4 *>(qr + 32 * ks + 4);
       }
-      split3_oct(v0, v1, qf[g][ks][0], qf[g][ks][1], qf[g][ks][2]);
+    }
+    eq[g] = 0;
+    if constexpr (H) {
+      float m = fmaxf(absmax_oct(qv[0][0], qv[0][1]), absmax_oct(qv[1][0], qv[1][1]));
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      eq[g] = f16_scale_exp(m);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if constexpr (H) split2h_oct(qv[ks][0], qv[ks][1], eq[g], qf[g][ks][0], qf[g][ks][1]);
+      else split3_oct(qv[ks][0], qv[ks][1], qf[g][ks][0], qf[g][ks][1], qf[g][ks][NP - 1]);
     }
   }
 
@@ -548,28 +569,62 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
   // K image: row = key, 8-byte unit c4 of the row (dims 4 c4 .. + 3): slot c4 >> 1, half c4 & 1
   // V image: row = dim, keys 4 kb .. + 3 at pos (t >> 1) * 32 + g * 8 + (t & 1) * 4 (t = kb >> 2, g = kb & 3): slot (t >> 1) * 4 + g, half t & 1
   const int vslot = ((kb >> 3) << 2) | (kb & 3), vhalf = (kb >> 2) & 1;
+  int ek = 0, ev_run = 200;                            // H: exponent of the K tile in LDS; running exponent of V (and of the O accumulators)
+  float fdev = 1.0f;                                   // H: 2^(drop of ev_run at this tile), applied with the softmax correction
+  auto publish_tile_max = [&]() {                      // H: largest |K|, |V| of the fetched tile, per wave
+    float mk = 0.f, mv = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mk = fmaxf(mk, fmaxf(fmaxf(fabsf(kreg[j].x), fabsf(kreg[j].y)), fmaxf(fabsf(kreg[j].z), fabsf(kreg[j].w))));
+      mv = fmaxf(mv, fmaxf(fmaxf(fabsf(vreg[j].x), fabsf(vreg[j].y)), fmaxf(fabsf(vreg[j].z), fabsf(vreg[j].w))));
+    }
+    mk = wave_max64(mk);
+    mv = wave_max64(mv);
+    if (lane == 0) {
+      tile_mx[wave] = mk;
+      tile_mx[4 + wave] = mv;
+    }
+  };
   auto stage = [&]() {
+    if constexpr (H) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4 *>(tile_mx), b4 = *reinterpret_cast<const f32x4 *>(tile_mx + 4);
+      ek = __builtin_amdgcn_readfirstlane(f16_scale_exp(fmaxf(fmaxf(a4.x, a4.y), fmaxf(a4.z, a4.w))));
+      const int need = __builtin_amdgcn_readfirstlane(f16_scale_exp(fmaxf(fmaxf(b4.x, b4.y), fmaxf(b4.z, b4.w))));
+      const int ev_new = need < ev_run ? need - 2 : ev_run;
+      fdev = __builtin_ldexpf(1.0f, ev_new - ev_run);
+      ev_run = ev_new;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = 4 * kb + j;
       unsigned hh[2], mm[2], ll[2];
-      split3_pair(kreg[j].x, kreg[j].y, hh[0], mm[0], ll[0]);
-      split3_pair(kreg[j].z, kreg[j].w, hh[1], mm[1], ll[1]);
+      if constexpr (H) {
+        split2h_pair(kreg[j].x, kreg[j].y, ek, hh[0], ll[0]);
+        split2h_pair(kreg[j].z, kreg[j].w, ek, hh[1], ll[1]);
+      } else {
+        split3_pair(kreg[j].x, kreg[j].y, hh[0], mm[0], ll[0]);
+        split3_pair(kreg[j].z, kreg[j].w, hh[1], mm[1], ll[1]);
+      }
       char *d = Kp + row * 128 + ((((c4 >> 1) ^ ((row >> 1) & 7)) << 4) | ((c4 & 1) << 3));
       *reinterpret_cast<uint2 *>(d) = make_uint2(hh[0], hh[1]);
-      *reinterpret_cast<uint2 *>(d + PARTB) = make_uint2(mm[0], mm[1]);
-      *reinterpret_cast<uint2 *>(d + 2 * PARTB) = make_uint2(ll[0], ll[1]);
+      if constexpr (!H) *reinterpret_cast<uint2 *>(d + PARTB) = make_uint2(mm[0], mm[1]);
+      *reinterpret_cast<uint2 *>(d + (NP - 1) * PARTB) = make_uint2(ll[0], ll[1]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = 4 * c4 + i;
       unsigned hh[2], mm[2], ll[2];
-      split3_pair(vreg[0][i], vreg[1][i], hh[0], mm[0], ll[0]);
-      split3_pair(vreg[2][i], vreg[3][i], hh[1], mm[1], ll[1]);
+      if constexpr (H) {
+        split2h_pair(vreg[0][i], vreg[1][i], ev_run, hh[0], ll[0]);
+        split2h_pair(vreg[2][i], vreg[3][i], ev_run, hh[1], ll[1]);
+      } else {
+        split3_pair(vreg[0][i], vreg[1][i], hh[0], mm[0], ll[0]);
+        split3_pair(vreg[2][i], vreg[3][i], hh[1], mm[1], ll[1]);
+      }
       char *d = Vp + row * 128 + (((vslot ^ (((row >> 1) ^ (row >> 3)) & 7)) << 4) | (vhalf << 3));   // V^T swizzle: see the fragment read
       *reinterpret_cast<uint2 *>(d) = make_uint2(hh[0], hh[1]);
-      *reinterpret_cast<uint2 *>(d + PARTB) = make_uint2(mm[0], mm[1]);
-      *reinterpret_cast<uint2 *>(d + 2 * PARTB) = make_uint2(ll[0], ll[1]);
+      if constexpr (!H) *reinterpret_cast<uint2 *>(d + PARTB) = make_uint2(mm[0], mm[1]);
+      *reinterpret_cast<uint2 *>(d + (NP - 1) * PARTB) = make_uint2(ll[0], ll[1]);
     }
   };
   // fragment reads: row 16 t + li, logical slot s -> physical s ^ ((li >> 1) & 7)
@@ -578,6 +633,7 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
   fetch(0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * 64;
+    if constexpr (H) publish_tile_max();
     __syncthreads();   // previous tile fully consumed
     stage();
     __syncthreads();
@@ -592,13 +648,24 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const char *kp = Kp + mt * 2048 + frow + (((ks * 4 + lk) ^ fsw) << 4);
+        if constexpr (H) {
+          const f16x8 kh = *reinterpret_cast<const f16x8 *>(kp), kl = *reinterpret_cast<const f16x8 *>(kp + PARTB);
+#pragma unroll
+          for (int g = 0; g < QW; ++g) {
+            const f16x8 qh = __builtin_bit_cast(f16x8, qf[g][ks][0]), ql = __builtin_bit_cast(f16x8, qf[g][ks][1]);
+            st[g][mt] = ASX_MFMA_F16(kl, qh, st[g][mt]);
+            st[g][mt] = ASX_MFMA_F16(kh, ql, st[g][mt]);
+            st[g][mt] = ASX_MFMA_F16(kh, qh, st[g][mt]);
+          }
+          continue;
+        }
         const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(kp);
         const bf16x8 km = *reinterpret_cast<const bf16x8 *>(kp + PARTB);
-        const bf16x8 kl = *reinterpret_cast<const bf16x8 *>(kp + 2 * PARTB);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8 *>(kp + (NP - 1) * PARTB);
 #pragma unroll
         for (int g = 0; g < QW; ++g) {
           const bf16x8 qh = __builtin_bit_cast(bf16x8, qf[g][ks][0]), qm = __builtin_bit_cast(bf16x8, qf[g][ks][1]),
-                       ql = __builtin_bit_cast(bf16x8, qf[g][ks][2]);
+                       ql = __builtin_bit_cast(bf16x8, qf[g][ks][NP - 1]);
           st[g][mt] = ASX_MFMA_BF16(kl, qh, st[g][mt]);
           st[g][mt] = ASX_MFMA_BF16(kh, ql, st[g][mt]);
           st[g][mt] = ASX_MFMA_BF16(km, qm, st[g][mt]);
@@ -612,12 +679,13 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
 #pragma unroll
     for (int g = 0; g < QW; ++g) {
       float mx = -INFINITY;
+      const float sfac = H ? __builtin_ldexpf(a.scale, -(ek + eq[g])) : a.scale;   // H: back to the operands' own scale, exact
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = k0 + mt * 16 + 4 * lk + r;
-          const float sv = (key < a.len) ? st[g][mt][r] * a.scale : -INFINITY;
+          const float sv = (key < a.len) ? st[g][mt][r] * sfac : -INFINITY;
           st[g][mt][r] = sv;
           mx = fmaxf(mx, sv);
         }
@@ -640,12 +708,35 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
       psum += __shfl_xor(psum, 32);
       l_run[g] = l_run[g] * corr + psum;
       m_run[g] = m_new;
+      const float corr_o = H ? corr * fdev : corr;     // H: the O accumulators follow V's running exponent
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc_o[g][dt] *= corr;
+      for (int dt = 0; dt < 4; ++dt) acc_o[g][dt] *= corr_o;
     }
     // ---- O^T[d, query] += V^T[d, key] P^T[key, query], 32 keys per k step (a V fragment serves every query group) ----
 #pragma unroll
     for (int kp = 0; kp < 2; ++kp) {
+      if constexpr (H) {
+        f16x8 p_h[QW], p_l[QW];
+#pragma unroll
+        for (int g = 0; g < QW; ++g) {
+          u32x4 ph, pl;
+          split2h_oct(st[g][2 * kp], st[g][2 * kp + 1], 0, ph, pl);   // probabilities: no exponent
+          p_h[g] = __builtin_bit_cast(f16x8, ph);
+          p_l[g] = __builtin_bit_cast(f16x8, pl);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const char *vp = Vp + dt * 2048 + frow + (((kp * 4 + lk) ^ (fsw ^ ((2 * dt + (li >> 3)) & 7))) << 4);
+          const f16x8 vh = *reinterpret_cast<const f16x8 *>(vp), vl = *reinterpret_cast<const f16x8 *>(vp + PARTB);
+#pragma unroll
+          for (int g = 0; g < QW; ++g) {
+            acc_o[g][dt] = ASX_MFMA_F16(vl, p_h[g], acc_o[g][dt]);
+            acc_o[g][dt] = ASX_MFMA_F16(vh, p_l[g], acc_o[g][dt]);
+            acc_o[g][dt] = ASX_MFMA_F16(vh, p_h[g], acc_o[g][dt]);
+          }
+        }
+        continue;
+      }
       bf16x8 p_h[QW], p_m[QW], p_l[QW];
 #pragma unroll
       for (int g = 0; g < QW; ++g) {
@@ -660,7 +751,7 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
         const char *vp = Vp + dt * 2048 + frow + (((kp * 4 + lk) ^ (fsw ^ ((2 * dt + (li >> 3)) & 7))) << 4);   // row = 16 dt + li: ((row >> 1) ^ (row >> 3)) & 7
         const bf16x8 vh = *reinterpret_cast<const bf16x8 *>(vp);
         const bf16x8 vm = *reinterpret_cast<const bf16x8 *>(vp + PARTB);
-        const bf16x8 vl = *reinterpret_cast<const bf16x8 *>(vp + 2 * PARTB);
+        const bf16x8 vl = *reinterpret_cast<const bf16x8 *>(vp + (NP - 1) * PARTB);
 #pragma unroll
         for (int g = 0; g < QW; ++g) {
           acc_o[g][dt] = ASX_MFMA_BF16(vl, p_h[g], acc_o[g][dt]);
@@ -686,6 +777,12 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
       for (int dt = 0; dt < 4; ++dt) {
         f32x4 o = acc_o[g][dt];
         o *= inv;
+        if constexpr (H) {                             // V's exponent (exact)
+          o.x = __builtin_ldexpf(o.x, -ev_run);
+          o.y = __builtin_ldexpf(o.y, -ev_run);
+          o.z = __builtin_ldexpf(o.z, -ev_run);
+          o.w = __builtin_ldexpf(o.w, -ev_run);
+        }
         *reinterpret_cast<f32x4 *>(a.out + row * inner + h * 64 + dt * 16 + 4 * lk) = o;
       }
     }

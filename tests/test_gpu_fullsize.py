@@ -33,13 +33,15 @@ def test_htdemucs_segment(A):
     eng.load_ht(A.HTConfig(segment=Fraction(39, 5)), sd)
     x = (0.3 * np.random.default_rng(0).standard_normal((1, 2, oc.training_length))).astype(np.float32)
     got = eng.ht_forward(x)
+    assert np.array_equal(got, eng.ht_forward(x)), "two forwards of the same segment differ"      # see test_bs_roformer_chunk
     want = D.ht_forward(x, sd, oc)
     assert rel_rms(got, want) < TOL, rel_rms(got, want)
 
 
-def test_htdemucs_segment_both_matrix_pipes(A):
-    """The bf16 x 6 kernels (tdf3_kernel incl. GATHER mode for the GLU rewrite convs and the k8 / s4 encoders, mha6_kernel) against
-    the fp32-MFMA kernels on the same segment, with proof of which ran (library launch counters)."""
+@pytest.mark.parametrize("arith", ["f16x3", "bf16x6"])
+def test_htdemucs_segment_both_matrix_pipes(A, arith):
+    """The split-operand kernels (tdf3_kernel incl. GATHER mode for the GLU rewrite convs and the k8 / s4 encoders, mha6_kernel; fp16 x 3 --
+    the default -- and bf16 x 6) against the fp32-MFMA kernels on the same segment, with proof of which ran (library launch counters)."""
     from oracle import demucs_oracle as D
     oc = D.HTConfig()
     sd = D.make_ht_state(oc, 0)
@@ -47,17 +49,21 @@ def test_htdemucs_segment_both_matrix_pipes(A):
     eng.load_ht(A.HTConfig(segment=Fraction(39, 5)), sd)
     x = (0.3 * np.random.default_rng(0).standard_normal((1, 2, oc.training_length))).astype(np.float32)
     names = ("tdf3_launches", "tdf3_gather_launches", "attn6_launches")
+    hnames = ("tdf3h_launches", "attn6h_launches")
     try:
         eng.set_option("gemm_bf16x6", 1)
-        c0 = [eng.counter(n) for n in names]
+        eng.set_option("gemm_f16x3", 1 if arith == "f16x3" else 0)
+        c0, h0 = [eng.counter(n) for n in names], [eng.counter(n) for n in hnames]
         y6 = eng.ht_forward(x)
-        c1 = [eng.counter(n) for n in names]
+        c1, h1 = [eng.counter(n) for n in names], [eng.counter(n) for n in hnames]
         assert all(b > a for a, b in zip(c0, c1)), dict(zip(names, zip(c0, c1)))
+        assert all((b > a) == (arith == "f16x3") for a, b in zip(h0, h1)), dict(zip(hnames, zip(h0, h1)))
         eng.set_option("gemm_bf16x6", 0)
         y32 = eng.ht_forward(x)
-        assert [eng.counter(n) for n in names] == c1, "the fp32 run went through a bf16 x 6 kernel"
+        assert [eng.counter(n) for n in names] == c1, "the fp32 run went through a split-operand kernel"
     finally:
         eng.set_option("gemm_bf16x6", 1)
+        eng.set_option("gemm_f16x3", 1)
     assert rel_rms(y6, y32) < 2e-5, rel_rms(y6, y32)
 
 
@@ -71,6 +77,7 @@ def test_hdemucs_chunk(A):
     eng.load_hd(A.HDConfig(segment=44), sd)
     x = (0.3 * np.random.default_rng(3).standard_normal((2, 2, 529201))).astype(np.float32)
     got = eng.hd_forward(x)
+    assert np.array_equal(got, eng.hd_forward(x)), "two forwards of the same chunk differ"
     want = H.hd_forward(x, sd, oc)
     assert rel_rms(got, want) < TOL, rel_rms(got, want)
 
@@ -89,6 +96,8 @@ def test_vr_clip(A):
         dm = A.VRDemixer({"model_params": mp, "primary_stem_name": "Instrumental", "torch_device": 0},
                          {"window_size": 512, "batch_size": 4, "aggression": 5, "asx_res_type": res}, state_dict=sd, nn_arch_size=arch)
         gp, gs = dm.separate_stems(wave)
+        gp2, gs2 = dm.separate_stems(wave)
+        assert np.array_equal(gp, gp2) and np.array_equal(gs, gs2), "two separations of the same clip differ"
         wp, ws = V.vr_separate(wave, sd, arch, V.ModelParams(mp), window_size=512, batch_size=2, aggression=5, wav_resolution=res)
         print(f"VR 4band_44100 full size, {res}: rel-RMS {rel_rms(gp, wp):.3e} / {rel_rms(gs, ws):.3e}")
         assert rel_rms(gp, wp) < TOL, rel_rms(gp, wp)
@@ -115,6 +124,7 @@ def test_mdx23c_chunk(A):
     Cn = cfg.hop_length * (cfg.dim_t - 1)
     x = (0.3 * np.random.default_rng(2).standard_normal((1, 2, Cn))).astype(np.float32)
     got = dm.engine.v3_forward(x)
+    assert np.array_equal(got, dm.engine.v3_forward(x)), "two forwards of the same chunk differ"
     want = M.v3_forward(x, sd, cfg)
     assert rel_rms(got, want) < TOL, rel_rms(got, want)
 
@@ -178,6 +188,7 @@ def test_mel_band_roformer_chunk(A):
     C = cfg.stft_hop_length * (cfg.dim_t - 1)
     x = (0.3 * np.random.default_rng(4).standard_normal((1, 2, C))).astype(np.float32)
     got = dm.engine.rof_forward(x)
+    assert np.array_equal(got, dm.engine.rof_forward(x)), "two forwards of the same chunk differ"
     want = R.roformer_forward(x, sd, cfg)
     assert rel_rms(got[:, 0] if got.ndim == 4 else got, want) < TOL
 
@@ -212,6 +223,7 @@ def test_htdemucs_6s_segment(A):
     eng.load_ht(A.HTConfig(sources=src, t_layers=2, segment=Fraction(39, 5)), sd)
     x = (0.3 * np.random.default_rng(6).standard_normal((1, 2, oc.training_length - 1000))).astype(np.float32)
     got = eng.ht_forward(x)
+    assert np.array_equal(got, eng.ht_forward(x)), "two forwards of the same segment differ"      # see test_bs_roformer_chunk
     want = D.ht_forward(x, sd, oc)
     assert got.shape == (1, 6, 2, oc.training_length - 1000)
     assert rel_rms(got, want) < TOL, rel_rms(got, want)

@@ -88,22 +88,27 @@ def test_stft_options_golden(A, golden_dir, key):
         assert rel_rms(eng2.rof_forward(w)[:, 0], go["fwd_" + key]) > 1e-2
 
 
-def test_forward_golden_both_matrix_pipes(A, g):
-    """The same golden vector through the bf16 x 6 kernels (row GEMM tdf3_kernel + attention6_kernel, the default) and through the
-    fp32-MFMA kernels (gemm_bf16x6 = 0), with proof of which attention kernel ran (library launch counter)."""
+@pytest.mark.parametrize("arith", ["f16x3", "bf16x6"])
+def test_forward_golden_both_matrix_pipes(A, g, arith):
+    """The same golden vector through the split-operand kernels (row GEMM tdf3_kernel + attention6_kernel; fp16 x 3 -- the default -- and
+    bf16 x 6) and through the fp32-MFMA kernels (gemm_bf16x6 = 0), with proof of which attention kernel ran (library launch counters)."""
     w = (0.4 * np.random.default_rng(81).standard_normal((2, 2, 320))).astype(np.float32)
     eng = demixer(A, CFG, 7, 8).engine
     try:
         eng.set_option("gemm_bf16x6", 1)
-        n0 = eng.counter("attn6_launches")
+        eng.set_option("gemm_f16x3", 1 if arith == "f16x3" else 0)
+        n0, h0 = eng.counter("attn6_launches"), eng.counter("attn6h_launches")
         y6 = eng.rof_forward(w)
         assert eng.counter("attn6_launches") > n0, "attention6_kernel did not run"
+        assert (eng.counter("attn6h_launches") > h0) == (arith == "f16x3"), "the other arithmetic of attention6_kernel ran"
+        assert np.array_equal(y6, eng.rof_forward(w)), "two forwards differ"
         eng.set_option("gemm_bf16x6", 0)
         n1 = eng.counter("attn6_launches")
         y32 = eng.rof_forward(w)
         assert eng.counter("attn6_launches") == n1, "the fp32 run went through attention6_kernel"
     finally:
         eng.set_option("gemm_bf16x6", 1)
+        eng.set_option("gemm_f16x3", 1)
     e6, e32 = rel_rms(y6[:, 0], g["fwd1"]), rel_rms(y32[:, 0], g["fwd1"])
     assert e6 < TOL and e32 < TOL, (e6, e32)
     assert e6 <= 2.0 * e32 + 1e-6, (e6, e32)             # fp32-grade, not a reduced-precision mode
