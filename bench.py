@@ -489,6 +489,9 @@ def main():
             "arithmetic": {"io": "float32",
                            "conv3x3": "Winograd F(2x2,3x3): fp32 MFMA (exact fma chains) below the winograd_bf16x6 channel count (default 144), "
                                       "six bf16 MFMA products on exactly split operands from there up (csrc/kernels_wino6.h)",
+                           "attention": ("as row_gemm (one exponent per query, per 64-key tile of K, a running one per tile of V, none for the probabilities)"
+                                         if (eng.option("gemm_bf16x6") > 0 and eng.option("gemm_f16x3") > 0) else
+                                         "six bf16 products on exactly split operands" if eng.option("gemm_bf16x6") > 0 else "fp32 MFMA"),
                            "row_gemm": ("three fp16 MFMA products on fp32 operands scaled per block by a power of two and split into two fp16 parts each "
                                         "(11 + 11 significand bits, dropped term < 2^-22 of a product; as close to a float64 GEMM as the fp32-MFMA "
                                         "kernel, tests/test_gpu_parity.py::test_rowgemm_bf16x6_vs_float64[f16x3], ::test_rowgemm_f16x3_block_exponent)")
