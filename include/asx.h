@@ -494,7 +494,7 @@ int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host
  * "tdf3h_launches" (those of them, plain or GATHER mode, that ran the fp16 x 3 arithmetic),
  * "tdf3_gather_launches" (its GATHER mode: channels-last convolutions), "attn6_launches" (attention6_kernel / mha6_kernel),
  * "attn6h_launches" (those of them on the fp16 x 3 arithmetic),
- * "wino6_launches" (conv_wino6_kernel: Winograd F(2x2,3x3) on the bf16 pipe).  ASX_ERR_INVALID for an unknown name. */
+ * "wino6_launches" (conv_wino6_kernel: Winograd F(2x2,3x3) on the 16-bit pipe), "wino6h_launches" (those on the fp16 x 3 arithmetic).  ASX_ERR_INVALID for an unknown name. */
 int asx_counter(const asx_engine *e, const char *name, int64_t *out);
 
 /* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host. */
@@ -555,7 +555,8 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
  * largest instead of a relative one.  Measured against a float64 GEMM: closer than the bf16 x 6 form on every shape (fewer accumulator
  * roundings), 1.1-1.5x its speed (profiles/r05_gemm_f16x3.txt).  The attention kernels follow the same switch (one exponent per query,
  * per 64-key tile of K, a running one per tile of V, none for the probabilities; 1.16-1.31x, profiles/r05_attention_f16x3.txt).
- * 0 = bf16 x 6 (exact three-way split) in all of them.  conv_wino6_kernel stays on bf16 x 6 under either value.
+ * conv_wino6_kernel too (U scaled per (channel group, position, 16-cout tile) at load, V by one running exponent per (wave, tile row);
+ * 1.04-1.11x, profiles/r05_wino6_f16x3.txt).  0 = bf16 x 6 (exact three-way split) in all of them.
  * The split weight images these kernels read are built on the FIRST forward after a load (one small kernel + one stream
  * synchronise per weight tensor) and belong to the engine: they are freed only when this engine's weights are re-loaded or the engine
  * is destroyed, never by another engine of the process -- so a hipGraph captured after one warm-up call stays valid while other

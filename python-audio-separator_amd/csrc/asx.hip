@@ -180,6 +180,7 @@ static void free_conv(ConvLayer &L) {
   L.wu3.release();
   L.wus.release();
   L.wu6.release();
+  L.wu6h.release();
   L.gn_w.release();
   L.gn_b.release();
 }
@@ -1006,7 +1007,7 @@ int asx_op_conv(asx_engine *e, const char *op, const float *x_host, int32_t B, i
   }
   ConvLayer L;
   DevBuf dx, dy, dskip;
-  BufGuard g{{&dx, &dy, &dskip, &L.w, &L.b, &L.wu, &L.wu2, &L.wu3, &L.wus, &L.wu6}};
+  BufGuard g{{&dx, &dy, &dskip, &L.w, &L.b, &L.wu, &L.wu2, &L.wu3, &L.wus, &L.wu6, &L.wu6h}};
   CHK(conv_setup(L, kind, cin, cout, relu ? 1 : 0));
   CHK(conv_pack(L, w_host, b_host, e->winograd));
   CHK(to_dev(dx, x_host, (size_t)B * cin * t * f));
@@ -1912,6 +1913,7 @@ int asx_counter(const asx_engine *e, const char *name, int64_t *out) {
   else if (nm == "attn6h_launches") *out = (int64_t)g_attn6h_launches.load();
   else if (nm == "tdf3_gather_launches") *out = (int64_t)g_tdf3_gather_launches.load();
   else if (nm == "wino6_launches") *out = (int64_t)g_wino6_launches.load();
+  else if (nm == "wino6h_launches") *out = (int64_t)g_wino6h_launches.load();
   else {
     set_err("asx_counter: unknown counter '%s'", name);
     return ASX_ERR_INVALID;

@@ -82,6 +82,7 @@ struct ConvLayer {
   DevBuf gn_w, gn_b;  // GroupNorm(2, cout) affine behind this conv (asx_net_config.norm == 1), else empty
   DevBuf wu6;      // conv_wino6_kernel (kernels_wino6.h): U split three ways into bf16, MFMA-fragment order [CG48][NCI32][wave 8][18][lane 64][4 x u32]
   int wu6_nci = 0; // 32-channel stages of that image (0 = not packed: Cin < 64)
+  DevBuf wu6h;     // the same for the fp16 x 3 arithmetic (wino6_pack_h): two fp16 parts per U, scaled per (group, position, 16-cout tile); exponents behind the fragments
 };
 
 struct TdfLayer {

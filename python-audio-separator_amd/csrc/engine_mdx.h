@@ -152,6 +152,9 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
         CHK(L.wu6.ensure(w6.size() * 4));
         HIPCHK(hipMemcpy(L.wu6.p, w6.data(), w6.size() * 4, hipMemcpyHostToDevice));
         L.wu6_nci = nci6;
+        wino6_pack_h(w, L.cout, L.cin, w6, &cg6, &nci6);   // which of the two images a launch reads is the engine's "gemm_f16x3" option then
+        CHK(L.wu6h.ensure(w6.size() * 4));
+        HIPCHK(hipMemcpy(L.wu6h.p, w6.data(), w6.size() * 4, hipMemcpyHostToDevice));
       }
     }
     // weight-stationary image: only where all of U fits the registers of eight waves (Cin <= 96) without much zero padding
@@ -198,6 +201,7 @@ static void launch_conv_dma_t(const ConvArgs &a, int nblk, hipStream_t s) {
 }
 
 static std::atomic<long long> g_wino6_launches{0};   // launches of conv_wino6_kernel (kernels_wino6.h) since the process started
+static std::atomic<long long> g_wino6h_launches{0};  // ... of which on the fp16 x 3 arithmetic
 
 // Optional view description of a conv's operands (channel slices of larger buffers).
 struct ConvView {
@@ -314,7 +318,8 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
       (int64_t)T * F < ((int64_t)1 << 24)) {
     // Winograd on the bf16 pipe, one workgroup per (8 x 32 tile, 48-channel group); the groups of a tile are consecutive on one XCD
     ConvArgs wa = a;
-    wa.wp = reinterpret_cast<const float *>(L.wu6.p);
+    const bool h3 = e->gemm_f16x3 > 0 && L.wu6h.p != nullptr;   // fp16 x 3 arithmetic (kernels_wino6.h: template parameter H)
+    wa.wp = reinterpret_cast<const float *>(h3 ? L.wu6h.p : L.wu6.p);
     wa.CG = L.wu_cg;
     wa.NCI = L.wu6_nci;
     wa.tilesT = (a.To + Wino6Cfg::TH - 1) / Wino6Cfg::TH;
@@ -329,12 +334,16 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
         if (!attr_done) {
           (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino6_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     Wino6Cfg::LDS_BYTES);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino6_kernel<0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Wino6Cfg::LDS_BYTES);
           attr_done = true;
         }
       }
       g_wino6_launches.fetch_add(1);
+      if (h3) g_wino6h_launches.fetch_add(1);
       return timed(e, cls, flops, bytes, s, [&]() {
-        hipLaunchKernelGGL((conv_wino6_kernel<0, 1>), dim3((unsigned)nb), dim3(512), Wino6Cfg::LDS_BYTES, s, wa);
+        if (h3) hipLaunchKernelGGL((conv_wino6_kernel<0, 1, true>), dim3((unsigned)nb), dim3(512), Wino6Cfg::LDS_BYTES, s, wa);
+        else hipLaunchKernelGGL((conv_wino6_kernel<0, 1>), dim3((unsigned)nb), dim3(512), Wino6Cfg::LDS_BYTES, s, wa);
       });
     }
   }

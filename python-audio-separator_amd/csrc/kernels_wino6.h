@@ -124,14 +124,128 @@ inline void wino6_pack(const float *w, int cout, int cin, std::vector<uint32_t> 
   *nci_out = NCI;
 }
 
+// ---- fp16 x 3 arithmetic (template parameter H of the kernel; kernels_gemm3.h has the scheme): U scaled per (channel group, position,
+// 16-cout tile) by a power of two (largest |U| of the tile in [2^14, 2^15)) and split into TWO fp16 parts; 12 fragments per wave and stage
+// instead of 18; the exponents -- int32 [cg][wave][q][n] -- follow the fragments.
+inline uint16_t wino6_f16_rne(float f) {               // float -> IEEE half, round to nearest even (finite inputs below 65520)
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const int32_t ex = (int32_t)((x >> 23) & 0xffu) - 127 + 15;
+  uint32_t mant = x & 0x7fffffu;
+  if (((x >> 23) & 0xffu) == 0xffu) return (uint16_t)(sign | 0x7c00u | (mant ? 0x200u : 0u));
+  if (ex >= 31) return (uint16_t)(sign | 0x7c00u);
+  if (ex <= 0) {                                       // subnormal half (or zero)
+    if (ex < -10) return (uint16_t)sign;
+    mant |= 0x800000u;
+    const int shift = 14 - ex;                         // 14 .. 24
+    uint32_t m = mant >> shift;
+    const uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (m & 1u))) ++m;
+    return (uint16_t)(sign | m);
+  }
+  uint32_t m = mant >> 13;
+  const uint32_t rem = mant & 0x1fffu;
+  uint32_t e2 = (uint32_t)ex;
+  if (rem > 0x1000u || (rem == 0x1000u && (m & 1u))) {
+    if (++m == 0x400u) {
+      m = 0;
+      if (++e2 >= 31u) return (uint16_t)(sign | 0x7c00u);
+    }
+  }
+  return (uint16_t)(sign | (e2 << 10) | m);
+}
+inline float wino6_f16_f(uint16_t h) {
+  const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  const uint32_t ex = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  float f;
+  uint32_t u;
+  if (ex == 0) {
+    f = ldexpf((float)m, -24);                         // subnormal: m * 2^-24
+    memcpy(&u, &f, 4);
+    u |= sign;
+  } else if (ex == 31) {
+    u = sign | 0x7f800000u | (m << 13);
+  } else {
+    u = sign | ((ex - 15 + 127) << 23) | (m << 13);
+  }
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline void wino6_pack_h(const float *w, int cout, int cin, std::vector<uint32_t> &img, int *cg_out, int *nci_out) {
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const int CG = (cout + 47) / 48, NCI = (cin + 31) / 32;
+  const size_t cinp = (size_t)NCI * 32, coutp = (size_t)CG * 48;
+  std::vector<float> U((size_t)16 * coutp * cinp, 0.f);   // [pos][cout_pad][cin_pad]
+  auto Uat = [&](int pos, size_t co, size_t c) -> float & { return U[((size_t)pos * coutp + co) * cinp + c]; };
+  for (int co = 0; co < cout; ++co)
+    for (int c = 0; c < cin; ++c) {
+      const float *g = &w[((size_t)co * cin + c) * 9];
+      double t[4][3];
+      for (int a = 0; a < 4; ++a)
+        for (int j = 0; j < 3; ++j) t[a][j] = G[a][0] * g[0 * 3 + j] + G[a][1] * g[1 * 3 + j] + G[a][2] * g[2 * 3 + j];
+      for (int a = 0; a < 4; ++a)
+        for (int bb = 0; bb < 4; ++bb) {
+          double u = t[a][0] * G[bb][0] + t[a][1] * G[bb][1] + t[a][2] * G[bb][2];
+          if ((a == 2) != (bb == 2)) u = -u;
+          Uat(a * 4 + bb, co, c) = (float)u;
+        }
+    }
+  const size_t frag_u32 = (size_t)CG * NCI * 8 * 12 * 64 * 4;
+  img.assign(frag_u32 + (size_t)CG * 8 * 2 * 3, 0u);
+  for (int cg = 0; cg < CG; ++cg)
+    for (int wave = 0; wave < 8; ++wave)
+      for (int q = 0; q < 2; ++q)
+        for (int n = 0; n < 3; ++n) {
+          const int pos = (wave >> 1) * 4 + 2 * (wave & 1) + q;
+          float mx = 0.f;
+          for (int li = 0; li < 16; ++li)
+            for (size_t c = 0; c < cinp; ++c) mx = std::max(mx, std::fabs(Uat(pos, (size_t)cg * 48 + n * 16 + li, c)));
+          int ex = 0;
+          if (mx > 0.f) {
+            int fe;
+            (void)frexpf(mx, &fe);
+            ex = 15 - fe;                              // mx 2^ex in [2^14, 2^15)
+          }
+          img[frag_u32 + (((size_t)cg * 8 + wave) * 2 + q) * 3 + n] = (uint32_t)ex;
+          for (int ci = 0; ci < NCI; ++ci)
+            for (int lane = 0; lane < 64; ++lane) {
+              const size_t co = (size_t)cg * 48 + n * 16 + (lane & 15);
+              const size_t c0 = (size_t)ci * 32 + (lane >> 4) * 8;
+              uint16_t hh[8], ll[8];
+              for (int e = 0; e < 8; ++e) {
+                const float us = ldexpf(Uat(pos, co, c0 + e), ex);
+                hh[e] = wino6_f16_rne(us);
+                ll[e] = wino6_f16_rne(us - wino6_f16_f(hh[e]));
+              }
+              const size_t f = (((size_t)cg * NCI + ci) * 8 + wave) * 12 + (q * 3 + n) * 2;
+              uint32_t *dh = &img[(f * 64 + lane) * 4], *dl = &img[((f + 1) * 64 + lane) * 4];
+              for (int e = 0; e < 4; ++e) {
+                dh[e] = (uint32_t)hh[2 * e] | ((uint32_t)hh[2 * e + 1] << 16);
+                dl[e] = (uint32_t)ll[2 * e] | ((uint32_t)ll[2 * e + 1] << 16);
+              }
+            }
+        }
+  *cg_out = CG;
+  *nci_out = NCI;
+}
+
 // ABL (ASX_WINO6_ABL, measurement-only builds whose results are garbage): 1 = no LDS-DMA after the first stage, 2 = no patch
 // reads / input transform / split (operands from registers), 4 = no output exchange / stores, 8 = no weight loads after the first
 // stage, 16 = no MFMA
 // ONE = 1: one workgroup per ITEM (spatial tile, channel group), grid = 8 * ceil(S / 8) * CG, the CG groups of a tile consecutive on
 // one XCD (block b runs on XCD b % 8) so that the re-read of the planes hits that XCD's L2; no cross-item prefetch.
-template <int ABL, int PR, int ONE = 0>
+// H: fp16 x 3.  V gets ONE running exponent per (wave, tile row m): the wave-wide largest |V| of the 16 tiles x 2 positions x 32 channels
+// a tile row contributes to a stage (DPP reduction), dropping with two bits of headroom; the accumulators of that tile row are multiplied
+// by the exact power of two in front of the stage's MFMAs (1.0 almost always); the output exchange reads them back through
+// 2^-(e_V[m] + e_U[q][n]).
+template <int ABL, int PR, int ONE = 0, bool H = false>
 __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
   using CFG = Wino6Cfg;
+  static_assert(!H || ABL == 0, "the ablation builds exist for the bf16 x 6 arithmetic only");
+  constexpr int NPART = H ? 2 : 3;
+  constexpr int WF = 6 * NPART;                        // weight fragments per wave and stage
+  constexpr int WST = 8 * WF * 64;                     // u32x4 per (cg, stage)
   constexpr int IWA = CFG::IWA, C4 = CFG::C4, PS = CFG::PS, LP = CFG::LP, SLOTS = CFG::SLOTS, RAWF = CFG::RAWF;
 
   const int tid = threadIdx.x;
@@ -198,14 +312,14 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
   };
 
   // ---- weight fragments: L2 -> registers, 18 per stage ----
-  const u32x4 *wimg = reinterpret_cast<const u32x4 *>(a.wp) + (int64_t)wave * (18 * 64) + lane;
-  u32x4 wr[2][3][3];                                   // [q][n][part]
+  const u32x4 *wimg = reinterpret_cast<const u32x4 *>(a.wp) + (int64_t)wave * (WF * 64) + lane;
+  u32x4 wr[2][3][NPART];                               // [q][n][part]
   auto load_w = [&](int cg, int ci, int q) {
-    const u32x4 *src = wimg + ((int64_t)cg * a.NCI + ci) * CFG::WSTAGE_U4 + q * (9 * 64);
+    const u32x4 *src = wimg + ((int64_t)cg * a.NCI + ci) * WST + q * (3 * NPART * 64);
 #pragma unroll
     for (int n = 0; n < 3; ++n)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wr[q][n][p] = src[(n * 3 + p) * 64];
+      for (int p = 0; p < NPART; ++p) wr[q][n][p] = src[(n * NPART + p) * 64];
   };
 
   // patch base of this lane: plane 8 lk, patch row ra / rb of tile row 0, column LP + 1 + 2 li (8-byte aligned)
@@ -234,11 +348,13 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int n = 0; n < 3; ++n) acc[m][q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int em[4] = {200, 200, 200, 200};                  // H: running exponent of tile row m (wave-uniform)
 
     for (int ci = 0; ci < a.NCI; ++ci) {
-      // this stage's planes were requested a stage ago, followed (in order) only by the 18 weight loads of this stage and, across
-      // an item boundary, the previous item's output stores: at most 18 younger requests may be outstanding
-      asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      // this stage's planes were requested a stage ago, followed (in order) only by the 18 (H: 12) weight loads of this stage and, across
+      // an item boundary, the previous item's output stores: at most that many younger requests may be outstanding
+      if constexpr (H) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
       const float *raw = lds_f + ((ABL & 1) ? 0 : bufbase(gs & 1));
       const bool last = ci + 1 == a.NCI;
@@ -246,6 +362,7 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
       for (int m = 0; m < 4; ++m) {
         // ---- V = B^T d B for positions (ga, 2 pr), (ga, 2 pr + 1) of this lane's tile (row m, column li), channels 8 lk .. + 7 ----
         unsigned vh[2][4], vm[2][4], vl[2][4];
+        float hv0[4][2], hv1[4][2];                    // H: the tile row's sixteen transformed values, kept until its exponent is known
 #pragma unroll
         for (int cp = 0; cp < 4; ++cp) {
           float v0[2], v1[2];
@@ -274,13 +391,49 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
           if constexpr (ABL & 2) {
             vh[0][cp] = __float_as_uint(v0[0]); vm[0][cp] = __float_as_uint(v0[1]); vl[0][cp] = __float_as_uint(v1[0]);
             vh[1][cp] = __float_as_uint(v1[1]); vm[1][cp] = __float_as_uint(v0[0] + v1[1]); vl[1][cp] = __float_as_uint(v0[1] + v1[0]);
+          } else if constexpr (H) {
+            hv0[cp][0] = v0[0];
+            hv0[cp][1] = v0[1];
+            hv1[cp][0] = v1[0];
+            hv1[cp][1] = v1[1];
           } else {
             split3_pair(v0[0], v0[1], vh[0][cp], vm[0][cp], vl[0][cp]);
             split3_pair(v1[0], v1[1], vh[1][cp], vm[1][cp], vl[1][cp]);
           }
         }
+        if constexpr (H) {
+          float mx = 0.f;
+#pragma unroll
+          for (int cp = 0; cp < 4; ++cp)
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(hv0[cp][0]), fabsf(hv0[cp][1])), fmaxf(fabsf(hv1[cp][0]), fabsf(hv1[cp][1]))));
+          mx = wave_max64(mx);
+          const int need = __builtin_amdgcn_readfirstlane(f16_scale_exp(mx));
+          const int e_new = need < em[m] ? need - 2 : em[m];
+          const float fdev = __builtin_ldexpf(1.0f, e_new - em[m]);
+          em[m] = e_new;
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[m][q][n] *= fdev;
+#pragma unroll
+          for (int cp = 0; cp < 4; ++cp) {
+            split2h_pair(hv0[cp][0], hv0[cp][1], e_new, vh[0][cp], vl[0][cp]);
+            split2h_pair(hv1[cp][0], hv1[cp][1], e_new, vh[1][cp], vl[1][cp]);
+          }
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+          if constexpr (H) {
+            const f16x8 fh = __builtin_bit_cast(f16x8, (u32x4){vh[q][0], vh[q][1], vh[q][2], vh[q][3]});
+            const f16x8 fl = __builtin_bit_cast(f16x8, (u32x4){vl[q][0], vl[q][1], vl[q][2], vl[q][3]});
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[m][q][n] = ASX_MFMA_F16(fl, __builtin_bit_cast(f16x8, wr[q][n][0]), acc[m][q][n]);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[m][q][n] = ASX_MFMA_F16(fh, __builtin_bit_cast(f16x8, wr[q][n][NPART - 1]), acc[m][q][n]);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[m][q][n] = ASX_MFMA_F16(fh, __builtin_bit_cast(f16x8, wr[q][n][0]), acc[m][q][n]);
+          }
+          if constexpr (!H) {
           const bf16x8 ah = __builtin_bit_cast(bf16x8, (u32x4){vh[q][0], vh[q][1], vh[q][2], vh[q][3]});
           const bf16x8 am = __builtin_bit_cast(bf16x8, (u32x4){vm[q][0], vm[q][1], vm[q][2], vm[q][3]});
           const bf16x8 al = __builtin_bit_cast(bf16x8, (u32x4){vl[q][0], vl[q][1], vl[q][2], vl[q][3]});
@@ -293,7 +446,7 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
 #pragma unroll
             for (int n = 0; n < 3; ++n) acc[m][q][n] = ASX_MFMA_BF16(al, __builtin_bit_cast(bf16x8, wr[q][n][0]), acc[m][q][n]);
 #pragma unroll
-            for (int n = 0; n < 3; ++n) acc[m][q][n] = ASX_MFMA_BF16(ah, __builtin_bit_cast(bf16x8, wr[q][n][2]), acc[m][q][n]);
+            for (int n = 0; n < 3; ++n) acc[m][q][n] = ASX_MFMA_BF16(ah, __builtin_bit_cast(bf16x8, wr[q][n][NPART - 1]), acc[m][q][n]);
 #pragma unroll
             for (int n = 0; n < 3; ++n) acc[m][q][n] = ASX_MFMA_BF16(am, __builtin_bit_cast(bf16x8, wr[q][n][1]), acc[m][q][n]);
 #pragma unroll
@@ -302,6 +455,7 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
             for (int n = 0; n < 3; ++n) acc[m][q][n] = ASX_MFMA_BF16(ah, __builtin_bit_cast(bf16x8, wr[q][n][1]), acc[m][q][n]);
 #pragma unroll
             for (int n = 0; n < 3; ++n) acc[m][q][n] = ASX_MFMA_BF16(ah, __builtin_bit_cast(bf16x8, wr[q][n][0]), acc[m][q][n]);
+          }
           }
           if (m == 3 && (!last || has_next)) {
             // the fragments of position q are dead: fetch the next stage's (of this item, or the first of the next item)
@@ -348,6 +502,21 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
       float *yb = a.y + (int64_t)b * a.y_bstride;
       const float *rbp = a.res ? a.res + (int64_t)b * a.aux_bstride : nullptr;
       float *zx = lds_f + (((gs - 1) & 1) ? RAWF : 0);   // last stage's buffer + the spare
+      int ew[2][3] = {{0, 0, 0}, {0, 0, 0}};             // H: exponents of this wave's six U tiles (scalar loads, as the bias below)
+      if constexpr (H) {
+        const uint32_t *ep = reinterpret_cast<const uint32_t *>(a.wp) + (int64_t)a.CG * a.NCI * WST * 4 + ((int64_t)cg * 8 + wave) * 6;
+        const uint64_t epv = reinterpret_cast<uint64_t>(ep);
+        const uint32_t elo = __builtin_amdgcn_readfirstlane((uint32_t)epv), ehi = __builtin_amdgcn_readfirstlane((uint32_t)(epv >> 32));
+        const uint64_t eps = ((uint64_t)ehi << 32) | elo;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) {
+            int v;
+            asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(eps), "n"((q * 3 + n) * 4) : "memory");
+            ew[q][n] = v;
+          }
+      }
 #pragma unroll
       for (int n = 0; n < 3; ++n) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // raw planes / the previous round's exchange image are dead
@@ -355,7 +524,11 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float m0 = acc[m][0][n][r], m1 = acc[m][1][n][r];
+            float m0 = acc[m][0][n][r], m1 = acc[m][1][n][r];
+            if constexpr (H) {                         // back to the operands' own scale (exact)
+              m0 = __builtin_ldexpf(m0, -(em[m] + ew[0][n]));
+              m1 = __builtin_ldexpf(m1, -(em[m] + ew[1][n]));
+            }
             f32x2 z;
             z.x = pr ? m0 : m0 + m1;
             z.y = pr ? -m0 - m1 : m1;
@@ -415,13 +588,13 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
   }
 }
 
-template <int ABL = 0, int ONE = 0>
+template <int ABL = 0, int ONE = 0, bool H = false>
 __global__ __launch_bounds__(512, 1) void conv_wino6_kernel(ConvArgs a) {
   extern __shared__ float lds_f[];
   // the column pair of a wave's positions decides which transform columns it forms: two instantiations of the body, chosen by a
   // wave-uniform branch (both run the same barrier sequence)
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino6_body<ABL, 1, ONE>(a, lds_f);
-  else wino6_body<ABL, 0, ONE>(a, lds_f);
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino6_body<ABL, 1, ONE, H>(a, lds_f);
+  else wino6_body<ABL, 0, ONE, H>(a, lds_f);
 }
 
 }  // namespace asx

@@ -861,14 +861,18 @@ def test_conv3x3_winograd_stationary(A, B, cin, cout, T, F, variant=1, relu=True
 
 @pytest.mark.parametrize("B,cin,cout,T,F,relu", [(1, 144, 144, 8, 96, True), (2, 96, 96, 10, 44, True), (1, 288, 288, 8, 96, True), (1, 64, 20, 16, 64, False),
                                                  (1, 80, 80, 9, 36, True), (3, 192, 192, 5, 33 * 4, True), (1, 240, 240, 16, 192, True), (2, 160, 50, 3, 8, False)])
-def test_conv3x3_winograd_bf16x6(A, B, cin, cout, T, F, relu):
+@pytest.mark.parametrize("arith", ARITH)
+def test_conv3x3_winograd_bf16x6(A, B, cin, cout, T, F, relu, arith):
     """conv_wino6_kernel (csrc/kernels_wino6.h, round 5: the default for 3x3 TFC layers with >= 144 input channels): Winograd
-    F(2x2,3x3) with the sixteen transform-domain GEMMs as six bf16 MFMA products on exactly split operands.  Against torch, against
-    conv_wino3_kernel on the same layer, with proof of which kernel ran; ragged planes, channel counts off the 32 / 48 grids, border
-    tiles, several batch items."""
+    F(2x2,3x3) with the sixteen transform-domain GEMMs on split operands -- six bf16 MFMA products on exact three-way splits, or
+    (gemm_f16x3, the default) three fp16 products on block-scaled two-way splits.  Against torch, against conv_wino3_kernel on the same
+    layer, with proof of which kernel and which arithmetic ran; ragged planes, channel counts off the 32 / 48 grids, border tiles,
+    several batch items."""
     eng = A.Engine(small_cfg(A))
     assert eng.option("winograd") == 3 and eng.option("winograd_bf16x6") == 144
     eng.set_option("winograd_bf16x6", 64)
+    eng.set_option("gemm_f16x3", 1 if arith == "f16x3" else 0)
+    h0 = eng.counter("wino6h_launches")
     rng = np.random.default_rng(cin * 1000 + cout + T + 13)
     x = rng.standard_normal((B, cin, T, F)).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
@@ -876,6 +880,9 @@ def test_conv3x3_winograd_bf16x6(A, B, cin, cout, T, F, relu):
     n0 = eng.counter("wino6_launches")
     y = eng.op_conv("conv3x3", x, w, b, relu=relu)
     assert eng.counter("wino6_launches") == n0 + 1, "conv_wino6_kernel did not run"
+    assert eng.counter("wino6h_launches") - h0 == (1 if arith == "f16x3" else 0), "the other arithmetic of conv_wino6_kernel ran"
+    assert np.array_equal(y, eng.op_conv("conv3x3", x, w, b, relu=relu)), "not deterministic"
+    n0 += 1
     ref = _torch_ref("conv3x3", x, w, b, relu=relu)
     assert np.isfinite(y).all(), "unwritten (NaN canary) output elements"
     assert max_abs(y, ref) < 5e-5, (max_abs(y, ref), rel_rms(y, ref))
@@ -903,14 +910,19 @@ def _hq3_excerpt():
     return _HQ3_EXCERPT
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 30, 36, 306])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 30, 36, 306, 366])
 def test_winograd_hq3_excerpt_vs_oracle(A, mode):
     # 3 = the default (conv_wino3_kernel on levels 0 / 1, conv_wino6_kernel from 144 channels); 30 = the weight-stationary kernel on the
-    # two outer levels; 36 = conv_wino6_kernel on every level it can take (>= 64 channels: level 1 too); 306 = conv_wino3_kernel everywhere
+    # two outer levels; 36 = conv_wino6_kernel on every level it can take (>= 64 channels: level 1 too); 306 = conv_wino3_kernel everywhere;
+    # 366 = as 36 with every split-operand kernel on the bf16 x 6 arithmetic (gemm_f16x3 = 0; the default is fp16 x 3)
     c = _hq3_excerpt()
     d, sd, mix, ref = c["d"], c["sd"], c["mix"], c["ref"]
     eng = A.Engine(A.MDXConfig(max_batch=2))
-    want6 = {3: 21, 36: 27, 306: 0}.get(mode)          # 3x3 launches per net pass on conv_wino6_kernel (6 per level, 3 at the bottleneck)
+    want6 = {3: 21, 36: 27, 306: 0, 366: 27}.get(mode)  # 3x3 launches per net pass on conv_wino6_kernel (6 per level, 3 at the bottleneck)
+    h3 = mode != 366
+    if mode == 366:
+        mode = 36
+        eng.set_option("gemm_f16x3", 0)
     if mode == 30:
         mode = 3
         eng.set_option("winograd_stationary", 1)
@@ -923,11 +935,12 @@ def test_winograd_hq3_excerpt_vs_oracle(A, mode):
     eng.set_option("winograd", mode)
     assert eng.option("winograd") == mode
     eng.load_net(A.NetConfig(), A.fold_convtdf_state(sd, d.num_blocks, d.l))
-    n6 = eng.counter("wino6_launches")
+    n6, n6h = eng.counter("wino6_launches"), eng.counter("wino6h_launches")
     got = eng.demix(mix)
     if want6 is not None:
         passes = -(-eng.plan(mix.shape[1])["n_chunks"] // 2)        # max_batch = 2
         assert eng.counter("wino6_launches") - n6 == want6 * passes, (eng.counter("wino6_launches") - n6, want6, passes)
+        assert eng.counter("wino6h_launches") - n6h == (want6 * passes if h3 else 0), (eng.counter("wino6h_launches") - n6h, want6, passes, h3)
     e = rel_rms(got, ref)
     print("HQ_3 excerpt rel-RMS (winograd):", e)
     assert e < TOL_STEM, e

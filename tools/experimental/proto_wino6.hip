@@ -49,9 +49,20 @@ static void pack_wu3(const std::vector<float> &w, int cout, int cin, std::vector
 }
 
 static int g_one = 0;
+static int g_h = 0;   // 1: the fp16 x 3 arithmetic (argv[7]; one-workgroup-per-item form only)
 template <int ABL>
 static void launch6(const ConvArgs &a, int nb) {
   static bool done = false;
+  if (g_h) {
+    static bool hdone = false;
+    if (!hdone) {
+      CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino6_kernel<0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Wino6Cfg::LDS_BYTES));
+      hdone = true;
+    }
+    const int S = a.tilesT * a.tilesF * a.B;
+    hipLaunchKernelGGL((conv_wino6_kernel<0, 1, true>), dim3(((S + 7) / 8) * 8 * a.CG), dim3(512), Wino6Cfg::LDS_BYTES, 0, a);
+    return;
+  }
   if (!done) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino6_kernel<ABL, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Wino6Cfg::LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino6_kernel<ABL, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Wino6Cfg::LDS_BYTES));
@@ -101,7 +112,8 @@ static void run_shape(const Shape &sh, int abl, int reps) {
   CK(hipMemcpy(dwu3, wu3.data(), wu3.size() * 4, hipMemcpyHostToDevice));
   std::vector<uint32_t> w6;
   int cg6, nci6;
-  wino6_pack(hw.data(), Cout, Cin, w6, &cg6, &nci6);
+  if (g_h) wino6_pack_h(hw.data(), Cout, Cin, w6, &cg6, &nci6);
+  else wino6_pack(hw.data(), Cout, Cin, w6, &cg6, &nci6);
   CK(hipMalloc(&dw6, w6.size() * 4));
   CK(hipMemcpy(dw6, w6.data(), w6.size() * 4, hipMemcpyHostToDevice));
 
@@ -242,6 +254,7 @@ int main(int argc, char **argv) {
   g_nt = argc > 4 ? atoi(argv[4]) : 0;
   g_grid = argc > 5 ? atoi(argv[5]) : 256;
   g_one = argc > 6 ? atoi(argv[6]) : 0;
+  g_h = argc > 7 ? atoi(argv[7]) : 0;
   std::vector<Shape> shapes = {
       {"one wg 48", 1, 48, 48, 8, 32, ACT_NONE, 0, 1},
       {"multi wg 40", 1, 40, 20, 16, 64, ACT_NONE, 0, 1},

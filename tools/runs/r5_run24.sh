@@ -1,7 +1,7 @@
 #!/bin/bash
 # attention on the fp16 x 3 arithmetic inside the engine: sibling lines with the option off / on in one call, then the whole GPU suite
 set -u
-O=$GRAFT_REPO_ROOT/gpurun_out/r5x
+O=$GRAFT_REPO_ROOT/gpurun_out/${1:-r5x}
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 for h in 0 1; do
