@@ -134,14 +134,16 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def per_level_table(launch_recs, g, wino, num_blocks=11, bf16x6=True, wino6_min_c=0):
+def per_level_table(launch_recs, g, wino, num_blocks=11, bf16x6=True, wino6_min_c=0, nprod=6):
     """The 3x3 TFC convs and the TDF row GEMMs of one profiled pass, grouped by U-Net level (VERDICT r4 next #2c).  A conv's level
     follows from its own algorithmic figures -- 3x3 conv c -> c over a plane P: flops = 18 c^2 P, bytes = 8 c P, so
     c = 4 flops / (9 bytes), level = c / g - 1; the 2 x num_blocks TDF launches come in the net's block order (encoder levels
     0 .. n-1, bottleneck n, decoder n-1 .. 0, two linears each).  Per level: launches, summed and average milliseconds, the
     algorithmic rate and the fraction of the matrix peak the launches EXECUTE (Winograd F(2x2,3x3): 4/9 of the direct
-    convolution's FLOPs on the fp32 pipe; bf16 x 6 row GEMM: six bf16 products per multiply-add against the bf16 peak), and the time
-    the launch's algorithmic bytes take at the 6.29 TB/s a device copy reaches."""
+    convolution's FLOPs on the fp32 pipe; split-operand kernels: `nprod` 16-bit products per multiply-add -- six on the bf16 x 6
+    arithmetic, three on fp16 x 3 -- against the 16-bit matrix peak), and the time the launch's algorithmic bytes take at the
+    6.29 TB/s a device copy reaches."""
+    arith = "fp16 x 3" if nprod == 3 else "bf16 x 6"
     def add(tab, key, ms, flops, nbytes):
         r = tab.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
         r["launches"] += 1
@@ -169,10 +171,10 @@ def per_level_table(launch_recs, g, wino, num_blocks=11, bf16x6=True, wino6_min_
                "hbm_floor_ms_per_launch": round(r["bytes"] / r["launches"] / 6.29e12 * 1e3, 3),
                "flops": r["flops"], "bytes": r["bytes"]}
         if wino and bf16x6 and wino6_min_c > 0 and c >= wino6_min_c:
-            # conv_wino6_kernel: 4/9 of the direct FLOPs as six bf16 products each, input channels padded to whole 32-channel stages
+            # conv_wino6_kernel: 4/9 of the direct FLOPs as `nprod` 16-bit products each, input channels padded to whole 32-channel stages
             pad = (-(-c // 32) * 32) / c
-            ent.update({"kernel": "conv_wino6_kernel (Winograd F(2x2,3x3), bf16 x 6)", "executed_tflops_bf16": round(tf * exf * 6 * pad, 1),
-                        "frac": round(tf * exf * 6 * pad / PEAK_BF16_MFMA_TFLOPS, 4), "peak": PEAK_BF16_MFMA_TFLOPS})
+            ent.update({"kernel": f"conv_wino6_kernel (Winograd F(2x2,3x3), {arith})", "executed_tflops_bf16": round(tf * exf * nprod * pad, 1),
+                        "frac": round(tf * exf * nprod * pad / PEAK_BF16_MFMA_TFLOPS, 4), "peak": PEAK_BF16_MFMA_TFLOPS})
         else:
             ent.update({"kernel": "conv_wino3_kernel (Winograd F(2x2,3x3), fp32 MFMA)" if wino else "conv_dma_kernel<3,3,...> (direct, fp32 MFMA)",
                         "executed_tflops": round(tf * exf, 1), "frac": round(tf * exf / PEAK_FP32_MFMA_TFLOPS, 4), "peak": PEAK_FP32_MFMA_TFLOPS})
@@ -184,7 +186,7 @@ def per_level_table(launch_recs, g, wino, num_blocks=11, bf16x6=True, wino6_min_
                "algorithmic_gb_per_launch": round(r["bytes"] / r["launches"] / 1e9, 3),
                "hbm_floor_ms_per_launch": round(r["bytes"] / r["launches"] / 6.29e12 * 1e3, 3)}
         if bf16x6:
-            ent.update({"executed_tflops_bf16": round(6 * tf, 1), "frac": round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4)})
+            ent.update({"executed_tflops_bf16": round(nprod * tf, 1), "frac": round(nprod * tf / PEAK_BF16_MFMA_TFLOPS, 4), "arithmetic": arith})
         else:
             ent["frac"] = round(tf / PEAK_FP32_MFMA_TFLOPS, 4)
         out["tdf"][f"L{lvl}.{'F_to_F8' if which == 0 else 'F8_to_F'}"] = ent
@@ -390,7 +392,7 @@ def main():
         wino = eng.option("winograd") > 0
         x6 = eng.option("gemm_bf16x6") > 0
         w6c = eng.option("winograd_bf16x6") if (eng.option("winograd") == 3 and x6) else 0
-        per_level = per_level_table(launch_recs, d.g, wino, d.num_blocks, x6, w6c)
+        per_level = per_level_table(launch_recs, d.g, wino, d.num_blocks, x6, w6c, 3 if (x6 and eng.option("gemm_f16x3") > 0) else 6)
         # the dominant kernel: conv_wino3_kernel (fp32 MFMA) on the levels below the bf16 x 6 threshold -- levels 0 / 1 of the HQ_3 net,
         # ~100 of the ~139 ms the 3x3 class takes; the deeper levels run conv_wino6_kernel and are listed per level
         dom = [v for v in per_level["conv3x3"].values() if "wino6" not in v["kernel"]]
@@ -488,7 +490,7 @@ def main():
             # what "f32" means inside: nothing runs in a reduced-precision mode
             "arithmetic": {"io": "float32",
                            "conv3x3": "Winograd F(2x2,3x3): fp32 MFMA (exact fma chains) below the winograd_bf16x6 channel count (default 144), "
-                                      "six bf16 MFMA products on exactly split operands from there up (csrc/kernels_wino6.h)",
+                                      "split operands on the 16-bit pipe from there up (csrc/kernels_wino6.h; same arithmetic as row_gemm)",
                            "attention": ("as row_gemm (one exponent per query, per 64-key tile of K, a running one per tile of V, none for the probabilities)"
                                          if (eng.option("gemm_bf16x6") > 0 and eng.option("gemm_f16x3") > 0) else
                                          "six bf16 products on exactly split operands" if eng.option("gemm_bf16x6") > 0 else "fp32 MFMA"),
