@@ -82,7 +82,7 @@ struct ConvLayer {
   DevBuf gn_w, gn_b;  // GroupNorm(2, cout) affine behind this conv (asx_net_config.norm == 1), else empty
   DevBuf wu6;      // conv_wino6_kernel (kernels_wino6.h): U split three ways into bf16, MFMA-fragment order [CG48][NCI32][wave 8][18][lane 64][4 x u32]
   int wu6_nci = 0; // 32-channel stages of that image (0 = not packed: Cin < 64)
-  DevBuf wu6h;     // the same for the fp16 x 3 arithmetic (wino6_pack_h): two fp16 parts per U, scaled per (group, position, 16-cout tile); exponents behind the fragments
+  DevBuf wu6h;     // the same for the fp16 x 3 arithmetic (wino6_pack_h): two fp16 parts per U, scaled per (position, cout); exponents behind the fragments
 };
 
 struct TdfLayer {
@@ -115,7 +115,7 @@ struct EnsCtx;
 struct W3Entry {
   const float *w;
   int N, K, cin;                                       // cin > 0: the (tap, chunk)-padded image of the GATHER mode, else 0
-  int kind;                                            // 0: bf16 x 3 parts; 1: fp16 x 2 parts + one exponent per 16-column tile
+  int kind;                                            // 0: bf16 x 3 parts; 1: fp16 x 2 parts + one exponent per group of four output columns
   void *img;
 };
 

@@ -614,7 +614,7 @@ static const u32x4 *w3_image(asx_engine *e, const float *w, int N, int K, hipStr
   const int nst = cin > 0 ? (K / cin) * ((cin + 31) / 32) : 0;
   const int ntiles = (N + 15) / 16, nk = cin > 0 ? ((nst + 1) & ~1) : ((K + 63) / 64) * 2;   // an even number of 32-wide stages (zero padded)
   W3Entry en{w, N, K, cin, kind, nullptr};
-  const size_t bytes = kind == 1 ? (size_t)ntiles * nk * 2 * 1024 + (size_t)ntiles * 4 : (size_t)ntiles * nk * 3 * 1024;
+  const size_t bytes = kind == 1 ? (size_t)ntiles * nk * 2 * 1024 + (size_t)ntiles * 16 : (size_t)ntiles * nk * 3 * 1024;   // kind 1: + four exponents per tile
   if (hipMalloc(&en.img, bytes) != hipSuccess) return nullptr;
   const int64_t total = (int64_t)ntiles * nk * 64;
   if (kind == 1)

@@ -72,12 +72,12 @@ __device__ __forceinline__ void split3_oct(const f32x4 &a, const f32x4 &b, u32x4
 // the bf16 x 6 form's 2^-24, but three accumulator roundings per k step instead of six: against a float64 GEMM the results measured
 // CLOSER than the bf16 x 6 kernel's on every shape of tools/proto_gemm3.hip (6.3e-7 against 8.5e-7 at K = 3072), both closer than the
 // fp32-MFMA kernel (tests/test_gpu_parity.py::test_rowgemm_bf16x6_vs_float64[f16x3], ::test_rowgemm_f16x3_block_exponent).
-// Scaling.  W: one exponent per 16-column fragment tile, chosen by the image builder (largest |w| of the tile in [2^14, 2^15)), stored
-// behind the fragments.  x: one RUNNING exponent PER ROW, found on line: the four lanes that fetch a row's 32 floats of a stage reduce
+// Scaling.  W: one exponent per group of FOUR output columns (the four a lane of the accumulator layout owns: free to apply), chosen by
+// the image builder (largest |w| of the group in [2^14, 2^15)), stored behind the fragments.  x: one RUNNING exponent PER ROW, found on line: the four lanes that fetch a row's 32 floats of a stage reduce
 // their largest |x| (two DPP steps) right before the split; when it would pass 2^15 under the row's exponent, the exponent drops (two
 // bits of headroom) and the drop goes through a small LDS table to the MFMA side, which multiplies that row's accumulators by the exact
 // power of two before the next stage's products arrive -- rare after a row's first stages, free when nothing changed (x 1.0).  The
-// epilogue multiplies every accumulator by 2^-(e_x[row] + e_w[tile]) (exact) and continues as the bf16 x 6 kernel does.  A row never
+// epilogue multiplies every accumulator by 2^-(e_x[row] + e_w[column group]) (exact) and continues as the bf16 x 6 kernel does.  A row never
 // sees another row's magnitude: an Inf / NaN row poisons itself only, rows 2^100 apart in one tile keep their own precision.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -197,24 +197,33 @@ __global__ __launch_bounds__(256) void w3_split_kernel(const float *__restrict__
   o[128] = l;
 }
 
-// fp16 x 3 image: img[((nt * nk + ks) * 2 + part) * 64 + lane], same fragment order, every 16-row tile scaled by 2^e[nt] with its
-// largest |w| in [2^14, 2^15); the int32 exponents e[ntiles] follow the fragments (at img + ntiles * nk * 128).  One workgroup per tile.
+// fp16 x 3 image: img[((nt * nk + ks) * 2 + part) * 64 + lane], same fragment order.  Every group of FOUR rows of a 16-row tile (the
+// four output columns one lane of the GEMM owns: accumulator layout) is scaled by its own 2^e, the group's largest |w| in
+// [2^14, 2^15): an output channel never shares an exponent with more than three neighbours (weights with a folded normalisation can
+// differ by orders of magnitude from channel to channel).  The int32 exponents e[ntiles][4] follow the fragments (at img + ntiles *
+// nk * 128).  One workgroup per tile; a thread's items all belong to ONE row (lane & 15 is fixed by tid).
 __global__ __launch_bounds__(256) void w3h_split_kernel(const float *__restrict__ w, u32x4 *__restrict__ img, int N, int K, int ntiles,
                                                         int cin = 0, int nst = 0) {
   const int nk = cin > 0 ? ((nst + 1) & ~1) : ((K + 63) >> 6) * 2;
   const int nt = blockIdx.x, tid = threadIdx.x;
-  __shared__ float red[4];
+  __shared__ float rowmax[256];
+  __shared__ int gexp[4];
   float m = 0.f;
   for (int it = tid; it < nk * 64; it += 256) {
     f32x4 a, b;
     w3_fetch(w, N, K, cin, nst, nt, it >> 6, it & 63, a, b);
     m = fmaxf(m, absmax_oct_finite(a, b));
   }
-  m = wave_max64(m);
-  if ((tid & 63) == 0) red[tid >> 6] = m;
+  rowmax[tid] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const int e = m > 0.f ? f16_scale_exp(m) : 0;
+  if (tid < 4) {
+    float g = 0.f;
+    for (int t = 0; t < 256; ++t)
+      if (((t & 15) >> 2) == tid) g = fmaxf(g, rowmax[t]);
+    gexp[tid] = g > 0.f ? f16_scale_exp(g) : 0;
+  }
+  __syncthreads();
+  const int e = gexp[(tid & 15) >> 2];
   for (int it = tid; it < nk * 64; it += 256) {
     f32x4 a, b;
     w3_fetch(w, N, K, cin, nst, nt, it >> 6, it & 63, a, b);
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256) void w3h_split_kernel(const float *__restrict_
     o[0] = h;
     o[64] = l;
   }
-  if (tid == 0) reinterpret_cast<int *>(img + (int64_t)ntiles * nk * 128)[nt] = e;
+  if (tid < 4) reinterpret_cast<int *>(img + (int64_t)ntiles * nk * 128)[nt * 4 + tid] = gexp[tid];
 }
 
 template <int V>
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
       }
       stage_h(IntC<0>{}, IntC<1>{}, ks);
       stage_h(IntC<1>{}, IntC<2>{}, ks + 1);
-      // back to the operands' own scale: 2^-(e_x[row] + e_w[column tile]), exact
+      // back to the operands' own scale: 2^-(e_x[row] + e_w[this lane's four columns]), exact
       const int *wexp = reinterpret_cast<const int *>(w3 + (int64_t)ntiles * nk * 128);
       int ex[MREP];
       read_tab(ex_tab, ex);                            // written before the last barrier (the last split is in stage nk - 2)
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
       for (int n = 0; n < NREP; ++n) {
         int nt = (n0 >> 4) + wave * NREP + n;
         nt = nt < ntiles ? nt : ntiles - 1;
-        const int ew = __builtin_amdgcn_readfirstlane(wexp[nt]);
+        const int ew = wexp[nt * 4 + lk];
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
           ldexp4_inplace(acc[n][m], -(ex[m] + ew));

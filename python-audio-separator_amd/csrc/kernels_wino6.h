@@ -124,9 +124,10 @@ inline void wino6_pack(const float *w, int cout, int cin, std::vector<uint32_t> 
   *nci_out = NCI;
 }
 
-// ---- fp16 x 3 arithmetic (template parameter H of the kernel; kernels_gemm3.h has the scheme): U scaled per (channel group, position,
-// 16-cout tile) by a power of two (largest |U| of the tile in [2^14, 2^15)) and split into TWO fp16 parts; 12 fragments per wave and stage
-// instead of 18; the exponents -- int32 [cg][wave][q][n] -- follow the fragments.
+// ---- fp16 x 3 arithmetic (template parameter H of the kernel; kernels_gemm3.h has the scheme): U scaled per (position, OUTPUT CHANNEL) by a
+// power of two (largest |U| over the input channels in [2^14, 2^15): the BatchNorm folded into these weights can make neighbouring channels
+// differ by orders of magnitude) and split into TWO fp16 parts; 12 fragments per wave and stage instead of 18; the exponents -- int32
+// [cg][wave][q][48 couts] -- follow the fragments (a lane of the accumulator layout owns one cout: applying them is free).
 inline uint16_t wino6_f16_rne(float f) {               // float -> IEEE half, round to nearest even (finite inputs below 65520)
   uint32_t x;
   memcpy(&x, &f, 4);
@@ -192,26 +193,29 @@ inline void wino6_pack_h(const float *w, int cout, int cin, std::vector<uint32_t
         }
     }
   const size_t frag_u32 = (size_t)CG * NCI * 8 * 12 * 64 * 4;
-  img.assign(frag_u32 + (size_t)CG * 8 * 2 * 3, 0u);
+  img.assign(frag_u32 + (size_t)CG * 8 * 2 * 48, 0u);
   for (int cg = 0; cg < CG; ++cg)
     for (int wave = 0; wave < 8; ++wave)
       for (int q = 0; q < 2; ++q)
         for (int n = 0; n < 3; ++n) {
           const int pos = (wave >> 1) * 4 + 2 * (wave & 1) + q;
-          float mx = 0.f;
-          for (int li = 0; li < 16; ++li)
+          int exs[16];
+          for (int li = 0; li < 16; ++li) {
+            float mx = 0.f;
             for (size_t c = 0; c < cinp; ++c) mx = std::max(mx, std::fabs(Uat(pos, (size_t)cg * 48 + n * 16 + li, c)));
-          int ex = 0;
-          if (mx > 0.f) {
-            int fe;
-            (void)frexpf(mx, &fe);
-            ex = 15 - fe;                              // mx 2^ex in [2^14, 2^15)
+            exs[li] = 0;
+            if (mx > 0.f) {
+              int fe;
+              (void)frexpf(mx, &fe);
+              exs[li] = 15 - fe;                       // mx 2^ex in [2^14, 2^15)
+            }
+            img[frag_u32 + (((size_t)cg * 8 + wave) * 2 + q) * 48 + n * 16 + li] = (uint32_t)exs[li];
           }
-          img[frag_u32 + (((size_t)cg * 8 + wave) * 2 + q) * 3 + n] = (uint32_t)ex;
           for (int ci = 0; ci < NCI; ++ci)
             for (int lane = 0; lane < 64; ++lane) {
               const size_t co = (size_t)cg * 48 + n * 16 + (lane & 15);
               const size_t c0 = (size_t)ci * 32 + (lane >> 4) * 8;
+              const int ex = exs[lane & 15];
               uint16_t hh[8], ll[8];
               for (int e = 0; e < 8; ++e) {
                 const float us = ldexpf(Uat(pos, co, c0 + e), ex);
@@ -238,7 +242,7 @@ inline void wino6_pack_h(const float *w, int cout, int cin, std::vector<uint32_t
 // H: fp16 x 3.  V gets ONE running exponent per (wave, tile row m): the wave-wide largest |V| of the 16 tiles x 2 positions x 32 channels
 // a tile row contributes to a stage (DPP reduction), dropping with two bits of headroom; the accumulators of that tile row are multiplied
 // by the exact power of two in front of the stage's MFMAs (1.0 almost always); the output exchange reads them back through
-// 2^-(e_V[m] + e_U[q][n]).
+// 2^-(e_V[m] + e_U[q][cout of the lane]).
 template <int ABL, int PR, int ONE = 0, bool H = false>
 __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
   using CFG = Wino6Cfg;
@@ -502,20 +506,15 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
       float *yb = a.y + (int64_t)b * a.y_bstride;
       const float *rbp = a.res ? a.res + (int64_t)b * a.aux_bstride : nullptr;
       float *zx = lds_f + (((gs - 1) & 1) ? RAWF : 0);   // last stage's buffer + the spare
-      int ew[2][3] = {{0, 0, 0}, {0, 0, 0}};             // H: exponents of this wave's six U tiles (scalar loads, as the bias below)
+      int ew[2][3] = {{0, 0, 0}, {0, 0, 0}};             // H: exponents of this LANE's couts (li) under the wave's two positions
       if constexpr (H) {
-        const uint32_t *ep = reinterpret_cast<const uint32_t *>(a.wp) + (int64_t)a.CG * a.NCI * WST * 4 + ((int64_t)cg * 8 + wave) * 6;
-        const uint64_t epv = reinterpret_cast<uint64_t>(ep);
-        const uint32_t elo = __builtin_amdgcn_readfirstlane((uint32_t)epv), ehi = __builtin_amdgcn_readfirstlane((uint32_t)(epv >> 32));
-        const uint64_t eps = ((uint64_t)ehi << 32) | elo;
+        // vector loads: fine in the one-workgroup-per-item form (nothing of a next item is in flight); the persistent forms of the
+        // harness would see the `vmcnt(0)` these bring drain their prefetch
+        const int *ep = reinterpret_cast<const int *>(a.wp) + (int64_t)a.CG * a.NCI * WST * 4 + ((int64_t)cg * 8 + wave) * 96 + li;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-          for (int n = 0; n < 3; ++n) {
-            int v;
-            asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(eps), "n"((q * 3 + n) * 4) : "memory");
-            ew[q][n] = v;
-          }
+          for (int n = 0; n < 3; ++n) ew[q][n] = ep[q * 48 + n * 16];
       }
 #pragma unroll
       for (int n = 0; n < 3; ++n) {

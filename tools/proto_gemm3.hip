@@ -102,7 +102,7 @@ static double run_shape(const Shape &sh, int abl, int reps) {
   CK(hipMalloc(&dy2, (size_t)M * N * 4));
   CK(hipMalloc(&dy3, (size_t)M * N * 4));
   const int ntiles = (N + 15) / 16, nk = ((K + 63) / 64) * 2;
-  CK(hipMalloc(&dw3, (size_t)ntiles * nk * 3 * 1024 + (size_t)ntiles * 4));
+  CK(hipMalloc(&dw3, (size_t)ntiles * nk * 3 * 1024 + (size_t)ntiles * 16));
   for (int64_t r0 = 0; r0 < M; r0 += HB) {
     const int64_t n = std::min<int64_t>(HB, M - r0);
     CK(hipMemcpy(dx + r0 * K, hx.data(), (size_t)n * K * 4, hipMemcpyHostToDevice));
