@@ -549,13 +549,13 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
  * 48 output channels) and the attention kernels of the Roformer / HTDemucs transformers (attention6_kernel, mha6_kernel);
  * 0 = the fp32-MFMA kernels (csrc/kernels_gemm2.h, kernels_halo.h, kernels_ht.h, kernels_rof.h) everywhere.
  * "gemm_f16x3" (also ASX_GEMM_F16X3): which split the row GEMMs and GATHER-mode convolutions above use while "gemm_bf16x6" is on.
- * 1 (default) = fp16 x 3: every row of x scaled by its own running power of two, every 16-column tile of W by one chosen at load, both
+ * 1 (default) = fp16 x 3: every row of x scaled by its own running power of two, every group of four output columns of W by one chosen at load, both
  * split into TWO fp16 parts (11 + 11 significand bits), three fp16 MFMA products per multiply-add instead of six, the dropped term
  * below 2^-22 of a product; elements more than 2^14 below their row's (tile's) largest keep an absolute error of 2^-37 of that
  * largest instead of a relative one.  Measured against a float64 GEMM: closer than the bf16 x 6 form on every shape (fewer accumulator
  * roundings), 1.1-1.5x its speed (profiles/r05_gemm_f16x3.txt).  The attention kernels follow the same switch (one exponent per query,
  * per 64-key tile of K, a running one per tile of V, none for the probabilities; 1.16-1.31x, profiles/r05_attention_f16x3.txt).
- * conv_wino6_kernel too (U scaled per (channel group, position, 16-cout tile) at load, V by one running exponent per (wave, tile row);
+ * conv_wino6_kernel too (U scaled per (position, output channel) at load, V by one running exponent per (wave, tile row);
  * 1.04-1.11x, profiles/r05_wino6_f16x3.txt).  0 = bf16 x 6 (exact three-way split) in all of them.
  * The split weight images these kernels read are built on the FIRST forward after a load (one small kernel + one stream
  * synchronise per weight tensor) and belong to the engine: they are freed only when this engine's weights are re-loaded or the engine

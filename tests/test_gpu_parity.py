@@ -264,13 +264,13 @@ def test_rowgemm_bf16x6_vs_float64(A, B, c, T, K, N, res, xs, arith):
     assert np.abs(y6 - ref).max() <= 1.5 * np.abs(y32 - ref).max() + 1e-6 * np.abs(ref).max(), (np.abs(y6 - ref).max(), np.abs(y32 - ref).max())
 
 
-# fp16 x 3 keeps one running exponent per ROW of x and one per 16-column tile of W.  What a block exponent has to survive: rows of
+# fp16 x 3 keeps one running exponent per ROW of x and one per four output columns of W.  What a block exponent has to survive: rows of
 # one workgroup tile 2^18 apart, a 2^-20 decay along k (a spectrum: loud low bins, quiet high bins), output columns that look at the quiet
 # half of k only, a weight tile 1e-6 of its neighbours, a maximum that keeps growing along k (accumulators rescaled stage after
 # stage), all-zero stages and all-zero rows.  Bars: whole result as close to float64 as the fp32 kernel; EVERY row and EVERY column group
 # within 4e-6 of its own scale (with ONE exponent per 128-row tile -- the first form of the kernel -- the "decay" case missed this by
 # 1e-2 on its quiet rows: that is what the per-row exponents are for).
-@pytest.mark.parametrize("shape", ["decay", "growing", "zeros"])
+@pytest.mark.parametrize("shape", ["decay", "growing", "zeros", "chan4"])
 def test_rowgemm_f16x3_block_exponent(A, shape):
     eng = A.Engine(small_cfg(A))
     B, c, T, K, N = 1, 2, 192, 1024, 272
@@ -288,6 +288,8 @@ def test_rowgemm_f16x3_block_exponent(A, shape):
     w = rng.standard_normal((N, K)) / np.sqrt(K)
     w[:16, : K // 2] = 0.0                             # these columns see the second half of k only
     w[16:32] *= 1e-6                                   # a quiet weight tile
+    if shape == "chan4":                               # W's exponents are per FOUR output columns: groups 2^40 apart inside one 16-column tile
+        w *= np.repeat(np.exp2(rng.integers(-20, 21, N // 4)), 4)[:, None]
     w = w.astype(np.float32)
     sc, sh = np.ones(c, np.float32), np.zeros(c, np.float32)
     lin = x.astype(np.float64) @ w.astype(np.float64).T
@@ -313,6 +315,10 @@ def test_rowgemm_f16x3_block_exponent(A, shape):
         ok = scale > 0
         worst = max(worst, float((err[ok] / scale[ok]).max()) if ok.any() else 0.0)
         assert (err[~ok] == 0).all(), "an all-zero row did not come out zero"
+    if shape == "chan4":                               # ... and every COLUMN at its own scale
+        cs = np.sqrt((lin.reshape(-1, N) ** 2).mean(axis=0))
+        ce = np.sqrt(((y.reshape(-1, N) - ref.reshape(-1, N)) ** 2).mean(axis=0))
+        worst = max(worst, float((ce / cs).max()))
     print(f"fp16 x 3 row GEMM, {shape}: rel-RMS {e:.3e} (fp32-MFMA {e32:.3e}), worst row x column-group error over its own scale {worst:.3e}")
     assert worst < 4e-6, worst
 
