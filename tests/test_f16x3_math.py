@@ -54,14 +54,14 @@ def test_three_products_match_a_float32_product():
 
 def emulate_rows(x, w, stage=32):
     """y = x @ w.T the way tdf3_kernel<H> does it: per-row running exponent (drops by need - 2 when a stage would pass 2^15,
-    accumulators multiplied by the exact power of two), per-16-row weight-tile exponent, fp32 accumulation of the three products."""
+    accumulators multiplied by the exact power of two), one weight exponent per four output columns, fp32 accumulation of the three products."""
     x, w = np.asarray(x, np.float32), np.asarray(w, np.float32)
     M, K = x.shape
     N = w.shape[0]
     ew = np.zeros(N, np.int64)
-    for t in range(0, N, 16):
-        m = np.abs(w[t:t + 16]).max()
-        ew[t:t + 16] = scale_exp(m)[()] if m > 0 else 0
+    for t in range(0, N, 4):                            # one exponent per four output columns (w3h_split_kernel)
+        m = np.abs(w[t:t + 4]).max()
+        ew[t:t + 4] = scale_exp(m)[()] if m > 0 else 0
     wh, wl, _ = split2(w, ew[:, None])
     acc = np.zeros((M, N), np.float32)
     e_row = np.full(M, 200, np.int64)
@@ -92,6 +92,7 @@ def test_running_exponent_gemm_is_fp32_grade():
     M, K, N = 48, 1024, 40
     w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     w[16:32] *= 1e-6                                                            # a quiet weight tile
+    w[32:36] *= 2.0 ** 30                                                       # a loud column group inside a tile
     cases = {
         "plain": rng.standard_normal((M, K)),
         "rows 2^40 apart": rng.standard_normal((M, K)) * np.exp2(rng.integers(-20, 21, (M, 1))),
