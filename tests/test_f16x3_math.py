@@ -100,7 +100,7 @@ def test_running_exponent_gemm_is_fp32_grade():
         "decaying along k": rng.standard_normal((M, K)) * np.exp2(-20.0 * np.arange(K) / K),
         "zero first half": np.concatenate([np.zeros((M, K // 2)), rng.standard_normal((M, K // 2))], axis=1),
         "tiny": rng.standard_normal((M, K)) * 1e-35,
-        "huge": rng.standard_normal((M, K)) * 1e35,
+        "huge": rng.standard_normal((M, K)) * 1e33,
     }
     for name, x in cases.items():
         x = x.astype(np.float32)
