@@ -182,10 +182,11 @@ struct asx_engine {
   // 1 (default): row GEMMs, channels-last convolutions (GATHER mode) and attention of THIS engine run the bf16 x 6 kernels when their
   // shapes allow (kernels_gemm3.h); 0: the fp32-MFMA kernels.  ASX_GEMM_BF16X6 or asx_set_option("gemm_bf16x6", n).
   int gemm_bf16x6 = getenv("ASX_GEMM_BF16X6") ? atoi(getenv("ASX_GEMM_BF16X6")) : 1;
-  // 1: the row GEMMs and GATHER-mode convolutions that "gemm_bf16x6" sends to tdf3_kernel run its fp16 x 3 arithmetic (block-scaled
-  // two-way fp16 split, three MFMAs per product instead of six: kernels_gemm3.h) -- 10-30 % faster per launch, as close to a float64
-  // GEMM as the bf16 x 6 form on finite data (profiles/r05_gemm_f16x3.txt); 0: bf16 x 6.  ASX_GEMM_F16X3 or
-  // asx_set_option("gemm_f16x3", n).
+  // 1 (default): every kernel "gemm_bf16x6" sends to the 16-bit matrix pipe -- tdf3_kernel (row GEMMs, GATHER-mode convolutions),
+  // attention6_kernel / mha6_kernel, conv_wino6_kernel -- runs the fp16 x 3 arithmetic: operands scaled by power-of-two block exponents and
+  // split into two fp16 parts, three MFMAs per product instead of six (kernels_gemm3.h); 4-30 % faster per launch, as close to float64 as the
+  // bf16 x 6 form on finite data (profiles/r05_gemm_f16x3.txt, r05_attention_f16x3.txt, r05_wino6_f16x3.txt).  0: bf16 x 6 (exact
+  // three-way split) everywhere.  ASX_GEMM_F16X3 or asx_set_option("gemm_f16x3", n).
   int gemm_f16x3 = getenv("ASX_GEMM_F16X3") ? atoi(getenv("ASX_GEMM_F16X3")) : 1;
   // 3x3 TFC convs with at least this many input channels run Winograd F(2x2,3x3) on the bf16 pipe (conv_wino6_kernel, kernels_wino6.h)
   // when "winograd" is 3 and "gemm_bf16x6" is on; 0 = never.  Default 144: measured faster than conv_wino3_kernel from level 2 of the
