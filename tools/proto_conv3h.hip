@@ -49,6 +49,15 @@ static void launch_abl(int abl, const Conv3hArgs &a, hipStream_t s) {
     case 14: return launch<14>(a, s);
     case 32: return launch<32>(a, s);
     case 64: return launch<64>(a, s);
+    case 160: return launch<160>(a, s);
+    case 288: return launch<288>(a, s);
+    case 416: return launch<416>(a, s);
+    case 512: return launch<512>(a, s);
+    case 1024: return launch<1024>(a, s);
+    case 34: return launch<34>(a, s);
+    case 36: return launch<36>(a, s);
+    case 38: return launch<38>(a, s);
+    case 40: return launch<40>(a, s);
     case 96: return launch<96>(a, s);
     default: return launch<0>(a, s);
   }
@@ -224,10 +233,11 @@ int main(int argc, char **argv) {
   if (abl == 0 && !quick) {
     const Shape small[] = {
         {"small 2x8x64", 2, 8, 64, ACT_RELU, 1, 0.f},
-        {"ragged 3x10x40", 3, 10, 40, ACT_NONE, 1, 0.f},
+        {"ragged 3x10x96", 3, 10, 96, ACT_NONE, 1, 0.f},
         {"one tile row 1x4x32", 1, 4, 32, ACT_RELU, 1, 0.f},
         {"tall 1x37x96 spread", 1, 37, 96, ACT_NONE, 1, 3.f},
-        {"wide 2x5x1100", 2, 5, 1100, ACT_RELU, 1, 2.f},
+        {"tall 2x67x64 wide spread", 2, 67, 64, ACT_NONE, 1, 8.f},
+        {"wide 2x5x1088", 2, 5, 1088, ACT_RELU, 1, 2.f},
     };
     for (const Shape &s : small)
       bad += run_shape(s, 0, 2, 0);
