@@ -102,6 +102,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--siblings", type=int, default=1, help="1: append short htdemucs / BS-Roformer / VR / hdemucs lines (N = 1 only)")
     ap.add_argument("--file-level", type=int, default=1, help="1: time Separator-level separate(wav) -> stem files after the timed region (N = 1 only)")
+    ap.add_argument("--no-arith-ab", action="store_true", help="skip the fp32-exact arithmetic A/B after the timed region (N = 1 only)")
     ap.add_argument("--no-overlap", action="store_true", help="blocking gather (A/B of the gather / compute overlap)")
     ap.add_argument("--config5", action="store_true", help="BASELINE config 5 preset: --mode files --songs-per-rank 8 (64 songs on 8 GPUs)")
     ap.add_argument("--traffic", choices=("live", "stored"), default="live",
@@ -134,34 +135,36 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def per_level_table(launch_recs, g, wino, num_blocks=11, bf16x6=True, wino6_min_c=0, nprod=6):
+def per_level_table(launch_recs, g, wino, num_blocks=11, conv3h=True):
     """The 3x3 TFC convs and the TDF row GEMMs of one profiled pass, grouped by U-Net level (VERDICT r4 next #2c).  A conv's level
     follows from its own algorithmic figures -- 3x3 conv c -> c over a plane P: flops = 18 c^2 P, bytes = 8 c P, so
     c = 4 flops / (9 bytes), level = c / g - 1; the 2 x num_blocks TDF launches come in the net's block order (encoder levels
-    0 .. n-1, bottleneck n, decoder n-1 .. 0, two linears each).  Per level: launches, summed and average milliseconds, the
-    algorithmic rate and the fraction of the matrix peak the launches EXECUTE (Winograd F(2x2,3x3): 4/9 of the direct
-    convolution's FLOPs on the fp32 pipe; split-operand kernels: `nprod` 16-bit products per multiply-add -- six on the bf16 x 6
-    arithmetic, three on fp16 x 3 -- against the 16-bit matrix peak), and the time the launch's algorithmic bytes take at the
-    6.29 TB/s a device copy reaches."""
-    arith = "fp16 x 3" if nprod == 3 else "bf16 x 6"
-    def add(tab, key, ms, flops, nbytes):
-        r = tab.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+    0 .. n-1, bottleneck n, decoder n-1 .. 0, two linears each).  Every launch record carries the number of 16-bit MFMA products per
+    multiply-add its kernel executed (Engine.profile_launches_ex: 6 = bf16 x 6, 3 = fp16 x 3, 0 = fp32 MFMA), which names the kernel:
+    a 3x3 launch on the 16-bit pipe is conv3h_kernel on the 48-channel level (direct implicit GEMM: ALL of the convolution's FLOPs,
+    its 432-deep reduction padded to 15 stages of 32) and conv_wino6_kernel elsewhere (Winograd F(2x2,3x3): 4/9 of them, input
+    channels padded to whole 32-channel stages); on the fp32 pipe it is conv_wino3_kernel (4/9) or the direct conv_dma_kernel.
+    Per level: launches, summed and average milliseconds, the algorithmic rate, the rate and fraction of the matrix peak the launches
+    EXECUTE, and the time the launch's algorithmic bytes take at the 6.29 TB/s a device copy reaches."""
+    def add(tab, key, ms, flops, nbytes, nprod):
+        r = tab.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "nprod": set()})
         r["launches"] += 1
         r["ms"] += ms
         r["flops"] += flops
         r["bytes"] += nbytes
+        r["nprod"].add(nprod)
     conv, tdf = {}, {}
     n = num_blocks // 2
     order = list(range(n)) + [n] + list(range(n - 1, -1, -1))
     tdf_recs = [r for r in launch_recs if r[0] == "tdf"]
     if len(tdf_recs) == 2 * num_blocks:
-        for i, (_, ms, flops, nbytes) in enumerate(tdf_recs):
-            add(tdf, (order[i // 2], i % 2), ms, flops, nbytes)
-    for cls, ms, flops, nbytes in launch_recs:
+        for i, (_, ms, flops, nbytes, nprod) in enumerate(tdf_recs):
+            add(tdf, (order[i // 2], i % 2), ms, flops, nbytes, nprod)
+    for cls, ms, flops, nbytes, nprod in launch_recs:
         if cls == "conv3x3" and nbytes > 0:
-            add(conv, int(round(4.0 * flops / (9.0 * nbytes) / g)) - 1, ms, flops, nbytes)
+            add(conv, int(round(4.0 * flops / (9.0 * nbytes) / g)) - 1, ms, flops, nbytes, nprod)
     out = {"conv3x3": {}, "tdf": {}}
-    exf = (4.0 / 9.0) if wino else 1.0
+    arith_name = {3: "fp16 x 3", 6: "bf16 x 6"}
     for lvl in sorted(conv):
         r = conv[lvl]
         c = g * (lvl + 1)
@@ -170,14 +173,23 @@ def per_level_table(launch_recs, g, wino, num_blocks=11, bf16x6=True, wino6_min_
                "algorithmic_tflops": round(tf, 1), "algorithmic_gb_per_launch": round(r["bytes"] / r["launches"] / 1e9, 3),
                "hbm_floor_ms_per_launch": round(r["bytes"] / r["launches"] / 6.29e12 * 1e3, 3),
                "flops": r["flops"], "bytes": r["bytes"]}
-        if wino and bf16x6 and wino6_min_c > 0 and c >= wino6_min_c:
-            # conv_wino6_kernel: 4/9 of the direct FLOPs as `nprod` 16-bit products each, input channels padded to whole 32-channel stages
+        npr = max(r["nprod"]) if len(r["nprod"]) == 1 else -1
+        if npr > 0 and wino and conv3h and c == 48:
+            pad = 480.0 / 432.0                       # 9 x 48 = 432 reduction elements in 15 stages of 32 (each kernel row ends on a half-empty stage)
+            ent.update({"kernel": f"conv3h_kernel (direct implicit GEMM, weights resident in LDS, {arith_name[npr]})", "nprod": npr,
+                        "executed_tflops_16bit": round(tf * npr * pad, 1), "frac": round(tf * npr * pad / PEAK_BF16_MFMA_TFLOPS, 4), "peak": PEAK_BF16_MFMA_TFLOPS})
+        elif npr > 0:
+            # conv_wino6_kernel: 4/9 of the direct FLOPs as `npr` 16-bit products each, input channels padded to whole 32-channel stages
             pad = (-(-c // 32) * 32) / c
-            ent.update({"kernel": f"conv_wino6_kernel (Winograd F(2x2,3x3), {arith})", "executed_tflops_bf16": round(tf * exf * nprod * pad, 1),
-                        "frac": round(tf * exf * nprod * pad / PEAK_BF16_MFMA_TFLOPS, 4), "peak": PEAK_BF16_MFMA_TFLOPS})
-        else:
-            ent.update({"kernel": "conv_wino3_kernel (Winograd F(2x2,3x3), fp32 MFMA)" if wino else "conv_dma_kernel<3,3,...> (direct, fp32 MFMA)",
+            ent.update({"kernel": f"conv_wino6_kernel (Winograd F(2x2,3x3), {arith_name[npr]})", "nprod": npr,
+                        "executed_tflops_16bit": round(tf * (4.0 / 9.0) * npr * pad, 1),
+                        "frac": round(tf * (4.0 / 9.0) * npr * pad / PEAK_BF16_MFMA_TFLOPS, 4), "peak": PEAK_BF16_MFMA_TFLOPS})
+        elif npr == 0:
+            exf = (4.0 / 9.0) if wino else 1.0
+            ent.update({"kernel": "conv_wino3_kernel (Winograd F(2x2,3x3), fp32 MFMA)" if wino else "conv_dma_kernel<3,3,...> (direct, fp32 MFMA)", "nprod": 0,
                         "executed_tflops": round(tf * exf, 1), "frac": round(tf * exf / PEAK_FP32_MFMA_TFLOPS, 4), "peak": PEAK_FP32_MFMA_TFLOPS})
+        else:
+            ent.update({"kernel": "mixed (launches of one level on different kernels)", "nprod": sorted(r["nprod"])})
         out["conv3x3"][f"L{lvl}"] = ent
     for (lvl, which) in sorted(tdf):
         r = tdf[(lvl, which)]
@@ -185,8 +197,9 @@ def per_level_table(launch_recs, g, wino, num_blocks=11, bf16x6=True, wino6_min_
         ent = {"launches": r["launches"], "ms": round(r["ms"], 3), "avg_launch_ms": round(r["ms"] / r["launches"], 4), "fp32_equivalent_tflops": round(tf, 1),
                "algorithmic_gb_per_launch": round(r["bytes"] / r["launches"] / 1e9, 3),
                "hbm_floor_ms_per_launch": round(r["bytes"] / r["launches"] / 6.29e12 * 1e3, 3)}
-        if bf16x6:
-            ent.update({"executed_tflops_bf16": round(nprod * tf, 1), "frac": round(nprod * tf / PEAK_BF16_MFMA_TFLOPS, 4), "arithmetic": arith})
+        npr = max(r["nprod"]) if len(r["nprod"]) == 1 else -1
+        if npr > 0:
+            ent.update({"executed_tflops_16bit": round(npr * tf, 1), "frac": round(npr * tf / PEAK_BF16_MFMA_TFLOPS, 4), "arithmetic": arith_name[npr]})
         else:
             ent["frac"] = round(tf / PEAK_FP32_MFMA_TFLOPS, 4)
         out["tdf"][f"L{lvl}.{'F_to_F8' if which == 0 else 'F8_to_F'}"] = ent
@@ -349,6 +362,27 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = songs_per_step * args.seconds * args.steps / dt
 
+    # ---- the same K steps on the fp32-EXACT arithmetic (gemm_f16x3 = 0: every split-operand kernel multiplies exact three-way bf16 splits, six
+    # products per multiply-add; conv3h_kernel's level falls back to conv_wino3_kernel), outside the timed region: both headlines are driver-timed
+    arithmetic_ab = None
+    if world == 1 and eng.option("gemm_bf16x6") > 0 and eng.option("gemm_f16x3") > 0 and not args.no_arith_ab:
+        eng.set_option("gemm_f16x3", 0)
+        for k in range(2):
+            step(k)
+        fence()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        fence()
+        dt6 = time.perf_counter() - t1
+        eng.set_option("gemm_f16x3", 1)
+        step(0)                                         # (the profiled pass below runs on the default again, its weight images are back)
+        fence()
+        arithmetic_ab = {"what": "the same timed loop with asx_set_option(gemm_f16x3, 0): six exact bf16 products per multiply-add (fp32-exact split operands) in the "
+                                 "row GEMMs, attention and conv_wino6_kernel; the 48-channel level on conv_wino3_kernel (fp32 MFMA) instead of conv3h_kernel",
+                         "value": round(songs_per_step * args.seconds * args.steps / dt6, 2), "ms_per_step": round(dt6 / args.steps * 1e3, 3),
+                         "steps": args.steps, "default_over_exact": round(dt6 / dt, 4)}
+
     # ---- what the exchange costs, outside the timed region (so that a sub-linear N > 1 result can be attributed) ----
     comm = {"gather_bytes_per_step": 0, "gather_ms": None, "fold_ms": None}
     if args.mode == "files":
@@ -387,15 +421,19 @@ def main():
         eng.profile_enable(True)
         eng.demix_dev(m0.data_ptr(), N, o0.data_ptr(), stream=stream)
         prof = eng.profile_read()
-        launch_recs = eng.profile_launches()
+        launch_recs = eng.profile_launches_ex()
         eng.profile_enable(False)
         wino = eng.option("winograd") > 0
         x6 = eng.option("gemm_bf16x6") > 0
         w6c = eng.option("winograd_bf16x6") if (eng.option("winograd") == 3 and x6) else 0
-        per_level = per_level_table(launch_recs, d.g, wino, d.num_blocks, x6, w6c, 3 if (x6 and eng.option("gemm_f16x3") > 0) else 6)
-        # the dominant kernel: conv_wino3_kernel (fp32 MFMA) on the levels below the bf16 x 6 threshold -- levels 0 / 1 of the HQ_3 net,
-        # ~100 of the ~139 ms the 3x3 class takes; the deeper levels run conv_wino6_kernel and are listed per level
-        dom = [v for v in per_level["conv3x3"].values() if "wino6" not in v["kernel"]]
+        c3h = eng.option("winograd") == 3 and x6 and eng.option("gemm_f16x3") > 0 and eng.option("conv_direct_f16x3") > 0
+        per_level = per_level_table(launch_recs, d.g, wino, d.num_blocks, c3h)
+        # the dominant kernel: conv_wino3_kernel (fp32 MFMA) on the levels neither conv3h_kernel (48 channels: level 0) nor conv_wino6_kernel
+        # (from the winograd_bf16x6 channel count up) takes -- level 1 of the HQ_3 net, ~48 of the ~120 ms the 3x3 class takes, the largest
+        # single kernel of the step; every level is listed in per_level with the kernel that ran it
+        dom = [v for v in per_level["conv3x3"].values() if v.get("nprod") == 0]
+        if not dom:
+            dom = list(per_level["conv3x3"].values())
         c = {"flops": sum(v["flops"] for v in dom), "bytes": sum(v["bytes"] for v in dom), "ms": sum(v["ms"] for v in dom),
              "launches": sum(v["launches"] for v in dom)}
         for v in per_level["conv3x3"].values():
@@ -425,7 +463,9 @@ def main():
                 traffic, source = round(live, 1), why
             else:
                 source = (source or "") + f" [live measurement unavailable: {why}]"
-        roofline = {"kernel": ("conv_wino3_kernel (TFC 3x3 convs of the levels below "
+        roofline = {"kernel": ("conv_wino3_kernel (TFC 3x3 convs of level 1: the levels below "
+                               f"{w6c} channels that conv3h_kernel does not take, Winograd F(2x2,3x3) on fp32 MFMA)" if (wino and w6c and c3h) else
+                               "conv_wino3_kernel (TFC 3x3 convs of the levels below "
                                f"{w6c} channels, Winograd F(2x2,3x3) on fp32 MFMA)" if (wino and w6c) else
                                "conv_wino3_kernel (TFC 3x3 convs, Winograd F(2x2,3x3) on fp32 MFMA)" if wino
                                else "conv_dma_kernel<3,3,1,1,3,4,2,0> (TFC 3x3 convs)"),
@@ -473,7 +513,11 @@ def main():
         res = {
             "metric": METRIC, "value": round(value, 2), "unit": "audio-s/wall-s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": ("f32 (I/O and accumulators; matrix products on the 16-bit pipe from block-scaled two-part fp16 operands, 22-bit products -- see arithmetic; "
+                      "fp32-exact setting timed in arithmetic_ab)" if (eng.option("gemm_bf16x6") > 0 and eng.option("gemm_f16x3") > 0) else
+                      "f32 (I/O and accumulators; matrix products from exactly split bf16 operands or fp32 MFMA -- see arithmetic)"),
+            "data": "synthetic",
             "config": {"workload": "UVR-MDX-NET-Inst_HQ_3 geometry (n_fft 6144, hop 1024, dim_f 3072, segment 256, "
                                    "overlap 0.25; ConvTDFNet g48 l3 11 blocks bn8, synthetic weights), "
                                    f"{args.seconds:g}-s 44.1 kHz stereo song(s), input resident in HBM"
@@ -486,11 +530,12 @@ def main():
             "rccl": dict({"world_size": dist.get_world_size() if use_dist else 1, "backend": dist.get_backend() if use_dist else None,
                           "launcher": "self" if os.environ.get("ASX_BENCH_LAUNCHED") == "1" else ("external" if "WORLD_SIZE" in os.environ else None)},
                          **comm),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "arithmetic_ab": arithmetic_ab,
             # what "f32" means inside: nothing runs in a reduced-precision mode
             "arithmetic": {"io": "float32",
-                           "conv3x3": "Winograd F(2x2,3x3): fp32 MFMA (exact fma chains) below the winograd_bf16x6 channel count (default 144), "
-                                      "split operands on the 16-bit pipe from there up (csrc/kernels_wino6.h; same arithmetic as row_gemm)",
+                           "conv3x3": "48-channel level: direct implicit GEMM on the fp16 pipe, two-part operands, one running power-of-two exponent per walk down T "
+                                      "(csrc/kernels_conv3h.h; same arithmetic as row_gemm); other levels below the winograd_bf16x6 channel count (default 144): "
+                                      "Winograd F(2x2,3x3) on fp32 MFMA (exact fma chains); from there up: Winograd on split operands on the 16-bit pipe (csrc/kernels_wino6.h)",
                            "attention": ("as row_gemm (one exponent per query, per 64-key tile of K, a running one per tile of V, none for the probabilities)"
                                          if (eng.option("gemm_bf16x6") > 0 and eng.option("gemm_f16x3") > 0) else
                                          "six bf16 products on exactly split operands" if eng.option("gemm_bf16x6") > 0 else "fp32 MFMA"),

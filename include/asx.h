@@ -47,7 +47,7 @@ extern "C" {
 #define ASX_ERR_HIP 2     /* a HIP runtime call failed (no GPU, OOM, launch) */
 #define ASX_ERR_STATE 3   /* call order violated (e.g. demix before commit)  */
 
-#define ASX_ABI_VERSION 6
+#define ASX_ABI_VERSION 7
 
 /* flags of asx_demix*(): */
 #define ASX_FLAG_MATCH_MIX 1u /* demix(mix, is_match_mix=True): overlap 0.02, no net (mdx_separator.py:308-313, :429-432) */
@@ -494,7 +494,8 @@ int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host
  * "tdf3h_launches" (those of them, plain or GATHER mode, that ran the fp16 x 3 arithmetic),
  * "tdf3_gather_launches" (its GATHER mode: channels-last convolutions), "attn6_launches" (attention6_kernel / mha6_kernel),
  * "attn6h_launches" (those of them on the fp16 x 3 arithmetic),
- * "wino6_launches" (conv_wino6_kernel: Winograd F(2x2,3x3) on the 16-bit pipe), "wino6h_launches" (those on the fp16 x 3 arithmetic).  ASX_ERR_INVALID for an unknown name. */
+ * "wino6_launches" (conv_wino6_kernel: Winograd F(2x2,3x3) on the 16-bit pipe), "wino6h_launches" (those on the fp16 x 3 arithmetic),
+ * "conv3h_launches" (ABI 7: conv3h_kernel, the direct fp16 x 3 convolution of the 48-channel level).  ASX_ERR_INVALID for an unknown name. */
 int asx_counter(const asx_engine *e, const char *name, int64_t *out);
 
 /* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host. */
@@ -541,6 +542,11 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
  * bf16 matrix pipe (conv_wino6_kernel, csrc/kernels_wino6.h: the sixteen transform-domain GEMMs as six bf16 MFMA products on exactly
  * split operands -- the arithmetic of "gemm_bf16x6", which must be on) instead of conv_wino3_kernel; needs "winograd" = 3.  Default 144
  * (levels 2 .. 5 of the HQ_3 net: measured 1.08-1.24x faster there, equal at 96 channels, slower at 48); 0 = never.
+ * "conv_direct_f16x3" (ABI 7; also ASX_CONV3H): 1 (default) = a 3x3 TFC convolution of 48 -> 48 channels on planes whose width is a multiple of
+ * 32 (level 0 of the HQ_3 geometry, the widest planes of the net) runs conv3h_kernel (csrc/kernels_conv3h.h): a DIRECT implicit GEMM on the fp16
+ * matrix pipe with the arithmetic of "gemm_f16x3" (which must be on, as "gemm_bf16x6" and "winograd" = 3) -- the two-part weight image stays in
+ * LDS for the whole launch, producer waves fetch four input rows per step into a ring walked down T and split them under one running
+ * power-of-two exponent per walk, consumer waves multiply; 5.3-5.8 ms per launch of 55 chunks against 8.5-8.9 on conv_wino3_kernel.  0 = conv_wino3_kernel.
  * "gemm_bf16x6" (per engine since ABI 6 -- it was process-wide; also ASX_GEMM_BF16X6 in the environment): 1 (default) = every row GEMM whose shape allows it
  * (K % 32 == 0, K >= 64, N > 64, N % 8 == 0, 16-byte aligned rows) runs csrc/kernels_gemm3.h -- both fp32 operands split EXACTLY into three
  * bf16 parts, six bf16 MFMA products with fp32 accumulation, the dropped cross terms below 2^-24 of a product: fp32-grade results
@@ -571,6 +577,9 @@ int asx_profile_read(asx_engine *e, asx_profile *out); /* synchronises the devic
 /* The launches behind those sums, one record each (class, hipEvent milliseconds, algorithmic flops and bytes), in launch order:
  * a profile class can mix MFMA-bound and HBM-bound launches (the Demucs "conv" class does), and a roofline is a per-launch
  * statement.  Writes min(*n, cap) records, *n = launches recorded.  Synchronises the device.  (ABI 4) */
+/* ABI 7: bits 8..15 of `cls` carry the number of 16-bit MFMA products per multiply-add the launch's kernel executed -- 6 (bf16 x 6: exactly
+ * split operands), 3 (fp16 x 3) or 0 (an fp32-MFMA / VALU kernel); the class is `cls & 0xff`.  A roofline fraction of a class that mixes
+ * pipes is executed work over the peak of the pipe that executed it, launch by launch. */
 typedef struct asx_launch_rec {
   int32_t cls;
   float ms;

@@ -45,6 +45,7 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
+    stamp = source_hash()                               # of what is about to be compiled (an edit during the compile must not be stamped as built)
     cmd = [hipcc_path()] + FLAGS + ["-o", OUT, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
@@ -54,7 +55,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(r.stderr)
     with open(STAMP, "w") as fh:
-        fh.write(source_hash() + "\n")
+        fh.write(stamp + "\n")
     return OUT
 
 

@@ -30,6 +30,7 @@
 #include "kernels_wino.h"
 #include "kernels_winos.h"
 #include "kernels_wino6.h"
+#include "kernels_conv3h.h"
 #ifndef ASX_TDF2_DEFAULT
 #define ASX_TDF2_DEFAULT 1
 #endif
@@ -1914,6 +1915,7 @@ int asx_counter(const asx_engine *e, const char *name, int64_t *out) {
   else if (nm == "tdf3_gather_launches") *out = (int64_t)g_tdf3_gather_launches.load();
   else if (nm == "wino6_launches") *out = (int64_t)g_wino6_launches.load();
   else if (nm == "wino6h_launches") *out = (int64_t)g_wino6h_launches.load();
+  else if (nm == "conv3h_launches") *out = (int64_t)g_conv3h_launches.load();
   else {
     set_err("asx_counter: unknown counter '%s'", name);
     return ASX_ERR_INVALID;
@@ -2086,6 +2088,10 @@ int asx_set_option(asx_engine *e, const char *key, int32_t value) {
     e->gemm_f16x3 = value > 0 ? 1 : 0;
     return ASX_OK;
   }
+  if (!strcmp(key, "conv_direct_f16x3")) {
+    e->conv3h = value > 0 ? 1 : 0;
+    return ASX_OK;
+  }
   set_err("asx_set_option: unknown option '%s'", key);
   return ASX_ERR_INVALID;
 }
@@ -2128,7 +2134,7 @@ int asx_profile_launches(asx_engine *e, asx_launch_rec *out, int32_t cap, int32_
   for (int32_t i = 0; i < *n && i < cap; ++i) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e->recs[i].a, e->recs[i].b));
-    out[i].cls = e->recs[i].cls;
+    out[i].cls = e->recs[i].cls | (e->recs[i].nprod << 8);
     out[i].ms = ms;
     out[i].flops = e->recs[i].flops;
     out[i].bytes = e->recs[i].bytes;

@@ -83,6 +83,7 @@ struct ConvLayer {
   DevBuf wu6;      // conv_wino6_kernel (kernels_wino6.h): U split three ways into bf16, MFMA-fragment order [CG48][NCI32][wave 8][18][lane 64][4 x u32]
   int wu6_nci = 0; // 32-channel stages of that image (0 = not packed: Cin < 64)
   DevBuf wu6h;     // the same for the fp16 x 3 arithmetic (wino6_pack_h): two fp16 parts per U, scaled per (position, cout); exponents behind the fragments
+  DevBuf w3h;      // conv3h_kernel (kernels_conv3h.h): the 48 -> 48 layers' two-part fp16 weights in fragment order, one exponent per output channel
 };
 
 struct TdfLayer {
@@ -100,6 +101,7 @@ struct Block {
 
 struct ProfRec {
   int cls;
+  int nprod;        // 16-bit MFMA products per multiply-add the launch executed: 6 (bf16 x 6), 3 (fp16 x 3), 0 = fp32 MFMA / VALU
   hipEvent_t a, b;
   double flops, bytes;
 };
@@ -192,12 +194,17 @@ struct asx_engine {
   // when "winograd" is 3 and "gemm_bf16x6" is on; 0 = never.  Default 144: measured faster than conv_wino3_kernel from level 2 of the
   // HQ_3 net down, equal on level 1, slower on level 0 (profiles/r05_wino6_forms.txt).  ASX_WINO6 or asx_set_option("winograd_bf16x6", n).
   int wino6 = getenv("ASX_WINO6") ? std::max(0, atoi(getenv("ASX_WINO6"))) : 144;
+  // 1 (default): 3x3 TFC convs of 48 -> 48 channels (level 0 of the HQ_3 geometry) run the DIRECT implicit GEMM on the fp16 x 3 arithmetic
+  // (conv3h_kernel, kernels_conv3h.h: weights resident in LDS, no Winograd transforms) while "winograd" is 3 and "gemm_bf16x6" / "gemm_f16x3"
+  // are on; 0: conv_wino3_kernel (fp32 MFMA).  5.6-5.8 ms per launch of 55 chunks against 8.5-8.9.  ASX_CONV3H or asx_set_option("conv_direct_f16x3", n).
+  int conv3h = getenv("ASX_CONV3H") ? std::max(0, atoi(getenv("ASX_CONV3H"))) : 1;
   // split (bf16 x 3) images of this engine's weight matrices, built on first use and freed only with the engine or when the engine's
   // own weights are re-loaded: another engine of the process can never invalidate a pointer a captured graph of this one holds
   std::vector<W3Entry> w3;
   std::mutex w3_mu;
   // profiling
   bool prof = false;
+  int prof_nprod = 0;   // set by the launchers of the split-operand kernels inside a timed() launch (see ProfRec::nprod)
   std::vector<ProfRec> recs;
 };
 
@@ -222,7 +229,9 @@ static int timed(asx_engine *e, int cls, double flops, double bytes, hipStream_t
   HIPCHK(hipEventCreate(&r.a));
   HIPCHK(hipEventCreate(&r.b));
   HIPCHK(hipEventRecord(r.a, s));
+  e->prof_nprod = 0;
   launch();
+  r.nprod = e->prof_nprod;
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(r.b, s));
   e->recs.push_back(r);

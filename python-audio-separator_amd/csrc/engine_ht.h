@@ -786,6 +786,7 @@ static int ht_mha(asx_engine *e, const float *q, int64_t ldq, const float *k, co
         else hipLaunchKernelGGL((mha6_kernel<4, 1>), grid6, dim3(256), 0, s, a6);
       }
       g_attn6_launches.fetch_add(1);
+      e->prof_nprod = e->gemm_f16x3 > 0 ? 3 : 6;
       return;
     }
     if (dh == 48 && mha_db) hipLaunchKernelGGL((mha_kernel<3, false, true>), grid, dim3(256), 0, s, a);

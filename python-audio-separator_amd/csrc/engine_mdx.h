@@ -157,6 +157,13 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
         HIPCHK(hipMemcpy(L.wu6h.p, w6.data(), w6.size() * 4, hipMemcpyHostToDevice));
       }
     }
+    // direct fp16 x 3 kernel (kernels_conv3h.h): the 48 -> 48 layers
+    if (L.cin == Conv3hCfg::C && L.cout == Conv3hCfg::C) {
+      std::vector<uint32_t> w3h;
+      conv3h_pack(w, w3h);
+      CHK(L.w3h.ensure(w3h.size() * 4));
+      HIPCHK(hipMemcpy(L.w3h.p, w3h.data(), w3h.size() * 4, hipMemcpyHostToDevice));
+    }
     // weight-stationary image: only where all of U fits the registers of eight waves (Cin <= 96) without much zero padding
     L.wus_ks = (L.cin > 40 && L.cin <= 48) ? 12 : ((L.cin > 88 && L.cin <= 96) ? 24 : 0);
     if (L.wus_ks) {
@@ -202,6 +209,7 @@ static void launch_conv_dma_t(const ConvArgs &a, int nblk, hipStream_t s) {
 
 static std::atomic<long long> g_wino6_launches{0};   // launches of conv_wino6_kernel (kernels_wino6.h) since the process started
 static std::atomic<long long> g_wino6h_launches{0};  // ... of which on the fp16 x 3 arithmetic
+static std::atomic<long long> g_conv3h_launches{0};  // launches of conv3h_kernel (kernels_conv3h.h)
 
 // Optional view description of a conv's operands (channel slices of larger buffers).
 struct ConvView {
@@ -314,6 +322,38 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     if (ragged) return k12 ? gos(&conv_winos_kernel<12, 0, true>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 0, true>, WinoSCfg<24>::LDS_BYTES);
     return k12 ? gos(&conv_winos_kernel<12, 0, false>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 0, false>, WinoSCfg<24>::LDS_BYTES);
   }
+  if (L.kind == CK_3X3 && e->winograd == 3 && e->gemm_bf16x6 > 0 && e->gemm_f16x3 > 0 && e->conv3h > 0 && L.w3h.p != nullptr && dma &&
+      v.res == nullptr && (a.act == ACT_RELU || a.act == ACT_NONE) && F % 32 == 0 && (int64_t)L.cin * T * F < ((int64_t)1 << 29) &&
+      a.y_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+    // direct implicit GEMM on the fp16 pipe, weights resident in LDS: one persistent 512-thread workgroup per CU (the walk assumes 8 XCDs x 32)
+    Conv3hArgs ca{};
+    ca.x = x;
+    ca.y = y;
+    ca.wimg = reinterpret_cast<const u32x4 *>(L.w3h.p);
+    ca.bias = L.b.f();
+    ca.B = B;
+    ca.T = T;
+    ca.F = F;
+    ca.x_bstride = a.x_bstride;
+    ca.y_bstride = a.y_bstride;
+    ca.act = a.act;
+    ca.tilesT = (T + 3) / 4;
+    ca.tilesF = F / 32;
+    {
+      static std::mutex attr_mutex;
+      static bool attr_done = false;
+      std::lock_guard<std::mutex> lock(attr_mutex);
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3h_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, Conv3hCfg::LDS_BYTES);
+        attr_done = true;
+      }
+    }
+    g_conv3h_launches.fetch_add(1);
+    return timed(e, cls, flops, bytes, s, [&]() {
+      e->prof_nprod = 3;
+      hipLaunchKernelGGL((conv3h_kernel<0>), dim3(256), dim3(512), Conv3hCfg::LDS_BYTES, s, ca);
+    });
+  }
   if (L.kind == CK_3X3 && e->winograd == 3 && e->gemm_bf16x6 > 0 && e->wino6 > 0 && L.cin >= e->wino6 && dma && L.wu6_nci > 0 &&
       (int64_t)T * F < ((int64_t)1 << 24)) {
     // Winograd on the bf16 pipe, one workgroup per (8 x 32 tile, 48-channel group); the groups of a tile are consecutive on one XCD
@@ -342,6 +382,7 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
       g_wino6_launches.fetch_add(1);
       if (h3) g_wino6h_launches.fetch_add(1);
       return timed(e, cls, flops, bytes, s, [&]() {
+        e->prof_nprod = h3 ? 3 : 6;
         if (h3) hipLaunchKernelGGL((conv_wino6_kernel<0, 1, true>), dim3((unsigned)nb), dim3(512), Wino6Cfg::LDS_BYTES, s, wa);
         else hipLaunchKernelGGL((conv_wino6_kernel<0, 1>), dim3((unsigned)nb), dim3(512), Wino6Cfg::LDS_BYTES, s, wa);
       });
@@ -662,6 +703,7 @@ static bool launch_tdf3_gather(asx_engine *e, const TdfDmaArgs &a, const RowGath
   const bool h = e->gemm_f16x3 > 0;
   const u32x4 *w3 = w3_image(e, a.w, a.N, a.K, s, (gq.cin & 31) ? gq.cin : 0, h ? 1 : 0);   // channel counts off the 32-grid get their own padded image
   if (!w3) return false;
+  e->prof_nprod = h ? 3 : 6;
   constexpr int BM = 16 * MREP, BN = 64 * NREP;
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
@@ -694,6 +736,7 @@ static bool launch_tdf3(asx_engine *e, const TdfDmaArgs &a, hipStream_t s) {
   const bool h = e->gemm_f16x3 > 0 && abl0 == 0 && (only_n == 0 || (only_n > 0 ? a.N == only_n : a.N != -only_n));
   const u32x4 *w3 = w3_image(e, a.w, a.N, a.K, s, 0, h ? 1 : 0);
   if (!w3) return false;                               // out of memory for the image: the caller falls back to the fp32 kernels
+  e->prof_nprod = h ? 3 : 6;
   if (h) {
     launch_tdf3_abl<NREP, MREP, 0, true>(a, w3, s);
     return true;

@@ -361,6 +361,7 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
           }
           g_attn6_launches.fetch_add(1);
           if (h3) g_attn6h_launches.fetch_add(1);
+          e->prof_nprod = h3 ? 3 : 6;
         } else
         if (v1) hipLaunchKernelGGL(attention_kernel, dim3(qtiles, H, (unsigned)nseq), dim3(256), 0, s, aa);
         else if (qw >= 2 && aa.len > 64) {

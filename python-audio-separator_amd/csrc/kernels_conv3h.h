@@ -288,7 +288,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(raw[S][j].x)), __builtin_fabsf(raw[S][j].y));   // v_max3_f32 with |.| modifiers
         m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(raw[S][j].z)), __builtin_fabsf(raw[S][j].w));
       }
-      m = fminf(wave_max64(m), 3.4028234663852886e38f);
+      m = wave_max64(m);
+      if (!(m <= 3.4028234663852886e38f)) {            // an Inf in the block (v_max never returns a NaN): the largest FINITE |x| sets the exponent --
+        m = 0.f;                                       // the Inf / NaN elements poison the outputs they reach and nothing else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          m = fmaxf(m, fmaxf(fmaxf(finite_or_zero(raw[S][j].x), finite_or_zero(raw[S][j].y)), fmaxf(finite_or_zero(raw[S][j].z), finite_or_zero(raw[S][j].w))));
+        }
+        m = wave_max64(m);
+      }
       if (lane == 0) maxtab[slot * 4 + pw] = m;
     };
     int e_prev = 0, js = -1;                           // exponent of the block split last, position of the next block to split inside its item
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // an element keeps its 22 significand bits down to 2^-12 of a block maximum that sits EUP = 8 bits under the range, and an
       // absolute error of 2^-34 of that maximum below: the consumers rescale accumulators only where the exponent moves (rarely).
       int need = f16_scale_exp(m) - 1;
-      need = need < 126 ? need : 126;                  // 2^e as a float
+      need = need < 100 ? need : 100;                  // 2^e and the epilogue's 2^-(e + weight exponent) stay normal floats
       int e = e_prev;
       if (js < 0 || need < e_prev) e = need;
       else if (need > e_prev + CFG::EUP) e = need < e_prev + 40 ? need : e_prev + 40;   // (a rise multiplies accumulators by 2^rise: bounded)
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int sg = 0; sg < CFG::SPK; ++sg) {
       int kk = 4 * sg + g;
-      kk = kk < CFG::KGY ? kk : CFG::KGY - 1;
+      kk = kk < CFG::KGY ? kk : CFG::KGY - 2 + (g & 1);   // half stage: lanes past the last k group re-read groups 16 / 17 (an odd slot distance: no bank conflict; their weight fragment is zero)
       vl[sg] = (kk / CFG::CG8 + li) * CFG::PSTR + (kk % CFG::CG8) * 16 + CFG::X_OFF;
     }
     const char *wl = lds + CFG::W_OFF + lane * 16;

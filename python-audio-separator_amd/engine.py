@@ -217,7 +217,7 @@ class HDConfig:
 _FP = C.POINTER(C.c_float)
 _lib = None
 
-ABI_VERSION = 6   # ASX_ABI_VERSION of include/asx.h the structures below mirror
+ABI_VERSION = 7   # ASX_ABI_VERSION of include/asx.h the structures below mirror
 
 # every symbol include/asx.h declares
 SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_create", "asx_engine_destroy",
@@ -444,7 +444,7 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         self._check(self._lib.asx_set_option(self._h, key.encode(), int(value)))
-        self._options[key] = (1 if int(value) > 0 else 0) if key in ("gemm_bf16x6", "gemm_f16x3") else int(value)
+        self._options[key] = (1 if int(value) > 0 else 0) if key in ("gemm_bf16x6", "gemm_f16x3", "conv_direct_f16x3") else int(value)
 
     def option(self, key: str) -> int:
         """Current value of an engine option (the library default when it was never set here)."""
@@ -452,7 +452,8 @@ class Engine:
                     "winograd_stationary": max(0, int(os.environ.get("ASX_WINOS", "0"))),
                     "gemm_bf16x6": 1 if int(os.environ.get("ASX_GEMM_BF16X6", "1")) > 0 else 0,
                     "gemm_f16x3": 1 if int(os.environ.get("ASX_GEMM_F16X3", "1")) > 0 else 0,
-                    "winograd_bf16x6": max(0, int(os.environ.get("ASX_WINO6", "144")))}
+                    "winograd_bf16x6": max(0, int(os.environ.get("ASX_WINO6", "144"))),
+                    "conv_direct_f16x3": 1 if int(os.environ.get("ASX_CONV3H", "1")) > 0 else 0}
         if key not in defaults:
             raise AsxError(f"unknown engine option {key!r} (known: {sorted(defaults)})")
         return self._options.get(key, defaults[key])
@@ -1069,7 +1070,16 @@ class Engine:
         self._check(self._lib.asx_profile_launches(self._h, None, 0, C.byref(n)))
         recs = (_LaunchRec * max(1, n.value))()
         self._check(self._lib.asx_profile_launches(self._h, recs, n.value, C.byref(n)))
-        return [(PROF_CLASSES[r.cls], float(r.ms), float(r.flops), float(r.bytes)) for r in recs[: n.value]]
+        return [(PROF_CLASSES[r.cls & 0xff], float(r.ms), float(r.flops), float(r.bytes)) for r in recs[: n.value]]
+
+    def profile_launches_ex(self):
+        """As profile_launches with a fifth field: the 16-bit MFMA products per multiply-add the launch executed -- 6 (bf16 x 6), 3 (fp16 x 3)
+        or 0 (fp32 MFMA / VALU kernels) -- bits 8..15 of asx_launch_rec.cls (ABI 7)."""
+        n = C.c_int32()
+        self._check(self._lib.asx_profile_launches(self._h, None, 0, C.byref(n)))
+        recs = (_LaunchRec * max(1, n.value))()
+        self._check(self._lib.asx_profile_launches(self._h, recs, n.value, C.byref(n)))
+        return [(PROF_CLASSES[r.cls & 0xff], float(r.ms), float(r.flops), float(r.bytes), (r.cls >> 8) & 0xff) for r in recs[: n.value]]
 
     def profile_read(self) -> dict:
         p = _Profile()

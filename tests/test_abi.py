@@ -32,7 +32,7 @@ def test_header_symbols_exported(lib):
 def test_abi_version(lib):
     hdr = open(os.path.join(ROOT, "include", "asx.h")).read()
     declared = int(re.search(r"#define\s+ASX_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert lib.asx_abi_version() == declared == E.ABI_VERSION == 6
+    assert lib.asx_abi_version() == declared == E.ABI_VERSION == 7
 
 
 def test_binding_refuses_a_library_of_another_abi(monkeypatch):

@@ -904,6 +904,81 @@ def test_conv3x3_winograd_bf16x6(A, B, cin, cout, T, F, relu, arith):
     assert e6 < 1e-6 and e6 <= 1.25 * e3 + 1e-8, (e6, e3)
 
 
+@pytest.mark.parametrize("B,T,F,relu,spread", [(1, 16, 128, True, 0.0), (2, 8, 64, True, 0.0), (3, 10, 96, False, 0.0), (1, 4, 32, True, 0.0),
+                                               (1, 37, 96, False, 3.0), (2, 67, 64, False, 8.0), (2, 5, 1088, True, 2.0), (1, 130, 3072 // 8, True, 1.0)])
+def test_conv3x3_direct_f16x3(A, B, T, F, relu, spread):
+    """conv3h_kernel (csrc/kernels_conv3h.h, round 6: the default for the 48 -> 48 layers, level 0 of the HQ_3 geometry): the 3x3 convolution
+    as a direct implicit GEMM on the fp16 pipe -- two-part operands, three products, weights resident in LDS, input rows in a ring walked down T,
+    one running power-of-two exponent per walk with accumulator rescales where it moves.  Against torch and float64, against conv_wino3_kernel
+    on the same layer, with proof of which kernel ran; ragged T, one-tile planes, several batch items, magnitudes that vary by `spread` decades
+    over the plane (the exponent moves: rescale paths), a folded-BatchNorm-like spread of the output channels' weight scales."""
+    import torch
+    eng = A.Engine(small_cfg(A))
+    assert eng.option("winograd") == 3 and eng.option("conv_direct_f16x3") == 1 and eng.option("gemm_f16x3") == 1
+    rng = np.random.default_rng(T * 1000 + F + 17)
+    x = rng.standard_normal((B, 48, T, F)).astype(np.float32)
+    if spread:
+        tt, ff = np.meshgrid(np.arange(T), np.arange(F), indexing="ij")
+        x *= (10.0 ** (spread * np.sin(0.013 * ff) * np.cos(0.21 * tt))).astype(np.float32)[None, None]
+    b = rng.standard_normal(48).astype(np.float32)
+    w = (rng.standard_normal((48, 48, 3, 3)) / np.sqrt(9 * 48)).astype(np.float32)
+    w *= (10.0 ** rng.uniform(-1, 1, size=(48, 1, 1, 1))).astype(np.float32)
+    n0 = eng.counter("conv3h_launches")
+    y = eng.op_conv("conv3x3", x, w, b, relu=relu)
+    assert eng.counter("conv3h_launches") == n0 + 1, "conv3h_kernel did not run"
+    assert np.array_equal(y, eng.op_conv("conv3x3", x, w, b, relu=relu)), "not deterministic"
+    assert np.isfinite(y).all(), "unwritten (NaN canary) output elements"
+    eng.set_option("conv_direct_f16x3", 0)
+    n0 = eng.counter("conv3h_launches")
+    y3 = eng.op_conv("conv3x3", x, w, b, relu=relu)
+    assert eng.counter("conv3h_launches") == n0, "the fp32 run went through conv3h_kernel"
+    r64 = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1)
+    # the bar of an fp32 chain: relative to sum |w x| over the taps (what the largest product of a sum is rounded against)
+    mag = torch.nn.functional.conv2d(torch.from_numpy(x).double().abs(), torch.from_numpy(w).double().abs(), torch.from_numpy(b).double().abs(), padding=1).numpy()
+    r64 = (torch.relu(r64) if relu else r64).numpy()
+    assert (np.abs(y - r64) <= 2e-6 * mag + 1e-30).all(), float((np.abs(y - r64) / (mag + 1e-30)).max())
+    e6, e3 = rel_rms(y, r64), rel_rms(y3, r64)
+    assert e6 < 1e-6 and e6 <= 1.25 * e3 + 1e-8, (e6, e3)
+
+
+@pytest.mark.parametrize("case", ["inf", "nan", "huge", "tiny", "zero"])
+def test_conv3x3_direct_f16x3_edge_values(A, case):
+    """Non-finite and extreme inputs of conv3h_kernel: an Inf / NaN pixel poisons outputs (as it does in the reference's fp32 convolution --
+    here possibly its whole 4 x 32 tile and the walk's following rows up to the next exponent move), never hangs or corrupts other batch items;
+    planes of 1e30 or 1e-30 keep fp32-grade relative accuracy (the exponent follows them); an all-zero plane gives the bias."""
+    import torch
+    eng = A.Engine(small_cfg(A))
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 48, 12, 64)).astype(np.float32)
+    b = rng.standard_normal(48).astype(np.float32)
+    w = (rng.standard_normal((48, 48, 3, 3)) / np.sqrt(9 * 48)).astype(np.float32)
+    if case == "inf":
+        x[0, 3, 5, 40] = np.inf
+    elif case == "nan":
+        x[0, 7, 2, 3] = np.nan
+    elif case == "huge":
+        x *= np.float32(1e30)
+        b[:] = 0
+    elif case == "tiny":
+        x *= np.float32(1e-30)
+        b[:] = 0
+    else:
+        x[:] = 0
+    n0 = eng.counter("conv3h_launches")
+    y = eng.op_conv("conv3x3", x, w, b, relu=False)
+    assert eng.counter("conv3h_launches") == n0 + 1
+    r64 = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1).numpy()
+    if case in ("inf", "nan"):
+        assert np.isfinite(y[1]).all() and rel_rms(y[1], r64[1]) < 1e-6, "the clean batch item was touched"
+        bad = ~np.isfinite(r64[0])
+        assert (~np.isfinite(y[0][bad])).all(), "a non-finite reference output came back finite"
+        assert np.isfinite(y[0][~bad]).all() and rel_rms(y[0][~bad], r64[0][~bad]) < 1e-6, "outputs the Inf / NaN cannot reach were touched"
+    elif case == "zero":
+        assert np.array_equal(y, np.broadcast_to(b[None, :, None, None], y.shape))
+    else:
+        assert np.isfinite(y).all() and rel_rms(y, r64) < 1e-6, rel_rms(y, r64)
+
+
 _HQ3_EXCERPT = {}
 
 
@@ -916,14 +991,19 @@ def _hq3_excerpt():
     return _HQ3_EXCERPT
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 30, 36, 306, 366])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 30, 36, 306, 366, 3000])
 def test_winograd_hq3_excerpt_vs_oracle(A, mode):
     # 3 = the default (conv_wino3_kernel on levels 0 / 1, conv_wino6_kernel from 144 channels); 30 = the weight-stationary kernel on the
     # two outer levels; 36 = conv_wino6_kernel on every level it can take (>= 64 channels: level 1 too); 306 = conv_wino3_kernel everywhere;
     # 366 = as 36 with every split-operand kernel on the bf16 x 6 arithmetic (gemm_f16x3 = 0; the default is fp16 x 3)
+    # 3000 = as 3 with the direct fp16 x 3 kernel of level 0 (conv3h_kernel, the default since round 6) switched off: conv_wino3_kernel there
     c = _hq3_excerpt()
     d, sd, mix, ref = c["d"], c["sd"], c["mix"], c["ref"]
     eng = A.Engine(A.MDXConfig(max_batch=2))
+    want3h = {3: 6, 36: 6, 30: 0, 3000: 0, 306: 6, 366: 0, 0: 0, 1: 0, 2: 0}[mode]   # level-0 3x3 launches per net pass on conv3h_kernel
+    if mode == 3000:
+        mode = 3
+        eng.set_option("conv_direct_f16x3", 0)
     want6 = {3: 21, 36: 27, 306: 0, 366: 27}.get(mode)  # 3x3 launches per net pass on conv_wino6_kernel (6 per level, 3 at the bottleneck)
     h3 = mode != 366
     if mode == 366:
@@ -941,10 +1021,11 @@ def test_winograd_hq3_excerpt_vs_oracle(A, mode):
     eng.set_option("winograd", mode)
     assert eng.option("winograd") == mode
     eng.load_net(A.NetConfig(), A.fold_convtdf_state(sd, d.num_blocks, d.l))
-    n6, n6h = eng.counter("wino6_launches"), eng.counter("wino6h_launches")
+    n6, n6h, n3h = eng.counter("wino6_launches"), eng.counter("wino6h_launches"), eng.counter("conv3h_launches")
     got = eng.demix(mix)
+    passes = -(-eng.plan(mix.shape[1])["n_chunks"] // 2)            # max_batch = 2
+    assert eng.counter("conv3h_launches") - n3h == want3h * passes, (eng.counter("conv3h_launches") - n3h, want3h, passes)
     if want6 is not None:
-        passes = -(-eng.plan(mix.shape[1])["n_chunks"] // 2)        # max_batch = 2
         assert eng.counter("wino6_launches") - n6 == want6 * passes, (eng.counter("wino6_launches") - n6, want6, passes)
         assert eng.counter("wino6h_launches") - n6h == (want6 * passes if h3 else 0), (eng.counter("wino6h_launches") - n6h, want6, passes, h3)
     e = rel_rms(got, ref)

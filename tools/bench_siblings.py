@@ -63,30 +63,44 @@ def dominant(eng, step, names, x6_classes=("tdf",)):
     eng.profile_enable(True)
     step()
     prof = eng.profile_read()
-    recs = eng.profile_launches()
+    recs = eng.profile_launches_ex()
     eng.profile_enable(False)
     k, v = max(((k, v) for k, v in prof.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
     tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
-    # The classes in `x6_classes` run the bf16 x 6 kernels when the option is on (row GEMM tdf3_kernel -- also in GATHER mode for
-    # the stride-1 / strided convs of the channels-last nets -- and attention6_kernel / mha6_kernel): six bf16 MFMA products per
-    # fp32 multiply-add on exactly split operands.  Their roofline is then the dense bf16 peak against EXECUTED work (6 x the
-    # algorithmic FLOPs; the launches outside the kernels' preconditions still run fp32 MFMA and are over-counted by this), with
-    # the algorithmic FLOP rate kept as `fp32_equivalent`.
-    x6 = eng.option("gemm_bf16x6") > 0
+    # Every launch record says how many 16-bit MFMA products per multiply-add its kernel executed (ABI 7): 6 = bf16 x 6 (exactly split operands),
+    # 3 = fp16 x 3 (block-scaled two-part operands, the default), 0 = an fp32-MFMA / VALU kernel.  A class's roofline is EXECUTED work over the
+    # peak of the pipe that executed it: the split-operand launches' algorithmic FLOPs x their product count against the dense 16-bit peak, the
+    # fp32 launches' own FLOPs against the fp32-MFMA peak -- never a flat factor over the class (a "x 6" label over fp16 x 3 launches
+    # doubled four fractions).  `fp32_equivalent` keeps the algorithmic rate.
 
-    def mfma_roof(cls, t):
-        if cls in x6_classes and x6:
-            return {"achieved": round(6.0 * t, 1), "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": round(6.0 * t / PEAK_BF16, 4),
-                    "dtype": "bf16 x 6 products (fp32-exact split operands)", "fp32_equivalent": round(t, 2),
-                    "fp32_equivalent_over_fp32_peak": round(t / PEAK, 4)}
-        return {"achieved": round(t, 2), "peak": PEAK, "unit": "TFLOP/s", "frac": round(t / PEAK, 4)}
-    roof = dict({"kernel": names.get(k, k), "bound": "mfma"}, **mfma_roof(k, tf))
+    def mfma_roof(rs):
+        """rs: launch records (cls, ms, flops, bytes, nprod) of one group"""
+        ms = sum(r[1] for r in rs)
+        lo = [r for r in rs if r[4] > 0]
+        fp = [r for r in rs if r[4] == 0]
+        out = {}
+        if lo:
+            ex = sum(r[2] * r[4] for r in lo)
+            t = sum(r[1] for r in lo)
+            npr = sorted(set(r[4] for r in lo))
+            out = {"achieved": round(ex / t / 1e9, 1), "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": round(ex / t / 1e9 / PEAK_BF16, 4),
+                   "dtype": " + ".join("fp16 x 3 products (block-scaled two-part operands)" if n == 3 else f"bf16 x {n} products (fp32-exact split operands)" for n in npr),
+                   "launches_16bit": len(lo), "ms_16bit": round(t, 2),
+                   "fp32_equivalent": round(sum(r[2] for r in lo) / t / 1e9, 2)}
+            if fp:
+                t2 = sum(r[1] for r in fp)
+                out["fp32_launches"] = {"launches": len(fp), "ms": round(t2, 2), "achieved": round(sum(r[2] for r in fp) / t2 / 1e9, 2), "peak": PEAK,
+                                        "frac": round(sum(r[2] for r in fp) / t2 / 1e9 / PEAK, 4)}
+            return out
+        a = sum(r[2] for r in fp) / max(ms, 1e-9) / 1e9
+        return {"achieved": round(a, 2), "peak": PEAK, "unit": "TFLOP/s", "frac": round(a / PEAK, 4)}
+    roof = dict({"kernel": names.get(k, k), "bound": "mfma"}, **mfma_roof([r for r in recs if r[0] == k]))
     roof.update({"traffic": None, "launches": v["launches"], "share_of_step_ms": round(v["ms"], 2)})
     mf = [r for r in recs if r[0] == k and r[3] > 0 and r[2] / r[3] >= 40.0]
     hb = [r for r in recs if r[0] == k and not (r[3] > 0 and r[2] / r[3] >= 40.0)]
     if mf:
         ms, fl = sum(r[1] for r in mf), sum(r[2] for r in mf)
-        roof["mfma_bound_launches"] = dict({"launches": len(mf), "ms": round(ms, 2)}, **mfma_roof(k, fl / ms / 1e9))
+        roof["mfma_bound_launches"] = dict({"launches": len(mf), "ms": round(ms, 2)}, **mfma_roof(mf))
     if hb:
         ms, by = sum(r[1] for r in hb), sum(r[3] for r in hb)
         roof["hbm_bound_launches"] = {"launches": len(hb), "ms": round(ms, 2), "achieved": round(by / ms / 1e6, 1), "unit": "GB/s",
@@ -96,7 +110,7 @@ def dominant(eng, step, names, x6_classes=("tdf",)):
         if not vv["launches"] or vv["ms"] <= 0:
             continue
         t, g = vv["flops"] / (vv["ms"] * 1e-3) / 1e12, vv["bytes"] / (vv["ms"] * 1e-3) / 1e9
-        stages[names.get(kk, kk)] = (dict({"bound": "mfma"}, **mfma_roof(kk, t))
+        stages[names.get(kk, kk)] = (dict({"bound": "mfma"}, **mfma_roof([r for r in recs if r[0] == kk]))
                                      if t / PEAK >= g / 8000.0 else
                                      {"bound": "hbm", "achieved": round(g, 1), "unit": "GB/s", "frac": round(g / 8000.0, 4)})
     roof["stage_roofline"] = stages
