@@ -45,6 +45,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the
 METRIC = "audio-sec separated / wall-sec (RTF), UVR-MDX-NET 44.1kHz stereo, 1/2/4/8 GPU"
 PMC_FILES = ("r05_pmc_conv3x3.json", "r03_pmc_conv3x3.json", "r02_pmc_conv3x3.json", "r01_pmc_conv3x3.json")
 PMC_FILES_WINO = ("r05_pmc_wino3.json", "r04_pmc_wino3.json", "r03_pmc_wino3.json")
+PMC_FILES_3H = ("r06_pmc_conv3h.json",)
 
 
 def cpu_baseline(seconds: float, seed: int):
@@ -135,14 +136,14 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def per_level_table(launch_recs, g, wino, num_blocks=11, conv3h=True):
+def per_level_table(launch_recs, g, wino, num_blocks=11, conv3h=96):
     """The 3x3 TFC convs and the TDF row GEMMs of one profiled pass, grouped by U-Net level (VERDICT r4 next #2c).  A conv's level
     follows from its own algorithmic figures -- 3x3 conv c -> c over a plane P: flops = 18 c^2 P, bytes = 8 c P, so
     c = 4 flops / (9 bytes), level = c / g - 1; the 2 x num_blocks TDF launches come in the net's block order (encoder levels
     0 .. n-1, bottleneck n, decoder n-1 .. 0, two linears each).  Every launch record carries the number of 16-bit MFMA products per
     multiply-add its kernel executed (Engine.profile_launches_ex: 6 = bf16 x 6, 3 = fp16 x 3, 0 = fp32 MFMA), which names the kernel:
-    a 3x3 launch on the 16-bit pipe is conv3h_kernel on the 48-channel level (direct implicit GEMM: ALL of the convolution's FLOPs,
-    its 432-deep reduction padded to 15 stages of 32) and conv_wino6_kernel elsewhere (Winograd F(2x2,3x3): 4/9 of them, input
+    a 3x3 launch on the 16-bit pipe is conv3h_kernel on the levels of 48 n <= `conv3h` channels (direct implicit GEMM: ALL of the convolution's
+    FLOPs, each 432-deep slice reduction padded to 15 stages of 32) and conv_wino6_kernel elsewhere (Winograd F(2x2,3x3): 4/9 of them, input
     channels padded to whole 32-channel stages); on the fp32 pipe it is conv_wino3_kernel (4/9) or the direct conv_dma_kernel.
     Per level: launches, summed and average milliseconds, the algorithmic rate, the rate and fraction of the matrix peak the launches
     EXECUTE, and the time the launch's algorithmic bytes take at the 6.29 TB/s a device copy reaches."""
@@ -174,9 +175,9 @@ def per_level_table(launch_recs, g, wino, num_blocks=11, conv3h=True):
                "hbm_floor_ms_per_launch": round(r["bytes"] / r["launches"] / 6.29e12 * 1e3, 3),
                "flops": r["flops"], "bytes": r["bytes"]}
         npr = max(r["nprod"]) if len(r["nprod"]) == 1 else -1
-        if npr > 0 and wino and conv3h and c == 48:
+        if npr > 0 and wino and conv3h and c % 48 == 0 and c <= conv3h:
             pad = 480.0 / 432.0                       # 9 x 48 = 432 reduction elements in 15 stages of 32 (each kernel row ends on a half-empty stage)
-            ent.update({"kernel": f"conv3h_kernel (direct implicit GEMM, weights resident in LDS, {arith_name[npr]})", "nprod": npr,
+            ent.update({"kernel": f"conv3h_kernel (direct implicit GEMM, weights resident in LDS, {arith_name[npr]}" + (f"; {(c // 48) ** 2} launches over 48-channel slices per layer)" if c > 48 else ")"), "nprod": npr,
                         "executed_tflops_16bit": round(tf * npr * pad, 1), "frac": round(tf * npr * pad / PEAK_BF16_MFMA_TFLOPS, 4), "peak": PEAK_BF16_MFMA_TFLOPS})
         elif npr > 0:
             # conv_wino6_kernel: 4/9 of the direct FLOPs as `npr` 16-bit products each, input channels padded to whole 32-channel stages
@@ -224,7 +225,7 @@ def pmc_child(args):
     eng.close()
 
 
-def live_traffic(args, kernel_substr):
+def live_traffic(args, kernel_substr, per_layers=0, dispatches_per_pass=0):
     """HBM bytes per launch of the dominant kernel, measured in THIS run: rocprofv3 --kernel-trace --pmc <counter> around a
     one-song child of this script, one counter per pass (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass),
     FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads), both in KiB.  -> (bytes per launch, launches seen, note)
@@ -254,14 +255,15 @@ def live_traffic(args, kernel_substr):
                             cnt += 1
             if cnt == 0:
                 return None, 0, f"rocprofv3 pass {ctr}: rc {r.returncode}, no dispatch of {kernel_substr} in its output ({r.stderr.decode(errors='replace')[-200:]!r})"
-            vals[ctr] = (tot / cnt, cnt)
+            # per_layers: bytes per conv LAYER (several dispatches each); the child runs whole passes (a warm-up and a measured one): cnt / dispatches_per_pass of them
+            vals[ctr] = (tot / (per_layers * (cnt / dispatches_per_pass) if per_layers > 0 and dispatches_per_pass > 0 else cnt), cnt)
     except Exception as e:                       # never take the headline line down
         return None, 0, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     fetch, write = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
     return fetch + write, vals["FETCH_SIZE"][1], (f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) around a one-song child of "
-                                                   f"bench.py inside this run, {vals['FETCH_SIZE'][1]} dispatches averaged; FETCH_SIZE x 2 per the gfx950 note "
+                                                   f"bench.py inside this run, {vals['FETCH_SIZE'][1]} dispatches " + (f"({dispatches_per_pass} per pass) summed and divided by the passes and by {per_layers} layers" if per_layers > 0 else "averaged") + "; FETCH_SIZE x 2 per the gfx950 note "
                                                    f"of MI355X_MICROARCH.md (fetch {fetch / 1e9:.3f} GB + write {write / 1e9:.3f} GB per launch)")
 
 
@@ -426,51 +428,57 @@ def main():
         wino = eng.option("winograd") > 0
         x6 = eng.option("gemm_bf16x6") > 0
         w6c = eng.option("winograd_bf16x6") if (eng.option("winograd") == 3 and x6) else 0
-        c3h = eng.option("winograd") == 3 and x6 and eng.option("gemm_f16x3") > 0 and eng.option("conv_direct_f16x3") > 0
+        c3h = eng.option("conv_direct_f16x3") if (eng.option("winograd") == 3 and x6 and eng.option("gemm_f16x3") > 0) else 0
         per_level = per_level_table(launch_recs, d.g, wino, d.num_blocks, c3h)
         # the dominant kernel: conv_wino3_kernel (fp32 MFMA) on the levels neither conv3h_kernel (48 channels: level 0) nor conv_wino6_kernel
         # (from the winograd_bf16x6 channel count up) takes -- level 1 of the HQ_3 net, ~48 of the ~120 ms the 3x3 class takes, the largest
         # single kernel of the step; every level is listed in per_level with the kernel that ran it
-        dom = [v for v in per_level["conv3x3"].values() if v.get("nprod") == 0]
-        if not dom:
-            dom = list(per_level["conv3x3"].values())
+        lv = per_level["conv3x3"]
+        dom3h = [v for v in lv.values() if v["kernel"].startswith("conv3h")]
+        dom3 = [v for v in lv.values() if v.get("nprod") == 0]
+        is3h = bool(dom3h) and sum(v["ms"] for v in dom3h) >= sum(v["ms"] for v in dom3)
+        dom = dom3h if is3h else (dom3 or list(lv.values()))
         c = {"flops": sum(v["flops"] for v in dom), "bytes": sum(v["bytes"] for v in dom), "ms": sum(v["ms"] for v in dom),
              "launches": sum(v["launches"] for v in dom)}
-        for v in per_level["conv3x3"].values():
+        for v in lv.values():
             v.pop("flops")
             v.pop("bytes")
         call = prof["conv3x3"]
         ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
-        # HBM bytes per launch: the ratio traffic / algorithmic bytes comes from the PMC passes kept under profiles/ (FETCH_SIZE x2 per
-        # the gfx950 correction + WRITE_SIZE) unless it is measured live below; traffic_source says which.
+        # HBM bytes per launch (= per conv LAYER: a 96-channel layer is four dispatches of conv3h_kernel): measured live below (rocprofv3 PMC passes,
+        # FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE, summed over the kernel's dispatches and divided by the layers) or, failing that,
+        # the ratio traffic / algorithmic bytes of the PMC record kept under profiles/ applied to this run's algorithmic bytes; traffic_source says which.
         traffic, source = None, None
-        for name in (PMC_FILES_WINO if wino else PMC_FILES):
+        for name in (PMC_FILES_3H if is3h else PMC_FILES_WINO if wino else PMC_FILES):
             pmc_path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc_path):
                 with open(pmc_path) as fh:
                     traffic = round(json.load(fh)["traffic_over_algorithmic"] * c["bytes"] / max(1, c["launches"]), 1)
                 source = f"stored: profiles/{name} (rocprofv3 --pmc passes), ratio applied to this run's algorithmic bytes"
                 break
-        # `achieved` / `frac` describe what the matrix pipe EXECUTES (<= 1 by construction): the Winograd kernel runs 16
-        # multiply-adds per 2 x 2 output tile and channel pair instead of the direct convolution's 36, i.e. 4/9 of the
-        # algorithmic FLOPs (exact on this geometry: channels are multiples of 4, planes multiples of the 8 x 32 tile).
-        # The direct-convolution (algorithmic) rate -- SURVEY 8d's per-unit figure over the same launch time -- is kept
-        # under `algorithmic`; it can exceed the peak and is NOT a roofline fraction.
-        exf = (4.0 / 9.0) if wino else 1.0
+        # `achieved` / `frac` describe what the matrix pipe EXECUTES (<= 1 by construction).  conv3h_kernel: three fp16 products per multiply-add of
+        # the direct convolution, each 432-deep slice reduction in 15 stages of 32 (x 480 / 432), against the dense 16-bit peak.  The Winograd
+        # kernels run 16 multiply-adds per 2 x 2 output tile and channel pair instead of the direct convolution's 36, i.e. 4/9 of the algorithmic
+        # FLOPs.  The direct-convolution (algorithmic) rate -- SURVEY 8d's per-unit figure over the same launch time -- is kept under
+        # `algorithmic`; it can exceed a peak and is NOT a roofline fraction.
+        exf = 3.0 * 480.0 / 432.0 if is3h else (4.0 / 9.0) if wino else 1.0
+        peak = PEAK_BF16_MFMA_TFLOPS if is3h else PEAK_FP32_MFMA_TFLOPS
         if world == 1 and args.traffic == "live":
-            live, nlaunch, why = live_traffic(args, "conv_wino3_kernel" if wino else "conv_dma_kernel<asx::ConvDmaCfg<3, 3, 1, 1")
+            live, nlaunch, why = live_traffic(args, "conv3h_kernel" if is3h else "conv_wino3_kernel" if wino else "conv_dma_kernel<asx::ConvDmaCfg<3, 3, 1, 1",
+                                              per_layers=c["launches"] if is3h else 0,
+                                              dispatches_per_pass=sum(v["launches"] * (v["channels"] // 48) ** 2 for v in dom3h) if is3h else 0)
             if live is not None:
                 traffic, source = round(live, 1), why
             else:
                 source = (source or "") + f" [live measurement unavailable: {why}]"
-        roofline = {"kernel": ("conv_wino3_kernel (TFC 3x3 convs of level 1: the levels below "
-                               f"{w6c} channels that conv3h_kernel does not take, Winograd F(2x2,3x3) on fp32 MFMA)" if (wino and w6c and c3h) else
+        roofline = {"kernel": (f"conv3h_kernel (TFC 3x3 convs of the levels up to {c3h} channels: direct implicit GEMM on the fp16 pipe, three products on two-part "
+                               "operands, 48 x 48 weight slices resident in LDS)" if is3h else
                                "conv_wino3_kernel (TFC 3x3 convs of the levels below "
                                f"{w6c} channels, Winograd F(2x2,3x3) on fp32 MFMA)" if (wino and w6c) else
                                "conv_wino3_kernel (TFC 3x3 convs, Winograd F(2x2,3x3) on fp32 MFMA)" if wino
                                else "conv_dma_kernel<3,3,1,1,3,4,2,0> (TFC 3x3 convs)"),
                     "bound": "mfma", "achieved": round(ach * exf, 2),
-                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach * exf / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach * exf / peak, 4),
                     "traffic": traffic, "traffic_source": source,
                     "algorithmic_bytes_per_launch": c["bytes"] / max(1, c["launches"]),
                     "launches": c["launches"],
@@ -478,11 +486,15 @@ def main():
                     "flops_per_launch": c["flops"] / max(1, c["launches"]) * exf,
                     "share_of_step_ms": round(c["ms"], 2),
                     "conv3x3_class_ms": round(call["ms"], 2), "conv3x3_class_launches": call["launches"]}
+        if is3h:
+            roofline["launch_is"] = "one conv layer (a 96-channel layer = four dispatches of the kernel over 48-channel slices); hbm floor of the launches: per_level"
         roofline["per_level"] = per_level
         if wino:
-            roofline["note"] = ("achieved / frac = EXECUTED MFMA FLOPs (Winograd F(2x2,3x3): 4/9 of the direct convolution's) / launch time "
-                                "/ fp32-MFMA peak; `algorithmic` = direct-convolution FLOPs over the same time (may exceed the peak, not a "
-                                "roofline fraction); `direct_kernel` = the non-Winograd kernel measured in this same run")
+            roofline["note"] = (("achieved / frac = EXECUTED 16-bit MFMA FLOPs (3 products x 480 / 432 stage padding per multiply-add of the direct convolution) / launch time "
+                                 "/ dense 16-bit peak; " if is3h else
+                                 "achieved / frac = EXECUTED MFMA FLOPs (Winograd F(2x2,3x3): 4/9 of the direct convolution's) / launch time / fp32-MFMA peak; ") +
+                                "`algorithmic` = direct-convolution FLOPs over the same time (fp32-equivalent; against the fp32 peak it may exceed 1 and is not a "
+                                "roofline fraction); `direct_kernel` = the fp32-MFMA non-Winograd kernel measured in this same run")
             roofline["algorithmic"] = {"flops_per_launch": c["flops"] / max(1, c["launches"]), "achieved": round(ach, 2),
                                        "unit": "TFLOP/s", "over_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}
             mode = eng.option("winograd")
@@ -565,8 +577,9 @@ def main():
                     if k == "conv3x3" and eng.option("winograd") > 0 and w6c > 0:
                         # two kernels share the class since round 5: conv_wino3_kernel (fp32 MFMA) below `w6c` channels -- its executed rate
                         # and fraction are `roofline.achieved / frac` -- and conv_wino6_kernel (bf16 x 6) from there up; per level: roofline.per_level
-                        stages[k] = {"bound": "mfma", "achieved": roofline["achieved"], "unit": "TFLOP/s", "frac": roofline["frac"],
-                                     "frac_is": "conv_wino3_kernel launches only (executed fp32 MFMA FLOPs); conv_wino6_kernel levels: roofline.per_level",
+                        stages[k] = {"bound": "mfma", "achieved": roofline["achieved"], "unit": "TFLOP/s", "frac": roofline["frac"], "peak": roofline["peak"],
+                                     "frac_is": "the launches of the class's dominant kernel only (roofline.kernel; executed MFMA FLOPs over that pipe's peak); every level "
+                                                "with the kernel that ran it: roofline.per_level",
                                      "algorithmic_achieved": round(tf, 2)}
                     elif k == "conv3x3" and eng.option("winograd") > 0:   # executed MFMA rate (4/9 of the algorithmic one, see roofline)
                         stages[k] = {"bound": "mfma", "achieved": round(tf * 4.0 / 9.0, 2), "unit": "TFLOP/s",

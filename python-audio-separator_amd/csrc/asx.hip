@@ -2089,7 +2089,7 @@ int asx_set_option(asx_engine *e, const char *key, int32_t value) {
     return ASX_OK;
   }
   if (!strcmp(key, "conv_direct_f16x3")) {
-    e->conv3h = value > 0 ? 1 : 0;
+    e->conv3h = value < 0 ? 0 : (int)value;
     return ASX_OK;
   }
   set_err("asx_set_option: unknown option '%s'", key);

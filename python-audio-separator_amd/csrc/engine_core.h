@@ -194,10 +194,13 @@ struct asx_engine {
   // when "winograd" is 3 and "gemm_bf16x6" is on; 0 = never.  Default 144: measured faster than conv_wino3_kernel from level 2 of the
   // HQ_3 net down, equal on level 1, slower on level 0 (profiles/r05_wino6_forms.txt).  ASX_WINO6 or asx_set_option("winograd_bf16x6", n).
   int wino6 = getenv("ASX_WINO6") ? std::max(0, atoi(getenv("ASX_WINO6"))) : 144;
-  // 1 (default): 3x3 TFC convs of 48 -> 48 channels (level 0 of the HQ_3 geometry) run the DIRECT implicit GEMM on the fp16 x 3 arithmetic
-  // (conv3h_kernel, kernels_conv3h.h: weights resident in LDS, no Winograd transforms) while "winograd" is 3 and "gemm_bf16x6" / "gemm_f16x3"
-  // are on; 0: conv_wino3_kernel (fp32 MFMA).  5.6-5.8 ms per launch of 55 chunks against 8.5-8.9.  ASX_CONV3H or asx_set_option("conv_direct_f16x3", n).
-  int conv3h = getenv("ASX_CONV3H") ? std::max(0, atoi(getenv("ASX_CONV3H"))) : 1;
+  // 3x3 TFC convs of 48 n -> 48 n channels with at most this many channels run the DIRECT implicit GEMM on the fp16 x 3 arithmetic (conv3h_kernel,
+  // kernels_conv3h.h: 48 x 48 weight slices resident in LDS, no Winograd transforms; n x n launches per layer, the input slices summed through
+  // the output) while "winograd" is 3 and "gemm_bf16x6" / "gemm_f16x3" are on; 0: never.  Default 144: levels 0, 1 and 2 of the HQ_3 geometry --
+  // 5.2-5.5 ms per launch of 55 chunks against 8.5-8.9 on conv_wino3_kernel at 48 channels, 6.0 against 8.0-8.2 at 96, 3.76 against 4.0-4.1
+  // (conv_wino6_kernel) at 144; the image is packed up to 144 channels.
+  // ASX_CONV3H or asx_set_option("conv_direct_f16x3", n).
+  int conv3h = getenv("ASX_CONV3H") ? std::max(0, atoi(getenv("ASX_CONV3H"))) : 144;
   // split (bf16 x 3) images of this engine's weight matrices, built on first use and freed only with the engine or when the engine's
   // own weights are re-loaded: another engine of the process can never invalidate a pointer a captured graph of this one holds
   std::vector<W3Entry> w3;

@@ -157,12 +157,20 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
         HIPCHK(hipMemcpy(L.wu6h.p, w6.data(), w6.size() * 4, hipMemcpyHostToDevice));
       }
     }
-    // direct fp16 x 3 kernel (kernels_conv3h.h): the 48 -> 48 layers
-    if (L.cin == Conv3hCfg::C && L.cout == Conv3hCfg::C) {
-      std::vector<uint32_t> w3h;
-      conv3h_pack(w, w3h);
-      CHK(L.w3h.ensure(w3h.size() * 4));
-      HIPCHK(hipMemcpy(L.w3h.p, w3h.data(), w3h.size() * 4, hipMemcpyHostToDevice));
+    // direct fp16 x 3 kernel (kernels_conv3h.h): layers of 48 n -> 48 n channels as n x n images of 48 x 48 (output slice major)
+    if (L.cin == L.cout && L.cin % Conv3hCfg::C == 0 && L.cin <= 3 * Conv3hCfg::C) {
+      const int nb = L.cin / Conv3hCfg::C;
+      std::vector<uint32_t> all, one;
+      std::vector<float> ws((size_t)Conv3hCfg::C * Conv3hCfg::C * 9);
+      for (int ob = 0; ob < nb; ++ob)
+        for (int ib = 0; ib < nb; ++ib) {
+          for (int co = 0; co < Conv3hCfg::C; ++co)
+            memcpy(&ws[(size_t)co * Conv3hCfg::C * 9], &w[(((size_t)(ob * Conv3hCfg::C + co)) * L.cin + (size_t)ib * Conv3hCfg::C) * 9], (size_t)Conv3hCfg::C * 9 * 4);
+          conv3h_pack(ws.data(), one);
+          all.insert(all.end(), one.begin(), one.end());
+        }
+      CHK(L.w3h.ensure(all.size() * 4));
+      HIPCHK(hipMemcpy(L.w3h.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
     }
     // weight-stationary image: only where all of U fits the registers of eight waves (Cin <= 96) without much zero padding
     L.wus_ks = (L.cin > 40 && L.cin <= 48) ? 12 : ((L.cin > 88 && L.cin <= 96) ? 24 : 0);
@@ -322,23 +330,27 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     if (ragged) return k12 ? gos(&conv_winos_kernel<12, 0, true>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 0, true>, WinoSCfg<24>::LDS_BYTES);
     return k12 ? gos(&conv_winos_kernel<12, 0, false>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 0, false>, WinoSCfg<24>::LDS_BYTES);
   }
-  if (L.kind == CK_3X3 && e->winograd == 3 && e->gemm_bf16x6 > 0 && e->gemm_f16x3 > 0 && e->conv3h > 0 && L.w3h.p != nullptr && dma &&
-      v.res == nullptr && (a.act == ACT_RELU || a.act == ACT_NONE) && F % 32 == 0 && (int64_t)L.cin * T * F < ((int64_t)1 << 29) &&
+  if (L.kind == CK_3X3 && e->winograd == 3 && e->gemm_bf16x6 > 0 && e->gemm_f16x3 > 0 && e->conv3h > 0 && L.cin <= e->conv3h && L.w3h.p != nullptr && dma &&
+      v.res == nullptr && (a.act == ACT_RELU || a.act == ACT_NONE) && F % 32 == 0 && (int64_t)Conv3hCfg::C * T * F < ((int64_t)1 << 29) &&
       a.y_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
-    // direct implicit GEMM on the fp16 pipe, weights resident in LDS: one persistent 512-thread workgroup per CU (the walk assumes 8 XCDs x 32)
-    Conv3hArgs ca{};
-    ca.x = x;
-    ca.y = y;
-    ca.wimg = reinterpret_cast<const u32x4 *>(L.w3h.p);
-    ca.bias = L.b.f();
-    ca.B = B;
-    ca.T = T;
-    ca.F = F;
-    ca.x_bstride = a.x_bstride;
-    ca.y_bstride = a.y_bstride;
-    ca.act = a.act;
-    ca.tilesT = (T + 3) / 4;
-    ca.tilesF = F / 32;
+    // direct implicit GEMM on the fp16 pipe, weights resident in LDS: one persistent 512-thread workgroup per CU (the walk assumes 8 XCDs x 32).
+    // A layer of 48 n channels runs as n x n launches: for every 48-channel slice of the OUTPUT, the input slices one after the other, each
+    // added to the sum of those before it (a.prev = the output itself), bias with the first, activation with the last.
+    const int nb = L.cin / Conv3hCfg::C;
+    const int tilesT = (T + 3) / 4, tilesF = F / 32;
+    // walk geometry: bands of 32 / 16 / 8 strips -- the narrowest planes that fill whole bands, charged for the extra block per segment of T
+    int bw = 32;
+    double best = 1e30;
+    for (int cand : {32, 16, 8}) {
+      if ((tilesT * cand) % 32 != 0) continue;
+      const int tps = tilesT * cand / 32;
+      const double cost = (double)((tilesF + cand - 1) / cand * cand) / tilesF * (tps + 1.0) / tps;
+      if (cost < best - 1e-9) {
+        best = cost;
+        bw = cand;
+      }
+    }
+    if (best > 1e29) bw = 32;                          // (tilesT not divisible: one segment)
     {
       static std::mutex attr_mutex;
       static bool attr_done = false;
@@ -348,10 +360,30 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
         attr_done = true;
       }
     }
-    g_conv3h_launches.fetch_add(1);
+    const int64_t plane = (int64_t)T * F;
     return timed(e, cls, flops, bytes, s, [&]() {
       e->prof_nprod = 3;
-      hipLaunchKernelGGL((conv3h_kernel<0>), dim3(256), dim3(512), Conv3hCfg::LDS_BYTES, s, ca);
+      for (int ob = 0; ob < nb; ++ob)
+        for (int ib = 0; ib < nb; ++ib) {
+          Conv3hArgs ca{};
+          ca.x = x + (int64_t)ib * Conv3hCfg::C * plane;
+          ca.y = y + (int64_t)ob * Conv3hCfg::C * plane;
+          ca.prev = ib > 0 ? ca.y : nullptr;
+          ca.wimg = reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(L.w3h.p) + (size_t)(ob * nb + ib) * Conv3hCfg::IMG_U32);
+          ca.bias = ib == 0 ? L.b.f() + ob * Conv3hCfg::C : nullptr;
+          ca.B = B;
+          ca.T = T;
+          ca.F = F;
+          ca.x_bstride = a.x_bstride;
+          ca.y_bstride = a.y_bstride;
+          ca.act = ib == nb - 1 ? a.act : ACT_NONE;
+          ca.tilesT = tilesT;
+          ca.tilesF = tilesF;
+          ca.bw = bw;
+          ca.tps = (tilesT * bw) % 32 == 0 ? tilesT * bw / 32 : tilesT;
+          hipLaunchKernelGGL((conv3h_kernel<0>), dim3(256), dim3(512), Conv3hCfg::LDS_BYTES, s, ca);
+          g_conv3h_launches.fetch_add(1);
+        }
     });
   }
   if (L.kind == CK_3X3 && e->winograd == 3 && e->gemm_bf16x6 > 0 && e->wino6 > 0 && L.cin >= e->wino6 && dma && L.wu6_nci > 0 &&

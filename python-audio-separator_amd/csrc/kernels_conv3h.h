@@ -38,7 +38,9 @@ struct Conv3hArgs {
   int B, T, F;
   int64_t x_bstride, y_bstride;
   int act;                   // ACT_NONE / ACT_RELU
-  int tilesT, tilesF;        // ceil(T / 4), ceil(F / 32)
+  int tilesT, tilesF;        // ceil(T / 4), F / 32
+  int bw, tps;               // walk geometry: strips per band (32, 16 or 8: an XCD's 32 workgroups take bw strips x 32 / bw segments of T), tiles per segment (tilesT * bw / 32)
+  const float *prev;         // nullptr, or a [B, 48, T, F] view (y's strides) ADDED in front of the activation: the partial sum of another 48-channel slice of the input
   long long *dbg;            // ABL & 32 (timeline build): [64 steps][8] s_memtime stamps of workgroup 0, then [4 workgroups][2048] step starts
 };
 
@@ -162,22 +164,25 @@ inline void conv3h_pack(const float *w, std::vector<uint32_t> &img) {
     }
 }
 
-// Block walk.  XCD x (block id & 7: where the dispatcher puts the workgroup, for speed only) takes the (b, 32-strip band) items x, x + 8, ...;
-// its 32 workgroups (block id >> 3) walk adjacent strips of the band down T together, so the halo columns a strip shares with its
-// neighbours are re-read from that XCD's L2.  An item is tilesT + 1 blocks of four input rows: block j = rows 4 j + 1 .. 4 j + 4, j = -1 ..
-// tilesT - 1; output tile j (rows 4 j .. 4 j + 3) needs rows 4 j - 1 .. 4 j + 4 = the last two rows of block j - 1 and block j.  Strips
-// past tilesF are all-padding (never stored): they keep the walk in step.  The grid is 256 workgroups.
+// Block walk.  XCD x (block id & 7: where the dispatcher puts the workgroup, for speed only) takes the (b, band of bw strips) items x, x + 8, ...;
+// its 32 workgroups (block id >> 3) are bw adjacent strips x 32 / bw segments of T and walk their segment down T together, so the halo
+// columns a strip shares with its neighbours are re-read from that XCD's L2 (bw = 32: one segment, planes at least 1024 wide; 16 / 8 for the
+// narrower planes of the deeper levels, where 32 strips would leave workgroups without work).  A segment is tps + 1 blocks of four input rows:
+// block j = rows r0 + 4 j + 1 .. r0 + 4 j + 4, j = -1 .. tps - 1 (r0 = the segment's first row); output tile j (rows r0 + 4 j .. + 3) needs rows
+// r0 + 4 j - 1 .. r0 + 4 j + 4 = the last two rows of block j - 1 and block j.  Strips past tilesF are all-padding (never stored): they keep the
+// walk in step.  The grid is 256 workgroups.
 struct Conv3hWalk {
   int item, j, b, strip;
 };
 __device__ __forceinline__ void conv3h_walk_item(const Conv3hArgs &a, int wg, Conv3hWalk &w) {
-  const int nbands = (a.tilesF + 31) >> 5;
+  const int nbands = (a.tilesF + a.bw - 1) / a.bw;
   w.b = w.item / nbands;
-  w.strip = (w.item - w.b * nbands) * 32 + (wg >> 3);
+  w.strip = (w.item - w.b * nbands) * a.bw + (wg >> 3) % a.bw;
 }
+__device__ __forceinline__ int conv3h_row0(const Conv3hArgs &a, int wg) { return ((wg >> 3) / a.bw) * a.tps * 4; }   // first row of the workgroup's segment
 __device__ __forceinline__ int conv3h_nblocks(const Conv3hArgs &a, int wg) {
-  const int items = a.B * ((a.tilesF + 31) >> 5), x = wg & 7;
-  return x < items ? ((items - x + 7) >> 3) * (a.tilesT + 1) : 0;
+  const int items = a.B * ((a.tilesF + a.bw - 1) / a.bw), x = wg & 7;
+  return x < items ? ((items - x + 7) >> 3) * (a.tps + 1) : 0;
 }
 __device__ __forceinline__ void conv3h_walk_init(const Conv3hArgs &a, int wg, Conv3hWalk &w) {
   w.item = wg & 7;
@@ -185,7 +190,7 @@ __device__ __forceinline__ void conv3h_walk_init(const Conv3hArgs &a, int wg, Co
   conv3h_walk_item(a, wg, w);
 }
 __device__ __forceinline__ void conv3h_walk_next(const Conv3hArgs &a, int wg, Conv3hWalk &w) {
-  if (++w.j == a.tilesT) {
+  if (++w.j == a.tps) {
     w.j = -1;
     w.item += 8;
     conv3h_walk_item(a, wg, w);
@@ -232,6 +237,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   const int64_t TF = (int64_t)a.T * a.F;
   const int NB = conv3h_nblocks(a, wg);
+  const int row0 = conv3h_row0(a, wg);
   const unsigned plane_bytes = (unsigned)(CFG::C * TF * 4);
 
   if (wave >= 4) {
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto fetch = [&](auto setc) {                      // the next block of the walk (nothing past the last one: every offset out of range)
       constexpr int S = decltype(setc)::value;
       const int tb = nf < NB ? wk.b : 0, f0 = wk.strip * 32;
-      const int t1 = nf < NB ? wk.j * 4 + 1 : -(1 << 20);
+      const int t1 = nf < NB ? row0 + wk.j * 4 + 1 : -(1 << 20);
       ++nf;
       conv3h_walk_next(a, wg, wk);
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (int64_t)tb * a.x_bstride), 0, plane_bytes, 0x00020000);
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (js < 0 || need < e_prev) e = need;
       else if (need > e_prev + CFG::EUP) e = need < e_prev + 40 ? need : e_prev + 40;   // (a rise multiplies accumulators by 2^rise: bounded)
       e_prev = e;
-      if (++js == a.tilesT) js = -1;
+      if (++js == a.tps) js = -1;
       if (ptid == 0) exps[slot3] = e;
       const float sc = __builtin_ldexpf(1.0f, e);
       char *dst = lds + CFG::X_OFF + slot3 * 4 * CFG::ROWB + loff;
@@ -445,22 +451,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // tile) runs among the MFMAs of the NEXT tile's stages 1 / 3 / 5 and its six stores behind stages 7..12 -- off the wave's critical path.
     f32x4 pacc[2][3];
     int pend_e = 0;
+    // accumulate mode (a.prev): the six lines of the other input slice's partial sums, fetched in the stores' own lane arrangement behind stage 6
+    // of the tile they belong to (the previous tile's epilogue has used the registers by then) and added in front of the activation
+    f32x4 pprev[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pprev[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto epi_chunk = [&](auto cc) {
       constexpr int c = decltype(cc)::value;
       const float sc = __builtin_ldexpf(1.0f, -(pend_e + ew[c]));   // exact power of two (|exponent| well inside the float range: weights and activations are)
       f32x4 v[2];
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
-        v[qq].x = fmaxf(__builtin_fmaf(pacc[qq][c].x, sc, bz[c]), act_lo);   // ReLU or nothing, without a branch (a branch would end the MFMA scheduling region)
-        v[qq].y = fmaxf(__builtin_fmaf(pacc[qq][c].y, sc, bz[c]), act_lo);
-        v[qq].z = fmaxf(__builtin_fmaf(pacc[qq][c].z, sc, bz[c]), act_lo);
-        v[qq].w = fmaxf(__builtin_fmaf(pacc[qq][c].w, sc, bz[c]), act_lo);
+        v[qq].x = __builtin_fmaf(pacc[qq][c].x, sc, bz[c]);
+        v[qq].y = __builtin_fmaf(pacc[qq][c].y, sc, bz[c]);
+        v[qq].z = __builtin_fmaf(pacc[qq][c].z, sc, bz[c]);
+        v[qq].w = __builtin_fmaf(pacc[qq][c].w, sc, bz[c]);
       }
       // channels c * 16 + 0..7 (store 2 c): lanes li < 8 keep their own pixel tile 0, lanes li >= 8 take pixel tile 1 of lane li - 8;
       // channels c * 16 + 8..15 (store 2 c + 1): lanes li >= 8 keep their own pixel tile 1, lanes li < 8 take pixel tile 0 of lane li + 8
       // (`v_mov_b32_dpp row_ror:8` written under a bank mask: one instruction per register)
-      pend[2 * c] = (f32x4){ror8m<0xC>(v[0].x, v[1].x), ror8m<0xC>(v[0].y, v[1].y), ror8m<0xC>(v[0].z, v[1].z), ror8m<0xC>(v[0].w, v[1].w)};
-      pend[2 * c + 1] = (f32x4){ror8m<0x3>(v[1].x, v[0].x), ror8m<0x3>(v[1].y, v[0].y), ror8m<0x3>(v[1].z, v[0].z), ror8m<0x3>(v[1].w, v[0].w)};
+      f32x4 o0 = {ror8m<0xC>(v[0].x, v[1].x), ror8m<0xC>(v[0].y, v[1].y), ror8m<0xC>(v[0].z, v[1].z), ror8m<0xC>(v[0].w, v[1].w)};
+      f32x4 o1 = {ror8m<0x3>(v[1].x, v[0].x), ror8m<0x3>(v[1].y, v[0].y), ror8m<0x3>(v[1].z, v[0].z), ror8m<0x3>(v[1].w, v[0].w)};
+      o0 += pprev[2 * c];                                // zeros outside the accumulate mode
+      o1 += pprev[2 * c + 1];
+      // ReLU or nothing, without a branch (a branch would end the MFMA scheduling region)
+      pend[2 * c] = (f32x4){fmaxf(o0.x, act_lo), fmaxf(o0.y, act_lo), fmaxf(o0.z, act_lo), fmaxf(o0.w, act_lo)};
+      pend[2 * c + 1] = (f32x4){fmaxf(o1.x, act_lo), fmaxf(o1.y, act_lo), fmaxf(o1.z, act_lo), fmaxf(o1.w, act_lo)};
     };
     auto flush = [&]() {
       epi_chunk(IntC<0>{});
@@ -490,6 +506,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
       if (j >= 0) {
+        // F % 32 == 0 (launcher): a strip is inside the image or outside as a whole; rows past T and padding strips get num_records 0
+        const int tt = row0 + j * 4 + wave;
+        const bool cur_ok = tt < a.T && f0 < a.F;
+        const int cur_vo = (((li & 7) * a.T + tt) * a.F + f0 + ((li >> 3) * 4 + g) * 4) * 4;
         // rows of the tile: u = 0, 1 = the last two rows of the previous block, u = 2..5 = this block; wave r, kernel row ky reads u = r + ky
         const int sp = s3 == 0 ? 2 : s3 - 1;
         const int e_cur = __builtin_amdgcn_readfirstlane(exps[s3]), e_old = __builtin_amdgcn_readfirstlane(exps[sp]);
@@ -562,6 +582,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (S == 6) {
+            if (a.prev != nullptr) {
+              __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.prev + (int64_t)tb * a.y_bstride), 0, cur_ok ? plane_bytes : 0u, 0x00020000);
+#pragma unroll
+              for (int k = 0; k < 6; ++k) pprev[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, cur_vo, soff[k], 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if constexpr ((ABL & 128) == 0 && S >= 7 && S <= 12) {
             flush_one(IntC<S - 7>{});                  // the previous tile's stores, one per stage: behind the producers' fetch burst, never two in a row
             if constexpr (S == 12) pend_rs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0, 0x00020000);
@@ -600,13 +628,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int c = 0; c < 3; ++c) pacc[qq][c] = acc[qq][c];
         pend_e = e_cur;
-        {
-          // F % 32 == 0 (launcher): a strip is inside the image or outside as a whole; rows past T and padding strips get num_records 0
-          const int tt = j * 4 + wave;
-          const bool ok = tt < a.T && f0 < a.F;
-          pend_rs = __builtin_amdgcn_make_buffer_rsrc(a.y + (int64_t)tb * a.y_bstride, 0, ok ? plane_bytes : 0u, 0x00020000);
-          pend_vo = (((li & 7) * a.T + tt) * a.F + f0 + ((li >> 3) * 4 + g) * 4) * 4;
-        }
+        pend_rs = __builtin_amdgcn_make_buffer_rsrc(a.y + (int64_t)tb * a.y_bstride, 0, cur_ok ? plane_bytes : 0u, 0x00020000);
+        pend_vo = cur_vo;
         if constexpr ((ABL & 128) != 0) flush();
       } else {
         flush();                                       // first block of an item: nothing to compute yet

@@ -877,6 +877,7 @@ def test_conv3x3_winograd_bf16x6(A, B, cin, cout, T, F, relu, arith):
     eng = A.Engine(small_cfg(A))
     assert eng.option("winograd") == 3 and eng.option("winograd_bf16x6") == 144
     eng.set_option("winograd_bf16x6", 64)
+    eng.set_option("conv_direct_f16x3", 0)             # (round 6: the direct kernel would take the 144-channel case first)
     eng.set_option("gemm_f16x3", 1 if arith == "f16x3" else 0)
     h0 = eng.counter("wino6h_launches")
     rng = np.random.default_rng(cin * 1000 + cout + T + 13)
@@ -904,28 +905,32 @@ def test_conv3x3_winograd_bf16x6(A, B, cin, cout, T, F, relu, arith):
     assert e6 < 1e-6 and e6 <= 1.25 * e3 + 1e-8, (e6, e3)
 
 
-@pytest.mark.parametrize("B,T,F,relu,spread", [(1, 16, 128, True, 0.0), (2, 8, 64, True, 0.0), (3, 10, 96, False, 0.0), (1, 4, 32, True, 0.0),
-                                               (1, 37, 96, False, 3.0), (2, 67, 64, False, 8.0), (2, 5, 1088, True, 2.0), (1, 130, 3072 // 8, True, 1.0)])
-def test_conv3x3_direct_f16x3(A, B, T, F, relu, spread):
+@pytest.mark.parametrize("B,T,F,relu,spread,c", [(1, 16, 128, True, 0.0, 48), (2, 8, 64, True, 0.0, 48), (3, 10, 96, False, 0.0, 48), (1, 4, 32, True, 0.0, 48),
+                                                 (1, 37, 96, False, 3.0, 48), (2, 67, 64, False, 8.0, 48), (2, 5, 1088, True, 2.0, 48), (1, 130, 3072 // 8, True, 1.0, 48),
+                                                 (2, 8, 64, True, 0.0, 96), (1, 18, 96, False, 2.0, 96), (1, 128, 512, True, 1.0, 96), (2, 64, 256, True, 1.0, 96),
+                                                 (1, 16, 256, True, 1.0, 144)])
+def test_conv3x3_direct_f16x3(A, B, T, F, relu, spread, c):
     """conv3h_kernel (csrc/kernels_conv3h.h, round 6: the default for the 48 -> 48 layers, level 0 of the HQ_3 geometry): the 3x3 convolution
     as a direct implicit GEMM on the fp16 pipe -- two-part operands, three products, weights resident in LDS, input rows in a ring walked down T,
     one running power-of-two exponent per walk with accumulator rescales where it moves.  Against torch and float64, against conv_wino3_kernel
     on the same layer, with proof of which kernel ran; ragged T, one-tile planes, several batch items, magnitudes that vary by `spread` decades
-    over the plane (the exponent moves: rescale paths), a folded-BatchNorm-like spread of the output channels' weight scales."""
+    over the plane (the exponent moves: rescale paths), a folded-BatchNorm-like spread of the output channels' weight scales.  Layers of 96 / 144
+    channels run as 4 / 9 launches over 48-channel slices (the input slices summed through the output: accumulate mode), on the narrower walks
+    (bands of 16 / 8 strips, several segments of T)."""
     import torch
     eng = A.Engine(small_cfg(A))
-    assert eng.option("winograd") == 3 and eng.option("conv_direct_f16x3") == 1 and eng.option("gemm_f16x3") == 1
-    rng = np.random.default_rng(T * 1000 + F + 17)
-    x = rng.standard_normal((B, 48, T, F)).astype(np.float32)
+    assert eng.option("winograd") == 3 and eng.option("conv_direct_f16x3") == 144 and eng.option("gemm_f16x3") == 1
+    rng = np.random.default_rng(T * 1000 + F + 17 + c)
+    x = rng.standard_normal((B, c, T, F)).astype(np.float32)
     if spread:
         tt, ff = np.meshgrid(np.arange(T), np.arange(F), indexing="ij")
         x *= (10.0 ** (spread * np.sin(0.013 * ff) * np.cos(0.21 * tt))).astype(np.float32)[None, None]
-    b = rng.standard_normal(48).astype(np.float32)
-    w = (rng.standard_normal((48, 48, 3, 3)) / np.sqrt(9 * 48)).astype(np.float32)
-    w *= (10.0 ** rng.uniform(-1, 1, size=(48, 1, 1, 1))).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    w = (rng.standard_normal((c, c, 3, 3)) / np.sqrt(9 * c)).astype(np.float32)
+    w *= (10.0 ** rng.uniform(-1, 1, size=(c, 1, 1, 1))).astype(np.float32)
     n0 = eng.counter("conv3h_launches")
     y = eng.op_conv("conv3x3", x, w, b, relu=relu)
-    assert eng.counter("conv3h_launches") == n0 + 1, "conv3h_kernel did not run"
+    assert eng.counter("conv3h_launches") == n0 + (c // 48) ** 2, "conv3h_kernel did not run"
     assert np.array_equal(y, eng.op_conv("conv3x3", x, w, b, relu=relu)), "not deterministic"
     assert np.isfinite(y).all(), "unwritten (NaN canary) output elements"
     eng.set_option("conv_direct_f16x3", 0)
@@ -939,6 +944,10 @@ def test_conv3x3_direct_f16x3(A, B, T, F, relu, spread):
     assert (np.abs(y - r64) <= 2e-6 * mag + 1e-30).all(), float((np.abs(y - r64) / (mag + 1e-30)).max())
     e6, e3 = rel_rms(y, r64), rel_rms(y3, r64)
     assert e6 < 1e-6 and e6 <= 1.25 * e3 + 1e-8, (e6, e3)
+    eng.set_option("conv_direct_f16x3", 48)            # the threshold is a channel count: a wider layer stays off the kernel
+    n0 = eng.counter("conv3h_launches")
+    eng.op_conv("conv3x3", x, w, b, relu=relu)
+    assert eng.counter("conv3h_launches") - n0 == (1 if c == 48 else 0)
 
 
 @pytest.mark.parametrize("case", ["inf", "nan", "huge", "tiny", "zero"])
@@ -991,20 +1000,25 @@ def _hq3_excerpt():
     return _HQ3_EXCERPT
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 30, 36, 306, 366, 3000])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 30, 36, 306, 366, 3000, 3048])
 def test_winograd_hq3_excerpt_vs_oracle(A, mode):
-    # 3 = the default (conv_wino3_kernel on levels 0 / 1, conv_wino6_kernel from 144 channels); 30 = the weight-stationary kernel on the
-    # two outer levels; 36 = conv_wino6_kernel on every level it can take (>= 64 channels: level 1 too); 306 = conv_wino3_kernel everywhere;
-    # 366 = as 36 with every split-operand kernel on the bf16 x 6 arithmetic (gemm_f16x3 = 0; the default is fp16 x 3)
-    # 3000 = as 3 with the direct fp16 x 3 kernel of level 0 (conv3h_kernel, the default since round 6) switched off: conv_wino3_kernel there
+    # 3 = the default (round 6: conv3h_kernel -- direct fp16 x 3 -- on the levels up to 144 channels, 1 / 4 / 9 launches per layer over 48-channel
+    # slices; conv_wino6_kernel from there up); 3000 = conv3h_kernel off (conv_wino3_kernel on levels 0 / 1, conv_wino6_kernel from 144 channels:
+    # round 5's default); 3048 = conv3h_kernel on level 0 only; 30 = the weight-stationary kernel on the two outer levels; 36 = the wino6 threshold
+    # at 64 channels (conv3h_kernel still takes its levels first); 306 = wino6 off; 366 = every split-operand kernel on the bf16 x 6 arithmetic
+    # (gemm_f16x3 = 0: no conv3h_kernel; conv_wino6_kernel from 64 channels); 0 / 1 / 2 = the direct fp32 kernel / the earlier Winograd generations
     c = _hq3_excerpt()
     d, sd, mix, ref = c["d"], c["sd"], c["mix"], c["ref"]
     eng = A.Engine(A.MDXConfig(max_batch=2))
-    want3h = {3: 6, 36: 6, 30: 0, 3000: 0, 306: 6, 366: 0, 0: 0, 1: 0, 2: 0}[mode]   # level-0 3x3 launches per net pass on conv3h_kernel
+    # launches per net pass (6 layers per level, 3 at the bottleneck level 5): conv3h_kernel 6 x 1 (level 0) + 6 x 4 (level 1) + 6 x 9 (level 2)
+    want3h = {3: 84, 36: 84, 306: 84, 30: 54, 3000: 0, 3048: 6, 366: 0, 0: 0, 1: 0, 2: 0}[mode]
+    want6 = {3: 15, 36: 15, 306: 0, 366: 27, 3000: 21, 3048: 21}.get(mode)   # conv_wino6_kernel: levels 3 .. 5 = 15, 2 .. 5 = 21, 1 .. 5 = 27
     if mode == 3000:
         mode = 3
         eng.set_option("conv_direct_f16x3", 0)
-    want6 = {3: 21, 36: 27, 306: 0, 366: 27}.get(mode)  # 3x3 launches per net pass on conv_wino6_kernel (6 per level, 3 at the bottleneck)
+    elif mode == 3048:
+        mode = 3
+        eng.set_option("conv_direct_f16x3", 48)
     h3 = mode != 366
     if mode == 366:
         mode = 36

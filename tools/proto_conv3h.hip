@@ -80,6 +80,7 @@ static double ref_at(const std::vector<float> &x, const std::vector<float> &w, c
   return s;
 }
 
+static int g_bw = 32;      // strips per band (argv[7]: 32, 16, 8)
 static int g_alias = 0;   // 1: every batch item reads item 0's planes, 2: and writes item 0's output (cache-resident traffic: is the launch DRAM- or CU-bound?)
 static int run_shape(const Shape &sh, int abl, int order, int reps) {
   const int C = 48;
@@ -130,6 +131,12 @@ static int run_shape(const Shape &sh, int abl, int order, int reps) {
   a.act = sh.act;
   a.tilesT = (sh.T + 3) / 4;
   a.tilesF = (sh.F + 31) / 32;
+  a.bw = g_bw;
+  a.tps = a.tilesT * g_bw / 32;
+  if ((a.tilesT * g_bw) % 32 != 0) {
+    a.bw = 32;
+    a.tps = a.tilesT;
+  }
   long long *ddbg = nullptr;
   CK(hipMalloc(&ddbg, (512 + 4 * 2048) * 8));
   CK(hipMemset(ddbg, 0, (512 + 4 * 2048) * 8));
@@ -222,6 +229,132 @@ static int run_shape(const Shape &sh, int abl, int order, int reps) {
   return bad;
 }
 
+// A 96 -> 96 layer as four launches of the 48-channel kernel: for each half of the output channels, the first half of the input channels
+// (bias, no activation), then the second half ADDED to it (a.prev = the output itself) with the activation.
+static int run_shape96(const Shape &sh, int reps) {
+  const int C = 96;
+  const size_t nb = (size_t)C * sh.T * sh.F, n = nb * sh.B;
+  std::mt19937 rng(4321);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  std::uniform_real_distribution<float> ud(0.f, 1.f);
+  std::vector<float> w((size_t)C * C * 9), bias(C), x(nb);
+  for (int co = 0; co < C; ++co) {
+    const float cs = std::pow(10.f, 2.f * (ud(rng) - 0.5f)) * 0.035f;
+    for (int i = 0; i < C * 9; ++i) w[(size_t)co * C * 9 + i] = nd(rng) * cs;
+    bias[co] = nd(rng) * 0.1f;
+  }
+  for (int c = 0; c < C; ++c)
+    for (int t = 0; t < sh.T; ++t)
+      for (int f = 0; f < sh.F; ++f) x[((size_t)c * sh.T + t) * sh.F + f] = nd(rng) * std::pow(10.f, sh.spread * (std::sin(0.013f * f) * std::cos(0.21f * t)));
+  float *dx, *dy, *dbias;
+  CK(hipMalloc(&dx, n * 4));
+  CK(hipMalloc(&dy, n * 4));
+  CK(hipMalloc(&dbias, C * 4));
+  CK(hipMemset(dy, 0xff, n * 4));
+  for (int b = 0; b < sh.B; ++b) CK(hipMemcpy(dx + (size_t)b * nb, x.data(), nb * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dbias, bias.data(), C * 4, hipMemcpyHostToDevice));
+  uint32_t *dimg[2][2];
+  for (int ob = 0; ob < 2; ++ob)
+    for (int ib = 0; ib < 2; ++ib) {
+      std::vector<float> ws((size_t)48 * 48 * 9);
+      for (int co = 0; co < 48; ++co)
+        for (int ci = 0; ci < 48; ++ci)
+          for (int k = 0; k < 9; ++k) ws[((size_t)co * 48 + ci) * 9 + k] = w[((size_t)(ob * 48 + co) * C + ib * 48 + ci) * 9 + k];
+      std::vector<uint32_t> img;
+      conv3h_pack(ws.data(), img);
+      CK(hipMalloc(&dimg[ob][ib], img.size() * 4));
+      CK(hipMemcpy(dimg[ob][ib], img.data(), img.size() * 4, hipMemcpyHostToDevice));
+    }
+  long long *ddbg = nullptr;
+  CK(hipMalloc(&ddbg, (512 + 4 * 2048) * 8));
+  auto go = [&]() {
+    for (int ob = 0; ob < 2; ++ob)
+      for (int ib = 0; ib < 2; ++ib) {
+        Conv3hArgs a{};
+        a.x = dx + (size_t)ib * 48 * sh.T * sh.F;
+        a.y = dy + (size_t)ob * 48 * sh.T * sh.F;
+        a.prev = ib ? a.y : nullptr;
+        a.wimg = reinterpret_cast<const u32x4 *>(dimg[ob][ib]);
+        a.bias = ib ? nullptr : dbias + ob * 48;
+        a.B = sh.B;
+        a.T = sh.T;
+        a.F = sh.F;
+        a.x_bstride = a.y_bstride = (int64_t)nb;
+        a.act = ib ? sh.act : ACT_NONE;
+        a.tilesT = (sh.T + 3) / 4;
+        a.tilesF = sh.F / 32;
+        a.bw = g_bw;
+        a.tps = a.tilesT * g_bw / 32;
+        if ((a.tilesT * g_bw) % 32 != 0) {
+          a.bw = 32;
+          a.tps = a.tilesT;
+        }
+        a.dbg = ddbg;
+        launch<0>(a, 0);
+      }
+  };
+  go();
+  CK(hipDeviceSynchronize());
+  int bad = 0;
+  std::vector<float> y0(nb), yl(nb);
+  CK(hipMemcpy(y0.data(), dy, nb * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(yl.data(), dy + (size_t)(sh.B - 1) * nb, nb * 4, hipMemcpyDeviceToHost));
+  if (memcmp(y0.data(), yl.data(), nb * 4) != 0) {
+    printf("  %s: batch item %d differs from item 0\n", sh.name, sh.B - 1);
+    ++bad;
+  }
+  double num = 0, den = 0, worst = 0;
+  size_t cnt = 0;
+  auto check = [&](int co, int t, int f) {
+    double s = bias[co], mag = std::fabs((double)bias[co]);
+    for (int ci = 0; ci < C; ++ci)
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tt = t + ky - 1, ff = f + kx - 1;
+          if (tt < 0 || tt >= sh.T || ff < 0 || ff >= sh.F) continue;
+          const double p = (double)w[((size_t)co * C + ci) * 9 + ky * 3 + kx] * (double)x[((size_t)ci * sh.T + tt) * sh.F + ff];
+          s += p;
+          mag += std::fabs(p);
+        }
+    if (sh.act == ACT_RELU && s < 0) s = 0;
+    const double g = y0[((size_t)co * sh.T + t) * sh.F + f], d = g - s;
+    num += d * d;
+    den += s * s;
+    worst = std::max(worst, std::fabs(d) / (mag + 1e-30));
+    if (!(std::fabs(d) <= 2e-6 * mag + 1e-30)) {
+      if (bad < 8) printf("  %s: mismatch at co %d t %d f %d: got %.9g want %.9g\n", sh.name, co, t, f, g, s);
+      ++bad;
+    }
+    ++cnt;
+  };
+  if (sh.full_check) {
+    for (int co = 0; co < C; ++co)
+      for (int t = 0; t < sh.T; ++t)
+        for (int f = 0; f < sh.F; ++f) check(co, t, f);
+  } else {
+    std::mt19937 r2(99);
+    for (int i = 0; i < 20000; ++i) check((int)(r2() % C), (int)(r2() % sh.T), (int)(r2() % sh.F));
+  }
+  printf("  %s (96 channels, four launches): %zu outputs checked, rel RMS %.3e, worst |d| / sum |w x| %.3e, %s\n", sh.name, cnt, std::sqrt(num / std::max(den, 1e-300)), worst,
+         bad ? "FAIL" : "ok");
+  if (reps > 0) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    go();
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) go();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  %s: %.3f ms per 96 -> 96 layer (four launches), bw %d\n", sh.name, ms / reps, g_bw);
+  }
+  CK(hipFree(dx));
+  CK(hipFree(dy));
+  return bad;
+}
+
 int main(int argc, char **argv) {
   const int abl = argc > 1 ? atoi(argv[1]) : 0;
   const int order = argc > 2 ? atoi(argv[2]) : 0;
@@ -229,6 +362,7 @@ int main(int argc, char **argv) {
   const int reps = argc > 4 ? atoi(argv[4]) : 5;
   const int quick = argc > 5 ? atoi(argv[5]) : 0;      // 1: the timing shape only (profiling runs)
   g_alias = argc > 6 ? atoi(argv[6]) : 0;
+  g_bw = argc > 7 ? atoi(argv[7]) : 32;
   int bad = 0;
   if (abl == 0 && !quick) {
     const Shape small[] = {
@@ -241,6 +375,14 @@ int main(int argc, char **argv) {
     };
     for (const Shape &s : small)
       bad += run_shape(s, 0, 2, 0);
+  }
+  if (quick == 2) {   // level 1 as four launches
+    const Shape s96[] = {{"small96 2x8x64", 2, 8, 64, ACT_RELU, 1, 0.f}, {"ragged96 1x18x96", 1, 18, 96, ACT_NONE, 1, 2.f}};
+    for (const Shape &s : s96) bad += run_shape96(s, 0);
+    const Shape l1 = {"level 1", Bt, 128, 1536, ACT_RELU, 0, 1.f};
+    bad += run_shape96(l1, reps);
+    printf(bad ? "FAILED (%d)\n" : "all ok\n", bad);
+    return bad ? 1 : 0;
   }
   const Shape l0 = {"level 0", Bt, 256, 3072, ACT_RELU, 0, 1.f};
   bad += run_shape(l0, abl, order, reps);
