@@ -103,6 +103,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--siblings", type=int, default=1, help="1: append short htdemucs / BS-Roformer / VR / hdemucs lines (N = 1 only)")
     ap.add_argument("--file-level", type=int, default=1, help="1: time Separator-level separate(wav) -> stem files after the timed region (N = 1 only)")
+    ap.add_argument("--no-graph", action="store_true", help="--mode chunks: launch the rank's chunk range eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-arith-ab", action="store_true", help="skip the fp32-exact arithmetic A/B after the timed region (N = 1 only)")
     ap.add_argument("--no-overlap", action="store_true", help="blocking gather (A/B of the gather / compute overlap)")
     ap.add_argument("--config5", action="store_true", help="BASELINE config 5 preset: --mode files --songs-per-rank 8 (64 songs on 8 GPUs)")
@@ -333,7 +334,7 @@ def main():
         from audio_separator_amd.sharding import ShardWorkspace
         mix = torch.from_numpy(O.synth_mix(N, seed=0)).to(dev)           # the same song on every rank
         adapter = HipEngineAdapter(eng)
-        shard_ws = ShardWorkspace()          # local / slab / out allocated once: the loop times compute + gather + fold
+        shard_ws = ShardWorkspace(graph=not args.no_graph)   # local / slab / out allocated once: the loop times compute + gather + fold; the rank's chunk-range compute replays a captured hipGraph from its third call on
 
         def step(k):
             sharded_demix(adapter, mix, workspace=shard_ws)
@@ -408,6 +409,7 @@ def main():
             comm["gather_ms"] = round(shard_ws.timings["gather_ms"], 3)
             comm["fold_ms"] = round(shard_ws.timings["fold_ms"], 3)
             comm["compute_ms"] = round(shard_ws.timings["compute_ms"], 3)
+        comm["graph"] = {"enabled": shard_ws.graph, "replays": shard_ws.graph_replays, "error": shard_ws.graph_error}
         cs = plan["chunk_size"]
         # local fold: (world - 1) seam chunks point-to-point + the folded slabs of the other ranks to rank 0
         comm["gather_bytes_per_step"] = (world - 1) * 2 * cs * 4 + int(2 * N * 4 * (world - 1) / world)
@@ -725,6 +727,8 @@ def dry_run(args, world, rank):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.mode == "chunks":
+        return dry_run_chunks(args, world, rank, use_dist)
     n = 4096
     S = args.songs_per_rank
     mixes = [torch.full((2, n), float(100 * rank + s)) for s in range(S)]
@@ -763,6 +767,72 @@ def dry_run(args, world, rank):
                                    "launcher": "self" if os.environ.get("ASX_BENCH_LAUNCHED") == "1" else
                                    ("external" if "WORLD_SIZE" in os.environ else None),
                                    "gather_bytes_per_step": pipe.gather_bytes_per_step}})
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def dry_run_chunks(args, world, rank, use_dist):
+    """--mode chunks on CPU: the SAME sharded_demix (chunk ranges, seam chunks to the right neighbour, local fold of the own sample range,
+    one gather of [2, N / G] slabs, ShardWorkspace reused over the steps) as the GPU run, over gloo, with a stand-in engine: 55 chunks of
+    4096 samples at stride 3072, each the song's own samples under a strictly positive window, folded by a per-sample gather with the
+    analytic divider -- so the folded song must come back equal to the input on rank 0, whichever rank computed which chunk.  The
+    workspace poisons (NaN) every chunk slot a rank does not hold: a fold that read a foreign chunk would show."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from audio_separator_amd.sharding import ShardWorkspace, sharded_demix, partition_chunks
+
+    class StandIn:
+        local_fold = True
+        C, STEP, NK = 4096, 3072, 55
+
+        def __init__(self):
+            self.w = (0.25 + torch.hann_window(self.C, periodic=False, dtype=torch.float64)).to(torch.float32)
+            self.calls = 0
+
+        def plan(self, n):
+            return {"chunk_size": self.C, "n_chunks": self.NK, "step": self.STEP, "padded_len": (self.NK - 1) * self.STEP + self.C, "trim": 0}
+
+        def demix_chunks(self, mix, n, k0, k1, out):
+            self.calls += 1
+            pad = torch.zeros((2, (self.NK - 1) * self.STEP + self.C), dtype=torch.float32)
+            pad[:, :n] = mix
+            for k in range(k0, k1):
+                out[k - k0].copy_(pad[:, k * self.STEP:k * self.STEP + self.C] * self.w)
+
+        def finalize(self, chunks, n, out):
+            L = (self.NK - 1) * self.STEP + self.C
+            acc = torch.zeros((2, L), dtype=torch.float64)
+            div = torch.zeros(L, dtype=torch.float64)
+            for k in range(self.NK):                  # a per-sample gather in chunk order: foreign (NaN) chunks land only outside the rank's range
+                acc[:, k * self.STEP:k * self.STEP + self.C] += chunks[k].to(torch.float64)
+                div[k * self.STEP:k * self.STEP + self.C] += self.w.to(torch.float64)
+            out.copy_((acc / div)[:, :n].to(torch.float32))
+
+    ad = StandIn()
+    n = (ad.NK - 1) * ad.STEP + ad.C - 1000
+    g = torch.Generator().manual_seed(0)
+    mix = torch.randn((2, n), generator=g, dtype=torch.float32)         # the same song on every rank
+    ws = ShardWorkspace(poison=True)
+    total = args.warmup + args.steps
+    worst, ok = 0.0, True
+    for k in range(total):
+        out = sharded_demix(ad, mix, workspace=ws)
+        if rank == 0:
+            ok = ok and out is not None and bool(torch.isfinite(out).all())
+            worst = max(worst, float((out - mix).abs().max())) if out is not None else float("inf")
+        else:
+            ok = ok and out is None
+    if use_dist:
+        dist.barrier()
+    ranges = partition_chunks(ad.NK, world)
+    if rank == 0:
+        emit({"metric": METRIC, "value": None, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "dry": True, "mode": "chunks", "fold_ok": bool(ok and worst < 1e-5), "fold_max_abs_err": worst, "calls": total,
+              "demix_calls_rank0": ad.calls, "chunk_ranges": ranges, "scaling": "strong",
+              "rccl": {"world_size": dist.get_world_size() if use_dist else 1, "backend": "gloo" if use_dist else None,
+                       "launcher": "self" if os.environ.get("ASX_BENCH_LAUNCHED") == "1" else ("external" if "WORLD_SIZE" in os.environ else None),
+                       "gather_bytes_per_step": (world - 1) * 2 * ad.C * 4 + int(2 * n * 4 * (world - 1) / world)}})
     if use_dist:
         dist.destroy_process_group()
 

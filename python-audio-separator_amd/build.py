@@ -10,6 +10,11 @@ DEPS = [SRC] + sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.
        [os.path.join(os.path.dirname(HERE), "include", "asx.h")]
 OUT = os.path.join(HERE, "libasx.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result"]
+# The default library carries the shipped kernel of every family plus one fp32-MFMA reference each (the in-library A/B); the superseded generations
+# -- conv_wino_kernel, conv_wino2_kernel, conv_winos_kernel, attention_kernel, the ablation instantiations of conv_wino3_kernel / tdf2_kernel /
+# tdf3_kernel -- are compiled in only with --experimental (or ASX_EXPERIMENTAL=1): build time and size, profiles/NOTES.md round 6.
+if os.environ.get("ASX_EXPERIMENTAL", "0") not in ("", "0") or "--experimental" in sys.argv:
+    FLAGS = FLAGS + ["-DASX_EXPERIMENTAL_KERNELS"]
 
 
 def hipcc_path():

@@ -28,7 +28,9 @@
 #include "kernels_gemm2.h"
 #include "kernels_gemm3.h"
 #include "kernels_wino.h"
-#include "kernels_winos.h"
+#ifdef ASX_EXPERIMENTAL_KERNELS
+#include "kernels_winos.h"   // weight-stationary Winograd: measured slower (profiles/NOTES.md round 4)
+#endif
 #include "kernels_wino6.h"
 #include "kernels_conv3h.h"
 #ifndef ASX_TDF2_DEFAULT
@@ -2069,10 +2071,17 @@ int asx_ht_bag_finish_dev(asx_engine *e, const float *est_dev, const float *tota
 int asx_set_option(asx_engine *e, const char *key, int32_t value) {
   REQUIRE(e && key, "asx_set_option: null argument");
   if (!strcmp(key, "winograd")) {
+#ifndef ASX_EXPERIMENTAL_KERNELS
+    REQUIRE(value <= 0 || value == 3, "asx_set_option: winograd = %d names a superseded kernel generation that only an experimental build carries "
+            "(python build.py --experimental); this library has 0 (direct kernel) and 3 (the default)", (int)value);
+#endif
     e->winograd = value < 0 ? 0 : (int)value;
     return ASX_OK;
   }
   if (!strcmp(key, "winograd_stationary")) {
+#ifndef ASX_EXPERIMENTAL_KERNELS
+    REQUIRE(value <= 0, "asx_set_option: the weight-stationary Winograd kernel (measured slower) is in experimental builds only (python build.py --experimental)");
+#endif
     e->winos = value < 0 ? 0 : (int)value;
     return ASX_OK;
   }

@@ -176,11 +176,19 @@ struct asx_engine {
   // 3x3 / pad-1 convs of the ConvTDFNet and TFC-TDF-v3 nets: 3 = Winograd F(2x2,3x3) (conv_wino3_kernel, the default), 0 = the
   // direct kernel (conv_dma_kernel), 1 / 2 = the earlier Winograd generations (kept for A/B runs).  ASX_WINOGRAD or
   // asx_set_option("winograd", n).
+#ifdef ASX_EXPERIMENTAL_KERNELS
   int winograd = getenv("ASX_WINOGRAD") ? std::max(0, atoi(getenv("ASX_WINOGRAD"))) : 3;
+#else   // generations 1 / 2 are not in this build: anything but 0 means the default
+  int winograd = getenv("ASX_WINOGRAD") ? (atoi(getenv("ASX_WINOGRAD")) <= 0 ? 0 : 3) : 3;
+#endif
   // 1: layers with Cin <= 96 run the weight-stationary Winograd kernel (conv_winos_kernel, kernels_winos.h) when the option above
   // is 3; 0 (default -- the stationary form measured 3-8 % slower, profiles/NOTES.md round 4): conv_wino3_kernel everywhere.
   // ASX_WINOS or asx_set_option("winograd_stationary", n).
+#ifdef ASX_EXPERIMENTAL_KERNELS
   int winos = getenv("ASX_WINOS") ? std::max(0, atoi(getenv("ASX_WINOS"))) : 0;
+#else
+  int winos = 0;
+#endif
   // 1 (default): row GEMMs, channels-last convolutions (GATHER mode) and attention of THIS engine run the bf16 x 6 kernels when their
   // shapes allow (kernels_gemm3.h); 0: the fp32-MFMA kernels.  ASX_GEMM_BF16X6 or asx_set_option("gemm_bf16x6", n).
   int gemm_bf16x6 = getenv("ASX_GEMM_BF16X6") ? atoi(getenv("ASX_GEMM_BF16X6")) : 1;

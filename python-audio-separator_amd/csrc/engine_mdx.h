@@ -131,6 +131,7 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
             dst3[(a * 4 + bb) * 3 + col / 16] = (float)U[a][bb];
           }
       }
+#ifdef ASX_EXPERIMENTAL_KERNELS
     if (wino_mode == 1) {
       CHK(L.wu.ensure(wu.size() * 4));
       HIPCHK(hipMemcpy(L.wu.p, wu.data(), wu.size() * 4, hipMemcpyHostToDevice));
@@ -139,6 +140,9 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
       CHK(L.wu2.ensure(wu2.size() * 4));
       HIPCHK(hipMemcpy(L.wu2.p, wu2.data(), wu2.size() * 4, hipMemcpyHostToDevice));
     }
+#else
+    (void)wino_mode;
+#endif
     CHK(L.wu3.ensure(wu3.size() * 4));
     HIPCHK(hipMemcpy(L.wu3.p, wu3.data(), wu3.size() * 4, hipMemcpyHostToDevice));
     // bf16 x 6 image (kernels_wino6.h) for every layer wide enough to be worth a 32-channel stage; which layers RUN on it is the
@@ -173,7 +177,11 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
       HIPCHK(hipMemcpy(L.w3h.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
     }
     // weight-stationary image: only where all of U fits the registers of eight waves (Cin <= 96) without much zero padding
+    L.wus_ks = 0;
+#ifdef ASX_EXPERIMENTAL_KERNELS
     L.wus_ks = (L.cin > 40 && L.cin <= 48) ? 12 : ((L.cin > 88 && L.cin <= 96) ? 24 : 0);
+#endif
+#ifdef ASX_EXPERIMENTAL_KERNELS
     if (L.wus_ks) {
       const size_t per = (size_t)8 * (6 * L.wus_ks / 4) * 64 * 4;
       std::vector<float> wus((size_t)L.wu_cg * per, 0.f);
@@ -193,6 +201,7 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
       CHK(L.wus.ensure(wus.size() * 4));
       HIPCHK(hipMemcpy(L.wus.p, wus.data(), wus.size() * 4, hipMemcpyHostToDevice));
     }
+#endif
   }
   const int nb = (L.kind == CK_UP) ? CT * 16 : std::max(L.cg * NW, ((L.cout + 47) / 48) * 48);
   std::vector<float> bp(nb, 0.f);
@@ -288,6 +297,7 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
   const bool dma = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (a.x_bstride % 4 == 0) &&
                    getenv("ASX_NO_DMA") == nullptr;
   const ConvArgs &d = a;
+#ifdef ASX_EXPERIMENTAL_KERNELS   // measured-and-rejected generations (profiles/NOTES.md): python build.py --experimental, or ASX_EXPERIMENTAL=1 in the environment of the build
   if (L.kind == CK_3X3 && e->winograd == 3 && e->winos == 1 && dma && L.wus.p != nullptr && a.Fo % 32 == 0 && v.res == nullptr &&
       (a.act == ACT_RELU || a.act == ACT_NONE) && (int64_t)L.cin * T * F < ((int64_t)1 << 30)) {
     // weight-stationary Winograd (kernels_winos.h): a workgroup walks a 32-pixel-wide column strip, one tile row per step
@@ -330,6 +340,7 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     if (ragged) return k12 ? gos(&conv_winos_kernel<12, 0, true>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 0, true>, WinoSCfg<24>::LDS_BYTES);
     return k12 ? gos(&conv_winos_kernel<12, 0, false>, WinoSCfg<12>::LDS_BYTES) : gos(&conv_winos_kernel<24, 0, false>, WinoSCfg<24>::LDS_BYTES);
   }
+#endif
   if (L.kind == CK_3X3 && e->winograd == 3 && e->gemm_bf16x6 > 0 && e->gemm_f16x3 > 0 && e->conv3h > 0 && L.cin <= e->conv3h && L.w3h.p != nullptr && dma &&
       v.res == nullptr && (a.act == ACT_RELU || a.act == ACT_NONE) && F % 32 == 0 && (int64_t)Conv3hCfg::C * T * F < ((int64_t)1 << 29) &&
       a.y_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
@@ -428,10 +439,6 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     wa.tilesT = (a.To + Wino3Cfg::TH - 1) / Wino3Cfg::TH;
     wa.tilesF = (a.Fo + Wino3Cfg::TW - 1) / Wino3Cfg::TW;
     const int nb = wa.CG * wa.tilesT * wa.tilesF * B;
-    static const int abl3 = getenv("ASX_WINO_ABL") ? atoi(getenv("ASX_WINO_ABL")) : 0;   // timing probes (results invalid)
-    // A/B builds: 6 (default): 4-channel stages x 2 LDS buffers, raw planes at an odd float stride; 5 / 4: rings of 3 / 4 buffers
-    // (two / three stages of DMA in flight, counted vmcnt); 0 / 2: 4 / 3 buffers at the even stride; 1: 8-channel stages x 2 buffers
-    static const int wcfg = getenv("ASX_WINO_CFG") ? atoi(getenv("ASX_WINO_CFG")) : 6;
     auto go = [&](auto kern, int lds, int stages) {
       {
         static std::mutex attr_mutex;            // engines may be driven from several host threads (one per bag member / rank)
@@ -443,6 +450,11 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
       wa.NCI = stages;
       return timed(e, cls, flops, bytes, s, [&]() { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, s, wa); });
     };
+#ifdef ASX_EXPERIMENTAL_KERNELS
+    static const int abl3 = getenv("ASX_WINO_ABL") ? atoi(getenv("ASX_WINO_ABL")) : 0;   // timing probes (results invalid)
+    // A/B builds: 6 (default): 4-channel stages x 2 LDS buffers, raw planes at an odd float stride; 5 / 4: rings of 3 / 4 buffers
+    // (two / three stages of DMA in flight, counted vmcnt); 0 / 2: 4 / 3 buffers at the even stride; 1: 8-channel stages x 2 buffers
+    static const int wcfg = getenv("ASX_WINO_CFG") ? atoi(getenv("ASX_WINO_CFG")) : 6;
     if (abl3) {
       switch (abl3) {
         case 1: return go(&conv_wino3_kernel<1>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
@@ -457,8 +469,10 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     if (wcfg == 0) return go(&conv_wino3_kernel<0>, Wino3Cfg::LDS_BYTES, L.wu3_nci);
     if (wcfg == 4) return go(&conv_wino3_kernel<0, 4, 4, 1>, Wino3CfgT<4, 4, 1>::LDS_BYTES, L.wu3_nci);
     if (wcfg == 5) return go(&conv_wino3_kernel<0, 4, 3, 1>, Wino3CfgT<4, 3, 1>::LDS_BYTES, L.wu3_nci);
+#endif
     return go(&conv_wino3_kernel<0, 4, 2, 1>, Wino3CfgT<4, 2, 1>::LDS_BYTES, L.wu3_nci);
   }
+#ifdef ASX_EXPERIMENTAL_KERNELS
   if (L.kind == CK_3X3 && e->winograd >= 2 && dma && L.wu2.p != nullptr) {
     ConvArgs wa = a;
     wa.wp = L.wu2.f();
@@ -495,6 +509,7 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
       hipLaunchKernelGGL(conv_wino_kernel, dim3(nb), dim3(256), WinoCfg::LDS_BYTES, s, wa);
     });
   }
+#endif
 #define ASX_CONV_CASE(KH, KW, S, PAD, NR, KC, RPW, EPI)                                      \
   do {                                                                                       \
     if (dma) launch_conv_dma_t<ConvDmaCfg<KH, KW, S, PAD, NR, KC, RPW, EPI>>(d, nblk, s);    \
@@ -624,6 +639,7 @@ static void launch_tdf2_abl(const TdfDmaArgs &a, hipStream_t s) {
 }
 template <int NREP, int MREP>
 static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
+#ifdef ASX_EXPERIMENTAL_KERNELS
   static const int abl = getenv("ASX_TDF2_ABL") ? atoi(getenv("ASX_TDF2_ABL")) : 0;   // ablation builds exist for the 128 x 192 tile only
   if constexpr (NREP == 3 && MREP == 8) {
     switch (abl) {
@@ -646,6 +662,7 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
       if (bk16 == 2) return launch_tdf2_abl<3, 4, 0, 16>(a, s);
     }
   }
+#endif
   launch_tdf2_abl<NREP, MREP, 0>(a, s);
 }
 
@@ -684,6 +701,15 @@ static const u32x4 *w3_image(asx_engine *e, const float *w, int N, int K, hipStr
   std::lock_guard<std::mutex> lk(e->w3_mu);
   for (auto &en : e->w3)
     if (en.w == w && en.N == N && en.K == K && en.cin == cin && en.kind == kind) return reinterpret_cast<const u32x4 *>(en.img);
+  {
+    // the build below synchronises the stream: inside a hipGraph capture that would invalidate the capture.  Say so and let the
+    // caller run the fp32 kernel of this launch -- a capture belongs behind one warm-up forward (and behind any asx_set_option that changes the arithmetic)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      set_err("split weight image of a %d x %d matrix requested while the stream is capturing: run one forward (after the last asx_set_option) before the capture", N, K);
+      return nullptr;
+    }
+  }
   const int nst = cin > 0 ? (K / cin) * ((cin + 31) / 32) : 0;
   const int ntiles = (N + 15) / 16, nk = cin > 0 ? ((nst + 1) & ~1) : ((K + 63) / 64) * 2;   // an even number of 32-wide stages (zero padded)
   W3Entry en{w, N, K, cin, kind, nullptr};
@@ -764,7 +790,8 @@ static bool launch_tdf3_gather_auto(asx_engine *e, const TdfDmaArgs &d, const Ro
 template <int NREP, int MREP>
 static bool launch_tdf3(asx_engine *e, const TdfDmaArgs &a, hipStream_t s) {
   static const int abl0 = getenv("ASX_TDF3_ABL") ? atoi(getenv("ASX_TDF3_ABL")) : 0;
-  static const int only_n = getenv("ASX_F16X3_N") ? atoi(getenv("ASX_F16X3_N")) : 0;   // bring-up: fp16 x 3 on the launches with this N only (< 0: all but)
+  // ASX_F16X3_N (bisection aid, kept: tools/debug_rof_race.py found the rotary-epilogue anomaly with it): fp16 x 3 on the launches with this N only (< 0: all but)
+  static const int only_n = getenv("ASX_F16X3_N") ? atoi(getenv("ASX_F16X3_N")) : 0;
   const bool h = e->gemm_f16x3 > 0 && abl0 == 0 && (only_n == 0 || (only_n > 0 ? a.N == only_n : a.N != -only_n));
   const u32x4 *w3 = w3_image(e, a.w, a.N, a.K, s, 0, h ? 1 : 0);
   if (!w3) return false;                               // out of memory for the image: the caller falls back to the fp32 kernels
@@ -773,6 +800,7 @@ static bool launch_tdf3(asx_engine *e, const TdfDmaArgs &a, hipStream_t s) {
     launch_tdf3_abl<NREP, MREP, 0, true>(a, w3, s);
     return true;
   }
+#ifdef ASX_EXPERIMENTAL_KERNELS
   static const int abl = getenv("ASX_TDF3_ABL") ? atoi(getenv("ASX_TDF3_ABL")) : 0;   // ablation builds exist for the 128 x 192 tile only
   if constexpr (NREP == 3 && MREP == 8) {
     switch (abl) {
@@ -784,6 +812,7 @@ static bool launch_tdf3(asx_engine *e, const TdfDmaArgs &a, hipStream_t s) {
       default: break;
     }
   }
+#endif
   launch_tdf3_abl<NREP, MREP, 0>(a, w3, s);
   return true;
 }

@@ -339,7 +339,11 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
       const int qtiles = (aa.len + 63) / 64;
       const double fl = 4.0 * (double)nseq * H * (double)aa.len * aa.len * c.dim_head;
       CHK(timed(e, ASX_PROF_CONV1X1, fl, 4.0 * M * 4 * inner, s, [&]() {
+#ifdef ASX_EXPERIMENTAL_KERNELS
         static const bool v1 = getenv("ASX_ATTN_V1") && atoi(getenv("ASX_ATTN_V1")) != 0;   // the 4-byte-fragment kernel (A/B)
+#else
+        constexpr bool v1 = false;
+#endif
         static const bool attn_db = getenv("ASX_ATTN_DB") && atoi(getenv("ASX_ATTN_DB")) != 0;   // A/B (default off until measured)
         static const int qw = getenv("ASX_ATTN_QW") ? atoi(getenv("ASX_ATTN_QW")) : 1;   // 2: 128 queries per workgroup (measured slower: 357 vs 328 ms)
         // bf16 x 6 form (kernels_rof.h: attention6_kernel) under the process-wide switch of the row GEMM; ASX_ATTN6=0: A/B
@@ -363,8 +367,11 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
           if (h3) g_attn6h_launches.fetch_add(1);
           e->prof_nprod = h3 ? 3 : 6;
         } else
+#ifdef ASX_EXPERIMENTAL_KERNELS
         if (v1) hipLaunchKernelGGL(attention_kernel, dim3(qtiles, H, (unsigned)nseq), dim3(256), 0, s, aa);
-        else if (qw >= 2 && aa.len > 64) {
+        else
+#endif
+        if (qw >= 2 && aa.len > 64) {
           AttnArgs a2 = aa;
           a2.nqt = (aa.len + 127) / 128;
           hipLaunchKernelGGL(attention2_kernel<2>, dim3((unsigned)(a2.nqt * H * nseq)), dim3(256), 0, s, a2);

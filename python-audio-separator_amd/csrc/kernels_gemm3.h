@@ -143,9 +143,16 @@ __device__ __forceinline__ float wave_max64(float v) {
 
 // v *= 2^e in place (tied operands; the epilogue's way back to the operands' own scale)
 __device__ __forceinline__ void ldexp4_inplace(f32x4 &v, int e) {
+#if defined(ASX_LDEXP_ASM)          // the form of round 5 (A/B builds of tools/proto_gemm3.hip only): hipcc pads no MFMA -> VALU wait states in front of an asm statement
   asm volatile("v_ldexp_f32 %0, %0, %4\n\tv_ldexp_f32 %1, %1, %4\n\tv_ldexp_f32 %2, %2, %4\n\tv_ldexp_f32 %3, %3, %4"
                : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)
                : "v"(e));
+#else
+  v.x = __builtin_ldexpf(v.x, e);
+  v.y = __builtin_ldexpf(v.y, e);
+  v.z = __builtin_ldexpf(v.z, e);
+  v.w = __builtin_ldexpf(v.w, e);
+#endif
 }
 
 // exponent e with m 2^e in [2^14, 2^15) (m > 0 finite); m == 0 gives 15
@@ -257,7 +264,8 @@ struct RowGather {
 };
 
 // H: the fp16 x 3 arithmetic (above) instead of bf16 x 6 -- two parts per operand, three MFMAs per product, x registers double
-// buffered (a stage's rows are fetched a whole stage before their maximum is needed), 32 more bytes of LDS for the per-wave maxima.
+// buffered (a stage's rows are fetched a whole stage before their maximum is needed), 12 * BM more bytes of LDS: the exponent-drop table of either
+// stage parity and the rows' current exponents (de_tab[2][BM], ex_tab[BM]).
 template <int NREP, int MREP, int ABL = 0, bool GATHER = false, bool H = false>
 __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 *__restrict__ w3, RowGather gq) {
   constexpr int BM = 16 * MREP, BN = 64 * NREP;

@@ -1359,7 +1359,7 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void mha6_kernel(MhaArgs a)
 #pragma unroll
         for (int g = 0; g < QW; ++g) {
           u32x4 ph, pl;
-          split2h_oct(st[g][2 * kp2], st[g][2 * kp2 + 1], 0, ph, pl);   // probabilities: no exponent
+          split2h_oct(st[g][2 * kp2], st[g][2 * kp2 + 1], 14, ph, pl);  // probabilities x 2^14 (kernels_rof.h: attention6_kernel); undone with V's exponent
           p_h[g] = __builtin_bit_cast(f16x8, ph);
           p_l[g] = __builtin_bit_cast(f16x8, pl);
         }
@@ -1415,10 +1415,10 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void mha6_kernel(MhaArgs a)
         f32x4 o = acc_o[g][dt];
         o *= inv;
         if constexpr (H) {                             // V's exponent (exact)
-          o.x = __builtin_ldexpf(o.x, -ev_run);
-          o.y = __builtin_ldexpf(o.y, -ev_run);
-          o.z = __builtin_ldexpf(o.z, -ev_run);
-          o.w = __builtin_ldexpf(o.w, -ev_run);
+          o.x = __builtin_ldexpf(o.x, -ev_run - 14);
+          o.y = __builtin_ldexpf(o.y, -ev_run - 14);
+          o.z = __builtin_ldexpf(o.z, -ev_run - 14);
+          o.w = __builtin_ldexpf(o.w, -ev_run - 14);
         }
         *reinterpret_cast<f32x4 *>(orow + dt * 16 + 4 * lk) = o;
       }

@@ -106,6 +106,7 @@ constexpr int ATT_QS = 66;  // LDS row strides (floats): Q/K == 2 (mod 32), V ==
 constexpr int ATT_VS = 68;
 constexpr int ATT_LDS_BYTES = (64 * ATT_QS * 2 + 64 * ATT_VS) * 4;
 
+#ifdef ASX_EXPERIMENTAL_KERNELS   // first attention generation (ASX_ATTN_V1): superseded by attention2_kernel / attention6_kernel; not in the default build
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   __shared__ float lds[64 * ATT_QS * 2 + 64 * ATT_VS];
   float *Qs = lds, *Ks = lds + 64 * ATT_QS, *Vs = lds + 128 * ATT_QS;
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     }
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // attention2_kernel: the same flash-style algorithm with 16-byte LDS fragment reads.  The MFMA k-steps are re-assigned so
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
 #pragma unroll
         for (int g = 0; g < QW; ++g) {
           u32x4 ph, pl;
-          split2h_oct(st[g][2 * kp], st[g][2 * kp + 1], 0, ph, pl);   // probabilities: no exponent
+          split2h_oct(st[g][2 * kp], st[g][2 * kp + 1], 14, ph, pl);  // probabilities (<= 1 behind the running maximum) x 2^14: the small ones stay clear of fp16's subnormals; undone with V's exponent
           p_h[g] = __builtin_bit_cast(f16x8, ph);
           p_l[g] = __builtin_bit_cast(f16x8, pl);
         }
@@ -778,10 +780,10 @@ __global__ __launch_bounds__(256, (QW == 1 ? 3 : 2)) void attention6_kernel(Attn
         f32x4 o = acc_o[g][dt];
         o *= inv;
         if constexpr (H) {                             // V's exponent (exact)
-          o.x = __builtin_ldexpf(o.x, -ev_run);
-          o.y = __builtin_ldexpf(o.y, -ev_run);
-          o.z = __builtin_ldexpf(o.z, -ev_run);
-          o.w = __builtin_ldexpf(o.w, -ev_run);
+          o.x = __builtin_ldexpf(o.x, -ev_run - 14);
+          o.y = __builtin_ldexpf(o.y, -ev_run - 14);
+          o.z = __builtin_ldexpf(o.z, -ev_run - 14);
+          o.w = __builtin_ldexpf(o.w, -ev_run - 14);
         }
         *reinterpret_cast<f32x4 *>(a.out + row * inner + h * 64 + dt * 16 + 4 * lk) = o;
       }

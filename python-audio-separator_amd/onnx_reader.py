@@ -366,6 +366,7 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
     # ("conv", k, stride, w[cout,cin,kh,kw], b, gn) | ("convT", w[cin,cout,2,2], b, gn) | ("lin", w[n,k], bias|None, scale, shift, gn);
     # gn = (gamma, beta) of a GroupNorm(2, c) behind the layer (weights then unfolded, scale / shift None), else None
     layers = []
+    norm_kind = []                                     # per layer: "bn" (BatchNorm folded), "gn" (GroupNorm behind it) or None (no norm at all)
     for idx, n in enumerate(nodes):
         if n.op == "Conv":
             w = np.asarray(inits[n.inputs[1]], np.float64)
@@ -382,6 +383,7 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
             if n.inputs[1] not in inits:
                 raise OnnxFormatError(f"{_where(n)}: weight is not a constant")
             layers.append(("conv", int(ks[0]), int(st[0]), w, b, gn))
+            norm_kind.append("bn" if j is not None else ("gn" if gn is not None else None))
         elif n.op == "ConvTranspose":
             w = np.asarray(inits[n.inputs[1]], np.float64)
             b = np.asarray(inits[n.inputs[2]], np.float64) if len(n.inputs) > 2 else np.zeros(w.shape[1])
@@ -390,6 +392,7 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
                 s, sh = _bn_affine(nodes[j], inits)
                 w, b = w * s[None, :, None, None], b * s + sh
             layers.append(("convT", w, b, gn_affine(idx) if j is None else None))
+            norm_kind.append("bn" if j is not None else ("gn" if layers[-1][-1] is not None else None))
         elif n.op == "MatMul":
             wname = n.inputs[1] if n.inputs[1] in inits else (n.inputs[0] if n.inputs[0] in inits else None)
             if wname is None:
@@ -407,9 +410,11 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
                 if gn is None:
                     raise OnnxFormatError(f"{_where(n)}: TDF Linear followed neither by BatchNormalization nor by the GroupNorm lowering")
                 layers.append(("lin", w, bias, None, None, gn))
+                norm_kind.append("gn")
                 continue
             s, sh = _bn_affine(nodes[jb], inits)
             layers.append(("lin", w, bias, s, sh, None))
+            norm_kind.append("bn")
         elif n.op == "Gemm":
             # Linear lowered as Reshape([-1, K]) -> Gemm(A, B, C) -> Reshape: Y = alpha * A * op(B) + beta * C
             if len(n.inputs) < 2 or n.inputs[1] not in inits or n.inputs[0] in inits:
@@ -430,9 +435,11 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
                 if gn is None:
                     raise OnnxFormatError(f"{_where(n)}: TDF Linear followed neither by BatchNormalization nor by the GroupNorm lowering")
                 layers.append(("lin", w, bias, None, None, gn))
+                norm_kind.append("gn")
                 continue
             s, sh = _bn_affine(nodes[jb], inits)
             layers.append(("lin", w, bias, s, sh, None))
+            norm_kind.append("bn")
 
     if len(layers) < 4 or layers[0][0] != "conv" or layers[0][1] != 1:
         raise OnnxFormatError("graph does not start with the 1x1 first_conv of ConvTDFNet")
@@ -440,11 +447,15 @@ def convtdf_from_onnx(path_or_bytes, dim_t: int | None = None):
     if stray:
         raise OnnxFormatError(f"{_where(stray[0])}: InstanceNormalization outside the GroupNorm(2, c) lowering of a conv / linear"
                               + (f" (and {len(stray) - 1} more)" if len(stray) > 1 else ""))
-    normed = [L for L in layers[:-1]]                  # every layer but the final conv carries a norm
-    kinds = {L[-1] is not None for L in normed}
+    # Every layer but the final conv carries a norm, all of one kind.  A conv WITHOUT a norm node counts as BatchNorm: torch's exporter folds an
+    # eval-mode BatchNorm into the Conv / ConvTranspose in front of it, so a folded norm and no norm at all are the same graph (ADVICE r5 asked for
+    # norm-less layers to be rejected: for convs they cannot be told apart; a Linear without either norm IS rejected above).  What can be
+    # checked: GroupNorm and BatchNorm layers never mix -- a GroupNorm graph has the lowering behind EVERY layer.
+    kinds = {"gn" if k == "gn" else "bn" for k in norm_kind[:-1]}
     if len(kinds) != 1:
-        raise OnnxFormatError("graph mixes BatchNorm and GroupNorm layers (or has layers without a norm); not a ConvTDFNet")
-    group = kinds.pop()
+        first_gn = norm_kind.index("gn")
+        raise OnnxFormatError(f"graph mixes GroupNorm layers (first: layer {first_gn}) with BatchNorm / norm-less ones; not a ConvTDFNet")
+    group = kinds.pop() == "gn"
     out: dict = {}
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
 

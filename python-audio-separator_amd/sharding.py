@@ -224,11 +224,42 @@ class ShardWorkspace:
     before folding, which proves on each call that the fold of the owned sample range reads none of them (the contract of
     ``local_fold`` below)."""
 
-    def __init__(self, timed: bool = False, poison: bool = False):
+    def __init__(self, timed: bool = False, poison: bool = False, graph: bool = False):
         self.key = None
         self.timed = timed
         self.poison = poison
         self.timings = {}
+        # graph: the rank's chunk-range compute (adapter.demix_chunks: ~130 kernel launches for 7 chunks of the HQ_3 net, a 25-30 ms step at 8 GPUs --
+        # where host launch jitter shows first) is captured into a hipGraph on its second call with the same arguments and replayed from then on;
+        # the first call runs eagerly (it sizes the engine's workspace and builds its weight images).  The collectives stay outside.
+        self.graph = graph
+        self._graphs = {}
+        self.graph_replays = 0
+        self.graph_error = None
+
+    def compute(self, adapter, mix, n, k0, k1, out):
+        """adapter.demix_chunks(mix, n, k0, k1, out), through a captured graph when `graph` is set and the tensors are on the GPU"""
+        if not self.graph or not mix.is_cuda or self.graph_error is not None:
+            return adapter.demix_chunks(mix, n, k0, k1, out)
+        import torch
+        key = (type(adapter).__name__, id(getattr(adapter, "engine", adapter)), mix.data_ptr(), int(n), int(k0), int(k1), out.data_ptr())
+        ent = self._graphs.get(key)
+        if ent is None:                                 # first call: eager
+            self._graphs[key] = "warm"
+            return adapter.demix_chunks(mix, n, k0, k1, out)
+        if ent == "warm":                               # second call: capture (nothing runs), then replay
+            try:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    adapter.demix_chunks(mix, n, k0, k1, out)
+                self._graphs[key] = ent = g
+            except Exception as e:                      # a capture the runtime refuses must never take the run down: stay eager
+                self.graph_error = f"{type(e).__name__}: {e}"
+                self._graphs.pop(key, None)
+                return adapter.demix_chunks(mix, n, k0, k1, out)
+        ent.replay()
+        self.graph_replays += 1
 
     def get(self, key, make):
         if self.key != key:
@@ -264,7 +295,10 @@ def _sharded_demix_local_fold(adapter, mix, plan, ranges, group, dst, workspace,
     if timed:
         ev[0].record()
     if k1 > k0:
-        adapter.demix_chunks(mix, n, k0, k1, allc[k0:k1])
+        if workspace is not None:
+            workspace.compute(adapter, mix, n, k0, k1, allc[k0:k1])
+        else:
+            adapter.demix_chunks(mix, n, k0, k1, allc[k0:k1])
     if timed:
         ev[1].record()
     # seam halos: chunk k goes to every LATER rank whose first chunk lies within h chunks of it (its right neighbour, unless
@@ -366,7 +400,10 @@ def sharded_demix(adapter, mix, group=None, dst: int = 0, workspace: ShardWorksp
     if timed:
         ev[0].record()
     if k1 > k0:
-        adapter.demix_chunks(mix, n, k0, k1, local[: k1 - k0])
+        if workspace is not None:
+            workspace.compute(adapter, mix, n, k0, k1, local[: k1 - k0])
+        else:
+            adapter.demix_chunks(mix, n, k0, k1, local[: k1 - k0])
     if timed:
         ev[1].record()
     if world == 1:

@@ -59,3 +59,34 @@ def test_single_rank_line():
     assert r.returncode == 0, r.stderr[-2000:]
     row = _line(r.stdout)
     assert row["n_gpus"] == 1 and row["rccl"]["world_size"] == 1
+
+
+def test_world_8_files_mode():
+    """First contact with eight ranks must be boring (VERDICT r5 #7a): the exact `bench.py --gpus 8 --mode files` code path -- self launch of
+    eight ranks, rendezvous on 127.0.0.1, FilesPipeline's double-buffered gather of every rank's stems to rank 0 -- over gloo on the CPU: one JSON
+    line, world size 8, every gathered buffer holding its own step's data of its own rank."""
+    r = _run([sys.executable, BENCH, "--gpus", "8", "--dry-gloo", "--mode", "files", "--steps", "3", "--warmup", "1", "--songs-per-rank", "2",
+              "--master-port", "29541"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    row = _line(r.stdout)
+    assert row["n_gpus"] == 8 and row["dry"] and row["mode"] == "files" and row["gather_ok"] and row["gathers_checked"] == 4 and row["gather_mismatches"] == []
+    assert {k: row["rccl"][k] for k in ("world_size", "backend", "launcher")} == {"world_size": 8, "backend": "gloo", "launcher": "self"}
+    assert row["rccl"]["gather_bytes_per_step"] == 7 * 2 * 2 * 4096 * 4          # seven foreign ranks' stems (2 songs x [2, 4096] floats each)
+    # the line's structure is the one-rank line's (same code, world 1)
+    one = _line(_run([sys.executable, BENCH, "--dry-gloo", "--mode", "files", "--steps", "3", "--warmup", "1", "--songs-per-rank", "2"]).stdout)
+    assert set(one) == set(row) and set(one["rccl"]) == set(row["rccl"]) and one["rccl"]["world_size"] == 1
+
+
+def test_world_8_chunks_mode():
+    """`bench.py --gpus 8 --mode chunks` (strong scaling of ONE song: 55 chunks in ranges of 7, 7, ..., 6, seam chunks to the right neighbour, local
+    fold, one gather of [2, N / 8] slabs) over gloo with the stand-in engine: the folded song equals the input on rank 0 while every chunk slot a
+    rank does not hold is NaN-poisoned."""
+    r = _run([sys.executable, BENCH, "--gpus", "8", "--dry-gloo", "--mode", "chunks", "--steps", "2", "--warmup", "1", "--master-port", "29543"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    row = _line(r.stdout)
+    assert row["n_gpus"] == 8 and row["dry"] and row["mode"] == "chunks" and row["fold_ok"], row
+    assert row["rccl"]["world_size"] == 8 and row["rccl"]["backend"] == "gloo" and row["scaling"] == "strong"
+    assert [tuple(x) for x in row["chunk_ranges"]] == [(0, 7), (7, 14), (14, 21), (21, 28), (28, 35), (35, 42), (42, 49), (49, 55)]
+    assert row["demix_calls_rank0"] == 3                                         # one range per call, three calls
+    one = _line(_run([sys.executable, BENCH, "--dry-gloo", "--mode", "chunks", "--steps", "2", "--warmup", "1"]).stdout)
+    assert set(one) == set(row) and one["fold_ok"] and one["rccl"]["world_size"] == 1

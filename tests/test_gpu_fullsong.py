@@ -83,3 +83,30 @@ def test_whole_workload_vs_oracle_digest(golden_dir, case):
     finally:
         for e in engines:
             e.close()
+
+
+@pytest.mark.parametrize("case", ["mdx_hq3", "htdemucs", "bs_roformer", "vr_2hp", "vr_2hp_sinc", "hdemucs_mmi", "mdx23c"])
+def test_whole_workload_is_deterministic(golden_dir, case):
+    """Every whole-workload case twice, on fresh engines: every output array bit for bit the same.  An RMS bar does not see a
+    kernel that returns a few hundred wrong elements of 76 M on every run, different ones each time -- the rotary epilogue of tdf3_kernel did
+    that in round 5 (profiles/r05_rotary_epilogue_race.txt; profiles/r06_rotary_isa.txt: the wait in front of the packed multiply is there, the
+    packed form fails with either descale, the scalar form does not) -- a bit-for-bit second run does, whichever kernel it is in."""
+    import torch
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    import audio_separator_amd as A
+    import fullsong_gpu as FG
+    z = np.load(os.path.join(golden_dir, f"fullsong_{case}_digest.npz"))
+    seconds = float(z["seconds"])
+    if case in ("htdemucs", "hdemucs_mmi", "bs_roformer"):
+        seconds = min(seconds, 61.0)                   # the same kernels on every chunk: a minute of them is enough for a determinism check
+    runs = []
+    for _ in range(2):
+        arrays, engines = FG.RUN[case](A, seconds, z)
+        runs.append({k: np.array(v, copy=True) for k, v in arrays.items()})
+        for e in engines:
+            e.close()
+    assert runs[0].keys() == runs[1].keys()
+    for k in runs[0]:
+        a, b = runs[0][k], runs[1][k]
+        same = np.array_equal(a, b) if a.dtype.kind != "f" else np.array_equal(a.view(np.uint32 if a.dtype == np.float32 else np.uint64), b.view(np.uint32 if b.dtype == np.float32 else np.uint64))
+        assert same, (case, k, int(np.sum(a != b)), "elements differ between two runs")
