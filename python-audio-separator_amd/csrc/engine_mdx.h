@@ -367,7 +367,8 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
       static bool attr_done = false;
       std::lock_guard<std::mutex> lock(attr_mutex);
       if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3h_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, Conv3hCfg::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3h_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Conv3hCfg::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3h_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Conv3hCfg::LDS_BYTES);
         attr_done = true;
       }
     }
@@ -392,7 +393,8 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
           ca.tilesF = tilesF;
           ca.bw = bw;
           ca.tps = (tilesT * bw) % 32 == 0 ? tilesT * bw / 32 : tilesT;
-          hipLaunchKernelGGL((conv3h_kernel<0>), dim3(256), dim3(512), Conv3hCfg::LDS_BYTES, s, ca);
+          if (ib > 0) hipLaunchKernelGGL((conv3h_kernel<0, true>), dim3(256), dim3(512), Conv3hCfg::LDS_BYTES, s, ca);
+          else hipLaunchKernelGGL((conv3h_kernel<0, false>), dim3(256), dim3(512), Conv3hCfg::LDS_BYTES, s, ca);
           g_conv3h_launches.fetch_add(1);
         }
     });

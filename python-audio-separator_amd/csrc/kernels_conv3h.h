@@ -217,7 +217,9 @@ __device__ __forceinline__ float ror8m(float keep, float from) {
 }
 
 // ABL (measurement-only builds, results are garbage): 2 = no global loads, 4 = no stores, 8 = no split / LDS writes, 32 = timeline stamps
-template <int ABL = 0>
+// ACC: accumulate mode (a.prev != nullptr): its own instantiation -- a run-time test in front of the six loads ended the MFMA scheduling region
+// and cost the plain launches a dozen register moves per tile
+template <int ABL = 0, bool ACC = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3h_kernel(Conv3hArgs a) {
   using CFG = Conv3hCfg;
   extern __shared__ float lds_f[];
@@ -456,8 +458,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 pprev[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) pprev[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto epi_chunk = [&](auto cc) {
-      constexpr int c = decltype(cc)::value;
+    auto epi_chunk = [&](auto kc) {                    // store k of the pending tile: channels (k / 2) * 16 + (k % 2) * 8 .. + 7, one whole 128-byte row each
+      constexpr int K = decltype(kc)::value, c = K / 2;
       const float sc = __builtin_ldexpf(1.0f, -(pend_e + ew[c]));   // exact power of two (|exponent| well inside the float range: weights and activations are)
       f32x4 v[2];
 #pragma unroll
@@ -467,21 +469,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         v[qq].z = __builtin_fmaf(pacc[qq][c].z, sc, bz[c]);
         v[qq].w = __builtin_fmaf(pacc[qq][c].w, sc, bz[c]);
       }
-      // channels c * 16 + 0..7 (store 2 c): lanes li < 8 keep their own pixel tile 0, lanes li >= 8 take pixel tile 1 of lane li - 8;
-      // channels c * 16 + 8..15 (store 2 c + 1): lanes li >= 8 keep their own pixel tile 1, lanes li < 8 take pixel tile 0 of lane li + 8
-      // (`v_mov_b32_dpp row_ror:8` written under a bank mask: one instruction per register)
-      f32x4 o0 = {ror8m<0xC>(v[0].x, v[1].x), ror8m<0xC>(v[0].y, v[1].y), ror8m<0xC>(v[0].z, v[1].z), ror8m<0xC>(v[0].w, v[1].w)};
-      f32x4 o1 = {ror8m<0x3>(v[1].x, v[0].x), ror8m<0x3>(v[1].y, v[0].y), ror8m<0x3>(v[1].z, v[0].z), ror8m<0x3>(v[1].w, v[0].w)};
-      o0 += pprev[2 * c];                                // zeros outside the accumulate mode
-      o1 += pprev[2 * c + 1];
+      // even k: lanes li < 8 keep their own pixel tile 0, lanes li >= 8 take pixel tile 1 of lane li - 8; odd k: lanes li >= 8 keep their own
+      // pixel tile 1, lanes li < 8 take pixel tile 0 of lane li + 8 (`v_mov_b32_dpp row_ror:8` written under a bank mask: one instruction per
+      // register).  Either half recomputes the eight scaled values it needs: sixteen VALU instructions per store, one store's worth per stage.
+      f32x4 o;
+      if constexpr (K % 2 == 0) o = (f32x4){ror8m<0xC>(v[0].x, v[1].x), ror8m<0xC>(v[0].y, v[1].y), ror8m<0xC>(v[0].z, v[1].z), ror8m<0xC>(v[0].w, v[1].w)};
+      else o = (f32x4){ror8m<0x3>(v[1].x, v[0].x), ror8m<0x3>(v[1].y, v[0].y), ror8m<0x3>(v[1].z, v[0].z), ror8m<0x3>(v[1].w, v[0].w)};
+      if constexpr (ACC) o += pprev[K];
       // ReLU or nothing, without a branch (a branch would end the MFMA scheduling region)
-      pend[2 * c] = (f32x4){fmaxf(o0.x, act_lo), fmaxf(o0.y, act_lo), fmaxf(o0.z, act_lo), fmaxf(o0.w, act_lo)};
-      pend[2 * c + 1] = (f32x4){fmaxf(o1.x, act_lo), fmaxf(o1.y, act_lo), fmaxf(o1.z, act_lo), fmaxf(o1.w, act_lo)};
+      pend[K] = (f32x4){fmaxf(o.x, act_lo), fmaxf(o.y, act_lo), fmaxf(o.z, act_lo), fmaxf(o.w, act_lo)};
     };
     auto flush = [&]() {
       epi_chunk(IntC<0>{});
       epi_chunk(IntC<1>{});
       epi_chunk(IntC<2>{});
+      epi_chunk(IntC<3>{});
+      epi_chunk(IntC<4>{});
+      epi_chunk(IntC<5>{});
       flush_one(IntC<0>{});
       flush_one(IntC<1>{});
       flush_one(IntC<2>{});
@@ -525,7 +529,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int p = 0; p < 2; ++p)
 #pragma unroll
           for (int c = 0; c < 3; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f16x8 wf[2][3][2], xf[2][2][2];
+        constexpr int PF = (ABL & 2048) ? 2 : 1;     // stages of fragment reads in flight ahead of the MFMAs (register sets: PF + 1); 2 measured 2 % slower (224 registers)
+        f16x8 wf[PF + 1][3][2], xf[PF + 1][2][2];
         auto load_stage = [&](auto bufc, auto sc) {
           constexpr int BUF = decltype(bufc)::value, S = decltype(sc)::value;
           constexpr int KY = S / CFG::SPK, SG = S % CFG::SPK;
@@ -565,34 +570,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // (scheduling groups; left alone, hipcc reads each fragment right before its first use and waits for it)
         __builtin_amdgcn_sched_barrier(0);
         load_stage(IntC<0>{}, IntC<0>{});
+        if constexpr (PF == 2) load_stage(IntC<1>{}, IntC<1>{});
         __builtin_amdgcn_sched_barrier(0);
         auto run = [&](auto sc, auto &&self) {
           constexpr int S = decltype(sc)::value;
-          if constexpr (S + 1 < CFG::NST) load_stage(IntC<(S + 1) & 1>{}, IntC<S + 1>{});
-          mfma_stage(IntC<S & 1>{});
-          constexpr bool EPI = (ABL & 128) == 0 && (S == 1 || S == 3 || S == 5);
-          if constexpr (EPI) epi_chunk(IntC<(S - 1) / 2>{});   // the previous tile's epilogue, one channel tile per stage, among this stage's MFMAs
-          if constexpr (S + 1 < CFG::NST) {
+          if constexpr (S + PF < CFG::NST) load_stage(IntC<(S + PF) % (PF + 1)>{}, IntC<S + PF>{});
+          mfma_stage(IntC<S % (PF + 1)>{});
+          constexpr bool EPI = (ABL & 128) == 0 && S >= 1 && S <= 6;
+          if constexpr (EPI) epi_chunk(IntC<S - 1>{});   // the previous tile's epilogue, one store's worth per stage, among this stage's MFMAs
+          if constexpr (S + PF < CFG::NST) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
               __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // two MFMA
-              if constexpr (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // six VALU of the epilogue chunk
+              if constexpr (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two VALU of the epilogue chunk
             }
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (S == 6) {
-            if (a.prev != nullptr) {
-              __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.prev + (int64_t)tb * a.y_bstride), 0, cur_ok ? plane_bytes : 0u, 0x00020000);
+          if constexpr (ACC && S == 7) {
+            __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.prev + (int64_t)tb * a.y_bstride), 0, cur_ok ? plane_bytes : 0u, 0x00020000);
 #pragma unroll
-              for (int k = 0; k < 6; ++k) pprev[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, cur_vo, soff[k], 0));
-            }
+            for (int k = 0; k < 6; ++k) pprev[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, cur_vo, soff[k], 0));
             __builtin_amdgcn_sched_barrier(0);
           }
-          if constexpr ((ABL & 128) == 0 && S >= 7 && S <= 12) {
-            flush_one(IntC<S - 7>{});                  // the previous tile's stores, one per stage: behind the producers' fetch burst, never two in a row
-            if constexpr (S == 12) pend_rs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0, 0x00020000);
+          if constexpr ((ABL & 128) == 0 && S >= 8 && S <= 13) {
+            flush_one(IntC<S - 8>{});                  // the previous tile's stores, one per stage: behind the producers' fetch burst, never two in a row
+            if constexpr (S == 13) pend_rs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0, 0x00020000);
             __builtin_amdgcn_sched_barrier(0);
           }
           if constexpr ((ABL & 256) == 0 && S + 1 < CFG::NST && (S + 1) % CFG::SPK == 0) {

@@ -33,10 +33,12 @@ template <int ABL>
 static void launch(const Conv3hArgs &a, hipStream_t s) {
   static bool done = false;
   if (!done) {
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3h_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, Conv3hCfg::LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3h_kernel<ABL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Conv3hCfg::LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3h_kernel<ABL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Conv3hCfg::LDS_BYTES));
     done = true;
   }
-  hipLaunchKernelGGL((conv3h_kernel<ABL>), dim3(256), dim3(512), Conv3hCfg::LDS_BYTES, s, a);
+  if (a.prev) hipLaunchKernelGGL((conv3h_kernel<ABL, true>), dim3(256), dim3(512), Conv3hCfg::LDS_BYTES, s, a);
+  else hipLaunchKernelGGL((conv3h_kernel<ABL, false>), dim3(256), dim3(512), Conv3hCfg::LDS_BYTES, s, a);
 }
 static void launch_abl(int abl, const Conv3hArgs &a, hipStream_t s) {
   switch (abl) {
@@ -49,11 +51,14 @@ static void launch_abl(int abl, const Conv3hArgs &a, hipStream_t s) {
     case 14: return launch<14>(a, s);
     case 32: return launch<32>(a, s);
     case 64: return launch<64>(a, s);
+    case 128: return launch<128>(a, s);
     case 160: return launch<160>(a, s);
     case 288: return launch<288>(a, s);
     case 416: return launch<416>(a, s);
     case 512: return launch<512>(a, s);
     case 1024: return launch<1024>(a, s);
+    case 2048: return launch<2048>(a, s);
+    case 2080: return launch<2080>(a, s);
     case 34: return launch<34>(a, s);
     case 36: return launch<36>(a, s);
     case 38: return launch<38>(a, s);
