@@ -1,27 +1,30 @@
 // 3x3 / pad 1 convolution of the TFC blocks (uvr_lib_v5/modules.py:11-17, mdxnet.py:97-113) as a DIRECT implicit GEMM on the fp16
 // matrix pipe with the fp16 x 3 arithmetic of kernels_gemm3.h (two-part operands, three products, fp32 accumulation) -- no Winograd
-// transforms, no cross-wave exchange.  First form: 48 -> 48 channels (level 0 of UVR-MDX-NET-Inst_HQ_3, the widest planes of the net).
+// transforms, no cross-wave exchange.  One kernel for 48 -> 48 channels; layers of 96 / 144 channels run as 4 / 9 launches over 48-channel
+// slices (accumulate mode).  DESIGN.md 6k has the design record and the measurements behind every choice below.
 //
-//   y[b, co, t, f] = act(bias[co] + sum_{ci, ky, kx} w[co, ci, ky, kx] x[b, ci, t + ky - 1, f + kx - 1])        [B, C, T, F] fp32, F fastest
+//   y[b, co, t, f] = act(bias[co] + prev[b, co, t, f] + sum_{ci, ky, kx} w[co, ci, ky, kx] x[b, ci, t + ky - 1, f + kx - 1])        [B, C, T, F] fp32, F fastest
 //
-// GEMM view.  M = output pixels (16 consecutive f per MFMA tile), N = output channels (3 tiles of 16), K = (tap, ci) = 9 x 48 = 432 =
-// 54 groups of eight channels = 13.5 stages of `v_mfma_f32_16x16x32_f16`.  A lane's eight K values are eight consecutive input channels
-// of ONE tap at ONE pixel, so the x operand is kept channels-LAST in LDS ([pixel][48 halves], 96 bytes per pixel and part).
+// GEMM view.  M = output pixels (16 consecutive f per MFMA tile), N = output channels (3 tiles of 16), K = (ky, kx, ci): a kernel row is
+// 3 x 48 = 144 = 18 groups of eight channels = 4.5 stages of `v_mfma_f32_16x16x32_f16`, padded to 5 (a stage never straddles input rows: rows of
+// different blocks carry different exponents) -- 15 stages per tile.  A lane's eight K values are eight consecutive input channels of ONE
+// tap at ONE pixel, so the x operand is kept channels-LAST in LDS ([ring row][34 pixels][48 halves], 96 bytes per pixel and part).
 //
-// One persistent 512-thread workgroup per CU, two kinds of waves:
-//   * waves 4-7 PRODUCE: the haloed 6 x 34-pixel input tile of a 4 x 32 output tile is fetched with `buffer_load_dword` (eight channel
-//     planes per item, out-of-image pixels through the buffer bounds check = 0), the tile's largest |x| is reduced (DPP inside a wave,
-//     a four-entry LDS table across the waves, published by the step barrier), every element is scaled by the tile's power of two
-//     into fp16's range, split h + l (kernels_gemm3.h: split2h_oct) and written as two 16-byte `ds_write_b128` per (pixel, 8 channels);
-//   * waves 0-3 CONSUME: wave r owns output row r of the tile (two 16-pixel MFMA tiles x three 16-channel tiles = six accumulators);
-//     per stage it reads six weight fragments and four x fragments (`ds_read_b128`) and issues 18 MFMAs (w_l x_h, w_h x_l, w_h x_h).
+// One persistent 512-thread workgroup per CU (grid 256), two kinds of waves, ONE `s_barrier` per 4 x 32 output tile:
+//   * waves 4-7 PRODUCE a block of four input rows x 40 columns x 48 channels per step: 240 (row, 8-channel group, column quad) items, one per
+//     lane, eight `buffer_load_dwordx4` each (out-of-image rows / columns through the buffer bounds check = 0).  Four register sets: block
+//     s + 4 is fetched, block s + 2's largest |x| reduced (v_max3 + DPP in a wave, a four-entry LDS table across waves, published by the step
+//     barrier), block s + 1 scaled by the walk's running power of two, split h + l (`v_fma_mixlo / hi_f16`) and written to its slot of a
+//     12-row ring (`ds_write_b128`, 2-way at worst);
+//   * waves 0-3 CONSUME block s: wave r owns output row r of the tile (two 16-pixel MFMA tiles x three 16-channel tiles = six accumulators);
+//     per stage it reads six weight fragments and four x fragments (`ds_read_b128`, a stage ahead) and issues 18 MFMAs (w_l x_h, w_h x_l,
+//     w_h x_h); where the exponent moved between the tile's two blocks, the accumulators are rescaled at the kernel-row boundary.  The finished
+//     tile's epilogue and its six whole-line nontemporal stores run among the MFMAs of the next tile.
 //   The two-part weight image (432 x 48 x 2 x 2 B = 81 KB, fragment order, one exponent per OUTPUT channel) is copied into LDS once per
-//   workgroup and stays for the whole launch; two x buffers (2 x 38.25 KB) alternate, ONE `s_barrier` per tile.  A tile is self
-//   contained (its two halo rows are fetched again by the tile below, from L2): one exponent per tile, no accumulator rescale.
-//   LDS: 82944 (W) + 2 x 39168 (x) + tables = 161.4 KB of the 160 KiB.
+//   workgroup and stays for the whole launch.  LDS: 82944 (W) + 78336 (ring) + tables = 161.3 KB of the 160 KiB.
 // Bank conflicts: a 16-pixel fragment read at the 96-byte pixel stride puts the sixteen lanes of every `ds_read_b128` service group on
 // sixteen distinct 16-byte slots (pixel stride 6 slots: p and p + 8 collide, and a group holds p mod 8 all different for each k group;
-// the two k groups of a service group are an odd number of slots apart) -- checked in tests/test_conv3h_layout.py.
+// the two k groups of a service group are an odd number of slots apart) -- checked in tests/test_conv3h_host.py.
 #pragma once
 #include <cstring>
 #include <vector>
