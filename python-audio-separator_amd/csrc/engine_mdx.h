@@ -349,13 +349,15 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     // added to the sum of those before it (a.prev = the output itself), bias with the first, activation with the last.
     const int nb = L.cin / Conv3hCfg::C;
     const int tilesT = (T + 3) / 4, tilesF = F / 32;
-    // walk geometry: bands of 32 / 16 / 8 strips -- the narrowest planes that fill whole bands, charged for the extra block per segment of T
+    // walk geometry: bands of 32 / 16 / 8 strips -- whole bands on the plane's width, charged for the extra block per segment of T and for how evenly
+    // the (b, band) items deal out over the 8 XCDs (a 7-chunk strong-scaling pass has 21 items of 32 strips at level 0: 3 / 2 per XCD; 84 of 8 strips: 11 / 10)
     int bw = 32;
     double best = 1e30;
     for (int cand : {32, 16, 8}) {
       if ((tilesT * cand) % 32 != 0) continue;
       const int tps = tilesT * cand / 32;
-      const double cost = (double)((tilesF + cand - 1) / cand * cand) / tilesF * (tps + 1.0) / tps;
+      const int bands = (tilesF + cand - 1) / cand, items = B * bands;
+      const double cost = (double)(bands * cand) / tilesF * (tps + 1.0) / tps * (double)((items + 7) / 8) / (items / 8.0);
       if (cost < best - 1e-9) {
         best = cost;
         bw = cand;
