@@ -251,7 +251,8 @@ class ShardWorkspace:
             try:
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g):
+                # thread_local: another thread of the process (RCCL's watchdog polling its events) must not invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     adapter.demix_chunks(mix, n, k0, k1, out)
                 self._graphs[key] = ent = g
             except Exception as e:                      # a capture the runtime refuses must never take the run down: stay eager
