@@ -495,7 +495,9 @@ int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host
  * "tdf3_gather_launches" (its GATHER mode: channels-last convolutions), "attn6_launches" (attention6_kernel / mha6_kernel),
  * "attn6h_launches" (those of them on the fp16 x 3 arithmetic),
  * "wino6_launches" (conv_wino6_kernel: Winograd F(2x2,3x3) on the 16-bit pipe), "wino6h_launches" (those on the fp16 x 3 arithmetic),
- * "conv3h_launches" (ABI 7: conv3h_kernel, the direct fp16 x 3 convolution of the 48-channel level).  ASX_ERR_INVALID for an unknown name. */
+ * "conv3h_launches" (ABI 7: conv3h_kernel, the direct fp16 x 3 convolution of the 48-channel level),
+ * "tdf3_pair_image_launches" (ABI 7: the tdf3_kernel launches that read their x operand as a pair image -- option "gemm_pair_images", experimental builds).
+ * ASX_ERR_INVALID for an unknown name. */
 int asx_counter(const asx_engine *e, const char *name, int64_t *out);
 
 /* bring-up hook: copy a named engine workspace buffer ("vr.hc", "vr.D0", ...) to the host. */
@@ -529,6 +531,14 @@ int asx_op_conv(asx_engine *e, const char *op, const float *x_host, int32_t batc
 int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int32_t t, int32_t k,
                const float *w_host, const float *bias_host, int32_t n, const float *scale_host,
                const float *shift_host, const float *res_host, float *y_host);
+/* (ABI 7) The two linears of a TDF block with a bottleneck, launched the way the net launches them (reference: TFC_TDF.tdf, modules.py:61-70 --
+ * Linear(f, f / bn) + norm + ReLU + Linear(f / bn, f) + norm + ReLU, then x + tdf(x)): y = x + relu(scale1 (relu(scale0 (x W0^T) + shift0) W1^T) + shift1)
+ * on x [B, c, t, f] viewed as rows of length f, W0 [n8, f], W1 [f, n8], scales / shifts per channel [c].  With option "gemm_pair_images" and shapes
+ * the fp16 x 3 row GEMM takes, the bottleneck activations travel between the two launches as a pair image.  h_host (optional, [B, c, t, n8]):
+ * the bottleneck activations as fp32 (decoded from the pair image when one was written) -- single-op test hook like asx_op_tdf. */
+int asx_op_tdf_block(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int32_t t, int32_t f, const float *w0_host,
+                     const float *scale0_host, const float *shift0_host, int32_t n8, const float *w1_host, const float *scale1_host,
+                     const float *shift1_host, float *y_host, float *h_host);
 
 /* ---- options ------------------------------------------------------------ */
 /* "winograd": kernel of the 3x3 / pad-1 TFC convolutions.  3 (default; also ASX_WINOGRAD in the environment) = Winograd
@@ -547,6 +557,12 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t batch, int32_t c, int
  * matrix pipe with the arithmetic of "gemm_f16x3" (which must be on, as "gemm_bf16x6" and "winograd" = 3) -- the two-part weight image stays in
  * LDS for the whole launch, producer waves fetch four input rows per step into a ring walked down T and split them under one running
  * power-of-two exponent per walk, consumer waves multiply; 5.3-5.8 ms per launch of 55 chunks against 8.5-8.9 on conv_wino3_kernel.  0 = conv_wino3_kernel.
+ * "gemm_pair_images" (ABI 7; experimental builds only -- the default library accepts 0 and refuses 1): a matrix whose only reader is a row GEMM
+ * on the "gemm_f16x3" arithmetic written by its producer (the epilogue of the row GEMM in front of it) as the two fp16 parts the reader
+ * multiplies -- four consecutive elements as h0 h1 h2 h3 l0 l1 l2 l3 in the 16 bytes of their fp32 values, one power-of-two exponent per
+ * (row, column tile of the producer) in a table beside it -- so that no column tile of the reader splits its rows again (the bottleneck
+ * activations of every TDF block, the hidden activations of the Roformer feed-forward).  Measured round 6: the reading launch alone 3-17 %
+ * faster, the nets unchanged (profiles/NOTES.md); default 0.
  * "gemm_bf16x6" (per engine since ABI 6 -- it was process-wide; also ASX_GEMM_BF16X6 in the environment): 1 (default) = every row GEMM whose shape allows it
  * (K % 32 == 0, K >= 64, N > 64, N % 8 == 0, 16-byte aligned rows) runs csrc/kernels_gemm3.h -- both fp32 operands split EXACTLY into three
  * bf16 parts, six bf16 MFMA products with fp32 accumulation, the dropped cross terms below 2^-24 of a product: fp32-grade results

@@ -1044,6 +1044,55 @@ int asx_op_tdf(asx_engine *e, const float *x_host, int32_t B, int32_t c, int32_t
   return rc2;
 }
 
+// x + tdf1(tdf0(x)): the two linears of a TDF block with a bottleneck, launched the way the net launches them (tdf_pair_launch: the bottleneck
+// activations as a pair image when option "gemm_pair_images" and the shapes allow).  h_host (optional): the bottleneck activations as fp32 --
+// decoded from the pair image when one was written
+int asx_op_tdf_block(asx_engine *e, const float *x_host, int32_t B, int32_t c, int32_t t, int32_t f, const float *w0_host, const float *scale0_host,
+                     const float *shift0_host, int32_t n8, const float *w1_host, const float *scale1_host, const float *shift1_host, float *y_host,
+                     float *h_host) {
+  REQUIRE(e && x_host && w0_host && w1_host && scale0_host && shift0_host && scale1_host && shift1_host && y_host && B > 0 && c > 0 && t > 0 &&
+              f > 0 && n8 > 0,
+          "asx_op_tdf_block: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  TdfLayer L0, L1;
+  DevBuf dx, dy, dh, dhe;
+  BufGuard g{{&dx, &dy, &dh, &dhe, &L0.w, &L0.bias, &L0.scale, &L0.shift, &L1.w, &L1.bias, &L1.scale, &L1.shift}};
+  CHK(tdf_pack(L0, n8, f, c, w0_host, nullptr, scale0_host, shift0_host));
+  CHK(tdf_pack(L1, f, n8, c, w1_host, nullptr, scale1_host, shift1_host));
+  const int64_t M = (int64_t)B * c * t;
+  CHK(to_dev(dx, x_host, (size_t)M * f));
+  CHK(dy.ensure((size_t)M * f * 4));
+  CHK(dh.ensure((size_t)M * n8 * 4 + 256));
+  CHK(dhe.ensure((size_t)M * ((n8 + 127) / 128) * 4 + 256));
+  HIPCHK(hipMemset(dy.p, 0xff, (size_t)M * f * 4));
+  HIPCHK(hipMemset(dh.p, 0xff, (size_t)M * n8 * 4));
+  HIPCHK(hipMemset(dhe.p, 0xff, (size_t)M * ((n8 + 127) / 128) * 4));
+  const long long ps0 = g_tdf3ps_launches.load();
+  int rc = tdf_pair_launch(e, L0, L1, dx.f(), dh.f(), reinterpret_cast<int *>(dhe.p), dy.f(), M, t, nullptr);
+  if (rc == ASX_OK) rc = to_host(y_host, dy, (size_t)M * f);   // synchronises: the launches are done with the images
+  if (rc == ASX_OK && h_host) {
+    rc = to_host(h_host, dh, (size_t)M * n8);
+    if (rc == ASX_OK && g_tdf3ps_launches.load() != ps0) {
+      // pair image -> fp32 on the host: groups of four columns as h0..h3 l0..l3, exponent per (row, column tile of the first linear)
+      TdfDmaArgs d0;
+      tdf_fill_args(e, L0, dx.f(), nullptr, dh.f(), M, t, 1, d0);
+      const int cols = tdf3_tile_cols(e, d0), nsp = (n8 + cols - 1) / cols;
+      std::vector<int> ex((size_t)M * nsp);
+      HIPCHK(hipMemcpy(ex.data(), dhe.p, ex.size() * 4, hipMemcpyDeviceToHost));
+      std::vector<uint16_t> raw(8);
+      for (int64_t r = 0; r < M; ++r)
+        for (int g4 = 0; g4 < n8 / 4; ++g4) {
+          float *grp = h_host + r * n8 + g4 * 4;
+          memcpy(raw.data(), grp, 16);
+          for (int i = 0; i < 4; ++i) grp[i] = ldexpf(conv3h_f16_f(raw[i]) + conv3h_f16_f(raw[4 + i]), -ex[(size_t)r * nsp + (g4 * 4) / cols]);
+        }
+    }
+  }
+  w3_drop(e, L0.w.p);
+  w3_drop(e, L1.w.p);
+  return rc;
+}
+
 // ---- MDXC / TFC-TDF v3 --------------------------------------------------------------
 int asx_v3_begin(asx_engine *e, const asx_v3_config *cfg) {
   w3_flush(e);
@@ -1918,6 +1967,7 @@ int asx_counter(const asx_engine *e, const char *name, int64_t *out) {
   else if (nm == "wino6_launches") *out = (int64_t)g_wino6_launches.load();
   else if (nm == "wino6h_launches") *out = (int64_t)g_wino6h_launches.load();
   else if (nm == "conv3h_launches") *out = (int64_t)g_conv3h_launches.load();
+  else if (nm == "tdf3_pair_image_launches") *out = (int64_t)g_tdf3ps_launches.load();
   else {
     set_err("asx_counter: unknown counter '%s'", name);
     return ASX_ERR_INVALID;
@@ -2099,6 +2149,16 @@ int asx_set_option(asx_engine *e, const char *key, int32_t value) {
   }
   if (!strcmp(key, "conv_direct_f16x3")) {
     e->conv3h = value < 0 ? 0 : (int)value;
+    return ASX_OK;
+  }
+  if (!strcmp(key, "gemm_pair_images")) {
+#ifndef ASX_EXPERIMENTAL_KERNELS
+    if (value > 0) {
+      set_err("asx_set_option: gemm_pair_images = 1 needs an experimental build (python build.py --experimental): the pair-image reader measured no faster in the nets and is not in the default library");
+      return ASX_ERR_INVALID;
+    }
+#endif
+    e->pair_images = value > 0 ? 1 : 0;
     return ASX_OK;
   }
   set_err("asx_set_option: unknown option '%s'", key);

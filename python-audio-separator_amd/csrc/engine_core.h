@@ -165,7 +165,7 @@ struct asx_engine {
   std::vector<ConvLayer> ds, us;
   // workspace
   int ws_batch = 0;  // chunks the workspace is sized for
-  DevBuf spec_in, spec_out, R[3], H, frames, chunk_out, d_starts, d_nact, d_peak, d_demixed;
+  DevBuf spec_in, spec_out, R[3], H, HE, frames, chunk_out, d_starts, d_nact, d_peak, d_demixed;
   DevBuf gn_part;    // per-plane float64 (sum, sum of squares) of the GroupNorm variant of the net (asx_net_config.norm == 1)
   DevBuf d_div;      // divider of the chunk fold for div_key's plan (input-independent: built once, asx_finalize_dev)
   DivKey div_key;
@@ -209,6 +209,18 @@ struct asx_engine {
   // (conv_wino6_kernel) at 144; the image is packed up to 144 channels.
   // ASX_CONV3H or asx_set_option("conv_direct_f16x3", n).
   int conv3h = getenv("ASX_CONV3H") ? std::max(0, atoi(getenv("ASX_CONV3H"))) : 144;
+  // EXPERIMENTAL builds only (`python build.py --experimental`; the default library refuses the option).  1: a matrix whose only reader is a row
+  // GEMM on the fp16 x 3 arithmetic is written by its producer as a PAIR IMAGE -- the two fp16 parts the GEMM multiplies, in the bytes of the
+  // fp32 values, one exponent per (row, column tile) beside it (kernels_net.h TdfDmaArgs::xexp; kernels_gemm3.h) -- so the reader splits
+  // nothing: the bottleneck activations of the TDF blocks, the Roformer feed-forward's hidden activations.  Measured round 6: the reader alone
+  // is 3-17 % faster (profiles/r06_tdf3h_abl.txt, r06_tdf_pair_image_chain.txt), the whole nets are not (MDX TDF class 33.3 vs 33.2 ms,
+  // BS-Roformer row GEMMs 940 vs 932 ms per step: profiles/NOTES.md) -- retired with the other measured-and-lost variants.  Default 0.
+  // ASX_PAIR_IMAGES or asx_set_option("gemm_pair_images", n).
+#ifdef ASX_EXPERIMENTAL_KERNELS
+  int pair_images = getenv("ASX_PAIR_IMAGES") ? atoi(getenv("ASX_PAIR_IMAGES")) : 0;
+#else
+  int pair_images = 0;
+#endif
   // split (bf16 x 3) images of this engine's weight matrices, built on first use and freed only with the engine or when the engine's
   // own weights are re-loaded: another engine of the process can never invalidate a pointer a captured graph of this one holds
   std::vector<W3Entry> w3;

@@ -675,6 +675,7 @@ static void launch_tdf2(const TdfDmaArgs &a, hipStream_t s) {
 // launches of tdf3_kernel since the process started (tests assert that the path under test is the one that ran)
 static std::atomic<long long> g_tdf3_launches{0};
 static std::atomic<long long> g_tdf3h_launches{0};   // ... of which on the fp16 x 3 arithmetic (plain and GATHER mode)
+static std::atomic<long long> g_tdf3ps_launches{0};  // ... of which read x as a pair image (operands split by their producer)
 static std::atomic<long long> g_attn6_launches{0};   // launches of attention6_kernel (kernels_rof.h) / mha6_kernel (kernels_ht.h)
 static std::atomic<long long> g_attn6h_launches{0};  // ... of which on the fp16 x 3 arithmetic
 
@@ -742,9 +743,9 @@ static bool tdf3_ok(const asx_engine *e, const TdfDmaArgs &d) {
          d.N > 64 && lda % 4 == 0 && ldy % 4 == 0 && ldr % 4 == 0 && a16(d.x) && a16(d.w) && a16(d.y) && (!d.res || a16(d.res)) &&
          (!d.bias || a16(d.bias)) && (uint64_t)16 * (uint64_t)ldy * 4 < (1ull << 31) && (uint64_t)16 * (uint64_t)ldr * 4 < (1ull << 31);
 }
-template <int NREP, int MREP, int ABL, bool H = false>
+template <int NREP, int MREP, int ABL, bool H = false, bool PS = false>
 static void launch_tdf3_abl(const TdfDmaArgs &a0, const u32x4 *w3, hipStream_t s) {
-  constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = H ? 2 * 2 * BM * 64 + 12 * BM : 2 * 3 * BM * 64;
+  constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS_BYTES = H ? tdf3h_lds_bytes(BM) : 2 * 3 * BM * 64;
   TdfDmaArgs a = a0;
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
@@ -754,9 +755,10 @@ static void launch_tdf3_abl(const TdfDmaArgs &a0, const u32x4 *w3, hipStream_t s
   // fabric traffic 2.0x -> ~1.0x algorithmic); 8 or more -> map 0 (column tiles partitioned over the XCDs; maps 1 / 2 measure the same).
   static const int map_env = getenv("ASX_TDF3_MAP") ? atoi(getenv("ASX_TDF3_MAP")) : -1;
   a.tile_map = map_env >= 0 ? (nbn >= 8 ? map_env % 10 : map_env / 10) : (nbn < 8 ? 1 : 0);
-  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL, false, H>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3, RowGather{});
+  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL, false, H, PS>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3, RowGather{});
   g_tdf3_launches.fetch_add(1);
   if (H) g_tdf3h_launches.fetch_add(1);
+  if (PS) g_tdf3ps_launches.fetch_add(1);
 }
 // GATHER mode (kernels_gemm3.h): stride-1 convolutions of the channels-last nets as implicit GEMMs on the same kernel
 static std::atomic<long long> g_tdf3_gather_launches{0};
@@ -770,7 +772,7 @@ static bool launch_tdf3_gather(asx_engine *e, const TdfDmaArgs &a, const RowGath
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
   if (h) {
-    hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, 0, true, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 2 * 2 * BM * 64 + 12 * BM, s, a, w3, gq);
+    hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, 0, true, true>), dim3((unsigned)(nbm * nbn)), dim3(256), tdf3h_lds_bytes(BM), s, a, w3, gq);
     g_tdf3h_launches.fetch_add(1);
   } else {
     hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, 0, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 2 * 3 * BM * 64, s, a, w3, gq);
@@ -800,7 +802,21 @@ static bool launch_tdf3(asx_engine *e, const TdfDmaArgs &a, hipStream_t s) {
   const u32x4 *w3 = w3_image(e, a.w, a.N, a.K, s, 0, h ? 1 : 0);
   if (!w3) return false;                               // out of memory for the image: the caller falls back to the fp32 kernels
   e->prof_nprod = h ? 3 : 6;
+  if ((a.xexp != nullptr || a.yexp != nullptr) && !h) {
+    // a pair image is only ever set up behind tdf3h_will_run(): reaching this line means the two disagree -- stop rather than multiply garbage
+    fprintf(stderr, "asx: pair-image operands on a launch that is not on the fp16 x 3 row GEMM (N=%d K=%d)\n", a.N, a.K);
+    abort();
+  }
   if (h) {
+#ifdef ASX_EXPERIMENTAL_KERNELS
+    if (a.xexp != nullptr) launch_tdf3_abl<NREP, MREP, 0, true, true>(a, w3, s);
+    else
+#else
+    if (a.xexp != nullptr || a.yexp != nullptr) {
+      fprintf(stderr, "asx: pair-image operands in a library built without them\n");
+      abort();
+    }
+#endif
     launch_tdf3_abl<NREP, MREP, 0, true>(a, w3, s);
     return true;
   }
@@ -821,12 +837,54 @@ static bool launch_tdf3(asx_engine *e, const TdfDmaArgs &a, hipStream_t s) {
   return true;
 }
 
+// which tile form launch_tdf_dma_auto gives a layer on tdf3_kernel: 0 = not tdf3's (N <= 64 or tdf3_ok says no), 1 = 64 x 128, 2 = 128 x 128, 3 = 128 x 192
+static int tdf3_tile_form(const asx_engine *e, const TdfDmaArgs &d) {
+  static const int t128 = getenv("ASX_GEMM_T128") ? atoi(getenv("ASX_GEMM_T128")) : 1;
+  static const int small = getenv("ASX_TDF2_SMALL") ? atoi(getenv("ASX_TDF2_SMALL")) : 0;   // A/B: 64 x 128 tiles (3+ workgroups per CU) on short-K layers
+  if (!tdf3_ok(e, d) || d.N <= 64) return 0;
+  if (d.N <= 128) return 1;
+  if ((small && d.K <= small) || d.prefer_small) return 1;
+  const double rows = (double)((d.M + 127) / 128);
+  auto cost = [&](int bn, double eff) {
+    const double blocks = rows * (double)((d.N + bn - 1) / bn);
+    return ceil(blocks / 512.0) * bn / eff;
+  };
+  // ASX_TDF3_EFF128: relative efficiency charged to the 128-column tile of the bf16 x 6 kernel.  Measured on the BS-Roformer and
+  // HTDemucs linears: 0.96 / 0.85 / 0.75 -> 1251 / 1262 / 1262 ms and 30.5 / 30.4 / 30.5 ms per song -- no reason to move off
+  // the fp32 kernel's figure (N = 512 stays on four 128-column tiles).
+  static const double eff128 = getenv("ASX_TDF3_EFF128") ? atof(getenv("ASX_TDF3_EFF128")) : 0.96;
+  // fp16 x 3: the 128-column tile needs 166 registers -- three workgroups per CU -- and measures as fast per MAC as the 192-column
+  // one or faster on the SHORT-K shapes (BS-Roformer FF1 4.45 vs 4.74 ms, qkv 2.85 vs 3.28, HTDemucs linear 0.266 vs 0.328:
+  // profiles/r05_gemm_f16x3.txt, "tile forms"): no handicap there.  Long K keeps it: the level-0 / level-1 first TDF linears
+  // (K = 3072 / 1536) are 3 % / 35 % slower on the narrow tile.
+  const double e128 = (e->gemm_f16x3 > 0 && d.K <= 512 && !getenv("ASX_TDF3_EFF128")) ? 1.0 : eff128;
+  const bool narrow3 = t128 == 2 || (t128 == 1 && cost(128, e128) < cost(192, 1.0));
+  return narrow3 ? 2 : 3;
+}
+
+// Will launch_tdf_dma_auto run this layer on the fp16 x 3 form of tdf3_kernel?  Only then may its x be a pair image, or its y be written as
+// one (TdfDmaArgs::xexp / yexp).  Builds (and caches) the layer's split weight image, so that the launch itself cannot fall back.
+static bool tdf3h_will_run(asx_engine *e, const TdfDmaArgs &d, hipStream_t s) {
+  static const bool dbg = getenv("ASX_TDF3_ABL") != nullptr || getenv("ASX_F16X3_N") != nullptr;   // bisection aids of launch_tdf3: no pair images with them
+  if (dbg || e->gemm_f16x3 <= 0 || e->pair_images <= 0 || tdf3_tile_form(e, d) == 0) return false;
+  return w3_image(e, d.w, d.N, d.K, s, 0, 1) != nullptr;
+}
+// columns per exponent span of the pair image this layer writes (its column tile)
+static int tdf3_tile_cols(const asx_engine *e, const TdfDmaArgs &d) { return tdf3_tile_form(e, d) == 3 ? 192 : 128; }
+// consumer side of a pair image written in `cols`-column spans: K of the consumer = N of the producer
+static void tdf3_set_xexp(TdfDmaArgs &d, const int *tab, int cols) {
+  d.xexp = tab;
+  d.xexp_gs = cols / 32;
+  d.xexp_n = (d.K + cols - 1) / cols;
+  d.xexp_inv = (65536 + d.xexp_gs - 1) / d.xexp_gs;   // (stage * inv) >> 16 == stage / gs for every stage < 65536 / gs (gs <= 64: K < 2^21 / ... checked by the caller's K)
+}
+
 static void launch_tdf_dma_auto(asx_engine *e, const TdfDmaArgs &d, hipStream_t s) {
   static const int t128 = getenv("ASX_GEMM_T128") ? atoi(getenv("ASX_GEMM_T128")) : 1;
   const bool v2 = tdf2_ok(d);
-  static const int small = getenv("ASX_TDF2_SMALL") ? atoi(getenv("ASX_TDF2_SMALL")) : 0;   // A/B: 64 x 128 tiles (3+ workgroups per CU) on short-K layers
-  const bool v3 = tdf3_ok(e, d);
-  if (v3 && ((small && d.K <= small) || d.prefer_small) && d.N > 128 && launch_tdf3<2, 4>(e, d, s)) return;
+  static const int small = getenv("ASX_TDF2_SMALL") ? atoi(getenv("ASX_TDF2_SMALL")) : 0;
+  const int form = tdf3_tile_form(e, d);
+  if (form == 1 && d.N > 128 && launch_tdf3<2, 4>(e, d, s)) return;
   if (v2 && ((small && d.K <= small) || d.prefer_small) && d.N > 128) return launch_tdf2<2, 4>(d, s);
   if (d.N > 128) {
     const double rows = (double)((d.M + 127) / 128);
@@ -835,29 +893,41 @@ static void launch_tdf_dma_auto(asx_engine *e, const TdfDmaArgs &d, hipStream_t 
       return ceil(blocks / 512.0) * bn / eff;
     };
     const bool narrow = t128 == 2 || (t128 == 1 && cost(128, 0.96) < cost(192, 1.0));
-    // ASX_TDF3_EFF128: relative efficiency charged to the 128-column tile of the bf16 x 6 kernel.  Measured on the BS-Roformer and
-    // HTDemucs linears: 0.96 / 0.85 / 0.75 -> 1251 / 1262 / 1262 ms and 30.5 / 30.4 / 30.5 ms per song -- no reason to move off
-    // the fp32 kernel's figure (N = 512 stays on four 128-column tiles).
-    static const double eff128 = getenv("ASX_TDF3_EFF128") ? atof(getenv("ASX_TDF3_EFF128")) : 0.96;
-    // fp16 x 3: the 128-column tile needs 166 registers -- three workgroups per CU -- and measures as fast per MAC as the 192-column
-    // one or faster on the SHORT-K shapes (BS-Roformer FF1 4.45 vs 4.74 ms, qkv 2.85 vs 3.28, HTDemucs linear 0.266 vs 0.328:
-    // profiles/r05_gemm_f16x3.txt, "tile forms"): no handicap there.  Long K keeps it: the level-0 / level-1 first TDF linears
-    // (K = 3072 / 1536) are 3 % / 35 % slower on the narrow tile.
-    const double e128 = (e->gemm_f16x3 > 0 && d.K <= 512 && !getenv("ASX_TDF3_EFF128")) ? 1.0 : eff128;
-    const bool narrow3 = t128 == 2 || (t128 == 1 && cost(128, e128) < cost(192, 1.0));
-    if (v3 && (narrow3 ? launch_tdf3<2, 8>(e, d, s) : launch_tdf3<3, 8>(e, d, s))) return;
+    if (form == 2 && launch_tdf3<2, 8>(e, d, s)) return;
+    if (form == 3 && launch_tdf3<3, 8>(e, d, s)) return;
     if (narrow) v2 ? launch_tdf2<2, 8>(d, s) : launch_tdf_dma_t<2, 8>(d, s);
     else v2 ? launch_tdf2<3, 8>(d, s) : launch_tdf_dma_t<3, 8>(d, s);
   } else if (d.N > 64) {
-    if (v3 && launch_tdf3<2, 4>(e, d, s)) return;
+    if (form == 1 && launch_tdf3<2, 4>(e, d, s)) return;
     v2 ? launch_tdf2<2, 4>(d, s) : launch_tdf_dma_t<2, 4>(d, s);
   } else {
     launch_tdf_dma_t<1, 4>(d, s);
   }
 }
 
+// pair_out / pair_in (tdf_block): y written / x read as a pair image with its exponent spans in `pair_tab` (`pair_cols` columns per span)
+static void tdf_fill_args(asx_engine *e, const TdfLayer &L, const float *x, const float *res, float *y, int64_t M, int T, int relu, TdfDmaArgs &d) {
+  d = TdfDmaArgs{};
+  d.x = x;
+  d.w = L.w.f();
+  d.bias = L.has_bias ? L.bias.f() : nullptr;
+  d.scale = L.scale.p ? L.scale.f() : nullptr;
+  d.shift = L.shift.p ? L.shift.f() : nullptr;
+  d.res = res;
+  d.zeros = e->d_zeros.f();
+  d.y = y;
+  d.M = M;
+  d.N = L.n;
+  d.K = L.k;
+  d.C = L.c;
+  d.T = T;
+  d.relu = relu;
+  static const int nt_mode = getenv("ASX_NT") ? atoi(getenv("ASX_NT")) : 0;
+  d.nt = ((nt_mode >> 1) & 1) | ((nt_mode >> 2) & 1) << 1;
+}
+
 static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const float *res, float *y, int64_t M,
-                      int T, hipStream_t s, int relu = 1) {
+                      int T, hipStream_t s, int relu = 1, int *pair_out = nullptr, const int *pair_in = nullptr, int pair_cols = 0) {
   TdfArgs a{};
   a.x = x;
   a.w = L.w.f();
@@ -876,23 +946,17 @@ static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const fl
   const double flops = 2.0 * (double)M * L.n * L.k;
   const double bytes = 4.0 * ((double)M * L.k + (double)M * L.n * (res ? 2 : 1) + (double)L.n * L.k);
   const bool dma = (L.k % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && getenv("ASX_NO_DMA") == nullptr;
-  TdfDmaArgs d{};
-  d.x = a.x;
-  d.w = a.w;
-  d.bias = a.bias;
-  d.scale = a.scale;
-  d.shift = a.shift;
-  d.res = a.res;
-  d.zeros = e->d_zeros.f();
-  d.y = a.y;
-  d.M = a.M;
-  d.N = a.N;
-  d.K = a.K;
-  d.C = a.C;
-  d.T = a.T;
-  d.relu = a.relu;
-  static const int nt_mode = getenv("ASX_NT") ? atoi(getenv("ASX_NT")) : 0;
-  d.nt = ((nt_mode >> 1) & 1) | ((nt_mode >> 2) & 1) << 1;
+  TdfDmaArgs d;
+  tdf_fill_args(e, L, x, res, y, M, T, relu, d);
+  if (pair_out) {
+    d.yexp = pair_out;
+    d.yexp_n = (L.n + pair_cols - 1) / pair_cols;
+  }
+  if (pair_in) tdf3_set_xexp(d, pair_in, pair_cols);
+  if ((pair_out || pair_in) && !dma) {
+    set_err("tdf_launch: pair image on a layer the row-GEMM kernels cannot take");
+    return ASX_ERR_STATE;
+  }
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
     if (dma) {
       launch_tdf_dma_auto(e, d, s);
@@ -902,6 +966,27 @@ static int tdf_launch(asx_engine *e, const TdfLayer &L, const float *x, const fl
       else launch_tdf_t<1, 4>(a, s);
     }
   });
+}
+
+// out = x + tdf1(tdf0(x)): the two linears of a TDF block with a bottleneck (modules.py:61-70).  The bottleneck activations H have one reader,
+// the second linear: when both linears run on the fp16 x 3 row GEMM the first writes H as a pair image (split once, in its epilogue; exponent
+// spans in HE) and the second multiplies the parts as they are (kernels_gemm3.h, "operands split by their producer").
+static int tdf_pair_launch(asx_engine *e, const TdfLayer &L0, const TdfLayer &L1, const float *x, float *H, int *HE, float *out, int64_t M, int T,
+                           hipStream_t s) {
+  int *pair_tab = nullptr;
+  int pair_cols = 0;
+  if (M > 0 && HE != nullptr) {
+    TdfDmaArgs d0, d1;
+    tdf_fill_args(e, L0, x, nullptr, H, M, T, 1, d0);
+    tdf_fill_args(e, L1, H, x, out, M, T, 1, d1);
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(H)) & 15) == 0 && getenv("ASX_NO_DMA") == nullptr;
+    if (al && L0.n % 32 == 0 && L0.k % 4 == 0 && L1.k % 4 == 0 && tdf3h_will_run(e, d0, s) && tdf3h_will_run(e, d1, s)) {
+      pair_cols = tdf3_tile_cols(e, d0);
+      pair_tab = HE;
+    }
+  }
+  CHK(tdf_launch(e, L0, x, nullptr, H, M, T, s, 1, pair_tab, nullptr, pair_cols));
+  return tdf_launch(e, L1, H, x, out, M, T, s, 1, nullptr, pair_tab, pair_cols);
 }
 
 static int tdf_pack(TdfLayer &L, int n, int k, int c, const float *w, const float *bias, const float *scale,
@@ -1123,12 +1208,11 @@ static int block_forward(asx_engine *e, const Block &blk, float *&cur, float *de
     cur = out;
     return ASX_OK;
   }
-  CHK(tdf_launch(e, blk.tdf0, cur, nullptr, e->H.f(), M, blk.t, s));
   // (A/B ASX_TDF_INPLACE=1: x + tdf(x) written over x where no skip copy is needed -- every output element depends on the
   // same element of x only)
   static const bool inplace = getenv("ASX_TDF_INPLACE") && atoi(getenv("ASX_TDF_INPLACE")) != 0;
   float *out = dest ? dest : (inplace ? cur : next_free(cur, nullptr));
-  CHK(tdf_launch(e, blk.tdf1, e->H.f(), cur, out, M, blk.t, s));
+  CHK(tdf_pair_launch(e, blk.tdf0, blk.tdf1, cur, e->H.f(), reinterpret_cast<int *>(e->HE.p), out, M, blk.t, s));
   cur = out;
   return ASX_OK;
 }
@@ -1186,6 +1270,8 @@ static int ensure_workspace(asx_engine *e, int Bchunks, bool need_net) {
     const size_t lvl0 = Bn * e->net.g * T * Fq * 4;
     for (int i = 0; i < 3; ++i) CHK(e->R[i].ensure(lvl0));
     CHK(e->H.ensure(Bn * e->net.g * T * (Fq / std::max(1, e->net.bn)) * 4 + 256));
+    // exponent spans of H as a pair image (tdf_block): one int per (row, 128-column tile) at most
+    CHK(e->HE.ensure(Bn * e->net.g * T * (size_t)((Fq / std::max(1, e->net.bn) + 127) / 128) * 4 + 256));
     if (e->net.norm == 1) CHK(e->gn_part.ensure(Bn * (size_t)e->net.g * (e->net.num_blocks / 2 + 1) * 16));
     const int n = e->net.num_blocks / 2;
     e->skip.resize(n);

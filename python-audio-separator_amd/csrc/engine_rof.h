@@ -42,7 +42,7 @@ struct RofNet {
   std::vector<std::vector<std::vector<RofLin>>> mask;  // [stem][band][mlp layer]
   // workspace
   int ws_batch = 0;
-  DevBuf X0, XB, TOK, XN, RS, QKV, ATT, GATE, FFH, HID, GLU, MASK, frames, chunk_out, d_starts, d_window;
+  DevBuf X0, XB, TOK, XN, RS, QKV, ATT, GATE, FFH, FFE, HID, GLU, MASK, frames, chunk_out, d_starts, d_window;
   DevBuf win_synth;   // stft_normalized: the synthesis window x sqrt(n_fft) (torch.istft multiplies its input by sqrt(n_fft) first)
 };
 
@@ -74,7 +74,7 @@ static void rof_free(RofNet &n) {
   for (auto &s : n.mask)
     for (auto &b : s)
       for (auto &l : b) rof_free_lin(l);
-  DevBuf *bufs[] = {&n.X0, &n.XB, &n.TOK, &n.XN, &n.RS, &n.QKV, &n.ATT, &n.GATE, &n.FFH, &n.HID, &n.GLU,
+  DevBuf *bufs[] = {&n.X0, &n.XB, &n.TOK, &n.XN, &n.RS, &n.QKV, &n.ATT, &n.GATE, &n.FFH, &n.FFE, &n.HID, &n.GLU,
                     &n.MASK, &n.frames, &n.chunk_out, &n.d_starts, &n.d_window, &n.win_synth};
   for (auto *b : bufs) b->release();
   n.ready = false;
@@ -181,15 +181,13 @@ static int rof_gelu_act() {
   return v;
 }
 
-static int rof_gemm(asx_engine *e, const RofLin &L, const float *x, int64_t lda, int64_t M, float *y, int64_t ldy,
-                    int act, const float *res, int64_t ldr, hipStream_t s, const RofRot *rot = nullptr,
-                    const float *rscale = nullptr) {
-  if (M <= 0) return ASX_OK;
+static int rof_gemm_args(asx_engine *e, const RofLin &L, const float *x, int64_t lda, int64_t M, float *y, int64_t ldy,
+                         int act, const float *res, int64_t ldr, const RofRot *rot, const float *rscale, TdfDmaArgs &d) {
   if ((L.k & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) {
     set_err("rof_gemm: K and the row stride must be multiples of 4 floats (K=%d lda=%lld)", L.k, (long long)lda);
     return ASX_ERR_INVALID;
   }
-  TdfDmaArgs d{};
+  d = TdfDmaArgs{};
   d.x = x;
   d.w = L.w.f();
   d.bias = L.has_bias ? L.b.f() : nullptr;
@@ -223,6 +221,22 @@ static int rof_gemm(asx_engine *e, const RofLin &L, const float *x, int64_t lda,
     set_err("rof_gemm: output rows must be 16-byte aligned (N=%d ldy=%lld)", L.n, (long long)ldy);
     return ASX_ERR_INVALID;
   }
+  return ASX_OK;
+}
+
+// pair_out / pair_in: y written / x read as a pair image (kernels_net.h TdfDmaArgs::yexp / xexp) with `pair_cols` columns per exponent span --
+// only behind tdf3h_will_run() for the layer
+static int rof_gemm(asx_engine *e, const RofLin &L, const float *x, int64_t lda, int64_t M, float *y, int64_t ldy,
+                    int act, const float *res, int64_t ldr, hipStream_t s, const RofRot *rot = nullptr,
+                    const float *rscale = nullptr, int *pair_out = nullptr, const int *pair_in = nullptr, int pair_cols = 0) {
+  if (M <= 0) return ASX_OK;
+  TdfDmaArgs d;
+  CHK(rof_gemm_args(e, L, x, lda, M, y, ldy, act, res, ldr, rot, rscale, d));
+  if (pair_out) {
+    d.yexp = pair_out;
+    d.yexp_n = (L.n + pair_cols - 1) / pair_cols;
+  }
+  if (pair_in) tdf3_set_xexp(d, pair_in, pair_cols);
   const double flops = 2.0 * (double)M * L.n * L.k;
   const double bytes = 4.0 * ((double)M * L.k + (double)M * L.n * (res ? 2 : 1) + (double)L.n * L.k);
   return timed(e, ASX_PROF_TDF, flops, bytes, s, [&]() {
@@ -387,15 +401,28 @@ static int rof_transformer(asx_engine *e, std::vector<RofLayer> &layers, bool ti
     }
     CHK(rof_gemm(e, L.attn.out, n.ATT.f(), inner, Mg, n.TOK.f(), D, 0, n.TOK.f(), D, s));   // + x (in place: each
     // output element depends only on ATT and on the same TOK element it overwrites)
-    // feed-forward: x = ff(x) + x
+    // feed-forward: x = ff(x) + x.  The hidden activations FFH have one reader, the second linear: when both linears run on the fp16 x 3 row
+    // GEMM the first writes them as a pair image (split once, in its GELU epilogue) and the second multiplies the parts as they are
+    // (kernels_gemm3.h, "operands split by their producer")
+    int *pair_tab = nullptr;
+    int pair_cols = 0;
+    {
+      TdfDmaArgs d1, d2;
+      if (rof_gemm_args(e, L.ff.l1, n.TOK.f(), D, Mg, n.FFH.f(), 4 * D, rof_gelu_act(), nullptr, 0, nullptr, nullptr, d1) == ASX_OK &&
+          rof_gemm_args(e, L.ff.l2, n.FFH.f(), 4 * D, Mg, n.TOK.f(), D, 0, n.TOK.f(), D, nullptr, nullptr, d2) == ASX_OK && (4 * D) % 32 == 0 &&
+          tdf3h_will_run(e, d1, s) && tdf3h_will_run(e, d2, s)) {
+        pair_cols = tdf3_tile_cols(e, d1);
+        pair_tab = reinterpret_cast<int *>(n.FFE.p);
+      }
+    }
     if (L.ff.norm_folded) {
       CHK(rof_rownorm(e, n.TOK.f(), D, D, n.RS.f(), Mg, s));
-      CHK(rof_gemm(e, L.ff.l1, n.TOK.f(), D, Mg, n.FFH.f(), 4 * D, rof_gelu_act(), nullptr, 0, s, nullptr, n.RS.f()));   // GELU
+      CHK(rof_gemm(e, L.ff.l1, n.TOK.f(), D, Mg, n.FFH.f(), 4 * D, rof_gelu_act(), nullptr, 0, s, nullptr, n.RS.f(), pair_tab, nullptr, pair_cols));   // GELU
     } else {
       CHK(rof_rmsnorm(e, n.TOK.f(), D, D, L.ff.norm_g.f(), n.XN.f(), D, Mg, s));
-      CHK(rof_gemm(e, L.ff.l1, n.XN.f(), D, Mg, n.FFH.f(), 4 * D, rof_gelu_act(), nullptr, 0, s));          // GELU
+      CHK(rof_gemm(e, L.ff.l1, n.XN.f(), D, Mg, n.FFH.f(), 4 * D, rof_gelu_act(), nullptr, 0, s, nullptr, nullptr, pair_tab, nullptr, pair_cols));   // GELU
     }
-    CHK(rof_gemm(e, L.ff.l2, n.FFH.f(), 4 * D, Mg, n.TOK.f(), D, 0, n.TOK.f(), D, s));
+    CHK(rof_gemm(e, L.ff.l2, n.FFH.f(), 4 * D, Mg, n.TOK.f(), D, 0, n.TOK.f(), D, s, nullptr, nullptr, nullptr, pair_tab, pair_cols));
   }
   // MelBandRoformer: Transformer(norm_output=True) (mel_band_roformer.py:111,120); in place (a row is read, then written)
   if (out_norm) CHK(rof_rmsnorm(e, n.TOK.f(), D, D, out_norm->f(), n.TOK.f(), D, Mg, s));
@@ -436,6 +463,7 @@ static int rof_ensure_workspace(asx_engine *e, int B) {
   CHK(n.ATT.ensure(M * inner * 4));
   CHK(n.GATE.ensure(M * ((c.heads + 3) / 4 * 4) * 4));
   CHK(n.FFH.ensure(M * 4 * D * 4));
+  CHK(n.FFE.ensure(M * (size_t)((4 * D + 127) / 128) * 4 + 256));   // exponent spans of FFH as a pair image
   CHK(n.HID.ensure(BT * hid * 4));
   CHK(n.GLU.ensure(BT * 2 * maxd * 4));
   CHK(n.MASK.ensure(BT * c.num_stems * n.W * 4));

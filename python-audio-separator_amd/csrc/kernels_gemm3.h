@@ -264,17 +264,30 @@ struct RowGather {
 };
 
 // H: the fp16 x 3 arithmetic (above) instead of bf16 x 6 -- two parts per operand, three MFMAs per product, x registers double
-// buffered (a stage's rows are fetched a whole stage before their maximum is needed), 12 * BM more bytes of LDS: the exponent-drop table of either
-// stage parity and the rows' current exponents (de_tab[2][BM], ex_tab[BM]).
-template <int NREP, int MREP, int ABL = 0, bool GATHER = false, bool H = false>
-__global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 *__restrict__ w3, RowGather gq) {
-  constexpr int BM = 16 * MREP, BN = 64 * NREP;
-  constexpr int XC = MREP / 4;                        // 8-float chunks per thread and stage (BM * 4 chunks / 256 threads)
+// buffered (a stage's rows are fetched a whole stage before their maximum is needed), 12 * BM + 16 more bytes of LDS: the exponent-drop table of either
+// stage parity, the rows' current exponents and, per stage parity, the last stage some row's exponent dropped at (de_tab[2][BM], ex_tab[BM], fl_tab[2]).
+// rmax[BM] (producer side of a pair image: the rows' largest |y| over the tile's columns) follows them.
+constexpr int tdf3h_lds_bytes(int BM) { return 2 * 2 * BM * 64 + 16 * BM + 16; }
+// PS (H only; instantiated by experimental builds and tools/proto_gemm3.hip -- measured round 6: the reader alone gains 3-17 %, the nets nothing,
+// profiles/NOTES.md): x is a PAIR IMAGE (kernels_net.h, TdfDmaArgs::xexp) -- split once by the kernel that produced it instead of by every column
+// tile of this GEMM: a chunk's two 16-byte loads are regrouped into its h and l parts (no arithmetic), brought from their span's exponent
+// to the row's (the smallest of the row's spans: eight v_pk_mul_f16 by a power of two) and stored; the row's exponent never changes, so
+// the accumulators are never rescaled.  Any H build WRITES a pair image when TdfDmaArgs::yexp is set (epilogue).
+// NW: waves per workgroup, 4 or 8.  Eight waves share ONE x tile between two 4-wave column halves (tile 128 x 32 NREP NW columns: 128 x 384 for
+// NREP = 3) -- half the x loads, splits and LDS stores per MFMA of the 4-wave form, one workgroup per CU instead of two.
+template <int NREP, int MREP, int ABL = 0, bool GATHER = false, bool H = false, bool PS = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tdf3_kernel(TdfDmaArgs a, const u32x4 *__restrict__ w3, RowGather gq) {
+  static_assert(!PS || (H && !GATHER), "pair-image operands: fp16 x 3 arithmetic, plain row GEMM");
+  static_assert(NW == 4 || (NW == 8 && MREP == 8 && !GATHER), "eight waves: 128-row tiles of the plain row GEMM");
+  constexpr int NT = 64 * NW;                         // threads
+  constexpr int BM = 16 * MREP, BN = 16 * NREP * NW;
+  constexpr int XC = BM * 4 / NT;                     // 8-float chunks per thread and stage (BM * 4 chunks / NT threads)
   constexpr int NP = H ? 2 : 3;                       // parts per operand
   constexpr int PART = BM * 64;                       // bytes of one part image
   constexpr int BUFB = NP * PART;                     // bytes of one stage buffer
-  static_assert(MREP % 4 == 0, "tile shape");
-  static_assert(!H || ABL == 0, "the ablation builds exist for the bf16 x 6 arithmetic only");
+  static_assert(MREP % 4 == 0 && XC >= 1, "tile shape");
+  // H builds: ABL bits 0 (no x loads / split after the prologue), 2 (no epilogue traffic), 3 (no weight loads after the prologue) and
+  // bit 4 = 16 (no per-row accumulator rescale) -- tools/proto_gemm3.hip
   extern __shared__ float lds_f[];
   char *lds = reinterpret_cast<char *>(lds_f);
 
@@ -346,13 +359,13 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
   // XOR (h = identity) lanes (li 0-3, lk 0) and (li 4-7, lk 1) of a group met on the same banks -- 40 % of the LDS cycles were
   // conflict cycles in the first PMC pass; this permutation puts the sixteen lanes of every group on sixteen distinct slots.
   auto hsw = [](int g) { return g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 3 : 1)); };
-  // ---- x rows: chunk q = tid + 256 i -> row q >> 2 of the tile, floats (q & 3) * 8 .. + 7 of the stage
+  // ---- x rows: chunk q = tid + NT i -> row q >> 2 of the tile, floats (q & 3) * 8 .. + 7 of the stage
   const float *xp[XC];
   int xw[XC];                                          // LDS byte offset of the chunk inside a part image
   int po[XC], pi[XC];                                  // GATHER: the row's pixel (o, i); o = -2^20 for rows past M (never valid)
 #pragma unroll
   for (int i = 0; i < XC; ++i) {
-    const int q = tid + 256 * i;
+    const int q = tid + NT * i;
     const int row = q >> 2, c = q & 3;
     int64_t r = m0 + row;
     if constexpr (GATHER) {
@@ -374,6 +387,8 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
     xw[i] = row * 64 + ((c ^ hsw((row >> 2) & 3)) << 4);
   }
   f32x4 xr[XC][2];
+  const int *xe[XC];                                   // PS: the exponent spans of this thread's rows
+  int ej[XC];                                          // PS: span exponent of the chunk held in xr
   auto load_x_sel = [&](int ks, int only) {            // only < 0: every chunk of the stage; else chunk `only` (H mode: a chunk's registers are refilled right after its split)
     const int kcs = ks < nkx ? ks : nkx - 1;           // wave-uniform clamp (see nk above)
     if constexpr (GATHER) {
@@ -397,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
         if (only >= 0 && i != only) continue;
         xr[i][0] = *reinterpret_cast<const f32x4 *>(xp[i] + kc);
         xr[i][1] = *reinterpret_cast<const f32x4 *>(xp[i] + kc + 4);
+        if constexpr (PS) ej[i] = xe[i][(kcs * a.xexp_inv) >> 16];
       }
     }
   };
@@ -416,15 +432,22 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
   // second table keeps every row's current exponent for the epilogue.  Non-finite elements poison their own row only.
   int *de_tab = reinterpret_cast<int *>(lds + 2 * BUFB);              // [stage parity][BM]: row r at (r & 15) * MREP + (r >> 4)
   int *ex_tab = de_tab + 2 * BM;                                      // [BM]: the exponent each row's parts in LDS / accumulators carry
+  int *fl_tab = ex_tab + BM;                                          // [stage parity]: the stage whose split last dropped some row's exponent (H)
+  int *rmax = fl_tab + 4;                                             // [BM]: pair-image epilogue, bits of the rows' largest finite |y|
+#ifdef ASX_EXPERIMENTAL_KERNELS
+  if constexpr (H) {
+    if (a.yexp != nullptr && tid < BM) rmax[tid] = 0;                 // (the stage loop's barriers order this before the epilogue's atomics)
+  }
+#endif
   int e_row[XC];
   int xslot[XC];
 #pragma unroll
   for (int i = 0; i < XC; ++i) {
-    const int row = (tid + 256 * i) >> 2;
+    const int row = (tid + NT * i) >> 2;
     e_row[i] = 200;                                    // any first stage lowers it (accumulators are zero then)
     xslot[i] = (row & 15) * MREP + (row >> 4);
   }
-  auto split_chunk_h = [&](int buf, int i) {
+  auto split_chunk_h = [&](int buf, int i, int ks_of) {   // ks_of: the stage these rows are the x of
     float m = absmax_oct(xr[i][0], xr[i][1]);
     {
       int b = __float_as_int(m);
@@ -440,6 +463,7 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
     if ((tid & 3) == 0) {
       de_tab[buf * BM + xslot[i]] = e_new - e_old;
       ex_tab[xslot[i]] = e_new;
+      if (e_new != e_old) fl_tab[buf] = ks_of;         // every writer of a stage writes the same value
     }
     char *dst = lds + buf * BUFB;
     u32x4 h, l;
@@ -447,6 +471,30 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
     *reinterpret_cast<u32x4 *>(dst + xw[i]) = h;
     *reinterpret_cast<u32x4 *>(dst + PART + xw[i]) = l;
   };
+  // PS: regroup, rescale to the row's exponent, store
+  auto split_chunk_ps = [&](int buf, int i) {
+    const int d = e_row[i] - ej[i];                      // <= 0: the row's exponent is its smallest span exponent
+    const _Float16 f1 = (_Float16)__builtin_ldexpf(1.0f, d < -25 ? -25 : d);   // exact down to 2^-24 (fp16's smallest subnormal), 0 below
+    const f16x2 ff = {f1, f1};
+    auto sc = [&](float v) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, __float_as_uint(v)) * ff); };
+    const u32x4 h = {sc(xr[i][0].x), sc(xr[i][0].y), sc(xr[i][1].x), sc(xr[i][1].y)};
+    const u32x4 l = {sc(xr[i][0].z), sc(xr[i][0].w), sc(xr[i][1].z), sc(xr[i][1].w)};
+    char *dst = lds + buf * BUFB;
+    *reinterpret_cast<u32x4 *>(dst + xw[i]) = h;
+    *reinterpret_cast<u32x4 *>(dst + PART + xw[i]) = l;
+  };
+  if constexpr (PS) {
+#pragma unroll
+    for (int i = 0; i < XC; ++i) {
+      int64_t r = m0 + ((tid + NT * i) >> 2);
+      r = r < a.M ? r : a.M - 1;
+      xe[i] = a.xexp + r * a.xexp_n;
+      int em = xe[i][0];
+      for (int j = 1; j < a.xexp_n; ++j) em = min(em, xe[i][j]);
+      e_row[i] = em;
+      if ((tid & 3) == 0) ex_tab[xslot[i]] = em;         // read by the epilogue, behind the stage loop's barriers
+    }
+  }
   // MFMA side: this lane's rows are 16 m + li
   auto read_tab = [&](const int *tab, int (&out)[MREP]) {
     const u32x4 *q = reinterpret_cast<const u32x4 *>(tab + li * MREP);
@@ -472,7 +520,10 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
     load_x(0);
     load_w(IntC<0>{}, 0);
 #pragma unroll
-    for (int i = 0; i < XC; ++i) split_chunk_h(0, i);
+    for (int i = 0; i < XC; ++i) {
+      if constexpr (PS) split_chunk_ps(0, i);
+      else split_chunk_h(0, i, 0);
+    }
     load_x(1);                                         // nk >= 2
   } else {
     load_x(0);
@@ -555,18 +606,37 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
     constexpr int P = decltype(par)::value;
     constexpr int MODE = decltype(mode)::value;
     __syncthreads();
-    if constexpr (MODE < 2) load_w(IntC<P ^ 1>{}, ks + 1);
-    int de[MREP];
-    read_tab(de_tab + P * BM, de);
-    // The rescale is a branch-free multiply by 2^de (1.0 almost always; 0 for de < -149: what the accumulators held is then below
-    // 2^-100 of what follows) in front of each row group's MFMAs.  As a rare branch (`if any lane has de != 0`) the compiler kept a
-    // second register set for the rescaled accumulators -- 256 VGPRs and 27 spilled against 220 and none -- and every launch measured
-    // 35-60 % slower (tools/runs/r5_run15.sh).
+    if constexpr (MODE < 2 && !(ABL & 8)) load_w(IntC<P ^ 1>{}, ks + 1);
+    // The exponent drops of the rows split during the previous stage: the accumulators of such a row are multiplied by 2^de (exact; 0 for
+    // de < -149: what they held is then below 2^-100 of what follows).  Rare after a tile's first stages, so the 4 MREP NREP multiplies
+    // sit behind a workgroup-uniform test of the stage stamp the splitting threads leave in fl_tab (round 6: as an unconditional
+    // multiply by 1.0 they were 4-10 % of the launch, profiles/r06_tdf3h_abl.txt).  In-place inline assembly: as a C++ multiply inside a
+    // branch the compiler kept a second register set for the rescaled accumulators (256 VGPRs and 27 spilled against 220 and none:
+    // tools/runs/r5_run15.sh).  ABL & 32: the unconditional form, for A/B.
     float fr[MREP];
+    if constexpr ((ABL & 32) != 0) {
+      int de[MREP];
+      read_tab(de_tab + P * BM, de);
 #pragma unroll
-    for (int m = 0; m < MREP; ++m) fr[m] = __builtin_ldexpf(1.0f, de[m]);
+      for (int m = 0; m < MREP; ++m) fr[m] = __builtin_ldexpf(1.0f, de[m]);
 #pragma unroll
-    for (int n = 0; n < NREP; ++n) acc[n][0] *= fr[0];
+      for (int n = 0; n < NREP; ++n) acc[n][0] *= fr[0];
+    } else if constexpr (!(ABL & 16) && !PS) {
+      if (__builtin_amdgcn_readfirstlane(fl_tab[P]) == ks) {
+        int de[MREP];
+        read_tab(de_tab + P * BM, de);
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const float f = __builtin_ldexpf(1.0f, de[m]);
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) {
+            asm volatile("v_mul_f32 %0, %4, %0\n\tv_mul_f32 %1, %4, %1\n\tv_mul_f32 %2, %4, %2\n\tv_mul_f32 %3, %4, %3"
+                         : "+v"(acc[n][m].x), "+v"(acc[n][m].y), "+v"(acc[n][m].z), "+v"(acc[n][m].w)
+                         : "v"(f));
+          }
+        }
+      }
+    }
     const char *xs = lds + P * BUFB + xf_off;
     f16x8 xf[2][2];
 #pragma unroll
@@ -578,8 +648,11 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
         for (int p = 0; p < 2; ++p) xf[(m + 1) & 1][p] = *reinterpret_cast<const f16x8 *>(xs + p * PART + (m + 1) * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
-      const bool has_split = MODE < 2 && (m >= 1) && ((m - 1) % 3 == 0) && ((m - 1) / 3 < XC);
-      if (has_split) split_chunk_h(P ^ 1, (m - 1) / 3);
+      const bool has_split = MODE < 2 && !(ABL & 1) && (m >= 1) && ((m - 1) % 3 == 0) && ((m - 1) / 3 < XC);
+      if (has_split) {
+        if constexpr (PS) split_chunk_ps(P ^ 1, (m - 1) / 3);
+        else split_chunk_h(P ^ 1, (m - 1) / 3, ks + 1);
+      }
       const f16x8 xh = xf[m & 1][0], xl = xf[m & 1][1];
       // smallest terms first; the NREP column tiles of one product are independent accumulators
 #pragma unroll
@@ -588,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
       for (int n = 0; n < NREP; ++n) acc[n][m] = ASX_MFMA_F16(__builtin_bit_cast(f16x8, wr[P][n][0]), xl, acc[n][m]);
 #pragma unroll
       for (int n = 0; n < NREP; ++n) acc[n][m] = ASX_MFMA_F16(__builtin_bit_cast(f16x8, wr[P][n][0]), xh, acc[n][m]);
-      if (m + 1 < MREP) {                              // the next row group's accumulators, behind this group's MFMAs
+      if (m + 1 < MREP && (ABL & 32)) {                // the next row group's accumulators, behind this group's MFMAs
 #pragma unroll
         for (int n = 0; n < NREP; ++n) acc[n][m + 1] *= fr[m + 1];
       }
@@ -597,9 +670,9 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
 #pragma unroll
         for (int g = 0; g < 3 * NREP; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU
+          __builtin_amdgcn_sched_group_barrier(0x002, PS ? 2 : 5, 0);   // five VALU (two with pair-image operands)
         }
-        __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);     // the chunk's ds_writes (two parts, two table entries)
+        __builtin_amdgcn_sched_group_barrier(0x200, PS ? 2 : 4, 0);     // the chunk's ds_writes (two parts, two table entries)
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -672,6 +745,58 @@ __global__ __launch_bounds__(256, 2) void tdf3_kernel(TdfDmaArgs a, const u32x4 
       return;
     }
   }
+#ifdef ASX_EXPERIMENTAL_KERNELS
+  if constexpr (H && !GATHER) {
+    if (a.yexp != nullptr) {
+      // ---- y as a PAIR IMAGE for the row GEMM that is its only reader (launcher: no residual, no rotary step, N % 32 == 0).  Pass 1: the
+      // epilogue arithmetic of the generic path in place, the rows' largest finite |y| over this tile's columns into rmax (LDS atomics:
+      // four lanes of four waves per row).  Pass 2: one exponent per (row, tile) -- the maximum lands in [2^14, 2^15) -- and each lane's
+      // four columns as h0..h3 l0..l3 in the 16 bytes the fp32 values would have taken.
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) {
+        const int64_t row = m0 + m * 16 + li;
+        const bool rok = row < a.M;
+        const int c = rok ? (int)(((uint32_t)row / (uint32_t)a.T) % (uint32_t)a.C) : 0;
+        const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
+        const float rw = (rok && a.rscale) ? a.rscale[row] : 1.f;
+        float mx = 0.f;
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+          const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+          const bool ok = rok && col < a.N;
+          const f32x4 b4 = (ok && a.bias != nullptr) ? *reinterpret_cast<const f32x4 *>(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          const f32x4 v = acc[n][m];
+          f32x4 o;
+          o.x = tdf_act(sc * __fmaf_rn(v.x, rw, b4.x) + sh, a.relu);
+          o.y = tdf_act(sc * __fmaf_rn(v.y, rw, b4.y) + sh, a.relu);
+          o.z = tdf_act(sc * __fmaf_rn(v.z, rw, b4.z) + sh, a.relu);
+          o.w = tdf_act(sc * __fmaf_rn(v.w, rw, b4.w) + sh, a.relu);
+          if (!ok) o = (f32x4){0.f, 0.f, 0.f, 0.f};
+          acc[n][m] = o;
+          mx = fmaxf(mx, fmaxf(fmaxf(finite_or_zero(o.x), finite_or_zero(o.y)), fmaxf(finite_or_zero(o.z), finite_or_zero(o.w))));
+        }
+        atomicMax(&rmax[m * 16 + li], __float_as_int(mx));   // non-negative floats order as their bit patterns
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) {
+        const int64_t row = m0 + m * 16 + li;
+        const int e = f16_scale_exp(__int_as_float(rmax[m * 16 + li]));
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+          const int col = n0 + wave * 16 * NREP + n * 16 + lk * 4;
+          if (row >= a.M || col >= a.N) continue;
+          unsigned h0, h1, l0, l1;
+          split2h_pair(acc[n][m].x, acc[n][m].y, e, h0, l0);
+          split2h_pair(acc[n][m].z, acc[n][m].w, e, h1, l1);
+          *reinterpret_cast<u32x4 *>(a.y + row * ldy + col) = (u32x4){h0, h1, l0, l1};
+        }
+      }
+      if (tid < BM && m0 + tid < a.M) a.yexp[(m0 + tid) * a.yexp_n + bg] = f16_scale_exp(__int_as_float(rmax[tid]));
+      return;
+    }
+  }
+#endif
   if constexpr ((ABL & 4) != 0) {
     float chk = 0.f;
 #pragma unroll

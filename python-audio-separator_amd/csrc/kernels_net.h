@@ -812,6 +812,15 @@ struct TdfDmaArgs {
                             // of (row block, column tile) per XCD
   int glu_cout;             // tdf3_kernel GATHER mode, 128-column tiles only: > 0 = GLU epilogue over value / gate fragment pairs (the rows of W are in
                             // ht_glu_perm order), glu_cout output channels: y[row][c / 2 + ...] = (acc_v + b) * sigmoid(acc_g + b)
+  // PAIR IMAGES (tdf3_kernel, fp16 x 3 arithmetic; kernels_gemm3.h "operands split by their producer"): a matrix whose only reader is a
+  // row GEMM is stored by its producer as the two fp16 parts the GEMM multiplies -- every 16 bytes hold four consecutive elements as
+  // h0 h1 h2 h3 l0 l1 l2 l3 (x 2^e = h + l), same row pitch as the fp32 matrix it replaces -- with one exponent per (row, column span)
+  // in an int table beside it.
+  const int *xexp;          // != nullptr: x IS a pair image; xexp[row * xexp_n + span] = e of columns [span * 32 xexp_gs, ...)
+  int xexp_n, xexp_gs;      // spans per row, 32-column stages per span
+  int xexp_inv;             // ceil(65536 / xexp_gs): stage -> span as (stage * xexp_inv) >> 16 (the launcher checks every stage of K)
+  int *yexp;                // != nullptr: y is WRITTEN as a pair image, one span per column tile of the launch: yexp[row * yexp_n + tile]
+  int yexp_n;               // (no residual, no rotary epilogue; N % 32 == 0)
 };
 
 // rotary step of the row-GEMM epilogues on the float4 (row, col .. col + 3), col % 4 == 0.  Every product and sum is rounded

@@ -237,7 +237,7 @@ SYMBOLS = ["asx_abi_version", "asx_last_error", "asx_device_count", "asx_engine_
            "asx_ht_standardize_dev", "asx_ht_bag_accumulate_dev", "asx_ht_bag_finish_dev", "asx_ensemble",
            "asx_ensemble_dev", "asx_invert_stem", "asx_normalize", "asx_normalize_dev", "asx_residual_dev",
            "asx_profile_launches", "asx_debug_trace", "asx_resample_sinc", "asx_resample_sinc_dev", "asx_counter",
-           "asx_set_stft_window"]
+           "asx_set_stft_window", "asx_op_tdf_block"]
 
 
 class _LaunchRec(C.Structure):     # struct asx_launch_rec
@@ -289,6 +289,7 @@ def load_library():
     lib.asx_run_model.argtypes = [vp, _FP, i32, _FP, u32]
     lib.asx_op_conv.argtypes = [vp, C.c_char_p, _FP, i32, i32, i32, i32, _FP, _FP, i32, _FP, i32, _FP]
     lib.asx_op_tdf.argtypes = [vp, _FP, i32, i32, i32, i32, _FP, _FP, i32, _FP, _FP, _FP, _FP]
+    lib.asx_op_tdf_block.argtypes = [vp, _FP, i32, i32, i32, i32, _FP, _FP, _FP, i32, _FP, _FP, _FP, _FP, _FP]
     lib.asx_v3_begin.argtypes = [vp, C.POINTER(_V3Cfg)]
     lib.asx_v3_commit.argtypes = [vp]
     lib.asx_v3_flops.argtypes = [vp, i32]
@@ -444,7 +445,7 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         self._check(self._lib.asx_set_option(self._h, key.encode(), int(value)))
-        self._options[key] = (1 if int(value) > 0 else 0) if key in ("gemm_bf16x6", "gemm_f16x3") else max(0, int(value)) if key == "conv_direct_f16x3" else int(value)
+        self._options[key] = (1 if int(value) > 0 else 0) if key in ("gemm_bf16x6", "gemm_f16x3", "gemm_pair_images") else max(0, int(value)) if key == "conv_direct_f16x3" else int(value)
 
     def option(self, key: str) -> int:
         """Current value of an engine option (the library default when it was never set here)."""
@@ -453,7 +454,8 @@ class Engine:
                     "gemm_bf16x6": 1 if int(os.environ.get("ASX_GEMM_BF16X6", "1")) > 0 else 0,
                     "gemm_f16x3": 1 if int(os.environ.get("ASX_GEMM_F16X3", "1")) > 0 else 0,
                     "winograd_bf16x6": max(0, int(os.environ.get("ASX_WINO6", "144"))),
-                    "conv_direct_f16x3": max(0, int(os.environ.get("ASX_CONV3H", "144")))}
+                    "conv_direct_f16x3": max(0, int(os.environ.get("ASX_CONV3H", "144"))),
+                    "gemm_pair_images": 0}
         if key not in defaults:
             raise AsxError(f"unknown engine option {key!r} (known: {sorted(defaults)})")
         return self._options.get(key, defaults[key])
@@ -1059,6 +1061,21 @@ class Engine:
         self._check(self._lib.asx_op_tdf(self._h, _ptr(x), B, c, t, k, _ptr(w), _optptr(bias), n, _ptr(scale),
                                          _ptr(shift), _optptr(res), _ptr(y)))
         return y
+
+    def op_tdf_block(self, x, w0, scale0, shift0, w1, scale1, shift1, return_hidden=False):
+        """x + tdf(x) of a TDF block with a bottleneck (two linears, launched as the net launches them); with return_hidden also the
+        bottleneck activations as fp32 (decoded from the pair image when the first linear wrote one)."""
+        x, w0, w1 = _f32(x), _f32(w0), _f32(w1)
+        scale0, shift0, scale1, shift1 = _f32(scale0), _f32(shift0), _f32(scale1), _f32(shift1)
+        B, c, t, f = x.shape
+        n8 = w0.shape[0]
+        if w0.shape != (n8, f) or w1.shape != (f, n8):
+            raise AsxError(f"op_tdf_block: W0 {w0.shape} / W1 {w1.shape} do not fit rows of length {f}")
+        y = np.empty((B, c, t, f), np.float32)
+        h = np.empty((B, c, t, n8), np.float32) if return_hidden else None
+        self._check(self._lib.asx_op_tdf_block(self._h, _ptr(x), B, c, t, f, _ptr(w0), _ptr(scale0), _ptr(shift0), n8, _ptr(w1),
+                                               _ptr(scale1), _ptr(shift1), _ptr(y), _optptr(h)))
+        return (y, h) if return_hidden else y
 
     # -- profiling --------------------------------------------------------------
     def profile_enable(self, on: bool = True):

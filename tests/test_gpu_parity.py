@@ -335,6 +335,72 @@ def test_rowgemm_f16x3_block_exponent(A, shape):
 #    change is noticed: h = Inf gives v - h = NaN, so an Inf / NaN in x makes every accumulator of its ROW NaN in the bf16 x 6
 #    kernel where the fp32-MFMA kernel holds +-Inf (NaN when signs cancel); the TDF epilogue's ReLU is a maxNum (v_max_f32), which
 #    returns 0 for NaN -- so the affected row comes out 0 here and {Inf, 0} there.  No other row may change by a single bit.
+# Pair images (round 6; kernels_gemm3.h "operands split by their producer", option "gemm_pair_images" -- EXPERIMENTAL builds): the bottleneck activations of a TDF block
+# written by the first linear's epilogue as the two fp16 parts the second linear multiplies.  Against the same block through fp32 activations and
+# against float64; the decoded image against the fp32 activations; proof by counter that the pair-image reader ran.
+PAIR_CASES = [
+    # B, c, T, F, F/8, what
+    (2, 48, 228, 3072, 384, "plain"),       # level 0 of HQ_3, enough rows (171 tiles) for the launcher's 128 x 192 tile: two 192-column spans
+    (2, 48, 64, 3072, 384, "plain"),        # the same layer on few rows: 128-column tiles, three spans
+    (1, 96, 40, 1536, 192, "plain"),        # level 1
+    (1, 3, 37, 768, 96, "plain"),           # 64 x 128 tile form, ragged rows, one span
+    (2, 5, 33, 1024, 224, "plain"),         # last span narrower than a tile, ragged rows
+    (1, 4, 64, 3072, 384, "quiet_span"),    # the first span 2^-12 of the second: each keeps its own exponent
+    (1, 4, 64, 3072, 384, "loud_rows"),     # rows of a tile 2^16 apart
+    (1, 4, 64, 3072, 384, "dead_rows"),     # ReLU leaves whole rows of zeros (exponent of an all-zero span)
+]
+
+
+@pytest.mark.parametrize("B,c,T,F,F8,what", PAIR_CASES)
+def test_tdf_block_pair_image(A, B, c, T, F, F8, what):
+    rng = np.random.default_rng(F + F8 + len(what))
+    x = rng.standard_normal((B, c, T, F)).astype(np.float32)
+    w0 = (rng.standard_normal((F8, F)) / np.sqrt(F)).astype(np.float32)
+    w1 = (rng.standard_normal((F, F8)) / np.sqrt(F8)).astype(np.float32)
+    sc0, sc1 = (0.5 + rng.random(c)).astype(np.float32), (0.5 + rng.random(c)).astype(np.float32)
+    sh0, sh1 = (0.05 * rng.standard_normal(c)).astype(np.float32), (0.2 * rng.standard_normal(c)).astype(np.float32)
+    if what == "quiet_span":
+        w0[: F8 // 2] *= 2.0 ** -12
+        sh0[:] = 0
+    elif what == "loud_rows":
+        x *= (2.0 ** (4 * (np.arange(T) % 5) - 8)).astype(np.float32)[None, None, :, None]
+    elif what == "dead_rows":
+        sh0[:] = 0
+        x[:, :, ::3, :] = 0                                  # every third row: h = relu(0) = 0 in every column
+    eng = A.Engine(small_cfg(A))
+    _set_or_skip(eng, "gemm_pair_images", 1)               # experimental builds only (measured round 6: no gain in the nets, profiles/NOTES.md)
+    assert eng.option("gemm_f16x3") == 1
+    n0, p0 = eng.counter("tdf3h_launches"), eng.counter("tdf3_pair_image_launches")
+    y1, h1 = eng.op_tdf_block(x, w0, sc0, sh0, w1, sc1, sh1, return_hidden=True)
+    assert eng.counter("tdf3h_launches") - n0 == 2 and eng.counter("tdf3_pair_image_launches") - p0 == 1, "the pair-image reader did not run"
+    eng.set_option("gemm_pair_images", 0)
+    p0 = eng.counter("tdf3_pair_image_launches")
+    y0, h0 = eng.op_tdf_block(x, w0, sc0, sh0, w1, sc1, sh1, return_hidden=True)
+    assert eng.counter("tdf3_pair_image_launches") == p0, "pair image with the option off"
+    assert np.isfinite(y1).all() and np.isfinite(h1).all(), "unwritten (NaN canary) elements"
+    x64 = x.astype(np.float64)
+    h64 = np.maximum(sc0[None, :, None, None] * (x64 @ w0.astype(np.float64).T) + sh0[None, :, None, None], 0)
+    ref = np.maximum(sc1[None, :, None, None] * (h64 @ w1.astype(np.float64).T) + sh1[None, :, None, None], 0) + x64
+    # the decoded image holds the fp32 activations to 2^-21 of each (row, span)'s largest value (two 11-bit parts, rounding of either)
+    # (a span = a column tile of the first linear: 128 or 192 columns, the launcher's choice)
+    def worst(cols):
+        w = 0.0
+        for s0 in range(0, F8, cols):
+            a, b = h1[..., s0:s0 + cols].astype(np.float64), h0[..., s0:s0 + cols].astype(np.float64)
+            top = np.abs(b).max(axis=-1, keepdims=True)
+            w = max(w, float((np.abs(a - b) / np.maximum(top, 1e-300)).max()))
+        return w
+    wspan = min(worst(128), worst(192))
+    assert wspan <= 2.0 ** -21, (worst(128), worst(192))
+    # rows: as close to float64 as the block through fp32 activations (same products up to the exponent the parts carry)
+    rows = lambda v: np.sqrt(((v - ref) ** 2).sum(-1))
+    nrm = np.sqrt(((ref - x64) ** 2).sum(-1)) + 1e-30       # scale of tdf(x), the part the GEMMs produce
+    e1, e0 = rows(y1.astype(np.float64)) / nrm, rows(y0.astype(np.float64)) / nrm
+    live = nrm > 1e-20
+    assert (e1[live] <= 1.5 * e0[live] + 3e-7).all(), (float(e1[live].max()), float(e0[live].max()))
+    assert rel_rms(y1, y0) < 2e-7, rel_rms(y1, y0)
+
+
 @pytest.mark.parametrize("arith", ARITH)
 @pytest.mark.parametrize("xs,bar", [(1e-30, None), (1e-35, 1e-4), (1e35, None)])
 def test_rowgemm_bf16x6_extreme_magnitudes(A, xs, bar, arith):

@@ -162,6 +162,34 @@ def test_ep317_shape_excerpt_vs_oracle(A):
     assert dm.engine.rof_flops(1) > 0
 
 
+def test_feed_forward_pair_image_ab(A):
+    """The hidden activations of every feed-forward travel between its two linears as a pair image (option "gemm_pair_images", round 6): same
+    excerpt with the option on and off -- the pair-image reader ran once per feed-forward, never with the option off, and the stems agree
+    far inside the parity tolerance (the products are the same up to the exponent the parts carry)."""
+    cfg = R.RoformerConfig(dim=128, depth=2, heads=4, dim_head=64, freqs_per_bands=R.DEFAULT_FREQS_PER_BANDS,
+                           dim_t=161, mlp_expansion_factor=2)
+    sd = R.make_roformer_state(cfg, 2)
+    n = 441 * 160 + 1000
+    mix = (0.3 * np.random.default_rng(11).standard_normal((2, n))).astype(np.float32)
+    dm = A.MDXCDemixer({"model_data": cfg.as_model_data(), "torch_device": 0, "secondary_stem_name": "other"},
+                       {"overlap": 1}, state_dict=sd)
+    eng = dm.engine
+    try:
+        eng.set_option("gemm_pair_images", 1)
+    except A.AsxError as exc:
+        pytest.skip(f"default library: {exc}")
+    p0 = eng.counter("tdf3_pair_image_launches")
+    on = dm.demix(mix)["vocals"]
+    got = eng.counter("tdf3_pair_image_launches") - p0
+    passes = -(-n // (441 * 160))                            # chunks of the excerpt, one pass each at this length (overlap 1)
+    assert got > 0 and got % (2 * cfg.depth) == 0, (got, passes)   # one per feed-forward: depth x (time + frequency transformer) per pass
+    eng.set_option("gemm_pair_images", 0)
+    p0 = eng.counter("tdf3_pair_image_launches")
+    off = dm.demix(mix)["vocals"]
+    assert eng.counter("tdf3_pair_image_launches") == p0
+    assert rel_rms(on, off) < 2e-6, rel_rms(on, off)
+
+
 def test_batching_is_invisible(A):
     mix = (0.4 * np.random.default_rng(13).standard_normal((2, 1500))).astype(np.float32)
     outs = [demixer(A, CFG, 7, 2, max_batch=mb).demix(mix)["vocals"] for mb in (1, 2, 64)]

@@ -46,12 +46,12 @@ static void launch2(const TdfDmaArgs &a, hipStream_t s) {
   hipLaunchKernelGGL((tdf2_kernel<NREP, MREP, 0, 32>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS, s, a, 1, -1);
 }
 
-template <int NREP, int MREP>
+template <int NREP, int MREP, int ABL = 0, bool PS = false, int NW = 4>
 static void launch3h(const TdfDmaArgs &a, const u32x4 *w3, hipStream_t s) {
-  constexpr int BM = 16 * MREP, BN = 64 * NREP, LDS = 2 * 2 * BM * 64 + 12 * BM;
+  constexpr int BM = 16 * MREP, BN = 16 * NREP * NW, LDS = tdf3h_lds_bytes(BM);
   const int64_t nbm = (a.M + BM - 1) / BM;
   const int nbn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, 0, false, true>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS, s, a, w3, RowGather{});
+  hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL, false, true, PS, NW>), dim3((unsigned)(nbm * nbn)), dim3(64 * NW), LDS, s, a, w3, RowGather{});
 }
 
 static int g_map = 0;   // TdfDmaArgs::tile_map of the tdf3 launches (argv[4])
@@ -283,7 +283,180 @@ static double run_shape(const Shape &sh, int abl, int reps) {
   return t3;
 }
 
+
+// ---- a TDF block's two linears with the bottleneck activations as a PAIR IMAGE (argv[8] = 1): gemm1 (F -> F/8, BN, ReLU) writes H split,
+// gemm2 (F/8 -> F, BN, ReLU, + x) reads the parts; against the same two launches through an fp32 H, and a float64 chain on sampled rows
+static void run_chain(const char *name, int64_t M, int F, int F8, int C, int T, int reps) {
+  std::mt19937 rng(99 + F);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  const int64_t HB = std::min<int64_t>(M, 4096);
+  std::vector<float> hx((size_t)HB * F), hw1((size_t)F8 * F), hw2((size_t)F * F8), hsc1(C), hsh1(C), hsc2(C), hsh2(C);
+  for (int64_t r = 0; r < HB; ++r) {
+    const float rowmag = std::ldexp(1.0f, (int)(r % 5) * 4 - 8);   // rows of a tile differ by up to 2^16
+    for (int k = 0; k < F; ++k) hx[(size_t)r * F + k] = nd(rng) * 3.0f * rowmag;
+  }
+  for (auto &v : hw1) v = nd(rng) / std::sqrt((float)F);
+  for (auto &v : hw2) v = nd(rng) / std::sqrt((float)F8);
+  for (int n = 0; n < F8 / 2; ++n)                       // the first half of H's columns (one exponent span of two) is 2^-12 of the second
+    for (int k = 0; k < F; ++k) hw1[(size_t)n * F + k] *= 2.44140625e-4f;
+  for (int c = 0; c < C; ++c) {
+    hsc1[c] = 0.5f + 0.5f * std::fabs(nd(rng));
+    hsh1[c] = 0.2f * nd(rng) * 1e-3f;
+    hsc2[c] = 0.5f + 0.5f * std::fabs(nd(rng));
+    hsh2[c] = 0.2f * nd(rng);
+  }
+  float *dx, *dw1, *dw2, *dsc1, *dsh1, *dsc2, *dsh2, *dhA, *dhB, *dyA, *dyB;
+  int *dexp;
+  u32x4 *dw31, *dw32;
+  CK(hipMalloc(&dx, (size_t)M * F * 4));
+  CK(hipMalloc(&dw1, hw1.size() * 4));
+  CK(hipMalloc(&dw2, hw2.size() * 4));
+  CK(hipMalloc(&dsc1, C * 4));
+  CK(hipMalloc(&dsh1, C * 4));
+  CK(hipMalloc(&dsc2, C * 4));
+  CK(hipMalloc(&dsh2, C * 4));
+  CK(hipMalloc(&dhA, (size_t)M * F8 * 4));
+  CK(hipMalloc(&dhB, (size_t)M * F8 * 4));
+  CK(hipMalloc(&dyA, (size_t)M * F * 4));
+  CK(hipMalloc(&dyB, (size_t)M * F * 4));
+  const int cols = 192, nsp = (F8 + cols - 1) / cols;
+  CK(hipMalloc(&dexp, (size_t)M * nsp * 4));
+  for (int64_t r0 = 0; r0 < M; r0 += HB) CK(hipMemcpy(dx + r0 * F, hx.data(), (size_t)std::min<int64_t>(HB, M - r0) * F * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dw1, hw1.data(), hw1.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dw2, hw2.data(), hw2.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dsc1, hsc1.data(), C * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dsh1, hsh1.data(), C * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dsc2, hsc2.data(), C * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dsh2, hsh2.data(), C * 4, hipMemcpyHostToDevice));
+  auto image = [&](const float *dw, int N, int K, u32x4 *&img) {
+    const int ntiles = (N + 15) / 16, nk = ((K + 63) / 64) * 2;
+    CK(hipMalloc(&img, (size_t)ntiles * nk * 2 * 1024 + (size_t)ntiles * 16));
+    hipLaunchKernelGGL(w3h_split_kernel, dim3((unsigned)ntiles), dim3(256), 0, 0, dw, img, N, K, ntiles);
+  };
+  image(dw1, F8, F, dw31);
+  image(dw2, F, F8, dw32);
+  CK(hipDeviceSynchronize());
+  TdfDmaArgs g1{}, g2{};
+  g1.x = dx; g1.w = dw1; g1.scale = dsc1; g1.shift = dsh1; g1.M = M; g1.N = F8; g1.K = F; g1.C = C; g1.T = T; g1.relu = 1; g1.tile_map = 1;
+  g2.w = dw2; g2.scale = dsc2; g2.shift = dsh2; g2.res = dx; g2.M = M; g2.N = F; g2.K = F8; g2.C = C; g2.T = T; g2.relu = 1; g2.tile_map = 0;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  auto time_it = [&](auto &&fn) {
+    fn();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) fn();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return (double)ms / reps;
+  };
+  TdfDmaArgs a1 = g1, a2 = g2, b1 = g1, b2 = g2;
+  a1.y = dhA; a2.x = dhA; a2.y = dyA;
+  b1.y = dhB; b1.yexp = dexp; b1.yexp_n = nsp;
+  b2.x = dhB; b2.y = dyB; b2.xexp = dexp; b2.xexp_n = nsp; b2.xexp_gs = cols / 32; b2.xexp_inv = (65536 + b2.xexp_gs - 1) / b2.xexp_gs;
+  const double tA1 = time_it([&]() { launch3h<3, 8>(a1, dw31, 0); });
+  const double tA2 = time_it([&]() { launch3h<3, 8>(a2, dw32, 0); });
+  const double tB1 = time_it([&]() { launch3h<3, 8>(b1, dw31, 0); });
+  const double tB2 = time_it([&]() { launch3h<3, 8, 0, true>(b2, dw32, 0); });
+  CK(hipGetLastError());
+  // sampled rows against float64
+  const int nsamp = 48;
+  std::vector<float> yA(F), yB(F), hA(F8);
+  std::vector<uint32_t> hBraw(F8);
+  std::vector<int> ex(nsp);
+  double eA = 0, eB = 0, nrm = 0, dAB = 0, hdec = 0, hnrm = 0, worstq = 0;
+  int nonfin = 0;
+  for (int si = 0; si < nsamp; ++si) {
+    int64_t row = (int64_t)((double)si / nsamp * M);
+    if (si == nsamp - 1) row = M - 1;
+    const int64_t hrow = row % HB;
+    const int c = (int)((row / T) % C);
+    CK(hipMemcpy(yA.data(), dyA + row * F, F * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(yB.data(), dyB + row * F, F * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hA.data(), dhA + row * F8, F8 * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hBraw.data(), dhB + row * F8, F8 * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(ex.data(), dexp + row * nsp, nsp * 4, hipMemcpyDeviceToHost));
+    std::vector<double> h64(F8);
+    for (int n = 0; n < F8; ++n) {
+      double acc = 0;
+      for (int k = 0; k < F; ++k) acc += (double)hx[hrow * F + k] * (double)hw1[(size_t)n * F + k];
+      const double v = hsc1[c] * acc + hsh1[c];
+      h64[n] = v > 0 ? v : 0;
+    }
+    // decode the pair image: group of four columns = four h then four l
+    double qmax[2] = {0, 0}, qerr[2] = {0, 0};
+    for (int n = 0; n < F8; ++n) {
+      const int g = n >> 2, i = n & 3;
+      const uint16_t *p = reinterpret_cast<const uint16_t *>(hBraw.data() + g * 4);
+      auto f16 = [](uint16_t b) {
+        const int s = b >> 15, e = (b >> 10) & 31, m = b & 1023;
+        double v = e == 0 ? std::ldexp((double)m, -24) : (e == 31 ? (m ? NAN : INFINITY) : std::ldexp(1.0 + m / 1024.0, e - 15));
+        return s ? -v : v;
+      };
+      const double dec = std::ldexp(f16(p[i]) + f16(p[4 + i]), -ex[n / cols]);
+      hdec += (dec - hA[n]) * (dec - hA[n]);
+      hnrm += (double)hA[n] * hA[n];
+      const int q = n / cols;
+      qmax[q] = std::max(qmax[q], std::fabs((double)hA[n]));
+      qerr[q] = std::max(qerr[q], std::fabs(dec - hA[n]));
+    }
+    for (int q = 0; q < 2 && q < nsp; ++q)
+      if (qmax[q] > 0) worstq = std::max(worstq, qerr[q] / qmax[q]);
+    for (int n = 0; n < F; ++n) {
+      double acc = 0;
+      for (int k = 0; k < F8; ++k) acc += h64[k] * (double)hw2[(size_t)n * F8 + k];
+      double v = hsc2[c] * acc + hsh2[c];
+      v = (v > 0 ? v : 0) + hx[hrow * F + n];
+      if (!std::isfinite(yB[n])) ++nonfin;
+      eA += (yA[n] - v) * (yA[n] - v);
+      eB += (yB[n] - v) * (yB[n] - v);
+      dAB += ((double)yA[n] - yB[n]) * ((double)yA[n] - yB[n]);
+      nrm += v * v;
+    }
+  }
+  printf("%-14s M=%-8lld F=%-5d F/8=%-4d | gemm1 fp32-out %.3f ms, pair-image-out %.3f ms | gemm2 fp32-in %.3f ms, pair-image-in %.3f ms | block %.3f -> %.3f ms\n"
+         "    y vs f64: fp32 H %.2e, pair image %.2e; the two %.2e apart; nonfinite %d | H decoded vs fp32 H: rel rms %.2e, worst |d| / span max %.2e\n",
+         name, (long long)M, F, F8, tA1, tB1, tA2, tB2, tA1 + tA2, tB1 + tB2, std::sqrt(eA / nrm), std::sqrt(eB / nrm), std::sqrt(dAB / nrm), nonfin,
+         std::sqrt(hdec / hnrm), worstq);
+  fflush(stdout);
+  for (void *p : {(void *)dx, (void *)dw1, (void *)dw2, (void *)dsc1, (void *)dsh1, (void *)dsc2, (void *)dsh2, (void *)dhA, (void *)dhB, (void *)dyA,
+                  (void *)dyB, (void *)dexp, (void *)dw31, (void *)dw32})
+    CK(hipFree(p));
+}
+
+static int g_habl = 0;  // ablation of the fp16 x 3 launches (argv[1] when h = 1): 1 no split, 4 no epilogue traffic, 8 no weight loads, 16 no rescale, sums
 static void launch3h_sel(const TdfDmaArgs &a, const u32x4 *w3, hipStream_t s) {
+  if (g_tile == 0 && g_habl) {
+    switch (g_habl) {
+      case 1: return launch3h<3, 8, 1>(a, w3, s);
+      case 4: return launch3h<3, 8, 4>(a, w3, s);
+      case 8: return launch3h<3, 8, 8>(a, w3, s);
+      case 16: return launch3h<3, 8, 16>(a, w3, s);
+      case 17: return launch3h<3, 8, 17>(a, w3, s);
+      case 21: return launch3h<3, 8, 21>(a, w3, s);
+      case 29: return launch3h<3, 8, 29>(a, w3, s);
+      case 32: return launch3h<3, 8, 32>(a, w3, s);
+      case 64: {   // timing only: the pair-image reader on fp32 data (garbage results) -- loads and LDS stores stay, the split arithmetic goes
+        static int *zt = nullptr;
+        if (!zt) {
+          CK(hipMalloc(&zt, (size_t)1 << 22));
+          CK(hipMemset(zt, 0, (size_t)1 << 22));
+        }
+        TdfDmaArgs b = a;
+        b.xexp = zt;
+        b.xexp_n = 1;
+        b.xexp_gs = a.K / 32;
+        b.xexp_inv = (65536 + b.xexp_gs - 1) / b.xexp_gs;
+        return launch3h<3, 8, 0, true>(b, w3, s);
+      }
+      default: fprintf(stderr, "h abl?\n"); exit(2);
+    }
+  }
+  if (g_tile == 3) return launch3h<3, 8, 0, false, 8>(a, w3, s);   // 128 x 384, eight waves
+  if (g_tile == 4) return launch3h<2, 8, 0, false, 8>(a, w3, s);   // 128 x 256, eight waves
   if (g_tile == 1) launch3h<2, 8>(a, w3, s);
   else if (g_tile == 2) launch3h<2, 4>(a, w3, s);
   else launch3h<3, 8>(a, w3, s);
@@ -297,6 +470,14 @@ int main(int argc, char **argv) {
   g_h = argc > 5 ? atoi(argv[5]) : 0;
   g_full = argc > 6 ? atoi(argv[6]) : 0;
   g_tile = argc > 7 ? atoi(argv[7]) : 0;
+  if (g_h) g_habl = abl;
+  if (argc > 8 && atoi(argv[8]) == 1) {
+    run_chain("ragged small", 1000, 384, 192, 3, 8, 3);
+    run_chain("tdf L0 block", 675840, 3072, 384, 48, 256, 5);
+    run_chain("tdf L1 block", 675840, 1536, 192, 96, 128, 5);
+    run_chain("tdf L2 block", 506880, 768, 96, 144, 64, 5);
+    return 0;
+  }
   std::vector<Shape> shapes = {
       {"small ragged", 1000, 200, 192, 3, 8, 1, 1, 1},
       {"small gelu", 4096 + 64, 512, 256, 1, 1, 2, 1, 1},
