@@ -157,6 +157,9 @@ __device__ __forceinline__ void ldexp4_inplace(f32x4 &v, int e) {
 
 // exponent e with m 2^e in [2^14, 2^15) (m > 0 finite); m == 0 gives 15
 __device__ __forceinline__ int f16_scale_exp(float m) { return 15 - __builtin_amdgcn_frexp_expf(m); }
+// running block exponents (tdf3_kernel rows, conv_wino6_kernel tile rows): rise when the block's largest element is this many bits below the
+// range; never more than RISE_CAP bits above the lowest exponent the accumulators have carried
+constexpr int F16X3_RISE = 10, F16X3_RISE_CAP = 40;
 
 // W[N, K] fp32 -> fragment-ordered bf16 x 3 image: img[((nt * nk + ks) * 3 + part) * 64 + lane] = 8 bf16 of row nt * 16 + (lane & 15),
 // k = ks * 32 + (lane >> 4) * 8 .. + 7; rows >= N and stages past K (the image holds an even number of stages) are zero.  One
@@ -440,11 +443,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tdf3_kernel(TdfDmaAr
   }
 #endif
   int e_row[XC];
+  int e_lo[XC];                                        // the lowest exponent the row has carried (its loudest stage so far)
   int xslot[XC];
 #pragma unroll
   for (int i = 0; i < XC; ++i) {
     const int row = (tid + NT * i) >> 2;
     e_row[i] = 200;                                    // any first stage lowers it (accumulators are zero then)
+    e_lo[i] = 200;
     xslot[i] = (row & 15) * MREP + (row >> 4);
   }
   auto split_chunk_h = [&](int buf, int i, int ks_of) {   // ks_of: the stage these rows are the x of
@@ -456,9 +461,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tdf3_kernel(TdfDmaAr
       t = __builtin_amdgcn_update_dpp(b, b, 0x4E, 0xf, 0xf, false);       // quad_perm [2, 3, 0, 1]
       m = fmaxf(__int_as_float(b), __int_as_float(t));
     }
+    // The exponent follows the row's magnitude along k BOTH ways (round 6): down at once when a stage would pass 2^15 (two bits of headroom), up
+    // again when a stage's largest element sits more than F16X3_RISE bits below the range -- so that a row whose magnitude decays along k (a
+    // spectrum's high bins, channels behind a folded normalisation) keeps 22-bit products instead of carrying its loudest stage's exponent to
+    // the end.  Either way the accumulators follow by an exact power of two.  The rise is capped F16X3_RISE_CAP bits above the row's lowest
+    // exponent so far: what such a stage adds is below 2^-40 of what the accumulators hold, and they can never be scaled out of fp32's range.
     const int need = f16_scale_exp(m);
     const int e_old = e_row[i];
-    const int e_new = need < e_old ? need - 2 : e_old;
+    int e_new = e_old;
+    if (need < e_old) e_new = need - 2;
+    else if (need > e_old + F16X3_RISE && m > 0.f) e_new = min(need - 2, e_lo[i] + F16X3_RISE_CAP);
+    e_lo[i] = min(e_lo[i], e_new);
     e_row[i] = e_new;
     if ((tid & 3) == 0) {
       de_tab[buf * BM + xslot[i]] = e_new - e_old;

@@ -353,6 +353,7 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
 #pragma unroll
         for (int n = 0; n < 3; ++n) acc[m][q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int em[4] = {200, 200, 200, 200};                  // H: running exponent of tile row m (wave-uniform)
+    int em_lo[4] = {200, 200, 200, 200};               // H: the lowest it has been (rise cap)
 
     for (int ci = 0; ci < a.NCI; ++ci) {
       // this stage's planes were requested a stage ago, followed (in order) only by the 18 (H: 12) weight loads of this stage and, across
@@ -412,13 +413,33 @@ __device__ __forceinline__ void wino6_body(const ConvArgs &a, float *lds_f) {
             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(hv0[cp][0]), fabsf(hv0[cp][1])), fmaxf(fabsf(hv1[cp][0]), fabsf(hv1[cp][1]))));
           mx = wave_max64(mx);
           const int need = __builtin_amdgcn_readfirstlane(f16_scale_exp(mx));
-          const int e_new = need < em[m] ? need - 2 : em[m];
+          // down at once, up again when the chunk's largest element is F16X3_RISE bits below the range (kernels_gemm3.h split_chunk_h), at most
+          // F16X3_RISE_CAP bits above the tile row's lowest exponent so far
+          int e_new = em[m];
+          if (need < em[m]) e_new = need - 2;
+          else if (need > em[m] + F16X3_RISE && mx > 0.f) e_new = min(need - 2, em_lo[m] + F16X3_RISE_CAP);
+          em_lo[m] = min(em_lo[m], e_new);
+          // the exponent drops in few stages of a tile: the 24 multiplies by 2^(e_new - e_old) sit behind the wave-uniform test (in-place
+          // inline assembly -- as C++ inside a branch the compiler may keep a second accumulator set, kernels_gemm3.h stage_h)
+#ifdef ASX_WINO6_RESCALE_ALWAYS
           const float fdev = __builtin_ldexpf(1.0f, e_new - em[m]);
-          em[m] = e_new;
 #pragma unroll
           for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int n = 0; n < 3; ++n) acc[m][q][n] *= fdev;
+#else
+          if (e_new != em[m]) {
+            const float fdev = __builtin_ldexpf(1.0f, e_new - em[m]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+              for (int n = 0; n < 3; ++n)
+                asm volatile("v_mul_f32 %0, %4, %0\n\tv_mul_f32 %1, %4, %1\n\tv_mul_f32 %2, %4, %2\n\tv_mul_f32 %3, %4, %3"
+                             : "+v"(acc[m][q][n].x), "+v"(acc[m][q][n].y), "+v"(acc[m][q][n].z), "+v"(acc[m][q][n].w)
+                             : "v"(fdev));
+          }
+#endif
+          em[m] = e_new;
 #pragma unroll
           for (int cp = 0; cp < 4; ++cp) {
             split2h_pair(hv0[cp][0], hv0[cp][1], e_new, vh[0][cp], vl[0][cp]);

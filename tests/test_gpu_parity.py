@@ -270,15 +270,17 @@ def test_rowgemm_bf16x6_vs_float64(A, B, c, T, K, N, res, xs, arith):
 # stage), all-zero stages and all-zero rows.  Bars: whole result as close to float64 as the fp32 kernel; EVERY row and EVERY column group
 # within 4e-6 of its own scale (with ONE exponent per 128-row tile -- the first form of the kernel -- the "decay" case missed this by
 # 1e-2 on its quiet rows: that is what the per-row exponents are for).
-@pytest.mark.parametrize("shape", ["decay", "growing", "zeros", "chan4"])
+@pytest.mark.parametrize("shape", ["decay", "decay60", "growing", "zeros", "chan4"])
 def test_rowgemm_f16x3_block_exponent(A, shape):
+    # "decay60" (round 6): x falls by 2^-60 along k -- the running row exponent has to RISE after the loud stages or the columns that look at
+    # the quiet half of k lose everything (tests/test_f16x3_math.py::test_running_exponent_follows_a_decay is the CPU model of the policy)
     eng = A.Engine(small_cfg(A))
     B, c, T, K, N = 1, 2, 192, 1024, 272
     rng = np.random.default_rng(91)
     x = rng.standard_normal((B, c, T, K))
     k = np.arange(K)
-    if shape == "decay":
-        x *= np.exp2(-20.0 * k / K)[None, None, None, :] * np.exp2(3.0 * (np.arange(T) % 7) - 9)[None, None, :, None]
+    if shape.startswith("decay"):
+        x *= np.exp2((-60.0 if shape == "decay60" else -20.0) * k / K)[None, None, None, :] * np.exp2(3.0 * (np.arange(T) % 7) - 9)[None, None, :, None]
     elif shape == "growing":
         x *= np.exp2(24.0 * k / K)[None, None, None, :]
     else:
@@ -980,6 +982,36 @@ def test_conv3x3_winograd_bf16x6(A, B, cin, cout, T, F, relu, arith):
     r64 = (torch.relu(r64) if relu else r64).numpy()
     e6, e3 = rel_rms(y, r64), rel_rms(y3, r64)
     assert e6 < 1e-6 and e6 <= 1.25 * e3 + 1e-8, (e6, e3)
+
+
+@pytest.mark.parametrize("bits,order", [(12, "decay"), (30, "decay"), (60, "decay"), (30, "grow"), (60, "grow")])
+def test_conv3x3_winograd_f16x3_block_exponent(A, bits, order):
+    """The running block exponent of conv_wino6_kernel<H> under stress: one power-of-two exponent per tile row and 32-channel chunk of
+    the transformed input, carried along the input channels.  The input channels decay (or grow) by 2^bits across the layer and half of the
+    output channels look at the QUIET half of the input channels only.  The exponent follows the magnitude both ways (round 6: it used to drop
+    only, so a decaying layer carried its loudest chunk's exponent to the end and the quiet half lost bits / 2 - 12 bits): both halves of
+    the output fp32-grade at any spread."""
+    import torch
+    B, cin, cout, T, F = 1, 192, 64, 16, 64
+    eng = A.Engine(small_cfg(A))
+    eng.set_option("winograd_bf16x6", 64)
+    eng.set_option("conv_direct_f16x3", 0)
+    rng = np.random.default_rng(bits * 3 + len(order))
+    e = bits * np.arange(cin) / (cin - 1)
+    mag = np.exp2(-e if order == "decay" else e - bits).astype(np.float32)                       # loudest channel at 1.0 either way
+    x = rng.standard_normal((B, cin, T, F)).astype(np.float32) * mag[None, :, None, None]
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    quiet = np.arange(cin) >= cin // 2 if order == "decay" else np.arange(cin) < cin // 2
+    w[: cout // 2, ~quiet] = 0                                                                   # output channels 0 .. 31: quiet inputs only
+    b = np.zeros(cout, np.float32)
+    n0 = eng.counter("wino6h_launches")
+    y = eng.op_conv("conv3x3", x, w, b, relu=False)
+    assert eng.counter("wino6h_launches") == n0 + 1, "conv_wino6_kernel<H> did not run"
+    assert np.isfinite(y).all()
+    r64 = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), padding=1).numpy()
+    eq, el = rel_rms(y[:, : cout // 2], r64[:, : cout // 2]), rel_rms(y[:, cout // 2:], r64[:, cout // 2:])
+    print(f"wino6<H>, channels {order} by 2^{bits}: rel-RMS vs float64 {eq:.2e} (outputs of the quiet half) / {el:.2e} (the others)")
+    assert eq < 5e-7 and el < 5e-7, (eq, el)
 
 
 @pytest.mark.parametrize("B,T,F,relu,spread,c", [(1, 16, 128, True, 0.0, 48), (2, 8, 64, True, 0.0, 48), (3, 10, 96, False, 0.0, 48), (1, 4, 32, True, 0.0, 48),
