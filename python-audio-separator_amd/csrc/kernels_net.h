@@ -728,9 +728,13 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
           af[m] = in_s[c2 * PS + ((wave * RPW + rr) * S + dy) * IWA + (cc * 16 + li) * S + dx2];
         }
 #pragma unroll
-        for (int m = 0; m < MREP; ++m)
+        for (int m = 0; m < MREP; ++m) {
+#ifdef ASX_ABL_UPDOWN   // timing probe (wrong results): half of the MFMAs of the down / up convs
+          if (m & 1) continue;
+#endif
 #pragma unroll
           for (int n = 0; n < NREP; ++n) acc[m][n] = ASX_MFMA(af[m], bf[n], acc[m][n]);
+        }
       }
     } else if constexpr (S == 2 && KW == 2 && KC == 4 && LP == 0) {
       // 2x2 / stride-2 conv: the two dx taps of an output pixel are adjacent floats -> one conflict-free ds_read_b64 per
@@ -771,9 +775,13 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
             af[m] = in_s[(kq * 4 + lk) * PS + ((wave * RPW + rr) * S + dy) * IWA + LP + (cc * 16 + li) * S + dx];
           }
 #pragma unroll
-          for (int m = 0; m < MREP; ++m)
+          for (int m = 0; m < MREP; ++m) {
+#ifdef ASX_ABL_UPDOWN
+            if (CFG::EPI == 1 && (m & 1)) continue;
+#endif
 #pragma unroll
             for (int n = 0; n < NREP; ++n) acc[m][n] = ASX_MFMA(af[m], bf[n], acc[m][n]);
+          }
         }
       }
     }
