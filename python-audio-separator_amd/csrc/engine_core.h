@@ -84,6 +84,8 @@ struct ConvLayer {
   int wu6_nci = 0; // 32-channel stages of that image (0 = not packed: Cin < 64)
   DevBuf wu6h;     // the same for the fp16 x 3 arithmetic (wino6_pack_h): two fp16 parts per U, scaled per (position, cout); exponents behind the fragments
   DevBuf w3h;      // conv3h_kernel (kernels_conv3h.h): the 48 -> 48 layers' two-part fp16 weights in fragment order, one exponent per output channel
+  DevBuf wd6;      // CK_DOWN: conv_down6_kernel (kernels_updown6.h): the weights split three ways into bf16, fragment order [CG48][stage of 8 channels][part][n][lane][8]
+  int wd6_cg = 0, wd6_nst = 0, wd6_nrep = 3;
 };
 
 struct TdfLayer {
@@ -209,6 +211,10 @@ struct asx_engine {
   // (conv_wino6_kernel) at 144; the image is packed up to 144 channels.
   // ASX_CONV3H or asx_set_option("conv_direct_f16x3", n).
   int conv3h = getenv("ASX_CONV3H") ? std::max(0, atoi(getenv("ASX_CONV3H"))) : 144;
+  // 1 (default): the 2 x 2 / stride-2 convolutions between the levels run conv_down6_kernel (kernels_updown6.h: bf16 x 6 -- exact three-way split
+  // operands on the 16-bit matrix pipe, fp32 accumulation) while "gemm_bf16x6" is on; 0: the fp32-MFMA kernel conv_dma_kernel<2, 2, 2, 0, ...>.
+  // ASX_DOWN6 or asx_set_option("conv_down_bf16x6", n).
+  int down6 = getenv("ASX_DOWN6") ? atoi(getenv("ASX_DOWN6")) : 1;
   // EXPERIMENTAL builds only (`python build.py --experimental`; the default library refuses the option).  1: a matrix whose only reader is a row
   // GEMM on the fp16 x 3 arithmetic is written by its producer as a PAIR IMAGE -- the two fp16 parts the GEMM multiplies, in the bytes of the
   // fp32 values, one exponent per (row, column tile) beside it (kernels_net.h TdfDmaArgs::xexp; kernels_gemm3.h) -- so the reader splits

@@ -203,6 +203,16 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
     }
 #endif
   }
+  if (L.kind == CK_DOWN) {
+    // bf16 x 6 image of the 2 x 2 / stride-2 conv (kernels_updown6.h); which kernel RUNS is the engine's "gemm_bf16x6" option at launch time
+    std::vector<uint32_t> w6;
+    static const int wide = getenv("ASX_DOWN6_WIDE") ? atoi(getenv("ASX_DOWN6_WIDE")) : 1;   // A/B: 96-channel workgroups where Cout % 96 == 0
+    L.wd6_nrep = (wide && L.cout % 96 == 0) ? 6 : 3;
+    if (L.wd6_nrep == 6) down6_pack<6>(w, L.cout, L.cin, w6, &L.wd6_cg, &L.wd6_nst);
+    else down6_pack<3>(w, L.cout, L.cin, w6, &L.wd6_cg, &L.wd6_nst);
+    CHK(L.wd6.ensure(w6.size() * 4));
+    HIPCHK(hipMemcpy(L.wd6.p, w6.data(), w6.size() * 4, hipMemcpyHostToDevice));
+  }
   const int nb = (L.kind == CK_UP) ? CT * 16 : std::max(L.cg * NW, ((L.cout + 47) / 48) * 48);
   std::vector<float> bp(nb, 0.f);
   for (int i = 0; i < L.cout; ++i) bp[i] = b ? b[i] : 0.f;
@@ -227,6 +237,7 @@ static void launch_conv_dma_t(const ConvArgs &a, int nblk, hipStream_t s) {
 static std::atomic<long long> g_wino6_launches{0};   // launches of conv_wino6_kernel (kernels_wino6.h) since the process started
 static std::atomic<long long> g_wino6h_launches{0};  // ... of which on the fp16 x 3 arithmetic
 static std::atomic<long long> g_conv3h_launches{0};  // launches of conv3h_kernel (kernels_conv3h.h)
+static std::atomic<long long> g_down6_launches{0};   // launches of conv_down6_kernel (kernels_updown6.h)
 
 // Optional view description of a conv's operands (channel slices of larger buffers).
 struct ConvView {
@@ -514,6 +525,29 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     });
   }
 #endif
+  if (L.kind == CK_DOWN && e->gemm_bf16x6 > 0 && e->down6 > 0 && L.wd6.p != nullptr && dma && (a.Fo & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+      a.y_bstride % 4 == 0 && (v.res == nullptr || ((reinterpret_cast<uintptr_t>(v.res) & 15) == 0 && a.aux_bstride % 4 == 0))) {
+    // the stride-2 conv on the 16-bit matrix pipe (bf16 x 6: exact three-way split operands, fp32 accumulation; kernels_updown6.h)
+    ConvArgs da = a;
+    da.wp = reinterpret_cast<const float *>(L.wd6.p);
+    da.CG = L.wd6_cg;
+    da.NCI = L.wd6_nst;
+    da.tilesT = (a.To + Down6Cfg::TH - 1) / Down6Cfg::TH;
+    da.tilesF = (a.Fo + Down6Cfg::TW - 1) / Down6Cfg::TW;
+    const int nb6 = da.CG * da.tilesT * da.tilesF * B;
+    static bool attr6 = false;
+    if (!attr6) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_down6_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, Down6CfgT<3>::LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_down6_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, Down6CfgT<6>::LDS_BYTES);
+      attr6 = true;
+    }
+    g_down6_launches.fetch_add(1);
+    return timed(e, cls, flops, bytes, s, [&]() {
+      e->prof_nprod = 6;
+      if (L.wd6_nrep == 6) hipLaunchKernelGGL(conv_down6_kernel<6>, dim3(nb6), dim3(256), Down6CfgT<6>::LDS_BYTES, s, da);
+      else hipLaunchKernelGGL(conv_down6_kernel<3>, dim3(nb6), dim3(256), Down6CfgT<3>::LDS_BYTES, s, da);
+    });
+  }
 #define ASX_CONV_CASE(KH, KW, S, PAD, NR, KC, RPW, EPI)                                      \
   do {                                                                                       \
     if (dma) launch_conv_dma_t<ConvDmaCfg<KH, KW, S, PAD, NR, KC, RPW, EPI>>(d, nblk, s);    \

@@ -1,0 +1,222 @@
+// The 2 x 2 / stride-2 convolution between the levels of ConvTDFNet (uvr_lib_v5/mdxnet.py:66-72: Conv2d(c, c + g, (2, 2), stride 2) + BN + ReLU) on the
+// 16-bit matrix pipe with fp32 results (round 6).  The fp32-MFMA kernel it replaces (conv_dma_kernel<2, 2, 2, 0, ...>, kernels_net.h) is bound
+// by the fp32 matrix pipe: with half of its MFMAs removed it runs 33 % faster (profiles/r06_updown_half_mfma_probe.txt).
+//
+// Arithmetic: the bf16 x 6 form of kernels_gemm3.h -- every fp32 operand an EXACT sum of three bf16 numbers, six `v_mfma_f32_16x16x32_bf16` products per
+// 32-deep k step, fp32 accumulation, dropped cross terms <= 2^-24 of a product -- no block exponents, so nothing to manage for a layer whose input is read once.
+//
+// Implicit GEMM per output row: M = output pixels, N = output channels, K = 4 Cin with k = (channel, dy, dx).  One MFMA k step = EIGHT channels x four taps; a
+// lane's eight k values are channels (2 lk, 2 lk + 1) x (dy, dx) of its output pixel -- four `ds_read_b64` (the two dx taps of a pixel are adjacent floats).
+// Workgroup = 2 output rows x 64 output pixels x 48 output channels, four waves x (2 pixel tiles x 3 channel tiles); the input planes arrive by LDS-DMA
+// exactly as in conv_dma_kernel (a stage = 8 planes of 4 rows x 128 floats = 16 KB, double buffered), the weights as a pre-split fragment-ordered bf16
+// image (9 KB per stage: 3 parts x 3 channel tiles x 64 lanes x 16 B) by the same DMA: 52 KB of LDS, three workgroups per CU.  The x fragments are split in
+// registers (22 VALU per fragment, shared by the 3 x 6 MFMAs that use it).
+#pragma once
+#include "kernels_gemm3.h"
+
+namespace asx {
+
+// NREP: 16-channel tiles of the output per workgroup: 3 (48 channels; 52 KB of LDS, three workgroups per CU) or 6 (96 channels: the input is fetched once
+// for all of them where Cout is a multiple of 96 -- 70 KB, two workgroups per CU)
+template <int NREP_>
+struct Down6CfgT {
+  static constexpr int TH = 2, TW = 64, KC = 8, NREP = NREP_, NW = 16 * NREP_;
+  static constexpr int IH = 2 * TH, IWA = 2 * TW;      // staged input rows / floats per row of a plane
+  static constexpr int PLANE = IH * IWA;               // 512 floats
+  static constexpr int PS = PLANE + 16;                // plane stride (floats): channel pairs (2 lk, 2 lk + 1) of neighbouring lane groups 32 banks apart
+  static constexpr int XBYTES = KC * PS * 4;           // 16,896
+  static constexpr int WSTAGE_U32 = 3 * NREP * 64 * 4; // 2304 uint32 = 9216 B per (channel group, stage): [part][n][lane][4 uint32]
+  static constexpr int BUF = XBYTES + WSTAGE_U32 * 4;  // 26,112 B
+  static constexpr int LDS_BYTES = 2 * BUF;
+};
+typedef Down6CfgT<3> Down6Cfg;
+
+// host: float -> bf16 (round to nearest even; NaN stays NaN)
+static inline uint16_t down6_bf16_rne(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)((u >> 16) | ((u & 0xffffu) ? 0x40u : 0u));
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float down6_bf16_f(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// host: w [cout, cin, 2, 2] fp32 -> image [cg][stage][part][n][lane][8 bf16]; lane (li = lane & 15, lk = lane >> 4) holds output channel cg * 16 NREP + n * 16 + li,
+// k values e * 4 + dy * 2 + dx for channels stage * 8 + 2 lk + e (zeros past cout / cin).  v = h + m + l exactly (the two differences are exact in fp32).
+template <int NREP>
+static inline void down6_pack(const float *w, int cout, int cin, std::vector<uint32_t> &img, int *cg_out, int *nst_out) {
+  using Down6Cfg = Down6CfgT<NREP>;
+  const int cg = (cout + Down6Cfg::NW - 1) / Down6Cfg::NW, nst = (cin + Down6Cfg::KC - 1) / Down6Cfg::KC;
+  img.assign((size_t)cg * nst * Down6Cfg::WSTAGE_U32, 0u);
+  uint16_t *o = reinterpret_cast<uint16_t *>(img.data());
+  for (int g = 0; g < cg; ++g)
+    for (int st = 0; st < nst; ++st)
+      for (int n = 0; n < Down6Cfg::NREP; ++n)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int co = g * Down6Cfg::NW + n * 16 + (lane & 15), lk = lane >> 4;
+          for (int e = 0; e < 2; ++e)
+            for (int tap = 0; tap < 4; ++tap) {
+              const int c = st * Down6Cfg::KC + 2 * lk + e;
+              const float v = (co < cout && c < cin) ? w[((size_t)co * cin + c) * 4 + tap] : 0.f;
+              const uint16_t h = down6_bf16_rne(v);
+              const float r1 = v - down6_bf16_f(h);
+              const uint16_t m = down6_bf16_rne(r1);
+              const uint16_t l = down6_bf16_rne(r1 - down6_bf16_f(m));
+              const uint16_t parts[3] = {h, m, l};
+              for (int p = 0; p < 3; ++p)
+                o[((((size_t)(g * nst + st) * 3 + p) * Down6Cfg::NREP + n) * 64 + lane) * 8 + e * 4 + tap] = parts[p];
+            }
+        }
+  if (cg_out) *cg_out = cg;
+  if (nst_out) *nst_out = nst;
+}
+
+// a.wp: the image above; a.CG / a.NCI: its channel groups / stages; a.tilesT / a.tilesF: tiles of 2 output rows x 64 output pixels.  F % 4 == 0 (launcher).
+template <int NREP>
+__global__ __launch_bounds__(256, NREP == 3 ? 3 : 2) void conv_down6_kernel(ConvArgs a) {
+  using C = Down6CfgT<NREP>;
+  extern __shared__ float lds_f[];
+  char *lds = reinterpret_cast<char *>(lds_f);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cg = lid % a.CG;
+  lid /= a.CG;
+  const int tf = lid % a.tilesF;
+  lid /= a.tilesF;
+  const int tt = lid % a.tilesT;
+  const int b = lid / a.tilesT;
+  const int to0 = tt * C::TH, fo0 = tf * C::TW;
+  const int ti0 = 2 * to0, fa0 = 2 * fo0;
+
+  const float *xb = a.x + (int64_t)b * a.x_bstride;
+  const uint32_t *wg = reinterpret_cast<const uint32_t *>(a.wp) + (int64_t)cg * a.NCI * C::WSTAGE_U32;
+  const int64_t plane_sz = (int64_t)a.T * a.F;
+
+  // a plane = 128 sixteen-byte slots (4 rows x 32): this lane's two slots, the same for every plane
+  int sp_off[2];
+  bool sp_ok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int sidx = j * 64 + lane;
+    const int row = sidx >> 5, c4 = sidx & 31;
+    const int t = ti0 + row, f = fa0 + c4 * 4;
+    sp_ok[j] = t < a.T && f < a.F;
+    sp_off[j] = t * a.F + f;
+  }
+  auto issue = [&](int st, int buf) {
+    float *in_s = reinterpret_cast<float *>(lds + buf * C::BUF);
+    uint32_t *w_s = reinterpret_cast<uint32_t *>(lds + buf * C::BUF + C::XBYTES);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int pl = wave + 4 * p;
+      const int c = st * C::KC + pl;
+      const float *xc = xb + (int64_t)c * plane_sz;
+      const bool cok = c < a.Cin;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float *src = (cok && sp_ok[j]) ? xc + sp_off[j] : a.zeros;
+        ASX_GLDS16(src, in_s + pl * C::PS + j * 256);
+      }
+    }
+    const uint32_t *ws = wg + (int64_t)st * C::WSTAGE_U32;
+#pragma unroll
+    for (int i = 0; i < (3 * C::NREP + 3) / 4; ++i) {
+      const int q = wave + 4 * i;                      // 3 NREP pieces of 1 KB
+      if (q < 3 * C::NREP) ASX_GLDS16(ws + q * 256 + lane * 4, w_s + q * 256);
+    }
+  };
+
+  f32x4 acc[2][C::NREP];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < C::NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // this wave: output row wave >> 1 of the tile, pixel tiles (wave & 1) * 2 + {0, 1}
+  const int row = wave >> 1, col0 = (wave & 1) * 2;
+  issue(0, 0);
+  for (int st = 0; st < a.NCI; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 1 < a.NCI) issue(st + 1, (st + 1) & 1);
+    const float *in_s = reinterpret_cast<const float *>(lds + (st & 1) * C::BUF);
+    const u32x4 *w_s = reinterpret_cast<const u32x4 *>(lds + (st & 1) * C::BUF + C::XBYTES);
+    bf16x8 bw[3][C::NREP];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int n = 0; n < C::NREP; ++n) bw[p][n] = __builtin_bit_cast(bf16x8, w_s[(p * C::NREP + n) * 64 + lane]);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      // eight k values of pixel (col0 + m) * 16 + li: channels 2 lk, 2 lk + 1 x (dy, dx)
+      const float *p0 = in_s + (2 * lk) * C::PS + (2 * row) * C::IWA + 2 * ((col0 + m) * 16 + li);
+      const f32x2 c0d0 = *reinterpret_cast<const f32x2 *>(p0);
+      const f32x2 c0d1 = *reinterpret_cast<const f32x2 *>(p0 + C::IWA);
+      const f32x2 c1d0 = *reinterpret_cast<const f32x2 *>(p0 + C::PS);
+      const f32x2 c1d1 = *reinterpret_cast<const f32x2 *>(p0 + C::PS + C::IWA);
+      unsigned hh[4], mm[4], ll[4];
+      split3_pair(c0d0.x, c0d0.y, hh[0], mm[0], ll[0]);
+      split3_pair(c0d1.x, c0d1.y, hh[1], mm[1], ll[1]);
+      split3_pair(c1d0.x, c1d0.y, hh[2], mm[2], ll[2]);
+      split3_pair(c1d1.x, c1d1.y, hh[3], mm[3], ll[3]);
+      const bf16x8 xh = __builtin_bit_cast(bf16x8, (u32x4){hh[0], hh[1], hh[2], hh[3]});
+      const bf16x8 xm = __builtin_bit_cast(bf16x8, (u32x4){mm[0], mm[1], mm[2], mm[3]});
+      const bf16x8 xl = __builtin_bit_cast(bf16x8, (u32x4){ll[0], ll[1], ll[2], ll[3]});
+      // smallest terms first (kernels_gemm3.h); the NREP channel tiles of one product are independent accumulators
+#pragma unroll
+      for (int n = 0; n < C::NREP; ++n) acc[m][n] = ASX_MFMA_BF16(xh, bw[2][n], acc[m][n]);
+#pragma unroll
+      for (int n = 0; n < C::NREP; ++n) acc[m][n] = ASX_MFMA_BF16(xl, bw[0][n], acc[m][n]);
+#pragma unroll
+      for (int n = 0; n < C::NREP; ++n) acc[m][n] = ASX_MFMA_BF16(xm, bw[1][n], acc[m][n]);
+#pragma unroll
+      for (int n = 0; n < C::NREP; ++n) acc[m][n] = ASX_MFMA_BF16(xh, bw[1][n], acc[m][n]);
+#pragma unroll
+      for (int n = 0; n < C::NREP; ++n) acc[m][n] = ASX_MFMA_BF16(xm, bw[0][n], acc[m][n]);
+#pragma unroll
+      for (int n = 0; n < C::NREP; ++n) acc[m][n] = ASX_MFMA_BF16(xh, bw[0][n], acc[m][n]);
+    }
+  }
+
+  // ---- epilogue: bias + activation (+ residual); a lane holds four consecutive pixels of output channel li of each channel tile
+  const int t = to0 + row;
+  if (t >= a.To) return;
+  float *yb = a.y + (int64_t)b * a.y_bstride;
+  const float *rb = a.res ? a.res + (int64_t)b * a.aux_bstride : nullptr;
+#pragma unroll
+  for (int n = 0; n < C::NREP; ++n) {
+    const int co = cg * C::NW + n * 16 + li;
+    if (co >= a.Cout) continue;
+    const float bv = a.bias[co];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int f = fo0 + (col0 + m) * 16 + lk * 4;
+      const int64_t off = ((int64_t)co * a.To + t) * a.Fo + f;
+      const f32x4 v = acc[m][n];
+      if ((a.Fo & 3) == 0 && f + 4 <= a.Fo) {
+        f32x4 o;
+        o.x = act_fn(v.x + bv, a.act);
+        o.y = act_fn(v.y + bv, a.act);
+        o.z = act_fn(v.z + bv, a.act);
+        o.w = act_fn(v.w + bv, a.act);
+        if (rb != nullptr) o += *reinterpret_cast<const f32x4 *>(rb + off);
+        *reinterpret_cast<f32x4 *>(yb + off) = o;
+      } else {
+        const float ov[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (f + r < a.Fo) yb[off + r] = act_fn(ov[r] + bv, a.act) + (rb != nullptr ? rb[off + r] : 0.f);
+      }
+    }
+  }
+}
+
+}  // namespace asx

@@ -175,6 +175,37 @@ def test_conv_layers(A, op, B, cin, cout, T, F):
     assert max_abs(y, ref) < 2e-5, (max_abs(y, ref), rel_rms(y, ref))
 
 
+@pytest.mark.parametrize("B,cin,cout,T,F", [(1, 48, 96, 16, 128), (2, 96, 144, 8, 256), (1, 144, 192, 12, 136), (2, 8, 16, 16, 32), (1, 50, 144, 6, 72),
+                                             (1, 20, 40, 7, 132), (1, 240, 288, 4, 192), (3, 48, 96, 2, 8)])
+def test_down_conv_bf16x6(A, B, cin, cout, T, F):
+    """conv_down6_kernel (csrc/kernels_updown6.h, round 6): the 2 x 2 / stride-2 conv between the levels on the 16-bit matrix pipe -- six bf16 products on
+    exactly split operands, fp32 accumulation.  Against float64 and against the fp32-MFMA kernel it replaces (option conv_down_bf16x6 = 0), with proof
+    of which ran; channel counts off the 8 / 48 grids, odd output heights, output widths off the 64-pixel tile, several batch items."""
+    import torch
+    eng = A.Engine(small_cfg(A))
+    assert eng.option("conv_down_bf16x6") == 1 and eng.option("gemm_bf16x6") == 1
+    rng = np.random.default_rng(cin * 100 + cout + F)
+    x = (rng.standard_normal((B, cin, T, F)) * np.exp2(rng.integers(-6, 7, (B, cin, 1, 1)))).astype(np.float32)   # channels 2^12 apart
+    w = (rng.standard_normal((cout, cin, 2, 2)) / np.sqrt(4 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    n0 = eng.counter("down6_launches")
+    y = eng.op_conv("down", x, w, b, relu=True)
+    assert eng.counter("down6_launches") == n0 + (1 if F % 8 == 0 else 0), "conv_down6_kernel did not run"   # (16-byte output rows: else the fp32 kernel)
+    assert np.array_equal(y, eng.op_conv("down", x, w, b, relu=True)), "not deterministic"
+    eng.set_option("conv_down_bf16x6", 0)
+    n0 = eng.counter("down6_launches")
+    y32 = eng.op_conv("down", x, w, b, relu=True)
+    assert eng.counter("down6_launches") == n0, "the fp32 run went through conv_down6_kernel"
+    assert np.isfinite(y).all(), "unwritten (NaN canary) output elements"
+    r64 = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=2)).numpy()
+    mag = torch.nn.functional.conv2d(torch.from_numpy(x).double().abs(), torch.from_numpy(w).double().abs(), stride=2).numpy() + np.abs(b)[None, :, None, None]
+    d6, d32 = np.abs(y - r64), np.abs(y32 - r64)
+    assert (d6 <= 8e-7 * mag + 1e-30).all(), float((d6 / mag).max())           # every output against the size of its own products (K <= 960: a few fp32 roundings of the running sum)
+    e6, e32 = rel_rms(y, r64), rel_rms(y32, r64)
+    print(f"down conv {cin} -> {cout}: rel-RMS vs float64 {e6:.2e} (bf16 x 6) / {e32:.2e} (fp32 MFMA)")
+    assert e6 <= 1.25 * e32 + 1e-8, (e6, e32)                                # at least as close as the fp32 kernel
+
+
 TDF_CASES = [
     # B, c, T, K, N, bias, res
     (1, 48, 16, 3072, 384, False, False), (1, 48, 16, 384, 3072, False, True), (2, 8, 16, 32, 8, True, False),
