@@ -187,6 +187,7 @@ static void free_conv(ConvLayer &L) {
   L.wu6h.release();
   L.w3h.release();
   L.wd6.release();
+  L.wup6.release();
   L.gn_w.release();
   L.gn_b.release();
 }
@@ -1013,7 +1014,7 @@ int asx_op_conv(asx_engine *e, const char *op, const float *x_host, int32_t B, i
   }
   ConvLayer L;
   DevBuf dx, dy, dskip;
-  BufGuard g{{&dx, &dy, &dskip, &L.w, &L.b, &L.wu, &L.wu2, &L.wu3, &L.wus, &L.wu6, &L.wu6h, &L.w3h, &L.wd6}};
+  BufGuard g{{&dx, &dy, &dskip, &L.w, &L.b, &L.wu, &L.wu2, &L.wu3, &L.wus, &L.wu6, &L.wu6h, &L.w3h, &L.wd6, &L.wup6}};
   CHK(conv_setup(L, kind, cin, cout, relu ? 1 : 0));
   CHK(conv_pack(L, w_host, b_host, e->winograd));
   CHK(to_dev(dx, x_host, (size_t)B * cin * t * f));
@@ -1972,6 +1973,7 @@ int asx_counter(const asx_engine *e, const char *name, int64_t *out) {
   else if (nm == "conv3h_launches") *out = (int64_t)g_conv3h_launches.load();
   else if (nm == "tdf3_pair_image_launches") *out = (int64_t)g_tdf3ps_launches.load();
   else if (nm == "down6_launches") *out = (int64_t)g_down6_launches.load();
+  else if (nm == "up6_launches") *out = (int64_t)g_up6_launches.load();
   else {
     set_err("asx_counter: unknown counter '%s'", name);
     return ASX_ERR_INVALID;
@@ -2157,6 +2159,10 @@ int asx_set_option(asx_engine *e, const char *key, int32_t value) {
   }
   if (!strcmp(key, "conv_down_bf16x6")) {
     e->down6 = value > 0 ? 1 : 0;
+    return ASX_OK;
+  }
+  if (!strcmp(key, "conv_up_bf16x6")) {
+    e->up6 = value > 0 ? 1 : 0;
     return ASX_OK;
   }
   if (!strcmp(key, "gemm_pair_images")) {

@@ -86,6 +86,8 @@ struct ConvLayer {
   DevBuf w3h;      // conv3h_kernel (kernels_conv3h.h): the 48 -> 48 layers' two-part fp16 weights in fragment order, one exponent per output channel
   DevBuf wd6;      // CK_DOWN: conv_down6_kernel (kernels_updown6.h): the weights split three ways into bf16, fragment order [CG48][stage of 8 channels][part][n][lane][8]
   int wd6_cg = 0, wd6_nst = 0, wd6_nrep = 3;
+  DevBuf wup6;     // CK_UP: conv_up6_kernel (kernels_updown6.h): [CG][stage of 32 channels][part][n][lane][8 bf16] over the 4 Cout virtual channels
+  int wup6_cg = 0, wup6_nst = 0;
 };
 
 struct TdfLayer {
@@ -215,6 +217,8 @@ struct asx_engine {
   // operands on the 16-bit matrix pipe, fp32 accumulation) while "gemm_bf16x6" is on; 0: the fp32-MFMA kernel conv_dma_kernel<2, 2, 2, 0, ...>.
   // ASX_DOWN6 or asx_set_option("conv_down_bf16x6", n).
   int down6 = getenv("ASX_DOWN6") ? atoi(getenv("ASX_DOWN6")) : 1;
+  // the same for the transposed 2 x 2 / stride-2 convolutions of the decoder (conv_up6_kernel).  ASX_UP6 or asx_set_option("conv_up_bf16x6", n).
+  int up6 = getenv("ASX_UP6") ? atoi(getenv("ASX_UP6")) : 1;
   // EXPERIMENTAL builds only (`python build.py --experimental`; the default library refuses the option).  1: a matrix whose only reader is a row
   // GEMM on the fp16 x 3 arithmetic is written by its producer as a PAIR IMAGE -- the two fp16 parts the GEMM multiplies, in the bytes of the
   // fp32 values, one exponent per (row, column tile) beside it (kernels_net.h TdfDmaArgs::xexp; kernels_gemm3.h) -- so the reader splits

@@ -213,6 +213,15 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
     CHK(L.wd6.ensure(w6.size() * 4));
     HIPCHK(hipMemcpy(L.wd6.p, w6.data(), w6.size() * 4, hipMemcpyHostToDevice));
   }
+  if (L.kind == CK_UP) {
+    // bf16 x 6 image of the transposed conv (kernels_updown6.h), same virtual-tile grouping as the fp32 image (L.nrep tiles per workgroup)
+    std::vector<uint32_t> w6;
+    if (L.nrep == 6) up6_pack<6>(w, L.cout, L.cin, w6, &L.wup6_cg, &L.wup6_nst);
+    else if (L.nrep == 4) up6_pack<4>(w, L.cout, L.cin, w6, &L.wup6_cg, &L.wup6_nst);
+    else up6_pack<2>(w, L.cout, L.cin, w6, &L.wup6_cg, &L.wup6_nst);
+    CHK(L.wup6.ensure(w6.size() * 4));
+    HIPCHK(hipMemcpy(L.wup6.p, w6.data(), w6.size() * 4, hipMemcpyHostToDevice));
+  }
   const int nb = (L.kind == CK_UP) ? CT * 16 : std::max(L.cg * NW, ((L.cout + 47) / 48) * 48);
   std::vector<float> bp(nb, 0.f);
   for (int i = 0; i < L.cout; ++i) bp[i] = b ? b[i] : 0.f;
@@ -238,6 +247,7 @@ static std::atomic<long long> g_wino6_launches{0};   // launches of conv_wino6_k
 static std::atomic<long long> g_wino6h_launches{0};  // ... of which on the fp16 x 3 arithmetic
 static std::atomic<long long> g_conv3h_launches{0};  // launches of conv3h_kernel (kernels_conv3h.h)
 static std::atomic<long long> g_down6_launches{0};   // launches of conv_down6_kernel (kernels_updown6.h)
+static std::atomic<long long> g_up6_launches{0};     // launches of conv_up6_kernel
 
 // Optional view description of a conv's operands (channel slices of larger buffers).
 struct ConvView {
@@ -546,6 +556,31 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
       e->prof_nprod = 6;
       if (L.wd6_nrep == 6) hipLaunchKernelGGL(conv_down6_kernel<6>, dim3(nb6), dim3(256), Down6CfgT<6>::LDS_BYTES, s, da);
       else hipLaunchKernelGGL(conv_down6_kernel<3>, dim3(nb6), dim3(256), Down6CfgT<3>::LDS_BYTES, s, da);
+    });
+  }
+  if (L.kind == CK_UP && e->gemm_bf16x6 > 0 && e->up6 > 0 && L.wup6.p != nullptr && dma && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && a.y_bstride % 4 == 0 &&
+      (skip == nullptr || ((reinterpret_cast<uintptr_t>(skip) & 15) == 0 && a.aux_bstride % 4 == 0))) {
+    // the transposed conv on the 16-bit matrix pipe (bf16 x 6; kernels_updown6.h)
+    ConvArgs ua = a;
+    ua.wp = reinterpret_cast<const float *>(L.wup6.p);
+    ua.CG = L.wup6_cg;
+    ua.NCI = L.wup6_nst;
+    ua.tilesT = (T + 1) / 2;
+    ua.tilesF = (F + 63) / 64;
+    const int nbu = ua.CG * ua.tilesT * ua.tilesF * B;
+    static bool attru = false;
+    if (!attru) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_up6_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, Up6CfgT<6>::LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_up6_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, Up6CfgT<4>::LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_up6_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, Up6CfgT<2>::LDS_BYTES);
+      attru = true;
+    }
+    g_up6_launches.fetch_add(1);
+    return timed(e, cls, flops, bytes, s, [&]() {
+      e->prof_nprod = 6;
+      if (L.nrep == 6) hipLaunchKernelGGL(conv_up6_kernel<6>, dim3(nbu), dim3(256), Up6CfgT<6>::LDS_BYTES, s, ua);
+      else if (L.nrep == 4) hipLaunchKernelGGL(conv_up6_kernel<4>, dim3(nbu), dim3(256), Up6CfgT<4>::LDS_BYTES, s, ua);
+      else hipLaunchKernelGGL(conv_up6_kernel<2>, dim3(nbu), dim3(256), Up6CfgT<2>::LDS_BYTES, s, ua);
     });
   }
 #define ASX_CONV_CASE(KH, KW, S, PAD, NR, KC, RPW, EPI)                                      \

@@ -445,7 +445,7 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         self._check(self._lib.asx_set_option(self._h, key.encode(), int(value)))
-        self._options[key] = (1 if int(value) > 0 else 0) if key in ("gemm_bf16x6", "gemm_f16x3", "gemm_pair_images", "conv_down_bf16x6") else max(0, int(value)) if key == "conv_direct_f16x3" else int(value)
+        self._options[key] = (1 if int(value) > 0 else 0) if key in ("gemm_bf16x6", "gemm_f16x3", "gemm_pair_images", "conv_down_bf16x6", "conv_up_bf16x6") else max(0, int(value)) if key == "conv_direct_f16x3" else int(value)
 
     def option(self, key: str) -> int:
         """Current value of an engine option (the library default when it was never set here)."""
@@ -456,7 +456,8 @@ class Engine:
                     "winograd_bf16x6": max(0, int(os.environ.get("ASX_WINO6", "144"))),
                     "conv_direct_f16x3": max(0, int(os.environ.get("ASX_CONV3H", "144"))),
                     "gemm_pair_images": 0,
-                    "conv_down_bf16x6": 1 if int(os.environ.get("ASX_DOWN6", "1")) > 0 else 0}
+                    "conv_down_bf16x6": 1 if int(os.environ.get("ASX_DOWN6", "1")) > 0 else 0,
+                    "conv_up_bf16x6": 1 if int(os.environ.get("ASX_UP6", "1")) > 0 else 0}
         if key not in defaults:
             raise AsxError(f"unknown engine option {key!r} (known: {sorted(defaults)})")
         return self._options.get(key, defaults[key])

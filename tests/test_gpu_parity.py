@@ -206,6 +206,39 @@ def test_down_conv_bf16x6(A, B, cin, cout, T, F):
     assert e6 <= 1.25 * e32 + 1e-8, (e6, e32)                                # at least as close as the fp32 kernel
 
 
+@pytest.mark.parametrize("B,cin,cout,T,F", [(1, 96, 48, 8, 64), (2, 144, 96, 4, 96), (1, 192, 144, 6, 72), (2, 16, 8, 8, 16), (1, 24, 16, 5, 8),
+                                             (1, 64, 32, 6, 40), (1, 288, 240, 2, 96), (1, 100, 20, 3, 68)])
+def test_up_conv_bf16x6(A, B, cin, cout, T, F):
+    """conv_up6_kernel (csrc/kernels_updown6.h, round 6): the transposed 2 x 2 / stride-2 conv of the decoder with its `x *= skip`, on the 16-bit matrix pipe
+    (six bf16 products on exactly split operands).  Against float64 and the fp32-MFMA kernel (option conv_up_bf16x6 = 0), with proof of which ran; every
+    virtual-tile grouping (Cout = 48 / 96 -> 6, 32 -> 4, 8 / 16 / 20 -> 2), channel counts off the 32-channel stage, odd heights, widths off the tile."""
+    import torch
+    eng = A.Engine(small_cfg(A))
+    assert eng.option("conv_up_bf16x6") == 1
+    rng = np.random.default_rng(cin * 100 + cout + F)
+    x = (rng.standard_normal((B, cin, T, F)) * np.exp2(rng.integers(-6, 7, (B, cin, 1, 1)))).astype(np.float32)
+    w = (rng.standard_normal((cin, cout, 2, 2)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    skip = rng.standard_normal((B, cout, 2 * T, 2 * F)).astype(np.float32)
+    n0 = eng.counter("up6_launches")
+    y = eng.op_conv("up", x, w, b, aux=skip, relu=True)
+    assert eng.counter("up6_launches") == n0 + 1, "conv_up6_kernel did not run"
+    assert np.array_equal(y, eng.op_conv("up", x, w, b, aux=skip, relu=True)), "not deterministic"
+    eng.set_option("conv_up_bf16x6", 0)
+    n0 = eng.counter("up6_launches")
+    y32 = eng.op_conv("up", x, w, b, aux=skip, relu=True)
+    assert eng.counter("up6_launches") == n0, "the fp32 run went through conv_up6_kernel"
+    assert np.isfinite(y).all(), "unwritten (NaN canary) output elements"
+    xt, wt = torch.from_numpy(x).double(), torch.from_numpy(w).double()
+    r64 = (torch.relu(torch.nn.functional.conv_transpose2d(xt, wt, torch.from_numpy(b).double(), stride=2)) * torch.from_numpy(skip).double()).numpy()
+    mag = (torch.nn.functional.conv_transpose2d(xt.abs(), wt.abs(), stride=2).numpy() + np.abs(b)[None, :, None, None]) * np.abs(skip)
+    d6 = np.abs(y - r64)
+    assert (d6 <= 8e-7 * mag + 1e-30).all(), float((d6 / np.maximum(mag, 1e-300)).max())
+    e6, e32 = rel_rms(y, r64), rel_rms(y32, r64)
+    print(f"up conv {cin} -> {cout}: rel-RMS vs float64 {e6:.2e} (bf16 x 6) / {e32:.2e} (fp32 MFMA)")
+    assert e6 <= 1.25 * e32 + 1e-8, (e6, e32)
+
+
 TDF_CASES = [
     # B, c, T, K, N, bias, res
     (1, 48, 16, 3072, 384, False, False), (1, 48, 16, 384, 3072, False, True), (2, 8, 16, 32, 8, True, False),
