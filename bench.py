@@ -575,7 +575,18 @@ def main():
                     continue
                 tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
                 gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9
-                if tf / PEAK_FP32_MFMA_TFLOPS >= gb / 8000.0:   # the roof the class sits closer to is the one that binds it
+                # the level-change convs run six bf16 products per multiply-add on the 16-bit pipe since round 6 (csrc/kernels_updown6.h): price them there
+                ud6 = (k == "down" and eng.option("conv_down_bf16x6") > 0 and eng.option("gemm_bf16x6") > 0) or \
+                      (k == "up" and eng.option("conv_up_bf16x6") > 0 and eng.option("gemm_bf16x6") > 0)
+                mfma_frac = tf * 6.0 / PEAK_BF16_MFMA_TFLOPS if ud6 else tf / PEAK_FP32_MFMA_TFLOPS
+                if ud6 and mfma_frac >= gb / 8000.0:
+                    stages[k] = {"bound": "mfma", "achieved": round(tf * 6.0, 1), "unit": "TFLOP/s", "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(mfma_frac, 4),
+                                 "dtype": "bf16 x 6 products (fp32-exact split operands)", "fp32_equivalent": round(tf, 2)}
+                elif ud6:
+                    stages[k] = {"bound": "hbm", "achieved": round(gb, 1), "unit": "GB/s", "frac": round(gb / 8000.0, 4), "frac_vs_copy": round(gb / 6290.0, 4),
+                                 "mfma": {"executed_tflops_16bit": round(tf * 6.0, 1), "frac": round(mfma_frac, 4),
+                                          "dtype": "bf16 x 6 products (fp32-exact split operands)", "fp32_equivalent": round(tf, 2)}}
+                elif tf / PEAK_FP32_MFMA_TFLOPS >= gb / 8000.0:   # the roof the class sits closer to is the one that binds it
                     if k == "conv3x3" and eng.option("winograd") > 0 and w6c > 0:
                         # two kernels share the class since round 5: conv_wino3_kernel (fp32 MFMA) below `w6c` channels -- its executed rate
                         # and fraction are `roofline.achieved / frac` -- and conv_wino6_kernel (bf16 x 6) from there up; per level: roofline.per_level

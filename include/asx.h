@@ -496,6 +496,7 @@ int asx_invert_stem(asx_engine *e, const float *mix_host, const float *stem_host
  * "attn6h_launches" (those of them on the fp16 x 3 arithmetic),
  * "wino6_launches" (conv_wino6_kernel: Winograd F(2x2,3x3) on the 16-bit pipe), "wino6h_launches" (those on the fp16 x 3 arithmetic),
  * "conv3h_launches" (ABI 7: conv3h_kernel, the direct fp16 x 3 convolution of the 48-channel level),
+ * "down6_launches" / "up6_launches" (ABI 7: conv_down6_kernel / conv_up6_kernel, the level-change convs on the 16-bit matrix pipe),
  * "tdf3_pair_image_launches" (ABI 7: the tdf3_kernel launches that read their x operand as a pair image -- option "gemm_pair_images", experimental builds).
  * ASX_ERR_INVALID for an unknown name. */
 int asx_counter(const asx_engine *e, const char *name, int64_t *out);
@@ -557,6 +558,12 @@ int asx_op_tdf_block(asx_engine *e, const float *x_host, int32_t batch, int32_t 
  * matrix pipe with the arithmetic of "gemm_f16x3" (which must be on, as "gemm_bf16x6" and "winograd" = 3) -- the two-part weight image stays in
  * LDS for the whole launch, producer waves fetch four input rows per step into a ring walked down T and split them under one running
  * power-of-two exponent per walk, consumer waves multiply; 5.3-5.8 ms per launch of 55 chunks against 8.5-8.9 on conv_wino3_kernel.  0 = conv_wino3_kernel.
+ * "conv_down_bf16x6" / "conv_up_bf16x6" (ABI 7; also ASX_DOWN6 / ASX_UP6): 1 (default) = the 2 x 2 / stride-2 convolutions between the levels
+ * (mdxnet.py:66-72) and the transposed ones of the decoder with their `x *= skip` (mdxnet.py:80-86, 113) run conv_down6_kernel / conv_up6_kernel
+ * (csrc/kernels_updown6.h) while "gemm_bf16x6" is on: the arithmetic of that option -- both fp32 operands split EXACTLY into three bf16 parts, six
+ * bf16 MFMA products per multiply-add, fp32 accumulation; the weights pre-split into a fragment-ordered image when they are loaded -- on
+ * input planes the LDS-DMA brings in as fp32; 5.5 against 8.9 ms and 8.4 against 10.2 ms per 4-minute song, closer to float64 than the
+ * fp32-MFMA kernels they replace.  0 = conv_dma_kernel<2, 2, 2, 0, ...> / <1, 1, 1, 0, ..., EPI_UP> (fp32 MFMA).
  * "gemm_pair_images" (ABI 7; experimental builds only -- the default library accepts 0 and refuses 1): a matrix whose only reader is a row GEMM
  * on the "gemm_f16x3" arithmetic written by its producer (the epilogue of the row GEMM in front of it) as the two fp16 parts the reader
  * multiplies -- four consecutive elements as h0 h1 h2 h3 l0 l1 l2 l3 in the 16 bytes of their fp32 values, one power-of-two exponent per

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, run 24: driver-style sequence on the final tree: GPU suite, smoke(), bench line
-mkdir -p gpurun_out/r6e
+mkdir -p gpurun_out/r6e; rm -f gpurun_out/r6e/*
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r6e/pytest_gpu.txt 2>&1
 tail -3 gpurun_out/r6e/pytest_gpu.txt
