@@ -7,17 +7,18 @@
 //
 // Implicit GEMM per output row: M = output pixels, N = output channels, K = 4 Cin with k = (channel, dy, dx).  One MFMA k step = EIGHT channels x four taps; a
 // lane's eight k values are channels (2 lk, 2 lk + 1) x (dy, dx) of its output pixel -- four `ds_read_b64` (the two dx taps of a pixel are adjacent floats).
-// Workgroup = 2 output rows x 64 output pixels x 48 output channels, four waves x (2 pixel tiles x 3 channel tiles); the input planes arrive by LDS-DMA
-// exactly as in conv_dma_kernel (a stage = 8 planes of 4 rows x 128 floats = 16 KB, double buffered), the weights as a pre-split fragment-ordered bf16
-// image (9 KB per stage: 3 parts x 3 channel tiles x 64 lanes x 16 B) by the same DMA: 52 KB of LDS, three workgroups per CU.  The x fragments are split in
-// registers (22 VALU per fragment, shared by the 3 x 6 MFMAs that use it).
+// Workgroup = 2 output rows x 64 output pixels x 48 (or 96) output channels, four waves x (2 pixel tiles x NREP channel tiles); the input planes arrive by
+// LDS-DMA exactly as in conv_dma_kernel (a stage = 8 planes of 4 rows x 128 floats = 16 KB), the weights as a pre-split fragment-ordered bf16 image (3 NREP KB
+// per stage: 3 parts x NREP channel tiles x 64 lanes x 16 B) by the same DMA.  ONE stage buffer (26 KB at NREP = 3): a workgroup waits for its own DMA, four
+// workgroups per CU cover each other's waits -- with two buffers and two or three workgroups the kernels measured slower (profiles/r06_up6_ab.txt).  The x
+// fragments are split in registers (22 VALU per fragment, shared by the 6 NREP MFMAs that use it); the weight parts are read from LDS one at a time.
 #pragma once
 #include "kernels_gemm3.h"
 
 namespace asx {
 
-// NREP: 16-channel tiles of the output per workgroup: 3 (48 channels; 52 KB of LDS, three workgroups per CU) or 6 (96 channels: the input is fetched once
-// for all of them where Cout is a multiple of 96 -- 70 KB, two workgroups per CU)
+// NREP: 16-channel tiles of the output per workgroup: 3 (48 channels, 26 KB of LDS) or 6 (96 channels: the input is fetched once for all of them where Cout is
+// a multiple of 96 -- 35 KB); four workgroups per CU either way
 template <int NREP_>
 struct Down6CfgT {
   static constexpr int TH = 2, TW = 64, KC = 8, NREP = NREP_, NW = 16 * NREP_;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256, 4) void conv_down6_kernel(ConvArgs a) {
 // nt -> pair = nt / 2 -> (dy = pair / CT, channel tile ct = pair % CT), dx = nt & 1, so that the two dx tiles of a pair interleave into 32-byte stores.
 // One MFMA k step = 32 input channels; a lane's eight k values are channels 2 (lk + 4 jj) + e of its pixel (jj = 0 .. 3, e = 0, 1): planes are stored in
 // PAIRS of 1 KB (one LDS-DMA instruction each) with 64 bytes of padding between pairs, which puts the four lane groups of a `ds_read_b32` on four
-// different 16-bank windows.  Workgroup = 2 input rows x 64 pixels x NREP virtual tiles; LDS 2 x (17 KB + 3 NREP KB).
+// different 16-bank windows.  Workgroup = 2 input rows x 64 pixels x NREP virtual tiles; LDS 17 KB + 3 NREP KB (one stage buffer, as above).
 template <int NREP_>
 struct Up6CfgT {
   static constexpr int TH = 2, TW = 64, KC = 32, NREP = NREP_;
