@@ -542,6 +542,8 @@ static int conv_launch(asx_engine *e, const ConvLayer &L, const float *x, const 
     da.wp = reinterpret_cast<const float *>(L.wd6.p);
     da.CG = L.wd6_cg;
     da.NCI = L.wd6_nst;
+    // (tiles of 4 output rows -- template parameter TH of the kernel, half the weight traffic per pixel -- measured 35 % / 100 % slower on the deeper levels /
+    // everywhere: three workgroups per CU instead of four, profiles/r06_down6_ab.txt; not instantiated)
     da.tilesT = (a.To + Down6Cfg::TH - 1) / Down6Cfg::TH;
     da.tilesF = (a.Fo + Down6Cfg::TW - 1) / Down6Cfg::TW;
     const int nb6 = da.CG * da.tilesT * da.tilesF * B;

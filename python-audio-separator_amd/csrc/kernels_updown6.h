@@ -19,11 +19,14 @@ namespace asx {
 
 // NREP: 16-channel tiles of the output per workgroup: 3 (48 channels, 26 KB of LDS) or 6 (96 channels: the input is fetched once for all of them where Cout is
 // a multiple of 96 -- 35 KB); four workgroups per CU either way
-template <int NREP_>
+// TH_: output rows per workgroup, 2 or 4 (the taller tile halves the weight traffic per pixel: the deeper levels, where the weights of a tile outweigh its input)
+template <int NREP_, int TH_ = 2>
 struct Down6CfgT {
-  static constexpr int TH = 2, TW = 64, KC = 8, NREP = NREP_, NW = 16 * NREP_;
+  static constexpr int TH = TH_, TW = 64, KC = 8, NREP = NREP_, NW = 16 * NREP_;
   static constexpr int IH = 2 * TH, IWA = 2 * TW;      // staged input rows / floats per row of a plane
-  static constexpr int PLANE = IH * IWA;               // 512 floats
+  static constexpr int PLANE = IH * IWA;               // 512 / 1024 floats
+  static constexpr int NJ = PLANE / 256;               // 1-KB DMA pieces per plane
+  static constexpr int PAIRS = TH / 2;                 // pixel-tile pairs per wave
   static constexpr int PS = PLANE + 16;                // plane stride (floats): channel pairs (2 lk, 2 lk + 1) of neighbouring lane groups 32 banks apart
   static constexpr int XBYTES = KC * PS * 4;           // 16,896
   static constexpr int WSTAGE_U32 = 3 * NREP * 64 * 4; // 2304 uint32 = 9216 B per (channel group, stage): [part][n][lane][4 uint32]
@@ -112,9 +115,9 @@ __device__ __forceinline__ void updown6_products(const u32x4 *w_s, int lane, con
 }
 
 // a.wp: the image above; a.CG / a.NCI: its channel groups / stages; a.tilesT / a.tilesF: tiles of 2 output rows x 64 output pixels.  F % 4 == 0 (launcher).
-template <int NREP>
-__global__ __launch_bounds__(256, 4) void conv_down6_kernel(ConvArgs a) {
-  using C = Down6CfgT<NREP>;
+template <int NREP, int TH = 2>
+__global__ __launch_bounds__(256, TH == 2 ? 4 : 3) void conv_down6_kernel(ConvArgs a) {
+  using C = Down6CfgT<NREP, TH>;
   extern __shared__ float lds_f[];
   char *lds = reinterpret_cast<char *>(lds_f);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -135,11 +138,11 @@ __global__ __launch_bounds__(256, 4) void conv_down6_kernel(ConvArgs a) {
   const uint32_t *wg = reinterpret_cast<const uint32_t *>(a.wp) + (int64_t)cg * a.NCI * C::WSTAGE_U32;
   const int64_t plane_sz = (int64_t)a.T * a.F;
 
-  // a plane = 128 sixteen-byte slots (4 rows x 32): this lane's two slots, the same for every plane
-  int sp_off[2];
-  bool sp_ok[2];
+  // a plane = 2 TH rows x 32 sixteen-byte slots: this lane's NJ slots, the same for every plane
+  int sp_off[C::NJ];
+  bool sp_ok[C::NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < C::NJ; ++j) {
     const int sidx = j * 64 + lane;
     const int row = sidx >> 5, c4 = sidx & 31;
     const int t = ti0 + row, f = fa0 + c4 * 4;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, 4) void conv_down6_kernel(ConvArgs a) {
       const float *xc = xb + (int64_t)c * plane_sz;
       const bool cok = c < a.Cin;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < C::NJ; ++j) {
         const float *src = (cok && sp_ok[j]) ? xc + sp_off[j] : a.zeros;
         ASX_GLDS16(src, in_s + pl * C::PS + j * 256);
       }
@@ -169,14 +172,16 @@ __global__ __launch_bounds__(256, 4) void conv_down6_kernel(ConvArgs a) {
     }
   };
 
-  f32x4 acc[2][C::NREP];
+  f32x4 acc[C::PAIRS][2][C::NREP];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int pi = 0; pi < C::PAIRS; ++pi)
 #pragma unroll
-    for (int n = 0; n < C::NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < C::NREP; ++n) acc[pi][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // this wave: output row wave >> 1 of the tile, pixel tiles (wave & 1) * 2 + {0, 1}
-  const int row = wave >> 1, col0 = (wave & 1) * 2;
+  // this wave, TH = 2: output row wave >> 1 of the tile, pixel tiles (wave & 1) * 2 + {0, 1}; TH = 4: output row `wave`, pixel-tile pairs {0, 1} and {2, 3}
+  const int row = TH == 2 ? (wave >> 1) : wave;
   for (int st = 0; st < a.NCI; ++st) {
     if (st > 0) __syncthreads();                       // every wave is done with the buffer
     issue(st, 0);
@@ -184,27 +189,31 @@ __global__ __launch_bounds__(256, 4) void conv_down6_kernel(ConvArgs a) {
     __syncthreads();
     const float *in_s = reinterpret_cast<const float *>(lds);
     const u32x4 *w_s = reinterpret_cast<const u32x4 *>(lds + C::XBYTES);
-    // the x fragments of both pixel tiles first, then the weight parts one at a time (l, m, h: smallest terms first) -- 4 NREP live weight registers
+    // the x fragments of a pair of pixel tiles first, then the weight parts one at a time (l, m, h: smallest terms first) -- 4 NREP live weight registers
     // instead of 12 NREP
-    bf16x8 xh[2], xm[2], xl[2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      // eight k values of pixel (col0 + m) * 16 + li: channels 2 lk, 2 lk + 1 x (dy, dx)
-      const float *p0 = in_s + (2 * lk) * C::PS + (2 * row) * C::IWA + 2 * ((col0 + m) * 16 + li);
-      const f32x2 c0d0 = *reinterpret_cast<const f32x2 *>(p0);
-      const f32x2 c0d1 = *reinterpret_cast<const f32x2 *>(p0 + C::IWA);
-      const f32x2 c1d0 = *reinterpret_cast<const f32x2 *>(p0 + C::PS);
-      const f32x2 c1d1 = *reinterpret_cast<const f32x2 *>(p0 + C::PS + C::IWA);
-      unsigned hh[4], mm[4], ll[4];
-      split3_pair(c0d0.x, c0d0.y, hh[0], mm[0], ll[0]);
-      split3_pair(c0d1.x, c0d1.y, hh[1], mm[1], ll[1]);
-      split3_pair(c1d0.x, c1d0.y, hh[2], mm[2], ll[2]);
-      split3_pair(c1d1.x, c1d1.y, hh[3], mm[3], ll[3]);
-      xh[m] = __builtin_bit_cast(bf16x8, (u32x4){hh[0], hh[1], hh[2], hh[3]});
-      xm[m] = __builtin_bit_cast(bf16x8, (u32x4){mm[0], mm[1], mm[2], mm[3]});
-      xl[m] = __builtin_bit_cast(bf16x8, (u32x4){ll[0], ll[1], ll[2], ll[3]});
+    for (int pi = 0; pi < C::PAIRS; ++pi) {
+      const int col0 = TH == 2 ? (wave & 1) * 2 : 2 * pi;
+      bf16x8 xh[2], xm[2], xl[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        // eight k values of pixel (col0 + m) * 16 + li: channels 2 lk, 2 lk + 1 x (dy, dx)
+        const float *p0 = in_s + (2 * lk) * C::PS + (2 * row) * C::IWA + 2 * ((col0 + m) * 16 + li);
+        const f32x2 c0d0 = *reinterpret_cast<const f32x2 *>(p0);
+        const f32x2 c0d1 = *reinterpret_cast<const f32x2 *>(p0 + C::IWA);
+        const f32x2 c1d0 = *reinterpret_cast<const f32x2 *>(p0 + C::PS);
+        const f32x2 c1d1 = *reinterpret_cast<const f32x2 *>(p0 + C::PS + C::IWA);
+        unsigned hh[4], mm[4], ll[4];
+        split3_pair(c0d0.x, c0d0.y, hh[0], mm[0], ll[0]);
+        split3_pair(c0d1.x, c0d1.y, hh[1], mm[1], ll[1]);
+        split3_pair(c1d0.x, c1d0.y, hh[2], mm[2], ll[2]);
+        split3_pair(c1d1.x, c1d1.y, hh[3], mm[3], ll[3]);
+        xh[m] = __builtin_bit_cast(bf16x8, (u32x4){hh[0], hh[1], hh[2], hh[3]});
+        xm[m] = __builtin_bit_cast(bf16x8, (u32x4){mm[0], mm[1], mm[2], mm[3]});
+        xl[m] = __builtin_bit_cast(bf16x8, (u32x4){ll[0], ll[1], ll[2], ll[3]});
+      }
+      updown6_products<C::NREP>(w_s, lane, xh, xm, xl, acc[pi]);
     }
-    updown6_products<C::NREP>(w_s, lane, xh, xm, xl, acc);
   }
 
   // ---- epilogue: bias + activation (+ residual); a lane holds four consecutive pixels of output channel li of each channel tile
@@ -218,25 +227,28 @@ __global__ __launch_bounds__(256, 4) void conv_down6_kernel(ConvArgs a) {
     if (co >= a.Cout) continue;
     const float bv = a.bias[co];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int f = fo0 + (col0 + m) * 16 + lk * 4;
-      const int64_t off = ((int64_t)co * a.To + t) * a.Fo + f;
-      const f32x4 v = acc[m][n];
-      if ((a.Fo & 3) == 0 && f + 4 <= a.Fo) {
-        f32x4 o;
-        o.x = act_fn(v.x + bv, a.act);
-        o.y = act_fn(v.y + bv, a.act);
-        o.z = act_fn(v.z + bv, a.act);
-        o.w = act_fn(v.w + bv, a.act);
-        if (rb != nullptr) o += *reinterpret_cast<const f32x4 *>(rb + off);
-        *reinterpret_cast<f32x4 *>(yb + off) = o;
-      } else {
-        const float ov[4] = {v.x, v.y, v.z, v.w};
+    for (int pi = 0; pi < C::PAIRS; ++pi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (f + r < a.Fo) yb[off + r] = act_fn(ov[r] + bv, a.act) + (rb != nullptr ? rb[off + r] : 0.f);
+      for (int m = 0; m < 2; ++m) {
+        const int col0 = TH == 2 ? (wave & 1) * 2 : 2 * pi;
+        const int f = fo0 + (col0 + m) * 16 + lk * 4;
+        const int64_t off = ((int64_t)co * a.To + t) * a.Fo + f;
+        const f32x4 v = acc[pi][m][n];
+        if ((a.Fo & 3) == 0 && f + 4 <= a.Fo) {
+          f32x4 o;
+          o.x = act_fn(v.x + bv, a.act);
+          o.y = act_fn(v.y + bv, a.act);
+          o.z = act_fn(v.z + bv, a.act);
+          o.w = act_fn(v.w + bv, a.act);
+          if (rb != nullptr) o += *reinterpret_cast<const f32x4 *>(rb + off);
+          *reinterpret_cast<f32x4 *>(yb + off) = o;
+        } else {
+          const float ov[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (f + r < a.Fo) yb[off + r] = act_fn(ov[r] + bv, a.act) + (rb != nullptr ? rb[off + r] : 0.f);
+        }
       }
-    }
   }
 }
 
