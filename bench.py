@@ -382,7 +382,8 @@ def main():
         step(0)                                         # (the profiled pass below runs on the default again, its weight images are back)
         fence()
         arithmetic_ab = {"what": "the same timed loop with asx_set_option(gemm_f16x3, 0): six exact bf16 products per multiply-add (fp32-exact split operands) in the "
-                                 "row GEMMs, attention and conv_wino6_kernel; the 48-channel level on conv_wino3_kernel (fp32 MFMA) instead of conv3h_kernel",
+                                 "row GEMMs, attention and conv_wino6_kernel; the levels up to 144 channels on conv_wino3_kernel (fp32 MFMA) / conv_wino6_kernel instead of conv3h_kernel; "
+                                 "the level-change convs (conv_down6_kernel / conv_up6_kernel) run six exact bf16 products in both legs",
                          "value": round(songs_per_step * args.seconds * args.steps / dt6, 2), "ms_per_step": round(dt6 / args.steps * 1e3, 3),
                          "steps": args.steps, "default_over_exact": round(dt6 / dt, 4)}
 
