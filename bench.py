@@ -491,6 +491,9 @@ def main():
                     "conv3x3_class_ms": round(call["ms"], 2), "conv3x3_class_launches": call["launches"]}
         if is3h:
             roofline["launch_is"] = "one conv layer (a 96-channel layer = four dispatches of the kernel over 48-channel slices); hbm floor of the launches: per_level"
+            roofline["peak_note"] = ("peak = the guide's dense 16-bit MFMA figure.  Measured on this chip (profiles/r06_micro_mfma.txt, not re-measured by this run): a pure "
+                                     "stream of v_mfma_f32_16x16x32_f16 reaches 2412 TFLOP/s on zero operands at 2.37 GHz and 1750-1920 TFLOP/s on operands that toggle the "
+                                     "datapath (clock 1.91-1.97 GHz) -- the sustained ceiling of the pipe with nothing else running")
         roofline["per_level"] = per_level
         if wino:
             roofline["note"] = (("achieved / frac = EXECUTED 16-bit MFMA FLOPs (3 products x 480 / 432 stage padding per multiply-add of the direct convolution) / launch time "
