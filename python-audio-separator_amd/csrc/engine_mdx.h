@@ -826,6 +826,17 @@ static void launch_tdf3_abl(const TdfDmaArgs &a0, const u32x4 *w3, hipStream_t s
   // fabric traffic 2.0x -> ~1.0x algorithmic); 8 or more -> map 0 (column tiles partitioned over the XCDs; maps 1 / 2 measure the same).
   static const int map_env = getenv("ASX_TDF3_MAP") ? atoi(getenv("ASX_TDF3_MAP")) : -1;
   a.tile_map = map_env >= 0 ? (nbn >= 8 ? map_env % 10 : map_env / 10) : (nbn < 8 ? 1 : 0);
+  // N = 384 exactly (the first TDF linear of level 0): ONE 8-wave workgroup per row block computes both 192-column halves from one x tile -- half the
+  // x loads, splits and LDS stores per MFMA (kernels_gemm3.h, template parameter NW).  ASX_TDF3_NW8=0: A/B
+  if constexpr (H && !PS && ABL == 0 && NREP == 3 && MREP == 8) {
+    static const bool nw8 = !(getenv("ASX_TDF3_NW8") && atoi(getenv("ASX_TDF3_NW8")) == 0);
+    if (nw8 && a.N == 384) {
+      hipLaunchKernelGGL((tdf3_kernel<3, 8, 0, false, true, false, 8>), dim3((unsigned)nbm), dim3(512), LDS_BYTES, s, a, w3, RowGather{});
+      g_tdf3_launches.fetch_add(1);
+      g_tdf3h_launches.fetch_add(1);
+      return;
+    }
+  }
   hipLaunchKernelGGL((tdf3_kernel<NREP, MREP, ABL, false, H, PS>), dim3((unsigned)(nbm * nbn)), dim3(256), LDS_BYTES, s, a, w3, RowGather{});
   g_tdf3_launches.fetch_add(1);
   if (H) g_tdf3h_launches.fetch_add(1);
