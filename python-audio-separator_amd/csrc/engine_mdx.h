@@ -34,6 +34,8 @@ static int pick_nrep_conv(int cout) {
 }
 static int pick_nrep_up(int cout) {
   const int ct = (cout + 15) / 16;  // virtual tiles = 4*ct, pairs must stay together
+  static const int force = getenv("ASX_UP_NREP") ? atoi(getenv("ASX_UP_NREP")) : 0;   // A/B: 4 = four virtual tiles per workgroup wherever they divide
+  if (force == 4 && (4 * ct) % 4 == 0) return 4;
   if ((4 * ct) % 6 == 0) return 6;
   if ((4 * ct) % 4 == 0) return 4;
   return 2;
