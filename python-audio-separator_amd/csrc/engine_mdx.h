@@ -164,7 +164,7 @@ static int conv_pack(ConvLayer &L, const float *w, const float *b, int wino_mode
       }
     }
     // direct fp16 x 3 kernel (kernels_conv3h.h): layers of 48 n -> 48 n channels as n x n images of 48 x 48 (output slice major)
-    if (L.cin == L.cout && L.cin % Conv3hCfg::C == 0 && L.cin <= 3 * Conv3hCfg::C) {
+    if (L.cin == L.cout && L.cin % Conv3hCfg::C == 0 && L.cin <= 3 * Conv3hCfg::C) {   // (up to 144 channels: on the deeper levels the n x n slice launches lose to conv_wino6_kernel -- 1.95 / 1.13 / 1.45 against 1.59 / 0.61 / 0.21 ms at 192 / 240 / 288 channels, profiles/r06_conv3h_deeper_levels.txt)
       const int nb = L.cin / Conv3hCfg::C;
       std::vector<uint32_t> all, one;
       std::vector<float> ws((size_t)Conv3hCfg::C * Conv3hCfg::C * 9);
