@@ -832,7 +832,7 @@ static void launch_tdf3_abl(const TdfDmaArgs &a0, const u32x4 *w3, hipStream_t s
   // x loads, splits and LDS stores per MFMA (kernels_gemm3.h, template parameter NW).  ASX_TDF3_NW8=0: A/B
   if constexpr (H && !PS && ABL == 0 && NREP == 3 && MREP == 8) {
     static const bool nw8 = !(getenv("ASX_TDF3_NW8") && atoi(getenv("ASX_TDF3_NW8")) == 0);
-    if (nw8 && a.N == 384) {
+    if (nw8 && a.N == 384 && a.yexp == nullptr) {        // (a pair-image producer writes one exponent span per 192-column tile: the 4-wave form)
       hipLaunchKernelGGL((tdf3_kernel<3, 8, 0, false, true, false, 8>), dim3((unsigned)nbm), dim3(512), LDS_BYTES, s, a, w3, RowGather{});
       g_tdf3_launches.fetch_add(1);
       g_tdf3h_launches.fetch_add(1);
